@@ -1,0 +1,135 @@
+"""ctypes front-end to oracle/libdada2oracle.so — the plain-C restatement
+(oracle/dada_oracle.c + oracle/rmath_ppois.c).  TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dada2_amd.opts import COpts, DadaOpts, DadaResult
+from oracle.ref import pack_inputs
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libdada2oracle.so")
+_lib = None
+
+
+class _CResult(C.Structure):
+    _fields_ = [
+        ("nclust", C.c_int), ("nraw", C.c_int), ("maxlen", C.c_int), ("ncol", C.c_int), ("nbirth_subs", C.c_int),
+        ("nalign", C.c_uint), ("nshroud", C.c_uint),
+        ("cl_sequence", C.POINTER(C.c_char_p)),
+        ("cl_abundance", C.POINTER(C.c_int)), ("cl_n0", C.POINTER(C.c_int)), ("cl_n1", C.POINTER(C.c_int)),
+        ("cl_nunq", C.POINTER(C.c_int)), ("cl_birth_from", C.POINTER(C.c_int)), ("cl_birth_ham", C.POINTER(C.c_int)),
+        ("cl_center", C.POINTER(C.c_int)),
+        ("cl_pval", C.POINTER(C.c_double)), ("cl_birth_pval", C.POINTER(C.c_double)),
+        ("cl_birth_fold", C.POINTER(C.c_double)), ("cl_birth_qave", C.POINTER(C.c_double)),
+        ("bs_pos", C.POINTER(C.c_int)), ("bs_clust", C.POINTER(C.c_int)),
+        ("bs_ref", C.POINTER(C.c_char)), ("bs_sub", C.POINTER(C.c_char)), ("bs_qual", C.POINTER(C.c_double)),
+        ("subqual", C.POINTER(C.c_int)), ("clusterquals", C.POINTER(C.c_double)),
+        ("map", C.POINTER(C.c_int)), ("pval", C.POINTER(C.c_double)),
+    ]
+
+
+def build():
+    """(Re)build libdada2oracle.so (and _ref where /root/reference exists) via oracle/Makefile."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            build()
+        L = C.CDLL(_PATH)
+        L.oracle_run.restype = C.POINTER(_CResult)
+        L.oracle_run.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_int, C.POINTER(COpts), C.c_char_p, C.c_int]
+        L.oracle_result_free.argtypes = [C.POINTER(_CResult)]
+        L.oracle_nwalign.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                     C.c_char_p]
+        L.oracle_compare.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.POINTER(COpts), C.c_double, C.c_void_p]
+        L.oracle_calc_pA.restype = C.c_double
+        L.oracle_calc_pA.argtypes = [C.c_int, C.c_double, C.c_int]
+        L.dada2_oracle_ppois.restype = C.c_double
+        L.dada2_oracle_ppois.argtypes = [C.c_double, C.c_double, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _arr(ptr, n, dt):
+    if n == 0:
+        return np.zeros(0, dtype=dt)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+
+def dada_uniques(seqs, abundances, priors, err, quals, opts: DadaOpts = None, *, max_clust=None,
+                 multithread=False, verbose=False, copts: COpts = None) -> DadaResult:
+    L = lib()
+    co = copts if copts is not None else (opts or DadaOpts()).to_c(max_clust=max_clust, multithread=multithread,
+                                                                  verbose=verbose)
+    arr, ab, pr, ef, ncol, q, qn = pack_inputs(seqs, abundances, priors, err, quals)
+    eb = C.create_string_buffer(1024)
+    rp = L.oracle_run(len(seqs), arr, ab.ctypes.data, pr.ctypes.data, ef.ctypes.data, ncol,
+                      q.ctypes.data if q is not None else None, qn, C.byref(co), eb, 1024)
+    if not rp:
+        raise RuntimeError(eb.value.decode())
+    try:
+        r = rp.contents
+        Cn, nb = r.nclust, r.nbirth_subs
+        clustering = {
+            "sequence": [r.cl_sequence[i].decode() for i in range(Cn)],
+            "abundance": _arr(r.cl_abundance, Cn, np.int32), "n0": _arr(r.cl_n0, Cn, np.int32),
+            "n1": _arr(r.cl_n1, Cn, np.int32), "nunq": _arr(r.cl_nunq, Cn, np.int32),
+            "pval": _arr(r.cl_pval, Cn, np.float64), "birth_from": _arr(r.cl_birth_from, Cn, np.int32),
+            "birth_pval": _arr(r.cl_birth_pval, Cn, np.float64), "birth_fold": _arr(r.cl_birth_fold, Cn, np.float64),
+            "birth_ham": _arr(r.cl_birth_ham, Cn, np.int32), "birth_qave": _arr(r.cl_birth_qave, Cn, np.float64),
+        }
+        birth_subs = {
+            "pos": _arr(r.bs_pos, nb, np.int32), "ref": [r.bs_ref[i].decode() for i in range(nb)],
+            "sub": [r.bs_sub[i].decode() for i in range(nb)], "qual": _arr(r.bs_qual, nb, np.float64),
+            "clust": _arr(r.bs_clust, nb, np.int32),
+        }
+        subqual = _arr(r.subqual, 16 * r.ncol, np.int32).reshape(r.ncol, 16).T.copy()
+        cq = _arr(r.clusterquals, r.maxlen * Cn, np.float64).reshape(Cn, r.maxlen).T.copy()
+        if q is None:
+            cq = np.zeros((r.maxlen, Cn))
+        return DadaResult(clustering, birth_subs, subqual, cq, _arr(r.map, r.nraw, np.int32),
+                          _arr(r.pval, r.nraw, np.float64),
+                          stats={"nalign": r.nalign, "nshroud": r.nshroud,
+                                 "center": _arr(r.cl_center, Cn, np.int32)})
+    finally:
+        L.oracle_result_free(rp)
+
+
+def nwalign(s1, s2, match=5, mismatch=-4, gap=-8, band=16, gapless=False):
+    n = len(s1) + len(s2) + 2
+    o0, o1 = C.create_string_buffer(n), C.create_string_buffer(n)
+    lib().oracle_nwalign(s1.encode(), s2.encode(), match, mismatch, gap, band, int(gapless), o0, o1)
+    return o0.value.decode(), o1.value.decode()
+
+
+def compare(cseq, cq, rseq, rq, err, opts: DadaOpts = None, kdist_cutoff=None):
+    o = opts or DadaOpts()
+    co = o.to_c()
+    e = np.ascontiguousarray(np.asarray(err, dtype=np.float64))
+    cqa = np.ascontiguousarray(cq, dtype=np.float64)
+    rqa = np.ascontiguousarray(rq, dtype=np.float64)
+    out = np.zeros(4)
+    lib().oracle_compare(cseq.encode(), cqa.ctypes.data, rseq.encode(), rqa.ctypes.data, e.ctypes.data, e.shape[1],
+                         C.byref(co), float(o.KDIST_CUTOFF if kdist_cutoff is None else kdist_cutoff),
+                         out.ctypes.data)
+    return float(out[0]), int(out[1]), float(out[2]), float(out[3])
+
+
+def calc_pA(reads, E, prior):
+    return lib().oracle_calc_pA(int(reads), float(E), int(bool(prior)))
+
+
+def ppois_upper(x, lam):
+    return lib().dada2_oracle_ppois(float(x), float(lam), 0)

@@ -1,0 +1,152 @@
+"""ctypes front-end to oracle/_ref/libdada2ref.so — the reference's own C++ compiled in
+place from /root/reference/src (recipe: oracle/Makefile).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, tests/golden/make_golden.py, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from dada2_amd.opts import COpts, DadaOpts, DadaResult, CLUSTERING_COLS, BIRTH_SUBS_COLS
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_ref", "libdada2ref.so")
+_lib = None
+
+
+def available() -> bool:
+    return os.path.exists(_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libdada2ref.so missing: run `make -C oracle` where /root/reference exists")
+        L = C.CDLL(_PATH)
+        L.ref_dada_uniques.restype = C.c_void_p
+        L.ref_dada_uniques.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_int, C.POINTER(COpts), C.c_char_p, C.c_int]
+        L.ref_result_free.argtypes = [C.c_void_p]
+        L.ref_result_get.restype = C.c_long
+        L.ref_result_get.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.ref_result_str.restype = C.c_char_p
+        L.ref_result_str.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_long]
+        L.ref_nwalign.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                  C.c_char_p, C.c_char_p, C.c_int]
+        L.ref_compare.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.POINTER(COpts), C.c_double, C.c_void_p, C.c_char_p, C.c_int]
+        L.ref_calc_pA.restype = C.c_double
+        L.ref_calc_pA.argtypes = [C.c_int, C.c_double, C.c_int]
+        L.dada2_oracle_ppois.restype = C.c_double
+        L.dada2_oracle_ppois.argtypes = [C.c_double, C.c_double, C.c_int]
+        L.dada2_shim_set_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def set_threads(n: int):
+    lib().dada2_shim_set_threads(int(n))
+
+
+def _get(h, a, b=None):
+    L = lib()
+    kind, nr, nc, data = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
+    n = L.ref_result_get(h, a.encode(), (b or "").encode(), C.byref(kind), C.byref(nr), C.byref(nc), C.byref(data))
+    if n < 0:
+        raise KeyError((a, b))
+    k = kind.value
+    if k == 2:
+        return [L.ref_result_str(h, a.encode(), (b or "").encode(), i).decode() for i in range(n)]
+    dt = np.int32 if k in (0, 3) else np.float64
+    if n == 0:
+        arr = np.zeros(0, dtype=dt)
+    else:
+        arr = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_int32 if dt == np.int32 else C.c_double)), shape=(n,)).copy()
+    if k in (3, 4):
+        arr = arr.reshape(nc.value, nr.value).T  # column-major -> [nr, nc]
+    return arr
+
+
+def pack_inputs(seqs, abundances, priors, err, quals):
+    """Common marshalling: quals is the R-side [N, maxlen] matrix (one row per unique, NaN
+    padded) or None; the boundary wants it transposed, maxlen x N column-major
+    (R/dada.R:337 `t(drpi$quals)`, Rmain.cpp:69,113) == the same C-contiguous [N, maxlen] buffer."""
+    n = len(seqs)
+    arr = (C.c_char_p * n)(*[s.encode("ascii") for s in seqs])
+    ab = np.ascontiguousarray(abundances, dtype=np.int32)
+    pr = np.ascontiguousarray(priors if priors is not None else np.zeros(n), dtype=np.uint8)
+    e = np.asarray(err, dtype=np.float64)
+    assert e.shape[0] == 16
+    ef = np.ascontiguousarray(e.T)  # column-major 16 x Q
+    if quals is None:
+        q, qn = None, 0
+    else:
+        q = np.ascontiguousarray(quals, dtype=np.float64)
+        assert q.shape[0] == n
+        qn = q.shape[1]
+    return arr, ab, pr, ef, e.shape[1], q, qn
+
+
+def dada_uniques(seqs, abundances, priors, err, quals, opts: DadaOpts = None, *, max_clust=None,
+                 multithread=False, verbose=False, copts: COpts = None) -> DadaResult:
+    """Run the reference's dada_uniques (Rmain.cpp:30)."""
+    L = lib()
+    co = copts if copts is not None else (opts or DadaOpts()).to_c(max_clust=max_clust, multithread=multithread,
+                                                                  verbose=verbose)
+    arr, ab, pr, ef, ncol, q, qn = pack_inputs(seqs, abundances, priors, err, quals)
+    eb = C.create_string_buffer(1024)
+    h = L.ref_dada_uniques(len(seqs), arr, ab.ctypes.data, pr.ctypes.data, ef.ctypes.data, ncol,
+                           q.ctypes.data if q is not None else None, qn, C.byref(co), eb, 1024)
+    if not h:
+        raise RuntimeError(eb.value.decode())
+    try:
+        clustering = {c: _get(h, "clustering", c) for c in CLUSTERING_COLS}
+        birth_subs = {c: _get(h, "birth_subs", c) for c in BIRTH_SUBS_COLS}
+        return DadaResult(clustering, birth_subs, _get(h, "subqual"), _get(h, "clusterquals"), _get(h, "map"),
+                          _get(h, "pval"))
+    finally:
+        L.ref_result_free(h)
+
+
+WHICH = {"endsfree": 0, "vectorized": 1, "gapless": 2, "global": 3}
+
+
+def nwalign(s1, s2, match=5, mismatch=-4, gap=-8, band=16, which="vectorized"):
+    L = lib()
+    n = len(s1) + len(s2) + 2
+    o0, o1, eb = C.create_string_buffer(n), C.create_string_buffer(n), C.create_string_buffer(512)
+    rc = L.ref_nwalign(s1.encode(), s2.encode(), match, mismatch, gap, band, WHICH[which], o0, o1, eb, 512)
+    if rc:
+        raise RuntimeError(eb.value.decode())
+    return o0.value.decode(), o1.value.decode()
+
+
+def compare(cseq, cq, rseq, rq, err, opts: DadaOpts = None, kdist_cutoff=None):
+    """(lambda, hamming|-1, kdist, kodist) for one centre/raw pair via sub_new + compute_lambda_ts."""
+    L = lib()
+    o = (opts or DadaOpts())
+    co = o.to_c()
+    e = np.ascontiguousarray(np.asarray(err, dtype=np.float64))  # row-major [16, Q] as cluster.cpp:166-170
+    cqa = np.ascontiguousarray(cq, dtype=np.float64)
+    rqa = np.ascontiguousarray(rq, dtype=np.float64)
+    out = np.zeros(4)
+    eb = C.create_string_buffer(512)
+    rc = L.ref_compare(cseq.encode(), cqa.ctypes.data, rseq.encode(), rqa.ctypes.data, e.ctypes.data, e.shape[1],
+                       C.byref(co), float(o.KDIST_CUTOFF if kdist_cutoff is None else kdist_cutoff),
+                       out.ctypes.data, eb, 512)
+    if rc:
+        raise RuntimeError(eb.value.decode())
+    return float(out[0]), int(out[1]), float(out[2]), float(out[3])
+
+
+def calc_pA(reads, E, prior):
+    return lib().ref_calc_pA(int(reads), float(E), int(bool(prior)))
+
+
+def ppois_upper(x, lam):
+    return lib().dada2_oracle_ppois(float(x), float(lam), 0)

@@ -1,0 +1,168 @@
+// oracle/shim/Rcpp.h — TEST INFRASTRUCTURE ONLY.
+//
+// Minimal stand-in for <Rcpp.h> so that the reference's own hot-path sources
+// (/root/reference/src/{Rmain,cluster,containers,kmers,misc,pval,error,
+// nwalign_endsfree,nwalign_vectorized}.cpp) compile UNMODIFIED, in place, into
+// oracle/_ref/libdada2ref.so (recipe: oracle/Makefile).  Nothing here is a copy
+// of Rcpp: it is a from-scratch value-semantics model of exactly the Rcpp
+// surface those nine files touch (SURVEY.md §8c lists it).  R and Rcpp are not
+// installed in this image, which is why this exists.
+//
+// The only arithmetic supplied here rather than by the reference is
+// Rcpp::ppois -> dada2_oracle_ppois (oracle/rmath_ppois.c).
+#ifndef DADA2_ORACLE_SHIM_RCPP_H
+#define DADA2_ORACLE_SHIM_RCPP_H
+
+#include <cstdio>
+#include <cstdarg>
+#include <cstdint>
+#include <cstring>
+#include <climits>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+extern "C" double dada2_oracle_ppois(double x, double lambda, int lower_tail);
+
+#define NA_INTEGER INT_MIN
+static inline double shim_na_real() {
+  // R's NA_real_: quiet NaN with low word 1954.
+  union { double d; uint64_t u; } v;
+  v.u = 0x7FF00000000007A2ULL;
+  return v.d;
+}
+#define NA_REAL (shim_na_real())
+
+extern "C" int dada2_shim_verbose;  // 0 = swallow Rprintf (default)
+static inline void Rprintf(const char *fmt, ...) {
+  if (!dada2_shim_verbose) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+}
+
+namespace Rcpp {
+
+inline void stop(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  throw std::runtime_error(buf);
+}
+inline void stop(const std::string &s) { throw std::runtime_error(s); }
+inline void checkUserInterrupt() {}
+
+template <typename T> class Vec {
+public:
+  std::vector<T> v;
+  Vec() {}
+  explicit Vec(size_t n) : v(n, T()) {}
+  size_t size() const { return v.size(); }
+  T &operator[](size_t i) { return v[i]; }
+  const T &operator[](size_t i) const { return v[i]; }
+  T &operator()(size_t i) { return v[i]; }
+  const T &operator()(size_t i) const { return v[i]; }
+  void push_back(const T &x) { v.push_back(x); }
+};
+
+class IntegerVector : public Vec<int> {
+public:
+  IntegerVector() {}
+  explicit IntegerVector(size_t n) : Vec<int>(n) {}
+};
+class NumericVector : public Vec<double> {
+public:
+  NumericVector() {}
+  explicit NumericVector(size_t n) : Vec<double>(n) {}
+  static double get_na() { return NA_REAL; }
+};
+class CharacterVector : public Vec<std::string> {
+public:
+  CharacterVector() {}
+  explicit CharacterVector(size_t n) : Vec<std::string>(n) {}
+};
+
+template <typename T> class Mat {
+public:
+  std::vector<T> v;
+  int nr, nc;
+  Mat() : nr(0), nc(0) {}
+  Mat(int nrow, int ncol) : v((size_t)nrow * (size_t)ncol, T()), nr(nrow), nc(ncol) {}
+  int nrow() const { return nr; }
+  int ncol() const { return nc; }
+  T &operator()(size_t r, size_t c) { return v[c * (size_t)nr + r]; }  // column-major, as R
+  const T &operator()(size_t r, size_t c) const { return v[c * (size_t)nr + r]; }
+};
+typedef Mat<double> NumericMatrix;
+typedef Mat<int> IntegerMatrix;
+
+template <typename T> inline T as(const NumericVector &x) { return (T)x[0]; }
+
+inline NumericVector ppois(const IntegerVector &x, double lambda, bool lower) {
+  NumericVector r(x.size());
+  for (size_t i = 0; i < x.size(); i++) r[i] = dada2_oracle_ppois((double)x[i], lambda, lower ? 1 : 0);
+  return r;
+}
+
+// ---- named-list model for List::create / DataFrame::create ------------------
+struct RObj;
+typedef std::shared_ptr<RObj> RObjP;
+struct RObj {
+  enum Kind { INT, DBL, STR, IMAT, DMAT, LIST } kind;
+  std::vector<int> iv;
+  std::vector<double> dv;
+  std::vector<std::string> sv;
+  int nr = 0, nc = 0;
+  std::vector<std::pair<std::string, RObjP>> items;
+  const RObj *get(const std::string &name) const {
+    for (auto &it : items)
+      if (it.first == name) return it.second.get();
+    return nullptr;
+  }
+};
+
+class List {
+public:
+  RObjP obj;
+  List() : obj(std::make_shared<RObj>()) { obj->kind = RObj::LIST; }
+  template <typename... A> static List create(const A &...a);
+};
+typedef List DataFrame;
+
+inline RObjP wrap(const IntegerVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::INT; o->iv = x.v; return o; }
+inline RObjP wrap(const NumericVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::DBL; o->dv = x.v; return o; }
+inline RObjP wrap(const CharacterVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::STR; o->sv = x.v; return o; }
+inline RObjP wrap(const std::vector<std::string> &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::STR; o->sv = x; return o; }
+inline RObjP wrap(const IntegerMatrix &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::IMAT; o->iv = x.v; o->nr = x.nr; o->nc = x.nc; return o; }
+inline RObjP wrap(const NumericMatrix &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::DMAT; o->dv = x.v; o->nr = x.nr; o->nc = x.nc; return o; }
+inline RObjP wrap(const List &x) { return x.obj; }
+
+struct Named {
+  std::string name;
+  RObjP val;
+};
+struct NameProxy {
+  std::string name;
+  template <typename T> Named operator=(const T &x) const { return Named{name, wrap(x)}; }
+};
+struct Placeholder {
+  NameProxy operator[](const char *n) const { return NameProxy{n}; }
+};
+static const Placeholder _ = Placeholder();
+
+template <typename... A> List List::create(const A &...a) {
+  List l;
+  Named arr[] = {a...};
+  for (auto &n : arr) l.obj->items.push_back({n.name, n.val});
+  return l;
+}
+
+}  // namespace Rcpp
+
+#endif

@@ -1,0 +1,52 @@
+// oracle/shim/RcppParallel.h — TEST INFRASTRUCTURE ONLY.
+//
+// Stand-in for <RcppParallel.h> (TBB is not installed here).  The reference
+// uses exactly two things (src/cluster.cpp:90,176; src/Rmain.cpp:179,222):
+// RcppParallel::Worker and RcppParallel::parallelFor(begin, end, worker, grain).
+// Per-index results are independent in both call sites, so chunking across
+// std::thread workers gives output identical to TBB's; the thread count is a
+// process global set through dada2_shim_set_threads() (1 = run inline).
+#ifndef DADA2_ORACLE_SHIM_RCPPPARALLEL_H
+#define DADA2_ORACLE_SHIM_RCPPPARALLEL_H
+
+#include <algorithm>
+#include <atomic>
+#include <cstddef>
+#include <thread>
+#include <vector>
+
+extern "C" int dada2_shim_nthreads;
+
+namespace RcppParallel {
+
+struct Worker {
+  virtual ~Worker() {}
+  virtual void operator()(std::size_t begin, std::size_t end) = 0;
+};
+
+inline void parallelFor(std::size_t begin, std::size_t end, Worker &worker, std::size_t grainSize = 1) {
+  std::size_t n = end > begin ? end - begin : 0;
+  int nt = dada2_shim_nthreads;
+  if (nt <= 1 || n <= grainSize) {
+    if (n) worker(begin, end);
+    return;
+  }
+  // dynamic chunks of a few grains each, handed out through an atomic cursor
+  std::size_t chunk = std::max<std::size_t>(grainSize, std::min<std::size_t>(256, n / (std::size_t)(8 * nt) + 1));
+  std::atomic<std::size_t> next(begin);
+  auto body = [&]() {
+    for (;;) {
+      std::size_t b = next.fetch_add(chunk);
+      if (b >= end) break;
+      worker(b, std::min(end, b + chunk));
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(body);
+  body();
+  for (auto &t : th) t.join();
+}
+
+}  // namespace RcppParallel
+
+#endif
