@@ -1,0 +1,139 @@
+"""CPU tests (-m "not gpu"): pin the oracle.
+
+1. oracle/dada_oracle.c (plain-C restatement) against the committed goldens that the
+   REFERENCE ITSELF produced (tests/golden/make_golden.py via oracle/_ref) — bit-exact,
+   p-values included, since both sides share oracle/rmath_ppois.c.
+2. where oracle/_ref is present, restatement vs reference live on fresh seeded inputs.
+3. the ppois restatement against 60-digit truth (golden) and scipy.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (GOLDEN, WHOLE_PATH_CASES, assert_results_equal, case_inputs, tperr1)
+from dada2_amd.opts import DadaOpts
+
+
+@pytest.mark.parametrize("name", WHOLE_PATH_CASES)
+def test_restatement_matches_reference_goldens(oracle_c, name):
+    d, err, pri, opts, exp, meta = case_inputs(name)
+    got = oracle_c.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, opts)
+    assert got.nclust == meta["nclust"]
+    assert_results_equal(got, exp, exact_float=True, check_birth_from="priors" not in meta)
+
+
+def test_known_outcomes_from_survey(oracle_c):
+    """SURVEY.md §4 probe: sam1F + tperr1 -> 10 partitions, 8655 comparisons / 3032 shrouded."""
+    d, err, pri, opts, exp, meta = case_inputs("sam1F_default")
+    got = oracle_c.dada_uniques(d.seqs, d.abundances, None, err, d.quals, opts)
+    assert got.clustering["abundance"].tolist() == [543, 376, 160, 61, 47, 69, 9, 13, 82, 68]
+    assert (got.stats["nalign"], got.stats["nshroud"]) == (8655, 3032)
+    d, err, pri, opts, exp, meta = case_inputs("samPB_band32")
+    got = oracle_c.dada_uniques(d.seqs, d.abundances, None, err, d.quals, opts)
+    assert got.clustering["abundance"].tolist() == [59, 107, 53, 68, 53, 27, 34, 18, 8, 13, 18, 12]
+
+
+def test_nwalign_goldens(oracle_c):
+    z = np.load(os.path.join(GOLDEN, "nwalign_pairs.npz"))
+    for s1, s2, band, a0, a1 in zip(z["s1"], z["s2"], z["band"], z["al0"], z["al1"]):
+        assert oracle_c.nwalign(str(s1), str(s2), 5, -4, -8, int(band)) == (str(a0), str(a1))
+
+
+@pytest.mark.parametrize("fq,band", [("sam1F", 16), ("samPB", 32)])
+def test_compare_goldens(oracle_c, fq, band):
+    from helpers import load_input
+    from dada2_amd.io import extend_err
+    d = load_input(fq)
+    err = extend_err(tperr1(), int(np.ceil(np.nanmax(d.quals))))
+    rows = np.load(os.path.join(GOLDEN, f"compare_{fq}.npy"))
+    o = DadaOpts(BAND_SIZE=band)
+    for c, r, lam, ham, kd, ko in rows[:: (1 if fq == "sam1F" else 2)]:
+        c, r = int(c), int(r)
+        got = oracle_c.compare(d.seqs[c], d.quals[c, :len(d.seqs[c])], d.seqs[r], d.quals[r, :len(d.seqs[r])], err, o,
+                               kdist_cutoff=0.42)
+        assert got == (lam, int(ham), kd, ko)
+
+
+def test_input_validation(oracle_c):
+    err = tperr1()
+    with pytest.raises(RuntimeError, match="Zero input"):
+        oracle_c.dada_uniques([], [], None, err, None)
+    with pytest.raises(RuntimeError, match="kmer-size"):
+        oracle_c.dada_uniques(["ACGT"], [1], None, err, None)
+
+
+def test_ppois_against_truth_and_scipy(oracle_c):
+    from scipy.special import pdtrc
+    rows = np.load(os.path.join(GOLDEN, "ppois_grid.npy"))
+    x, lam, truth, ref_p = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]
+    got = np.array([oracle_c.ppois_upper(a, b) for a, b in zip(x, lam)])
+    assert np.array_equal(got, ref_p)                      # same bits as when the goldens were made
+    normal = truth > 2.3e-308
+    rel = np.abs(got[normal] - truth[normal]) / truth[normal]
+    # R's algorithm redoes results < 1e-292 in log space (pgamma.c), losing ~|log p|*eps there
+    main = truth[normal] > 1e-290
+    # dpois_raw = exp(-stirlerr - bd0)/sqrt(2 pi x): conditioning ~ |log p| * eps, so deep tails carry ~1e-12
+    assert rel[main].max() < 2e-12, rel[main].max()
+    shallow = truth[normal] > 1e-20
+    assert rel[shallow].max() < 1e-13, rel[shallow].max()
+    assert rel[~main].max() < 2e-11, rel[~main].max()
+    assert (got[truth == 0.0] == 0.0).all()
+    sp = pdtrc(x[normal][main], lam[normal][main])
+    ok = sp > 1e-300
+    assert (np.abs(sp[ok] - got[normal][main][ok]) / got[normal][main][ok]).max() < 1e-11
+    # calc_pA columns (conditional / unconditional), reference pval.cpp:44-64
+    for (a, b, pc, pu) in rows[::7, [0, 1, 4, 5]]:
+        assert oracle_c.calc_pA(int(a) + 1, b, False) == pc or (np.isnan(pc) and np.isnan(oracle_c.calc_pA(int(a) + 1, b, False)))
+        assert oracle_c.calc_pA(int(a) + 1, b, True) == pu
+
+
+# ---------------------------------------------------------------------------------------------
+# live cross-checks against the reference (only where oracle/_ref has been built)
+def _random_sample(seed, n=600, L=120, G=8, Lmin=None, indel=0.0):
+    from dada2_amd.synth import make_sample
+    return make_sample(tperr1(), n, L=L, G=G, seed=seed, Lmin=Lmin, indel_rate=indel, chunk=2000)
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (1, {}), (2, dict(BAND_SIZE=4)), (3, dict(GREEDY=False, GAPLESS=False)), (4, dict(USE_KMERS=False)),
+    (5, dict(MIN_FOLD=2, MIN_HAMMING=2, MIN_ABUNDANCE=2)), (6, dict(OMEGA_A=1e-4, OMEGA_C=1e-2)),
+    (7, dict(SSE=0)), (8, dict(VECTORIZED_ALIGNMENT=False, KDIST_CUTOFF=0.3)), (9, dict(MAX_CLUST=3)),
+])
+def test_restatement_vs_reference_live(oracle_c, oracle_ref, seed, kw):
+    ragged = seed % 2 == 0
+    d = _random_sample(seed, Lmin=100 if ragged else None, indel=2e-3 if ragged else 0.0)
+    o = DadaOpts(**kw)
+    pri = None
+    if seed == 6:
+        pri = (np.arange(d.nraw) % 17 == 3).astype(np.uint8)
+    for mt in (False, True):
+        a = oracle_ref.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o, multithread=mt)
+        b = oracle_c.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o, multithread=mt)
+        assert_results_equal(a, b, exact_float=True, check_birth_from=pri is None)
+
+
+# NOTE: there is no "no quality matrix" case to pin: with a 0-row quals matrix the reference
+# itself crashes (error.cpp:158 reads raw->qual[pos1] unconditionally), and R always passes
+# quals (R/dada.R:337) — the product therefore rejects quals == NULL up front.
+
+
+def test_nwalign_vs_both_reference_aligners(oracle_c, oracle_ref):
+    rng = np.random.default_rng(99)
+    for k in range(1500):
+        L1 = int(rng.integers(6, 200))
+        a = rng.integers(0, 4, L1)
+        b = a.copy() if k % 4 else rng.integers(0, 4, int(rng.integers(6, 200)))
+        for _ in range(int(rng.integers(0, 6))):
+            p = int(rng.integers(0, len(b)))
+            r = rng.random()
+            b = np.delete(b, p) if (r < 0.3 and len(b) > 8) else (np.insert(b, p, rng.integers(0, 4)) if r < 0.6 else b)
+            if r >= 0.6:
+                b[p] = rng.integers(0, 4)
+        s1 = "".join("ACGT"[i] for i in a)
+        s2 = "".join("ACGT"[i] for i in b)
+        band = int(rng.choice([1, 2, 3, 8, 15, 16, 17, 32, -1]))
+        g = int(rng.choice([-8, -2, -12]))
+        want = oracle_ref.nwalign(s1, s2, 5, -4, g, band, "vectorized")
+        assert want == oracle_ref.nwalign(s1, s2, 5, -4, g, band, "endsfree")
+        assert oracle_c.nwalign(s1, s2, 5, -4, g, band) == want
