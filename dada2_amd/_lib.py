@@ -1,0 +1,101 @@
+"""ctypes binding of libdada2hip.so (include/dada2hip.h).  There is deliberately no
+fallback: if the HIP library has not been built, or no GPU is usable, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .opts import COpts
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdada2hip.so")
+_lib = None
+
+
+class Dada2HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class CStats(C.Structure):
+    _fields_ = [
+        ("ncompare", C.c_uint64), ("nskipped", C.c_uint64), ("nshroud", C.c_uint64), ("ngapless", C.c_uint64),
+        ("nnw", C.c_uint64), ("nshuffle", C.c_uint64), ("nstored", C.c_uint64),
+        ("rounds", C.c_uint32), ("reserved", C.c_uint32),
+        ("ms_total", C.c_double), ("ms_upload", C.c_double), ("ms_screen", C.c_double), ("ms_nw", C.c_double),
+        ("ms_gapless", C.c_double), ("ms_bookkeep", C.c_double), ("ms_pval", C.c_double), ("ms_final", C.c_double),
+        ("nw_kernel_ms", C.c_double), ("nw_kernel_launches", C.c_uint64), ("nw_cells", C.c_uint64),
+        ("screen_kernel_ms", C.c_double), ("screen_kernel_launches", C.c_uint64), ("screen_bytes", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/dada2hip.h declares (tests/test_abi.py checks the .so exports all of them)
+EXPORTS = [
+    "dada2hip_dada_uniques", "dada2hip_sample_create", "dada2hip_sample_set_priors", "dada2hip_sample_run",
+    "dada2hip_sample_free", "dada2hip_sample_nraw", "dada2hip_sample_maxlen", "dada2hip_result_nclust",
+    "dada2hip_result_nraw", "dada2hip_result_maxlen", "dada2hip_result_ncol", "dada2hip_result_nbirth_subs",
+    "dada2hip_result_sequence", "dada2hip_result_abundance", "dada2hip_result_n0", "dada2hip_result_n1",
+    "dada2hip_result_nunq", "dada2hip_result_clust_pval", "dada2hip_result_birth_from", "dada2hip_result_birth_pval",
+    "dada2hip_result_birth_fold", "dada2hip_result_birth_ham", "dada2hip_result_birth_qave", "dada2hip_result_center",
+    "dada2hip_result_bs_pos", "dada2hip_result_bs_ref", "dada2hip_result_bs_sub", "dada2hip_result_bs_qual",
+    "dada2hip_result_bs_clust", "dada2hip_result_subqual", "dada2hip_result_clusterquals", "dada2hip_result_map",
+    "dada2hip_result_pval", "dada2hip_result_stats", "dada2hip_result_free", "dada2hip_nwalign", "dada2hip_nwvec",
+    "dada2hip_sample_compare", "dada2hip_calc_pA", "dada2hip_version",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Dada2HipError(2, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, cp = C.c_void_p, C.c_int32, C.c_char_p
+    L.dada2hip_version.restype = cp
+    L.dada2hip_sample_create.argtypes = [ip, C.POINTER(cp), vp, vp, vp, ip, ip, C.POINTER(vp), cp, C.c_size_t]
+    L.dada2hip_sample_set_priors.argtypes = [vp, vp, cp, C.c_size_t]
+    L.dada2hip_sample_run.argtypes = [vp, vp, ip, C.POINTER(COpts), vp, C.POINTER(vp), cp, C.c_size_t]
+    L.dada2hip_sample_free.argtypes = [vp]
+    L.dada2hip_sample_nraw.argtypes = [vp]
+    L.dada2hip_sample_maxlen.argtypes = [vp]
+    L.dada2hip_dada_uniques.argtypes = [ip, C.POINTER(cp), vp, vp, vp, ip, vp, ip, C.POINTER(COpts), ip, vp,
+                                        C.POINTER(vp), cp, C.c_size_t]
+    for name in ("nclust", "nraw", "maxlen", "ncol", "nbirth_subs"):
+        getattr(L, "dada2hip_result_" + name).argtypes = [vp]
+        getattr(L, "dada2hip_result_" + name).restype = ip
+    L.dada2hip_result_sequence.argtypes = [vp, ip]
+    L.dada2hip_result_sequence.restype = cp
+    for name in ("abundance", "n0", "n1", "nunq", "birth_from", "birth_ham", "center", "bs_pos", "bs_clust", "subqual",
+                 "map"):
+        f = getattr(L, "dada2hip_result_" + name)
+        f.argtypes = [vp]
+        f.restype = C.POINTER(C.c_int32)
+    for name in ("clust_pval", "birth_pval", "birth_fold", "birth_qave", "bs_qual", "clusterquals", "pval"):
+        f = getattr(L, "dada2hip_result_" + name)
+        f.argtypes = [vp]
+        f.restype = C.POINTER(C.c_double)
+    for name in ("bs_ref", "bs_sub"):
+        f = getattr(L, "dada2hip_result_" + name)
+        f.argtypes = [vp]
+        f.restype = C.POINTER(C.c_char)
+    L.dada2hip_result_stats.argtypes = [vp, C.POINTER(CStats)]
+    L.dada2hip_result_free.argtypes = [vp]
+    L.dada2hip_nwalign.argtypes = [cp, cp, ip, ip, ip, ip, ip, ip, ip, cp, cp, cp, C.c_size_t]
+    L.dada2hip_nwvec.argtypes = [ip, C.POINTER(cp), C.POINTER(cp), ip, ip, ip, ip, ip, ip, C.POINTER(cp), cp, C.c_size_t]
+    L.dada2hip_sample_compare.argtypes = [vp, ip, vp, ip, C.POINTER(COpts), C.c_double, vp, vp, vp, vp,
+                                          C.POINTER(CStats), cp, C.c_size_t]
+    L.dada2hip_calc_pA.argtypes = [ip, vp, vp, vp, ip, vp, cp, C.c_size_t]
+    _lib = L
+    return L
+
+
+def check(rc, errbuf):
+    if rc != 0:
+        raise Dada2HipError(rc, errbuf.value.decode(errors="replace"))

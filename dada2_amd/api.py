@@ -1,0 +1,279 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+* ``dada_uniques(...)``  — the ``.Call`` of R/RcppExports.R:8-10 (src/Rmain.cpp:30): same
+  argument meaning, same six outputs, errors raised with the reference's messages.
+* ``Sample``             — the same call split into "make the uniques resident in HBM" and
+  "run with this error matrix", which is what the selfConsist loop of R/dada.R:256-405 needs.
+* ``nwalign`` / ``nwvec`` — R/misc.R:179 ``nwalign()`` -> C_nwalign / C_nwvec.
+* ``dada(...)``          — the per-sample loop + selfConsist loop of R/dada.R:144-487, reduced
+  to what the hot path needs (single process; ``dada2_amd.multi`` shards samples over GPUs).
+
+R is not installed in this image, so this Python layer stands where R/dada.R
+stands; INTEGRATION.md shows the Rcpp stub that binds the same C ABI from R.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .io import Derep, extend_err
+from .opts import COpts, DadaOpts, DadaResult
+
+_EB = 2048
+
+
+def _pack(seqs, abundances, priors, quals):
+    n = len(seqs)
+    arr = (C.c_char_p * max(n, 1))(*[s.encode("ascii") for s in seqs])
+    ab = np.ascontiguousarray(abundances, dtype=np.int32)
+    pr = None if priors is None else np.ascontiguousarray(priors, dtype=np.uint8)
+    q = None if quals is None else np.ascontiguousarray(quals, dtype=np.float64)
+    if q is not None and q.ndim == 2 and q.shape[0] != n:
+        raise ValueError("derep$quals matrices must have one row for each derep$unique sequence.")
+    return arr, ab, pr, q, (0 if q is None else q.shape[1])
+
+
+def _err_colmajor(err):
+    e = np.asarray(err, dtype=np.float64)
+    if e.ndim != 2 or e.shape[0] != 16:
+        raise _lib.Dada2HipError(1, "Error matrix must have 16 rows.")
+    return np.ascontiguousarray(e.T), e.shape[1]
+
+
+def _collect(L, h) -> DadaResult:
+    Cn = L.dada2hip_result_nclust(h)
+    N = L.dada2hip_result_nraw(h)
+    ml = L.dada2hip_result_maxlen(h)
+    nc = L.dada2hip_result_ncol(h)
+    nb = L.dada2hip_result_nbirth_subs(h)
+
+    def arr(name, n, dt):
+        if n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(getattr(L, "dada2hip_result_" + name)(h), shape=(n,)).astype(dt, copy=True)
+
+    clustering = {
+        "sequence": [L.dada2hip_result_sequence(h, i).decode() for i in range(Cn)],
+        "abundance": arr("abundance", Cn, np.int32), "n0": arr("n0", Cn, np.int32), "n1": arr("n1", Cn, np.int32),
+        "nunq": arr("nunq", Cn, np.int32), "pval": arr("clust_pval", Cn, np.float64),
+        "birth_from": arr("birth_from", Cn, np.int32), "birth_pval": arr("birth_pval", Cn, np.float64),
+        "birth_fold": arr("birth_fold", Cn, np.float64), "birth_ham": arr("birth_ham", Cn, np.int32),
+        "birth_qave": arr("birth_qave", Cn, np.float64),
+    }
+    ref = L.dada2hip_result_bs_ref(h)
+    sub = L.dada2hip_result_bs_sub(h)
+    birth_subs = {
+        "pos": arr("bs_pos", nb, np.int32), "ref": [ref[i].decode() for i in range(nb)],
+        "sub": [sub[i].decode() for i in range(nb)], "qual": arr("bs_qual", nb, np.float64),
+        "clust": arr("bs_clust", nb, np.int32),
+    }
+    subqual = arr("subqual", 16 * nc, np.int32).reshape(nc, 16).T.copy()
+    cq = arr("clusterquals", ml * Cn, np.float64).reshape(Cn, ml).T.copy()
+    st = _lib.CStats()
+    L.dada2hip_result_stats(h, C.byref(st))
+    stats = st.as_dict()
+    stats["center"] = arr("center", Cn, np.int32)
+    return DadaResult(clustering, birth_subs, subqual, cq, arr("map", N, np.int32), arr("pval", N, np.float64), stats)
+
+
+def _copts(opts, max_clust, multithread, verbose, copts):
+    if copts is not None:
+        return copts
+    return (opts or DadaOpts()).to_c(max_clust=max_clust, multithread=multithread, verbose=verbose)
+
+
+def dada_uniques(seqs, abundances, priors, err, quals, opts: DadaOpts = None, *, max_clust=None, multithread=False,
+                 verbose=False, copts: COpts = None, device: int = 0) -> DadaResult:
+    """One ``dada_uniques`` call (src/Rmain.cpp:30) on the GPU.  ``quals`` is the derep-side
+    [N, maxlen] matrix (NaN past a short read's end); ``err`` is 16 x Q."""
+    L = _lib.lib()
+    co = _copts(opts, max_clust, multithread, verbose, copts)
+    arr, ab, pr, q, qn = _pack(seqs, abundances, priors, quals)
+    e, ncol = _err_colmajor(err)
+    eb = C.create_string_buffer(_EB)
+    h = C.c_void_p()
+    rc = L.dada2hip_dada_uniques(len(seqs), arr, ab.ctypes.data, pr.ctypes.data if pr is not None else None,
+                                 e.ctypes.data, ncol, q.ctypes.data if q is not None else None, qn, C.byref(co),
+                                 device, None, C.byref(h), eb, _EB)
+    _lib.check(rc, eb)
+    try:
+        return _collect(L, h)
+    finally:
+        L.dada2hip_result_free(h)
+
+
+class Sample:
+    """Uniques of one sample resident in HBM (dada2hip_sample_*): 2-bit reads, rounded
+    qualities and k-mer records are uploaded/built once and reused by every ``run``."""
+
+    def __init__(self, seqs, abundances, priors, quals, device: int = 0):
+        L = _lib.lib()
+        arr, ab, pr, q, qn = _pack(seqs, abundances, priors, quals)
+        eb = C.create_string_buffer(_EB)
+        self._h = C.c_void_p()
+        rc = L.dada2hip_sample_create(len(seqs), arr, ab.ctypes.data, pr.ctypes.data if pr is not None else None,
+                                      q.ctypes.data if q is not None else None, qn, device, C.byref(self._h), eb, _EB)
+        _lib.check(rc, eb)
+        self.nraw = len(seqs)
+        self.device = device
+
+    @classmethod
+    def from_derep(cls, d: Derep, priors=None, device: int = 0):
+        return cls(d.seqs, d.abundances, priors, d.quals, device)
+
+    def set_priors(self, priors):
+        eb = C.create_string_buffer(_EB)
+        pr = np.ascontiguousarray(priors, dtype=np.uint8)
+        _lib.check(_lib.lib().dada2hip_sample_set_priors(self._h, pr.ctypes.data, eb, _EB), eb)
+
+    def run(self, err, opts: DadaOpts = None, *, max_clust=None, multithread=False, verbose=False,
+            copts: COpts = None) -> DadaResult:
+        L = _lib.lib()
+        co = _copts(opts, max_clust, multithread, verbose, copts)
+        e, ncol = _err_colmajor(err)
+        eb = C.create_string_buffer(_EB)
+        h = C.c_void_p()
+        _lib.check(L.dada2hip_sample_run(self._h, e.ctypes.data, ncol, C.byref(co), None, C.byref(h), eb, _EB), eb)
+        try:
+            return _collect(L, h)
+        finally:
+            L.dada2hip_result_free(h)
+
+    def compare(self, centre: int, err, opts: DadaOpts = None, kdist_cutoff=None, skip=None):
+        """One b_compare round (cluster.cpp:90-149): (lambda[N], hamming[N], cls[N], stats)."""
+        L = _lib.lib()
+        o = opts or DadaOpts()
+        co = o.to_c()
+        e, ncol = _err_colmajor(err)
+        lam = np.zeros(self.nraw)
+        ham = np.zeros(self.nraw, dtype=np.uint32)
+        cls = np.zeros(self.nraw, dtype=np.uint8)
+        sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8)
+        st = _lib.CStats()
+        eb = C.create_string_buffer(_EB)
+        rc = L.dada2hip_sample_compare(self._h, int(centre), e.ctypes.data, ncol, C.byref(co),
+                                       float(o.KDIST_CUTOFF if kdist_cutoff is None else kdist_cutoff),
+                                       sk.ctypes.data if sk is not None else None, lam.ctypes.data, ham.ctypes.data,
+                                       cls.ctypes.data, C.byref(st), eb, _EB)
+        _lib.check(rc, eb)
+        return lam, ham, cls, st.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().dada2hip_sample_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nwvec(s1, s2, match=5, mismatch=-4, gap=-8, band=-1, endsfree=True, device: int = 0):
+    """C_nwvec (src/nwalign_vectorized.cpp:321): list of (al0, al1) for the pairs."""
+    L = _lib.lib()
+    n = len(s1)
+    if n != len(s2):
+        raise ValueError("Character vectors to be aligned must be of equal length.")
+    a = (C.c_char_p * n)(*[x.encode() for x in s1])
+    b = (C.c_char_p * n)(*[x.encode() for x in s2])
+    bufs = [C.create_string_buffer(len(s1[i // 2]) + len(s2[i // 2]) + 2) for i in range(2 * n)]
+    out = (C.c_char_p * (2 * n))(*[C.cast(x, C.c_char_p) for x in bufs])
+    eb = C.create_string_buffer(_EB)
+    _lib.check(L.dada2hip_nwvec(n, a, b, match, mismatch, gap, band, int(endsfree), device, out, eb, _EB), eb)
+    return [(bufs[2 * i].value.decode(), bufs[2 * i + 1].value.decode()) for i in range(n)]
+
+
+def nwalign(s1, s2, match=5, mismatch=-4, gap=-8, homo_gap=None, band=-1, endsfree=True, device: int = 0):
+    """R/misc.R:179 nwalign(): one pair, returns (al0, al1)."""
+    L = _lib.lib()
+    o0 = C.create_string_buffer(len(s1) + len(s2) + 2)
+    o1 = C.create_string_buffer(len(s1) + len(s2) + 2)
+    eb = C.create_string_buffer(_EB)
+    rc = L.dada2hip_nwalign(s1.encode(), s2.encode(), match, mismatch, gap, gap if homo_gap is None else homo_gap, band,
+                            int(endsfree), device, o0, o1, eb, _EB)
+    _lib.check(rc, eb)
+    return o0.value.decode(), o1.value.decode()
+
+
+def calc_pA_device(reads, E, prior, device: int = 0):
+    """calc_pA (src/pval.cpp:44-64) evaluated by the device kernel."""
+    L = _lib.lib()
+    r = np.ascontiguousarray(reads, dtype=np.int32)
+    e = np.ascontiguousarray(E, dtype=np.float64)
+    p = np.ascontiguousarray(prior, dtype=np.uint8)
+    out = np.zeros(r.size)
+    eb = C.create_string_buffer(_EB)
+    _lib.check(L.dada2hip_calc_pA(r.size, r.ctypes.data, e.ctypes.data, p.ctypes.data, device, out.ctypes.data, eb, _EB), eb)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+def accumulate_trans(trans_list):
+    """R/errorModels.R:462-471."""
+    maxcol = max(t.shape[1] for t in trans_list)
+    out = np.zeros((16, maxcol), dtype=np.int64)
+    for t in trans_list:
+        out[:, : t.shape[1]] += t
+    return out
+
+
+def noqual_errfun(trans, pseudocount=1):
+    """R/errorModels.R:222-249 (noqualErrfun): one rate per transition, aggregated over quality."""
+    trans = np.asarray(trans, dtype=np.float64)
+    obs = trans.sum(axis=1) + pseudocount
+    err = np.zeros_like(trans)
+    for i in range(4):
+        tot = obs[4 * i: 4 * i + 4].sum()
+        rates = obs[4 * i: 4 * i + 4] / tot
+        for j in range(4):
+            if i != j:
+                err[4 * i + j, :] = rates[j]
+        err[5 * i, :] = 1.0 - sum(rates[j] for j in range(4) if j != i)
+    return err
+
+
+def dada(dereps, err=None, *, self_consist=False, err_fun=noqual_errfun, opts: DadaOpts = None, priors=None,
+         device: int = 0, verbose=False, samples=None):
+    """The sample loop and selfConsist loop of R/dada.R:256-405 over resident samples.
+
+    ``err_fun`` maps the accumulated 16 x Q transition counts to a new error matrix; the
+    reference's default is ``loessErrfun`` (stats::loess, third-party, not available here) so the
+    deterministic ``noqualErrfun`` stands in.  Returns (list[DadaResult], err_out,
+    list of err matrices tried)."""
+    o = (opts or DadaOpts()).normalised()
+    single = isinstance(dereps, Derep)
+    if single:
+        dereps = [dereps]
+    own = samples is None
+    if own:
+        samples = [Sample.from_derep(d, None if priors is None else priors[i], device) for i, d in enumerate(dereps)]
+    initialize = self_consist and err is None
+    nconsist = 0 if initialize else 1
+    errs = []
+    try:
+        while True:
+            if nconsist > 0:
+                errs.append(np.array(err, copy=True))
+            results = []
+            for d, smp in zip(dereps, samples):
+                qmax = int(np.ceil(np.nanmax(d.quals)))
+                erri = np.ones((16, max(41, qmax + 1))) if initialize else extend_err(err, qmax)   # R/dada.R:297-313
+                results.append(smp.run(erri, o, max_clust=1 if initialize else None, verbose=verbose))
+            cur = accumulate_trans([r.subqual for r in results])
+            new_err = err_fun(cur) if err_fun is not None else None
+            if initialize:
+                initialize = False
+                new_err[[0, 5, 10, 15], :] = 1.0                                                   # R/dada.R:385-388
+            err = new_err
+            if (not self_consist) or any(np.array_equal(e, err) for e in errs) or nconsist >= o.MAX_CONSIST:
+                break
+            nconsist += 1
+    finally:
+        if own:
+            for smp in samples:
+                smp.close()
+    return (results[0] if single else results), err, errs

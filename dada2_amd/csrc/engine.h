@@ -1,0 +1,103 @@
+// engine.h — shared declarations between the HIP kernels (kernels.hip) and the host driver
+// (driver.cpp / capi.cpp) of libdada2hip.so.  Host language is C++ because the reference's
+// host side for this path is compiled C++ (Rcpp); see include/dada2hip.h for the boundary.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/dada2hip.h"
+
+namespace d2 {
+
+constexpr int KMER_SIZE = 5;       // /root/reference/src/dada.h:27
+constexpr int NKMER = 1024;        // 4^5
+constexpr int RANK_SAT = 63;       // 6-bit occurrence rank packed above the 10-bit k-mer id
+constexpr int MAX_SHUFFLE = 10;    // dada.h:30
+constexpr int SEQLEN = 9999;       // dada.h:24
+constexpr double TAIL_APPROX_CUTOFF = 1e-7;  // dada.h:25
+
+// comparison classes written by the screen kernel
+enum : uint8_t { CLS_SKIP = 0, CLS_SHROUD = 1, CLS_GAPLESS = 2, CLS_NW = 3 };
+
+struct DeviceError {
+  int code;
+  std::string msg;
+};
+
+#define D2_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      throw d2::DeviceError{DADA2HIP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(_e) +  \
+                                                     " at " __FILE__ ":" + std::to_string(__LINE__)}; \
+  } while (0)
+
+// Uniques of one sample, resident in HBM (layout: DESIGN.md §3).
+struct SampleDev {
+  int32_t N = 0, maxlen = 0, minlen = 0;
+  int32_t W2 = 0;   // u32 words per 2-bit packed sequence row (multiple of 4 -> 16 B aligned rows)
+  int32_t LQ = 0;   // bytes per quality row (multiple of 16)
+  int32_t LK = 0;   // u16 entries per ordered-k-mer row (multiple of 8 -> 16 B)
+  int32_t HMAX = 0; // heavy-k-mer slots per unique ((maxlen-4)/64)
+  uint32_t *seq2 = nullptr;   // [N][W2]   base p: word p/16, bits 2*(p%16); codes A,C,G,T = 0..3
+  uint8_t *qual = nullptr;    // [N][LQ]   (uint8) round(mean quality)  (containers.cpp:34)
+  uint16_t *kord = nullptr;   // [N][LK]   k-mer id (10 bits) | min(occurrence rank, 63) << 10
+  uint32_t *heavy = nullptr;  // [N][HMAX] k-mers occurring > 63 times: id | count << 16
+  uint8_t *nheavy = nullptr;  // [N]
+  int32_t *len = nullptr;     // [N]
+  uint32_t *reads = nullptr;  // [N]
+  uint8_t *prior = nullptr;   // [N]
+};
+
+struct AlignParams {
+  int32_t match, mismatch, gap, band, sentinel;
+  int32_t use_quals, ncol;
+};
+
+struct ScreenParams {
+  int32_t use_kmers, gapless, band, sse;
+};
+
+// launch wrappers implemented in kernels.hip -----------------------------------------------------
+void launch_round_quals(const double *d_q, int n, int maxlen, const int32_t *d_len, uint8_t *d_out, int LQ,
+                        int32_t *d_flags, hipStream_t st);
+void launch_build_kmers(const SampleDev &S, hipStream_t st);
+// counters: [0]=#NW work items, [1]=#gapless work items, [2]=#shrouded, [3]=#skipped
+void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip,
+                   const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
+                   int32_t *d_gl_list, int32_t *d_counters, hipStream_t st);
+void launch_gapless(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
+                    const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err,
+                    double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, hipStream_t st);
+void launch_pair_class(const SampleDev &S, const int32_t *d_pc, const int32_t *d_pr, int n, const ScreenParams &sp,
+                       uint8_t *d_out, hipStream_t st);
+
+struct NwScratch {
+  uint32_t *ptr = nullptr;  // traceback pointers  [wave][row][NPW][64]
+  uint32_t *tcode = nullptr;  // transition nibbles  [wave][word][64]
+  int32_t *rows = nullptr;    // generic kernel: DP row [wave][Wgen][64]
+  size_t ptr_words_per_wave = 0, t_words_per_wave = 0, row_words_per_wave = 0;
+  int nwaves = 0;
+};
+// Returns the WMAX class that will be used for (band, maxlen, minlen): 33, 65, 129 or 0 (generic).
+int nw_class(int band, int maxlen, int minlen);
+size_t nw_ptr_words_per_wave(int wclass, int band, int maxlen, int minlen);
+void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
+               const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err, const NwScratch &scr,
+               double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, uint8_t *d_moves,
+               int moves_stride, int32_t *d_nmoves, hipStream_t st);
+
+void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint8_t *d_prior, double *d_out,
+                    hipStream_t st);
+
+// final tables from the per-unique aligned views (error.cpp:131-172, :225-258)
+void launch_final_tables(const SampleDev &S, const uint16_t *d_view, int LV, const int32_t *d_cluster_of,
+                         const int32_t *d_centre_of_cluster, const uint8_t *d_correct, int ncol, int has_quals,
+                         int32_t *d_trans, unsigned long long *d_qsum, uint32_t *d_qn, int32_t *d_nsubs, int nclust,
+                         hipStream_t st);
+
+}  // namespace d2

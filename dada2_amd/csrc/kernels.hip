@@ -1,0 +1,685 @@
+// kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for DADA2's divisive-denoising
+// hot path.  No MFMA: the work is integer DP, byte/halfword streaming and sequential fp64 products
+// (DESIGN.md §4 gives the roofline of each kernel).  Reference behaviour followed, file:line under
+// /root/reference/src:
+//   k_build_kmers   assign_kmer / assign_kmer8 / assign_kmer_order      kmers.cpp:158-279
+//   k_screen        kmer_dist_SSEi_8 / kmer_dist_SSEi / kord_dist_SSEi  kmers.cpp:29-150
+//                   + the dispatch of raw_align                          nwalign_endsfree.cpp:10-73
+//   k_gapless       nwalign_gapless + al2subs + compute_lambda_ts       nwalign_endsfree.cpp:539-639, pval.cpp:144-197
+//   k_nw / k_nw_gen nwalign_vectorized2 == nwalign_endsfree + al2subs + compute_lambda_ts
+//                                                                        nwalign_vectorized.cpp:71-318, nwalign_endsfree.cpp:76-216
+//   k_calc_pA       calc_pA                                              pval.cpp:44-64
+//   k_final_*       b_make_transition_by_quality_matrix / b_make_cluster_quality_matrix   error.cpp:131-172, :225-258
+#include "engine.h"
+#include "ppois.h"
+
+namespace d2 {
+
+static __device__ __forceinline__ uint32_t base_at(const uint32_t *__restrict__ row, int p) {
+  return (row[p >> 4] >> ((p & 15) << 1)) & 3u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// quality upload: double mean quality -> (uint8) round()   (containers.cpp:34); NA/NaN past the end.
+__global__ void k_round_quals(const double *__restrict__ q, int n, int maxlen, const int32_t *__restrict__ len,
+                              uint8_t *__restrict__ out, int LQ, int32_t *__restrict__ flags) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)n * (size_t)LQ;
+  for (; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    int r = (int)(idx / LQ), p = (int)(idx % LQ);
+    uint8_t v = 0;
+    if (p < len[r]) {
+      double x = round(q[(size_t)r * maxlen + p]);
+      if (!(x >= 0.0 && x <= 255.0)) { atomicOr(flags, 1); x = 0.0; }
+      v = (uint8_t)x;
+      atomicMax(flags + 1, (int)v);
+    }
+    out[idx] = v;
+  }
+}
+
+void launch_round_quals(const double *d_q, int n, int maxlen, const int32_t *d_len, uint8_t *d_out, int LQ,
+                        int32_t *d_flags, hipStream_t st) {
+  size_t total = (size_t)n * LQ;
+  int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_round_quals, dim3(grid), dim3(256), 0, st, d_q, n, maxlen, d_len, d_out, LQ, d_flags);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-mer records, one thread per unique with a private 1024-entry u16 count table in LDS
+// (table[km][lane], 128 KiB per 64-thread block).  For every position i < len-4 it emits the
+// ordered k-mer id (kmers.cpp:246-279) together with its occurrence rank = number of earlier
+// positions holding the same k-mer, saturated at 63.  With ranks, the unordered overlap of the
+// count tables (kmers.cpp:13-93) is   sum_k min(a_k, b_k) = #{ i : rank_i < count_centre[kmer_i] },
+// so a round streams ~2 B/position instead of the 1 KiB count table per unique; k-mers that occur
+// more than 63 times go to a small per-unique "heavy" list and are corrected exactly.
+__global__ __launch_bounds__(64) void k_build_kmers(SampleDev S) {
+  __shared__ uint16_t tbl[NKMER * 64];
+  const int lane = threadIdx.x;
+  uint16_t *t = tbl + lane;
+  for (int base = blockIdx.x * 64; base < S.N; base += gridDim.x * 64) {
+    const int r = base + lane;
+    for (int k = 0; k < NKMER; k++) t[k * 64] = 0;
+    if (r < S.N) {
+      const uint32_t *row = S.seq2 + (size_t)r * S.W2;
+      uint16_t *ko = S.kord + (size_t)r * S.LK;
+      const int L = S.len[r], nk = L - KMER_SIZE + 1;
+      uint32_t km = 0;
+      for (int p = 0; p < L; p++) {
+        km = ((km << 2) | base_at(row, p)) & (NKMER - 1);   // first base most significant (kmers.cpp:176-184)
+        if (p >= KMER_SIZE - 1) {
+          uint32_t rk = t[km * 64];
+          t[km * 64] = (uint16_t)(rk + 1);
+          ko[p - (KMER_SIZE - 1)] = (uint16_t)(km | ((rk < RANK_SAT ? rk : RANK_SAT) << 10));
+        }
+      }
+      for (int i = nk; i < S.LK; i++) ko[i] = 0xFFFFu;
+      int nh = 0;
+      if (S.HMAX > 0)
+        for (int k = 0; k < NKMER; k++) {
+          uint32_t c = t[k * 64];
+          if (c > RANK_SAT) S.heavy[(size_t)r * S.HMAX + nh++] = (uint32_t)k | (c << 16);
+        }
+      S.nheavy[r] = (uint8_t)nh;
+    }
+  }
+}
+
+void launch_build_kmers(const SampleDev &S, hipStream_t st) {
+  int grid = std::min((S.N + 63) / 64, 1024);
+  hipLaunchKernelGGL(k_build_kmers, dim3(grid), dim3(64), 0, st, S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-mer screen of one b_compare round: every unique against the partition centre.  16 lanes per
+// unique (4 uniques per wave); the centre's count table and ordered k-mers live in LDS.  HBM-bound:
+// algorithmic bytes per unique = 2*(len-4) (k-mer records) + 4 (len) + 1 (skip) + 1 (class out).
+__global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenParams sp,
+                                                const uint8_t *__restrict__ skip, const int32_t *__restrict__ thresh,
+                                                uint8_t *__restrict__ cls, double *__restrict__ lam,
+                                                uint32_t *__restrict__ ham, int32_t *__restrict__ nw_list,
+                                                int32_t *__restrict__ gl_list, int32_t *__restrict__ counters,
+                                                int cap) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t *ccnt = s_mem;                                  // [1024] centre k-mer counts
+  int32_t *s_cnt = (int32_t *)(s_mem + NKMER);             // [4] block-local counters, [4..5] global bases
+  int32_t *s_nw = (int32_t *)(s_mem + NKMER + 8);          // [cap] this block's NW work items
+  int32_t *s_gl = s_nw + cap;                              // [cap] this block's gapless work items
+  uint16_t *ckord = (uint16_t *)(s_gl + cap);              // [LK] centre ordered k-mers
+  const int tid = threadIdx.x;
+  const int Lc = S.len[centre], nkc = Lc - KMER_SIZE + 1;
+  for (int k = tid; k < NKMER; k += 256) ccnt[k] = 0;
+  if (tid < 8) s_cnt[tid] = 0;
+  __syncthreads();
+  if (sp.use_kmers) {
+    const uint16_t *crow = S.kord + (size_t)centre * S.LK;
+    for (int i = tid; i < nkc; i += 256) {
+      uint32_t km = crow[i] & 1023u;
+      atomicAdd(&ccnt[km], 1u);
+      ckord[i] = (uint16_t)km;
+    }
+  }
+  __syncthreads();
+  const int sub = tid & 15, grp = tid >> 4;
+  for (int base = blockIdx.x * 16; base < S.N; base += gridDim.x * 16) {
+    const int r = base + grp;
+    if (r >= S.N) continue;
+    const bool skipped = skip && skip[r];
+    uint32_t dot = 0, ord = 0;
+    int Lr = 0, d = 0;
+    if (!skipped) {
+      Lr = S.len[r];
+      d = (Lc < Lr ? Lc : Lr) - KMER_SIZE + 1;
+      if (sp.use_kmers) {
+        const int nkr = Lr - KMER_SIZE + 1;
+        const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
+        for (int i0 = sub * 8; i0 < nkr; i0 += 128) {
+          uint4 v = row[i0 >> 3];
+          uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int i = i0 + e;
+            const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+            if (i < nkr) {
+              const uint32_t km = x & 1023u, rk = x >> 10;
+              if (rk < RANK_SAT) dot += (rk < ccnt[km]);
+              if (i < d) ord += (km == ckord[i]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {   // reduce over the 16-lane group
+      dot += __shfl_xor(dot, o, 16);
+      ord += __shfl_xor(ord, o, 16);
+    }
+    if (sub == 0) {
+      uint8_t c;
+      if (skipped) {
+        c = CLS_SKIP;
+      } else {
+        if (sp.use_kmers && S.HMAX > 0) {
+          const int nh = S.nheavy[r];
+          for (int h = 0; h < nh; h++) {
+            const uint32_t e = S.heavy[(size_t)r * S.HMAX + h], km = e & 1023u, cr = e >> 16, cc = ccnt[km];
+            const uint32_t m = cr < cc ? cr : cc;
+            if (m > RANK_SAT) dot += m - RANK_SAT;
+          }
+        }
+        dot &= 0xFFFFu;   // the reference accumulates in uint16_t (kmers.cpp:16,34,69)
+        ord &= 0xFFFFu;
+        const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || Lr == Lc);   // kord_dist: -1 on unequal lengths when SSE==0
+        if (sp.use_kmers && (int)dot < thresh[d]) c = CLS_SHROUD;                       // kdist > kdist_cutoff
+        else if (sp.band == 0 || (gl_ok && ord == dot)) c = CLS_GAPLESS;                // kodist == kdist
+        else c = CLS_NW;
+      }
+      cls[r] = c;
+      if (c == CLS_SKIP || c == CLS_SHROUD) { lam[r] = 0.0; ham[r] = 0xFFFFFFFFu; atomicAdd(&s_cnt[c == CLS_SKIP ? 3 : 2], 1); }
+      else if (c == CLS_GAPLESS) s_gl[atomicAdd(&s_cnt[1], 1)] = r;
+      else s_nw[atomicAdd(&s_cnt[0], 1)] = r;
+    }
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const int n = s_cnt[tid];
+    s_cnt[4 + tid] = n ? atomicAdd(&counters[tid], n) : 0;   // one global atomic per list per block
+  }
+  __syncthreads();
+  for (int i = tid; i < s_cnt[0]; i += 256) nw_list[s_cnt[4] + i] = s_nw[i];
+  for (int i = tid; i < s_cnt[1]; i += 256) gl_list[s_cnt[5] + i] = s_gl[i];
+}
+
+void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip,
+                   const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
+                   int32_t *d_gl_list, int32_t *d_counters, hipStream_t st) {
+  int grid = std::min((S.N + 15) / 16, 2048);
+  int iters = ((S.N + 15) / 16 + grid - 1) / grid;
+  int cap = iters * 16;
+  size_t lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 16;
+  while (lds > 96 * 1024) {   // very large N: more blocks, shorter per-block lists
+    grid *= 2;
+    iters = ((S.N + 15) / 16 + grid - 1) / grid;
+    cap = iters * 16;
+    lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 16;
+  }
+  hipLaunchKernelGGL(k_screen, dim3(grid), dim3(256), lds, st, S, centre, sp, d_skip, d_thresh, d_cls, d_lambda, d_ham,
+                     d_nw_list, d_gl_list, d_counters, cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Class of isolated (centre, raw) pairs — the birth substitutions of Rmain.cpp:209-215 are
+// sub_new(parent centre, new centre, use_kmers, cutoff 1.0): never shrouded (kdist <= 1), gapless iff
+// band == 0 or ordered == unordered k-mer overlap (nwalign_endsfree.cpp:54).  One wave per pair.
+__global__ __launch_bounds__(256) void k_pair_class(SampleDev S, const int32_t *__restrict__ pc,
+                                                    const int32_t *__restrict__ pr, int n, ScreenParams sp,
+                                                    uint8_t *__restrict__ out) {
+  __shared__ uint32_t s_cnt[4][NKMER];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t *ccnt = s_cnt[w];
+  for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
+    const int pair = base + w;
+    const bool on = pair < n;
+    const int c = on ? pc[pair] : 0, r = on ? pr[pair] : 0;
+    const int Lc = S.len[c], Lr = S.len[r], nkc = Lc - KMER_SIZE + 1, nkr = Lr - KMER_SIZE + 1;
+    const int d = (Lc < Lr ? Lc : Lr) - KMER_SIZE + 1;
+    const uint16_t *crow = S.kord + (size_t)c * S.LK, *rrow = S.kord + (size_t)r * S.LK;
+    for (int k = lane; k < NKMER; k += 64) ccnt[k] = 0;
+    __syncthreads();
+    for (int i = lane; i < nkc; i += 64) atomicAdd(&ccnt[crow[i] & 1023u], 1u);
+    __syncthreads();
+    uint32_t dot = 0, ord = 0;
+    for (int i = lane; i < nkr; i += 64) {
+      const uint32_t x = rrow[i], km = x & 1023u, rk = x >> 10;
+      if (rk < RANK_SAT) dot += (rk < ccnt[km]);
+      if (i < d) ord += (km == (crow[i] & 1023u));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { dot += __shfl_xor(dot, o, 64); ord += __shfl_xor(ord, o, 64); }
+    if (on && lane == 0) {
+      if (S.HMAX > 0) {
+        const int nh = S.nheavy[r];
+        for (int h = 0; h < nh; h++) {
+          const uint32_t e = S.heavy[(size_t)r * S.HMAX + h], cr = e >> 16, cc = ccnt[e & 1023u];
+          const uint32_t m = cr < cc ? cr : cc;
+          if (m > RANK_SAT) dot += m - RANK_SAT;
+        }
+      }
+      dot &= 0xFFFFu; ord &= 0xFFFFu;
+      const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || Lr == Lc);
+      out[pair] = (sp.band == 0 || (gl_ok && ord == dot)) ? CLS_GAPLESS : CLS_NW;
+    }
+    __syncthreads();
+  }
+}
+
+void launch_pair_class(const SampleDev &S, const int32_t *d_pc, const int32_t *d_pr, int n, const ScreenParams &sp,
+                       uint8_t *d_out, hipStream_t st) {
+  if (n <= 0) return;
+  int grid = std::min((n + 3) / 4, 1024);
+  hipLaunchKernelGGL(k_pair_class, dim3(grid), dim3(256), 0, st, S, d_pc, d_pr, n, sp, d_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gapless comparison: position-wise pairing (nwalign_gapless), substitutions where both bases
+// exist and differ (al2subs), lambda as the sequential fp64 product over raw positions
+// (compute_lambda_ts).  One thread per unique; the centre is wave-uniform.
+__global__ __launch_bounds__(256) void k_gapless(SampleDev S, int centre, const int32_t *__restrict__ chunk_centre,
+                                                 const int32_t *__restrict__ work, const int32_t *__restrict__ nwork_dev,
+                                                 int nwork_host, AlignParams ap, const double *__restrict__ err,
+                                                 double *__restrict__ lam, uint32_t *__restrict__ ham,
+                                                 uint16_t *__restrict__ view, int LV, int view_by_chunk) {
+  extern __shared__ double s_err[];
+  for (int i = threadIdx.x; i < 16 * ap.ncol; i += blockDim.x) s_err[i] = err[i];
+  __syncthreads();
+  const int nwork = nwork_dev ? *nwork_dev : nwork_host;
+  const int lane = threadIdx.x & 63, gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  for (int chunk = gwave; chunk * 64 < nwork; chunk += nwaves) {
+    const int idx = chunk * 64 + lane;
+    const int r = idx < nwork ? work[idx] : -1;
+    if (r < 0) continue;
+    const int c = chunk_centre ? chunk_centre[chunk] : centre;
+    const uint32_t *crow = S.seq2 + (size_t)c * S.W2, *rrow = S.seq2 + (size_t)r * S.W2;
+    const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
+    const int L1 = S.len[c], L2 = S.len[r];
+    const size_t vr = view_by_chunk ? (size_t)chunk : (size_t)r;
+    double l = 1.0;
+    uint32_t h = 0, cw = 0, rw = 0, qw = 0;
+    for (int p = 0; p < L2; p++) {
+      if ((p & 15) == 0) { rw = rrow[p >> 4]; cw = p < L1 ? crow[p >> 4] : 0; }
+      if ((p & 3) == 0) qw = *(const uint32_t *)(qrow + p);
+      const uint32_t rb = (rw >> ((p & 15) << 1)) & 3u, q = ap.use_quals ? ((qw >> ((p & 3) << 3)) & 255u) : 0u;
+      uint32_t t = 5u * rb;
+      if (p < L1) {
+        const uint32_t cb = (cw >> ((p & 15) << 1)) & 3u;
+        t = 4u * cb + rb;
+        h += (cb != rb);
+        if (view) view[vr * LV + p] = (uint16_t)(0x8000u | (rb << 8) | q);
+      }
+      l = l * s_err[t * ap.ncol + q];
+    }
+    if (view) for (int p = L2; p < L1; p++) view[vr * LV + p] = 0;   // centre positions opposite the end gap
+    lam[r] = l;
+    ham[r] = h;
+  }
+}
+
+void launch_gapless(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
+                    const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err,
+                    double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, hipStream_t st) {
+  int maxwork = d_nwork ? S.N : nwork_host;
+  if (maxwork <= 0) return;
+  int grid = std::min((maxwork + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_gapless, dim3(grid), dim3(256), (size_t)16 * ap.ncol * sizeof(double), st, S, centre,
+                     d_chunk_centre, d_work, d_nwork, nwork_host, ap, d_err, d_lambda, d_ham, d_view, LV, view_by_chunk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Banded ends-free Needleman-Wunsch, ONE ALIGNMENT PER LANE (64 per wave, the centre is
+// wave-uniform).  Band coordinates: cell (i, j) lives at k = j - i + lband, so in row i
+//   diag (i-1,j-1) = d[k] of the previous row, up (i-1,j) = d[k+1], left (i,j-1) = d[k-1] of this row;
+// the row is updated in place in registers (d[WMAX]).  Tie-break up > left > diag
+// (nwalign_endsfree.cpp:146-156).  First row/column are 0 (ends-free), moves along the last
+// row/column are free (:121-134), neighbours outside the band read `sentinel` (:113-119).
+// 2-bit traceback pointers go to an HBM scratch ring laid out [row][word][lane] so every store is a
+// coalesced 256 B; the traceback emits the transition code of every raw position (4 bits) and the
+// lambda product then runs forward over raw positions 0..len-1 exactly as pval.cpp:188-192 does.
+struct NwArgs {
+  SampleDev S;
+  int centre;
+  const int32_t *chunk_centre;
+  const int32_t *work;
+  const int32_t *nwork_dev;
+  int nwork_host;
+  AlignParams ap;
+  const double *err;
+  uint32_t *ptr_scr;
+  uint32_t *t_scr;
+  int32_t *row_scr;
+  size_t ptr_wpw, t_wpw, row_wpw;
+  double *lam;
+  uint32_t *ham;
+  uint16_t *view;
+  int LV;
+  int view_by_chunk;
+  uint8_t *moves;
+  int moves_stride;
+  int32_t *nmoves;
+};
+
+// shared tail: traceback + lambda.  NPW = pointer words per row.
+template <int NPW>
+static __device__ __forceinline__ void nw_traceback_lambda(const NwArgs &a, const double *s_err, int lane, int idx,
+                                                           bool active, int r, int c, int L1, int L2, int lband,
+                                                           const uint32_t *ptr, uint32_t *tsc, int npw_rt, int chunk) {
+  const SampleDev &S = a.S;
+  const size_t vr = a.view_by_chunk ? (size_t)chunk : (size_t)r;
+  const uint32_t *crow = S.seq2 + (size_t)c * S.W2, *rrow = S.seq2 + (size_t)r * S.W2;
+  const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
+  const int npw = NPW > 0 ? NPW : npw_rt;
+  int i = L1, j = L2, k = L2 - L1 + lband;
+  uint32_t h = 0, tw = 0;
+  int step = 0;
+  while (i > 0 || j > 0) {
+    uint32_t p;
+    if (i == 0) p = 2;
+    else if (j == 0) p = 3;
+    else p = (ptr[((size_t)i * npw + (k >> 4)) * 64 + lane] >> ((k & 15) << 1)) & 3u;
+    if (a.moves && active) a.moves[(size_t)idx * a.moves_stride + step] = (uint8_t)p;
+    step++;
+    if (p == 3) {
+      i--; k++;
+      if (a.view && active) a.view[vr * a.LV + i] = 0;
+    } else {
+      const int pj = j - 1;
+      const uint32_t rb = base_at(rrow, pj);
+      uint32_t t = 5u * rb;
+      if (p != 2) {
+        const uint32_t cb = base_at(crow, i - 1);
+        t = 4u * cb + rb;
+        h += (cb != rb);
+        i--;
+        if (a.view && active) a.view[vr * a.LV + i] = (uint16_t)(0x8000u | (rb << 8) | (a.ap.use_quals ? qrow[pj] : 0));
+      } else {
+        k--;
+      }
+      j--;
+      tw |= t << ((pj & 7) << 2);
+      if ((pj & 7) == 0) { tsc[(size_t)(pj >> 3) * 64 + lane] = tw; tw = 0; }
+    }
+  }
+  if (a.nmoves && active) a.nmoves[idx] = step;
+  // lambda: sequential fp64 product over raw positions (pval.cpp:188-192)
+  double l = 1.0;
+  uint32_t qw = 0;
+  for (int pj = 0; pj < L2; pj++) {
+    if ((pj & 7) == 0) tw = tsc[(size_t)(pj >> 3) * 64 + lane];
+    if ((pj & 3) == 0) qw = *(const uint32_t *)(qrow + pj);
+    const uint32_t t = (tw >> ((pj & 7) << 2)) & 15u, q = a.ap.use_quals ? ((qw >> ((pj & 3) << 3)) & 255u) : 0u;
+    l = l * s_err[t * a.ap.ncol + q];
+  }
+  if (active) { a.lam[r] = l; a.ham[r] = h; }
+}
+
+template <int WMAX>
+__global__ __launch_bounds__(256) void k_nw(NwArgs a) {
+  constexpr int NPW = (2 * WMAX + 31) / 32;   // pointer words per row
+  constexpr int NW32 = (WMAX + 15) / 16;      // raw-window words (2-bit codes)
+  extern __shared__ double s_err[];
+  for (int i = threadIdx.x; i < 16 * a.ap.ncol; i += blockDim.x) s_err[i] = a.err[i];
+  __syncthreads();
+  const SampleDev &S = a.S;
+  const int lane = threadIdx.x & 63, gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  uint32_t *ptr = a.ptr_scr + (size_t)gwave * a.ptr_wpw;
+  uint32_t *tsc = a.t_scr + (size_t)gwave * a.t_wpw;
+  const int nwork = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
+  const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
+  for (int chunk = gwave; chunk * 64 < nwork; chunk += nwaves) {
+    const int idx = chunk * 64 + lane;
+    const int c = __builtin_amdgcn_readfirstlane(a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
+    int r = idx < nwork ? a.work[idx] : -1;
+    const bool active = r >= 0;
+    if (!active) r = c;                       // idle lanes align the centre to itself, results dropped
+    const int L1 = __builtin_amdgcn_readfirstlane(S.len[c]);
+    const int L2 = S.len[r];
+    const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
+    const int W = lband + rband + 1;          // <= WMAX (host picks the kernel class)
+    const uint32_t *crow = S.seq2 + (size_t)c * S.W2, *rrow = S.seq2 + (size_t)r * S.W2;
+
+    int d[WMAX];
+    // row 0: D[0][j] = 0 for 0 <= j <= min(rband, L2)
+#pragma unroll
+    for (int k = 0; k < WMAX; k++) {
+      const int j = k - lband;
+      d[k] = (j >= 0 && j <= rband && j <= L2) ? 0 : SENT;
+    }
+    // raw window: code at k = base of raw position (0-based) i - lband + k - 1, for the row about to be computed
+    uint32_t win[NW32];
+#pragma unroll
+    for (int w = 0; w < NW32; w++) win[w] = 0;
+    for (int k = 0; k < WMAX; k++) {          // prologue for row i = 1
+      const int p = 1 - lband + k - 1;
+      const uint32_t code = (p >= 0 && p < L2) ? base_at(rrow, p) : 0u;
+      // shift the whole window right by one code and insert at the top
+#pragma unroll
+      for (int w = 0; w < NW32 - 1; w++) win[w] = (win[w] >> 2) | (win[w + 1] << 30);
+      win[NW32 - 1] = (win[NW32 - 1] >> 2) | (code << (((WMAX - 1) & 15) << 1));
+    }
+    int kzero = lband - 1;                    // k of column j == 0 in row i (row 1 here)
+    int kend = L2 - 1 + lband;                // k of column j == L2 in row i
+    uint32_t cw = 0;
+    for (int i = 1; i <= L1; i++) {
+      if (((i - 1) & 15) == 0) cw = crow[(i - 1) >> 4];   // wave-uniform -> scalar load
+      const uint32_t cb = (cw >> (((i - 1) & 15) << 1)) & 3u;
+      const uint32_t crep = cb * 0x55555555u;
+      uint32_t m[NW32];
+#pragma unroll
+      for (int w = 0; w < NW32; w++) {
+        const uint32_t x = win[w] ^ crep;
+        m[w] = ~(x | (x >> 1)) & 0x55555555u;             // bit 2k' set where raw base == centre base
+      }
+      const int gapL = (i == L1) ? 0 : GAP;               // free moves along the last row
+      const int khi = kend < W - 1 ? kend : W - 1;
+      uint32_t pw[NPW];
+#pragma unroll
+      for (int w = 0; w < NPW; w++) pw[w] = 0;
+      int leftv = SENT;
+#pragma unroll
+      for (int k = 0; k < WMAX; k++) {
+        const uint32_t mbit = (m[k >> 4] >> ((k & 15) << 1)) & 1u;
+        const int diag = d[k] + (mbit ? MATCH : MISMATCH);
+        const int upn = (k + 1 < WMAX) ? d[k + 1] : SENT;
+        const int up = upn + ((k == kend) ? 0 : GAP);       // free moves along the last column
+        const int left = leftv + gapL;
+        const bool t1 = left >= diag;
+        const int e1 = t1 ? left : diag;
+        const uint32_t p1 = t1 ? 2u : 1u;
+        const bool t2 = up >= e1;
+        const int e = t2 ? up : e1;
+        const uint32_t p = t2 ? 3u : p1;
+        const bool valid = (k > kzero) && (k <= khi);
+        const int v = valid ? e : ((k == kzero) ? 0 : SENT);
+        d[k] = v;
+        leftv = v;
+        pw[k >> 4] |= p << ((k & 15) << 1);
+      }
+#pragma unroll
+      for (int w = 0; w < NPW; w++) ptr[((size_t)i * NPW + w) * 64 + lane] = pw[w];
+      // advance the raw window to row i+1
+      {
+        const int p = (i + 1) - lband + (WMAX - 1) - 1;
+        const uint32_t code = (p >= 0 && p < L2) ? base_at(rrow, p) : 0u;
+#pragma unroll
+        for (int w = 0; w < NW32 - 1; w++) win[w] = (win[w] >> 2) | (win[w + 1] << 30);
+        win[NW32 - 1] = (win[NW32 - 1] >> 2) | (code << (((WMAX - 1) & 15) << 1));
+      }
+      kzero--;
+      kend--;
+    }
+    nw_traceback_lambda<NPW>(a, s_err, lane, idx, active, r, c, L1, L2, lband, ptr, tsc, NPW, chunk);
+  }
+}
+
+// Generic variant for any band (incl. unbanded, band < 0) and any length difference: same recurrence,
+// DP row kept in an HBM/L2 scratch row [k][lane] instead of registers.  Used only when the band
+// window does not fit the register classes (default nwalign() calls, exotic BAND_SIZE).
+__global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
+  extern __shared__ double s_err[];
+  for (int i = threadIdx.x; i < 16 * a.ap.ncol; i += blockDim.x) s_err[i] = a.err[i];
+  __syncthreads();
+  const SampleDev &S = a.S;
+  const int lane = threadIdx.x & 63, gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int npw = (2 * Wgen + 31) / 32;
+  uint32_t *ptr = a.ptr_scr + (size_t)gwave * a.ptr_wpw;
+  uint32_t *tsc = a.t_scr + (size_t)gwave * a.t_wpw;
+  int32_t *drow = a.row_scr + (size_t)gwave * a.row_wpw;
+  const int nwork = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
+  const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap;
+  for (int chunk = gwave; chunk * 64 < nwork; chunk += nwaves) {
+    const int idx = chunk * 64 + lane;
+    const int c = a.chunk_centre ? a.chunk_centre[chunk] : a.centre;
+    int r = idx < nwork ? a.work[idx] : -1;
+    const bool active = r >= 0;
+    if (!active) r = c;
+    const int L1 = S.len[c], L2 = S.len[r];
+    const int B = a.ap.band < 0 ? (L1 > L2 ? L1 : L2) : a.ap.band;   // band < 0: full matrix
+    const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
+    const int W = lband + rband + 1;
+    const uint32_t *crow = S.seq2 + (size_t)c * S.W2, *rrow = S.seq2 + (size_t)r * S.W2;
+    for (int k = 0; k < Wgen; k++) {
+      const int j = k - lband;
+      drow[(size_t)k * 64 + lane] = (j >= 0 && j <= rband && j <= L2) ? 0 : SENT;
+    }
+    for (int i = 1; i <= L1; i++) {
+      const uint32_t cb = base_at(crow, i - 1);
+      const int gapL = (i == L1) ? 0 : GAP;
+      const int kzero = lband - i, kend = L2 - i + lband;
+      const int khi = kend < W - 1 ? kend : W - 1;
+      int leftv = SENT;
+      uint32_t pwv = 0;
+      int dk = drow[lane];
+      for (int k = 0; k < Wgen; k++) {
+        const int upn = (k + 1 < Wgen) ? drow[(size_t)(k + 1) * 64 + lane] : SENT;
+        const int j = i - lband + k;
+        const bool valid = (k > kzero) && (k <= khi);
+        int v = (k == kzero) ? 0 : SENT;
+        uint32_t p = 0;
+        if (valid) {
+          const uint32_t rb = base_at(rrow, j - 1);
+          const int diag = dk + (rb == cb ? MATCH : MISMATCH);
+          const int up = upn + ((k == kend) ? 0 : GAP);
+          const int left = leftv + gapL;
+          const bool t1 = left >= diag;
+          const int e1 = t1 ? left : diag;
+          const bool t2 = up >= e1;
+          v = t2 ? up : e1;
+          p = t2 ? 3u : (t1 ? 2u : 1u);
+        }
+        drow[(size_t)k * 64 + lane] = v;
+        leftv = v;
+        dk = upn;
+        pwv |= p << ((k & 15) << 1);
+        if ((k & 15) == 15 || k == Wgen - 1) { ptr[((size_t)i * npw + (k >> 4)) * 64 + lane] = pwv; pwv = 0; }
+      }
+    }
+    nw_traceback_lambda<0>(a, s_err, lane, idx, active, r, c, L1, L2, lband, ptr, tsc, npw, chunk);
+  }
+}
+
+int nw_class(int band, int maxlen, int minlen) {
+  if (band < 0) return 0;
+  const int W = 2 * band + (maxlen - minlen) + 1;
+  if (W <= 33) return 33;
+  if (W <= 65) return 65;
+  if (W <= 129) return 129;
+  return 0;
+}
+
+size_t nw_ptr_words_per_wave(int wclass, int band, int maxlen, int minlen) {
+  int W = wclass;
+  if (wclass == 0) W = (band < 0) ? (2 * maxlen + 1) : (2 * band + (maxlen - minlen) + 1);
+  const int npw = (2 * W + 31) / 32;
+  return (size_t)(maxlen + 1) * npw * 64;
+}
+
+void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
+               const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err, const NwScratch &scr,
+               double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, uint8_t *d_moves,
+               int moves_stride, int32_t *d_nmoves, hipStream_t st) {
+  int maxwork = d_nwork ? S.N : nwork_host;
+  if (maxwork <= 0) return;
+  int waves = std::min((maxwork + 63) / 64, scr.nwaves);
+  int grid = (waves + 3) / 4;
+  if (grid * 4 > scr.nwaves) grid = scr.nwaves / 4;
+  if (grid < 1) grid = 1;
+  NwArgs a;
+  a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
+  a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.ptr_scr = scr.ptr; a.t_scr = scr.tcode; a.row_scr = scr.rows;
+  a.ptr_wpw = scr.ptr_words_per_wave; a.t_wpw = scr.t_words_per_wave; a.row_wpw = scr.row_words_per_wave;
+  a.lam = d_lambda; a.ham = d_ham; a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.moves = d_moves; a.moves_stride = moves_stride;
+  a.nmoves = d_nmoves;
+  size_t lds = (size_t)16 * ap.ncol * sizeof(double);
+  switch (wclass) {
+    case 33: hipLaunchKernelGGL(k_nw<33>, dim3(grid), dim3(256), lds, st, a); break;
+    case 65: hipLaunchKernelGGL(k_nw<65>, dim3(grid), dim3(256), lds, st, a); break;
+    case 129: hipLaunchKernelGGL(k_nw<129>, dim3(grid), dim3(256), lds, st, a); break;
+    default: {
+      int Wgen = (ap.band < 0) ? (2 * S.maxlen + 1) : (2 * ap.band + (S.maxlen - S.minlen) + 1);
+      hipLaunchKernelGGL(k_nw_gen, dim3(grid), dim3(256), lds, st, a, Wgen);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_calc_pA(int n, const int32_t *__restrict__ reads, const double *__restrict__ E,
+                          const uint8_t *__restrict__ prior, double *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = pp::calc_pA(reads[i], E[i], prior ? prior[i] != 0 : false);
+}
+
+void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint8_t *d_prior, double *d_out,
+                    hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_calc_pA, dim3((n + 127) / 128), dim3(128), 0, st, n, d_reads, d_E, d_prior, d_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output tables from the aligned views.  view[r][pos0] = 0x8000 | rawbase<<8 | q for centre positions
+// aligned to a raw base, 0 for centre positions opposite a gap.
+//   $subqual[t = 4*centre_base + raw_base][q] += reads    (error.cpp:152-167; int32 wrap-around as R's int)
+//   $clusterquals: sum(q*reads), sum(reads) per (cluster, pos0)  (error.cpp:241-252); integer sums are
+//   exact and order-independent, the host divides (the reference's fp64 sum of integers is exact < 2^53).
+//   nsubs[r] = substitutions of the final alignment (for n0/n1, error.cpp:58-61).
+__global__ __launch_bounds__(256) void k_final_tables(SampleDev S, const uint16_t *__restrict__ view, int LV,
+                                                      const int32_t *__restrict__ cluster_of,
+                                                      const int32_t *__restrict__ centre_of_cluster,
+                                                      const uint8_t *__restrict__ correct, int ncol, int has_quals,
+                                                      int32_t *__restrict__ trans, unsigned long long *__restrict__ qsum,
+                                                      uint32_t *__restrict__ qn, int32_t *__restrict__ nsubs) {
+  extern __shared__ uint32_t s_hist[];   // [16*ncol]
+  const int nb = 16 * ncol;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s_hist[i] = 0;
+  __syncthreads();
+  // one wave per unique, lanes stride over centre positions
+  const int lane = threadIdx.x & 63, gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  for (int r = gwave; r < S.N; r += nwaves) {
+    const int cl = cluster_of[r], c = centre_of_cluster[cl];
+    const int Lc = S.len[c];
+    const uint32_t *crow = S.seq2 + (size_t)c * S.W2;
+    const uint32_t reads = S.reads[r];
+    const bool corr = correct[r] != 0;
+    uint32_t ns = 0;
+    for (int p = lane; p < Lc; p += 64) {
+      const uint32_t v = view[(size_t)r * LV + p];
+      if (v & 0x8000u) {
+        const uint32_t rb = (v >> 8) & 3u, q = v & 255u, cb = base_at(crow, p);
+        ns += (cb != rb);
+        if (corr) {
+          atomicAdd(&s_hist[(has_quals ? q : 0u) * 16 + 4u * cb + rb], reads);
+          if (has_quals) {
+            atomicAdd(&qsum[(size_t)cl * S.maxlen + p], (unsigned long long)(q * reads));
+            atomicAdd(&qn[(size_t)cl * S.maxlen + p], reads);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ns += __shfl_xor(ns, o, 64);
+    if (lane == 0) nsubs[r] = (int32_t)ns;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += blockDim.x)
+    if (s_hist[i]) atomicAdd((uint32_t *)&trans[i], s_hist[i]);
+}
+
+void launch_final_tables(const SampleDev &S, const uint16_t *d_view, int LV, const int32_t *d_cluster_of,
+                         const int32_t *d_centre_of_cluster, const uint8_t *d_correct, int ncol, int has_quals,
+                         int32_t *d_trans, unsigned long long *d_qsum, uint32_t *d_qn, int32_t *d_nsubs, int nclust,
+                         hipStream_t st) {
+  (void)nclust;
+  int grid = std::min((S.N + 3) / 4, 2048);
+  hipLaunchKernelGGL(k_final_tables, dim3(grid), dim3(256), (size_t)16 * ncol * 4, st, S, d_view, LV, d_cluster_of,
+                     d_centre_of_cluster, d_correct, ncol, has_quals, d_trans, d_qsum, d_qn, d_nsubs);
+}
+
+}  // namespace d2

@@ -1,0 +1,172 @@
+/*
+ * dada2hip.h — C ABI of libdada2hip.so, the MI355X (gfx950) implementation of DADA2's
+ * divisive-denoising hot path.  This is the drop-in boundary: these entry points are what
+ * the reference's Rcpp glue for the path would bind (INTEGRATION.md shows the 40-line
+ * Rcpp translation unit that re-exports `_dada2_dada_uniques`, `_dada2_C_nwalign` and
+ * `_dada2_C_nwvec` on top of them, so R/dada.R and R/misc.R call the new path unchanged).
+ *
+ * Reference interfaces replaced (all paths relative to /root/reference):
+ *   dada2hip_dada_uniques   <- dada_uniques()      src/Rmain.cpp:30-295  (.Call `_dada2_dada_uniques`,
+ *                                                   src/RcppExports.cpp:18-53, R/RcppExports.R:8-10)
+ *   dada2hip_sample_* / _run<- the same call split so reads/qualities/k-mer tables stay resident in
+ *                              HBM across the selfConsist passes of R/dada.R:256-405 (only `err` changes)
+ *   dada2hip_nwalign        <- C_nwalign()         src/evaluate.cpp:18-62    (`_dada2_C_nwalign`, RcppExports.cpp:94)
+ *   dada2hip_nwvec          <- C_nwvec()           src/nwalign_vectorized.cpp:321-343 (`_dada2_C_nwvec`, :227)
+ *   dada2hip_result_*       <- the Rcpp::List of six objects built at src/Rmain.cpp:254-294 and src/error.cpp
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every call returns 0 on success or a
+ * non-zero code with a NUL-terminated message in `errbuf` (the reference's Rcpp::stop texts are
+ * kept where one exists).  Inputs are borrowed for the duration of the call only.  A result is
+ * owned by the library until dada2hip_result_free().  There is NO CPU fallback: every entry point
+ * that computes fails with DADA2HIP_ERR_DEVICE when no gfx950 device is usable.
+ */
+#ifndef DADA2HIP_H
+#define DADA2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DADA2HIP_OK            0
+#define DADA2HIP_ERR_INPUT     1   /* validation failure (messages of src/Rmain.cpp:52-78) */
+#define DADA2HIP_ERR_DEVICE    2   /* no usable GPU / HIP runtime error */
+#define DADA2HIP_ERR_RUNTIME   3   /* runtime error of the algorithm ("Lambda out-of-range error." ...) */
+#define DADA2HIP_ERR_UNSUPPORTED 4 /* option outside the implemented path (homopolymer gap penalty) */
+#define DADA2HIP_ERR_ABORTED   5   /* should_abort() returned non-zero (Rcpp::checkUserInterrupt analogue) */
+
+#define DADA2HIP_NA_INTEGER (-2147483647 - 1)   /* R's NA_integer_ */
+
+/* The 23 scalars dada_uniques takes positionally (src/Rmain.cpp:33-47); doubles first so the
+ * struct has no padding (112 bytes).  Defaults and normalisation: R/dada.R:1-27, :222-237. */
+typedef struct dada2hip_opts {
+  double kdist_cutoff, omegaA, omegaP, omegaC, min_fold;
+  int32_t match, mismatch, gap, homo_gap, band_size, max_clust, min_hamming, min_abund;
+  int32_t use_kmers, detect_singletons, use_quals, final_consensus, vectorized_alignment;
+  int32_t multithread, verbose, SSE, gapless, greedy;
+} dada2hip_opts;
+
+/* Optional host callbacks (replace Rprintf and Rcpp::checkUserInterrupt, src/Rmain.cpp:317-333). */
+typedef struct dada2hip_hooks {
+  void (*log)(const char *msg, void *user);
+  int (*should_abort)(void *user);   /* polled once per divisive round */
+  void *user;
+} dada2hip_hooks;
+
+typedef struct dada2hip_sample dada2hip_sample;   /* uniques of one sample, resident in HBM */
+typedef struct dada2hip_result dada2hip_result;
+
+/* Counters of one run (the reference's nalign/nshroud, src/dada.h:113-114, plus device timings). */
+typedef struct dada2hip_stats {
+  uint64_t ncompare;     /* raws offered to b_compare over all rounds (nraw x rounds)            */
+  uint64_t nskipped;     /* greedy skips: reads > centre reads, or locked (cluster.cpp:127-130)  */
+  uint64_t nshroud;      /* k-mer screened out (nwalign_endsfree.cpp:51-53)                      */
+  uint64_t ngapless;     /* gapless pairings (:54-55)                                            */
+  uint64_t nnw;          /* banded NW alignments incl. the final-subs pass (:57-64)              */
+  uint64_t nshuffle;     /* b_shuffle2 calls                                                     */
+  uint64_t nstored;      /* Comparisons kept (cluster.cpp:189-199)                               */
+  uint32_t rounds;       /* b_compare rounds = final number of partitions                        */
+  uint32_t reserved;
+  double ms_total, ms_upload, ms_screen, ms_nw, ms_gapless, ms_bookkeep, ms_pval, ms_final;
+  double nw_kernel_ms;   /* summed HIP-event time of the NW kernel launches                      */
+  uint64_t nw_kernel_launches;
+  uint64_t nw_cells;     /* DP cells those launches filled (algorithmic work)      */
+  double screen_kernel_ms;
+  uint64_t screen_kernel_launches;
+  uint64_t screen_bytes; /* algorithmic bytes the screen launches had to read                     */
+} dada2hip_stats;
+
+/* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------
+ * seqs       nraw NUL-terminated ACGT strings (abundance-sorted, R/sequenceIO.R:98)
+ * abundances nraw ints; priors nraw bytes (0/1) or NULL
+ * err        16 x err_ncol doubles, COLUMN-major (R NumericMatrix), rows A2A,A2C,..,T2T
+ * quals      quals_nrow x nraw doubles, column-major: positions are rows, uniques are columns
+ *            (src/Rmain.cpp:69,113); quals_nrow must equal the longest sequence.  Required: the
+ *            reference dereferences it unconditionally (src/error.cpp:158) and R always passes it.
+ * device     HIP device ordinal (the reference has no such notion; the R glue passes 0). */
+int dada2hip_dada_uniques(int32_t nraw, const char *const *seqs, const int32_t *abundances,
+                          const uint8_t *priors, const double *err, int32_t err_ncol, const double *quals,
+                          int32_t quals_nrow, const dada2hip_opts *opts, int32_t device,
+                          const dada2hip_hooks *hooks, dada2hip_result **out, char *errbuf, size_t errlen);
+
+/* ---- resident form --------------------------------------------------------------------------- */
+int dada2hip_sample_create(int32_t nraw, const char *const *seqs, const int32_t *abundances,
+                           const uint8_t *priors, const double *quals, int32_t quals_nrow, int32_t device,
+                           dada2hip_sample **out, char *errbuf, size_t errlen);
+int dada2hip_sample_set_priors(dada2hip_sample *s, const uint8_t *priors, char *errbuf, size_t errlen);
+int dada2hip_sample_run(dada2hip_sample *s, const double *err, int32_t err_ncol, const dada2hip_opts *opts,
+                        const dada2hip_hooks *hooks, dada2hip_result **out, char *errbuf, size_t errlen);
+void dada2hip_sample_free(dada2hip_sample *s);
+int32_t dada2hip_sample_nraw(const dada2hip_sample *s);
+int32_t dada2hip_sample_maxlen(const dada2hip_sample *s);
+
+/* ---- result access (library-owned arrays, valid until dada2hip_result_free) -------------------
+ * $clustering (src/error.cpp:121-126): one row per partition. */
+int32_t dada2hip_result_nclust(const dada2hip_result *r);
+int32_t dada2hip_result_nraw(const dada2hip_result *r);
+int32_t dada2hip_result_maxlen(const dada2hip_result *r);
+int32_t dada2hip_result_ncol(const dada2hip_result *r);          /* columns of $subqual */
+int32_t dada2hip_result_nbirth_subs(const dada2hip_result *r);
+const char *dada2hip_result_sequence(const dada2hip_result *r, int32_t i);
+const int32_t *dada2hip_result_abundance(const dada2hip_result *r);
+const int32_t *dada2hip_result_n0(const dada2hip_result *r);
+const int32_t *dada2hip_result_n1(const dada2hip_result *r);
+const int32_t *dada2hip_result_nunq(const dada2hip_result *r);
+const double *dada2hip_result_clust_pval(const dada2hip_result *r);
+const int32_t *dada2hip_result_birth_from(const dada2hip_result *r);   /* 1-based, NA for row 0 */
+const double *dada2hip_result_birth_pval(const dada2hip_result *r);
+const double *dada2hip_result_birth_fold(const dada2hip_result *r);
+const int32_t *dada2hip_result_birth_ham(const dada2hip_result *r);
+const double *dada2hip_result_birth_qave(const dada2hip_result *r);
+const int32_t *dada2hip_result_center(const dada2hip_result *r);       /* 0-based unique index of each centre (extra) */
+/* $birth_subs (src/error.cpp:299) */
+const int32_t *dada2hip_result_bs_pos(const dada2hip_result *r);       /* 1-based */
+const char *dada2hip_result_bs_ref(const dada2hip_result *r);          /* one char per row */
+const char *dada2hip_result_bs_sub(const dada2hip_result *r);
+const double *dada2hip_result_bs_qual(const dada2hip_result *r);
+const int32_t *dada2hip_result_bs_clust(const dada2hip_result *r);     /* 1-based */
+/* $subqual 16 x ncol int32 column-major; $clusterquals maxlen x nclust double column-major (NA past the
+ * centre's length); $map nraw int32 (1-based or NA); $pval nraw double. */
+const int32_t *dada2hip_result_subqual(const dada2hip_result *r);
+const double *dada2hip_result_clusterquals(const dada2hip_result *r);
+const int32_t *dada2hip_result_map(const dada2hip_result *r);
+const double *dada2hip_result_pval(const dada2hip_result *r);
+void dada2hip_result_stats(const dada2hip_result *r, dada2hip_stats *out);
+void dada2hip_result_free(dada2hip_result *r);
+
+/* ---- pairwise alignment exports ---------------------------------------------------------------
+ * dada2hip_nwalign == C_nwalign(s1, s2, match, mismatch, gap_p, homo_gap_p, band, endsfree)
+ * (src/evaluate.cpp:18): ACGT in, two gapped strings out (capacity >= len1+len2+1 each).
+ * dada2hip_nwvec == C_nwvec (src/nwalign_vectorized.cpp:321): n pairs at once; out[2*i], out[2*i+1]
+ * are caller buffers of capacity >= len1_i+len2_i+1.  Both run the device NW kernel.
+ * Only endsfree=1 with homo_gap_p == gap_p is on the denoising path and implemented. */
+int dada2hip_nwalign(const char *s1, const char *s2, int32_t match, int32_t mismatch, int32_t gap_p,
+                     int32_t homo_gap_p, int32_t band, int32_t endsfree, int32_t device, char *out0, char *out1,
+                     char *errbuf, size_t errlen);
+int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int32_t match, int32_t mismatch,
+                   int32_t gap_p, int32_t band, int32_t endsfree, int32_t device, char *const *out,
+                   char *errbuf, size_t errlen);
+
+/* One b_compare round exposed for kernel-level parity tests and for bench.py's roofline leg:
+ * compares every unique of `s` against unique `centre` exactly as CompareParallel does
+ * (src/cluster.cpp:90-149) with the given k-mer cutoff and greedy-skip mask (skip[i] != 0 => NULL
+ * sub); writes lambda[nraw], hamming[nraw] (0xFFFFFFFF for NULL subs) and cls[nraw]
+ * (0 skipped, 1 shrouded, 2 gapless, 3 NW). */
+int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *err, int32_t err_ncol,
+                            const dada2hip_opts *opts, double kdist_cutoff, const uint8_t *skip,
+                            double *lambda, uint32_t *hamming, uint8_t *cls, dada2hip_stats *stats,
+                            char *errbuf, size_t errlen);
+
+/* Poisson tail used for the abundance p-value: calc_pA (src/pval.cpp:44-64) evaluated by the
+ * device kernel for n (reads, E) pairs — for parity tests against the oracle. */
+int dada2hip_calc_pA(int32_t n, const int32_t *reads, const double *E_reads, const uint8_t *prior, int32_t device,
+                     double *out, char *errbuf, size_t errlen);
+
+const char *dada2hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DADA2HIP_H */

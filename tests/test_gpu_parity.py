@@ -1,0 +1,135 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+(a) the committed goldens the reference itself produced and (b) the oracle on seeded inputs.
+Bar (BASELINE.json north_star): bit-exact sequences / indices / partition membership / counts,
+p-values within 1e-10 relative."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, WHOLE_PATH_CASES, P_RTOL, assert_results_equal, case_inputs, load_input, tperr1
+from dada2_amd.io import extend_err
+from dada2_amd.opts import DadaOpts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dada2_amd import api as a
+    return a
+
+
+@pytest.mark.parametrize("name", WHOLE_PATH_CASES)
+def test_whole_path_matches_reference_goldens(api, oracle_c, name):
+    d, err, pri, opts, exp, meta = case_inputs(name)
+    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, opts)
+    assert got.nclust == meta["nclust"]
+    assert_results_equal(got, exp, p_rtol=P_RTOL, check_birth_from="priors" not in meta)
+    want = oracle_c.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, opts)
+    assert_results_equal(got, want, p_rtol=P_RTOL, check_birth_from="priors" not in meta)
+
+
+@pytest.mark.parametrize("fq,band", [("sam1F", 16), ("samPB", 32)])
+def test_compare_round_matches_reference(api, fq, band):
+    """lambda / hamming / class of one b_compare round against the reference's sub_new + compute_lambda_ts."""
+    d = load_input(fq)
+    err = extend_err(tperr1(), int(np.ceil(np.nanmax(d.quals))))
+    rows = np.load(os.path.join(GOLDEN, f"compare_{fq}.npy"))
+    o = DadaOpts(BAND_SIZE=band)
+    smp = api.Sample.from_derep(d)
+    try:
+        for c in sorted(set(rows[:, 0].astype(int))):
+            lam, ham, cls, st = smp.compare(c, err, o, kdist_cutoff=0.42)
+            sel = rows[rows[:, 0] == c]
+            r = sel[:, 1].astype(int)
+            assert np.array_equal(lam[r], sel[:, 2]), "lambda bits differ"
+            want_ham = np.where(sel[:, 3] < 0, 0xFFFFFFFF, sel[:, 3]).astype(np.uint32)
+            assert np.array_equal(ham[r], want_ham)
+            shrouded = sel[:, 3] < 0
+            assert np.array_equal(cls[r] == 1, shrouded)
+            gapless = (~shrouded) & (sel[:, 4] == sel[:, 5])
+            assert np.array_equal(cls[r] == 2, gapless)
+    finally:
+        smp.close()
+
+
+def test_nwvec_matches_reference_alignments(api):
+    z = np.load(os.path.join(GOLDEN, "nwalign_pairs.npz"))
+    s1, s2, band = [str(x) for x in z["s1"]], [str(x) for x in z["s2"]], z["band"]
+    for b in sorted(set(band.tolist())):
+        idx = np.nonzero(band == b)[0]
+        got = api.nwvec([s1[i] for i in idx], [s2[i] for i in idx], 5, -4, -8, int(b))
+        for k, i in enumerate(idx):
+            assert got[k] == (str(z["al0"][i]), str(z["al1"][i])), (i, b)
+    assert api.nwalign(s1[0], s2[0], band=16) == (str(z["al0"][0]), str(z["al1"][0]))
+
+
+def _sample(seed, n, L=120, G=8, Lmin=None, indel=0.0):
+    from dada2_amd.synth import make_sample
+    return make_sample(tperr1(), n, L=L, G=G, seed=seed, Lmin=Lmin, indel_rate=indel, chunk=4000)
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (1, {}), (2, dict(BAND_SIZE=4)), (3, dict(GREEDY=False, GAPLESS=False)), (4, dict(USE_KMERS=False)),
+    (5, dict(MIN_FOLD=2, MIN_HAMMING=2, MIN_ABUNDANCE=2)), (6, dict(OMEGA_A=1e-4, OMEGA_C=1e-2)),
+    (7, dict(SSE=0)), (8, dict(VECTORIZED_ALIGNMENT=False, KDIST_CUTOFF=0.3)), (9, dict(MAX_CLUST=3)),
+    (10, dict(BAND_SIZE=0)), (11, dict(BAND_SIZE=-1)), (12, dict(BAND_SIZE=40)),
+])
+def test_seeded_samples_match_oracle(api, oracle_c, seed, kw):
+    ragged = seed % 2 == 0
+    d = _sample(seed, 800, Lmin=100 if ragged else None, indel=2e-3 if ragged else 0.0)
+    o = DadaOpts(**kw)
+    pri = (np.arange(d.nraw) % 17 == 3).astype(np.uint8) if seed == 6 else None
+    got = api.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)
+    want = oracle_c.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)
+    assert_results_equal(got, want, p_rtol=P_RTOL, check_birth_from=pri is None)
+
+
+def test_resident_sample_reuse_and_selfconsist(api, oracle_c):
+    """selfConsist loop (R/dada.R:256-405): the resident sample is reused across passes with only err
+    changing; every pass must equal the oracle run with the same err."""
+    d = _sample(31, 1500, L=150, G=16)
+    res, err_out, errs = api.dada(d, None, self_consist=True, opts=DadaOpts(OMEGA_C=0, MAX_CONSIST=4))
+    assert len(errs) >= 2
+    want = oracle_c.dada_uniques(d.seqs, d.abundances, None, errs[-1], d.quals, DadaOpts(OMEGA_C=0))
+    assert_results_equal(res, want, p_rtol=P_RTOL)
+
+
+def test_device_pvalue_kernel(api, oracle_c):
+    rows = np.load(os.path.join(GOLDEN, "ppois_grid.npy"))
+    reads = rows[:, 0].astype(np.int32) + 1
+    for prior, col in ((0, 4), (1, 5)):
+        got = api.calc_pA_device(reads, rows[:, 1], np.full(reads.size, prior, dtype=np.uint8))
+        want = rows[:, col]
+        ok = np.isfinite(want) & (want > 1e-300)
+        rel = np.abs(got[ok] - want[ok]) / want[ok]
+        assert rel.max() < P_RTOL, rel.max()
+        assert (got[want == 0] == 0).all()
+
+
+def test_size_independent_properties_at_scale(api):
+    """Config-2-like size (bench workload scaled down): properties that hold for any correct run."""
+    d = _sample(77, 20000, L=250, G=64)
+    r = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())
+    C = r.nclust
+    m = r.map
+    assert ((m >= 1) & (m <= C) | (m == -2 ** 31)).all()
+    # abundance of each partition = reads of the corrected uniques mapped to it; nunq likewise
+    ok = m > 0
+    assert np.array_equal(np.bincount(m[ok] - 1, weights=d.abundances[ok], minlength=C).astype(np.int64), r.clustering["abundance"].astype(np.int64))
+    assert np.array_equal(np.bincount(m[ok] - 1, minlength=C), r.clustering["nunq"])
+    # every centre maps to its own partition, has p = 1, and its sequence is the partition's sequence
+    cen = r.stats["center"]
+    assert np.array_equal(m[cen], np.arange(1, C + 1)) and (r.pval[cen] == 1.0).all()
+    assert [d.seqs[c] for c in cen] == r.clustering["sequence"]
+    # the transition matrix counts every aligned base of every corrected read once: column sums by row
+    # group equal reads x aligned positions; total = sum over corrected uniques of reads * aligned length
+    assert r.subqual.sum() > 0 and (r.subqual >= 0).all()
+    # births are in decreasing significance only per parent; all birth p-values below OMEGA_A
+    assert (r.clustering["birth_pval"][1:] < 1e-40).all()
+    # idempotence: a second run on the same resident inputs gives identical output
+    r2 = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())
+    assert_results_equal(r, r2, exact_float=True)
