@@ -1,0 +1,89 @@
+"""Sample-level sharding of a multi-sample dada()/learnErrors run over the GPUs of one node.
+
+The path shards naturally at sample granularity: each ``dada_uniques`` call
+depends only on its own sample and the shared error matrix (R/dada.R:266-366).  One process per
+GPU (``torch.distributed``, backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests); rank r owns
+samples r, r+W, r+2W, ... resident on its own GPU for the whole selfConsist loop.  The only
+cross-rank exchange is ``accumulateTrans`` (R/errorModels.R:462-471): one all-reduce(sum) of the
+16 x Q int64 transition-count matrix per pass (<= 12 KB, latency-bound; xGMI bandwidth is
+irrelevant at this size).  Every rank then refits ``err`` from the identical reduced counts, so no
+broadcast is needed and all ranks take the same termination decision.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .io import extend_err
+from .opts import DadaOpts
+
+
+def shard(n_samples: int, rank: int, world: int):
+    """Indices of the samples rank ``rank`` owns (round-robin)."""
+    return list(range(rank, n_samples, world))
+
+
+def allreduce_trans(local_trans: np.ndarray, maxcol: int, dist=None, device=None) -> np.ndarray:
+    """Sum of the per-rank 16 x Q transition matrices (accumulateTrans across ranks)."""
+    buf = np.zeros((16, maxcol), dtype=np.int64)
+    buf[:, : local_trans.shape[1]] += local_trans
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return buf
+    import torch
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts = None, make_runner=None, dist=None,
+               device=None, max_col: int = None):
+    """dada() over many samples, sharded across the ranks of ``dist``.
+
+    ``dereps``       all samples (every rank sees the list; only its shard is touched)
+    ``make_runner``  derep -> object with .run(err, opts, max_clust=...) -> DadaResult and .close();
+                     default = GPU-resident dada2_amd.api.Sample on this rank's device
+    Returns (dict sample_index -> DadaResult for the local shard, err_out, list of err tried).
+    Mirrors the loop of R/dada.R:256-405 (see dada2_amd.api.dada for the single-process form)."""
+    from .api import accumulate_trans, noqual_errfun
+    o = (opts or DadaOpts()).normalised()
+    err_fun = err_fun or noqual_errfun
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    mine = shard(len(dereps), rank, world)
+    if make_runner is None:
+        from .api import Sample
+        dev_index = device.index if device is not None and getattr(device, "index", None) is not None else 0
+        make_runner = lambda d: Sample.from_derep(d, device=dev_index)   # noqa: E731
+    runners = {i: make_runner(dereps[i]) for i in mine}
+    qmax_all = max(int(np.ceil(np.nanmax(d.quals))) for d in dereps)
+    maxcol = max_col or max(41, qmax_all + 1, 0 if err is None else np.asarray(err).shape[1])
+    initialize = self_consist and err is None
+    nconsist = 0 if initialize else 1
+    errs, results = [], {}
+    try:
+        while True:
+            if nconsist > 0:
+                errs.append(np.array(err, copy=True))
+            local = np.zeros((16, maxcol), dtype=np.int64)
+            for i in mine:
+                d = dereps[i]
+                qmax = int(np.ceil(np.nanmax(d.quals)))
+                erri = np.ones((16, max(41, qmax + 1))) if initialize else extend_err(err, qmax)
+                results[i] = runners[i].run(erri, o, max_clust=1 if initialize else None)
+                t = results[i].subqual
+                local[:, : t.shape[1]] += t
+            cur = allreduce_trans(local, maxcol, dist, device)
+            new_err = err_fun(cur)
+            if initialize:
+                initialize = False
+                new_err[[0, 5, 10, 15], :] = 1.0
+            err = new_err
+            if (not self_consist) or any(np.array_equal(e, err) for e in errs) or nconsist >= o.MAX_CONSIST:
+                break
+            nconsist += 1
+    finally:
+        for r in runners.values():
+            if hasattr(r, "close"):
+                r.close()
+    return results, err, errs

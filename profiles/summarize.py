@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 (rocpd sqlite) outputs into profiles/<tag>_summary.md + <tag>_kernel_stats.csv.
+usage: summarize.py <dir with trace/ pmc_fetch/ pmc_write/ pmc_valu/> <tag>"""
+import csv, glob, os, sqlite3, sys
+
+out, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.abspath(__file__))
+L = [f"# rocprofv3 summary `{tag}`", "",
+     "Command profiled: `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` (3 full dada_uniques passes over the",
+     "100k-unique config-2 sample; one rocprofv3 run per section, PMC passes separate from the trace).", ""]
+
+
+def short(n):
+    n = n.replace("d2::", "")
+    return n.split("(")[0][:60]
+
+
+dbs = glob.glob(os.path.join(out, "trace", "*.db"))
+if dbs:
+    db = sqlite3.connect(dbs[0])
+    rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+    with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
+        w.writerows(rows)
+    L += ["## Kernel stats (`rocprofv3 --kernel-trace --stats`)", "", "| kernel | calls | total ms | avg us | % of GPU time |", "|---|---|---|---|---|"]
+    for n, c, tot, avg, pct in rows:
+        L.append(f"| `{short(n)}` | {c} | {tot / 1e3:.3f} | {avg:.2f} | {pct:.2f} |")
+    L.append("")
+    res = list(db.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
+                          "max(workgroup_x), avg(grid_x) from kernels where name like 'd2::%' or name like 'void d2::%' group by name"))
+    L += ["## Dispatch resources", "", "| kernel | VGPR | AGPR | SGPR | LDS B | scratch B | wg | avg grid threads |", "|---|---|---|---|---|---|---|---|"]
+    for r in res:
+        L.append(f"| `{short(r[0])}` | {r[1]} | {r[2]} | {r[3]} | {r[4]} | {r[5]} | {r[6]} | {r[7]:.0f} |")
+    L.append("")
+for sub, title in (("pmc_fetch", "FETCH_SIZE (KB; gfx950: x2 for wide coalesced reads, MI355X_MICROARCH.md §HBM)"),
+                   ("pmc_write", "WRITE_SIZE (KB)"), ("pmc_valu", "SQ / GRBM counters")):
+    dbs = glob.glob(os.path.join(out, sub, "*.db"))
+    if not dbs:
+        continue
+    db = sqlite3.connect(dbs[0])
+    rows = list(db.execute("select kernel_name, counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
+                           "where kernel_name like 'd2::%' or kernel_name like 'void d2::%' group by kernel_name, counter_name"))
+    L += [f"## PMC pass: {title}", "", "| kernel | counter | dispatches | sum | avg / dispatch | avg dispatch ns |", "|---|---|---|---|---|---|"]
+    for k, c, n, s, a, d in rows:
+        L.append(f"| `{short(k)}` | {c} | {n} | {s:.6g} | {a:.6g} | {d:.0f} |")
+    L.append("")
+open(os.path.join(root, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
+print("\n".join(L))
