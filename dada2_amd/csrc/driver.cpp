@@ -381,8 +381,11 @@ struct Run {
     auto t1 = clk::now();
     if (n_nw > 0) {
       D2_HIP(hipEventRecord(s->ev0, stq));
-      launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, ap, s->d_err.p, s->scr, s->d_lambda.p,
-                s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
+      if (use_coop(n_nw))
+        launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, stq);
+      else
+        launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, ap, s->d_err.p, s->scr, s->d_lambda.p,
+                  s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
       D2_HIP(hipEventRecord(s->ev1, stq));
     }
     D2_HIP(hipMemcpyAsync(s->h_lambda.p, s->d_lambda.p, (size_t)N * 8, hipMemcpyDeviceToHost, stq));
@@ -396,6 +399,18 @@ struct Run {
       st.nw_cells += (uint64_t)n_nw * nw_cells_per_alignment();
     }
     st.ms_nw += ms_since(t1);
+  }
+
+  // Kernel choice for a round's NW batch: the cooperative anti-diagonal kernel (k_nw_ad, low latency)
+  // for batches that cannot fill the chip one-alignment-per-lane, the lane-per-alignment kernel (k_nw,
+  // ~3x fewer instructions per alignment) for very large ones.  DADA2HIP_NW_KERNEL=lane|coop forces one.
+  bool use_coop(int n_nw) const {
+    const size_t lds = nw_ad_lds_bytes(s->D, ap);
+    if (lds == 0 || lds > 150 * 1024) return false;
+    const char *f = getenv("DADA2HIP_NW_KERNEL");
+    if (f && !strcmp(f, "lane")) return false;
+    if (f && !strcmp(f, "coop")) return true;
+    return n_nw < 262144;
   }
 
   uint64_t nw_cells_per_alignment() const {

@@ -10,6 +10,8 @@
 //                                                                        nwalign_vectorized.cpp:71-318, nwalign_endsfree.cpp:76-216
 //   k_calc_pA       calc_pA                                              pval.cpp:44-64
 //   k_final_*       b_make_transition_by_quality_matrix / b_make_cluster_quality_matrix   error.cpp:131-172, :225-258
+#include <cstring>
+
 #include "engine.h"
 #include "ppois.h"
 
@@ -564,6 +566,208 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
     }
     nw_traceback_lambda<0>(a, s_err, lane, idx, active, r, c, L1, L2, lband, ptr, tsc, npw, chunk);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Low-latency variant for the per-round batches (a few thousand alignments): the same recurrence
+// swept by ANTI-DIAGONALS with GL lanes per alignment (64/GL alignments per wave).  Lane g owns
+// band cells k = 2g, 2g+1; on anti-diagonal t = i + j the cells with k = t + lband (mod 2) are
+// live, so every lane updates exactly one cell per step: diag = its own cell two steps ago, left /
+// up = the neighbouring cells one step ago — one of them its own other cell, the other fetched
+// from the neighbour lane with a DPP wave shift.  Pointers (2 bits per lane per step) stay in LDS.
+// The traceback (one lane per alignment) skips whole diagonal runs per LDS word and emits run
+// descriptors; all lanes then turn runs into per-position error-model factors in LDS, and one lane
+// multiplies them in raw-position order (pval.cpp:188-192) — bit-identical to k_nw.
+template <int GL>
+__global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, int W2, int nwords, int runcap) {
+  constexpr int APW = 64 / GL;
+  extern __shared__ double s_dyn[];
+  double *s_err = s_dyn;
+  const int nerr = 16 * a.ap.ncol;
+  for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
+  const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t per_wave_words = (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * W2;
+  uint32_t *wbase = (uint32_t *)(s_dyn + nerr) + (size_t)wib * per_wave_words;
+  uint32_t *ptr = wbase;                                   // [nwords][64]
+  const int al = lane / GL, g = lane % GL;                 // alignment slot in the wave, lane in the group
+  uint32_t *runs = wbase + (size_t)nwords * 64 + (size_t)al * runcap;
+  uint32_t *cseq = wbase + (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)al * 2 * W2;
+  uint32_t *rseq = cseq + W2;
+  double *fac = (double *)ptr + (size_t)al * (nwords * 32 / APW);   // factors reuse the pointer area
+  __syncthreads();
+  const SampleDev &S = a.S;
+  const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
+  const int nwork = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
+  const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
+  for (int chunk = gwave; chunk * APW < nwork; chunk += nwaves) {
+    const int idx = chunk * APW + al;
+    const int c = a.chunk_centre ? a.chunk_centre[chunk] : a.centre;
+    int r = idx < nwork ? a.work[idx] : -1;
+    const bool active = r >= 0;
+    if (!active) r = c;
+    const int L1 = S.len[c], L2 = S.len[r];
+    const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
+    const int W = lband + rband + 1;                       // <= 2*GL
+    const int T = L1 + L2;
+    // stage both sequences (2-bit words) in LDS
+    for (int w = g; w < W2; w += GL) {
+      cseq[w] = S.seq2[(size_t)c * S.W2 + w];
+      rseq[w] = S.seq2[(size_t)r * S.W2 + w];
+    }
+    int Tmax = T;
+#pragma unroll
+    for (int o = GL; o < 64; o <<= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
+    int d0 = SENT, d1 = SENT;
+    uint32_t pw = 0;
+    const int wlast = (W2 > 0 ? W2 : 1) - 1;
+    // words for step 0
+    int par = lband & 1, k = 2 * g + par;
+    int i = (0 - k + lband) >> 1, j = 0 - i;
+    uint32_t cw = cseq[min(max((i - 1) >> 4, 0), wlast)], rw = rseq[min(max((j - 1) >> 4, 0), wlast)];
+    for (int t = 0; t <= Tmax; t++) {
+      // prefetch the words of step t+1
+      const int parn = par ^ 1, kn = 2 * g + parn;
+      const int in = (t + 1 - kn + lband) >> 1, jn = t + 1 - in;
+      const uint32_t cwn = cseq[min(max((in - 1) >> 4, 0), wlast)], rwn = rseq[min(max((jn - 1) >> 4, 0), wlast)];
+      const int lft_in = __builtin_amdgcn_update_dpp(SENT, d1, 0x138, 0xF, 0xF, false);   // lane-1's d1 (wave_shr:1)
+      const int upn_in = __builtin_amdgcn_update_dpp(SENT, d0, 0x130, 0xF, 0xF, false);   // lane+1's d0 (wave_shl:1)
+      const int own = par ? d1 : d0;
+      const int left_src = par ? d0 : (g == 0 ? SENT : lft_in);
+      const int up_src = par ? (g == GL - 1 ? SENT : upn_in) : d1;
+      const uint32_t cb = (cw >> (((i - 1) & 15) << 1)) & 3u, rb = (rw >> (((j - 1) & 15) << 1)) & 3u;
+      const int diag = own + (cb == rb ? MATCH : MISMATCH);
+      const int up = up_src + (j == L2 ? 0 : GAP);
+      const int left = left_src + (i == L1 ? 0 : GAP);
+      const bool t1 = left >= diag;
+      const int e1 = t1 ? left : diag;
+      const bool t2 = up >= e1;
+      const int e = t2 ? up : e1;
+      uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
+      const bool inmat = (i >= 0) && (j >= 0) && (i <= L1) && (j <= L2) && (k < W);
+      const bool interior = inmat && (i >= 1) && (j >= 1);
+      const int val = interior ? e : (inmat ? 0 : SENT);
+      if (!interior) p = (i == 0) ? 2u : 3u;                 // first row: left, first column: up (:88-98)
+      if (par) d1 = val; else d0 = val;
+      pw |= p << ((t & 15) << 1);
+      if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
+      par = parn; k = kn; i = in; j = jn; cw = cwn; rw = rwn;
+    }
+    if ((Tmax & 15) != 15) ptr[(size_t)(Tmax >> 4) * 64 + lane] = pw;
+    // ---- traceback by the first lane of each group: run descriptors ---------------------------------
+    // descriptor: pj_lo (12 bits) | n (12 bits) << 12 | (delta + 128) << 24, delta = pi - pj; 255 << 24 = gap in centre
+    int nruns = 0;
+    if (g == 0) {
+      int ti = L1, tj = L2;
+      while (ti > 0 || tj > 0) {
+        const int t = ti + tj, kk = tj - ti + lband;
+        const int col = al * GL + (kk >> 1);
+        const int f = t & 15;
+        const uint32_t word = ptr[(size_t)(t >> 4) * 64 + col];
+        // fields of this cell's parity at positions <= f that are NOT diagonal (01)
+        const uint32_t x = word ^ 0x55555555u;
+        uint32_t nz = (x | (x >> 1)) & 0x55555555u;
+        nz &= (f & 1) ? 0x44444444u : 0x11111111u;
+        nz &= (f == 15) ? 0xFFFFFFFFu : ((1u << ((f + 1) << 1)) - 1u);
+        int n;                                               // diagonal moves available inside this word
+        bool stop;
+        if (nz) { const int fb = (31 - __clz(nz)) >> 1; n = (f - fb) >> 1; stop = true; }
+        else { n = (f >> 1) + 1; stop = false; }
+        if (n > 0) {
+          // (cells on the first row/column carry pointers 2/3, so a run never crosses them)
+          runs[nruns++] = (uint32_t)(tj - n) | ((uint32_t)n << 12) | ((uint32_t)(ti - tj + 128) << 24);
+          ti -= n; tj -= n;
+        }
+        if (stop && (ti > 0 || tj > 0)) {   // (0,0) carries an axis pointer too: the path ends there
+          const int t2s = ti + tj;
+          const uint32_t w2 = (t2s >> 4) == (t >> 4) ? word : ptr[(size_t)(t2s >> 4) * 64 + col];
+          const uint32_t p = (w2 >> ((t2s & 15) << 1)) & 3u;
+          if (p == 2u) { tj--; runs[nruns++] = (uint32_t)tj | (1u << 12) | (255u << 24); }
+          else ti--;                                         // p == 3 (p == 1 cannot be here)
+        }
+      }
+    }
+    nruns = __shfl(nruns, al * GL, 64);
+    int nrmax = nruns;
+#pragma unroll
+    for (int o = GL; o < 64; o <<= 1) nrmax = max(nrmax, __shfl_xor(nrmax, o, 64));
+    // ---- factors e[pj] = err[t(pj)][q(pj)] and hamming, all lanes -----------------------------------
+    const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
+    uint32_t h = 0;
+    for (int ri = 0; ri < nrmax; ri++) {
+      if (ri < nruns) {
+        const uint32_t dsc = runs[ri];
+        const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
+        for (int pj = lo + g; pj < lo + n; pj += GL) {
+          const uint32_t rb = (rseq[pj >> 4] >> ((pj & 15) << 1)) & 3u;
+          uint32_t tc = 5u * rb;
+          if (dl != 255) {
+            const int pi = pj + dl - 128;
+            const uint32_t cb = (cseq[pi >> 4] >> ((pi & 15) << 1)) & 3u;
+            tc = 4u * cb + rb;
+            h += (cb != rb);
+          }
+          const uint32_t q = a.ap.use_quals ? qrow[pj] : 0u;
+          fac[pj] = s_err[tc * a.ap.ncol + q];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < GL; o <<= 1) h += __shfl_xor(h, o, 64);
+    // ---- lambda: sequential product in raw-position order, one lane per alignment --------------------
+    if (g == 0) {
+      double l = 1.0;
+      int pj = 0;
+      for (; pj + 4 <= L2; pj += 4) {
+        const double f0 = fac[pj], f1 = fac[pj + 1], f2 = fac[pj + 2], f3 = fac[pj + 3];
+        l = l * f0; l = l * f1; l = l * f2; l = l * f3;
+      }
+      for (; pj < L2; pj++) l = l * fac[pj];
+      if (active) { a.lam[r] = l; a.ham[r] = h; }
+    }
+  }
+}
+
+void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
+                  const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err, double *d_lambda,
+                  uint32_t *d_ham, hipStream_t st) {
+  int maxwork = d_nwork ? S.N : nwork_host;
+  if (maxwork <= 0) return;
+  NwArgs a;
+  memset(&a, 0, sizeof a);
+  a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
+  a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
+  const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
+  const int GL = W <= 64 ? 32 : 64, APW = 64 / GL;
+  const int nsteps = 2 * S.maxlen + 1;
+  int nwords = (nsteps + 15) / 16;
+  // the factor area (maxlen doubles per alignment) aliases the pointer area
+  while ((size_t)nwords * 32 / APW < (size_t)S.maxlen) nwords++;
+  const int runcap = nsteps + 1;
+  const int W2 = S.W2;
+  size_t per_wave = ((size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * W2) * 4;
+  size_t lds = (size_t)16 * ap.ncol * 8 + 4 * per_wave;
+  int waves = (maxwork + APW - 1) / APW;
+  int grid = std::min((waves + 3) / 4, 256 * 8);
+  if (GL == 32) {
+    (void)hipFuncSetAttribute((const void *)k_nw_ad<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_nw_ad<32>, dim3(grid), dim3(256), lds, st, a, W2, nwords, runcap);
+  } else {
+    (void)hipFuncSetAttribute((const void *)k_nw_ad<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_nw_ad<64>, dim3(grid), dim3(256), lds, st, a, W2, nwords, runcap);
+  }
+}
+
+// LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
+size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
+  if (ap.band <= 0 || S.maxlen > 2047) return 0;
+  const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
+  if (W > 128) return 0;
+  const int GL = W <= 64 ? 32 : 64, APW = 64 / GL;
+  const int nsteps = 2 * S.maxlen + 1;
+  int nwords = (nsteps + 15) / 16;
+  while ((size_t)nwords * 32 / APW < (size_t)S.maxlen) nwords++;
+  size_t per_wave = ((size_t)nwords * 64 + (size_t)APW * (nsteps + 1) + (size_t)APW * 2 * S.W2) * 4;
+  return (size_t)16 * ap.ncol * 8 + 4 * per_wave;
 }
 
 int nw_class(int band, int maxlen, int minlen) {

@@ -22,8 +22,12 @@ def api():
     return a
 
 
+@pytest.mark.parametrize("nw_kernel", ["coop", "lane"])
 @pytest.mark.parametrize("name", WHOLE_PATH_CASES)
-def test_whole_path_matches_reference_goldens(api, oracle_c, name):
+def test_whole_path_matches_reference_goldens(api, oracle_c, name, nw_kernel, monkeypatch):
+    """Both NW kernels (cooperative anti-diagonal k_nw_ad / lane-per-alignment k_nw) must give the
+    reference's answer; DADA2HIP_NW_KERNEL forces the choice the driver otherwise makes by batch size."""
+    monkeypatch.setenv("DADA2HIP_NW_KERNEL", nw_kernel)
     d, err, pri, opts, exp, meta = case_inputs(name)
     got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, opts)
     assert got.nclust == meta["nclust"]
@@ -78,7 +82,8 @@ def _sample(seed, n, L=120, G=8, Lmin=None, indel=0.0):
     (7, dict(SSE=0)), (8, dict(VECTORIZED_ALIGNMENT=False, KDIST_CUTOFF=0.3)), (9, dict(MAX_CLUST=3)),
     (10, dict(BAND_SIZE=0)), (11, dict(BAND_SIZE=-1)), (12, dict(BAND_SIZE=40)),
 ])
-def test_seeded_samples_match_oracle(api, oracle_c, seed, kw):
+def test_seeded_samples_match_oracle(api, oracle_c, seed, kw, monkeypatch):
+    monkeypatch.setenv("DADA2HIP_NW_KERNEL", "coop" if seed % 3 else "lane")
     ragged = seed % 2 == 0
     d = _sample(seed, 800, Lmin=100 if ragged else None, indel=2e-3 if ragged else 0.0)
     o = DadaOpts(**kw)
