@@ -287,17 +287,18 @@ std::vector<int32_t> make_thresh(int maxlen, double cutoff) {
 
 struct Comp { uint32_t i, index; double lambda; uint32_t hamming; };   // dada.h:42-47
 
-struct Bi {   // dada.h:85-105
-  std::vector<uint32_t> raw;
+// Host mirror of one partition (dada.h:85-105): only what is needed to replay the reference's slot
+// order and to take the per-round, C-sized decisions.  All per-unique state lives on the device.
+struct Bi {
+  std::vector<uint32_t> raw;       // members in the reference's slot order
   uint32_t reads = 0, center = 0xFFFFFFFFu;
-  bool update_e = true, check_locks = true;
-  double self = 0;
   char birth_type = 'I';
   uint32_t birth_from = 0;
   double birth_pval = 0, birth_fold = 1, birth_e = 0;
   Comp birth_comp{0, 0, 0, 0};
-  std::vector<Comp> comp;
 };
+
+struct BudKeyH { double p; uint32_t reads; uint32_t pad; };
 
 struct Run {
   dada2hip_sample *s;
@@ -305,15 +306,31 @@ struct Run {
   const dada2hip_hooks *hooks;
   int N, ncol;
   std::vector<double> err_rowmajor;
-  std::vector<double> p, E_minmax;
-  std::vector<Comp> comp;
-  std::vector<uint8_t> lock, correct;
   std::vector<Bi> bi;
+  std::vector<int32_t> clust_of, slot_of;       // host copies, maintained by replaying moves
   dada2hip_stats st;
   std::vector<int32_t> thresh_round, thresh_one;
   AlignParams ap;
   ScreenParams sp;
   int wclass;
+  PartState P;
+  int ccap = 0;                                   // capacity of the per-cluster device arrays
+  // device buffers owned by the run
+  DevBuf<double> d_Emin, d_clam, d_p, d_nlam, d_ph_lam;
+  DevBuf<uint8_t> d_lock, d_slot0, d_upd, d_chk;
+  DevBuf<int32_t> d_clof, d_ci, d_head, d_ni, d_nnext, d_ncount, d_centre, d_errflag, d_movers, d_nmovers, d_ties0, d_ties1,
+      d_nties, d_ph_ji, d_ph_n, d_cl_of_centre;
+  DevBuf<uint32_t> d_cham, d_nham, d_creads, d_creads_snap;
+  DevBuf<unsigned long long> d_totals;
+  DevBuf<BudKeyH> d_partial, d_best;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> nw_events, screen_events;
+  size_t ev_used = 0;
+  std::vector<uint64_t> nw_event_cells;
+
+  ~Run() {
+    for (auto &e : nw_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : screen_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
 
   void logf(const char *fmt, ...) {
     if (!o.verbose || !hooks || !hooks->log) return;
@@ -325,92 +342,302 @@ struct Run {
     hooks->log(buf, hooks->user);
   }
 
-  // containers.cpp:150-197
-  void bi_add_raw(int i, uint32_t r) { bi[i].raw.push_back(r); bi[i].reads += s->h_reads[r]; bi[i].update_e = true; }
-  uint32_t bi_pop_raw(int i, uint32_t slot) {
-    Bi &b = bi[i];
-    uint32_t r = b.raw[slot];
-    b.raw[slot] = b.raw.back();   // swap-with-last (containers.cpp:187)
-    b.raw.pop_back();
-    b.reads -= s->h_reads[r];
-    b.update_e = true;
-    return r;
-  }
-  // cluster.cpp:371-386
-  void bi_assign_center(int i) {
-    Bi &b = bi[i];
-    uint32_t mx = 0;
-    b.center = 0xFFFFFFFFu;
-    for (uint32_t r : b.raw) {
-      lock[r] = 0;
-      if (s->h_reads[r] > mx) { b.center = r; mx = s->h_reads[r]; }
-    }
-    b.check_locks = true;
+  std::pair<hipEvent_t, hipEvent_t> new_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+    hipEvent_t a, b;
+    D2_HIP(hipEventCreate(&a));
+    D2_HIP(hipEventCreate(&b));
+    v.push_back({a, b});
+    return v.back();
   }
 
-  // one b_compare round on the device: dense lambda/hamming for every unique (cluster.cpp:90-149)
-  void device_compare(int centre, double cutoff, const uint8_t *h_skip_or_null, bool count_stats) {
+  // ---- device state -----------------------------------------------------------------------------
+  void alloc_state() {
+    const size_t n = (size_t)N;
+    d_Emin.alloc(n); d_clam.alloc(n); d_p.alloc(n); d_lock.alloc(n); d_slot0.alloc(n); d_clof.alloc(n); d_ci.alloc(n);
+    d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(3 * n); d_nmovers.alloc(1);
+    d_ties0.alloc(n); d_ties1.alloc(n); d_nties.alloc(2); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_best.alloc(2);
+    P.E_minmax = d_Emin.p; P.comp_lam = d_clam.p; P.p = d_p.p; P.lock = d_lock.p; P.slot0 = d_slot0.p; P.clust_of = d_clof.p;
+    P.comp_i = d_ci.p; P.comp_ham = d_cham.p; P.head = d_head.p; P.node_count = d_ncount.p; P.err_flag = d_errflag.p;
+    P.totals = d_totals.p;
+    grow_nodes(std::max<size_t>(4 * n, 1u << 20));
+    grow_clusters(256);
+    hipStream_t stq = s->stream;
+    std::vector<double> em(n, -999.0);                           // containers.cpp:39
+    D2_HIP(hipMemcpyAsync(d_Emin.p, em.data(), n * 8, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemsetAsync(d_clam.p, 0, n * 8, stq));
+    D2_HIP(hipMemsetAsync(d_p.p, 0, n * 8, stq));
+    D2_HIP(hipMemsetAsync(d_lock.p, 0, n, stq));
+    D2_HIP(hipMemsetAsync(d_slot0.p, 0, n, stq));
+    D2_HIP(hipMemsetAsync(d_clof.p, 0, n * 4, stq));
+    D2_HIP(hipMemsetAsync(d_ci.p, 0, n * 4, stq));
+    D2_HIP(hipMemsetAsync(d_cham.p, 0, n * 4, stq));
+    D2_HIP(hipMemsetAsync(d_head.p, 0xFF, n * 4, stq));          // -1
+    D2_HIP(hipMemsetAsync(d_ncount.p, 0, 4, stq));
+    D2_HIP(hipMemsetAsync(d_errflag.p, 0, 4, stq));
+    D2_HIP(hipMemsetAsync(d_totals.p, 0, 32, stq));
+    D2_HIP(hipStreamSynchronize(stq));                           // `em` goes out of scope
+  }
+
+  void grow_nodes(size_t cap) {
+    if (cap <= (size_t)P.node_cap) return;
+    if (cap > 0x7FFFFFF0u) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: comparison store exceeds 2^31 entries"};
+    DevBuf<int32_t> ni, nn;
+    DevBuf<double> nl;
+    DevBuf<uint32_t> nh;
+    ni.alloc(cap); nn.alloc(cap); nl.alloc(cap); nh.alloc(cap);
+    if (P.node_cap > 0) {
+      D2_HIP(hipMemcpyAsync(ni.p, d_ni.p, (size_t)P.node_cap * 4, hipMemcpyDeviceToDevice, s->stream));
+      D2_HIP(hipMemcpyAsync(nn.p, d_nnext.p, (size_t)P.node_cap * 4, hipMemcpyDeviceToDevice, s->stream));
+      D2_HIP(hipMemcpyAsync(nl.p, d_nlam.p, (size_t)P.node_cap * 8, hipMemcpyDeviceToDevice, s->stream));
+      D2_HIP(hipMemcpyAsync(nh.p, d_nham.p, (size_t)P.node_cap * 4, hipMemcpyDeviceToDevice, s->stream));
+      D2_HIP(hipStreamSynchronize(s->stream));
+    }
+    std::swap(d_ni.p, ni.p); std::swap(d_ni.n, ni.n);
+    std::swap(d_nnext.p, nn.p); std::swap(d_nnext.n, nn.n);
+    std::swap(d_nlam.p, nl.p); std::swap(d_nlam.n, nl.n);
+    std::swap(d_nham.p, nh.p); std::swap(d_nham.n, nh.n);
+    P.node_i = d_ni.p; P.node_next = d_nnext.p; P.node_lam = d_nlam.p; P.node_ham = d_nham.p;
+    P.node_cap = (int32_t)cap;
+  }
+
+  void grow_clusters(int cap) {
+    if (cap <= ccap) return;
+    DevBuf<uint32_t> cr, cs;
+    DevBuf<int32_t> ce;
+    DevBuf<uint8_t> up, ch;
+    cr.alloc(cap); cs.alloc(cap); ce.alloc(cap); up.alloc(cap); ch.alloc(cap);
+    hipStream_t stq = s->stream;
+    D2_HIP(hipMemsetAsync(cr.p, 0, (size_t)cap * 4, stq));
+    D2_HIP(hipMemsetAsync(ce.p, 0, (size_t)cap * 4, stq));
+    D2_HIP(hipMemsetAsync(up.p, 0, (size_t)cap, stq));
+    D2_HIP(hipMemsetAsync(ch.p, 0, (size_t)cap, stq));
+    if (ccap > 0) {
+      D2_HIP(hipMemcpyAsync(cr.p, d_creads.p, (size_t)ccap * 4, hipMemcpyDeviceToDevice, stq));
+      D2_HIP(hipMemcpyAsync(ce.p, d_centre.p, (size_t)ccap * 4, hipMemcpyDeviceToDevice, stq));
+      D2_HIP(hipMemcpyAsync(up.p, d_upd.p, (size_t)ccap, hipMemcpyDeviceToDevice, stq));
+      D2_HIP(hipMemcpyAsync(ch.p, d_chk.p, (size_t)ccap, hipMemcpyDeviceToDevice, stq));
+    }
+    D2_HIP(hipStreamSynchronize(stq));
+    std::swap(d_creads.p, cr.p); std::swap(d_creads.n, cr.n);
+    std::swap(d_creads_snap.p, cs.p); std::swap(d_creads_snap.n, cs.n);
+    std::swap(d_centre.p, ce.p); std::swap(d_centre.n, ce.n);
+    std::swap(d_upd.p, up.p); std::swap(d_upd.n, up.n);
+    std::swap(d_chk.p, ch.p); std::swap(d_chk.n, ch.n);
+    P.creads = d_creads.p; P.centre_of = d_centre.p; P.update_e = d_upd.p; P.check_locks = d_chk.p;
+    ccap = cap;
+  }
+
+  // publish a (new) partition's centre / reads / flags to the device
+  void push_cluster(int i, bool update_e, bool check_locks) {
+    hipStream_t stq = s->stream;
+    if (i >= ccap) grow_clusters(std::max(ccap * 2, i + 1));
+    const uint32_t rd = bi[i].reads;
+    const int32_t ce = (int32_t)bi[i].center;
+    const uint8_t u = update_e, c = check_locks;
+    D2_HIP(hipMemcpyAsync(P.creads + i, &rd, 4, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemcpyAsync(P.centre_of + i, &ce, 4, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemcpyAsync(P.update_e + i, &u, 1, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemcpyAsync(P.check_locks + i, &c, 1, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipStreamSynchronize(stq));   // sources are stack temporaries
+  }
+
+  // ---- one b_compare round, entirely on the device (cluster.cpp:90-204) ---------------------------
+  void compare_round(int ci, double cutoff) {
     SampleDev &D = s->D;
     hipStream_t stq = s->stream;
+    const int centre = (int)bi[ci].center;
     auto t0 = clk::now();
     const std::vector<int32_t> &th = (cutoff == 1.0) ? thresh_one : thresh_round;
     D2_HIP(hipMemcpyAsync(s->d_thresh.p, th.data(), th.size() * 4, hipMemcpyHostToDevice, stq));
-    if (h_skip_or_null) D2_HIP(hipMemcpyAsync(s->d_skip.p, h_skip_or_null, (size_t)N, hipMemcpyHostToDevice, stq));
     D2_HIP(hipMemsetAsync(s->d_counters.p, 0, 8 * 4, stq));
-    D2_HIP(hipEventRecord(s->ev0, stq));
-    launch_screen(D, centre, sp, h_skip_or_null ? s->d_skip.p : nullptr, s->d_thresh.p, s->d_cls.p, s->d_lambda.p,
-                  s->d_ham.p, s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, stq);
-    D2_HIP(hipEventRecord(s->ev1, stq));
-    D2_HIP(hipMemcpyAsync(s->h_counters.p, s->d_counters.p, 4 * 4, hipMemcpyDeviceToHost, stq));
-    launch_gapless(D, centre, nullptr, s->d_gl_list.p, s->d_counters.p + 1, 0, ap, s->d_err.p, s->d_lambda.p,
-                   s->d_ham.p, nullptr, 0, 0, stq);
-    D2_HIP(hipStreamSynchronize(stq));   // counters on the host: sizes the NW grid
-    float ems = 0;
-    D2_HIP(hipEventElapsedTime(&ems, s->ev0, s->ev1));
-    st.screen_kernel_ms += ems;
-    st.screen_kernel_launches++;
+    auto evs = new_events(screen_events);
+    D2_HIP(hipEventRecord(evs.first, stq));
+    launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, s->d_thresh.p, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
+                  s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, stq);
+    D2_HIP(hipEventRecord(evs.second, stq));
+    launch_gapless(D, centre, nullptr, s->d_gl_list.p, s->d_counters.p + 1, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
+                   nullptr, 0, 0, stq);
+    // NW batch size is only known on the device: both kernels loop over the device-side count with a
+    // fixed persistent grid.  Round 0 aligns every unique (lane-per-alignment kernel), later rounds a few
+    // thousand (cooperative kernel).
+    auto evn = new_events(nw_events);
+    D2_HIP(hipEventRecord(evn.first, stq));
+    const char *f = getenv("DADA2HIP_NW_KERNEL");
+    const bool coop_ok = nw_ad_lds_bytes(D, ap) > 0 && nw_ad_lds_bytes(D, ap) <= 150 * 1024;
+    bool coop = coop_ok && (ci != 0 || N < 65536);
+    if (f && !strcmp(f, "lane")) coop = false;
+    if (f && !strcmp(f, "coop") && coop_ok) coop = true;
+    if (coop)
+      launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, s->d_counters.p, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, stq);
+    else
+      launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, s->d_counters.p, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
+                s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
+    D2_HIP(hipEventRecord(evn.second, stq));
+    launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, s->d_counters.p, stq);
+    st.ncompare += (uint64_t)N;
     st.ms_screen += ms_since(t0);
-    const int n_nw = s->h_counters.p[0], n_gl = s->h_counters.p[1];
-    if (count_stats) {
-      st.ncompare += (uint64_t)N;
-      st.nshroud += (uint64_t)s->h_counters.p[2];
-      st.nskipped += (uint64_t)s->h_counters.p[3];
-      st.ngapless += (uint64_t)n_gl;
-      st.nnw += (uint64_t)n_nw;
-    }
-    auto t1 = clk::now();
-    if (n_nw > 0) {
-      D2_HIP(hipEventRecord(s->ev0, stq));
-      if (use_coop(n_nw))
-        launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, stq);
-      else
-        launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, ap, s->d_err.p, s->scr, s->d_lambda.p,
-                  s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
-      D2_HIP(hipEventRecord(s->ev1, stq));
-    }
-    D2_HIP(hipMemcpyAsync(s->h_lambda.p, s->d_lambda.p, (size_t)N * 8, hipMemcpyDeviceToHost, stq));
-    D2_HIP(hipMemcpyAsync(s->h_ham.p, s->d_ham.p, (size_t)N * 4, hipMemcpyDeviceToHost, stq));
-    D2_HIP(hipStreamSynchronize(stq));
-    D2_HIP(hipGetLastError());
-    if (n_nw > 0) {
-      D2_HIP(hipEventElapsedTime(&ems, s->ev0, s->ev1));
-      st.nw_kernel_ms += ems;
-      st.nw_kernel_launches++;
-      st.nw_cells += (uint64_t)n_nw * nw_cells_per_alignment();
-    }
-    st.ms_nw += ms_since(t1);
   }
 
-  // Kernel choice for a round's NW batch: the cooperative anti-diagonal kernel (k_nw_ad, low latency)
-  // for batches that cannot fill the chip one-alignment-per-lane, the lane-per-alignment kernel (k_nw,
-  // ~3x fewer instructions per alignment) for very large ones.  DADA2HIP_NW_KERNEL=lane|coop forces one.
-  bool use_coop(int n_nw) const {
-    const size_t lds = nw_ad_lds_bytes(s->D, ap);
-    if (lds == 0 || lds > 150 * 1024) return false;
-    const char *f = getenv("DADA2HIP_NW_KERNEL");
-    if (f && !strcmp(f, "lane")) return false;
-    if (f && !strcmp(f, "coop")) return true;
-    return n_nw < 262144;
+  // ---- b_shuffle2: device arg-max + move, host replay of the moves in the reference's order -------
+  bool shuffle() {
+    auto t0 = clk::now();
+    SampleDev &D = s->D;
+    hipStream_t stq = s->stream;
+    const int C = (int)bi.size();
+    D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)C * 4, hipMemcpyDeviceToDevice, stq));
+    D2_HIP(hipMemsetAsync(d_nmovers.p, 0, 4, stq));
+    launch_shuffle(P, D, d_creads_snap.p, d_movers.p, d_nmovers.p, stq);
+    int32_t nm = 0;
+    D2_HIP(hipMemcpyAsync(&nm, d_nmovers.p, 4, hipMemcpyDeviceToHost, stq));
+    D2_HIP(hipStreamSynchronize(stq));
+    st.nshuffle++;
+    if (nm > 0) {
+      std::vector<int32_t> mv((size_t)3 * nm);
+      D2_HIP(hipMemcpy(mv.data(), d_movers.p, mv.size() * 4, hipMemcpyDeviceToHost));
+      // reference order: partitions ascending, slots descending (cluster.cpp:242-259)
+      std::vector<int32_t> order(nm);
+      for (int k = 0; k < nm; k++) order[k] = k;
+      std::sort(order.begin(), order.end(), [&](int a, int b) {
+        const int fa = mv[3 * a + 1], fb = mv[3 * b + 1];
+        if (fa != fb) return fa < fb;
+        return slot_of[mv[3 * a]] > slot_of[mv[3 * b]];
+      });
+      bool slot0_changed = false;
+      for (int k : order) {
+        const uint32_t r = (uint32_t)mv[3 * k];
+        const int from = mv[3 * k + 1], to = mv[3 * k + 2];
+        Bi &bf = bi[from];
+        const int slot = slot_of[r];
+        // bi_pop_raw: swap-with-last (containers.cpp:183-197)
+        const uint32_t last = bf.raw.back();
+        bf.raw[slot] = last;
+        slot_of[last] = slot;
+        bf.raw.pop_back();
+        bf.reads -= s->h_reads[r];
+        if (slot == 0) slot0_changed = true;
+        // bi_add_raw (containers.cpp:150-162)
+        Bi &bt = bi[to];
+        slot_of[r] = (int32_t)bt.raw.size();
+        bt.raw.push_back(r);
+        bt.reads += s->h_reads[r];
+        clust_of[r] = to;
+      }
+      if (slot0_changed) push_slot0();
+    }
+    st.ms_bookkeep += ms_since(t0);
+    return nm > 0;
+  }
+
+  void push_slot0() {   // only reachable when a slot-0 unique is not its partition's centre (unsorted input)
+    std::vector<uint8_t> f(N, 0);
+    for (auto &b : bi) if (!b.raw.empty()) f[b.raw[0]] = 1;
+    D2_HIP(hipMemcpy(P.slot0, f.data(), (size_t)N, hipMemcpyHostToDevice));
+  }
+
+  void p_update() {
+    auto t0 = clk::now();
+    hipStream_t stq = s->stream;
+    launch_pupdate(P, s->D, o.greedy, o.detect_singletons, stq);
+    D2_HIP(hipMemsetAsync(P.update_e, 0, (size_t)bi.size(), stq));
+    D2_HIP(hipMemsetAsync(P.check_locks, 0, (size_t)bi.size(), stq));
+    st.ms_pval += ms_since(t0);
+  }
+
+  // ---- b_bud (cluster.cpp:274-350): device arg-min, host tie-break in (partition, slot) order ------
+  int bud() {
+    auto t0 = clk::now();
+    SampleDev &D = s->D;
+    hipStream_t stq = s->stream;
+    BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
+    const uint32_t c0 = bi[0].center;
+    D2_HIP(hipMemsetAsync(d_nties.p, 0, 8, stq));
+    launch_bud(P, D, bp, 1.0, s->h_reads[c0], d_partial.p, d_best.p, d_ties0.p, d_ties1.p, d_nties.p, stq);
+    struct { BudKeyH best[2]; int32_t nties[2]; int32_t errflag; } h;
+    D2_HIP(hipMemcpyAsync(h.best, d_best.p, sizeof h.best, hipMemcpyDeviceToHost, stq));
+    D2_HIP(hipMemcpyAsync(h.nties, d_nties.p, 8, hipMemcpyDeviceToHost, stq));
+    D2_HIP(hipMemcpyAsync(&h.errflag, P.err_flag, 4, hipMemcpyDeviceToHost, stq));
+    D2_HIP(hipStreamSynchronize(stq));
+    D2_HIP(hipGetLastError());
+    check_errflag(h.errflag);
+    auto pick = [&](int track) -> int {   // first tied candidate in scan order (i ascending, slot ascending)
+      const int n = h.nties[track];
+      if (n <= 0) return -1;
+      std::vector<int32_t> t(n);
+      D2_HIP(hipMemcpy(t.data(), track ? d_ties1.p : d_ties0.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+      int best = t[0];
+      for (int k = 1; k < n; k++) {
+        const int r = t[k];
+        if (clust_of[r] < clust_of[best] || (clust_of[r] == clust_of[best] && slot_of[r] < slot_of[best])) best = r;
+      }
+      return best;
+    };
+    const int minraw = pick(0);
+    const double pA = (minraw >= 0 ? h.best[0].p : 1.0) * N;        // minraw stays the cluster-0 centre (p = 1) otherwise
+    int newi = 0;
+    auto birth = [&](int raw, char type, double pval) {
+      struct { int32_t ci; double lam; uint32_t ham; } c;
+      D2_HIP(hipMemcpy(&c.ci, P.comp_i + raw, 4, hipMemcpyDeviceToHost));
+      D2_HIP(hipMemcpy(&c.lam, P.comp_lam + raw, 8, hipMemcpyDeviceToHost));
+      D2_HIP(hipMemcpy(&c.ham, P.comp_ham + raw, 4, hipMemcpyDeviceToHost));
+      const int from = clust_of[raw];
+      const double expected = c.lam * bi[from].reads;
+      // bi_pop_raw(from, slot)
+      Bi &bf = bi[from];
+      const int slot = slot_of[raw];
+      const uint32_t last = bf.raw.back();
+      bf.raw[slot] = last;
+      slot_of[last] = slot;
+      bf.raw.pop_back();
+      bf.reads -= s->h_reads[raw];
+      bi.emplace_back();
+      newi = (int)bi.size() - 1;
+      Bi &nb = bi[newi];
+      nb.birth_type = type;
+      nb.birth_from = type == 'A' ? (uint32_t)from : 0u;             // never assigned for "P" births (cluster.cpp:331-345)
+      nb.birth_pval = pval; nb.birth_fold = s->h_reads[raw] / expected; nb.birth_e = expected;
+      nb.birth_comp = Comp{(uint32_t)c.ci, (uint32_t)raw, c.lam, c.ham};
+      nb.raw.push_back((uint32_t)raw);
+      nb.reads = s->h_reads[raw];
+      nb.center = (uint32_t)raw;                                      // bi_assign_center: the only member
+      slot_of[raw] = 0;
+      clust_of[raw] = newi;
+      // device: membership, lock reset (bi_assign_center unlocks members), slot-0 flag, partition records
+      hipStream_t q = s->stream;
+      const int32_t ni = newi;
+      const uint8_t zero = 0, one = 1;
+      D2_HIP(hipMemcpyAsync(P.clust_of + raw, &ni, 4, hipMemcpyHostToDevice, q));
+      D2_HIP(hipMemcpyAsync(P.lock + raw, &zero, 1, hipMemcpyHostToDevice, q));
+      D2_HIP(hipMemcpyAsync(P.slot0 + raw, &one, 1, hipMemcpyHostToDevice, q));
+      D2_HIP(hipStreamSynchronize(q));
+      if (slot == 0) push_slot0();
+      push_cluster(newi, true, true);
+      push_cluster(from, true, false);   // reads changed; update_e set by bi_pop_raw (check_locks of `from` is already clear)
+    };
+    if (pA < o.omegaA && minraw >= 0) {
+      birth(minraw, 'A', pA);
+      logf(", Division (naive): Raw %d from Bi %u, pA=%.2e", minraw, bi[newi].birth_from, pA);
+    } else {
+      const int minraw_p = pick(1);
+      const double pP = minraw_p >= 0 ? h.best[1].p : 1.0;
+      if (pP < o.omegaP && minraw_p >= 0) {
+        birth(minraw_p, 'P', pP);
+        logf(", Division (prior): Raw %d, pP=%.2e", minraw_p, pP);
+      }
+    }
+    st.ms_bookkeep += ms_since(t0);
+    return newi;
+  }
+
+  void check_errflag(int32_t f) {
+    if (f & 1) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "Lambda out-of-range error."};
+    if (f & 2) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: comparison store overflow"};
+  }
+
+  void ensure_node_capacity() {
+    int32_t cnt = 0;
+    D2_HIP(hipMemcpy(&cnt, P.node_count, 4, hipMemcpyDeviceToHost));
+    st.nstored = (uint64_t)cnt;
+    if ((size_t)cnt + (size_t)N > (size_t)P.node_cap) grow_nodes(std::max((size_t)P.node_cap * 2, (size_t)cnt + 2 * (size_t)N));
   }
 
   uint64_t nw_cells_per_alignment() const {
@@ -418,139 +645,6 @@ struct Run {
     const int L = s->D.maxlen;
     if (o.band_size < 0) return (uint64_t)(L + 1) * (L + 1);
     return (uint64_t)(2 * L + 1) * (uint64_t)(o.band_size + 1);
-  }
-
-  // serial store filter of b_compare_parallel (cluster.cpp:179-201)
-  void store_round(int i) {
-    auto t0 = clk::now();
-    Bi &b = bi[i];
-    const uint32_t c = b.center, creads = s->h_reads[c];
-    const double *lamv = s->h_lambda.p;
-    const uint32_t *hamv = s->h_ham.p;
-    const double total = (double)0 + (double)s->total_reads;   // b->reads is unsigned int; lambda * b->reads in fp64
-    for (uint32_t index = 0; index < (uint32_t)N; index++) {
-      const double lambda = lamv[index];
-      if (lambda < 0 || lambda > 1) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "Lambda out-of-range error."};
-      if (index == c) b.self = lambda;
-      if (lambda * total > E_minmax[index]) {
-        if (lambda * creads > E_minmax[index]) E_minmax[index] = lambda * creads;
-        Comp cp{(uint32_t)i, index, lambda, hamv[index]};
-        b.comp.push_back(cp);
-        st.nstored++;
-        if (i == 0 || index == c) comp[index] = cp;
-      }
-    }
-    st.ms_bookkeep += ms_since(t0);
-  }
-
-  // b_shuffle2 (cluster.cpp:210-266)
-  bool shuffle() {
-    auto t0 = clk::now();
-    bool shuffled = false;
-    const int C = (int)bi.size();
-    std::vector<double> emax(N);
-    std::vector<const Comp *> cmax(N);
-    for (int idx = 0; idx < N; idx++) { cmax[idx] = &bi[0].comp[idx]; emax[idx] = cmax[idx]->lambda * bi[0].reads; }
-    for (int i = 1; i < C; i++) {
-      const double breads = bi[i].reads;
-      for (const Comp &cp : bi[i].comp) {
-        double e = cp.lambda * breads;
-        if (e > emax[cp.index]) { cmax[cp.index] = &cp; emax[cp.index] = e; }
-      }
-    }
-    for (int i = 0; i < C; i++) {
-      for (int r = (int)bi[i].raw.size() - 1; r >= 0; r--) {
-        uint32_t raw = bi[i].raw[r];
-        if (cmax[raw]->i != (uint32_t)i) {
-          if (raw == bi[i].center) continue;
-          bi_pop_raw(i, (uint32_t)r);
-          bi_add_raw((int)cmax[raw]->i, raw);
-          comp[raw] = *cmax[raw];
-          shuffled = true;
-        }
-      }
-    }
-    st.nshuffle++;
-    st.ms_bookkeep += ms_since(t0);
-    return shuffled;
-  }
-
-  // get_pA (pval.cpp:67-89)
-  double get_pA(uint32_t raw, int i) {
-    const double lambda = comp[raw].lambda;
-    const uint32_t hamming = comp[raw].hamming;
-    if (s->h_reads[raw] == 1 && !s->h_prior[raw] && !o.detect_singletons) return 1.;
-    if (hamming == 0) return 1.;
-    if (lambda == 0) return 0.;
-    return pp::calc_pA((int)s->h_reads[raw], lambda * bi[i].reads, s->h_prior[raw] || o.detect_singletons);
-  }
-
-  // b_p_update (pval.cpp:14-40)
-  void p_update() {
-    auto t0 = clk::now();
-    for (int i = 0; i < (int)bi.size(); i++) {
-      Bi &b = bi[i];
-      if (b.update_e) {
-        for (uint32_t raw : b.raw) p[raw] = get_pA(raw, i);
-        b.update_e = false;
-      }
-      if (o.greedy && b.check_locks) {
-        for (uint32_t raw : b.raw) {
-          double E_center = s->h_reads[b.center] * comp[raw].lambda;
-          if (E_center > s->h_reads[raw]) lock[raw] = 1;
-          if (raw == b.center) lock[raw] = 1;
-        }
-        b.check_locks = false;
-      }
-    }
-    st.ms_pval += ms_since(t0);
-  }
-
-  // b_bud (cluster.cpp:274-350)
-  int bud() {
-    auto t0 = clk::now();
-    int mini = -1, minr = -1, mini_p = -1, minr_p = -1;
-    uint32_t minraw = bi[0].center, minraw_p = bi[0].center;
-    for (int i = 0; i < (int)bi.size(); i++) {
-      const Bi &b = bi[i];
-      for (int r = 1; r < (int)b.raw.size(); r++) {
-        const uint32_t raw = b.raw[r];
-        if (s->h_reads[raw] < (uint32_t)o.min_abund) continue;
-        if ((int)comp[raw].hamming >= o.min_hamming) {
-          if (o.min_fold <= 1 || ((double)s->h_reads[raw]) >= o.min_fold * comp[raw].lambda * b.reads) {
-            if (p[raw] < p[minraw] || (p[raw] == p[minraw] && s->h_reads[raw] > s->h_reads[minraw])) { mini = i; minr = r; minraw = raw; }
-            if (s->h_prior[raw] && (p[raw] < p[minraw_p] || (p[raw] == p[minraw_p] && s->h_reads[raw] > s->h_reads[minraw_p]))) { mini_p = i; minr_p = r; minraw_p = raw; }
-          }
-        }
-      }
-    }
-    const double pA = p[minraw] * N, pP = p[minraw_p];
-    int newi = 0;
-    if (pA < o.omegaA && mini >= 0) {
-      const double expected = comp[minraw].lambda * bi[mini].reads;
-      uint32_t raw = bi_pop_raw(mini, (uint32_t)minr);
-      bi.emplace_back();
-      newi = (int)bi.size() - 1;
-      Bi &nb = bi[newi];
-      nb.birth_type = 'A'; nb.birth_from = (uint32_t)mini; nb.birth_pval = pA; nb.birth_fold = s->h_reads[raw] / expected;
-      nb.birth_e = expected; nb.birth_comp = comp[minraw];
-      bi_add_raw(newi, raw);
-      bi_assign_center(newi);
-      logf(", Division (naive): Raw %u from Bi %d, pA=%.2e", raw, mini, pA);
-    } else if (pP < o.omegaP && mini_p >= 0) {
-      const double expected = comp[minraw_p].lambda * bi[mini_p].reads;
-      uint32_t raw = bi_pop_raw(mini_p, (uint32_t)minr_p);
-      bi.emplace_back();
-      newi = (int)bi.size() - 1;
-      Bi &nb = bi[newi];
-      nb.birth_type = 'P'; nb.birth_from = 0;   // never assigned in the reference (cluster.cpp:331-345)
-      nb.birth_pval = pP; nb.birth_fold = s->h_reads[raw] / expected; nb.birth_e = expected; nb.birth_comp = comp[minraw_p];
-      bi_add_raw(newi, raw);
-      bi_assign_center(newi);
-      logf(", Division (prior): Raw %u from Bi %d, pP=%.2e", raw, mini_p, pP);
-    }
-    st.ms_bookkeep += ms_since(t0);
-    return newi;
   }
 };
 
@@ -577,6 +671,19 @@ void check_opts(const dada2hip_opts &o, int qmax, int ncol) {
   if (o.use_quals && qmax > ncol - 1) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "Rounded quality exceeded range of err lookup table."};
 }
 
+void init_run(Run &run, dada2hip_sample *s, const double *err, int err_ncol, const dada2hip_opts *opts, double cutoff) {
+  run.s = s; run.o = *opts; run.N = s->D.N; run.ncol = err_ncol;
+  memset(&run.st, 0, sizeof run.st);
+  upload_err(s, err, err_ncol, run.err_rowmajor);
+  alloc_round_buffers(s);
+  ensure_scratch(s, opts->band_size);
+  run.wclass = s->scr_class;
+  run.ap = AlignParams{opts->match, opts->mismatch, opts->gap, opts->band_size, nw_sentinel(*opts), opts->use_quals, err_ncol};
+  run.sp = ScreenParams{opts->use_kmers, opts->gapless, opts->band_size, opts->SSE};
+  run.thresh_round = make_thresh(s->D.maxlen, cutoff);
+  run.thresh_one = make_thresh(s->D.maxlen, 1.0);
+}
+
 // ---- dada_uniques proper: run_dada (Rmain.cpp:297-336) + outputs (Rmain.cpp:172-294, error.cpp) --
 void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2hip_opts *opts,
                 const dada2hip_hooks *hooks, dada2hip_result *R) {
@@ -587,46 +694,39 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   SampleDev &D = s->D;
   const int N = D.N;
   Run run;
-  run.s = s; run.o = *opts; run.hooks = hooks; run.N = N; run.ncol = err_ncol;
-  memset(&run.st, 0, sizeof run.st);
+  run.hooks = hooks;
+  init_run(run, s, err, err_ncol, opts, opts->kdist_cutoff);
   run.st.ms_upload = s->ms_upload;
-  upload_err(s, err, err_ncol, run.err_rowmajor);
-  alloc_round_buffers(s);
-  ensure_scratch(s, opts->band_size);
-  run.wclass = s->scr_class;
-  run.ap = AlignParams{opts->match, opts->mismatch, opts->gap, opts->band_size, nw_sentinel(*opts), opts->use_quals, err_ncol};
-  run.sp = ScreenParams{opts->use_kmers, opts->gapless, opts->band_size, opts->SSE};
-  run.thresh_round = make_thresh(D.maxlen, opts->kdist_cutoff);
-  run.thresh_one = make_thresh(D.maxlen, 1.0);
-  run.p.assign(N, 0.0);
-  run.E_minmax.assign(N, -999.0);                 // containers.cpp:39
-  run.comp.assign(N, Comp{0, 0, 0, 0});
-  run.lock.assign(N, 0);
-  run.correct.assign(N, 1);
-  // b_init (containers.cpp:111-137)
+  hipStream_t stq = s->stream;
+  run.alloc_state();
+  // b_init (containers.cpp:111-137): one partition holding every unique, centre = first max-reads member
+  run.clust_of.assign(N, 0);
+  run.slot_of.resize(N);
   run.bi.emplace_back();
-  run.bi[0].birth_type = 'I'; run.bi[0].birth_fold = 1.0; run.bi[0].birth_e = (double)(uint32_t)s->total_reads;
-  run.bi[0].raw.reserve(N);
-  for (int i = 0; i < N; i++) run.bi_add_raw(0, (uint32_t)i);
-  run.bi_assign_center(0);
+  {
+    Bi &b0 = run.bi[0];
+    b0.birth_type = 'I'; b0.birth_fold = 1.0; b0.birth_e = (double)(uint32_t)s->total_reads;
+    b0.raw.resize(N);
+    uint32_t mx = 0;
+    for (int i = 0; i < N; i++) {
+      b0.raw[i] = (uint32_t)i;
+      run.slot_of[i] = i;
+      b0.reads += s->h_reads[i];
+      if (s->h_reads[i] > mx) { b0.center = (uint32_t)i; mx = s->h_reads[i]; }
+    }
+    const uint8_t one = 1;
+    D2_HIP(hipMemcpy(run.P.slot0, &one, 1, hipMemcpyHostToDevice));   // unique 0 sits in slot 0 of partition 0
+    run.push_cluster(0, true, true);
+  }
 
-  auto make_skip = [&](int i) -> const uint8_t * {
-    if (!opts->greedy) return nullptr;
-    const uint32_t creads = s->h_reads[run.bi[i].center];
-    uint8_t *sk = s->h_skip.p;
-    for (int r = 0; r < N; r++) sk[r] = (s->h_reads[r] > creads || run.lock[r]) ? 1 : 0;   // cluster.cpp:127-130
-    return sk;
-  };
-
-  run.device_compare((int)run.bi[0].center, 1.0, make_skip(0), true);   // Rmain.cpp:309-310: no k-mer screen in round 0
-  run.store_round(0);
+  run.compare_round(0, 1.0);                          // Rmain.cpp:309-310: no k-mer screen in round 0
   run.p_update();
   int max_clust = opts->max_clust < 1 ? N : opts->max_clust;
   int newi;
   while ((int)run.bi.size() < max_clust && (newi = run.bud())) {
     run.logf("\nNew Cluster C%i:", newi);
-    run.device_compare((int)run.bi[newi].center, opts->kdist_cutoff, make_skip(newi), true);
-    run.store_round(newi);
+    run.ensure_node_capacity();
+    run.compare_round(newi, opts->kdist_cutoff);
     int nshuffle = 0;
     bool shuffled;
     do { shuffled = run.shuffle(); } while (shuffled && ++nshuffle < MAX_SHUFFLE);
@@ -640,7 +740,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   auto t_final = clk::now();
   const int C = (int)run.bi.size();
   const int LV = D.maxlen;
-  std::vector<int32_t> work, chunk_centre, cluster_of(N), centre_of_cluster(C);
+  std::vector<int32_t> work, chunk_centre, centre_of_cluster(C);
   work.reserve((size_t)N + 64 * (size_t)C);
   for (int i = 0; i < C; i++) {
     centre_of_cluster[i] = (int32_t)run.bi[i].center;
@@ -648,54 +748,38 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     for (size_t k = 0; k < m.size(); k++) {
       if (k % 64 == 0) chunk_centre.push_back((int32_t)run.bi[i].center);
       work.push_back((int32_t)m[k]);
-      cluster_of[m[k]] = i;
     }
     while (work.size() % 64) work.push_back(-1);
   }
   s->d_work.alloc(work.size()); s->d_chunk_centre.alloc(chunk_centre.size());
   s->d_view.alloc((size_t)N * LV);
-  s->d_cluster_of.alloc(N); s->d_centre_of_cluster.alloc(C); s->d_correct.alloc(N);
+  s->d_correct.alloc(N);
   s->d_trans.alloc((size_t)16 * err_ncol); s->d_nsubs.alloc(N);
   s->d_qsum.alloc((size_t)C * D.maxlen); s->d_qn.alloc((size_t)C * D.maxlen);
-  hipStream_t stq = s->stream;
   D2_HIP(hipMemcpyAsync(s->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, stq));
   D2_HIP(hipMemcpyAsync(s->d_chunk_centre.p, chunk_centre.data(), chunk_centre.size() * 4, hipMemcpyHostToDevice, stq));
-  D2_HIP(hipMemcpyAsync(s->d_cluster_of.p, cluster_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, stq));
-  D2_HIP(hipMemcpyAsync(s->d_centre_of_cluster.p, centre_of_cluster.data(), (size_t)C * 4, hipMemcpyHostToDevice, stq));
   if (opts->band_size == 0) {
     launch_gapless(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->d_lambda.p,
                    s->d_ham.p, s->d_view.p, LV, 0, stq);
     run.st.ngapless += (uint64_t)N;
   } else {
-    D2_HIP(hipEventRecord(s->ev0, stq));
+    auto evn = run.new_events(run.nw_events);
+    D2_HIP(hipEventRecord(evn.first, stq));
     launch_nw(D, run.wclass, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr,
               s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, 0, nullptr, stq);
-    D2_HIP(hipEventRecord(s->ev1, stq));
-    D2_HIP(hipStreamSynchronize(stq));
-    float ems = 0;
-    D2_HIP(hipEventElapsedTime(&ems, s->ev0, s->ev1));
-    run.st.nw_kernel_ms += ems;
-    run.st.nw_kernel_launches++;
+    D2_HIP(hipEventRecord(evn.second, stq));
     run.st.nnw += (uint64_t)N;
-    run.st.nw_cells += (uint64_t)N * run.nw_cells_per_alignment();
   }
-
-  // final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252)
+  // final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252), on the device
+  launch_final_p(run.P, D, opts->omegaC, s->d_correct.p, stq);
+  std::vector<uint8_t> correct(N);
   R->pval.assign(N, 0.0);
-  for (int i = 0; i < C; i++)
-    for (uint32_t raw : run.bi[i].raw) {
-      if (run.bi[i].center == raw) run.p[raw] = 1.0;
-      else {
-        run.p[raw] = pp::calc_pA((int)s->h_reads[raw], run.comp[raw].lambda * run.bi[i].reads, true);
-        if (run.p[raw] < opts->omegaC) run.correct[raw] = 0;
-      }
-      R->pval[raw] = run.p[raw];
-    }
-  D2_HIP(hipMemcpyAsync(s->d_correct.p, run.correct.data(), (size_t)N, hipMemcpyHostToDevice, stq));
+  D2_HIP(hipMemcpyAsync(R->pval.data(), run.P.p, (size_t)N * 8, hipMemcpyDeviceToHost, stq));
+  D2_HIP(hipMemcpyAsync(correct.data(), s->d_correct.p, (size_t)N, hipMemcpyDeviceToHost, stq));
   D2_HIP(hipMemsetAsync(s->d_trans.p, 0, (size_t)16 * err_ncol * 4, stq));
   D2_HIP(hipMemsetAsync(s->d_qsum.p, 0, (size_t)C * D.maxlen * 8, stq));
   D2_HIP(hipMemsetAsync(s->d_qn.p, 0, (size_t)C * D.maxlen * 4, stq));
-  launch_final_tables(D, s->d_view.p, LV, s->d_cluster_of.p, s->d_centre_of_cluster.p, s->d_correct.p, err_ncol, 1,
+  launch_final_tables(D, s->d_view.p, LV, run.P.clust_of, run.P.centre_of, s->d_correct.p, err_ncol, 1,
                       s->d_trans.p, s->d_qsum.p, s->d_qn.p, s->d_nsubs.p, C, stq);
   std::vector<int32_t> nsubs(N);
   std::vector<unsigned long long> qsum((size_t)C * D.maxlen);
@@ -705,6 +789,33 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   D2_HIP(hipMemcpyAsync(qsum.data(), s->d_qsum.p, qsum.size() * 8, hipMemcpyDeviceToHost, stq));
   D2_HIP(hipMemcpyAsync(qn.data(), s->d_qn.p, qn.size() * 4, hipMemcpyDeviceToHost, stq));
   D2_HIP(hipMemcpyAsync(R->subqual.data(), s->d_trans.p, R->subqual.size() * 4, hipMemcpyDeviceToHost, stq));
+
+  // post-hoc partition p-values (error.cpp:101-119): comparisons of partition i against the centres of others
+  std::vector<int32_t> ph_ji;
+  std::vector<double> ph_lam;
+  {
+    std::vector<int32_t> cl_of_centre(N, -1);
+    for (int i = 0; i < C; i++) cl_of_centre[run.bi[i].center] = i;
+    const int cap = std::max(1 << 16, 4 * C * 64);
+    run.d_cl_of_centre.alloc(N); run.d_ph_ji.alloc(2 * (size_t)cap); run.d_ph_lam.alloc(cap); run.d_ph_n.alloc(1);
+    D2_HIP(hipMemcpyAsync(run.d_cl_of_centre.p, cl_of_centre.data(), (size_t)N * 4, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemsetAsync(run.d_ph_n.p, 0, 4, stq));
+    launch_posthoc(run.P, D, run.d_cl_of_centre.p, run.d_ph_ji.p, run.d_ph_lam.p, run.d_ph_n.p, cap, stq);
+    int32_t n = 0;
+    D2_HIP(hipMemcpyAsync(&n, run.d_ph_n.p, 4, hipMemcpyDeviceToHost, stq));
+    D2_HIP(hipStreamSynchronize(stq));
+    if (n > cap) {   // dense centre-vs-centre store: retry with the exact size
+      run.d_ph_ji.alloc(2 * (size_t)n); run.d_ph_lam.alloc(n);
+      D2_HIP(hipMemsetAsync(run.d_ph_n.p, 0, 4, stq));
+      launch_posthoc(run.P, D, run.d_cl_of_centre.p, run.d_ph_ji.p, run.d_ph_lam.p, run.d_ph_n.p, n, stq);
+      D2_HIP(hipStreamSynchronize(stq));
+    }
+    ph_ji.resize(2 * (size_t)n); ph_lam.resize(n);
+    if (n) {
+      D2_HIP(hipMemcpy(ph_ji.data(), run.d_ph_ji.p, ph_ji.size() * 4, hipMemcpyDeviceToHost));
+      D2_HIP(hipMemcpy(ph_lam.data(), run.d_ph_lam.p, ph_lam.size() * 8, hipMemcpyDeviceToHost));
+    }
+  }
 
   // birth substitutions (Rmain.cpp:209-215,231-234): parent centre vs new centre, k-mers on, cutoff 1.0.
   // One pair per wave chunk; the aligned views go to their own plane, one row per pair.
@@ -744,6 +855,23 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   }
   D2_HIP(hipStreamSynchronize(stq));
   D2_HIP(hipGetLastError());
+  {   // error flag + run totals of the screen counters
+    int32_t ef = 0;
+    unsigned long long tot[4];
+    D2_HIP(hipMemcpy(&ef, run.P.err_flag, 4, hipMemcpyDeviceToHost));
+    D2_HIP(hipMemcpy(tot, run.P.totals, 32, hipMemcpyDeviceToHost));
+    run.check_errflag(ef);
+    run.st.nnw += tot[0]; run.st.ngapless += tot[1]; run.st.nshroud = tot[2]; run.st.nskipped = tot[3];
+    int32_t cnt = 0;
+    D2_HIP(hipMemcpy(&cnt, run.P.node_count, 4, hipMemcpyDeviceToHost));
+    run.st.nstored = (uint64_t)cnt;
+    float ems;
+    for (auto &e : run.nw_events) { D2_HIP(hipEventElapsedTime(&ems, e.first, e.second)); run.st.nw_kernel_ms += ems; }
+    for (auto &e : run.screen_events) { D2_HIP(hipEventElapsedTime(&ems, e.first, e.second)); run.st.screen_kernel_ms += ems; }
+    run.st.nw_kernel_launches = run.nw_events.size();
+    run.st.screen_kernel_launches = run.screen_events.size();
+    run.st.nw_cells = run.st.nnw * run.nw_cells_per_alignment();
+  }
 
   // ---- assemble the six outputs -------------------------------------------------------------------
   R->nclust = C; R->nraw = N; R->maxlen = D.maxlen; R->ncol = err_ncol;
@@ -751,7 +879,6 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   R->abundance.assign(C, 0); R->n0.assign(C, 0); R->n1.assign(C, 0); R->nunq.assign(C, 0);
   R->birth_from.assign(C, 0); R->birth_ham.assign(C, 0); R->center.assign(C, 0);
   R->clust_pval.assign(C, 0); R->birth_pval.assign(C, 0); R->birth_fold.assign(C, 0); R->birth_qave.assign(C, 0);
-  std::unordered_map<uint32_t, int> center_of;
   for (int i = 0; i < C; i++) {   // b_make_clustering_df (error.cpp:9-127)
     const Bi &b = run.bi[i];
     uint32_t max_reads = 0;
@@ -760,7 +887,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     R->sequence[i] = max_raw >= 0 ? s->seqs[max_raw] : std::string("");
     R->center[i] = (int32_t)b.center;
     for (uint32_t raw : b.raw) {
-      if (!run.correct[raw]) continue;
+      if (!correct[raw]) continue;
       R->abundance[i] += (int32_t)s->h_reads[raw];
       R->nunq[i]++;
       if (nsubs[raw] == 0) R->n0[i] += (int32_t)s->h_reads[raw];
@@ -773,15 +900,16 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       R->birth_from[i] = (int32_t)b.birth_from + 1;
       R->birth_pval[i] = b.birth_pval; R->birth_fold[i] = b.birth_fold; R->birth_ham[i] = (int32_t)b.birth_comp.hamming;
     }
-    center_of[b.center] = i;
   }
-  {   // post-hoc p-value (error.cpp:101-119)
+  {   // post-hoc p-value (error.cpp:101-119): tot_e[j] += lambda * bi[i].reads in ascending i
     std::vector<double> tot_e(C, 0.0);
-    for (int i = 0; i < C; i++)
-      for (const Comp &cp : run.bi[i].comp) {
-        auto it = center_of.find(cp.index);
-        if (it != center_of.end() && it->second != i) tot_e[it->second] += cp.lambda * run.bi[i].reads;
-      }
+    std::vector<int32_t> order(ph_lam.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = (int32_t)k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+      if (ph_ji[2 * a] != ph_ji[2 * b]) return ph_ji[2 * a] < ph_ji[2 * b];
+      return ph_ji[2 * a + 1] < ph_ji[2 * b + 1];
+    });
+    for (int k : order) tot_e[ph_ji[2 * k]] += ph_lam[k] * run.bi[ph_ji[2 * k + 1]].reads;
     for (int i = 0; i < C; i++) R->clust_pval[i] = pp::calc_pA((int)s->h_reads[run.bi[i].center], tot_e[i], true);
   }
   // birth_subs data.frame (error.cpp:261-300) + birth_qave (error.cpp:83-92)
@@ -813,7 +941,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   }
   R->map.assign(N, DADA2HIP_NA_INTEGER);   // Rmain.cpp:268-279
   for (int i = 0; i < C; i++)
-    for (uint32_t raw : run.bi[i].raw) R->map[raw] = run.correct[raw] ? i + 1 : DADA2HIP_NA_INTEGER;
+    for (uint32_t raw : run.bi[i].raw) R->map[raw] = correct[raw] ? i + 1 : DADA2HIP_NA_INTEGER;
   run.st.ms_final = ms_since(t_final);
   run.st.ms_total = ms_since(t_total);
   R->stats = run.st;
@@ -890,21 +1018,52 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
     if (centre < 0 || centre >= s->D.N) throw InputError{"dada2hip: centre out of range"};
     check_opts(*opts, s->qmax, err_ncol);
     Run run;
-    run.s = s; run.o = *opts; run.hooks = nullptr; run.N = s->D.N; run.ncol = err_ncol;
-    memset(&run.st, 0, sizeof run.st);
-    upload_err(s, err, err_ncol, run.err_rowmajor);
-    alloc_round_buffers(s);
-    ensure_scratch(s, opts->band_size);
-    run.wclass = s->scr_class;
-    run.ap = AlignParams{opts->match, opts->mismatch, opts->gap, opts->band_size, nw_sentinel(*opts), opts->use_quals, err_ncol};
-    run.sp = ScreenParams{opts->use_kmers, opts->gapless, opts->band_size, opts->SSE};
-    run.thresh_round = make_thresh(s->D.maxlen, kdist_cutoff);
-    run.thresh_one = make_thresh(s->D.maxlen, 1.0);
-    if (skip) memcpy(s->h_skip.p, skip, (size_t)s->D.N);
-    run.device_compare(centre, kdist_cutoff == 1.0 ? 1.0 : kdist_cutoff, skip ? s->h_skip.p : nullptr, true);
-    if (lambda) memcpy(lambda, s->h_lambda.p, (size_t)s->D.N * 8);
-    if (hamming) memcpy(hamming, s->h_ham.p, (size_t)s->D.N * 4);
-    if (cls) D2_HIP(hipMemcpy(cls, s->d_cls.p, (size_t)s->D.N, hipMemcpyDeviceToHost));
+    run.hooks = nullptr;
+    init_run(run, s, err, err_ncol, opts, kdist_cutoff);
+    SampleDev &D = s->D;
+    hipStream_t stq = s->stream;
+    const int N = D.N;
+    if (skip) D2_HIP(hipMemcpyAsync(s->d_skip.p, skip, (size_t)N, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemcpyAsync(s->d_thresh.p, run.thresh_round.data(), run.thresh_round.size() * 4, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemsetAsync(s->d_counters.p, 0, 8 * 4, stq));
+    D2_HIP(hipEventRecord(s->ev0, stq));
+    launch_screen(D, centre, run.sp, skip ? s->d_skip.p : nullptr, nullptr, 0, s->d_thresh.p, s->d_cls.p, s->d_lambda.p,
+                  s->d_ham.p, s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, stq);
+    D2_HIP(hipEventRecord(s->ev1, stq));
+    launch_gapless(D, centre, nullptr, s->d_gl_list.p, s->d_counters.p + 1, 0, run.ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
+                   nullptr, 0, 0, stq);
+    D2_HIP(hipMemcpyAsync(s->h_counters.p, s->d_counters.p, 16, hipMemcpyDeviceToHost, stq));
+    D2_HIP(hipStreamSynchronize(stq));
+    float ems = 0;
+    D2_HIP(hipEventElapsedTime(&ems, s->ev0, s->ev1));
+    run.st.screen_kernel_ms = ems;
+    run.st.screen_kernel_launches = 1;
+    const int n_nw = s->h_counters.p[0];
+    run.st.ncompare = (uint64_t)N; run.st.nnw = (uint64_t)n_nw; run.st.ngapless = (uint64_t)s->h_counters.p[1];
+    run.st.nshroud = (uint64_t)s->h_counters.p[2]; run.st.nskipped = (uint64_t)s->h_counters.p[3];
+    if (n_nw > 0) {
+      const char *f = getenv("DADA2HIP_NW_KERNEL");
+      const bool coop_ok = nw_ad_lds_bytes(D, run.ap) > 0 && nw_ad_lds_bytes(D, run.ap) <= 150 * 1024;
+      bool coop = coop_ok && n_nw < 65536;
+      if (f && !strcmp(f, "lane")) coop = false;
+      if (f && !strcmp(f, "coop") && coop_ok) coop = true;
+      D2_HIP(hipEventRecord(s->ev0, stq));
+      if (coop)
+        launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, run.ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, stq);
+      else
+        launch_nw(D, run.wclass, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, run.ap, s->d_err.p, s->scr, s->d_lambda.p,
+                  s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
+      D2_HIP(hipEventRecord(s->ev1, stq));
+      D2_HIP(hipStreamSynchronize(stq));
+      D2_HIP(hipEventElapsedTime(&ems, s->ev0, s->ev1));
+      run.st.nw_kernel_ms = ems;
+      run.st.nw_kernel_launches = 1;
+      run.st.nw_cells = (uint64_t)n_nw * run.nw_cells_per_alignment();
+    }
+    if (lambda) D2_HIP(hipMemcpy(lambda, s->d_lambda.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (hamming) D2_HIP(hipMemcpy(hamming, s->d_ham.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (cls) D2_HIP(hipMemcpy(cls, s->d_cls.p, (size_t)N, hipMemcpyDeviceToHost));
+    D2_HIP(hipGetLastError());
     if (stats) *stats = run.st;
   });
 }

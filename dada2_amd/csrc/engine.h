@@ -62,13 +62,55 @@ struct ScreenParams {
   int32_t use_kmers, gapless, band, sse;
 };
 
+// Device-resident partition state (B / Bi / Raw bookkeeping fields of dada.h:65-123 as SoA).
+struct PartState {
+  double *E_minmax = nullptr;     // [N]  Raw::E_minmax
+  uint8_t *lock = nullptr;        // [N]  Raw::lock
+  int32_t *clust_of = nullptr;    // [N]  partition the unique currently belongs to
+  int32_t *comp_i = nullptr;      // [N]  Raw::comp (i, lambda, hamming)
+  double *comp_lam = nullptr;
+  uint32_t *comp_ham = nullptr;
+  double *p = nullptr;            // [N]  Raw::p
+  uint8_t *slot0 = nullptr;       // [N]  occupies slot 0 of its partition (b_bud skips r = 0, cluster.cpp:285)
+  int32_t *head = nullptr;        // [N]  head of the unique's list of stored comparisons
+  int32_t *node_i = nullptr;      // [cap] Comparison nodes (Bi::comp entries), appended round by round
+  double *node_lam = nullptr;
+  uint32_t *node_ham = nullptr;
+  int32_t *node_next = nullptr;
+  int32_t *node_count = nullptr;
+  int32_t node_cap = 0;
+  uint32_t *creads = nullptr;     // [C]  Bi::reads
+  int32_t *centre_of = nullptr;   // [C]  Bi::center
+  uint8_t *update_e = nullptr;    // [C]
+  uint8_t *check_locks = nullptr; // [C]
+  int32_t *err_flag = nullptr;
+  unsigned long long *totals = nullptr;   // [4] run totals of the screen counters
+};
+
+struct BudParams {
+  double min_fold;
+  int32_t min_hamming, min_abund;
+};
+
+void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
+                  const uint32_t *d_ham, const int32_t *d_round_counters, hipStream_t st);
+void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
+                    hipStream_t st);
+void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, hipStream_t st);
+// d_partial: 2*1024 keys of 16 B; d_best: 2 keys {double p; uint32 reads; pad}
+void launch_bud(const PartState &P, const SampleDev &S, const BudParams &bp, double init_p, uint32_t init_reads, void *d_partial,
+                void *d_best, int32_t *d_ties0, int32_t *d_ties1, int32_t *d_nties, hipStream_t st);
+void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st);
+void launch_posthoc(const PartState &P, const SampleDev &S, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam,
+                    int32_t *d_nout, int cap, hipStream_t st);
+
 // launch wrappers implemented in kernels.hip -----------------------------------------------------
 void launch_round_quals(const double *d_q, int n, int maxlen, const int32_t *d_len, uint8_t *d_out, int LQ,
                         int32_t *d_flags, hipStream_t st);
 void launch_build_kmers(const SampleDev &S, hipStream_t st);
 // counters: [0]=#NW work items, [1]=#gapless work items, [2]=#shrouded, [3]=#skipped
-void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip,
-                   const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
+void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,
+                   int greedy, const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
                    int32_t *d_gl_list, int32_t *d_counters, hipStream_t st);
 void launch_gapless(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                     const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err,

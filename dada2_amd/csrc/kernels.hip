@@ -97,7 +97,8 @@ void launch_build_kmers(const SampleDev &S, hipStream_t st) {
 // unique (4 uniques per wave); the centre's count table and ordered k-mers live in LDS.  HBM-bound:
 // algorithmic bytes per unique = 2*(len-4) (k-mer records) + 4 (len) + 1 (skip) + 1 (class out).
 __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenParams sp,
-                                                const uint8_t *__restrict__ skip, const int32_t *__restrict__ thresh,
+                                                const uint8_t *__restrict__ skip, const uint8_t *__restrict__ lock,
+                                                int greedy, const int32_t *__restrict__ thresh,
                                                 uint8_t *__restrict__ cls, double *__restrict__ lam,
                                                 uint32_t *__restrict__ ham, int32_t *__restrict__ nw_list,
                                                 int32_t *__restrict__ gl_list, int32_t *__restrict__ counters,
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
   uint16_t *ckord = (uint16_t *)(s_gl + cap);              // [LK] centre ordered k-mers
   const int tid = threadIdx.x;
   const int Lc = S.len[centre], nkc = Lc - KMER_SIZE + 1;
+  const uint32_t creads = S.reads[centre];
   for (int k = tid; k < NKMER; k += 256) ccnt[k] = 0;
   if (tid < 8) s_cnt[tid] = 0;
   __syncthreads();
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
   for (int base = blockIdx.x * 16; base < S.N; base += gridDim.x * 16) {
     const int r = base + grp;
     if (r >= S.N) continue;
-    const bool skipped = skip && skip[r];
+    // greedy skip (cluster.cpp:127-130): more reads than the centre, or locked to its partition
+    const bool skipped = (skip && skip[r]) || (greedy && (S.reads[r] > creads || (lock && lock[r])));
     uint32_t dot = 0, ord = 0;
     int Lr = 0, d = 0;
     if (!skipped) {
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
   for (int i = tid; i < s_cnt[1]; i += 256) gl_list[s_cnt[5] + i] = s_gl[i];
 }
 
-void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip,
-                   const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
+void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,
+                   int greedy, const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
                    int32_t *d_gl_list, int32_t *d_counters, hipStream_t st) {
   int grid = std::min((S.N + 15) / 16, 2048);
   int iters = ((S.N + 15) / 16 + grid - 1) / grid;
@@ -205,7 +208,7 @@ void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const
     cap = iters * 16;
     lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 16;
   }
-  hipLaunchKernelGGL(k_screen, dim3(grid), dim3(256), lds, st, S, centre, sp, d_skip, d_thresh, d_cls, d_lambda, d_ham,
+  hipLaunchKernelGGL(k_screen, dim3(grid), dim3(256), lds, st, S, centre, sp, d_skip, d_lock, greedy, d_thresh, d_cls, d_lambda, d_ham,
                      d_nw_list, d_gl_list, d_counters, cap);
 }
 
@@ -812,6 +815,268 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
       hipLaunchKernelGGL(k_nw_gen, dim3(grid), dim3(256), lds, st, a, Wgen);
     }
   }
+}
+
+// ================================================================================================
+// Device-resident partition state.  Everything that is O(nraw) per round in the
+// reference's serial bookkeeping runs here; the host only replays the (few) membership moves to keep
+// the reference's slot order, and takes the C-sized decisions.
+//
+// Stored comparisons (Bi::comp, dada.h:104) are kept per UNIQUE as a linked list of nodes
+// (cluster i, lambda, hamming): a round appends at most one node per unique, so the list is in
+// descending cluster order and b_shuffle2's arg-max (cluster.cpp:229-239) is one walk per unique.
+
+// store filter of b_compare_parallel (cluster.cpp:179-201) for the round of cluster `ci`
+__global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci, int centre, double total_reads,
+                                               const double *__restrict__ lam, const uint32_t *__restrict__ ham,
+                                               const int32_t *__restrict__ round_counters) {
+  __shared__ int s_n, s_base;
+  const uint32_t creads = S.reads[centre];
+  if (blockIdx.x == 0 && threadIdx.x < 4)   // fold this round's screen counters into the run totals
+    atomicAdd((unsigned long long *)&P.totals[threadIdx.x], (unsigned long long)round_counters[threadIdx.x]);
+  for (int base = blockIdx.x * 256; base < S.N; base += gridDim.x * 256) {
+    const int r = base + threadIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    bool keep = false;
+    double l = 0.0;
+    uint32_t h = 0;
+    int pos = 0;
+    if (r < S.N) {
+      l = lam[r];
+      h = ham[r];
+      if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);          // "Lambda out-of-range error." (cluster.cpp:184)
+      const double em = P.E_minmax[r];
+      keep = l * total_reads > em;                                     // this cluster could attract this raw
+      if (keep) {
+        if (l * creads > em) P.E_minmax[r] = l * creads;
+        pos = atomicAdd(&s_n, 1);
+        if (ci == 0 || r == centre) { P.comp_i[r] = ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_n ? atomicAdd(P.node_count, s_n) : 0;
+    __syncthreads();
+    if (keep) {
+      const int n = s_base + pos;
+      if (n < P.node_cap) {
+        P.node_i[n] = ci; P.node_lam[n] = l; P.node_ham[n] = h;
+        P.node_next[n] = P.head[r];
+        P.head[r] = n;
+      } else atomicOr(P.err_flag, 2);
+    }
+    __syncthreads();
+  }
+}
+
+// b_shuffle2 (cluster.cpp:210-266): per unique, the stored comparison with the largest expected
+// reads lambda * bi[i].reads (reads as of the start of the call; ties go to the lowest cluster),
+// then the move unless the unique is its partition's centre.  Movers are reported to the host,
+// which replays them in the reference's order to maintain slots.
+__global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const uint32_t *__restrict__ creads_snap,
+                                                 int32_t *__restrict__ movers, int32_t *__restrict__ nmovers) {
+  __shared__ int s_n, s_base;
+  for (int base = blockIdx.x * 256; base < S.N; base += gridDim.x * 256) {
+    const int r = base + threadIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    bool move = false;
+    int from = 0, to = 0, pos = 0;
+    if (r < S.N) {
+      double best_e = -1.0, best_l = 0.0;
+      int best_i = 0x7FFFFFFF;
+      uint32_t best_h = 0;
+      for (int n = P.head[r]; n >= 0; n = P.node_next[n]) {
+        const int i = P.node_i[n];
+        const double l = P.node_lam[n], e = l * creads_snap[i];
+        if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = l; best_h = P.node_ham[n]; }
+      }
+      from = P.clust_of[r];
+      if (best_i != 0x7FFFFFFF && best_i != from && r != P.centre_of[from]) {
+        move = true;
+        to = best_i;
+        P.clust_of[r] = to;
+        P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
+        atomicAdd(&P.creads[to], S.reads[r]);
+        atomicSub(&P.creads[from], S.reads[r]);
+        P.update_e[to] = 1; P.update_e[from] = 1;
+        pos = atomicAdd(&s_n, 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_n ? atomicAdd(nmovers, s_n) : 0;
+    __syncthreads();
+    if (move) { int32_t *m = movers + 3 * (size_t)(s_base + pos); m[0] = r; m[1] = from; m[2] = to; }
+    __syncthreads();
+  }
+}
+
+// get_pA (pval.cpp:67-89)
+static __device__ __forceinline__ double dev_get_pA(uint32_t reads, bool prior, bool detect_singletons, double lambda,
+                                                    uint32_t hamming, uint32_t bi_reads) {
+  if (reads == 1 && !prior && !detect_singletons) return 1.;
+  if (hamming == 0) return 1.;
+  if (lambda == 0) return 0.;
+  return pp::calc_pA((int)reads, lambda * bi_reads, prior || detect_singletons);
+}
+
+// b_p_update (pval.cpp:14-40): p-values of the members of partitions whose composition changed, and
+// greedy locking the first time a partition's centre is in place.
+__global__ __launch_bounds__(256) void k_pupdate(PartState P, SampleDev S, int greedy, int detect_singletons) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= S.N) return;
+  const int cl = P.clust_of[r];
+  const double l = P.comp_lam[r];
+  const uint32_t reads = S.reads[r];
+  if (P.update_e[cl]) P.p[r] = dev_get_pA(reads, S.prior[r] != 0, detect_singletons != 0, l, P.comp_ham[r], P.creads[cl]);
+  if (greedy && P.check_locks[cl]) {
+    const int c = P.centre_of[cl];
+    const double E_center = S.reads[c] * l;
+    if (E_center > reads) P.lock[r] = 1;
+    if (r == c) P.lock[r] = 1;
+  }
+}
+
+// b_bud (cluster.cpp:274-350), arg-min part.  Key order: p ascending, then reads descending; exact
+// ties are resolved by the host in (partition, slot) scan order.  track 0 = all candidates, 1 = priors.
+struct BudKey { double p; uint32_t reads; };
+static __device__ __forceinline__ bool bud_better(double p, uint32_t reads, const BudKey &b) {
+  return p < b.p || (p == b.p && reads > b.reads);
+}
+static __device__ __forceinline__ bool bud_candidate(const PartState &P, const SampleDev &S, int r, BudParams bp) {
+  if (P.slot0[r]) return false;                                          // r = 0 is skipped as "the centre" (:285)
+  const uint32_t reads = S.reads[r];
+  if (reads < (uint32_t)bp.min_abund) return false;
+  if ((int)P.comp_ham[r] < bp.min_hamming) return false;
+  if (!(bp.min_fold <= 1 || ((double)reads) >= bp.min_fold * P.comp_lam[r] * P.creads[P.clust_of[r]])) return false;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_bud_min(PartState P, SampleDev S, BudParams bp, BudKey init, BudKey *__restrict__ partial) {
+  __shared__ BudKey s_k[2][4];
+  BudKey b0 = init, b1 = init;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+    if (!bud_candidate(P, S, r, bp)) continue;
+    const double p = P.p[r];
+    const uint32_t reads = S.reads[r];
+    if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
+    if (S.prior[r] && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    BudKey t;
+    t.p = __shfl_xor(b0.p, o, 64); t.reads = __shfl_xor(b0.reads, o, 64);
+    if (bud_better(t.p, t.reads, b0)) b0 = t;
+    t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
+    if (bud_better(t.p, t.reads, b1)) b1 = t;
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_k[0][w] = b0; s_k[1][w] = b1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; k++) {
+      if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
+      if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
+    }
+    partial[2 * blockIdx.x] = b0;
+    partial[2 * blockIdx.x + 1] = b1;
+  }
+}
+
+// second stage: reduce the block partials (one block), publish best keys
+__global__ __launch_bounds__(256) void k_bud_final(const BudKey *__restrict__ partial, int nblocks, BudKey init, BudKey *__restrict__ best) {
+  __shared__ BudKey s_k[2][256];
+  BudKey b0 = init, b1 = init;
+  for (int k = threadIdx.x; k < nblocks; k += 256) {
+    if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
+    if (bud_better(partial[2 * k + 1].p, partial[2 * k + 1].reads, b1)) b1 = partial[2 * k + 1];
+  }
+  s_k[0][threadIdx.x] = b0; s_k[1][threadIdx.x] = b1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 256; k++) {
+      if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
+      if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
+    }
+    best[0] = b0; best[1] = b1;
+  }
+}
+
+// third stage: every candidate whose key equals the best one (normally exactly one) -> tie lists
+__global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudParams bp, BudKey init, const BudKey *__restrict__ best,
+                                                  int32_t *__restrict__ ties0, int32_t *__restrict__ ties1,
+                                                  int32_t *__restrict__ nties) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= S.N || !bud_candidate(P, S, r, bp)) return;
+  const double p = P.p[r];
+  const uint32_t reads = S.reads[r];
+  const BudKey b0 = best[0], b1 = best[1];
+  if (bud_better(b0.p, b0.reads, init) && p == b0.p && reads == b0.reads) ties0[atomicAdd(&nties[0], 1)] = r;
+  if (S.prior[r] && bud_better(b1.p, b1.reads, init) && p == b1.p && reads == b1.reads) ties1[atomicAdd(&nties[1], 1)] = r;
+}
+
+// final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252)
+__global__ __launch_bounds__(256) void k_final_p(PartState P, SampleDev S, double omegaC, uint8_t *__restrict__ correct) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= S.N) return;
+  const int cl = P.clust_of[r];
+  double p = 1.0;
+  uint8_t ok = 1;
+  if (r != P.centre_of[cl]) {
+    p = pp::calc_pA((int)S.reads[r], P.comp_lam[r] * P.creads[cl], true);
+    if (p < omegaC) ok = 0;
+  }
+  P.p[r] = p;
+  correct[r] = ok;
+}
+
+// post-hoc partition p-value inputs (error.cpp:101-119): stored comparisons of partition i whose unique
+// is the centre of another partition j -> (j, i, lambda); the host sums them in ascending i.
+__global__ __launch_bounds__(256) void k_posthoc(PartState P, SampleDev S, int nnodes, const int32_t *__restrict__ cluster_of_centre,
+                                                 const int32_t *__restrict__ node_raw, int32_t *__restrict__ out_ji,
+                                                 double *__restrict__ out_lam, int32_t *__restrict__ nout, int cap) {
+  (void)nnodes; (void)node_raw;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= S.N) return;
+  const int j = cluster_of_centre[r];
+  if (j < 0) return;
+  for (int n = P.head[r]; n >= 0; n = P.node_next[n]) {
+    const int i = P.node_i[n];
+    if (i == j) continue;
+    const int k = atomicAdd(nout, 1);
+    if (k < cap) { out_ji[2 * k] = j; out_ji[2 * k + 1] = i; out_lam[k] = P.node_lam[n]; }
+  }
+}
+
+void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
+                  const uint32_t *d_ham, const int32_t *d_round_counters, hipStream_t st) {
+  int grid = std::min((S.N + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_store, dim3(grid), dim3(256), 0, st, P, S, ci, centre, total_reads, d_lam, d_ham, d_round_counters);
+}
+void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
+                    hipStream_t st) {
+  int grid = std::min((S.N + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_shuffle, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers);
+}
+void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, hipStream_t st) {
+  hipLaunchKernelGGL(k_pupdate, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, greedy, detect_singletons);
+}
+void launch_bud(const PartState &P, const SampleDev &S, const BudParams &bp, double init_p, uint32_t init_reads, void *d_partial,
+                void *d_best, int32_t *d_ties0, int32_t *d_ties1, int32_t *d_nties, hipStream_t st) {
+  BudKey init{init_p, init_reads};
+  int grid = std::min((S.N + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_bud_min, dim3(grid), dim3(256), 0, st, P, S, bp, init, (BudKey *)d_partial);
+  hipLaunchKernelGGL(k_bud_final, dim3(1), dim3(256), 0, st, (const BudKey *)d_partial, grid, init, (BudKey *)d_best);
+  hipLaunchKernelGGL(k_bud_ties, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, bp, init, (const BudKey *)d_best, d_ties0,
+                     d_ties1, d_nties);
+}
+void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st) {
+  hipLaunchKernelGGL(k_final_p, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, omegaC, d_correct);
+}
+void launch_posthoc(const PartState &P, const SampleDev &S, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam,
+                    int32_t *d_nout, int cap, hipStream_t st) {
+  hipLaunchKernelGGL(k_posthoc, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, 0, d_cluster_of_centre, nullptr, d_out_ji,
+                     d_out_lam, d_nout, cap);
 }
 
 // ------------------------------------------------------------------------------------------------
