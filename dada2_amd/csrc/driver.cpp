@@ -322,7 +322,14 @@ struct Run {
       d_nties, d_ph_ji, d_ph_n, d_cl_of_centre;
   DevBuf<uint32_t> d_cham, d_nham, d_creads, d_creads_snap;
   DevBuf<unsigned long long> d_totals;
-  DevBuf<BudKeyH> d_partial, d_best;
+  DevBuf<BudKeyH> d_partial;
+  DevBuf<BudOut> d_budout;
+  PinBuf<BudOut> h_budout;
+  PinBuf<int32_t> h_small;                      // [0] = mover count, [8..] first movers
+  DevBuf<int32_t> d_pool, d_thresh_one, d_thresh_round;   // zeroed counter pool; k-mer threshold tables
+  size_t pool_next = 0;
+  static constexpr size_t POOL_INTS = 1 << 18;
+  static constexpr int MOVERS_INLINE = 2048;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nw_events, screen_events;
   size_t ev_used = 0;
   std::vector<uint64_t> nw_event_cells;
@@ -355,7 +362,9 @@ struct Run {
     const size_t n = (size_t)N;
     d_Emin.alloc(n); d_clam.alloc(n); d_p.alloc(n); d_lock.alloc(n); d_slot0.alloc(n); d_clof.alloc(n); d_ci.alloc(n);
     d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(3 * n); d_nmovers.alloc(1);
-    d_ties0.alloc(n); d_ties1.alloc(n); d_nties.alloc(2); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_best.alloc(2);
+    d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_budout.alloc(1);
+    h_budout.alloc(1); h_small.alloc(8 + 3 * MOVERS_INLINE); d_pool.alloc(POOL_INTS);
+    d_thresh_one.alloc(thresh_one.size()); d_thresh_round.alloc(thresh_round.size());
     P.E_minmax = d_Emin.p; P.comp_lam = d_clam.p; P.p = d_p.p; P.lock = d_lock.p; P.slot0 = d_slot0.p; P.clust_of = d_clof.p;
     P.comp_i = d_ci.p; P.comp_ham = d_cham.p; P.head = d_head.p; P.node_count = d_ncount.p; P.err_flag = d_errflag.p;
     P.totals = d_totals.p;
@@ -375,6 +384,10 @@ struct Run {
     D2_HIP(hipMemsetAsync(d_ncount.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(d_errflag.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(d_totals.p, 0, 32, stq));
+    D2_HIP(hipMemsetAsync(d_pool.p, 0, POOL_INTS * 4, stq));
+    pool_next = 0;
+    D2_HIP(hipMemcpyAsync(d_thresh_one.p, thresh_one.data(), thresh_one.size() * 4, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemcpyAsync(d_thresh_round.p, thresh_round.data(), thresh_round.size() * 4, hipMemcpyHostToDevice, stq));
     D2_HIP(hipStreamSynchronize(stq));                           // `em` goes out of scope
   }
 
@@ -408,11 +421,13 @@ struct Run {
     cr.alloc(cap); cs.alloc(cap); ce.alloc(cap); up.alloc(cap); ch.alloc(cap);
     hipStream_t stq = s->stream;
     D2_HIP(hipMemsetAsync(cr.p, 0, (size_t)cap * 4, stq));
+    D2_HIP(hipMemsetAsync(cs.p, 0, (size_t)cap * 4, stq));
     D2_HIP(hipMemsetAsync(ce.p, 0, (size_t)cap * 4, stq));
     D2_HIP(hipMemsetAsync(up.p, 0, (size_t)cap, stq));
     D2_HIP(hipMemsetAsync(ch.p, 0, (size_t)cap, stq));
     if (ccap > 0) {
       D2_HIP(hipMemcpyAsync(cr.p, d_creads.p, (size_t)ccap * 4, hipMemcpyDeviceToDevice, stq));
+      D2_HIP(hipMemcpyAsync(cs.p, d_creads_snap.p, (size_t)ccap * 4, hipMemcpyDeviceToDevice, stq));
       D2_HIP(hipMemcpyAsync(ce.p, d_centre.p, (size_t)ccap * 4, hipMemcpyDeviceToDevice, stq));
       D2_HIP(hipMemcpyAsync(up.p, d_upd.p, (size_t)ccap, hipMemcpyDeviceToDevice, stq));
       D2_HIP(hipMemcpyAsync(ch.p, d_chk.p, (size_t)ccap, hipMemcpyDeviceToDevice, stq));
@@ -425,6 +440,17 @@ struct Run {
     std::swap(d_chk.p, ch.p); std::swap(d_chk.n, ch.n);
     P.creads = d_creads.p; P.centre_of = d_centre.p; P.update_e = d_upd.p; P.check_locks = d_chk.p;
     ccap = cap;
+  }
+
+  // 8 zeroed ints from the counter pool (no per-round memset launches)
+  int32_t *pool8() {
+    if (pool_next + 8 > POOL_INTS) {
+      D2_HIP(hipMemsetAsync(d_pool.p, 0, POOL_INTS * 4, s->stream));
+      pool_next = 0;
+    }
+    int32_t *p = d_pool.p + pool_next;
+    pool_next += 8;
+    return p;
   }
 
   // publish a (new) partition's centre / reads / flags to the device
@@ -447,15 +473,14 @@ struct Run {
     hipStream_t stq = s->stream;
     const int centre = (int)bi[ci].center;
     auto t0 = clk::now();
-    const std::vector<int32_t> &th = (cutoff == 1.0) ? thresh_one : thresh_round;
-    D2_HIP(hipMemcpyAsync(s->d_thresh.p, th.data(), th.size() * 4, hipMemcpyHostToDevice, stq));
-    D2_HIP(hipMemsetAsync(s->d_counters.p, 0, 8 * 4, stq));
+    const int32_t *th = (cutoff == 1.0) ? d_thresh_one.p : d_thresh_round.p;
+    int32_t *ctr = pool8();
     auto evs = new_events(screen_events);
     D2_HIP(hipEventRecord(evs.first, stq));
-    launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, s->d_thresh.p, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
-                  s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, stq);
+    launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, th, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
+                  s->d_nw_list.p, s->d_gl_list.p, ctr, stq);
     D2_HIP(hipEventRecord(evs.second, stq));
-    launch_gapless(D, centre, nullptr, s->d_gl_list.p, s->d_counters.p + 1, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
+    launch_gapless(D, centre, nullptr, s->d_gl_list.p, ctr + 1, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
                    nullptr, 0, 0, stq);
     // NW batch size is only known on the device: both kernels loop over the device-side count with a
     // fixed persistent grid.  Round 0 aligns every unique (lane-per-alignment kernel), later rounds a few
@@ -468,12 +493,12 @@ struct Run {
     if (f && !strcmp(f, "lane")) coop = false;
     if (f && !strcmp(f, "coop") && coop_ok) coop = true;
     if (coop)
-      launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, s->d_counters.p, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, stq);
+      launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, stq);
     else
-      launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, s->d_counters.p, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
+      launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
                 s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
     D2_HIP(hipEventRecord(evn.second, stq));
-    launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, s->d_counters.p, stq);
+    launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, stq);
     st.ncompare += (uint64_t)N;
     st.ms_screen += ms_since(t0);
   }
@@ -484,16 +509,24 @@ struct Run {
     SampleDev &D = s->D;
     hipStream_t stq = s->stream;
     const int C = (int)bi.size();
-    D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)C * 4, hipMemcpyDeviceToDevice, stq));
-    D2_HIP(hipMemsetAsync(d_nmovers.p, 0, 4, stq));
-    launch_shuffle(P, D, d_creads_snap.p, d_movers.p, d_nmovers.p, stq);
-    int32_t nm = 0;
-    D2_HIP(hipMemcpyAsync(&nm, d_nmovers.p, 4, hipMemcpyDeviceToHost, stq));
+    int32_t *cnt = pool8();
+    launch_shuffle(P, D, d_creads_snap.p, d_movers.p, cnt, stq);
+    int32_t *hs = h_small.p;
+    D2_HIP(hipMemcpyAsync(hs, cnt, 4, hipMemcpyDeviceToHost, stq));
+    D2_HIP(hipMemcpyAsync(hs + 8, d_movers.p, (size_t)3 * std::min(MOVERS_INLINE, N) * 4, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
+    const int nm = hs[0];
     st.nshuffle++;
     if (nm > 0) {
-      std::vector<int32_t> mv((size_t)3 * nm);
-      D2_HIP(hipMemcpy(mv.data(), d_movers.p, mv.size() * 4, hipMemcpyDeviceToHost));
+      // partition reads changed: refresh the snapshot the next arg-max will use (reads as of call start)
+      D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)C * 4, hipMemcpyDeviceToDevice, stq));
+      std::vector<int32_t> big;
+      const int32_t *mv = hs + 8;
+      if (nm > MOVERS_INLINE) {
+        big.resize((size_t)3 * nm);
+        D2_HIP(hipMemcpy(big.data(), d_movers.p, big.size() * 4, hipMemcpyDeviceToHost));
+        mv = big.data();
+      }
       // reference order: partitions ascending, slots descending (cluster.cpp:242-259)
       std::vector<int32_t> order(nm);
       for (int k = 0; k < nm; k++) order[k] = k;
@@ -537,9 +570,7 @@ struct Run {
   void p_update() {
     auto t0 = clk::now();
     hipStream_t stq = s->stream;
-    launch_pupdate(P, s->D, o.greedy, o.detect_singletons, stq);
-    D2_HIP(hipMemsetAsync(P.update_e, 0, (size_t)bi.size(), stq));
-    D2_HIP(hipMemsetAsync(P.check_locks, 0, (size_t)bi.size(), stq));
+    launch_pupdate(P, s->D, o.greedy, o.detect_singletons, stq);   // (flags are cleared by the bud kernels that follow)
     st.ms_pval += ms_since(t0);
   }
 
@@ -550,37 +581,41 @@ struct Run {
     hipStream_t stq = s->stream;
     BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
     const uint32_t c0 = bi[0].center;
-    D2_HIP(hipMemsetAsync(d_nties.p, 0, 8, stq));
-    launch_bud(P, D, bp, 1.0, s->h_reads[c0], d_partial.p, d_best.p, d_ties0.p, d_ties1.p, d_nties.p, stq);
-    struct { BudKeyH best[2]; int32_t nties[2]; int32_t errflag; } h;
-    D2_HIP(hipMemcpyAsync(h.best, d_best.p, sizeof h.best, hipMemcpyDeviceToHost, stq));
-    D2_HIP(hipMemcpyAsync(h.nties, d_nties.p, 8, hipMemcpyDeviceToHost, stq));
-    D2_HIP(hipMemcpyAsync(&h.errflag, P.err_flag, 4, hipMemcpyDeviceToHost, stq));
+    launch_bud(P, D, bp, 1.0, s->h_reads[c0], d_partial.p, d_budout.p, d_ties0.p, d_ties1.p, (int)bi.size(), stq);
+    D2_HIP(hipMemcpyAsync(h_budout.p, d_budout.p, sizeof(BudOut), hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
     D2_HIP(hipGetLastError());
-    check_errflag(h.errflag);
-    auto pick = [&](int track) -> int {   // first tied candidate in scan order (i ascending, slot ascending)
+    const BudOut &h = *h_budout.p;
+    check_errflag(h.err_flag);
+    st.nstored = (uint64_t)h.node_count;
+    if ((size_t)h.node_count + (size_t)N > (size_t)P.node_cap)
+      grow_nodes(std::max((size_t)P.node_cap * 2, (size_t)h.node_count + 2 * (size_t)N));
+    // first tied candidate in scan order (partition ascending, slot ascending)
+    auto pick = [&](int track, BudTie &out) -> bool {
       const int n = h.nties[track];
-      if (n <= 0) return -1;
-      std::vector<int32_t> t(n);
+      if (!h.found[track] || n <= 0) return false;
+      auto before = [&](int a, int b) { return clust_of[a] < clust_of[b] || (clust_of[a] == clust_of[b] && slot_of[a] < slot_of[b]); };
+      if (n <= BUD_TIES) {
+        int bk = 0;
+        for (int k = 1; k < n; k++) if (before(h.ties[track][k].raw, h.ties[track][bk].raw)) bk = k;
+        out = h.ties[track][bk];
+        return true;
+      }
+      std::vector<int32_t> t(n);   // mass tie (e.g. many p == 0 with equal reads): fetch the full list
       D2_HIP(hipMemcpy(t.data(), track ? d_ties1.p : d_ties0.p, (size_t)n * 4, hipMemcpyDeviceToHost));
       int best = t[0];
-      for (int k = 1; k < n; k++) {
-        const int r = t[k];
-        if (clust_of[r] < clust_of[best] || (clust_of[r] == clust_of[best] && slot_of[r] < slot_of[best])) best = r;
-      }
-      return best;
+      for (int k = 1; k < n; k++) if (before(t[k], best)) best = t[k];
+      out.raw = best;
+      D2_HIP(hipMemcpy(&out.comp_i, P.comp_i + best, 4, hipMemcpyDeviceToHost));
+      D2_HIP(hipMemcpy(&out.comp_lam, P.comp_lam + best, 8, hipMemcpyDeviceToHost));
+      D2_HIP(hipMemcpy(&out.comp_ham, P.comp_ham + best, 4, hipMemcpyDeviceToHost));
+      return true;
     };
-    const int minraw = pick(0);
-    const double pA = (minraw >= 0 ? h.best[0].p : 1.0) * N;        // minraw stays the cluster-0 centre (p = 1) otherwise
     int newi = 0;
-    auto birth = [&](int raw, char type, double pval) {
-      struct { int32_t ci; double lam; uint32_t ham; } c;
-      D2_HIP(hipMemcpy(&c.ci, P.comp_i + raw, 4, hipMemcpyDeviceToHost));
-      D2_HIP(hipMemcpy(&c.lam, P.comp_lam + raw, 8, hipMemcpyDeviceToHost));
-      D2_HIP(hipMemcpy(&c.ham, P.comp_ham + raw, 4, hipMemcpyDeviceToHost));
+    auto birth = [&](const BudTie &c, char type, double pval) {
+      const int raw = c.raw;
       const int from = clust_of[raw];
-      const double expected = c.lam * bi[from].reads;
+      const double expected = c.comp_lam * bi[from].reads;
       // bi_pop_raw(from, slot)
       Bi &bf = bi[from];
       const int slot = slot_of[raw];
@@ -589,39 +624,36 @@ struct Run {
       slot_of[last] = slot;
       bf.raw.pop_back();
       bf.reads -= s->h_reads[raw];
+      const uint32_t reads_from = bf.reads;
       bi.emplace_back();
       newi = (int)bi.size() - 1;
       Bi &nb = bi[newi];
       nb.birth_type = type;
       nb.birth_from = type == 'A' ? (uint32_t)from : 0u;             // never assigned for "P" births (cluster.cpp:331-345)
       nb.birth_pval = pval; nb.birth_fold = s->h_reads[raw] / expected; nb.birth_e = expected;
-      nb.birth_comp = Comp{(uint32_t)c.ci, (uint32_t)raw, c.lam, c.ham};
+      nb.birth_comp = Comp{(uint32_t)c.comp_i, (uint32_t)raw, c.comp_lam, c.comp_ham};
       nb.raw.push_back((uint32_t)raw);
       nb.reads = s->h_reads[raw];
       nb.center = (uint32_t)raw;                                      // bi_assign_center: the only member
       slot_of[raw] = 0;
       clust_of[raw] = newi;
-      // device: membership, lock reset (bi_assign_center unlocks members), slot-0 flag, partition records
-      hipStream_t q = s->stream;
-      const int32_t ni = newi;
-      const uint8_t zero = 0, one = 1;
-      D2_HIP(hipMemcpyAsync(P.clust_of + raw, &ni, 4, hipMemcpyHostToDevice, q));
-      D2_HIP(hipMemcpyAsync(P.lock + raw, &zero, 1, hipMemcpyHostToDevice, q));
-      D2_HIP(hipMemcpyAsync(P.slot0 + raw, &one, 1, hipMemcpyHostToDevice, q));
-      D2_HIP(hipStreamSynchronize(q));
+      if (newi >= ccap) grow_clusters(std::max(ccap * 2, newi + 1));
+      launch_apply_bud(P, d_creads_snap.p, raw, newi, from, nb.reads, reads_from, s->stream);
       if (slot == 0) push_slot0();
-      push_cluster(newi, true, true);
-      push_cluster(from, true, false);   // reads changed; update_e set by bi_pop_raw (check_locks of `from` is already clear)
     };
-    if (pA < o.omegaA && minraw >= 0) {
-      birth(minraw, 'A', pA);
-      logf(", Division (naive): Raw %d from Bi %u, pA=%.2e", minraw, bi[newi].birth_from, pA);
+    BudTie c;
+    const bool have = pick(0, c);
+    const double pA = (have ? h.best_p[0] : 1.0) * N;               // minraw stays the cluster-0 centre (p = 1) otherwise
+    if (pA < o.omegaA && have) {
+      birth(c, 'A', pA);
+      logf(", Division (naive): Raw %d from Bi %u, pA=%.2e", c.raw, bi[newi].birth_from, pA);
     } else {
-      const int minraw_p = pick(1);
-      const double pP = minraw_p >= 0 ? h.best[1].p : 1.0;
-      if (pP < o.omegaP && minraw_p >= 0) {
-        birth(minraw_p, 'P', pP);
-        logf(", Division (prior): Raw %d, pP=%.2e", minraw_p, pP);
+      BudTie cp;
+      const bool havep = pick(1, cp);
+      const double pP = havep ? h.best_p[1] : 1.0;
+      if (pP < o.omegaP && havep) {
+        birth(cp, 'P', pP);
+        logf(", Division (prior): Raw %d, pP=%.2e", cp.raw, pP);
       }
     }
     st.ms_bookkeep += ms_since(t0);
@@ -717,6 +749,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     const uint8_t one = 1;
     D2_HIP(hipMemcpy(run.P.slot0, &one, 1, hipMemcpyHostToDevice));   // unique 0 sits in slot 0 of partition 0
     run.push_cluster(0, true, true);
+    D2_HIP(hipMemcpy(run.d_creads_snap.p, run.P.creads, 4, hipMemcpyDeviceToDevice));
   }
 
   run.compare_round(0, 1.0);                          // Rmain.cpp:309-310: no k-mer screen in round 0
@@ -725,7 +758,6 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   int newi;
   while ((int)run.bi.size() < max_clust && (newi = run.bud())) {
     run.logf("\nNew Cluster C%i:", newi);
-    run.ensure_node_capacity();
     run.compare_round(newi, opts->kdist_cutoff);
     int nshuffle = 0;
     bool shuffled;

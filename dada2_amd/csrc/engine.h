@@ -97,9 +97,20 @@ void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, do
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
                     hipStream_t st);
 void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, hipStream_t st);
-// d_partial: 2*1024 keys of 16 B; d_best: 2 keys {double p; uint32 reads; pad}
+// result block of one b_bud evaluation, fetched by the host in a single copy
+constexpr int BUD_TIES = 16;
+struct BudTie { int32_t raw, comp_i; uint32_t comp_ham, pad; double comp_lam; };
+struct BudOut {
+  double best_p[2];
+  uint32_t best_reads[2];
+  int32_t found[2], nties[2];
+  int32_t err_flag, node_count;
+  BudTie ties[2][BUD_TIES];
+};
 void launch_bud(const PartState &P, const SampleDev &S, const BudParams &bp, double init_p, uint32_t init_reads, void *d_partial,
-                void *d_best, int32_t *d_ties0, int32_t *d_ties1, int32_t *d_nties, hipStream_t st);
+                BudOut *d_out, int32_t *d_over0, int32_t *d_over1, int nclust, hipStream_t st);
+void launch_apply_bud(const PartState &P, uint32_t *d_creads_snap, int raw, int newi, int from, uint32_t reads_new,
+                      uint32_t reads_from, hipStream_t st);
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st);
 void launch_posthoc(const PartState &P, const SampleDev &S, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam,
                     int32_t *d_nout, int cap, hipStream_t st);

@@ -983,8 +983,11 @@ __global__ __launch_bounds__(256) void k_bud_min(PartState P, SampleDev S, BudPa
   }
 }
 
-// second stage: reduce the block partials (one block), publish best keys
-__global__ __launch_bounds__(256) void k_bud_final(const BudKey *__restrict__ partial, int nblocks, BudKey init, BudKey *__restrict__ best) {
+// second stage: reduce the block partials (one block), publish best keys; also gathers the error flag
+// and the comparison-store fill level into the result block and clears the per-partition flags that
+// k_pupdate has just consumed (pval.cpp:24,37).
+__global__ __launch_bounds__(256) void k_bud_final(PartState P, const BudKey *__restrict__ partial, int nblocks, BudKey init,
+                                                   BudOut *__restrict__ out, int nclust) {
   __shared__ BudKey s_k[2][256];
   BudKey b0 = init, b1 = init;
   for (int k = threadIdx.x; k < nblocks; k += 256) {
@@ -992,27 +995,53 @@ __global__ __launch_bounds__(256) void k_bud_final(const BudKey *__restrict__ pa
     if (bud_better(partial[2 * k + 1].p, partial[2 * k + 1].reads, b1)) b1 = partial[2 * k + 1];
   }
   s_k[0][threadIdx.x] = b0; s_k[1][threadIdx.x] = b1;
+  for (int k = threadIdx.x; k < nclust; k += 256) { P.update_e[k] = 0; P.check_locks[k] = 0; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int k = 1; k < 256; k++) {
       if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
       if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
     }
-    best[0] = b0; best[1] = b1;
+    out->best_p[0] = b0.p; out->best_p[1] = b1.p;
+    out->best_reads[0] = b0.reads; out->best_reads[1] = b1.reads;
+    out->found[0] = bud_better(b0.p, b0.reads, init); out->found[1] = bud_better(b1.p, b1.reads, init);
+    out->nties[0] = 0; out->nties[1] = 0;
+    out->err_flag = *P.err_flag;
+    out->node_count = *P.node_count;
   }
 }
 
-// third stage: every candidate whose key equals the best one (normally exactly one) -> tie lists
-__global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudParams bp, BudKey init, const BudKey *__restrict__ best,
-                                                  int32_t *__restrict__ ties0, int32_t *__restrict__ ties1,
-                                                  int32_t *__restrict__ nties) {
+// third stage: every candidate whose key equals the best one (normally exactly one) -> tie records
+__global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudParams bp, BudOut *__restrict__ out,
+                                                  int32_t *__restrict__ overflow0, int32_t *__restrict__ overflow1) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= S.N || !bud_candidate(P, S, r, bp)) return;
   const double p = P.p[r];
   const uint32_t reads = S.reads[r];
-  const BudKey b0 = best[0], b1 = best[1];
-  if (bud_better(b0.p, b0.reads, init) && p == b0.p && reads == b0.reads) ties0[atomicAdd(&nties[0], 1)] = r;
-  if (S.prior[r] && bud_better(b1.p, b1.reads, init) && p == b1.p && reads == b1.reads) ties1[atomicAdd(&nties[1], 1)] = r;
+  for (int track = 0; track < 2; track++) {
+    if (track == 1 && !S.prior[r]) continue;
+    if (!out->found[track] || p != out->best_p[track] || reads != out->best_reads[track]) continue;
+    const int k = atomicAdd(&out->nties[track], 1);
+    if (k < BUD_TIES) {
+      BudTie &t = out->ties[track][k];
+      t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
+    }
+    (track ? overflow1 : overflow0)[k] = r;
+  }
+}
+
+// Applies a birth decided by the host (cluster.cpp:313-347): the unique leaves `from`, becomes the only
+// member and centre of the new partition; bi_assign_center unlocks it; both partitions are flagged.
+__global__ void k_apply_bud(PartState P, uint32_t *creads_snap, int raw, int newi, int from, uint32_t reads_new, uint32_t reads_from) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  P.clust_of[raw] = newi;
+  P.lock[raw] = 0;
+  P.slot0[raw] = 1;
+  P.creads[newi] = reads_new; creads_snap[newi] = reads_new;
+  P.creads[from] = reads_from; creads_snap[from] = reads_from;
+  P.centre_of[newi] = raw;
+  P.update_e[newi] = 1; P.check_locks[newi] = 1;
+  P.update_e[from] = 1;
 }
 
 // final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252)
@@ -1062,13 +1091,16 @@ void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int dete
   hipLaunchKernelGGL(k_pupdate, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, greedy, detect_singletons);
 }
 void launch_bud(const PartState &P, const SampleDev &S, const BudParams &bp, double init_p, uint32_t init_reads, void *d_partial,
-                void *d_best, int32_t *d_ties0, int32_t *d_ties1, int32_t *d_nties, hipStream_t st) {
+                BudOut *d_out, int32_t *d_over0, int32_t *d_over1, int nclust, hipStream_t st) {
   BudKey init{init_p, init_reads};
   int grid = std::min((S.N + 255) / 256, 1024);
   hipLaunchKernelGGL(k_bud_min, dim3(grid), dim3(256), 0, st, P, S, bp, init, (BudKey *)d_partial);
-  hipLaunchKernelGGL(k_bud_final, dim3(1), dim3(256), 0, st, (const BudKey *)d_partial, grid, init, (BudKey *)d_best);
-  hipLaunchKernelGGL(k_bud_ties, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, bp, init, (const BudKey *)d_best, d_ties0,
-                     d_ties1, d_nties);
+  hipLaunchKernelGGL(k_bud_final, dim3(1), dim3(256), 0, st, P, (const BudKey *)d_partial, grid, init, d_out, nclust);
+  hipLaunchKernelGGL(k_bud_ties, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, bp, d_out, d_over0, d_over1);
+}
+void launch_apply_bud(const PartState &P, uint32_t *d_creads_snap, int raw, int newi, int from, uint32_t reads_new,
+                      uint32_t reads_from, hipStream_t st) {
+  hipLaunchKernelGGL(k_apply_bud, dim3(1), dim3(64), 0, st, P, d_creads_snap, raw, newi, from, reads_new, reads_from);
 }
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st) {
   hipLaunchKernelGGL(k_final_p, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, omegaC, d_correct);
