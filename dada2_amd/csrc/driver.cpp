@@ -480,8 +480,6 @@ struct Run {
     launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, th, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
                   s->d_nw_list.p, s->d_gl_list.p, ctr, stq);
     D2_HIP(hipEventRecord(evs.second, stq));
-    launch_gapless(D, centre, nullptr, s->d_gl_list.p, ctr + 1, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
-                   nullptr, 0, 0, stq);
     // NW batch size is only known on the device: both kernels loop over the device-side count with a
     // fixed persistent grid.  Round 0 aligns every unique (lane-per-alignment kernel), later rounds a few
     // thousand (cooperative kernel).
@@ -492,11 +490,14 @@ struct Run {
     bool coop = coop_ok && (ci != 0 || N < 65536);
     if (f && !strcmp(f, "lane")) coop = false;
     if (f && !strcmp(f, "coop") && coop_ok) coop = true;
-    if (coop)
-      launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, stq);
-    else
+    if (coop)   // the gapless pairings of the round share the kernel's factor/product tail
+      launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, ctr, 0, s->d_gl_list.p, ctr + 1, ap, s->d_err.p, s->d_lambda.p,
+                   s->d_ham.p, stq);
+    else {
+      launch_gapless(D, centre, nullptr, s->d_gl_list.p, ctr + 1, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, nullptr, 0, 0, stq);
       launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
                 s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
+    }
     D2_HIP(hipEventRecord(evn.second, stq));
     launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, stq);
     st.ncompare += (uint64_t)N;
@@ -1081,7 +1082,8 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
       if (f && !strcmp(f, "coop") && coop_ok) coop = true;
       D2_HIP(hipEventRecord(s->ev0, stq));
       if (coop)
-        launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, run.ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, stq);
+        launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
+                     s->d_ham.p, stq);
       else
         launch_nw(D, run.wclass, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, run.ap, s->d_err.p, s->scr, s->d_lambda.p,
                   s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);

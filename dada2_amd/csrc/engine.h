@@ -144,9 +144,10 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
                double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, uint8_t *d_moves,
                int moves_stride, int32_t *d_nmoves, hipStream_t st);
 
+// d_gl_work/d_gl_nwork (optional): the round's gapless comparisons, processed by the same kernel
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
-                  const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err, double *d_lambda,
-                  uint32_t *d_ham, hipStream_t st);
+                  const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
+                  const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, hipStream_t st);
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap);
 
 void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint8_t *d_prior, double *d_out,

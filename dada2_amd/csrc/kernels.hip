@@ -581,111 +581,156 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
 // The traceback (one lane per alignment) skips whole diagonal runs per LDS word and emits run
 // descriptors; all lanes then turn runs into per-position error-model factors in LDS, and one lane
 // multiplies them in raw-position order (pval.cpp:188-192) — bit-identical to k_nw.
+constexpr int AD_PAD = 80;   // guard bytes either side of the byte-expanded sequences (indices run -GL..len+GL)
+
+// one anti-diagonal step of one lane's live cell.  PAR is the cell parity (k = 2g + PAR).
+template <int GL, int PAR>
+static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
+                                               const uint8_t *cbytes, const uint8_t *rbytes, int t, bool g_first, bool g_last,
+                                               bool kok, int L1, int L2, int SENT, int MATCH, int MISMATCH, int GAP) {
+  // the one base that changes for the next step: raw base after an even cell, centre base after an odd one
+  const uint32_t vnext = PAR ? cbytes[i] : rbytes[j];
+  int left_src, up_src, own;
+  if (PAR == 0) {
+    const int lft = __builtin_amdgcn_update_dpp(SENT, d1, 0x138, 0xF, 0xF, false);   // lane-1's odd cell (wave_shr:1)
+    own = d0; left_src = g_first ? SENT : lft; up_src = d1;
+  } else {
+    const int upn = __builtin_amdgcn_update_dpp(SENT, d0, 0x130, 0xF, 0xF, false);   // lane+1's even cell (wave_shl:1)
+    own = d1; left_src = d0; up_src = g_last ? SENT : upn;
+  }
+  const int diag = own + (cb == rb ? MATCH : MISMATCH);
+  const int up = up_src + (j == L2 ? 0 : GAP);      // free moves along the last column
+  const int left = left_src + (i == L1 ? 0 : GAP);  // ... and the last row
+  const bool t1 = left >= diag;
+  const int e1 = max(left, diag);
+  const bool t2 = up >= e1;
+  const int e = max(up, e1);
+  const bool interior = kok && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
+  // cells before/after the matrix are never read by a live cell, so only the band edge needs the sentinel
+  const int val = interior ? e : (kok ? 0 : SENT);
+  const uint32_t p = interior ? (t2 ? 3u : (t1 ? 2u : 1u)) : (i <= 0 ? 2u : 3u);   // first row: left, first column: up
+  if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
+  pw |= p << ((t & 15) << 1);
+}
+
 template <int GL>
-__global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, int W2, int nwords, int runcap) {
+__global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
+                                               int nwords, int runcap, int seqbytes) {
   constexpr int APW = 64 / GL;
   extern __shared__ double s_dyn[];
   double *s_err = s_dyn;
   const int nerr = 16 * a.ap.ncol;
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t per_wave_words = (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * W2;
+  const size_t per_wave_words = (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * (seqbytes / 4);
   uint32_t *wbase = (uint32_t *)(s_dyn + nerr) + (size_t)wib * per_wave_words;
   uint32_t *ptr = wbase;                                   // [nwords][64]
   const int al = lane / GL, g = lane % GL;                 // alignment slot in the wave, lane in the group
   uint32_t *runs = wbase + (size_t)nwords * 64 + (size_t)al * runcap;
-  uint32_t *cseq = wbase + (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)al * 2 * W2;
-  uint32_t *rseq = cseq + W2;
+  uint8_t *cbytes = (uint8_t *)(wbase + (size_t)nwords * 64 + (size_t)APW * runcap) + (size_t)al * 2 * seqbytes + AD_PAD;
+  uint8_t *rbytes = cbytes + seqbytes;
   double *fac = (double *)ptr + (size_t)al * (nwords * 32 / APW);   // factors reuse the pointer area
   __syncthreads();
   const SampleDev &S = a.S;
   const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
-  const int nwork = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
+  const int n_nw = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
+  const int n_gl = gl_work ? *gl_nwork_dev : 0;            // gapless items ride along: same factors/product tail
+  const int nwork = n_nw + n_gl;
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
   for (int chunk = gwave; chunk * APW < nwork; chunk += nwaves) {
     const int idx = chunk * APW + al;
     const int c = a.chunk_centre ? a.chunk_centre[chunk] : a.centre;
-    int r = idx < nwork ? a.work[idx] : -1;
+    int r = idx < n_nw ? a.work[idx] : (idx < nwork ? gl_work[idx - n_nw] : -1);
+    const bool gapless = idx >= n_nw;
     const bool active = r >= 0;
     if (!active) r = c;
     const int L1 = S.len[c], L2 = S.len[r];
     const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
     const int W = lband + rband + 1;                       // <= 2*GL
-    const int T = L1 + L2;
-    // stage both sequences (2-bit words) in LDS
-    for (int w = g; w < W2; w += GL) {
-      cseq[w] = S.seq2[(size_t)c * S.W2 + w];
-      rseq[w] = S.seq2[(size_t)r * S.W2 + w];
-    }
+    const int T = (gapless || !active) ? -1 : L1 + L2;     // idle / gapless slots run no DP steps of their own
+    // stage both sequences as bytes (one base per byte, guard bytes either side)
+    for (int p = g; p < L1; p += GL) cbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)c * S.W2, p);
+    for (int p = g; p < L2; p += GL) rbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)r * S.W2, p);
     int Tmax = T;
 #pragma unroll
     for (int o = GL; o < 64; o <<= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
-    int d0 = SENT, d1 = SENT;
-    uint32_t pw = 0;
-    const int wlast = (W2 > 0 ? W2 : 1) - 1;
-    // words for step 0
-    int par = lband & 1, k = 2 * g + par;
-    int i = (0 - k + lband) >> 1, j = 0 - i;
-    uint32_t cw = cseq[min(max((i - 1) >> 4, 0), wlast)], rw = rseq[min(max((j - 1) >> 4, 0), wlast)];
-    for (int t = 0; t <= Tmax; t++) {
-      // prefetch the words of step t+1
-      const int parn = par ^ 1, kn = 2 * g + parn;
-      const int in = (t + 1 - kn + lband) >> 1, jn = t + 1 - in;
-      const uint32_t cwn = cseq[min(max((in - 1) >> 4, 0), wlast)], rwn = rseq[min(max((jn - 1) >> 4, 0), wlast)];
-      const int lft_in = __builtin_amdgcn_update_dpp(SENT, d1, 0x138, 0xF, 0xF, false);   // lane-1's d1 (wave_shr:1)
-      const int upn_in = __builtin_amdgcn_update_dpp(SENT, d0, 0x130, 0xF, 0xF, false);   // lane+1's d0 (wave_shl:1)
-      const int own = par ? d1 : d0;
-      const int left_src = par ? d0 : (g == 0 ? SENT : lft_in);
-      const int up_src = par ? (g == GL - 1 ? SENT : upn_in) : d1;
-      const uint32_t cb = (cw >> (((i - 1) & 15) << 1)) & 3u, rb = (rw >> (((j - 1) & 15) << 1)) & 3u;
-      const int diag = own + (cb == rb ? MATCH : MISMATCH);
-      const int up = up_src + (j == L2 ? 0 : GAP);
-      const int left = left_src + (i == L1 ? 0 : GAP);
-      const bool t1 = left >= diag;
-      const int e1 = t1 ? left : diag;
-      const bool t2 = up >= e1;
-      const int e = t2 ? up : e1;
-      uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
-      const bool inmat = (i >= 0) && (j >= 0) && (i <= L1) && (j <= L2) && (k < W);
-      const bool interior = inmat && (i >= 1) && (j >= 1);
-      const int val = interior ? e : (inmat ? 0 : SENT);
-      if (!interior) p = (i == 0) ? 2u : 3u;                 // first row: left, first column: up (:88-98)
-      if (par) d1 = val; else d0 = val;
-      pw |= p << ((t & 15) << 1);
-      if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
-      par = parn; k = kn; i = in; j = jn; cw = cwn; rw = rwn;
-    }
-    if ((Tmax & 15) != 15) ptr[(size_t)(Tmax >> 4) * 64 + lane] = pw;
-    // ---- traceback by the first lane of each group: run descriptors ---------------------------------
-    // descriptor: pj_lo (12 bits) | n (12 bits) << 12 | (delta + 128) << 24, delta = pi - pj; 255 << 24 = gap in centre
     int nruns = 0;
-    if (g == 0) {
-      int ti = L1, tj = L2;
-      while (ti > 0 || tj > 0) {
-        const int t = ti + tj, kk = tj - ti + lband;
-        const int col = al * GL + (kk >> 1);
-        const int f = t & 15;
-        const uint32_t word = ptr[(size_t)(t >> 4) * 64 + col];
-        // fields of this cell's parity at positions <= f that are NOT diagonal (01)
-        const uint32_t x = word ^ 0x55555555u;
-        uint32_t nz = (x | (x >> 1)) & 0x55555555u;
-        nz &= (f & 1) ? 0x44444444u : 0x11111111u;
-        nz &= (f == 15) ? 0xFFFFFFFFu : ((1u << ((f + 1) << 1)) - 1u);
-        int n;                                               // diagonal moves available inside this word
-        bool stop;
-        if (nz) { const int fb = (31 - __clz(nz)) >> 1; n = (f - fb) >> 1; stop = true; }
-        else { n = (f >> 1) + 1; stop = false; }
-        if (n > 0) {
-          // (cells on the first row/column carry pointers 2/3, so a run never crosses them)
-          runs[nruns++] = (uint32_t)(tj - n) | ((uint32_t)n << 12) | ((uint32_t)(ti - tj + 128) << 24);
-          ti -= n; tj -= n;
+    if (Tmax >= 0) {
+      int d0 = SENT, d1 = SENT;
+      uint32_t pw = 0;
+      const int par0 = lband & 1;
+      int k = 2 * g + par0;
+      int i = (0 - k + lband) >> 1, j = 0 - i;
+      uint32_t cb = cbytes[i - 1], rb = rbytes[j - 1];
+      const bool g_first = g == 0, g_last = g == GL - 1;
+      const bool kok0 = 2 * g < W, kok1 = 2 * g + 1 < W;
+      const bool uniform_even = __all(par0 == 0), uniform_odd = __all(par0 == 1);
+      int t = 0;
+      if (uniform_even || uniform_odd) {
+        // all alignments of the wave are in phase: steps alternate even / odd cells for every lane
+        if (uniform_odd) {
+          ad_step<GL, 1>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          t++;
         }
-        if (stop && (ti > 0 || tj > 0)) {   // (0,0) carries an axis pointer too: the path ends there
-          const int t2s = ti + tj;
-          const uint32_t w2 = (t2s >> 4) == (t >> 4) ? word : ptr[(size_t)(t2s >> 4) * 64 + col];
-          const uint32_t p = (w2 >> ((t2s & 15) << 1)) & 3u;
-          if (p == 2u) { tj--; runs[nruns++] = (uint32_t)tj | (1u << 12) | (255u << 24); }
-          else ti--;                                         // p == 3 (p == 1 cannot be here)
+        for (; t + 1 <= Tmax; t += 2) {
+          ad_step<GL, 0>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
+          ad_step<GL, 1>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t + 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          if (((t + 1) & 15) == 15) { ptr[(size_t)((t + 1) >> 4) * 64 + lane] = pw; pw = 0; }
+        }
+        if (t <= Tmax) {
+          ad_step<GL, 0>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
+          t++;
+        }
+      } else {
+        // mixed phases (ragged lengths): per-lane parity, both variants evaluated under the lane's own mask
+        int par = par0;
+        for (; t <= Tmax; t++) {
+          if (par == 0) ad_step<GL, 0>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          // (DPP reads of inactive lanes return their registers unchanged, which is what the neighbour needs)
+          if (par == 1) ad_step<GL, 1>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
+          par ^= 1;
+        }
+      }
+      if (((t - 1) & 15) != 15) ptr[(size_t)((t - 1) >> 4) * 64 + lane] = pw;
+    }
+    // ---- run descriptors: pj_lo (12 bits) | n (12 bits) << 12 | (delta + 128) << 24, delta = pi - pj; 255 = gap in centre
+    if (g == 0 && active) {
+      if (gapless) {
+        // nwalign_gapless (nwalign_endsfree.cpp:539-555): position-wise pairing, the longer raw's tail faces gaps
+        const int n = L1 < L2 ? L1 : L2;
+        runs[nruns++] = 0u | ((uint32_t)n << 12) | (128u << 24);
+        if (L2 > n) runs[nruns++] = (uint32_t)n | ((uint32_t)(L2 - n) << 12) | (255u << 24);
+      } else {
+        int ti = L1, tj = L2;
+        while (ti > 0 || tj > 0) {
+          const int t = ti + tj, kk = tj - ti + lband;
+          const int col = al * GL + (kk >> 1);
+          const int f = t & 15;
+          const uint32_t word = ptr[(size_t)(t >> 4) * 64 + col];
+          // fields of this cell's parity at positions <= f that are NOT diagonal (01)
+          const uint32_t x = word ^ 0x55555555u;
+          uint32_t nz = (x | (x >> 1)) & 0x55555555u;
+          nz &= (f & 1) ? 0x44444444u : 0x11111111u;
+          nz &= (f == 15) ? 0xFFFFFFFFu : ((1u << ((f + 1) << 1)) - 1u);
+          int n;                                               // diagonal moves available inside this word
+          bool stop;
+          if (nz) { const int fb = (31 - __clz(nz)) >> 1; n = (f - fb) >> 1; stop = true; }
+          else { n = (f >> 1) + 1; stop = false; }
+          if (n > 0) {
+            // (cells on the first row/column carry pointers 2/3, so a run never crosses them)
+            runs[nruns++] = (uint32_t)(tj - n) | ((uint32_t)n << 12) | ((uint32_t)(ti - tj + 128) << 24);
+            ti -= n; tj -= n;
+          }
+          if (stop && (ti > 0 || tj > 0)) {   // (0,0) carries an axis pointer too: the path ends there
+            const int t2s = ti + tj;
+            const uint32_t w2 = (t2s >> 4) == (t >> 4) ? word : ptr[(size_t)(t2s >> 4) * 64 + col];
+            const uint32_t p = (w2 >> ((t2s & 15) << 1)) & 3u;
+            if (p == 2u) { tj--; runs[nruns++] = (uint32_t)tj | (1u << 12) | (255u << 24); }
+            else ti--;                                         // p == 3 (p == 1 cannot be here)
+          }
         }
       }
     }
@@ -701,11 +746,10 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, int W2, int nwords, int
         const uint32_t dsc = runs[ri];
         const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
         for (int pj = lo + g; pj < lo + n; pj += GL) {
-          const uint32_t rb = (rseq[pj >> 4] >> ((pj & 15) << 1)) & 3u;
+          const uint32_t rb = rbytes[pj];
           uint32_t tc = 5u * rb;
           if (dl != 255) {
-            const int pi = pj + dl - 128;
-            const uint32_t cb = (cseq[pi >> 4] >> ((pi & 15) << 1)) & 3u;
+            const uint32_t cb = cbytes[pj + dl - 128];
             tc = 4u * cb + rb;
             h += (cb != rb);
           }
@@ -717,46 +761,56 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, int W2, int nwords, int
 #pragma unroll
     for (int o = 1; o < GL; o <<= 1) h += __shfl_xor(h, o, 64);
     // ---- lambda: sequential product in raw-position order, one lane per alignment --------------------
-    if (g == 0) {
+    if (g == 0 && active) {
       double l = 1.0;
       int pj = 0;
-      for (; pj + 4 <= L2; pj += 4) {
+      for (; pj + 8 <= L2; pj += 8) {
         const double f0 = fac[pj], f1 = fac[pj + 1], f2 = fac[pj + 2], f3 = fac[pj + 3];
-        l = l * f0; l = l * f1; l = l * f2; l = l * f3;
+        const double f4 = fac[pj + 4], f5 = fac[pj + 5], f6 = fac[pj + 6], f7 = fac[pj + 7];
+        l = l * f0; l = l * f1; l = l * f2; l = l * f3; l = l * f4; l = l * f5; l = l * f6; l = l * f7;
       }
       for (; pj < L2; pj++) l = l * fac[pj];
-      if (active) { a.lam[r] = l; a.ham[r] = h; }
+      a.lam[r] = l;
+      a.ham[r] = h;
     }
   }
 }
 
+static void nw_ad_geometry(const SampleDev &S, const AlignParams &ap, int &GL, int &nwords, int &runcap, int &seqbytes, size_t &lds) {
+  const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
+  GL = W <= 64 ? 32 : 64;
+  const int APW = 64 / GL;
+  const int nsteps = 2 * S.maxlen + 1;
+  nwords = (nsteps + 15) / 16;
+  while ((size_t)nwords * 32 / APW < (size_t)S.maxlen) nwords++;   // the factor area (maxlen doubles) aliases the pointer area
+  runcap = nsteps + 1;
+  seqbytes = (S.maxlen + 2 * AD_PAD + 7) & ~7;
+  const size_t per_wave = ((size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * (seqbytes / 4)) * 4;
+  lds = (size_t)16 * ap.ncol * 8 + 4 * per_wave;
+}
+
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
-                  const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err, double *d_lambda,
-                  uint32_t *d_ham, hipStream_t st) {
+                  const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
+                  const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, hipStream_t st) {
   int maxwork = d_nwork ? S.N : nwork_host;
-  if (maxwork <= 0) return;
+  if (maxwork <= 0 && !d_gl_work) return;
   NwArgs a;
   memset(&a, 0, sizeof a);
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
-  const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
-  const int GL = W <= 64 ? 32 : 64, APW = 64 / GL;
-  const int nsteps = 2 * S.maxlen + 1;
-  int nwords = (nsteps + 15) / 16;
-  // the factor area (maxlen doubles per alignment) aliases the pointer area
-  while ((size_t)nwords * 32 / APW < (size_t)S.maxlen) nwords++;
-  const int runcap = nsteps + 1;
-  const int W2 = S.W2;
-  size_t per_wave = ((size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * W2) * 4;
-  size_t lds = (size_t)16 * ap.ncol * 8 + 4 * per_wave;
-  int waves = (maxwork + APW - 1) / APW;
+  int GL, nwords, runcap, seqbytes;
+  size_t lds;
+  nw_ad_geometry(S, ap, GL, nwords, runcap, seqbytes, lds);
+  const int APW = 64 / GL;
+  int waves = (std::max(maxwork, 1) + APW - 1) / APW;
+  if (d_gl_work) waves = (S.N + APW - 1) / APW;
   int grid = std::min((waves + 3) / 4, 256 * 8);
   if (GL == 32) {
     (void)hipFuncSetAttribute((const void *)k_nw_ad<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_nw_ad<32>, dim3(grid), dim3(256), lds, st, a, W2, nwords, runcap);
+    hipLaunchKernelGGL(k_nw_ad<32>, dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, nwords, runcap, seqbytes);
   } else {
     (void)hipFuncSetAttribute((const void *)k_nw_ad<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_nw_ad<64>, dim3(grid), dim3(256), lds, st, a, W2, nwords, runcap);
+    hipLaunchKernelGGL(k_nw_ad<64>, dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, nwords, runcap, seqbytes);
   }
 }
 
@@ -765,12 +819,10 @@ size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   if (ap.band <= 0 || S.maxlen > 2047) return 0;
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 128) return 0;
-  const int GL = W <= 64 ? 32 : 64, APW = 64 / GL;
-  const int nsteps = 2 * S.maxlen + 1;
-  int nwords = (nsteps + 15) / 16;
-  while ((size_t)nwords * 32 / APW < (size_t)S.maxlen) nwords++;
-  size_t per_wave = ((size_t)nwords * 64 + (size_t)APW * (nsteps + 1) + (size_t)APW * 2 * S.W2) * 4;
-  return (size_t)16 * ap.ncol * 8 + 4 * per_wave;
+  int GL, nwords, runcap, seqbytes;
+  size_t lds;
+  nw_ad_geometry(S, ap, GL, nwords, runcap, seqbytes, lds);
+  return lds;
 }
 
 int nw_class(int band, int maxlen, int minlen) {
@@ -994,11 +1046,19 @@ __global__ __launch_bounds__(256) void k_bud_final(PartState P, const BudKey *__
     if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
     if (bud_better(partial[2 * k + 1].p, partial[2 * k + 1].reads, b1)) b1 = partial[2 * k + 1];
   }
-  s_k[0][threadIdx.x] = b0; s_k[1][threadIdx.x] = b1;
   for (int k = threadIdx.x; k < nclust; k += 256) { P.update_e[k] = 0; P.check_locks[k] = 0; }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    BudKey t;
+    t.p = __shfl_xor(b0.p, o, 64); t.reads = __shfl_xor(b0.reads, o, 64);
+    if (bud_better(t.p, t.reads, b0)) b0 = t;
+    t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
+    if (bud_better(t.p, t.reads, b1)) b1 = t;
+  }
+  if ((threadIdx.x & 63) == 0) { s_k[0][threadIdx.x >> 6] = b0; s_k[1][threadIdx.x >> 6] = b1; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 256; k++) {
+    for (int k = 1; k < 4; k++) {
       if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
       if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
     }
