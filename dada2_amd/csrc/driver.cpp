@@ -85,7 +85,7 @@ struct dada2hip_sample {
   // per-run device work buffers (kept across runs: selfConsist passes reuse them)
   DevBuf<uint8_t> d_skip, d_cls, d_correct, d_moves;
   DevBuf<double> d_lambda, d_err;
-  DevBuf<uint32_t> d_ham, scr_ptr, scr_t, d_qn;
+  DevBuf<uint32_t> d_ham, scr_ptr, scr_t, d_qn, d_ctab;
   DevBuf<int32_t> d_nw_list, d_gl_list, d_counters, d_thresh, scr_rows, d_work, d_chunk_centre, d_cluster_of,
       d_centre_of_cluster, d_trans, d_nsubs, d_nmoves;
   DevBuf<uint16_t> d_view, d_view_b;
@@ -478,7 +478,7 @@ struct Run {
     auto evs = new_events(screen_events);
     D2_HIP(hipEventRecord(evs.first, stq));
     launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, th, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
-                  s->d_nw_list.p, s->d_gl_list.p, ctr, stq);
+                  s->d_nw_list.p, s->d_gl_list.p, ctr, s->d_ctab.p, stq);
     D2_HIP(hipEventRecord(evs.second, stq));
     // NW batch size is only known on the device: both kernels loop over the device-side count with a
     // fixed persistent grid.  Round 0 aligns every unique (lane-per-alignment kernel), later rounds a few
@@ -499,7 +499,7 @@ struct Run {
                 s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
     }
     D2_HIP(hipEventRecord(evn.second, stq));
-    launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, stq);
+    launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p, stq);
     st.ncompare += (uint64_t)N;
     st.ms_screen += ms_since(t0);
   }
@@ -693,6 +693,7 @@ void alloc_round_buffers(dada2hip_sample *s) {
   const size_t N = (size_t)s->D.N;
   s->d_skip.alloc(N); s->d_cls.alloc(N); s->d_lambda.alloc(N); s->d_ham.alloc(N);
   s->d_nw_list.alloc(N); s->d_gl_list.alloc(N); s->d_counters.alloc(8); s->d_thresh.alloc(s->D.maxlen + 2);
+  s->d_ctab.alloc(NKMER + (size_t)s->D.LK / 2 + 64);
   s->h_lambda.alloc(N); s->h_ham.alloc(N); s->h_skip.alloc(N); s->h_cls.alloc(N); s->h_counters.alloc(8);
 }
 
@@ -1061,7 +1062,7 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
     D2_HIP(hipMemsetAsync(s->d_counters.p, 0, 8 * 4, stq));
     D2_HIP(hipEventRecord(s->ev0, stq));
     launch_screen(D, centre, run.sp, skip ? s->d_skip.p : nullptr, nullptr, 0, s->d_thresh.p, s->d_cls.p, s->d_lambda.p,
-                  s->d_ham.p, s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, stq);
+                  s->d_ham.p, s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, s->d_ctab.p, stq);
     D2_HIP(hipEventRecord(s->ev1, stq));
     launch_gapless(D, centre, nullptr, s->d_gl_list.p, s->d_counters.p + 1, 0, run.ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
                    nullptr, 0, 0, stq);
@@ -1073,7 +1074,11 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
     run.st.screen_kernel_launches = 1;
     const int n_nw = s->h_counters.p[0];
     run.st.ncompare = (uint64_t)N; run.st.nnw = (uint64_t)n_nw; run.st.ngapless = (uint64_t)s->h_counters.p[1];
-    run.st.nshroud = (uint64_t)s->h_counters.p[2]; run.st.nskipped = (uint64_t)s->h_counters.p[3];
+    {
+      std::vector<uint8_t> hc(N);
+      D2_HIP(hipMemcpy(hc.data(), s->d_cls.p, (size_t)N, hipMemcpyDeviceToHost));
+      for (int i = 0; i < N; i++) { run.st.nshroud += hc[i] == CLS_SHROUD; run.st.nskipped += hc[i] == CLS_SKIP; }
+    }
     if (n_nw > 0) {
       const char *f = getenv("DADA2HIP_NW_KERNEL");
       const bool coop_ok = nw_ad_lds_bytes(D, run.ap) > 0 && nw_ad_lds_bytes(D, run.ap) <= 150 * 1024;

@@ -93,7 +93,7 @@ struct BudParams {
 };
 
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
-                  const uint32_t *d_ham, const int32_t *d_round_counters, hipStream_t st);
+                  const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, hipStream_t st);
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
                     hipStream_t st);
 void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, hipStream_t st);
@@ -122,7 +122,7 @@ void launch_build_kmers(const SampleDev &S, hipStream_t st);
 // counters: [0]=#NW work items, [1]=#gapless work items, [2]=#shrouded, [3]=#skipped
 void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,
                    int greedy, const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
-                   int32_t *d_gl_list, int32_t *d_counters, hipStream_t st);
+                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, hipStream_t st);
 void launch_gapless(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                     const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err,
                     double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, hipStream_t st);

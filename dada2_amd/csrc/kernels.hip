@@ -93,6 +93,26 @@ void launch_build_kmers(const SampleDev &S, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Centre record of a round: 5-mer count table (u32[1024]) followed by the ordered k-mers (u16[LK]),
+// built once by one block so the screen blocks only copy 4.5 KB out of L2.
+__global__ __launch_bounds__(256) void k_centre_table(SampleDev S, int centre, uint32_t *__restrict__ ctab) {
+  __shared__ uint32_t cnt[NKMER];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < NKMER; k += 256) cnt[k] = 0;
+  __syncthreads();
+  const int nkc = S.len[centre] - KMER_SIZE + 1;
+  const uint16_t *crow = S.kord + (size_t)centre * S.LK;
+  uint16_t *ko = (uint16_t *)(ctab + NKMER);
+  for (int i = tid; i < S.LK; i += 256) {
+    const uint32_t km = crow[i] & 1023u;
+    if (i < nkc) atomicAdd(&cnt[km], 1u);
+    ko[i] = i < nkc ? (uint16_t)km : (uint16_t)0xFFFF;
+  }
+  __syncthreads();
+  for (int k = tid; k < NKMER; k += 256) ctab[k] = cnt[k];
+}
+
+// ------------------------------------------------------------------------------------------------
 // k-mer screen of one b_compare round: every unique against the partition centre.  16 lanes per
 // unique (4 uniques per wave); the centre's count table and ordered k-mers live in LDS.  HBM-bound:
 // algorithmic bytes per unique = 2*(len-4) (k-mer records) + 4 (len) + 1 (skip) + 1 (class out).
@@ -102,45 +122,47 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
                                                 uint8_t *__restrict__ cls, double *__restrict__ lam,
                                                 uint32_t *__restrict__ ham, int32_t *__restrict__ nw_list,
                                                 int32_t *__restrict__ gl_list, int32_t *__restrict__ counters,
-                                                int cap) {
-  extern __shared__ uint32_t s_mem[];
+                                                int cap, const uint32_t *__restrict__ ctab) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
   uint32_t *ccnt = s_mem;                                  // [1024] centre k-mer counts
   int32_t *s_cnt = (int32_t *)(s_mem + NKMER);             // [4] block-local counters, [4..5] global bases
   int32_t *s_nw = (int32_t *)(s_mem + NKMER + 8);          // [cap] this block's NW work items
   int32_t *s_gl = s_nw + cap;                              // [cap] this block's gapless work items
   uint16_t *ckord = (uint16_t *)(s_gl + cap);              // [LK] centre ordered k-mers
   const int tid = threadIdx.x;
-  const int Lc = S.len[centre], nkc = Lc - KMER_SIZE + 1;
+  const int Lc = S.len[centre];
   const uint32_t creads = S.reads[centre];
-  for (int k = tid; k < NKMER; k += 256) ccnt[k] = 0;
+  // centre record (k-mer count table + ordered k-mers) was built once for the round by k_centre_table
+  {
+    const uint4 *src = (const uint4 *)ctab;
+    ((uint4 *)ccnt)[tid] = src[tid];                                   // 1024 x u32 = 256 x 16 B
+    const int nk4 = (S.LK * 2 + 15) / 16;
+    const uint4 *srck = (const uint4 *)(ctab + NKMER);
+    for (int i = tid; i < nk4; i += 256) ((uint4 *)ckord)[i] = srck[i];
+  }
   if (tid < 8) s_cnt[tid] = 0;
   __syncthreads();
-  if (sp.use_kmers) {
-    const uint16_t *crow = S.kord + (size_t)centre * S.LK;
-    for (int i = tid; i < nkc; i += 256) {
-      uint32_t km = crow[i] & 1023u;
-      atomicAdd(&ccnt[km], 1u);
-      ckord[i] = (uint16_t)km;
-    }
-  }
-  __syncthreads();
   const int sub = tid & 15, grp = tid >> 4;
+  const int nchunk = S.LK >> 3;                               // 16-byte chunks (8 k-mer records) per row
   for (int base = blockIdx.x * 16; base < S.N; base += gridDim.x * 16) {
     const int r = base + grp;
     if (r >= S.N) continue;
+    // issue the row's first chunk and the per-unique scalars together (independent loads)
+    const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 cur = (sp.use_kmers && sub < nchunk) ? row[sub] : zero4;
+    const int Lr = S.len[r];
     // greedy skip (cluster.cpp:127-130): more reads than the centre, or locked to its partition
     const bool skipped = (skip && skip[r]) || (greedy && (S.reads[r] > creads || (lock && lock[r])));
     uint32_t dot = 0, ord = 0;
-    int Lr = 0, d = 0;
-    if (!skipped) {
-      Lr = S.len[r];
-      d = (Lc < Lr ? Lc : Lr) - KMER_SIZE + 1;
-      if (sp.use_kmers) {
-        const int nkr = Lr - KMER_SIZE + 1;
-        const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
-        for (int i0 = sub * 8; i0 < nkr; i0 += 128) {
-          uint4 v = row[i0 >> 3];
-          uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int d = (Lc < Lr ? Lc : Lr) - KMER_SIZE + 1;
+    if (!skipped && sp.use_kmers) {
+      const int nkr = Lr - KMER_SIZE + 1;
+      for (int ch = sub; ch < nchunk; ch += 16) {
+        const uint4 nxt = (ch + 16 < nchunk) ? row[ch + 16] : zero4;   // prefetch one chunk ahead
+        const int i0 = ch << 3;
+        if (i0 < nkr) {
+          const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
           for (int e = 0; e < 8; e++) {
             const int i = i0 + e;
@@ -152,6 +174,7 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
             }
           }
         }
+        cur = nxt;
       }
     }
 #pragma unroll
@@ -180,13 +203,13 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
         else c = CLS_NW;
       }
       cls[r] = c;
-      if (c == CLS_SKIP || c == CLS_SHROUD) { lam[r] = 0.0; ham[r] = 0xFFFFFFFFu; atomicAdd(&s_cnt[c == CLS_SKIP ? 3 : 2], 1); }
+      if (c == CLS_SKIP || c == CLS_SHROUD) { lam[r] = 0.0; ham[r] = 0xFFFFFFFFu; }   // (counted by k_store from cls[])
       else if (c == CLS_GAPLESS) s_gl[atomicAdd(&s_cnt[1], 1)] = r;
       else s_nw[atomicAdd(&s_cnt[0], 1)] = r;
     }
   }
   __syncthreads();
-  if (tid < 4) {
+  if (tid < 2) {
     const int n = s_cnt[tid];
     s_cnt[4 + tid] = n ? atomicAdd(&counters[tid], n) : 0;   // one global atomic per list per block
   }
@@ -197,19 +220,20 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
 
 void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,
                    int greedy, const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
-                   int32_t *d_gl_list, int32_t *d_counters, hipStream_t st) {
+                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, hipStream_t st) {
+  hipLaunchKernelGGL(k_centre_table, dim3(1), dim3(256), 0, st, S, centre, d_ctab);
   int grid = std::min((S.N + 15) / 16, 2048);
   int iters = ((S.N + 15) / 16 + grid - 1) / grid;
   int cap = iters * 16;
-  size_t lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 16;
-  while (lds > 96 * 1024) {   // very large N: more blocks, shorter per-block lists
+  size_t lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 32;
+  while (lds > 64 * 1024) {   // very large N: more blocks, shorter per-block lists
     grid *= 2;
     iters = ((S.N + 15) / 16 + grid - 1) / grid;
     cap = iters * 16;
-    lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 16;
+    lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 32;
   }
-  hipLaunchKernelGGL(k_screen, dim3(grid), dim3(256), lds, st, S, centre, sp, d_skip, d_lock, greedy, d_thresh, d_cls, d_lambda, d_ham,
-                     d_nw_list, d_gl_list, d_counters, cap);
+  hipLaunchKernelGGL(k_screen, dim3(grid), dim3(256), lds, st, S, centre, sp, d_skip, d_lock, greedy, d_thresh, d_cls, d_lambda,
+                     d_ham, d_nw_list, d_gl_list, d_counters, cap, (const uint32_t *)d_ctab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -581,13 +605,16 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
 // The traceback (one lane per alignment) skips whole diagonal runs per LDS word and emits run
 // descriptors; all lanes then turn runs into per-position error-model factors in LDS, and one lane
 // multiplies them in raw-position order (pval.cpp:188-192) — bit-identical to k_nw.
-constexpr int AD_PAD = 80;   // guard bytes either side of the byte-expanded sequences (indices run -GL..len+GL)
+// guard entries either side of the staged sequences (cell indices run about -GL .. len+GL)
+static inline int ad_pad(int GL) { return GL + 8; }
 
 // one anti-diagonal step of one lane's live cell.  PAR is the cell parity (k = 2g + PAR).
-template <int GL, int PAR>
+template <int GL, int PAR, bool DEF>
 static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
-                                               const uint8_t *cbytes, const uint8_t *rbytes, int t, bool g_first, bool g_last,
-                                               bool kok, int L1, int L2, int SENT, int MATCH, int MISMATCH, int GAP) {
+                                               const uint32_t *cbytes, const uint32_t *rbytes, int t, bool g_first, bool g_last,
+                                               bool kok, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
+  // DEF: the reference's default scoring (MATCH 5, MISMATCH -4, GAP -8, vectorized sentinel) as literals
+  const int SENT = DEF ? -32760 : SENT_, MATCH = DEF ? 5 : MATCH_, MISMATCH = DEF ? -4 : MISMATCH_, GAP = DEF ? -8 : GAP_;
   // the one base that changes for the next step: raw base after an even cell, centre base after an odd one
   const uint32_t vnext = PAR ? cbytes[i] : rbytes[j];
   int left_src, up_src, own;
@@ -613,7 +640,7 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
   pw |= p << ((t & 15) << 1);
 }
 
-template <int GL>
+template <int GL, bool DEF>
 __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                int nwords, int runcap, int seqbytes) {
   constexpr int APW = 64 / GL;
@@ -622,13 +649,13 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
   const int nerr = 16 * a.ap.ncol;
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t per_wave_words = (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * (seqbytes / 4);
+  const size_t per_wave_words = (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * seqbytes;   // seqbytes = entries (one u32 per base)
   uint32_t *wbase = (uint32_t *)(s_dyn + nerr) + (size_t)wib * per_wave_words;
   uint32_t *ptr = wbase;                                   // [nwords][64]
   const int al = lane / GL, g = lane % GL;                 // alignment slot in the wave, lane in the group
   uint32_t *runs = wbase + (size_t)nwords * 64 + (size_t)al * runcap;
-  uint8_t *cbytes = (uint8_t *)(wbase + (size_t)nwords * 64 + (size_t)APW * runcap) + (size_t)al * 2 * seqbytes + AD_PAD;
-  uint8_t *rbytes = cbytes + seqbytes;
+  uint32_t *cbytes = wbase + (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)al * 2 * seqbytes + (GL + 8);
+  uint32_t *rbytes = cbytes + seqbytes;
   double *fac = (double *)ptr + (size_t)al * (nwords * 32 / APW);   // factors reuse the pointer area
   __syncthreads();
   const SampleDev &S = a.S;
@@ -649,13 +676,14 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
     const int W = lband + rband + 1;                       // <= 2*GL
     const int T = (gapless || !active) ? -1 : L1 + L2;     // idle / gapless slots run no DP steps of their own
     // stage both sequences as bytes (one base per byte, guard bytes either side)
-    for (int p = g; p < L1; p += GL) cbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)c * S.W2, p);
-    for (int p = g; p < L2; p += GL) rbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)r * S.W2, p);
+    for (int p = g; p < L1; p += GL) cbytes[p] = base_at(S.seq2 + (size_t)c * S.W2, p);
+    for (int p = g; p < L2; p += GL) rbytes[p] = base_at(S.seq2 + (size_t)r * S.W2, p);
     int Tmax = T;
 #pragma unroll
     for (int o = GL; o < 64; o <<= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
     int nruns = 0;
-    if (Tmax >= 0) {
+    const int dbg = a.moves_stride;
+    if (Tmax >= 0 && !(dbg & 1)) {
       int d0 = SENT, d1 = SENT;
       uint32_t pw = 0;
       const int par0 = lband & 1;
@@ -669,17 +697,17 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       if (uniform_even || uniform_odd) {
         // all alignments of the wave are in phase: steps alternate even / odd cells for every lane
         if (uniform_odd) {
-          ad_step<GL, 1>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          ad_step<GL, 1, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
           t++;
         }
         for (; t + 1 <= Tmax; t += 2) {
-          ad_step<GL, 0>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
           if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
-          ad_step<GL, 1>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t + 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          ad_step<GL, 1, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t + 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
           if (((t + 1) & 15) == 15) { ptr[(size_t)((t + 1) >> 4) * 64 + lane] = pw; pw = 0; }
         }
         if (t <= Tmax) {
-          ad_step<GL, 0>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
           if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
           t++;
         }
@@ -687,9 +715,9 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
         // mixed phases (ragged lengths): per-lane parity, both variants evaluated under the lane's own mask
         int par = par0;
         for (; t <= Tmax; t++) {
-          if (par == 0) ad_step<GL, 0>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          if (par == 0) ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
           // (DPP reads of inactive lanes return their registers unchanged, which is what the neighbour needs)
-          if (par == 1) ad_step<GL, 1>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          if (par == 1) ad_step<GL, 1, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
           if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
           par ^= 1;
         }
@@ -697,7 +725,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       if (((t - 1) & 15) != 15) ptr[(size_t)((t - 1) >> 4) * 64 + lane] = pw;
     }
     // ---- run descriptors: pj_lo (12 bits) | n (12 bits) << 12 | (delta + 128) << 24, delta = pi - pj; 255 = gap in centre
-    if (g == 0 && active) {
+    if (g == 0 && active && !(dbg & 2)) {
       if (gapless) {
         // nwalign_gapless (nwalign_endsfree.cpp:539-555): position-wise pairing, the longer raw's tail faces gaps
         const int n = L1 < L2 ? L1 : L2;
@@ -705,7 +733,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
         if (L2 > n) runs[nruns++] = (uint32_t)n | ((uint32_t)(L2 - n) << 12) | (255u << 24);
       } else {
         int ti = L1, tj = L2;
-        while (ti > 0 || tj > 0) {
+        for (int guard = L1 + L2 + 2; guard > 0 && (ti > 0 || tj > 0); guard--) {   // bounded: never spin on bad pointers
           const int t = ti + tj, kk = tj - ti + lband;
           const int col = al * GL + (kk >> 1);
           const int f = t & 15;
@@ -741,7 +769,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
     // ---- factors e[pj] = err[t(pj)][q(pj)] and hamming, all lanes -----------------------------------
     const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
     uint32_t h = 0;
-    for (int ri = 0; ri < nrmax; ri++) {
+    for (int ri = 0; ri < nrmax && !(dbg & 4); ri++) {
       if (ri < nruns) {
         const uint32_t dsc = runs[ri];
         const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
@@ -761,7 +789,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
 #pragma unroll
     for (int o = 1; o < GL; o <<= 1) h += __shfl_xor(h, o, 64);
     // ---- lambda: sequential product in raw-position order, one lane per alignment --------------------
-    if (g == 0 && active) {
+    if (g == 0 && active && !(dbg & 8)) {
       double l = 1.0;
       int pj = 0;
       for (; pj + 8 <= L2; pj += 8) {
@@ -784,8 +812,8 @@ static void nw_ad_geometry(const SampleDev &S, const AlignParams &ap, int &GL, i
   nwords = (nsteps + 15) / 16;
   while ((size_t)nwords * 32 / APW < (size_t)S.maxlen) nwords++;   // the factor area (maxlen doubles) aliases the pointer area
   runcap = nsteps + 1;
-  seqbytes = (S.maxlen + 2 * AD_PAD + 7) & ~7;
-  const size_t per_wave = ((size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * (seqbytes / 4)) * 4;
+  seqbytes = (S.maxlen + 2 * ad_pad(GL) + 7) & ~7;   // entries per staged sequence (one u32 per base)
+  const size_t per_wave = ((size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * seqbytes) * 4;
   lds = (size_t)16 * ap.ncol * 8 + 4 * per_wave;
 }
 
@@ -798,6 +826,7 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   memset(&a, 0, sizeof a);
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
+  { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
   int GL, nwords, runcap, seqbytes;
   size_t lds;
   nw_ad_geometry(S, ap, GL, nwords, runcap, seqbytes, lds);
@@ -805,13 +834,16 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   int waves = (std::max(maxwork, 1) + APW - 1) / APW;
   if (d_gl_work) waves = (S.N + APW - 1) / APW;
   int grid = std::min((waves + 3) / 4, 256 * 8);
-  if (GL == 32) {
-    (void)hipFuncSetAttribute((const void *)k_nw_ad<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_nw_ad<32>, dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, nwords, runcap, seqbytes);
-  } else {
-    (void)hipFuncSetAttribute((const void *)k_nw_ad<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_nw_ad<64>, dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, nwords, runcap, seqbytes);
-  }
+  const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
+#define D2_LAUNCH_AD(GLV, DEFV)                                                                                          \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, nwords, runcap,    \
+                       seqbytes);                                                                                        \
+  } while (0)
+  if (GL == 32) { if (def) D2_LAUNCH_AD(32, true); else D2_LAUNCH_AD(32, false); }
+  else { if (def) D2_LAUNCH_AD(64, true); else D2_LAUNCH_AD(64, false); }
+#undef D2_LAUNCH_AD
 }
 
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
@@ -881,11 +913,14 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
 // store filter of b_compare_parallel (cluster.cpp:179-201) for the round of cluster `ci`
 __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci, int centre, double total_reads,
                                                const double *__restrict__ lam, const uint32_t *__restrict__ ham,
-                                               const int32_t *__restrict__ round_counters) {
-  __shared__ int s_n, s_base;
+                                               const int32_t *__restrict__ round_counters, const uint8_t *__restrict__ cls) {
+  __shared__ int s_n, s_base, s_cls[2];
   const uint32_t creads = S.reads[centre];
-  if (blockIdx.x == 0 && threadIdx.x < 4)   // fold this round's screen counters into the run totals
+  if (blockIdx.x == 0 && threadIdx.x < 2)   // fold this round's work-list sizes into the run totals
     atomicAdd((unsigned long long *)&P.totals[threadIdx.x], (unsigned long long)round_counters[threadIdx.x]);
+  if (threadIdx.x < 2) s_cls[threadIdx.x] = 0;
+  __syncthreads();
+  int my_shroud = 0, my_skip = 0;
   for (int base = blockIdx.x * 256; base < S.N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
     if (threadIdx.x == 0) s_n = 0;
@@ -897,6 +932,9 @@ __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci,
     if (r < S.N) {
       l = lam[r];
       h = ham[r];
+      const uint8_t cl = cls[r];
+      my_shroud += (cl == CLS_SHROUD);
+      my_skip += (cl == CLS_SKIP);
       if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);          // "Lambda out-of-range error." (cluster.cpp:184)
       const double em = P.E_minmax[r];
       keep = l * total_reads > em;                                     // this cluster could attract this raw
@@ -919,6 +957,13 @@ __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci,
     }
     __syncthreads();
   }
+  // class statistics of the round (nshroud / greedy skips, dada.h:113-114)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { my_shroud += __shfl_xor(my_shroud, o, 64); my_skip += __shfl_xor(my_skip, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cls[0], my_shroud); atomicAdd(&s_cls[1], my_skip); }
+  __syncthreads();
+  if (threadIdx.x < 2 && s_cls[threadIdx.x])
+    atomicAdd((unsigned long long *)&P.totals[2 + threadIdx.x], (unsigned long long)s_cls[threadIdx.x]);
 }
 
 // b_shuffle2 (cluster.cpp:210-266): per unique, the stored comparison with the largest expected
@@ -1138,9 +1183,9 @@ __global__ __launch_bounds__(256) void k_posthoc(PartState P, SampleDev S, int n
 }
 
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
-                  const uint32_t *d_ham, const int32_t *d_round_counters, hipStream_t st) {
+                  const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, hipStream_t st) {
   int grid = std::min((S.N + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_store, dim3(grid), dim3(256), 0, st, P, S, ci, centre, total_reads, d_lam, d_ham, d_round_counters);
+  hipLaunchKernelGGL(k_store, dim3(grid), dim3(256), 0, st, P, S, ci, centre, total_reads, d_lam, d_ham, d_round_counters, d_cls);
 }
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
                     hipStream_t st) {
