@@ -110,6 +110,15 @@ struct dada2hip_result {
 
 namespace {
 
+// Wait for the stream by polling: the per-round decision points (shuffle movers, bud result) sit on
+// the critical path, and a polled wait returns microseconds sooner than a blocking one.
+void sync_spin(hipStream_t st) {
+  hipError_t e;
+  while ((e = hipStreamQuery(st)) == hipErrorNotReady) {}
+  if (e != hipSuccess)
+    throw d2::DeviceError{DADA2HIP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e) + " (stream wait)"};
+}
+
 void set_err(char *errbuf, size_t errlen, const std::string &m) {
   if (errbuf && errlen) snprintf(errbuf, errlen, "%s", m.c_str());
 }
@@ -515,7 +524,7 @@ struct Run {
     int32_t *hs = h_small.p;
     D2_HIP(hipMemcpyAsync(hs, cnt, 4, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipMemcpyAsync(hs + 8, d_movers.p, (size_t)3 * std::min(MOVERS_INLINE, N) * 4, hipMemcpyDeviceToHost, stq));
-    D2_HIP(hipStreamSynchronize(stq));
+    sync_spin(stq);
     const int nm = hs[0];
     st.nshuffle++;
     if (nm > 0) {
@@ -584,7 +593,7 @@ struct Run {
     const uint32_t c0 = bi[0].center;
     launch_bud(P, D, bp, 1.0, s->h_reads[c0], d_partial.p, d_budout.p, d_ties0.p, d_ties1.p, (int)bi.size(), stq);
     D2_HIP(hipMemcpyAsync(h_budout.p, d_budout.p, sizeof(BudOut), hipMemcpyDeviceToHost, stq));
-    D2_HIP(hipStreamSynchronize(stq));
+    sync_spin(stq);
     D2_HIP(hipGetLastError());
     const BudOut &h = *h_budout.p;
     check_errflag(h.err_flag);

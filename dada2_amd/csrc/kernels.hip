@@ -163,14 +163,17 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
         const int i0 = ch << 3;
         if (i0 < nkr) {
           const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+          const uint4 ck4 = ((const uint4 *)ckord)[ch];               // the centre's 8 ordered k-mers of this chunk
+          const uint32_t cw[4] = {ck4.x, ck4.y, ck4.z, ck4.w};
 #pragma unroll
           for (int e = 0; e < 8; e++) {
             const int i = i0 + e;
             const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+            const uint32_t cx = (cw[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
             if (i < nkr) {
               const uint32_t km = x & 1023u, rk = x >> 10;
               if (rk < RANK_SAT) dot += (rk < ccnt[km]);
-              if (i < d) ord += (km == ckord[i]);
+              if (i < d) ord += (km == cx);
             }
           }
         }
@@ -607,11 +610,12 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
 // multiplies them in raw-position order (pval.cpp:188-192) — bit-identical to k_nw.
 // guard entries either side of the staged sequences (cell indices run about -GL .. len+GL)
 static inline int ad_pad(int GL) { return GL + 8; }
+constexpr int AD_RCAP = 64;   // run descriptors buffered per alignment between traceback chunks
 
 // one anti-diagonal step of one lane's live cell.  PAR is the cell parity (k = 2g + PAR).
 template <int GL, int PAR, bool DEF>
 static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
-                                               const uint32_t *cbytes, const uint32_t *rbytes, int t, bool g_first, bool g_last,
+                                               const uint8_t *cbytes, const uint8_t *rbytes, int t, bool g_first, bool g_last,
                                                bool kok, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
   // DEF: the reference's default scoring (MATCH 5, MISMATCH -4, GAP -8, vectorized sentinel) as literals
   const int SENT = DEF ? -32760 : SENT_, MATCH = DEF ? 5 : MATCH_, MISMATCH = DEF ? -4 : MISMATCH_, GAP = DEF ? -8 : GAP_;
@@ -640,23 +644,51 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
   pw |= p << ((t & 15) << 1);
 }
 
+// LDS geometry of k_nw_ad, shared by host and device
+struct AdGeom {
+  int GL, APW, NCOL;        // lanes per alignment, alignments per wave, pointer columns per alignment (= ceil(W/2))
+  int nwords;               // pointer words per column (16 steps each)
+  int area_words;           // per alignment: max(pointer words, 2*maxlen for the fp64 factors that later alias them)
+  int seqbytes;             // bytes per staged sequence incl. guards (multiple of 8)
+  int tbytes;               // bytes per transition-code / quality row (multiple of 8)
+  int per_wave_words;
+};
+static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minlen) {
+  AdGeom G;
+  const int W = 2 * band + (maxlen - minlen) + 1;
+  G.GL = W <= 64 ? 32 : 64;
+  G.APW = 64 / G.GL;
+  G.NCOL = (W + 1) / 2;
+  G.nwords = (2 * maxlen + 1 + 15) / 16;
+  G.area_words = G.nwords * G.NCOL;
+  if (G.area_words < 2 * maxlen) G.area_words = 2 * maxlen;
+  G.area_words = (G.area_words + 1) & ~1;
+  G.seqbytes = (maxlen + 2 * (G.GL + 8) + 7) & ~7;
+  G.tbytes = (maxlen + 7) & ~7;
+  G.per_wave_words = G.APW * (G.area_words + AD_RCAP + (2 * G.seqbytes + 2 * G.tbytes) / 4);
+  return G;
+}
+
 template <int GL, bool DEF>
 __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
-                                               int nwords, int runcap, int seqbytes) {
+                                               AdGeom G) {
   constexpr int APW = 64 / GL;
-  extern __shared__ double s_dyn[];
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double *s_err = s_dyn;
   const int nerr = 16 * a.ap.ncol;
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t per_wave_words = (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * seqbytes;   // seqbytes = entries (one u32 per base)
-  uint32_t *wbase = (uint32_t *)(s_dyn + nerr) + (size_t)wib * per_wave_words;
-  uint32_t *ptr = wbase;                                   // [nwords][64]
   const int al = lane / GL, g = lane % GL;                 // alignment slot in the wave, lane in the group
-  uint32_t *runs = wbase + (size_t)nwords * 64 + (size_t)al * runcap;
-  uint32_t *cbytes = wbase + (size_t)nwords * 64 + (size_t)APW * runcap + (size_t)al * 2 * seqbytes + (GL + 8);
-  uint32_t *rbytes = cbytes + seqbytes;
-  double *fac = (double *)ptr + (size_t)al * (nwords * 32 / APW);   // factors reuse the pointer area
+  // per-alignment LDS: [pointer words | later: fp64 factors][run descriptors][centre bytes][raw bytes][tcodes][quals]
+  uint32_t *abase = (uint32_t *)(s_dyn + nerr) + ((size_t)wib * APW + al) * (G.per_wave_words / APW);
+  uint32_t *ptr = abase;                                   // [nwords][NCOL]
+  double *fac = (double *)abase;
+  uint32_t *runs = abase + G.area_words;
+  uint8_t *cbytes = (uint8_t *)(runs + AD_RCAP) + (GL + 8);
+  uint8_t *rbytes = cbytes + G.seqbytes;
+  uint8_t *tcode = (uint8_t *)(runs + AD_RCAP) + 2 * G.seqbytes;
+  uint8_t *qlds = tcode + G.tbytes;
+  const int NCOL = G.NCOL;
   __syncthreads();
   const SampleDev &S = a.S;
   const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
@@ -673,15 +705,18 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
     if (!active) r = c;
     const int L1 = S.len[c], L2 = S.len[r];
     const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
-    const int W = lband + rband + 1;                       // <= 2*GL
+    const int W = lband + rband + 1;                       // <= 2*NCOL
     const int T = (gapless || !active) ? -1 : L1 + L2;     // idle / gapless slots run no DP steps of their own
-    // stage both sequences as bytes (one base per byte, guard bytes either side)
-    for (int p = g; p < L1; p += GL) cbytes[p] = base_at(S.seq2 + (size_t)c * S.W2, p);
-    for (int p = g; p < L2; p += GL) rbytes[p] = base_at(S.seq2 + (size_t)r * S.W2, p);
+    // stage both sequences (one base per byte, guard bytes either side) and the raw's qualities
+    for (int p = g; p < L1; p += GL) cbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)c * S.W2, p);
+    for (int p = g; p < L2; p += GL) rbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)r * S.W2, p);
+    {
+      const uint32_t *qsrc = (const uint32_t *)(S.qual + (size_t)r * S.LQ);
+      for (int w = g; w * 4 < L2; w += GL) ((uint32_t *)qlds)[w] = qsrc[w];
+    }
     int Tmax = T;
 #pragma unroll
     for (int o = GL; o < 64; o <<= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
-    int nruns = 0;
     const int dbg = a.moves_stride;
     if (Tmax >= 0 && !(dbg & 1)) {
       int d0 = SENT, d1 = SENT;
@@ -692,8 +727,10 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       uint32_t cb = cbytes[i - 1], rb = rbytes[j - 1];
       const bool g_first = g == 0, g_last = g == GL - 1;
       const bool kok0 = 2 * g < W, kok1 = 2 * g + 1 < W;
+      const bool colok = g < NCOL;
       const bool uniform_even = __all(par0 == 0), uniform_odd = __all(par0 == 1);
       int t = 0;
+#define AD_FLUSH(TT) if (((TT) & 15) == 15) { if (colok) ptr[((TT) >> 4) * NCOL + g] = pw; pw = 0; }
       if (uniform_even || uniform_odd) {
         // all alignments of the wave are in phase: steps alternate even / odd cells for every lane
         if (uniform_odd) {
@@ -702,13 +739,13 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
         }
         for (; t + 1 <= Tmax; t += 2) {
           ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
+          AD_FLUSH(t)
           ad_step<GL, 1, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t + 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          if (((t + 1) & 15) == 15) { ptr[(size_t)((t + 1) >> 4) * 64 + lane] = pw; pw = 0; }
+          AD_FLUSH(t + 1)
         }
         if (t <= Tmax) {
           ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
+          AD_FLUSH(t)
           t++;
         }
       } else {
@@ -716,79 +753,103 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
         int par = par0;
         for (; t <= Tmax; t++) {
           if (par == 0) ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          // (DPP reads of inactive lanes return their registers unchanged, which is what the neighbour needs)
+          // (DPP reads of inactive lanes return `old`, and group-boundary reads are masked anyway)
           if (par == 1) ad_step<GL, 1, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          if ((t & 15) == 15) { ptr[(size_t)(t >> 4) * 64 + lane] = pw; pw = 0; }
+          AD_FLUSH(t)
           par ^= 1;
         }
       }
-      if (((t - 1) & 15) != 15) ptr[(size_t)((t - 1) >> 4) * 64 + lane] = pw;
+#undef AD_FLUSH
+      if (((t - 1) & 15) != 15 && colok) ptr[((t - 1) >> 4) * NCOL + g] = pw;
     }
-    // ---- run descriptors: pj_lo (12 bits) | n (12 bits) << 12 | (delta + 128) << 24, delta = pi - pj; 255 = gap in centre
-    if (g == 0 && active && !(dbg & 2)) {
-      if (gapless) {
-        // nwalign_gapless (nwalign_endsfree.cpp:539-555): position-wise pairing, the longer raw's tail faces gaps
-        const int n = L1 < L2 ? L1 : L2;
-        runs[nruns++] = 0u | ((uint32_t)n << 12) | (128u << 24);
-        if (L2 > n) runs[nruns++] = (uint32_t)n | ((uint32_t)(L2 - n) << 12) | (255u << 24);
-      } else {
-        int ti = L1, tj = L2;
-        for (int guard = L1 + L2 + 2; guard > 0 && (ti > 0 || tj > 0); guard--) {   // bounded: never spin on bad pointers
-          const int t = ti + tj, kk = tj - ti + lband;
-          const int col = al * GL + (kk >> 1);
-          const int f = t & 15;
-          const uint32_t word = ptr[(size_t)(t >> 4) * 64 + col];
-          // fields of this cell's parity at positions <= f that are NOT diagonal (01)
-          const uint32_t x = word ^ 0x55555555u;
-          uint32_t nz = (x | (x >> 1)) & 0x55555555u;
-          nz &= (f & 1) ? 0x44444444u : 0x11111111u;
-          nz &= (f == 15) ? 0xFFFFFFFFu : ((1u << ((f + 1) << 1)) - 1u);
-          int n;                                               // diagonal moves available inside this word
-          bool stop;
-          if (nz) { const int fb = (31 - __clz(nz)) >> 1; n = (f - fb) >> 1; stop = true; }
-          else { n = (f >> 1) + 1; stop = false; }
-          if (n > 0) {
-            // (cells on the first row/column carry pointers 2/3, so a run never crosses them)
-            runs[nruns++] = (uint32_t)(tj - n) | ((uint32_t)n << 12) | ((uint32_t)(ti - tj + 128) << 24);
-            ti -= n; tj -= n;
-          }
-          if (stop && (ti > 0 || tj > 0)) {   // (0,0) carries an axis pointer too: the path ends there
-            const int t2s = ti + tj;
-            const uint32_t w2 = (t2s >> 4) == (t >> 4) ? word : ptr[(size_t)(t2s >> 4) * 64 + col];
-            const uint32_t p = (w2 >> ((t2s & 15) << 1)) & 3u;
-            if (p == 2u) { tj--; runs[nruns++] = (uint32_t)tj | (1u << 12) | (255u << 24); }
-            else ti--;                                         // p == 3 (p == 1 cannot be here)
-          }
-        }
-      }
-    }
-    nruns = __shfl(nruns, al * GL, 64);
-    int nrmax = nruns;
-#pragma unroll
-    for (int o = GL; o < 64; o <<= 1) nrmax = max(nrmax, __shfl_xor(nrmax, o, 64));
-    // ---- factors e[pj] = err[t(pj)][q(pj)] and hamming, all lanes -----------------------------------
-    const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
+    // ---- traceback (first lane of each group) in chunks of <= AD_RCAP merged runs, expanded by all lanes into one
+    //      transition code per raw position.  Run: pj_lo (12 b) | n (12 b) << 12 | (delta + 128) << 24, delta = pi - pj;
+    //      255 << 24 = gap in the centre (self transition).
+    int ti = L1, tj = L2;
+    bool done = !active || (dbg & 2);
     uint32_t h = 0;
-    for (int ri = 0; ri < nrmax && !(dbg & 4); ri++) {
-      if (ri < nruns) {
-        const uint32_t dsc = runs[ri];
-        const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
-        for (int pj = lo + g; pj < lo + n; pj += GL) {
-          const uint32_t rb = rbytes[pj];
-          uint32_t tc = 5u * rb;
-          if (dl != 255) {
-            const uint32_t cb = cbytes[pj + dl - 128];
-            tc = 4u * cb + rb;
-            h += (cb != rb);
+    int guard = L1 + L2 + 2;                               // bounded: never spin on bad pointers
+    while (true) {
+      int nruns = 0;
+      if (g == 0 && !done) {
+        uint32_t last = 0;                                 // pending (mergeable) run, 0 = none
+        auto push = [&](int lo, int n, int dl) {
+          if (last) {
+            const int llo = last & 4095, ln = (last >> 12) & 4095, ldl = (int)(last >> 24);
+            if (ldl == dl && lo + n == llo) { last = (uint32_t)lo | ((uint32_t)(ln + n) << 12) | ((uint32_t)dl << 24); return; }
+            runs[nruns++] = last;
           }
-          const uint32_t q = a.ap.use_quals ? qrow[pj] : 0u;
-          fac[pj] = s_err[tc * a.ap.ncol + q];
+          last = (uint32_t)lo | ((uint32_t)n << 12) | ((uint32_t)dl << 24);
+        };
+        if (gapless) {
+          // nwalign_gapless (nwalign_endsfree.cpp:539-555): position-wise pairing, a longer raw's tail faces gaps
+          const int n = L1 < L2 ? L1 : L2;
+          runs[nruns++] = 0u | ((uint32_t)n << 12) | (128u << 24);
+          if (L2 > n) runs[nruns++] = (uint32_t)n | ((uint32_t)(L2 - n) << 12) | (255u << 24);
+          done = true;
+        } else {
+          while ((ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard-- > 0) {
+            const int t = ti + tj, kk = tj - ti + lband;
+            const int col = kk >> 1;
+            const int f = t & 15;
+            const uint32_t word = ptr[(t >> 4) * NCOL + col];
+            // fields of this cell's parity at positions <= f that are NOT diagonal (01)
+            const uint32_t x = word ^ 0x55555555u;
+            uint32_t nz = (x | (x >> 1)) & 0x55555555u;
+            nz &= (f & 1) ? 0x44444444u : 0x11111111u;
+            nz &= (f == 15) ? 0xFFFFFFFFu : ((1u << ((f + 1) << 1)) - 1u);
+            int n;                                           // diagonal moves available inside this word
+            bool stop;
+            if (nz) { const int fb = (31 - __clz(nz)) >> 1; n = (f - fb) >> 1; stop = true; }
+            else { n = (f >> 1) + 1; stop = false; }
+            if (n > 0) {   // (cells on the first row/column carry pointers 2/3, so a run never crosses them)
+              push(tj - n, n, ti - tj + 128);
+              ti -= n; tj -= n;
+            }
+            if (stop && (ti > 0 || tj > 0)) {                // (0,0) carries an axis pointer too: the path ends there
+              const int t2s = ti + tj;
+              const uint32_t w2 = (t2s >> 4) == (t >> 4) ? word : ptr[(t2s >> 4) * NCOL + col];
+              const uint32_t p = (w2 >> ((t2s & 15) << 1)) & 3u;
+              if (p == 2u) { tj--; push(tj, 1, 255); }
+              else ti--;                                     // p == 3 (p == 1 cannot be here)
+            }
+          }
+          if (last) runs[nruns++] = last;
+          if (!(ti > 0 || tj > 0) || guard <= 0) done = true;
         }
       }
+      nruns = __shfl(nruns, al * GL, 64);
+      done = __shfl((int)done, al * GL, 64) != 0;
+      int nrmax = nruns;
+#pragma unroll
+      for (int o = GL; o < 64; o <<= 1) nrmax = max(nrmax, __shfl_xor(nrmax, o, 64));
+      for (int ri = 0; ri < nrmax; ri++) {
+        if (ri < nruns) {
+          const uint32_t dsc = runs[ri];
+          const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
+          for (int pj = lo + g; pj < lo + n; pj += GL) {
+            const uint32_t rb = rbytes[pj];
+            uint32_t tc = 5u * rb;
+            if (dl != 255) {
+              const uint32_t cb = cbytes[pj + dl - 128];
+              tc = 4u * cb + rb;
+              h += (cb != rb);
+            }
+            tcode[pj] = (uint8_t)tc;
+          }
+        }
+      }
+      if (__all(done)) break;
     }
+    // ---- factors e[pj] = err[t(pj)][q(pj)] (they overwrite the pointer area, no longer needed) ----------------
+    if (!(dbg & 4))
+      for (int pj = g; pj < L2; pj += GL) {
+        const uint32_t q = a.ap.use_quals ? qlds[pj] : 0u;
+        fac[pj] = s_err[(uint32_t)tcode[pj] * a.ap.ncol + q];
+      }
 #pragma unroll
     for (int o = 1; o < GL; o <<= 1) h += __shfl_xor(h, o, 64);
-    // ---- lambda: sequential product in raw-position order, one lane per alignment --------------------
+    // ---- lambda: sequential product in raw-position order (pval.cpp:188-192), one lane per alignment ---------
     if (g == 0 && active && !(dbg & 8)) {
       double l = 1.0;
       int pj = 0;
@@ -804,19 +865,6 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
   }
 }
 
-static void nw_ad_geometry(const SampleDev &S, const AlignParams &ap, int &GL, int &nwords, int &runcap, int &seqbytes, size_t &lds) {
-  const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
-  GL = W <= 64 ? 32 : 64;
-  const int APW = 64 / GL;
-  const int nsteps = 2 * S.maxlen + 1;
-  nwords = (nsteps + 15) / 16;
-  while ((size_t)nwords * 32 / APW < (size_t)S.maxlen) nwords++;   // the factor area (maxlen doubles) aliases the pointer area
-  runcap = nsteps + 1;
-  seqbytes = (S.maxlen + 2 * ad_pad(GL) + 7) & ~7;   // entries per staged sequence (one u32 per base)
-  const size_t per_wave = ((size_t)nwords * 64 + (size_t)APW * runcap + (size_t)APW * 2 * seqbytes) * 4;
-  lds = (size_t)16 * ap.ncol * 8 + 4 * per_wave;
-}
-
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, hipStream_t st) {
@@ -827,21 +875,18 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
   { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
-  int GL, nwords, runcap, seqbytes;
-  size_t lds;
-  nw_ad_geometry(S, ap, GL, nwords, runcap, seqbytes, lds);
-  const int APW = 64 / GL;
-  int waves = (std::max(maxwork, 1) + APW - 1) / APW;
-  if (d_gl_work) waves = (S.N + APW - 1) / APW;
+  const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
+  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
+  int waves = (std::max(maxwork, 1) + G.APW - 1) / G.APW;
+  if (d_gl_work) waves = (S.N + G.APW - 1) / G.APW;
   int grid = std::min((waves + 3) / 4, 256 * 8);
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
 #define D2_LAUNCH_AD(GLV, DEFV)                                                                                          \
   do {                                                                                                                   \
     (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, nwords, runcap,    \
-                       seqbytes);                                                                                        \
+    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);               \
   } while (0)
-  if (GL == 32) { if (def) D2_LAUNCH_AD(32, true); else D2_LAUNCH_AD(32, false); }
+  if (G.GL == 32) { if (def) D2_LAUNCH_AD(32, true); else D2_LAUNCH_AD(32, false); }
   else { if (def) D2_LAUNCH_AD(64, true); else D2_LAUNCH_AD(64, false); }
 #undef D2_LAUNCH_AD
 }
@@ -851,10 +896,8 @@ size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   if (ap.band <= 0 || S.maxlen > 2047) return 0;
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 128) return 0;
-  int GL, nwords, runcap, seqbytes;
-  size_t lds;
-  nw_ad_geometry(S, ap, GL, nwords, runcap, seqbytes, lds);
-  return lds;
+  const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
+  return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
 }
 
 int nw_class(int band, int maxlen, int minlen) {
