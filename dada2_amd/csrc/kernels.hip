@@ -613,7 +613,9 @@ static inline int ad_pad(int GL) { return GL + 8; }
 constexpr int AD_RCAP = 64;   // run descriptors buffered per alignment between traceback chunks
 
 // one anti-diagonal step of one lane's live cell.  PAR is the cell parity (k = 2g + PAR).
-template <int GL, int PAR, bool DEF>
+// LEAN: steady-state step — every in-band cell of the wave is an interior cell away from the last
+// row/column, so the matrix-edge logic (axis cells, free end gaps) is compiled out.
+template <int GL, int PAR, bool DEF, bool LEAN>
 static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
                                                const uint8_t *cbytes, const uint8_t *rbytes, int t, bool g_first, bool g_last,
                                                bool kok, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
@@ -630,16 +632,22 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
     own = d1; left_src = d0; up_src = g_last ? SENT : upn;
   }
   const int diag = own + (cb == rb ? MATCH : MISMATCH);
-  const int up = up_src + (j == L2 ? 0 : GAP);      // free moves along the last column
-  const int left = left_src + (i == L1 ? 0 : GAP);  // ... and the last row
+  const int up = up_src + ((!LEAN && j == L2) ? 0 : GAP);      // free moves along the last column
+  const int left = left_src + ((!LEAN && i == L1) ? 0 : GAP);  // ... and the last row
   const bool t1 = left >= diag;
   const int e1 = max(left, diag);
   const bool t2 = up >= e1;
   const int e = max(up, e1);
-  const bool interior = kok && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
-  // cells before/after the matrix are never read by a live cell, so only the band edge needs the sentinel
-  const int val = interior ? e : (kok ? 0 : SENT);
-  const uint32_t p = interior ? (t2 ? 3u : (t1 ? 2u : 1u)) : (i <= 0 ? 2u : 3u);   // first row: left, first column: up
+  int val;
+  uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
+  if (LEAN) {
+    val = kok ? e : SENT;
+  } else {
+    const bool interior = kok && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
+    // cells before/after the matrix are never read by a live cell, so only the band edge needs the sentinel
+    val = interior ? e : (kok ? 0 : SENT);
+    if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
+  }
   if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
   pw |= p << ((t & 15) << 1);
 }
@@ -732,29 +740,42 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       int t = 0;
 #define AD_FLUSH(TT) if (((TT) & 15) == 15) { if (colok) ptr[((TT) >> 4) * NCOL + g] = pw; pw = 0; }
       if (uniform_even || uniform_odd) {
-        // all alignments of the wave are in phase: steps alternate even / odd cells for every lane
-        if (uniform_odd) {
-          ad_step<GL, 1, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          t++;
-        }
-        for (; t + 1 <= Tmax; t += 2) {
-          ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+        // all alignments of the wave are in phase: steps alternate even / odd cells for every lane.
+        // Steady state [tA, tB): every in-band cell of every alignment in the wave is interior and off the
+        // last row / column (i >= 1, j >= 1, i < L1, j < L2 for all k in the band).
+        int tA = (lband > rband ? lband : rband) + 2, tB = min(2 * L1 - lband, 2 * L2 - rband);
+        if (T < 0) { tA = 0; tB = 0x3FFFFFFF; }             // idle / gapless slot: no constraint
+#pragma unroll
+        for (int o = GL; o < 64; o <<= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
+        tA = __builtin_amdgcn_readfirstlane(tA);
+        tB = __builtin_amdgcn_readfirstlane(tB);
+        const int p0 = uniform_odd ? 1 : 0;                  // parity of step t is (t + p0) & 1
+        if (((tA + p0) & 1) != 0) tA++;                      // the lean loop starts on an even cell
+#define AD_FULL_STEP(TT)                                                                                                        \
+  {                                                                                                                             \
+    if ((((TT) + p0) & 1) == 0)                                                                                                 \
+      ad_step<GL, 0, DEF, false>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, (TT), g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    else                                                                                                                        \
+      ad_step<GL, 1, DEF, false>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, (TT), g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    AD_FLUSH(TT)                                                                                                                \
+  }
+        const int tA_end = min(tA, Tmax + 1);
+        for (; t < tA_end; t++) AD_FULL_STEP(t)
+        for (; t + 1 < tB && t + 1 <= Tmax; t += 2) {
+          ad_step<GL, 0, DEF, true>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
           AD_FLUSH(t)
-          ad_step<GL, 1, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t + 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          ad_step<GL, 1, DEF, true>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t + 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
           AD_FLUSH(t + 1)
         }
-        if (t <= Tmax) {
-          ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          AD_FLUSH(t)
-          t++;
-        }
+        for (; t <= Tmax; t++) AD_FULL_STEP(t)
+#undef AD_FULL_STEP
       } else {
         // mixed phases (ragged lengths): per-lane parity, both variants evaluated under the lane's own mask
         int par = par0;
         for (; t <= Tmax; t++) {
-          if (par == 0) ad_step<GL, 0, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          if (par == 0) ad_step<GL, 0, DEF, false>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
           // (DPP reads of inactive lanes return `old`, and group-boundary reads are masked anyway)
-          if (par == 1) ad_step<GL, 1, DEF>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          if (par == 1) ad_step<GL, 1, DEF, false>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
           AD_FLUSH(t)
           par ^= 1;
         }
