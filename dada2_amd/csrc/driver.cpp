@@ -702,7 +702,7 @@ void alloc_round_buffers(dada2hip_sample *s) {
   const size_t N = (size_t)s->D.N;
   s->d_skip.alloc(N); s->d_cls.alloc(N); s->d_lambda.alloc(N); s->d_ham.alloc(N);
   s->d_nw_list.alloc(N); s->d_gl_list.alloc(N); s->d_counters.alloc(8); s->d_thresh.alloc(s->D.maxlen + 2);
-  s->d_ctab.alloc(NKMER + (size_t)s->D.LK / 2 + 64);
+  s->d_ctab.alloc(768 + (size_t)s->D.LK / 2 + 64);
   s->h_lambda.alloc(N); s->h_ham.alloc(N); s->h_skip.alloc(N); s->h_cls.alloc(N); s->h_counters.alloc(8);
 }
 

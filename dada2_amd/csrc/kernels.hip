@@ -93,8 +93,11 @@ void launch_build_kmers(const SampleDev &S, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Centre record of a round: 5-mer count table (u32[1024]) followed by the ordered k-mers (u16[LK]),
-// built once by one block so the screen blocks only copy 4.5 KB out of L2.
+// Centre record of a round, built once by one block so the screen blocks only copy ~3.5 KB out of L2:
+//   ctab[0..255]    : u8[1024]  min(count, 63) per 5-mer  (rank_i < min(count,63) <=> rank_i < 63 && rank_i < count)
+//   ctab[256..767]  : u16[1024] full counts (only read for the rare "heavy" k-mer correction)
+//   ctab[768.. ]    : u16[LK]   ordered k-mers, 0xFFFF past the end
+constexpr int CTAB_SAT = 0, CTAB_CNT = 256, CTAB_ORD = 768;
 __global__ __launch_bounds__(256) void k_centre_table(SampleDev S, int centre, uint32_t *__restrict__ ctab) {
   __shared__ uint32_t cnt[NKMER];
   const int tid = threadIdx.x;
@@ -102,14 +105,20 @@ __global__ __launch_bounds__(256) void k_centre_table(SampleDev S, int centre, u
   __syncthreads();
   const int nkc = S.len[centre] - KMER_SIZE + 1;
   const uint16_t *crow = S.kord + (size_t)centre * S.LK;
-  uint16_t *ko = (uint16_t *)(ctab + NKMER);
+  uint16_t *ko = (uint16_t *)(ctab + CTAB_ORD);
   for (int i = tid; i < S.LK; i += 256) {
     const uint32_t km = crow[i] & 1023u;
     if (i < nkc) atomicAdd(&cnt[km], 1u);
     ko[i] = i < nkc ? (uint16_t)km : (uint16_t)0xFFFF;
   }
   __syncthreads();
-  for (int k = tid; k < NKMER; k += 256) ctab[k] = cnt[k];
+  uint8_t *sat = (uint8_t *)(ctab + CTAB_SAT);
+  uint16_t *full = (uint16_t *)(ctab + CTAB_CNT);
+  for (int k = tid; k < NKMER; k += 256) {
+    const uint32_t c = cnt[k];
+    sat[k] = (uint8_t)(c < RANK_SAT ? c : RANK_SAT);
+    full[k] = (uint16_t)c;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -124,87 +133,96 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
                                                 int32_t *__restrict__ gl_list, int32_t *__restrict__ counters,
                                                 int cap, const uint32_t *__restrict__ ctab) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
-  uint32_t *ccnt = s_mem;                                  // [1024] centre k-mer counts
-  int32_t *s_cnt = (int32_t *)(s_mem + NKMER);             // [4] block-local counters, [4..5] global bases
-  int32_t *s_nw = (int32_t *)(s_mem + NKMER + 8);          // [cap] this block's NW work items
-  int32_t *s_gl = s_nw + cap;                              // [cap] this block's gapless work items
-  uint16_t *ckord = (uint16_t *)(s_gl + cap);              // [LK] centre ordered k-mers
+  const uint8_t *csat = (const uint8_t *)s_mem;            // [1024] min(count, 63)
+  const uint16_t *cfull = (const uint16_t *)(s_mem + CTAB_CNT);   // [1024] full counts
+  int32_t *s_cnt = (int32_t *)(s_mem + CTAB_ORD);           // [8]
+  int32_t *s_nw = s_cnt + 8;                                // [cap] this block's NW work items
+  int32_t *s_gl = s_nw + cap;                               // [cap] this block's gapless work items
+  const uint16_t *ckord = (const uint16_t *)(s_gl + cap);   // [LK] centre ordered k-mers
   const int tid = threadIdx.x;
   const int Lc = S.len[centre];
   const uint32_t creads = S.reads[centre];
-  // centre record (k-mer count table + ordered k-mers) was built once for the round by k_centre_table
-  {
+  {   // centre record built once for the round by k_centre_table
     const uint4 *src = (const uint4 *)ctab;
-    ((uint4 *)ccnt)[tid] = src[tid];                                   // 1024 x u32 = 256 x 16 B
+    for (int i = tid; i < CTAB_ORD / 4; i += 256) ((uint4 *)s_mem)[i] = src[i];
     const int nk4 = (S.LK * 2 + 15) / 16;
-    const uint4 *srck = (const uint4 *)(ctab + NKMER);
+    const uint4 *srck = (const uint4 *)(ctab + CTAB_ORD);
     for (int i = tid; i < nk4; i += 256) ((uint4 *)ckord)[i] = srck[i];
   }
   if (tid < 8) s_cnt[tid] = 0;
   __syncthreads();
   const int sub = tid & 15, grp = tid >> 4;
   const int nchunk = S.LK >> 3;                               // 16-byte chunks (8 k-mer records) per row
+  const bool two = nchunk <= 32;                              // each lane owns <= 2 chunks: keep them in registers
   for (int base = blockIdx.x * 16; base < S.N; base += gridDim.x * 16) {
     const int r = base + grp;
     if (r >= S.N) continue;
-    // issue the row's first chunk and the per-unique scalars together (independent loads)
+    // issue the row's chunks and the per-unique scalars together (independent loads)
     const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    uint4 cur = (sp.use_kmers && sub < nchunk) ? row[sub] : zero4;
+    const uint4 pad4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // rank 63: never counted
+    uint4 c0 = (sp.use_kmers && sub < nchunk) ? row[sub] : pad4;
+    uint4 c1 = (sp.use_kmers && two && sub + 16 < nchunk) ? row[sub + 16] : pad4;
     const int Lr = S.len[r];
     // greedy skip (cluster.cpp:127-130): more reads than the centre, or locked to its partition
     const bool skipped = (skip && skip[r]) || (greedy && (S.reads[r] > creads || (lock && lock[r])));
-    uint32_t dot = 0, ord = 0;
     const int d = (Lc < Lr ? Lc : Lr) - KMER_SIZE + 1;
-    if (!skipped && sp.use_kmers) {
-      const int nkr = Lr - KMER_SIZE + 1;
-      for (int ch = sub; ch < nchunk; ch += 16) {
-        const uint4 nxt = (ch + 16 < nchunk) ? row[ch + 16] : zero4;   // prefetch one chunk ahead
-        const int i0 = ch << 3;
-        if (i0 < nkr) {
-          const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-          const uint4 ck4 = ((const uint4 *)ckord)[ch];               // the centre's 8 ordered k-mers of this chunk
-          const uint32_t cw[4] = {ck4.x, ck4.y, ck4.z, ck4.w};
+    // ---- pass 1: unordered overlap  dot = #{ i : rank_i < min(count_centre[kmer_i], 63) }
+    // (rows are padded with 0xFFFF = rank 63 past len-4, so no bounds test is needed)
+    uint32_t dot = 0;
+    auto dot8 = [&](const uint4 &v) {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const int i = i0 + e;
-            const uint32_t x = (w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-            const uint32_t cx = (cw[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-            if (i < nkr) {
-              const uint32_t km = x & 1023u, rk = x >> 10;
-              if (rk < RANK_SAT) dot += (rk < ccnt[km]);
-              if (i < d) ord += (km == cx);
-            }
-          }
-        }
-        cur = nxt;
+      for (int e = 0; e < 4; e++) {
+        const uint32_t x = w[e];
+        dot += (((x >> 10) & 63u) < csat[x & 1023u]);
+        dot += ((x >> 26) < csat[(x >> 16) & 1023u]);
       }
+    };
+    if (!skipped && sp.use_kmers) {
+      dot8(c0);
+      if (two) dot8(c1);
+      else for (int ch = sub + 16; ch < nchunk; ch += 16) dot8(row[ch]);
     }
 #pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) {   // reduce over the 16-lane group
-      dot += __shfl_xor(dot, o, 16);
-      ord += __shfl_xor(ord, o, 16);
+    for (int o = 8; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 16);
+    if (!skipped && sp.use_kmers && S.HMAX > 0) {            // k-mers occurring > 63 times: exact correction
+      const int nh = S.nheavy[r];
+      for (int h = 0; h < nh; h++) {
+        const uint32_t e = S.heavy[(size_t)r * S.HMAX + h], cr = e >> 16, cc = cfull[e & 1023u];
+        const uint32_t m = cr < cc ? cr : cc;
+        if (m > RANK_SAT) dot += m - RANK_SAT;
+      }
+    }
+    dot &= 0xFFFFu;                                           // the reference accumulates in uint16_t (kmers.cpp:16,34,69)
+    const bool shroud = !skipped && sp.use_kmers && (int)dot < thresh[d];   // kdist > kdist_cutoff
+    // ---- pass 2 (survivors only, ~5 % of a round): ordered overlap over the first d positions
+    const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || Lr == Lc);   // kord_dist: -1 on unequal lengths when SSE==0
+    uint32_t ord = 0;
+    if (!skipped && !shroud && gl_ok && sp.band != 0) {
+      auto ord8 = [&](const uint4 &v, int ch) {
+        const uint4 ck4 = ((const uint4 *)ckord)[ch];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w}, cw[4] = {ck4.x, ck4.y, ck4.z, ck4.w};
+        const int i0 = ch << 3;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t t = (w[e] ^ cw[e]) & 0x03FF03FFu;    // k-mer ids only (rank bits masked off)
+          ord += ((t & 0xFFFFu) == 0 && i0 + 2 * e < d);
+          ord += ((t >> 16) == 0 && i0 + 2 * e + 1 < d);
+        }
+      };
+      if (sub < nchunk) ord8(c0, sub);
+      if (two) { if (sub + 16 < nchunk) ord8(c1, sub + 16); }
+      else for (int ch = sub + 16; ch < nchunk; ch += 16) ord8(row[ch], ch);
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) ord += __shfl_xor(ord, o, 16);
+      ord &= 0xFFFFu;
     }
     if (sub == 0) {
       uint8_t c;
-      if (skipped) {
-        c = CLS_SKIP;
-      } else {
-        if (sp.use_kmers && S.HMAX > 0) {
-          const int nh = S.nheavy[r];
-          for (int h = 0; h < nh; h++) {
-            const uint32_t e = S.heavy[(size_t)r * S.HMAX + h], km = e & 1023u, cr = e >> 16, cc = ccnt[km];
-            const uint32_t m = cr < cc ? cr : cc;
-            if (m > RANK_SAT) dot += m - RANK_SAT;
-          }
-        }
-        dot &= 0xFFFFu;   // the reference accumulates in uint16_t (kmers.cpp:16,34,69)
-        ord &= 0xFFFFu;
-        const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || Lr == Lc);   // kord_dist: -1 on unequal lengths when SSE==0
-        if (sp.use_kmers && (int)dot < thresh[d]) c = CLS_SHROUD;                       // kdist > kdist_cutoff
-        else if (sp.band == 0 || (gl_ok && ord == dot)) c = CLS_GAPLESS;                // kodist == kdist
-        else c = CLS_NW;
-      }
+      if (skipped) c = CLS_SKIP;
+      else if (shroud) c = CLS_SHROUD;
+      else if (sp.band == 0 || (gl_ok && ord == dot)) c = CLS_GAPLESS;                // kodist == kdist
+      else c = CLS_NW;
       cls[r] = c;
       if (c == CLS_SKIP || c == CLS_SHROUD) { lam[r] = 0.0; ham[r] = 0xFFFFFFFFu; }   // (counted by k_store from cls[])
       else if (c == CLS_GAPLESS) s_gl[atomicAdd(&s_cnt[1], 1)] = r;
@@ -228,12 +246,12 @@ void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const
   int grid = std::min((S.N + 15) / 16, 2048);
   int iters = ((S.N + 15) / 16 + grid - 1) / grid;
   int cap = iters * 16;
-  size_t lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 32;
+  size_t lds = (size_t)(CTAB_ORD + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 32;
   while (lds > 64 * 1024) {   // very large N: more blocks, shorter per-block lists
     grid *= 2;
     iters = ((S.N + 15) / 16 + grid - 1) / grid;
     cap = iters * 16;
-    lds = (size_t)(NKMER + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 32;
+    lds = (size_t)(CTAB_ORD + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 32;
   }
   hipLaunchKernelGGL(k_screen, dim3(grid), dim3(256), lds, st, S, centre, sp, d_skip, d_lock, greedy, d_thresh, d_cls, d_lambda,
                      d_ham, d_nw_list, d_gl_list, d_counters, cap, (const uint32_t *)d_ctab);
