@@ -138,3 +138,59 @@ def test_size_independent_properties_at_scale(api):
     # idempotence: a second run on the same resident inputs gives identical output
     r2 = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())
     assert_results_equal(r, r2, exact_float=True)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 65])
+def test_tiny_inputs(api, oracle_c, n):
+    """Degenerate sizes: a single unique, fewer uniques than a wave, one over a wave."""
+    d = _sample(200 + n, max(n, 8), L=60, G=8)
+    seqs, ab, q = d.seqs[:n], d.abundances[:n], d.quals[:n]
+    got = api.dada_uniques(seqs, ab, None, tperr1(), q, DadaOpts())
+    want = oracle_c.dada_uniques(seqs, ab, None, tperr1(), q, DadaOpts())
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+def test_unsorted_input_keeps_reference_slot_semantics(api, oracle_c):
+    """b_bud skips slot 0 as 'the centre' (cluster.cpp:285) — only true for abundance-sorted input.
+    Feed the uniques in reverse order: the reference's quirk must be reproduced, not fixed."""
+    d = _sample(301, 500, L=100, G=8)
+    seqs, ab, q = d.seqs[::-1], d.abundances[::-1].copy(), d.quals[::-1].copy()
+    got = api.dada_uniques(seqs, ab, None, tperr1(), q, DadaOpts())
+    want = oracle_c.dada_uniques(seqs, ab, None, tperr1(), q, DadaOpts())
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+def test_low_complexity_heavy_kmers(api, oracle_c):
+    """Sequences whose 5-mers repeat > 63 times exercise the saturated-rank correction of the screen
+    (the reference's u8 tables overflow there and fall back to u16, nwalign_endsfree.cpp:23-26)."""
+    rng = np.random.default_rng(5)
+    base = "A" * 120 + "ACGTTGCA" * 10 + "C" * 100
+    seqs, ab = [base], [500]
+    for k in range(60):
+        s = list(base)
+        for _ in range(int(rng.integers(1, 6))):
+            p = int(rng.integers(0, len(s)))
+            s[p] = "ACGT"[int(rng.integers(0, 4))]
+        s = "".join(s)
+        if s not in seqs:
+            seqs.append(s)
+            ab.append(int(rng.integers(1, 40)))
+    order = np.argsort(-np.array(ab), kind="stable")
+    seqs = [seqs[i] for i in order]
+    ab = np.array(ab, dtype=np.int32)[order]
+    q = np.full((len(seqs), len(base)), 30.0)
+    got = api.dada_uniques(seqs, ab, None, tperr1(), q, DadaOpts())
+    want = oracle_c.dada_uniques(seqs, ab, None, tperr1(), q, DadaOpts())
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+def test_errors_keep_reference_messages(api):
+    from dada2_amd import _lib
+    d = _sample(302, 100, L=60, G=4)
+    with pytest.raises(_lib.Dada2HipError, match="exceeded range of err lookup table"):
+        api.dada_uniques(d.seqs, d.abundances, None, tperr1()[:, :20], d.quals, DadaOpts())
+    with pytest.raises(_lib.Dada2HipError, match="A/C/G/T"):
+        api.dada_uniques(["ACGTNACGTA", "ACGTAACGTA"], [5, 1], None, tperr1(), np.full((2, 10), 30.0), DadaOpts())
+    with pytest.raises(_lib.Dada2HipError) as ei:
+        api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts(HOMOPOLYMER_GAP_PENALTY=-1))
+    assert ei.value.code == 4
