@@ -114,6 +114,13 @@ def main():
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None,
                    "avg_launch_ms": sc_ms / sc_n, "launches": st["screen_kernel_launches"]}
         roof_sc["frac"] = roof_sc["achieved"] / roof_sc["peak"]
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_traffic.json;
+        # bench.py cannot run the profiler on itself) — null when no matching profile is committed
+        tr = load_traffic()
+        if tr and args.uniques == 100_000 and args.length == 250:
+            roof_nw["traffic"] = tr.get("void k_nw_ad<32, true>", {}).get("hbm_bytes_per_launch")
+            roof_sc["traffic"] = tr.get("k_screen", {}).get("hbm_bytes_per_launch")
+            roof_nw["traffic_source"] = roof_sc["traffic_source"] = tr.get("_file")
         roofline = roof_nw if nw_ms >= sc_ms else roof_sc
         other = roof_sc if nw_ms >= sc_ms else roof_nw
 
@@ -142,6 +149,17 @@ def main():
     smp.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def load_traffic():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    t = json.load(open(files[-1]))
+    k = dict(t.get("kernels", {}))
+    k["_file"] = os.path.relpath(files[-1], ROOT)
+    return k
 
 
 def cpu_baseline(d, err, opts, cpu_uniques, gpu_res):

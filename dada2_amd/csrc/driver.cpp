@@ -90,9 +90,6 @@ struct dada2hip_sample {
       d_centre_of_cluster, d_trans, d_nsubs, d_nmoves;
   DevBuf<uint16_t> d_view, d_view_b;
   DevBuf<unsigned long long> d_qsum;
-  PinBuf<double> h_lambda;
-  PinBuf<uint32_t> h_ham;
-  PinBuf<uint8_t> h_skip, h_cls;
   PinBuf<int32_t> h_counters;
   NwScratch scr;
   int scr_class = -1, scr_band = 0;
@@ -113,6 +110,8 @@ namespace {
 // Wait for the stream by polling: the per-round decision points (shuffle movers, bud result) sit on
 // the critical path, and a polled wait returns microseconds sooner than a blocking one.
 void sync_spin(hipStream_t st) {
+  static const int mode = [] { const char *e = getenv("DADA2HIP_WAIT"); return (e && !strcmp(e, "block")) ? 0 : 1; }();
+  if (mode == 0) { D2_HIP(hipStreamSynchronize(st)); return; }
   hipError_t e;
   while ((e = hipStreamQuery(st)) == hipErrorNotReady) {}
   if (e != hipSuccess)
@@ -328,7 +327,7 @@ struct Run {
   DevBuf<double> d_Emin, d_clam, d_p, d_nlam, d_ph_lam;
   DevBuf<uint8_t> d_lock, d_slot0, d_upd, d_chk;
   DevBuf<int32_t> d_clof, d_ci, d_head, d_ni, d_nnext, d_ncount, d_centre, d_errflag, d_movers, d_nmovers, d_ties0, d_ties1,
-      d_nties, d_ph_ji, d_ph_n, d_cl_of_centre;
+      d_ph_ji, d_ph_n, d_cl_of_centre;
   DevBuf<uint32_t> d_cham, d_nham, d_creads, d_creads_snap;
   DevBuf<unsigned long long> d_totals;
   DevBuf<BudKeyH> d_partial;
@@ -370,9 +369,9 @@ struct Run {
   void alloc_state() {
     const size_t n = (size_t)N;
     d_Emin.alloc(n); d_clam.alloc(n); d_p.alloc(n); d_lock.alloc(n); d_slot0.alloc(n); d_clof.alloc(n); d_ci.alloc(n);
-    d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(3 * n); d_nmovers.alloc(1);
+    d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(6 * n); d_nmovers.alloc(1);
     d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_budout.alloc(1);
-    h_budout.alloc(1); h_small.alloc(8 + 3 * MOVERS_INLINE); d_pool.alloc(POOL_INTS);
+    h_budout.alloc(1); h_small.alloc(2 * (8 + 3 * MOVERS_INLINE)); d_pool.alloc(POOL_INTS);
     d_thresh_one.alloc(thresh_one.size()); d_thresh_round.alloc(thresh_round.size());
     P.E_minmax = d_Emin.p; P.comp_lam = d_clam.p; P.p = d_p.p; P.lock = d_lock.p; P.slot0 = d_slot0.p; P.clust_of = d_clof.p;
     P.comp_i = d_ci.p; P.comp_ham = d_cham.p; P.head = d_head.p; P.node_count = d_ncount.p; P.err_flag = d_errflag.p;
@@ -514,61 +513,126 @@ struct Run {
   }
 
   // ---- b_shuffle2: device arg-max + move, host replay of the moves in the reference's order -------
-  bool shuffle() {
-    auto t0 = clk::now();
-    SampleDev &D = s->D;
+  // replay a batch of device moves in the reference's order: partitions ascending, slots descending
+  // (cluster.cpp:242-259), keeping bi_pop_raw's swap-with-last / bi_add_raw's append (containers.cpp:150-197)
+  void replay_moves(const int32_t *mv, int nm) {
+    std::vector<int32_t> order(nm);
+    for (int k = 0; k < nm; k++) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+      const int fa = mv[3 * a + 1], fb = mv[3 * b + 1];
+      if (fa != fb) return fa < fb;
+      return slot_of[mv[3 * a]] > slot_of[mv[3 * b]];
+    });
+    bool slot0_changed = false;
+    for (int k : order) {
+      const uint32_t r = (uint32_t)mv[3 * k];
+      const int from = mv[3 * k + 1], to = mv[3 * k + 2];
+      Bi &bf = bi[from];
+      const int slot = slot_of[r];
+      const uint32_t last = bf.raw.back();
+      bf.raw[slot] = last;
+      slot_of[last] = slot;
+      bf.raw.pop_back();
+      bf.reads -= s->h_reads[r];
+      if (slot == 0) slot0_changed = true;
+      Bi &bt = bi[to];
+      slot_of[r] = (int32_t)bt.raw.size();
+      bt.raw.push_back(r);
+      bt.reads += s->h_reads[r];
+      clust_of[r] = to;
+    }
+    if (slot0_changed) push_slot0();
+  }
+
+  // enqueue one b_shuffle2 (device arg-max + move); its mover count/list land in pinned slot `slot`
+  int32_t *enqueue_shuffle(int slot) {
     hipStream_t stq = s->stream;
-    const int C = (int)bi.size();
     int32_t *cnt = pool8();
-    launch_shuffle(P, D, d_creads_snap.p, d_movers.p, cnt, stq);
-    int32_t *hs = h_small.p;
+    launch_shuffle(P, s->D, d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, cnt, stq);
+    int32_t *hs = h_small.p + (size_t)slot * (8 + 3 * MOVERS_INLINE);
     D2_HIP(hipMemcpyAsync(hs, cnt, 4, hipMemcpyDeviceToHost, stq));
-    D2_HIP(hipMemcpyAsync(hs + 8, d_movers.p, (size_t)3 * std::min(MOVERS_INLINE, N) * 4, hipMemcpyDeviceToHost, stq));
-    sync_spin(stq);
-    const int nm = hs[0];
+    D2_HIP(hipMemcpyAsync(hs + 8, d_movers.p + (size_t)slot * 3 * N, (size_t)3 * std::min(MOVERS_INLINE, N) * 4,
+                          hipMemcpyDeviceToHost, stq));
+    // partition reads may have changed: refresh the snapshot the next arg-max uses (reads as of call start)
+    D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)bi.size() * 4, hipMemcpyDeviceToDevice, stq));
     st.nshuffle++;
-    if (nm > 0) {
-      // partition reads changed: refresh the snapshot the next arg-max will use (reads as of call start)
-      D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)C * 4, hipMemcpyDeviceToDevice, stq));
-      std::vector<int32_t> big;
-      const int32_t *mv = hs + 8;
-      if (nm > MOVERS_INLINE) {
-        big.resize((size_t)3 * nm);
-        D2_HIP(hipMemcpy(big.data(), d_movers.p, big.size() * 4, hipMemcpyDeviceToHost));
-        mv = big.data();
+    return cnt;
+  }
+
+  void apply_shuffle_result(int slot) {
+    const int32_t *hs = h_small.p + (size_t)slot * (8 + 3 * MOVERS_INLINE);
+    const int nm = hs[0];
+    if (nm <= 0) return;
+    if (nm > MOVERS_INLINE) {
+      std::vector<int32_t> big((size_t)3 * nm);
+      D2_HIP(hipMemcpy(big.data(), d_movers.p + (size_t)slot * 3 * N, big.size() * 4, hipMemcpyDeviceToHost));
+      replay_moves(big.data(), nm);
+    } else replay_moves(hs + 8, nm);
+  }
+
+  // The tail of one divisive round (Rmain.cpp:320-329 + the b_bud of the next iteration, :316): shuffle until
+  // stable (at most MAX_SHUFFLE), b_p_update, b_bud.  The common case is "first shuffle moves, second does
+  // not", so two shuffles, the p-value update and the bud evaluation are enqueued back to back and fetched
+  // with ONE synchronisation; the p-update/bud kernels cancel themselves on the device if the second shuffle
+  // still moved something, and the host then continues shuffling exactly as the reference would.
+  // Returns the new partition index (0 = no division).
+  int round_tail(bool do_shuffle) {
+    auto t0 = clk::now();
+    hipStream_t stq = s->stream;
+    int nsh = 0;
+    const int32_t *guard = nullptr;
+    if (do_shuffle) {
+      enqueue_shuffle(0);
+      guard = enqueue_shuffle(1);
+      nsh = 2;
+    }
+    enqueue_pupdate_bud(guard);
+    sync_spin(stq);
+    D2_HIP(hipGetLastError());
+    if (do_shuffle) {
+      const int nm1 = h_small.p[0], nm2 = h_small.p[8 + 3 * MOVERS_INLINE];
+      apply_shuffle_result(0);
+      apply_shuffle_result(1);
+      if (nm1 == 0) st.nshuffle--;                     // the reference stops after the first unmoving shuffle
+      if (nm2 > 0) {                                    // speculation cancelled: keep shuffling like the reference
+        bool shuffled = true;
+        while (shuffled && nsh < MAX_SHUFFLE) {
+          enqueue_shuffle(0);
+          sync_spin(stq);
+          shuffled = h_small.p[0] > 0;
+          apply_shuffle_result(0);
+          nsh++;
+        }
+        enqueue_pupdate_bud(nullptr);
+        sync_spin(stq);
+        D2_HIP(hipGetLastError());
       }
-      // reference order: partitions ascending, slots descending (cluster.cpp:242-259)
-      std::vector<int32_t> order(nm);
-      for (int k = 0; k < nm; k++) order[k] = k;
-      std::sort(order.begin(), order.end(), [&](int a, int b) {
-        const int fa = mv[3 * a + 1], fb = mv[3 * b + 1];
-        if (fa != fb) return fa < fb;
-        return slot_of[mv[3 * a]] > slot_of[mv[3 * b]];
-      });
-      bool slot0_changed = false;
-      for (int k : order) {
-        const uint32_t r = (uint32_t)mv[3 * k];
-        const int from = mv[3 * k + 1], to = mv[3 * k + 2];
-        Bi &bf = bi[from];
-        const int slot = slot_of[r];
-        // bi_pop_raw: swap-with-last (containers.cpp:183-197)
-        const uint32_t last = bf.raw.back();
-        bf.raw[slot] = last;
-        slot_of[last] = slot;
-        bf.raw.pop_back();
-        bf.reads -= s->h_reads[r];
-        if (slot == 0) slot0_changed = true;
-        // bi_add_raw (containers.cpp:150-162)
-        Bi &bt = bi[to];
-        slot_of[r] = (int32_t)bt.raw.size();
-        bt.raw.push_back(r);
-        bt.reads += s->h_reads[r];
-        clust_of[r] = to;
-      }
-      if (slot0_changed) push_slot0();
     }
     st.ms_bookkeep += ms_since(t0);
-    return nm > 0;
+    return decide_bud();
+  }
+
+  // last round when max_clust stops the loop (Rmain.cpp:316): only the shuffles matter for the outputs
+  void round_tail_no_bud() {
+    auto t0 = clk::now();
+    int nsh = 0;
+    bool shuffled;
+    do {
+      enqueue_shuffle(0);
+      sync_spin(s->stream);
+      shuffled = h_small.p[0] > 0;
+      apply_shuffle_result(0);
+    } while (shuffled && ++nsh < MAX_SHUFFLE);
+    st.ms_bookkeep += ms_since(t0);
+  }
+
+  void enqueue_pupdate_bud(const int32_t *guard) {
+    hipStream_t stq = s->stream;
+    SampleDev &D = s->D;
+    launch_pupdate(P, D, o.greedy, o.detect_singletons, guard, stq);
+    BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
+    launch_bud(P, D, bp, 1.0, s->h_reads[bi[0].center], d_partial.p, d_budout.p, d_ties0.p, d_ties1.p, (int)bi.size(), guard, stq);
+    D2_HIP(hipMemcpyAsync(h_budout.p, d_budout.p, sizeof(BudOut), hipMemcpyDeviceToHost, stq));
   }
 
   void push_slot0() {   // only reachable when a slot-0 unique is not its partition's centre (unsorted input)
@@ -577,25 +641,11 @@ struct Run {
     D2_HIP(hipMemcpy(P.slot0, f.data(), (size_t)N, hipMemcpyHostToDevice));
   }
 
-  void p_update() {
-    auto t0 = clk::now();
-    hipStream_t stq = s->stream;
-    launch_pupdate(P, s->D, o.greedy, o.detect_singletons, stq);   // (flags are cleared by the bud kernels that follow)
-    st.ms_pval += ms_since(t0);
-  }
-
   // ---- b_bud (cluster.cpp:274-350): device arg-min, host tie-break in (partition, slot) order ------
-  int bud() {
+  int decide_bud() {
     auto t0 = clk::now();
-    SampleDev &D = s->D;
-    hipStream_t stq = s->stream;
-    BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
-    const uint32_t c0 = bi[0].center;
-    launch_bud(P, D, bp, 1.0, s->h_reads[c0], d_partial.p, d_budout.p, d_ties0.p, d_ties1.p, (int)bi.size(), stq);
-    D2_HIP(hipMemcpyAsync(h_budout.p, d_budout.p, sizeof(BudOut), hipMemcpyDeviceToHost, stq));
-    sync_spin(stq);
-    D2_HIP(hipGetLastError());
     const BudOut &h = *h_budout.p;
+    if (!h.valid) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: bud evaluation not valid"};
     check_errflag(h.err_flag);
     st.nstored = (uint64_t)h.node_count;
     if ((size_t)h.node_count + (size_t)N > (size_t)P.node_cap)
@@ -675,13 +725,6 @@ struct Run {
     if (f & 2) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: comparison store overflow"};
   }
 
-  void ensure_node_capacity() {
-    int32_t cnt = 0;
-    D2_HIP(hipMemcpy(&cnt, P.node_count, 4, hipMemcpyDeviceToHost));
-    st.nstored = (uint64_t)cnt;
-    if ((size_t)cnt + (size_t)N > (size_t)P.node_cap) grow_nodes(std::max((size_t)P.node_cap * 2, (size_t)cnt + 2 * (size_t)N));
-  }
-
   uint64_t nw_cells_per_alignment() const {
     // algorithmic DP cells of one alignment: (L1 + L2 + 1) anti-diagonals x (band + 1)
     const int L = s->D.maxlen;
@@ -703,7 +746,7 @@ void alloc_round_buffers(dada2hip_sample *s) {
   s->d_skip.alloc(N); s->d_cls.alloc(N); s->d_lambda.alloc(N); s->d_ham.alloc(N);
   s->d_nw_list.alloc(N); s->d_gl_list.alloc(N); s->d_counters.alloc(8); s->d_thresh.alloc(s->D.maxlen + 2);
   s->d_ctab.alloc(768 + (size_t)s->D.LK / 2 + 64);
-  s->h_lambda.alloc(N); s->h_ham.alloc(N); s->h_skip.alloc(N); s->h_cls.alloc(N); s->h_counters.alloc(8);
+  s->h_counters.alloc(8);
 }
 
 void check_opts(const dada2hip_opts &o, int qmax, int ncol) {
@@ -764,18 +807,18 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   }
 
   run.compare_round(0, 1.0);                          // Rmain.cpp:309-310: no k-mer screen in round 0
-  run.p_update();
   int max_clust = opts->max_clust < 1 ? N : opts->max_clust;
-  int newi;
-  while ((int)run.bi.size() < max_clust && (newi = run.bud())) {
+  // run_dada's loop (Rmain.cpp:312-331), rotated: every iteration ends with b_p_update + the b_bud that opens
+  // the reference's next iteration, so one device round trip serves both.
+  int newi = 0;
+  if ((int)run.bi.size() < max_clust) newi = run.round_tail(false);   // b_p_update after round 0, then the first b_bud
+  while (newi) {
     run.logf("\nNew Cluster C%i:", newi);
     run.compare_round(newi, opts->kdist_cutoff);
-    int nshuffle = 0;
-    bool shuffled;
-    do { shuffled = run.shuffle(); } while (shuffled && ++nshuffle < MAX_SHUFFLE);
-    run.p_update();
     if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
       throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
+    if ((int)run.bi.size() < max_clust) newi = run.round_tail(true);
+    else { run.round_tail_no_bud(); newi = 0; }   // max_clust reached: shuffle to stability, no further b_bud
   }
   run.st.rounds = (uint32_t)run.bi.size();
 

@@ -96,7 +96,8 @@ void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, do
                   const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, hipStream_t st);
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
                     hipStream_t st);
-void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, hipStream_t st);
+void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const int32_t *d_guard,
+                    hipStream_t st);
 // result block of one b_bud evaluation, fetched by the host in a single copy
 constexpr int BUD_TIES = 16;
 struct BudTie { int32_t raw, comp_i; uint32_t comp_ham, pad; double comp_lam; };
@@ -105,10 +106,11 @@ struct BudOut {
   uint32_t best_reads[2];
   int32_t found[2], nties[2];
   int32_t err_flag, node_count;
+  int32_t valid, pad;          // 0 when a speculative evaluation was cancelled on the device
   BudTie ties[2][BUD_TIES];
 };
 void launch_bud(const PartState &P, const SampleDev &S, const BudParams &bp, double init_p, uint32_t init_reads, void *d_partial,
-                BudOut *d_out, int32_t *d_over0, int32_t *d_over1, int nclust, hipStream_t st);
+                BudOut *d_out, int32_t *d_over0, int32_t *d_over1, int nclust, const int32_t *d_guard, hipStream_t st);
 void launch_apply_bud(const PartState &P, uint32_t *d_creads_snap, int raw, int newi, int from, uint32_t reads_new,
                       uint32_t reads_from, hipStream_t st);
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st);

@@ -922,7 +922,11 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
 #define D2_LAUNCH_AD(GLV, DEFV)                                                                                          \
   do {                                                                                                                   \
-    (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    static size_t attr_set = 0;                                                                                          \
+    if (lds > attr_set) {                                                                                                \
+      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set = lds;                                                                                                    \
+    }                                                                                                                    \
     hipLaunchKernelGGL((k_nw_ad<GLV, DEFV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);               \
   } while (0)
   if (G.GL == 32) { if (def) D2_LAUNCH_AD(32, true); else D2_LAUNCH_AD(32, false); }
@@ -1101,7 +1105,9 @@ static __device__ __forceinline__ double dev_get_pA(uint32_t reads, bool prior, 
 
 // b_p_update (pval.cpp:14-40): p-values of the members of partitions whose composition changed, and
 // greedy locking the first time a partition's centre is in place.
-__global__ __launch_bounds__(256) void k_pupdate(PartState P, SampleDev S, int greedy, int detect_singletons) {
+__global__ __launch_bounds__(256) void k_pupdate(PartState P, SampleDev S, int greedy, int detect_singletons,
+                                                 const int32_t *__restrict__ guard) {
+  if (guard && *guard != 0) return;   // speculative launch: a later shuffle still moved uniques, redo after it
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= S.N) return;
   const int cl = P.clust_of[r];
@@ -1131,8 +1137,10 @@ static __device__ __forceinline__ bool bud_candidate(const PartState &P, const S
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_bud_min(PartState P, SampleDev S, BudParams bp, BudKey init, BudKey *__restrict__ partial) {
+__global__ __launch_bounds__(256) void k_bud_min(PartState P, SampleDev S, BudParams bp, BudKey init, BudKey *__restrict__ partial,
+                                                 const int32_t *__restrict__ guard) {
   __shared__ BudKey s_k[2][4];
+  if (guard && *guard != 0) return;
   BudKey b0 = init, b1 = init;
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
     if (!bud_candidate(P, S, r, bp)) continue;
@@ -1166,8 +1174,9 @@ __global__ __launch_bounds__(256) void k_bud_min(PartState P, SampleDev S, BudPa
 // and the comparison-store fill level into the result block and clears the per-partition flags that
 // k_pupdate has just consumed (pval.cpp:24,37).
 __global__ __launch_bounds__(256) void k_bud_final(PartState P, const BudKey *__restrict__ partial, int nblocks, BudKey init,
-                                                   BudOut *__restrict__ out, int nclust) {
+                                                   BudOut *__restrict__ out, int nclust, const int32_t *__restrict__ guard) {
   __shared__ BudKey s_k[2][256];
+  if (guard && *guard != 0) { if (threadIdx.x == 0) { out->valid = 0; out->nties[0] = 0; out->nties[1] = 0; out->found[0] = 0; out->found[1] = 0; } return; }
   BudKey b0 = init, b1 = init;
   for (int k = threadIdx.x; k < nblocks; k += 256) {
     if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
@@ -1195,12 +1204,15 @@ __global__ __launch_bounds__(256) void k_bud_final(PartState P, const BudKey *__
     out->nties[0] = 0; out->nties[1] = 0;
     out->err_flag = *P.err_flag;
     out->node_count = *P.node_count;
+    out->valid = 1;
   }
 }
 
 // third stage: every candidate whose key equals the best one (normally exactly one) -> tie records
 __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudParams bp, BudOut *__restrict__ out,
-                                                  int32_t *__restrict__ overflow0, int32_t *__restrict__ overflow1) {
+                                                  int32_t *__restrict__ overflow0, int32_t *__restrict__ overflow1,
+                                                  const int32_t *__restrict__ guard) {
+  if (guard && *guard != 0) return;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= S.N || !bud_candidate(P, S, r, bp)) return;
   const double p = P.p[r];
@@ -1274,16 +1286,17 @@ void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_cr
   int grid = std::min((S.N + 255) / 256, 2048);
   hipLaunchKernelGGL(k_shuffle, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers);
 }
-void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, hipStream_t st) {
-  hipLaunchKernelGGL(k_pupdate, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, greedy, detect_singletons);
+void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const int32_t *d_guard,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(k_pupdate, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, greedy, detect_singletons, d_guard);
 }
 void launch_bud(const PartState &P, const SampleDev &S, const BudParams &bp, double init_p, uint32_t init_reads, void *d_partial,
-                BudOut *d_out, int32_t *d_over0, int32_t *d_over1, int nclust, hipStream_t st) {
+                BudOut *d_out, int32_t *d_over0, int32_t *d_over1, int nclust, const int32_t *d_guard, hipStream_t st) {
   BudKey init{init_p, init_reads};
   int grid = std::min((S.N + 255) / 256, 1024);
-  hipLaunchKernelGGL(k_bud_min, dim3(grid), dim3(256), 0, st, P, S, bp, init, (BudKey *)d_partial);
-  hipLaunchKernelGGL(k_bud_final, dim3(1), dim3(256), 0, st, P, (const BudKey *)d_partial, grid, init, d_out, nclust);
-  hipLaunchKernelGGL(k_bud_ties, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, bp, d_out, d_over0, d_over1);
+  hipLaunchKernelGGL(k_bud_min, dim3(grid), dim3(256), 0, st, P, S, bp, init, (BudKey *)d_partial, d_guard);
+  hipLaunchKernelGGL(k_bud_final, dim3(1), dim3(256), 0, st, P, (const BudKey *)d_partial, grid, init, d_out, nclust, d_guard);
+  hipLaunchKernelGGL(k_bud_ties, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, bp, d_out, d_over0, d_over1, d_guard);
 }
 void launch_apply_bud(const PartState &P, uint32_t *d_creads_snap, int raw, int newi, int from, uint32_t reads_new,
                       uint32_t reads_from, hipStream_t st) {

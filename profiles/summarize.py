@@ -45,5 +45,24 @@ for sub, title in (("pmc_fetch", "FETCH_SIZE (KB; gfx950: x2 for wide coalesced 
     for k, c, n, s, a, d in rows:
         L.append(f"| `{short(k)}` | {c} | {n} | {s:.6g} | {a:.6g} | {d:.0f} |")
     L.append("")
+# per-launch HBM traffic of the hot kernels from the PMC passes (KB -> bytes).  gfx950: FETCH_SIZE reports half the
+# bytes of a wide coalesced read (MI355X_MICROARCH.md §HBM) -> doubled; WRITE_SIZE is taken as reported (uncalibrated).
+import json
+traffic = {}
+for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    dbs = glob.glob(os.path.join(out, sub, "*.db"))
+    if not dbs:
+        continue
+    db = sqlite3.connect(dbs[0])
+    for k, n, a in db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? and "
+                              "(kernel_name like 'd2::%' or kernel_name like 'void d2::%') group by kernel_name", (cname,)):
+        traffic.setdefault(short(k), {})[cname + "_KB_avg"] = a
+        traffic[short(k)]["dispatches"] = n
+for k, v in traffic.items():
+    v["hbm_bytes_per_launch"] = 2 * 1024 * v.get("FETCH_SIZE_KB_avg", 0.0) + 1024 * v.get("WRITE_SIZE_KB_avg", 0.0)
+if traffic:
+    json.dump({"tag": tag, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+               "note": "avg per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 half-count on wide reads)",
+               "kernels": traffic}, open(os.path.join(root, f"{tag}_traffic.json"), "w"), indent=1)
 open(os.path.join(root, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
 print("\n".join(L))
