@@ -337,7 +337,7 @@ struct Run {
   DevBuf<int32_t> d_pool, d_thresh_one, d_thresh_round;   // zeroed counter pool; k-mer threshold tables
   size_t pool_next = 0;
   static constexpr size_t POOL_INTS = 1 << 18;
-  static constexpr int MOVERS_INLINE = 2048;
+  static constexpr int MOVERS_INLINE = 512;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nw_events, screen_events;
   size_t ev_used = 0;
   std::vector<uint64_t> nw_event_cells;
@@ -1151,6 +1151,8 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
       run.st.nw_kernel_launches = 1;
       run.st.nw_cells = (uint64_t)n_nw * run.nw_cells_per_alignment();
     }
+    launch_fill_null(N, s->d_cls.p, s->d_lambda.p, s->d_ham.p, stq);
+    D2_HIP(hipStreamSynchronize(stq));
     if (lambda) D2_HIP(hipMemcpy(lambda, s->d_lambda.p, (size_t)N * 8, hipMemcpyDeviceToHost));
     if (hamming) D2_HIP(hipMemcpy(hamming, s->d_ham.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     if (cls) D2_HIP(hipMemcpy(cls, s->d_cls.p, (size_t)N, hipMemcpyDeviceToHost));

@@ -92,6 +92,7 @@ struct BudParams {
   int32_t min_hamming, min_abund;
 };
 
+void launch_fill_null(int n, const uint8_t *d_cls, double *d_lam, uint32_t *d_ham, hipStream_t st);
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
                   const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, hipStream_t st);
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,

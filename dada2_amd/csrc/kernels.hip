@@ -224,9 +224,10 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
       else if (sp.band == 0 || (gl_ok && ord == dot)) c = CLS_GAPLESS;                // kodist == kdist
       else c = CLS_NW;
       cls[r] = c;
-      if (c == CLS_SKIP || c == CLS_SHROUD) { lam[r] = 0.0; ham[r] = 0xFFFFFFFFu; }   // (counted by k_store from cls[])
-      else if (c == CLS_GAPLESS) s_gl[atomicAdd(&s_cnt[1], 1)] = r;
-      else s_nw[atomicAdd(&s_cnt[0], 1)] = r;
+      // skipped / shrouded uniques get lambda 0, hamming -1 (cluster.cpp:139-143): implied by cls[], not written here
+      // (8-byte scattered stores cost a 64-byte HBM write each); k_store / k_fill_null materialise them.
+      if (c == CLS_GAPLESS) s_gl[atomicAdd(&s_cnt[1], 1)] = r;
+      else if (c == CLS_NW) s_nw[atomicAdd(&s_cnt[0], 1)] = r;
     }
   }
   __syncthreads();
@@ -1016,11 +1017,11 @@ __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci,
     uint32_t h = 0;
     int pos = 0;
     if (r < S.N) {
-      l = lam[r];
-      h = ham[r];
       const uint8_t cl = cls[r];
       my_shroud += (cl == CLS_SHROUD);
       my_skip += (cl == CLS_SKIP);
+      if (cl == CLS_SHROUD || cl == CLS_SKIP) { l = 0.0; h = 0xFFFFFFFFu; }   // NULL sub (cluster.cpp:139-143)
+      else { l = lam[r]; h = ham[r]; }
       if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);          // "Lambda out-of-range error." (cluster.cpp:184)
       const double em = P.E_minmax[r];
       keep = l * total_reads > em;                                     // this cluster could attract this raw
@@ -1274,6 +1275,15 @@ __global__ __launch_bounds__(256) void k_posthoc(PartState P, SampleDev S, int n
     const int k = atomicAdd(nout, 1);
     if (k < cap) { out_ji[2 * k] = j; out_ji[2 * k + 1] = i; out_lam[k] = P.node_lam[n]; }
   }
+}
+
+// dense (lambda, hamming) view for dada2hip_sample_compare: materialise the NULL-sub entries implied by cls[]
+__global__ void k_fill_null(int n, const uint8_t *__restrict__ cls, double *__restrict__ lam, uint32_t *__restrict__ ham) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && (cls[r] == CLS_SHROUD || cls[r] == CLS_SKIP)) { lam[r] = 0.0; ham[r] = 0xFFFFFFFFu; }
+}
+void launch_fill_null(int n, const uint8_t *d_cls, double *d_lam, uint32_t *d_ham, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill_null, dim3((n + 255) / 256), dim3(256), 0, st, n, d_cls, d_lam, d_ham);
 }
 
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,

@@ -194,3 +194,17 @@ def test_errors_keep_reference_messages(api):
     with pytest.raises(_lib.Dada2HipError) as ei:
         api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts(HOMOPOLYMER_GAP_PENALTY=-1))
     assert ei.value.code == 4
+
+
+def test_work_counters_match_reference_counts(api, oracle_c):
+    """The run's comparison counters must equal the reference's own (dada.h:113-114 nalign / nshroud):
+    guards against correct-but-wasteful dispatch (e.g. shrouded uniques sent to the aligner)."""
+    d, err, pri, opts, exp, meta = case_inputs("sam1F_default")
+    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, opts)
+    want = oracle_c.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, opts)   # serial counters: real alignments only
+    st = got.stats
+    assert st["ncompare"] - st["nskipped"] == want.stats["nalign"] == 8655
+    assert st["nshroud"] == want.stats["nshroud"] == 3032
+    # every non-skipped, non-shrouded comparison is exactly one gapless pairing or one NW (+ final pass + births)
+    rounds_work = st["ncompare"] - st["nskipped"] - st["nshroud"]
+    assert st["nnw"] + st["ngapless"] == rounds_work + d.nraw + (got.nclust - 1)
