@@ -94,6 +94,7 @@ struct dada2hip_sample {
   NwScratch scr;
   int scr_class = -1, scr_band = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::shared_ptr<void> run_cache;   // Run object: partition-state buffers reused by every dada2hip_sample_run
 };
 
 struct dada2hip_result {
@@ -339,7 +340,7 @@ struct Run {
   static constexpr size_t POOL_INTS = 1 << 18;
   static constexpr int MOVERS_INLINE = 512;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nw_events, screen_events;
-  size_t ev_used = 0;
+  size_t nw_ev_used = 0, screen_ev_used = 0;
   std::vector<uint64_t> nw_event_cells;
 
   ~Run() {
@@ -357,12 +358,14 @@ struct Run {
     hooks->log(buf, hooks->user);
   }
 
-  std::pair<hipEvent_t, hipEvent_t> new_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
-    hipEvent_t a, b;
-    D2_HIP(hipEventCreate(&a));
-    D2_HIP(hipEventCreate(&b));
-    v.push_back({a, b});
-    return v.back();
+  std::pair<hipEvent_t, hipEvent_t> new_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t &used) {
+    if (used == v.size()) {
+      hipEvent_t a, b;
+      D2_HIP(hipEventCreate(&a));
+      D2_HIP(hipEventCreate(&b));
+      v.push_back({a, b});
+    }
+    return v[used++];
   }
 
   // ---- device state -----------------------------------------------------------------------------
@@ -379,6 +382,14 @@ struct Run {
     grow_nodes(std::max<size_t>(4 * n, 1u << 20));
     grow_clusters(256);
     hipStream_t stq = s->stream;
+    // (buffers persist across runs of the same sample: clear what a previous run left behind)
+    D2_HIP(hipMemsetAsync(P.creads, 0, (size_t)ccap * 4, stq));
+    D2_HIP(hipMemsetAsync(d_creads_snap.p, 0, (size_t)ccap * 4, stq));
+    D2_HIP(hipMemsetAsync(P.centre_of, 0, (size_t)ccap * 4, stq));
+    D2_HIP(hipMemsetAsync(P.update_e, 0, (size_t)ccap, stq));
+    D2_HIP(hipMemsetAsync(P.check_locks, 0, (size_t)ccap, stq));
+    bi.clear();
+    nw_ev_used = screen_ev_used = 0;
     std::vector<double> em(n, -999.0);                           // containers.cpp:39
     D2_HIP(hipMemcpyAsync(d_Emin.p, em.data(), n * 8, hipMemcpyHostToDevice, stq));
     D2_HIP(hipMemsetAsync(d_clam.p, 0, n * 8, stq));
@@ -483,7 +494,7 @@ struct Run {
     auto t0 = clk::now();
     const int32_t *th = (cutoff == 1.0) ? d_thresh_one.p : d_thresh_round.p;
     int32_t *ctr = pool8();
-    auto evs = new_events(screen_events);
+    auto evs = new_events(screen_events, screen_ev_used);
     D2_HIP(hipEventRecord(evs.first, stq));
     launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, th, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
                   s->d_nw_list.p, s->d_gl_list.p, ctr, s->d_ctab.p, stq);
@@ -491,7 +502,7 @@ struct Run {
     // NW batch size is only known on the device: both kernels loop over the device-side count with a
     // fixed persistent grid.  Round 0 aligns every unique (lane-per-alignment kernel), later rounds a few
     // thousand (cooperative kernel).
-    auto evn = new_events(nw_events);
+    auto evn = new_events(nw_events, nw_ev_used);
     D2_HIP(hipEventRecord(evn.first, stq));
     const char *f = getenv("DADA2HIP_NW_KERNEL");
     const bool coop_ok = nw_ad_lds_bytes(D, ap) > 0 && nw_ad_lds_bytes(D, ap) <= 150 * 1024;
@@ -779,7 +790,8 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   check_opts(*opts, s->qmax, err_ncol);
   SampleDev &D = s->D;
   const int N = D.N;
-  Run run;
+  if (!s->run_cache) s->run_cache = std::make_shared<Run>();
+  Run &run = *static_cast<Run *>(s->run_cache.get());
   run.hooks = hooks;
   init_run(run, s, err, err_ncol, opts, opts->kdist_cutoff);
   run.st.ms_upload = s->ms_upload;
@@ -849,7 +861,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
                    s->d_ham.p, s->d_view.p, LV, 0, stq);
     run.st.ngapless += (uint64_t)N;
   } else {
-    auto evn = run.new_events(run.nw_events);
+    auto evn = run.new_events(run.nw_events, run.nw_ev_used);
     D2_HIP(hipEventRecord(evn.first, stq));
     launch_nw(D, run.wclass, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr,
               s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, 0, nullptr, stq);
@@ -952,10 +964,10 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     D2_HIP(hipMemcpy(&cnt, run.P.node_count, 4, hipMemcpyDeviceToHost));
     run.st.nstored = (uint64_t)cnt;
     float ems;
-    for (auto &e : run.nw_events) { D2_HIP(hipEventElapsedTime(&ems, e.first, e.second)); run.st.nw_kernel_ms += ems; }
-    for (auto &e : run.screen_events) { D2_HIP(hipEventElapsedTime(&ems, e.first, e.second)); run.st.screen_kernel_ms += ems; }
-    run.st.nw_kernel_launches = run.nw_events.size();
-    run.st.screen_kernel_launches = run.screen_events.size();
+    for (size_t k = 0; k < run.nw_ev_used; k++) { D2_HIP(hipEventElapsedTime(&ems, run.nw_events[k].first, run.nw_events[k].second)); run.st.nw_kernel_ms += ems; }
+    for (size_t k = 0; k < run.screen_ev_used; k++) { D2_HIP(hipEventElapsedTime(&ems, run.screen_events[k].first, run.screen_events[k].second)); run.st.screen_kernel_ms += ems; }
+    run.st.nw_kernel_launches = run.nw_ev_used;
+    run.st.screen_kernel_launches = run.screen_ev_used;
     run.st.nw_cells = run.st.nnw * run.nw_cells_per_alignment();
   }
 
