@@ -683,14 +683,14 @@ struct AdGeom {
 static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minlen) {
   AdGeom G;
   const int W = 2 * band + (maxlen - minlen) + 1;
-  G.GL = W <= 64 ? 32 : 64;
+  G.GL = W <= 42 ? 21 : (W <= 64 ? 32 : 64);   // 21 lanes x 2 cells cover the default band (W = 33): 3 alignments per wave
   G.APW = 64 / G.GL;
   G.NCOL = (W + 1) / 2;
   G.nwords = (2 * maxlen + 1 + 15) / 16;
   G.area_words = G.nwords * G.NCOL;
   if (G.area_words < 2 * maxlen) G.area_words = 2 * maxlen;
   G.area_words = (G.area_words + 1) & ~1;
-  G.seqbytes = (maxlen + 2 * (G.GL + 8) + 7) & ~7;
+  G.seqbytes = (maxlen + 2 * (G.GL + 11) + 7) & ~7;
   G.tbytes = (maxlen + 7) & ~7;
   G.per_wave_words = G.APW * (G.area_words + AD_RCAP + (2 * G.seqbytes + 2 * G.tbytes) / 4);
   return G;
@@ -705,13 +705,16 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
   const int nerr = 16 * a.ap.ncol;
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int al = lane / GL, g = lane % GL;                 // alignment slot in the wave, lane in the group
+  // alignment slot in the wave / lane in the group.  With GL = 21 lane 63 is a ghost: it rides along the DP as an
+  // extra, always-out-of-band lane of the last group and is excluded from everything else.
+  const bool ghost = lane / GL >= APW;
+  const int al = ghost ? APW - 1 : lane / GL, g = ghost ? GL : lane % GL;
   // per-alignment LDS: [pointer words | later: fp64 factors][run descriptors][centre bytes][raw bytes][tcodes][quals]
   uint32_t *abase = (uint32_t *)(s_dyn + nerr) + ((size_t)wib * APW + al) * (G.per_wave_words / APW);
   uint32_t *ptr = abase;                                   // [nwords][NCOL]
   double *fac = (double *)abase;
   uint32_t *runs = abase + G.area_words;
-  uint8_t *cbytes = (uint8_t *)(runs + AD_RCAP) + (GL + 8);
+  uint8_t *cbytes = (uint8_t *)(runs + AD_RCAP) + (GL + 11);
   uint8_t *rbytes = cbytes + G.seqbytes;
   uint8_t *tcode = (uint8_t *)(runs + AD_RCAP) + 2 * G.seqbytes;
   uint8_t *qlds = tcode + G.tbytes;
@@ -735,15 +738,15 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
     const int W = lband + rband + 1;                       // <= 2*NCOL
     const int T = (gapless || !active) ? -1 : L1 + L2;     // idle / gapless slots run no DP steps of their own
     // stage both sequences (one base per byte, guard bytes either side) and the raw's qualities
-    for (int p = g; p < L1; p += GL) cbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)c * S.W2, p);
-    for (int p = g; p < L2; p += GL) rbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)r * S.W2, p);
-    {
+    if (!ghost) {
+      for (int p = g; p < L1; p += GL) cbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)c * S.W2, p);
+      for (int p = g; p < L2; p += GL) rbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)r * S.W2, p);
       const uint32_t *qsrc = (const uint32_t *)(S.qual + (size_t)r * S.LQ);
       for (int w = g; w * 4 < L2; w += GL) ((uint32_t *)qlds)[w] = qsrc[w];
     }
     int Tmax = T;
 #pragma unroll
-    for (int o = GL; o < 64; o <<= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
+    for (int o = 32; o >= 1; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
     const int dbg = a.moves_stride;
     if (Tmax >= 0 && !(dbg & 1)) {
       int d0 = SENT, d1 = SENT;
@@ -752,9 +755,9 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       int k = 2 * g + par0;
       int i = (0 - k + lband) >> 1, j = 0 - i;
       uint32_t cb = cbytes[i - 1], rb = rbytes[j - 1];
-      const bool g_first = g == 0, g_last = g == GL - 1;
-      const bool kok0 = 2 * g < W, kok1 = 2 * g + 1 < W;
-      const bool colok = g < NCOL;
+      const bool g_first = g == 0, g_last = ghost || (g == GL - 1 && lane != 62);   // lane 62's neighbour may be the ghost (all SENT)
+      const bool kok0 = !ghost && 2 * g < W, kok1 = !ghost && 2 * g + 1 < W;
+      const bool colok = !ghost && g < NCOL;
       const bool uniform_even = __all(par0 == 0), uniform_odd = __all(par0 == 1);
       int t = 0;
 #define AD_FLUSH(TT) if (((TT) & 15) == 15) { if (colok) ptr[((TT) >> 4) * NCOL + g] = pw; pw = 0; }
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
         int tA = (lband > rband ? lband : rband) + 2, tB = min(2 * L1 - lband, 2 * L2 - rband);
         if (T < 0) { tA = 0; tB = 0x3FFFFFFF; }             // idle / gapless slot: no constraint
 #pragma unroll
-        for (int o = GL; o < 64; o <<= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
+        for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
         tA = __builtin_amdgcn_readfirstlane(tA);
         tB = __builtin_amdgcn_readfirstlane(tB);
         const int p0 = uniform_odd ? 1 : 0;                  // parity of step t is (t + p0) & 1
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
     int guard = L1 + L2 + 2;                               // bounded: never spin on bad pointers
     while (true) {
       int nruns = 0;
-      if (g == 0 && !done) {
+      if (g == 0 && !done && !ghost) {
         uint32_t last = 0;                                 // pending (mergeable) run, 0 = none
         auto push = [&](int lo, int n, int dl) {
           if (last) {
@@ -862,9 +865,9 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       done = __shfl((int)done, al * GL, 64) != 0;
       int nrmax = nruns;
 #pragma unroll
-      for (int o = GL; o < 64; o <<= 1) nrmax = max(nrmax, __shfl_xor(nrmax, o, 64));
+      for (int o = 32; o >= 1; o >>= 1) nrmax = max(nrmax, __shfl_xor(nrmax, o, 64));
       for (int ri = 0; ri < nrmax; ri++) {
-        if (ri < nruns) {
+        if (ri < nruns && !ghost) {
           const uint32_t dsc = runs[ri];
           const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
           for (int pj = lo + g; pj < lo + n; pj += GL) {
@@ -882,13 +885,15 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       if (__all(done)) break;
     }
     // ---- factors e[pj] = err[t(pj)][q(pj)] (they overwrite the pointer area, no longer needed) ----------------
-    if (!(dbg & 4))
+    if (!(dbg & 4) && !ghost)
       for (int pj = g; pj < L2; pj += GL) {
         const uint32_t q = a.ap.use_quals ? qlds[pj] : 0u;
         fac[pj] = s_err[(uint32_t)tcode[pj] * a.ap.ncol + q];
       }
-#pragma unroll
-    for (int o = 1; o < GL; o <<= 1) h += __shfl_xor(h, o, 64);
+    // hamming: group sum through LDS (group sizes are not powers of two); the run buffer is free by now
+    if (g == 0 && !ghost) runs[0] = 0;
+    if (!ghost && h) atomicAdd(&runs[0], h);
+    h = runs[0];
     // ---- lambda: sequential product in raw-position order (pval.cpp:188-192), one lane per alignment ---------
     if (g == 0 && active && !(dbg & 8)) {
       double l = 1.0;
@@ -930,7 +935,8 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
     }                                                                                                                    \
     hipLaunchKernelGGL((k_nw_ad<GLV, DEFV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);               \
   } while (0)
-  if (G.GL == 32) { if (def) D2_LAUNCH_AD(32, true); else D2_LAUNCH_AD(32, false); }
+  if (G.GL == 21) { if (def) D2_LAUNCH_AD(21, true); else D2_LAUNCH_AD(21, false); }
+  else if (G.GL == 32) { if (def) D2_LAUNCH_AD(32, true); else D2_LAUNCH_AD(32, false); }
   else { if (def) D2_LAUNCH_AD(64, true); else D2_LAUNCH_AD(64, false); }
 #undef D2_LAUNCH_AD
 }
