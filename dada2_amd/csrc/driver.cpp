@@ -332,13 +332,14 @@ struct Run {
   DevBuf<uint32_t> d_cham, d_nham, d_creads, d_creads_snap;
   DevBuf<unsigned long long> d_totals;
   DevBuf<BudKeyH> d_partial;
-  DevBuf<BudOut> d_budout;
-  PinBuf<BudOut> h_budout;
-  PinBuf<int32_t> h_small;                      // [0] = mover count, [8..] first movers
+  DevBuf<RoundOut> d_rout;
+  PinBuf<RoundOut> h_rout;                      // the round tail's result block (one D2H per round)
   DevBuf<int32_t> d_pool, d_thresh_one, d_thresh_round;   // zeroed counter pool; k-mer threshold tables
   size_t pool_next = 0;
   static constexpr size_t POOL_INTS = 1 << 18;
-  static constexpr int MOVERS_INLINE = 512;
+  int ev_round = 0;                             // rounds since the last event-timed one (kernel timing is sampled)
+  double nw_ms_big = 0, nw_ms_sampled = 0, sc_ms_sampled = 0;
+  int nw_n_sampled = 0, sc_n_sampled = 0, n_round_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nw_events, screen_events;
   size_t nw_ev_used = 0, screen_ev_used = 0;
   std::vector<uint64_t> nw_event_cells;
@@ -373,8 +374,8 @@ struct Run {
     const size_t n = (size_t)N;
     d_Emin.alloc(n); d_clam.alloc(n); d_p.alloc(n); d_lock.alloc(n); d_slot0.alloc(n); d_clof.alloc(n); d_ci.alloc(n);
     d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(6 * n); d_nmovers.alloc(1);
-    d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_budout.alloc(1);
-    h_budout.alloc(1); h_small.alloc(2 * (8 + 3 * MOVERS_INLINE)); d_pool.alloc(POOL_INTS);
+    d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_rout.alloc(1);
+    h_rout.alloc(1); d_pool.alloc(POOL_INTS);
     d_thresh_one.alloc(thresh_one.size()); d_thresh_round.alloc(thresh_round.size());
     P.E_minmax = d_Emin.p; P.comp_lam = d_clam.p; P.p = d_p.p; P.lock = d_lock.p; P.slot0 = d_slot0.p; P.clust_of = d_clof.p;
     P.comp_i = d_ci.p; P.comp_ham = d_cham.p; P.head = d_head.p; P.node_count = d_ncount.p; P.err_flag = d_errflag.p;
@@ -390,6 +391,8 @@ struct Run {
     D2_HIP(hipMemsetAsync(P.check_locks, 0, (size_t)ccap, stq));
     bi.clear();
     nw_ev_used = screen_ev_used = 0;
+    ev_round = 0; nw_ms_big = nw_ms_sampled = sc_ms_sampled = 0; nw_n_sampled = sc_n_sampled = n_round_launches = 0;
+    D2_HIP(hipMemsetAsync(d_rout.p, 0, sizeof(RoundOut), stq));
     std::vector<double> em(n, -999.0);                           // containers.cpp:39
     D2_HIP(hipMemcpyAsync(d_Emin.p, em.data(), n * 8, hipMemcpyHostToDevice, stq));
     D2_HIP(hipMemsetAsync(d_clam.p, 0, n * 8, stq));
@@ -487,23 +490,25 @@ struct Run {
   }
 
   // ---- one b_compare round, entirely on the device (cluster.cpp:90-204) ---------------------------
-  void compare_round(int ci, double cutoff) {
+  // `centre` is passed explicitly: the host mirror of the new partition may be filled in after the launches.
+  void compare_round(int ci, int centre, double cutoff) {
     SampleDev &D = s->D;
     hipStream_t stq = s->stream;
-    const int centre = (int)bi[ci].center;
     auto t0 = clk::now();
     const int32_t *th = (cutoff == 1.0) ? d_thresh_one.p : d_thresh_round.p;
     int32_t *ctr = pool8();
-    auto evs = new_events(screen_events, screen_ev_used);
-    D2_HIP(hipEventRecord(evs.first, stq));
+    // kernel timing with HIP events is sampled (round 0 and every 8th round): an event pair per kernel per round costs
+    // four API calls on a host-enqueue-bound critical path
+    const bool timed = ci == 0 || (ev_round++ % 8) == 0;
+    std::pair<hipEvent_t, hipEvent_t> evs{}, evn{};
+    if (timed) { evs = new_events(screen_events, screen_ev_used); D2_HIP(hipEventRecord(evs.first, stq)); }
     launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, th, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
-                  s->d_nw_list.p, s->d_gl_list.p, ctr, s->d_ctab.p, stq);
-    D2_HIP(hipEventRecord(evs.second, stq));
+                  s->d_nw_list.p, s->d_gl_list.p, ctr, s->d_ctab.p, /*build_table=*/ci == 0, stq);
+    if (timed) D2_HIP(hipEventRecord(evs.second, stq));
     // NW batch size is only known on the device: both kernels loop over the device-side count with a
     // fixed persistent grid.  Round 0 aligns every unique (lane-per-alignment kernel), later rounds a few
     // thousand (cooperative kernel).
-    auto evn = new_events(nw_events, nw_ev_used);
-    D2_HIP(hipEventRecord(evn.first, stq));
+    if (timed) { evn = new_events(nw_events, nw_ev_used); D2_HIP(hipEventRecord(evn.first, stq)); }
     const char *f = getenv("DADA2HIP_NW_KERNEL");
     const bool coop_ok = nw_ad_lds_bytes(D, ap) > 0 && nw_ad_lds_bytes(D, ap) <= 150 * 1024;
     bool coop = coop_ok && (ci != 0 || N < 65536);
@@ -517,8 +522,10 @@ struct Run {
       launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
                 s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
     }
-    D2_HIP(hipEventRecord(evn.second, stq));
-    launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p, stq);
+    if (timed) D2_HIP(hipEventRecord(evn.second, stq));
+    launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p,
+                 d_rout.p->cnt, stq);
+    n_round_launches++;
     st.ncompare += (uint64_t)N;
     st.ms_screen += ms_since(t0);
   }
@@ -555,41 +562,51 @@ struct Run {
     if (slot0_changed) push_slot0();
   }
 
-  // enqueue one b_shuffle2 (device arg-max + move); its mover count/list land in pinned slot `slot`
+  // enqueue one b_shuffle2 (device arg-max + move); count and first movers go to slot `slot` of the round's result block
   int32_t *enqueue_shuffle(int slot) {
     hipStream_t stq = s->stream;
-    int32_t *cnt = pool8();
-    launch_shuffle(P, s->D, d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, cnt, stq);
-    int32_t *hs = h_small.p + (size_t)slot * (8 + 3 * MOVERS_INLINE);
-    D2_HIP(hipMemcpyAsync(hs, cnt, 4, hipMemcpyDeviceToHost, stq));
-    D2_HIP(hipMemcpyAsync(hs + 8, d_movers.p + (size_t)slot * 3 * N, (size_t)3 * std::min(MOVERS_INLINE, N) * 4,
-                          hipMemcpyDeviceToHost, stq));
+    RoundOut *ro = d_rout.p;
+    launch_shuffle(P, s->D, d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot], stq);
     // partition reads may have changed: refresh the snapshot the next arg-max uses (reads as of call start)
-    D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)bi.size() * 4, hipMemcpyDeviceToDevice, stq));
+    D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)nclust_dev * 4, hipMemcpyDeviceToDevice, stq));
     st.nshuffle++;
-    return cnt;
+    return ro->cnt + slot;
+  }
+  int nclust_dev = 1;   // partitions the device knows about (the host mirror may lag by one birth)
+
+  void fetch_round_out() {
+    D2_HIP(hipMemcpyAsync(h_rout.p, d_rout.p, sizeof(RoundOut), hipMemcpyDeviceToHost, s->stream));
+    sync_spin(s->stream);
+    D2_HIP(hipGetLastError());
   }
 
   void apply_shuffle_result(int slot) {
-    const int32_t *hs = h_small.p + (size_t)slot * (8 + 3 * MOVERS_INLINE);
-    const int nm = hs[0];
+    const RoundOut &ro = *h_rout.p;
+    const int nm = ro.cnt[slot];
     if (nm <= 0) return;
     if (nm > MOVERS_INLINE) {
       std::vector<int32_t> big((size_t)3 * nm);
       D2_HIP(hipMemcpy(big.data(), d_movers.p + (size_t)slot * 3 * N, big.size() * 4, hipMemcpyDeviceToHost));
       replay_moves(big.data(), nm);
-    } else replay_moves(hs + 8, nm);
+    } else replay_moves(ro.mov[slot], nm);
+  }
+
+  void enqueue_pupdate_bud(const int32_t *guard) {
+    BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
+    launch_pupdate_bud(P, s->D, o.greedy, o.detect_singletons, bp, 1.0, s->h_reads[bi[0].center], d_partial.p, &d_rout.p->bud,
+                       d_ties0.p, d_ties1.p, nclust_dev, guard, s->stream);
   }
 
   // The tail of one divisive round (Rmain.cpp:320-329 + the b_bud of the next iteration, :316): shuffle until
   // stable (at most MAX_SHUFFLE), b_p_update, b_bud.  The common case is "first shuffle moves, second does
   // not", so two shuffles, the p-value update and the bud evaluation are enqueued back to back and fetched
-  // with ONE synchronisation; the p-update/bud kernels cancel themselves on the device if the second shuffle
-  // still moved something, and the host then continues shuffling exactly as the reference would.
-  // Returns the new partition index (0 = no division).
-  int round_tail(bool do_shuffle) {
+  // with ONE synchronisation and ONE copy; the p-update/bud kernels cancel themselves on the device if the second
+  // shuffle still moved something, and the host then continues shuffling exactly as the reference would.
+  // On return h_rout holds a valid bud evaluation; moves not yet replayed on the host are described by
+  // pending_slots (the caller replays them after it has launched the next round).
+  int pending_slots = 0;
+  void round_tail(bool do_shuffle) {
     auto t0 = clk::now();
-    hipStream_t stq = s->stream;
     int nsh = 0;
     const int32_t *guard = nullptr;
     if (do_shuffle) {
@@ -598,29 +615,33 @@ struct Run {
       nsh = 2;
     }
     enqueue_pupdate_bud(guard);
-    sync_spin(stq);
-    D2_HIP(hipGetLastError());
+    fetch_round_out();
+    pending_slots = do_shuffle ? 2 : 0;
     if (do_shuffle) {
-      const int nm1 = h_small.p[0], nm2 = h_small.p[8 + 3 * MOVERS_INLINE];
-      apply_shuffle_result(0);
-      apply_shuffle_result(1);
+      const int nm1 = h_rout.p->cnt[0], nm2 = h_rout.p->cnt[1];
       if (nm1 == 0) st.nshuffle--;                     // the reference stops after the first unmoving shuffle
       if (nm2 > 0) {                                    // speculation cancelled: keep shuffling like the reference
+        apply_shuffle_result(0);
+        apply_shuffle_result(1);
+        pending_slots = 0;
         bool shuffled = true;
         while (shuffled && nsh < MAX_SHUFFLE) {
+          D2_HIP(hipMemsetAsync(d_rout.p->cnt, 0, 8, s->stream));
           enqueue_shuffle(0);
-          sync_spin(stq);
-          shuffled = h_small.p[0] > 0;
+          fetch_round_out();
+          shuffled = h_rout.p->cnt[0] > 0;
           apply_shuffle_result(0);
           nsh++;
         }
         enqueue_pupdate_bud(nullptr);
-        sync_spin(stq);
-        D2_HIP(hipGetLastError());
+        fetch_round_out();
       }
     }
     st.ms_bookkeep += ms_since(t0);
-    return decide_bud();
+  }
+  void replay_pending() {
+    for (int k = 0; k < pending_slots; k++) apply_shuffle_result(k);
+    pending_slots = 0;
   }
 
   // last round when max_clust stops the loop (Rmain.cpp:316): only the shuffles matter for the outputs
@@ -629,21 +650,13 @@ struct Run {
     int nsh = 0;
     bool shuffled;
     do {
+      D2_HIP(hipMemsetAsync(d_rout.p->cnt, 0, 8, s->stream));
       enqueue_shuffle(0);
-      sync_spin(s->stream);
-      shuffled = h_small.p[0] > 0;
+      fetch_round_out();
+      shuffled = h_rout.p->cnt[0] > 0;
       apply_shuffle_result(0);
     } while (shuffled && ++nsh < MAX_SHUFFLE);
     st.ms_bookkeep += ms_since(t0);
-  }
-
-  void enqueue_pupdate_bud(const int32_t *guard) {
-    hipStream_t stq = s->stream;
-    SampleDev &D = s->D;
-    launch_pupdate(P, D, o.greedy, o.detect_singletons, guard, stq);
-    BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
-    launch_bud(P, D, bp, 1.0, s->h_reads[bi[0].center], d_partial.p, d_budout.p, d_ties0.p, d_ties1.p, (int)bi.size(), guard, stq);
-    D2_HIP(hipMemcpyAsync(h_budout.p, d_budout.p, sizeof(BudOut), hipMemcpyDeviceToHost, stq));
   }
 
   void push_slot0() {   // only reachable when a slot-0 unique is not its partition's centre (unsorted input)
@@ -653,9 +666,13 @@ struct Run {
   }
 
   // ---- b_bud (cluster.cpp:274-350): device arg-min, host tie-break in (partition, slot) order ------
-  int decide_bud() {
-    auto t0 = clk::now();
-    const BudOut &h = *h_budout.p;
+  struct Birth { bool yes = false; char type = 'A'; BudTie c{}; double pval = 0; int newi = 0; };
+
+  // Decide from the fetched evaluation.  With a single best candidate (the normal case) everything needed comes
+  // from the device (its partition, that partition's reads), so the next round can be launched before the host
+  // mirror is brought up to date; exact (p, reads) ties need the host's slot order and force the replay first.
+  Birth decide_bud() {
+    const BudOut &h = h_rout.p->bud;
     if (!h.valid) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: bud evaluation not valid"};
     check_errflag(h.err_flag);
     st.nstored = (uint64_t)h.node_count;
@@ -665,6 +682,8 @@ struct Run {
     auto pick = [&](int track, BudTie &out) -> bool {
       const int n = h.nties[track];
       if (!h.found[track] || n <= 0) return false;
+      if (n == 1) { out = h.ties[track][0]; return true; }
+      replay_pending();                                   // slot order must be current
       auto before = [&](int a, int b) { return clust_of[a] < clust_of[b] || (clust_of[a] == clust_of[b] && slot_of[a] < slot_of[b]); };
       if (n <= BUD_TIES) {
         int bk = 0;
@@ -677,58 +696,65 @@ struct Run {
       int best = t[0];
       for (int k = 1; k < n; k++) if (before(t[k], best)) best = t[k];
       out.raw = best;
+      out.from = clust_of[best];
+      out.from_reads = bi[out.from].reads;
       D2_HIP(hipMemcpy(&out.comp_i, P.comp_i + best, 4, hipMemcpyDeviceToHost));
       D2_HIP(hipMemcpy(&out.comp_lam, P.comp_lam + best, 8, hipMemcpyDeviceToHost));
       D2_HIP(hipMemcpy(&out.comp_ham, P.comp_ham + best, 4, hipMemcpyDeviceToHost));
       return true;
     };
-    int newi = 0;
-    auto birth = [&](const BudTie &c, char type, double pval) {
-      const int raw = c.raw;
-      const int from = clust_of[raw];
-      const double expected = c.comp_lam * bi[from].reads;
-      // bi_pop_raw(from, slot)
-      Bi &bf = bi[from];
-      const int slot = slot_of[raw];
-      const uint32_t last = bf.raw.back();
-      bf.raw[slot] = last;
-      slot_of[last] = slot;
-      bf.raw.pop_back();
-      bf.reads -= s->h_reads[raw];
-      const uint32_t reads_from = bf.reads;
-      bi.emplace_back();
-      newi = (int)bi.size() - 1;
-      Bi &nb = bi[newi];
-      nb.birth_type = type;
-      nb.birth_from = type == 'A' ? (uint32_t)from : 0u;             // never assigned for "P" births (cluster.cpp:331-345)
-      nb.birth_pval = pval; nb.birth_fold = s->h_reads[raw] / expected; nb.birth_e = expected;
-      nb.birth_comp = Comp{(uint32_t)c.comp_i, (uint32_t)raw, c.comp_lam, c.comp_ham};
-      nb.raw.push_back((uint32_t)raw);
-      nb.reads = s->h_reads[raw];
-      nb.center = (uint32_t)raw;                                      // bi_assign_center: the only member
-      slot_of[raw] = 0;
-      clust_of[raw] = newi;
-      if (newi >= ccap) grow_clusters(std::max(ccap * 2, newi + 1));
-      launch_apply_bud(P, d_creads_snap.p, raw, newi, from, nb.reads, reads_from, s->stream);
-      if (slot == 0) push_slot0();
-    };
+    Birth b;
     BudTie c;
     const bool have = pick(0, c);
     const double pA = (have ? h.best_p[0] : 1.0) * N;               // minraw stays the cluster-0 centre (p = 1) otherwise
-    if (pA < o.omegaA && have) {
-      birth(c, 'A', pA);
-      logf(", Division (naive): Raw %d from Bi %u, pA=%.2e", c.raw, bi[newi].birth_from, pA);
-    } else {
+    if (pA < o.omegaA && have) { b.yes = true; b.type = 'A'; b.c = c; b.pval = pA; }
+    else {
       BudTie cp;
       const bool havep = pick(1, cp);
       const double pP = havep ? h.best_p[1] : 1.0;
-      if (pP < o.omegaP && havep) {
-        birth(cp, 'P', pP);
-        logf(", Division (prior): Raw %d, pP=%.2e", cp.raw, pP);
-      }
+      if (pP < o.omegaP && havep) { b.yes = true; b.type = 'P'; b.c = cp; b.pval = pP; }
     }
-    st.ms_bookkeep += ms_since(t0);
-    return newi;
+    if (b.yes) b.newi = nclust_dev;
+    return b;
+  }
+
+  // device side of a birth (cluster.cpp:313-347) + the new centre's k-mer record; one launch
+  void launch_birth(const Birth &b) {
+    const int raw = b.c.raw;
+    if (b.newi >= ccap) grow_clusters(std::max(ccap * 2, b.newi + 1));
+    launch_apply_bud(P, s->D, d_creads_snap.p, raw, b.newi, b.c.from, s->h_reads[raw], b.c.from_reads - s->h_reads[raw],
+                     s->d_ctab.p, s->stream);
+    nclust_dev = b.newi + 1;
+  }
+
+  // host mirror of the same birth: bi_pop_raw from its partition, new Bi with the unique as only member and centre
+  void record_birth(const Birth &b) {
+    const int raw = b.c.raw;
+    const int from = clust_of[raw];
+    if (from != b.c.from) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: host/device membership diverged"};
+    const double expected = b.c.comp_lam * bi[from].reads;
+    Bi &bf = bi[from];
+    const int slot = slot_of[raw];
+    const uint32_t last = bf.raw.back();
+    bf.raw[slot] = last;
+    slot_of[last] = slot;
+    bf.raw.pop_back();
+    bf.reads -= s->h_reads[raw];
+    bi.emplace_back();
+    const int newi = (int)bi.size() - 1;
+    Bi &nb = bi[newi];
+    nb.birth_type = b.type;
+    nb.birth_from = b.type == 'A' ? (uint32_t)from : 0u;              // never assigned for "P" births (cluster.cpp:331-345)
+    nb.birth_pval = b.pval; nb.birth_fold = s->h_reads[raw] / expected; nb.birth_e = expected;
+    nb.birth_comp = Comp{(uint32_t)b.c.comp_i, (uint32_t)raw, b.c.comp_lam, b.c.comp_ham};
+    nb.raw.push_back((uint32_t)raw);
+    nb.reads = s->h_reads[raw];
+    nb.center = (uint32_t)raw;                                       // bi_assign_center: the only member
+    slot_of[raw] = 0;
+    clust_of[raw] = newi;
+    if (slot == 0) push_slot0();
+    if (b.type == 'A') logf(", Division (naive): Raw %d from Bi %d, pA=%.2e", raw, from, b.pval);
+    else logf(", Division (prior): Raw %d, pP=%.2e", raw, b.pval);
   }
 
   void check_errflag(int32_t f) {
@@ -818,19 +844,28 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     D2_HIP(hipMemcpy(run.d_creads_snap.p, run.P.creads, 4, hipMemcpyDeviceToDevice));
   }
 
-  run.compare_round(0, 1.0);                          // Rmain.cpp:309-310: no k-mer screen in round 0
+  run.nclust_dev = 1;
+  run.compare_round(0, (int)run.bi[0].center, 1.0);   // Rmain.cpp:309-310: no k-mer screen in round 0
   int max_clust = opts->max_clust < 1 ? N : opts->max_clust;
   // run_dada's loop (Rmain.cpp:312-331), rotated: every iteration ends with b_p_update + the b_bud that opens
-  // the reference's next iteration, so one device round trip serves both.
-  int newi = 0;
-  if ((int)run.bi.size() < max_clust) newi = run.round_tail(false);   // b_p_update after round 0, then the first b_bud
-  while (newi) {
-    run.logf("\nNew Cluster C%i:", newi);
-    run.compare_round(newi, opts->kdist_cutoff);
-    if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
-      throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
-    if ((int)run.bi.size() < max_clust) newi = run.round_tail(true);
-    else { run.round_tail_no_bud(); newi = 0; }   // max_clust reached: shuffle to stability, no further b_bud
+  // the reference's next iteration, so one device round trip serves both.  After a decision the next round's
+  // kernels are launched first; the host mirror (moves replay, birth record) is updated while the GPU works.
+  if (run.nclust_dev < max_clust) {
+    run.round_tail(false);                            // b_p_update after round 0, then the first b_bud
+    for (;;) {
+      Run::Birth b = run.decide_bud();
+      if (!b.yes) { run.replay_pending(); break; }
+      run.logf("\nNew Cluster C%i:", b.newi);
+      run.launch_birth(b);
+      run.compare_round(b.newi, b.c.raw, opts->kdist_cutoff);
+      const bool more = run.nclust_dev < max_clust;
+      run.replay_pending();                           // host mirror catches up while the GPU runs the round
+      run.record_birth(b);
+      if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
+        throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
+      if (!more) { run.round_tail_no_bud(); break; }  // max_clust reached: shuffle to stability, no further b_bud
+      run.round_tail(true);
+    }
   }
   run.st.rounds = (uint32_t)run.bi.size();
 
@@ -963,11 +998,21 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     int32_t cnt = 0;
     D2_HIP(hipMemcpy(&cnt, run.P.node_count, 4, hipMemcpyDeviceToHost));
     run.st.nstored = (uint64_t)cnt;
+    // kernel times: event-timed launches (round 0, every 8th round, the final pass) extrapolated to all launches
     float ems;
-    for (size_t k = 0; k < run.nw_ev_used; k++) { D2_HIP(hipEventElapsedTime(&ems, run.nw_events[k].first, run.nw_events[k].second)); run.st.nw_kernel_ms += ems; }
-    for (size_t k = 0; k < run.screen_ev_used; k++) { D2_HIP(hipEventElapsedTime(&ems, run.screen_events[k].first, run.screen_events[k].second)); run.st.screen_kernel_ms += ems; }
-    run.st.nw_kernel_launches = run.nw_ev_used;
-    run.st.screen_kernel_launches = run.screen_ev_used;
+    double nw_big = 0, nw_small = 0, sc_sum = 0;
+    int n_small = 0;
+    for (size_t k = 0; k < run.nw_ev_used; k++) {
+      D2_HIP(hipEventElapsedTime(&ems, run.nw_events[k].first, run.nw_events[k].second));
+      if (k == 0 || k + 1 == run.nw_ev_used) nw_big += ems;           // round 0 and the final pass (every unique aligned)
+      else { nw_small += ems; n_small++; }
+    }
+    for (size_t k = 0; k < run.screen_ev_used; k++) { D2_HIP(hipEventElapsedTime(&ems, run.screen_events[k].first, run.screen_events[k].second)); sc_sum += ems; }
+    const int rounds = run.n_round_launches;
+    run.st.nw_kernel_ms = nw_big + (n_small ? nw_small / n_small * (rounds - 1) : 0.0);
+    run.st.nw_kernel_launches = (uint64_t)rounds + 1;
+    run.st.screen_kernel_ms = run.screen_ev_used ? sc_sum / run.screen_ev_used * rounds : 0.0;
+    run.st.screen_kernel_launches = (uint64_t)rounds;
     run.st.nw_cells = run.st.nnw * run.nw_cells_per_alignment();
   }
 
@@ -1126,7 +1171,7 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
     D2_HIP(hipMemsetAsync(s->d_counters.p, 0, 8 * 4, stq));
     D2_HIP(hipEventRecord(s->ev0, stq));
     launch_screen(D, centre, run.sp, skip ? s->d_skip.p : nullptr, nullptr, 0, s->d_thresh.p, s->d_cls.p, s->d_lambda.p,
-                  s->d_ham.p, s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, s->d_ctab.p, stq);
+                  s->d_ham.p, s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, s->d_ctab.p, true, stq);
     D2_HIP(hipEventRecord(s->ev1, stq));
     launch_gapless(D, centre, nullptr, s->d_gl_list.p, s->d_counters.p + 1, 0, run.ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
                    nullptr, 0, 0, stq);

@@ -94,14 +94,12 @@ struct BudParams {
 
 void launch_fill_null(int n, const uint8_t *d_cls, double *d_lam, uint32_t *d_ham, hipStream_t st);
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
-                  const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, hipStream_t st);
+                  const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, int32_t *d_zero2, hipStream_t st);
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
-                    hipStream_t st);
-void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const int32_t *d_guard,
-                    hipStream_t st);
+                    int32_t *d_inline, hipStream_t st);
 // result block of one b_bud evaluation, fetched by the host in a single copy
 constexpr int BUD_TIES = 16;
-struct BudTie { int32_t raw, comp_i; uint32_t comp_ham, pad; double comp_lam; };
+struct BudTie { int32_t raw, comp_i; uint32_t comp_ham; int32_t from; uint32_t from_reads, pad; double comp_lam; };
 struct BudOut {
   double best_p[2];
   uint32_t best_reads[2];
@@ -110,10 +108,22 @@ struct BudOut {
   int32_t valid, pad;          // 0 when a speculative evaluation was cancelled on the device
   BudTie ties[2][BUD_TIES];
 };
-void launch_bud(const PartState &P, const SampleDev &S, const BudParams &bp, double init_p, uint32_t init_reads, void *d_partial,
-                BudOut *d_out, int32_t *d_over0, int32_t *d_over1, int nclust, const int32_t *d_guard, hipStream_t st);
-void launch_apply_bud(const PartState &P, uint32_t *d_creads_snap, int raw, int newi, int from, uint32_t reads_new,
-                      uint32_t reads_from, hipStream_t st);
+// Everything the host needs from one round tail, fetched with a single copy.
+constexpr int MOVERS_INLINE = 512;
+struct RoundOut {
+  int32_t cnt[2];              // movers of the two speculative shuffles (zeroed by k_store of the same round)
+  int32_t pad[2];
+  BudOut bud;
+  int32_t mov[2][3 * MOVERS_INLINE];   // first movers of each shuffle (raw, from, to); the full lists stay on the device
+};
+// fused b_p_update + first stage of b_bud, then the two small bud stages
+void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const BudParams &bp,
+                        double init_p, uint32_t init_reads, void *d_partial, BudOut *d_out, int32_t *d_over0, int32_t *d_over1,
+                        int nclust, const int32_t *d_guard, hipStream_t st);
+// birth + the new centre's k-mer record for the coming round (one launch)
+void launch_apply_bud(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, int raw, int newi, int from,
+                      uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, hipStream_t st);
+void launch_centre_table(const SampleDev &S, int centre, uint32_t *d_ctab, hipStream_t st);
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st);
 void launch_posthoc(const PartState &P, const SampleDev &S, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam,
                     int32_t *d_nout, int cap, hipStream_t st);
@@ -125,7 +135,7 @@ void launch_build_kmers(const SampleDev &S, hipStream_t st);
 // counters: [0]=#NW work items, [1]=#gapless work items, [2]=#shrouded, [3]=#skipped
 void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,
                    int greedy, const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
-                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, hipStream_t st);
+                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, bool build_table, hipStream_t st);
 void launch_gapless(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                     const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err,
                     double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, hipStream_t st);

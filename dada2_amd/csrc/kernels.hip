@@ -98,8 +98,7 @@ void launch_build_kmers(const SampleDev &S, hipStream_t st) {
 //   ctab[256..767]  : u16[1024] full counts (only read for the rare "heavy" k-mer correction)
 //   ctab[768.. ]    : u16[LK]   ordered k-mers, 0xFFFF past the end
 constexpr int CTAB_SAT = 0, CTAB_CNT = 256, CTAB_ORD = 768;
-__global__ __launch_bounds__(256) void k_centre_table(SampleDev S, int centre, uint32_t *__restrict__ ctab) {
-  __shared__ uint32_t cnt[NKMER];
+static __device__ __forceinline__ void centre_table_body(const SampleDev &S, int centre, uint32_t *__restrict__ ctab, uint32_t *cnt) {
   const int tid = threadIdx.x;
   for (int k = tid; k < NKMER; k += 256) cnt[k] = 0;
   __syncthreads();
@@ -119,6 +118,13 @@ __global__ __launch_bounds__(256) void k_centre_table(SampleDev S, int centre, u
     sat[k] = (uint8_t)(c < RANK_SAT ? c : RANK_SAT);
     full[k] = (uint16_t)c;
   }
+}
+__global__ __launch_bounds__(256) void k_centre_table(SampleDev S, int centre, uint32_t *__restrict__ ctab) {
+  __shared__ uint32_t cnt[NKMER];
+  centre_table_body(S, centre, ctab, cnt);
+}
+void launch_centre_table(const SampleDev &S, int centre, uint32_t *d_ctab, hipStream_t st) {
+  hipLaunchKernelGGL(k_centre_table, dim3(1), dim3(256), 0, st, S, centre, d_ctab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -242,8 +248,8 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
 
 void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,
                    int greedy, const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
-                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, hipStream_t st) {
-  hipLaunchKernelGGL(k_centre_table, dim3(1), dim3(256), 0, st, S, centre, d_ctab);
+                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, bool build_table, hipStream_t st) {
+  if (build_table) hipLaunchKernelGGL(k_centre_table, dim3(1), dim3(256), 0, st, S, centre, d_ctab);
   int grid = std::min((S.N + 15) / 16, 2048);
   int iters = ((S.N + 15) / 16 + grid - 1) / grid;
   int cap = iters * 16;
@@ -1006,8 +1012,10 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
 // store filter of b_compare_parallel (cluster.cpp:179-201) for the round of cluster `ci`
 __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci, int centre, double total_reads,
                                                const double *__restrict__ lam, const uint32_t *__restrict__ ham,
-                                               const int32_t *__restrict__ round_counters, const uint8_t *__restrict__ cls) {
+                                               const int32_t *__restrict__ round_counters, const uint8_t *__restrict__ cls,
+                                               int32_t *__restrict__ zero2) {
   __shared__ int s_n, s_base, s_cls[2];
+  if (blockIdx.x == 0 && threadIdx.x < 2 && zero2) zero2[threadIdx.x] = 0;   // this round's shuffle counters
   const uint32_t creads = S.reads[centre];
   if (blockIdx.x == 0 && threadIdx.x < 2)   // fold this round's work-list sizes into the run totals
     atomicAdd((unsigned long long *)&P.totals[threadIdx.x], (unsigned long long)round_counters[threadIdx.x]);
@@ -1064,7 +1072,8 @@ __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci,
 // then the move unless the unique is its partition's centre.  Movers are reported to the host,
 // which replays them in the reference's order to maintain slots.
 __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const uint32_t *__restrict__ creads_snap,
-                                                 int32_t *__restrict__ movers, int32_t *__restrict__ nmovers) {
+                                                 int32_t *__restrict__ movers, int32_t *__restrict__ nmovers,
+                                                 int32_t *__restrict__ inl) {
   __shared__ int s_n, s_base;
   for (int base = blockIdx.x * 256; base < S.N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
@@ -1096,7 +1105,12 @@ __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_n ? atomicAdd(nmovers, s_n) : 0;
     __syncthreads();
-    if (move) { int32_t *m = movers + 3 * (size_t)(s_base + pos); m[0] = r; m[1] = from; m[2] = to; }
+    if (move) {
+      const int k = s_base + pos;
+      int32_t *m = movers + 3 * (size_t)k;
+      m[0] = r; m[1] = from; m[2] = to;
+      if (inl && k < MOVERS_INLINE) { inl[3 * k] = r; inl[3 * k + 1] = from; inl[3 * k + 2] = to; }
+    }
     __syncthreads();
   }
 }
@@ -1108,25 +1122,6 @@ static __device__ __forceinline__ double dev_get_pA(uint32_t reads, bool prior, 
   if (hamming == 0) return 1.;
   if (lambda == 0) return 0.;
   return pp::calc_pA((int)reads, lambda * bi_reads, prior || detect_singletons);
-}
-
-// b_p_update (pval.cpp:14-40): p-values of the members of partitions whose composition changed, and
-// greedy locking the first time a partition's centre is in place.
-__global__ __launch_bounds__(256) void k_pupdate(PartState P, SampleDev S, int greedy, int detect_singletons,
-                                                 const int32_t *__restrict__ guard) {
-  if (guard && *guard != 0) return;   // speculative launch: a later shuffle still moved uniques, redo after it
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= S.N) return;
-  const int cl = P.clust_of[r];
-  const double l = P.comp_lam[r];
-  const uint32_t reads = S.reads[r];
-  if (P.update_e[cl]) P.p[r] = dev_get_pA(reads, S.prior[r] != 0, detect_singletons != 0, l, P.comp_ham[r], P.creads[cl]);
-  if (greedy && P.check_locks[cl]) {
-    const int c = P.centre_of[cl];
-    const double E_center = S.reads[c] * l;
-    if (E_center > reads) P.lock[r] = 1;
-    if (r == c) P.lock[r] = 1;
-  }
 }
 
 // b_bud (cluster.cpp:274-350), arg-min part.  Key order: p ascending, then reads descending; exact
@@ -1144,15 +1139,27 @@ static __device__ __forceinline__ bool bud_candidate(const PartState &P, const S
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_bud_min(PartState P, SampleDev S, BudParams bp, BudKey init, BudKey *__restrict__ partial,
-                                                 const int32_t *__restrict__ guard) {
+// b_p_update fused with the first stage of b_bud: every thread refreshes p / lock of its uniques (pval.cpp:14-40)
+// and folds them straight into the block's (p, reads) minimum.
+__global__ __launch_bounds__(256) void k_pupdate_budmin(PartState P, SampleDev S, int greedy, int detect_singletons, BudParams bp,
+                                                        BudKey init, BudKey *__restrict__ partial,
+                                                        const int32_t *__restrict__ guard) {
   __shared__ BudKey s_k[2][4];
-  if (guard && *guard != 0) return;
+  if (guard && *guard != 0) return;   // speculative launch: a later shuffle still moved uniques, redo after it
   BudKey b0 = init, b1 = init;
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
-    if (!bud_candidate(P, S, r, bp)) continue;
-    const double p = P.p[r];
+    const int cl = P.clust_of[r];
+    const double l = P.comp_lam[r];
     const uint32_t reads = S.reads[r];
+    double p = P.p[r];
+    if (P.update_e[cl]) { p = dev_get_pA(reads, S.prior[r] != 0, detect_singletons != 0, l, P.comp_ham[r], P.creads[cl]); P.p[r] = p; }
+    if (greedy && P.check_locks[cl]) {
+      const int c = P.centre_of[cl];
+      const double E_center = S.reads[c] * l;
+      if (E_center > reads) P.lock[r] = 1;
+      if (r == c) P.lock[r] = 1;
+    }
+    if (!bud_candidate(P, S, r, bp)) continue;
     if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
     if (S.prior[r] && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
   }
@@ -1231,6 +1238,7 @@ __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudP
     if (k < BUD_TIES) {
       BudTie &t = out->ties[track][k];
       t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
+      t.from = P.clust_of[r]; t.from_reads = P.creads[t.from];
     }
     (track ? overflow1 : overflow0)[k] = r;
   }
@@ -1238,16 +1246,20 @@ __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudP
 
 // Applies a birth decided by the host (cluster.cpp:313-347): the unique leaves `from`, becomes the only
 // member and centre of the new partition; bi_assign_center unlocks it; both partitions are flagged.
-__global__ void k_apply_bud(PartState P, uint32_t *creads_snap, int raw, int newi, int from, uint32_t reads_new, uint32_t reads_from) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  P.clust_of[raw] = newi;
-  P.lock[raw] = 0;
-  P.slot0[raw] = 1;
-  P.creads[newi] = reads_new; creads_snap[newi] = reads_new;
-  P.creads[from] = reads_from; creads_snap[from] = reads_from;
-  P.centre_of[newi] = raw;
-  P.update_e[newi] = 1; P.check_locks[newi] = 1;
-  P.update_e[from] = 1;
+__global__ __launch_bounds__(256) void k_apply_bud(PartState P, SampleDev S, uint32_t *creads_snap, int raw, int newi, int from,
+                                                   uint32_t reads_new, uint32_t reads_from, uint32_t *__restrict__ ctab) {
+  __shared__ uint32_t cnt[NKMER];
+  if (threadIdx.x == 0) {
+    P.clust_of[raw] = newi;
+    P.lock[raw] = 0;
+    P.slot0[raw] = 1;
+    P.creads[newi] = reads_new; creads_snap[newi] = reads_new;
+    P.creads[from] = reads_from; creads_snap[from] = reads_from;
+    P.centre_of[newi] = raw;
+    P.update_e[newi] = 1; P.check_locks[newi] = 1;
+    P.update_e[from] = 1;
+  }
+  centre_table_body(S, raw, ctab, cnt);   // the new centre's k-mer record for the round that follows
 }
 
 // final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252)
@@ -1293,30 +1305,29 @@ void launch_fill_null(int n, const uint8_t *d_cls, double *d_lam, uint32_t *d_ha
 }
 
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
-                  const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, hipStream_t st) {
+                  const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, int32_t *d_zero2, hipStream_t st) {
   int grid = std::min((S.N + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_store, dim3(grid), dim3(256), 0, st, P, S, ci, centre, total_reads, d_lam, d_ham, d_round_counters, d_cls);
+  hipLaunchKernelGGL(k_store, dim3(grid), dim3(256), 0, st, P, S, ci, centre, total_reads, d_lam, d_ham, d_round_counters, d_cls,
+                     d_zero2);
 }
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
-                    hipStream_t st) {
+                    int32_t *d_inline, hipStream_t st) {
   int grid = std::min((S.N + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_shuffle, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers);
+  hipLaunchKernelGGL(k_shuffle, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers, d_inline);
 }
-void launch_pupdate(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const int32_t *d_guard,
-                    hipStream_t st) {
-  hipLaunchKernelGGL(k_pupdate, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, greedy, detect_singletons, d_guard);
-}
-void launch_bud(const PartState &P, const SampleDev &S, const BudParams &bp, double init_p, uint32_t init_reads, void *d_partial,
-                BudOut *d_out, int32_t *d_over0, int32_t *d_over1, int nclust, const int32_t *d_guard, hipStream_t st) {
+void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const BudParams &bp,
+                        double init_p, uint32_t init_reads, void *d_partial, BudOut *d_out, int32_t *d_over0, int32_t *d_over1,
+                        int nclust, const int32_t *d_guard, hipStream_t st) {
   BudKey init{init_p, init_reads};
   int grid = std::min((S.N + 255) / 256, 1024);
-  hipLaunchKernelGGL(k_bud_min, dim3(grid), dim3(256), 0, st, P, S, bp, init, (BudKey *)d_partial, d_guard);
+  hipLaunchKernelGGL(k_pupdate_budmin, dim3(grid), dim3(256), 0, st, P, S, greedy, detect_singletons, bp, init, (BudKey *)d_partial,
+                     d_guard);
   hipLaunchKernelGGL(k_bud_final, dim3(1), dim3(256), 0, st, P, (const BudKey *)d_partial, grid, init, d_out, nclust, d_guard);
   hipLaunchKernelGGL(k_bud_ties, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, bp, d_out, d_over0, d_over1, d_guard);
 }
-void launch_apply_bud(const PartState &P, uint32_t *d_creads_snap, int raw, int newi, int from, uint32_t reads_new,
-                      uint32_t reads_from, hipStream_t st) {
-  hipLaunchKernelGGL(k_apply_bud, dim3(1), dim3(64), 0, st, P, d_creads_snap, raw, newi, from, reads_new, reads_from);
+void launch_apply_bud(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, int raw, int newi, int from,
+                      uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, hipStream_t st) {
+  hipLaunchKernelGGL(k_apply_bud, dim3(1), dim3(256), 0, st, P, S, d_creads_snap, raw, newi, from, reads_new, reads_from, d_ctab);
 }
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st) {
   hipLaunchKernelGGL(k_final_p, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, omegaC, d_correct);
