@@ -70,6 +70,7 @@ using namespace d2;
 struct dada2hip_sample {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;    // late fetches (long mover lists) that must not queue behind the next round's kernels
   SampleDev D;
   DevBuf<uint32_t> seq2, heavy, reads;
   DevBuf<uint8_t> qual, nheavy, prior;
@@ -188,7 +189,8 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
 
   select_device(device);
   s->device = device;
-  D2_HIP(hipStreamCreate(&s->stream));
+  D2_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  D2_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
   D2_HIP(hipEventCreate(&s->ev0));
   D2_HIP(hipEventCreate(&s->ev1));
   SampleDev &D = s->D;
@@ -334,6 +336,7 @@ struct Run {
   DevBuf<BudKeyH> d_partial;
   DevBuf<RoundOut> d_rout;
   PinBuf<RoundOut> h_rout;                      // the round tail's result block (one D2H per round)
+  PinBuf<int32_t> h_big;                        // long mover lists
   DevBuf<int32_t> d_pool, d_thresh_one, d_thresh_round;   // zeroed counter pool; k-mer threshold tables
   size_t pool_next = 0;
   static constexpr size_t POOL_INTS = 1 << 18;
@@ -585,9 +588,12 @@ struct Run {
     const int nm = ro.cnt[slot];
     if (nm <= 0) return;
     if (nm > MOVERS_INLINE) {
-      std::vector<int32_t> big((size_t)3 * nm);
-      D2_HIP(hipMemcpy(big.data(), d_movers.p + (size_t)slot * 3 * N, big.size() * 4, hipMemcpyDeviceToHost));
-      replay_moves(big.data(), nm);
+      // the shuffle that wrote this list has completed (we synchronised on it); fetch it on the side stream so the
+      // copy does not wait for the next round's kernels already queued on the main stream
+      h_big.alloc((size_t)3 * nm);
+      D2_HIP(hipMemcpyAsync(h_big.p, d_movers.p + (size_t)slot * 3 * N, (size_t)3 * nm * 4, hipMemcpyDeviceToHost, s->side));
+      D2_HIP(hipStreamSynchronize(s->side));
+      replay_moves(h_big.p, nm);
     } else replay_moves(ro.mov[slot], nm);
   }
 
@@ -1121,6 +1127,7 @@ int dada2hip_sample_set_priors(dada2hip_sample *s, const uint8_t *priors, char *
 void dada2hip_sample_free(dada2hip_sample *s) {
   if (!s) return;
   if (s->stream) { (void)hipSetDevice(s->device); (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+  if (s->side) (void)hipStreamDestroy(s->side);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
