@@ -208,3 +208,20 @@ def test_work_counters_match_reference_counts(api, oracle_c):
     # every non-skipped, non-shrouded comparison is exactly one gapless pairing or one NW (+ final pass + births)
     rounds_work = st["ncompare"] - st["nskipped"] - st["nshroud"]
     assert st["nnw"] + st["ngapless"] == rounds_work + d.nraw + (got.nclust - 1)
+
+
+def test_full_config2_parity_vs_reference_itself(api):
+    """BASELINE.json configs[1] at full size (100 k uniques x 250 nt, tperr1): the GPU result against the
+    reference's own C++ (oracle/_ref, built in the authoring container and shipped as a binary) on all host
+    cores.  Skipped where the prebuilt reference is absent."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not present")
+    from dada2_amd.synth import make_sample
+    d = make_sample(tperr1(), 100_000, L=250, G=256, seed=20260925 + 2)
+    got = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())
+    ref.set_threads(os.cpu_count() or 1)
+    want = ref.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts(), multithread=True)
+    ref.set_threads(1)
+    assert got.nclust == want.nclust > 50
+    assert_results_equal(got, want, p_rtol=P_RTOL)
