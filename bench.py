@@ -118,7 +118,8 @@ def main():
         # bench.py cannot run the profiler on itself) — null when no matching profile is committed
         tr = load_traffic()
         if tr and args.uniques == 100_000 and args.length == 250:
-            roof_nw["traffic"] = tr.get("void k_nw_ad<32, true>", {}).get("hbm_bytes_per_launch")
+            coop = [v for k, v in tr.items() if k.startswith("void k_nw_ad") and isinstance(v, dict)]   # the per-round NW kernel
+            roof_nw["traffic"] = max(coop, key=lambda v: v.get("dispatches", 0)).get("hbm_bytes_per_launch") if coop else None
             roof_sc["traffic"] = tr.get("k_screen", {}).get("hbm_bytes_per_launch")
             roof_nw["traffic_source"] = roof_sc["traffic_source"] = tr.get("_file")
         roofline = roof_nw if nw_ms >= sc_ms else roof_sc
