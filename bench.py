@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--length", type=int, default=250)
     ap.add_argument("--variants", type=int, default=256)
     ap.add_argument("--band", type=int, default=16)
+    ap.add_argument("--lmin", type=int, default=0, help="ragged true-variant lengths in [lmin, length] (long-read configs)")
+    ap.add_argument("--q-hi", type=float, default=38.0)
+    ap.add_argument("--q-lo", type=float, default=22.0)
+    ap.add_argument("--q-sd", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-uniques", type=int, default=0, help="prefix of the sample timed on the CPU (0 = auto)")
     args = ap.parse_args()
@@ -62,7 +66,9 @@ def main():
     tperr1 = np.load(os.path.join(ROOT, "tests", "golden", "tperr1.npy"))
     opts = DadaOpts(BAND_SIZE=args.band)
     t0 = time.time()
-    d = make_sample(tperr1, args.uniques, L=args.length, G=args.variants, seed=20260925 + 2 + 1000 * rank)
+    d = make_sample(tperr1, args.uniques, L=args.length, G=args.variants, seed=20260925 + 2 + 1000 * rank,
+                    Lmin=args.lmin or None, q_hi=args.q_hi, q_lo=args.q_lo, q_sd=args.q_sd,
+                    chunk=200_000 if args.length <= 500 else 20_000)
     t_gen = time.time() - t0
     smp = api.Sample.from_derep(d, device=local)
 
@@ -181,7 +187,8 @@ def cpu_baseline(d, err, opts, cpu_uniques, gpu_res):
         out["seconds"] = t_all
         out["partitions"] = r.nclust
         # single thread on a smaller prefix so the default run stays within minutes
-        n1 = min(n, 20_000)
+        L = max(len(x) for x in seqs[:64])
+        n1 = min(n, max(500, int(20_000 * (250.0 / max(L, 250)) ** 2)))   # ~10-30 s of scalar CPU work at any read length
         ref.set_threads(1)
         t0 = time.perf_counter()
         r1 = ref.dada_uniques(seqs[:n1], ab[:n1], None, err, q[:n1], opts, multithread=False)

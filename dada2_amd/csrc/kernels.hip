@@ -962,6 +962,8 @@ int nw_class(int band, int maxlen, int minlen) {
   if (W <= 33) return 33;
   if (W <= 65) return 65;
   if (W <= 129) return 129;
+  if (W <= 193) return 193;   // ragged long reads (configs[4]): one wave per SIMD, the band row still in registers
+  if (W <= 257) return 257;
   return 0;
 }
 
@@ -993,6 +995,8 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
     case 33: hipLaunchKernelGGL(k_nw<33>, dim3(grid), dim3(256), lds, st, a); break;
     case 65: hipLaunchKernelGGL(k_nw<65>, dim3(grid), dim3(256), lds, st, a); break;
     case 129: hipLaunchKernelGGL(k_nw<129>, dim3(grid), dim3(256), lds, st, a); break;
+    case 193: hipLaunchKernelGGL(k_nw<193>, dim3(grid), dim3(256), lds, st, a); break;
+    case 257: hipLaunchKernelGGL(k_nw<257>, dim3(grid), dim3(256), lds, st, a); break;
     default: {
       int Wgen = (ap.band < 0) ? (2 * S.maxlen + 1) : (2 * ap.band + (S.maxlen - S.minlen) + 1);
       hipLaunchKernelGGL(k_nw_gen, dim3(grid), dim3(256), lds, st, a, Wgen);

@@ -93,6 +93,17 @@ def test_seeded_samples_match_oracle(api, oracle_c, seed, kw, monkeypatch):
     assert_results_equal(got, want, p_rtol=P_RTOL, check_birth_from=pri is None)
 
 
+@pytest.mark.parametrize("L,Lmin,band", [(300, 200, 32), (300, 160, 32), (260, 100, 64)])
+def test_ragged_wide_band_classes(api, oracle_c, L, Lmin, band):
+    """Ragged long-read shaped inputs: band + length spread of 165 / 205 / 289 cells -> the 193- and 257-cell
+    register classes of the lane kernel and the generic any-width kernel."""
+    d = _sample(40 + band + Lmin, 400, L=L, G=8, Lmin=Lmin, indel=1e-3)
+    o = DadaOpts(BAND_SIZE=band)
+    got = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)
+    want = oracle_c.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
 def test_resident_sample_reuse_and_selfconsist(api, oracle_c):
     """selfConsist loop (R/dada.R:256-405): the resident sample is reused across passes with only err
     changing; every pass must equal the oracle run with the same err."""
