@@ -86,7 +86,9 @@ struct dada2hip_sample {
   // per-run device work buffers (kept across runs: selfConsist passes reuse them)
   DevBuf<uint8_t> d_skip, d_cls, d_correct, d_moves;
   DevBuf<double> d_lambda, d_err;
-  DevBuf<uint32_t> d_ham, scr_ptr, scr_t, d_qn, d_ctab;
+  DevBuf<uint32_t> d_ham, scr_ptr, scr_t, d_qn, d_ctab, scr_adw;
+  int scr_adw_waves = 0, scr_adw_band = -999;
+  size_t scr_adw_wpw = 0;
   DevBuf<int32_t> d_nw_list, d_gl_list, d_counters, d_thresh, scr_rows, d_work, d_chunk_centre, d_cluster_of,
       d_centre_of_cluster, d_trans, d_nsubs, d_nmoves;
   DevBuf<uint16_t> d_view, d_view_b;
@@ -278,6 +280,18 @@ void ensure_scratch(dada2hip_sample *s, int band) {
   }
   s->scr_class = wc;
   s->scr_band = band;
+}
+
+// pointer ring of the wide anti-diagonal kernel: one slot per resident wave, at most 3 GiB
+void ensure_adw_scratch(dada2hip_sample *s, const AlignParams &ap) {
+  if (s->scr_adw.p && s->scr_adw_band == ap.band) return;
+  const size_t wpw = nw_adw_ptr_words_per_wave(s->D, ap);
+  int waves = std::min(8192, nw_adw_waves(s->D, ap, s->D.N));
+  while (waves > 4 && (size_t)waves * wpw > ((size_t)3 << 28)) waves = (waves / 2 + 3) & ~3;
+  s->scr_adw.alloc((size_t)waves * wpw);
+  s->scr_adw_waves = waves;
+  s->scr_adw_wpw = wpw;
+  s->scr_adw_band = ap.band;
 }
 
 // kdist > cutoff  <=>  dot < thresh[d]   with kdist = 1 - dot/d evaluated exactly as kmers.cpp:47,91 does
@@ -517,13 +531,23 @@ struct Run {
     bool coop = coop_ok && (ci != 0 || N < 65536);
     if (f && !strcmp(f, "lane")) coop = false;
     if (f && !strcmp(f, "coop") && coop_ok) coop = true;
-    if (coop)   // the gapless pairings of the round share the kernel's factor/product tail
+    // band windows too wide for the LDS-pointer kernel (ragged long reads): eight cells per lane, pointers in HBM
+    bool wide = !coop && nw_adw_ok(D, ap) && nw_adw_lds_bytes(D, ap) <= 150 * 1024 && wclass != 33 && wclass != 65 &&
+                N < (1 << 20);
+    if (f && !strcmp(f, "lane")) wide = false;
+    if (f && !strcmp(f, "wide")) wide = nw_adw_ok(D, ap) && nw_adw_lds_bytes(D, ap) <= 150 * 1024;
+    if (coop && !wide)   // the gapless pairings of the round share the kernel's factor/product tail
       launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, ctr, 0, s->d_gl_list.p, ctr + 1, ap, s->d_err.p, s->d_lambda.p,
                    s->d_ham.p, stq);
     else {
       launch_gapless(D, centre, nullptr, s->d_gl_list.p, ctr + 1, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, nullptr, 0, 0, stq);
-      launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
-                s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
+      if (wide) {
+        ensure_adw_scratch(s, ap);
+        launch_nw_adw(D, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr_adw.p, s->scr_adw_wpw,
+                      s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, stq);
+      } else
+        launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
+                  s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
     }
     if (timed) D2_HIP(hipEventRecord(evn.second, stq));
     launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p,

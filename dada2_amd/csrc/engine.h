@@ -163,6 +163,15 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, hipStream_t st);
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap);
 
+// wide-band / long-read anti-diagonal kernel (8 band cells per lane, pointers in an HBM ring of `scr_waves` wave slots)
+bool nw_adw_ok(const SampleDev &S, const AlignParams &ap);
+size_t nw_adw_ptr_words_per_wave(const SampleDev &S, const AlignParams &ap);
+int nw_adw_waves(const SampleDev &S, const AlignParams &ap, int nwork);
+size_t nw_adw_lds_bytes(const SampleDev &S, const AlignParams &ap);
+void launch_nw_adw(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work, const int32_t *d_nwork,
+                   int nwork_host, const AlignParams &ap, const double *d_err, uint32_t *d_ptr_scr, size_t ptr_wpw,
+                   int scr_waves, double *d_lambda, uint32_t *d_ham, hipStream_t st);
+
 void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint8_t *d_prior, double *d_out,
                     hipStream_t st);
 

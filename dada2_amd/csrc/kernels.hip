@@ -956,6 +956,324 @@ size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide-band / long-read variant of the anti-diagonal kernel (BASELINE.json configs[4]: ~1 500 nt, band 32,
+// ragged lengths -> band windows of 100-500 cells).  Same sweep as k_nw_ad, but every lane owns EIGHT
+// consecutive band cells (four live per step, all in registers), so 21 / 32 / 64 lanes cover windows of 168 /
+// 256 / 512 cells, and the 2-bit pointers go to an HBM scratch ring ([16-step block][cell pair][lane]: each flush
+// is four coalesced 256-B stores per wave) instead of LDS, which leaves LDS for 8 waves per CU.  The band origin
+// of each alignment is shifted by one cell when its left band is odd, so every alignment of a wave is in phase
+// (even cells on even steps) whatever the pair's length difference.
+// Cell k' = 8g + c of lane g maps to the pair's band cell k = k' - s (s = lband & 1); lbs = lband + s.
+// On an even step t the live cells c = 2m have i = I - m, j = J + m with I = (t - 8g + lbs) / 2, J = t - I; on the
+// following odd step the cells c = 2m + 1 have i = I - m, j = J + 1 + m.  The four centre bases and four raw bases
+// a step needs are two byte-packed shift registers fed by one LDS byte load per step.
+struct AdwGeom {
+  int GL, APW, pad, seqbytes, tbytes, fch, per_al_bytes, nblk16;
+};
+static __host__ __device__ inline AdwGeom adw_geom(int band, int maxlen, int minlen) {
+  AdwGeom G;
+  const int We = 2 * band + (maxlen - minlen) + 2;        // widest window + the phase cell
+  G.GL = We <= 168 ? 21 : (We <= 256 ? 32 : 64);
+  G.APW = 64 / G.GL;
+  G.pad = 8 * G.GL + 8;                                   // guard bytes either side of a staged sequence
+  G.seqbytes = (maxlen + 2 * G.pad + 7) & ~7;
+  G.tbytes = (maxlen + 7) & ~7;
+  G.fch = (G.seqbytes / 8) & ~7;                          // fp64 factors per chunk (they alias the centre bytes)
+  G.per_al_bytes = AD_RCAP * 4 + 2 * G.seqbytes + G.tbytes;
+  G.nblk16 = (2 * maxlen + 1 + 15) / 16 + 1;
+  return G;
+}
+
+// one step of a lane's four live cells.  PAR = parity of the live cells; FS = 2 * (t & 15) (field shift).
+template <int PAR, bool LEAN, bool DEF>
+static __device__ __forceinline__ void adw_step(int (&d)[8], uint32_t (&pw)[4], int fs, uint32_t x, int nb, uint32_t kmask,
+                                                int I, int Jr, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
+  const int SENT = DEF ? -32760 : SENT_, MATCH = DEF ? 5 : MATCH_, MISMATCH = DEF ? -4 : MISMATCH_, GAP = DEF ? -8 : GAP_;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int c = 2 * m + PAR;
+    const int left_src = PAR ? d[c - 1] : (m == 0 ? nb : d[c - 1]);
+    const int up_src = PAR ? (m == 3 ? nb : d[c + 1]) : d[c + 1];
+    const bool kin = (kmask >> c) & 1u;
+    const int diag = d[c] + (((x >> (8 * m)) & 0xFFu) == 0 ? MATCH : MISMATCH);
+    const int i = I - m, j = Jr + m;
+    const int up = up_src + ((!LEAN && j == L2) ? 0 : GAP);      // free moves along the last column
+    const int left = left_src + ((!LEAN && i == L1) ? 0 : GAP);  // ... and the last row
+    const bool t1 = left >= diag;
+    const int e1 = max(left, diag);
+    const bool t2 = up >= e1;
+    const int e = max(up, e1);
+    uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
+    int val;
+    if (LEAN) {
+      val = kin ? e : SENT;
+    } else {
+      const bool interior = kin && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
+      val = interior ? e : (kin ? 0 : SENT);
+      if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
+    }
+    d[c] = val;
+    pw[m] |= p << fs;
+  }
+}
+
+template <int GL, bool DEF>
+__global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
+  constexpr int APW = 64 / GL;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double *s_err = s_dyn;
+  const int nerr = 16 * a.ap.ncol;
+  for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
+  const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool ghost = lane / GL >= APW;                     // GL = 21: lane 63 rides along with no cells of its own
+  const int al = ghost ? APW - 1 : lane / GL, g = ghost ? GL : lane % GL;
+  uint8_t *abase = (uint8_t *)(s_dyn + nerr) + ((size_t)wib * APW + al) * G.per_al_bytes;
+  uint32_t *runs = (uint32_t *)abase;
+  double *fac = (double *)(abase + AD_RCAP * 4);           // aliases the centre bytes once the transition codes exist
+  uint8_t *cbytes = abase + AD_RCAP * 4 + G.pad;
+  uint8_t *rbytes = cbytes + G.seqbytes;
+  uint8_t *tcode = abase + AD_RCAP * 4 + 2 * G.seqbytes;
+  __syncthreads();
+  const SampleDev &S = a.S;
+  const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
+  uint32_t *pg = a.ptr_scr + (size_t)gwave * a.ptr_wpw;    // [16-step block][cell pair 0..3][lane]
+  const int nwork = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
+  const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
+  for (int chunk = gwave; chunk * APW < nwork; chunk += nwaves) {
+    const int idx = chunk * APW + al;
+    const int c = a.chunk_centre ? a.chunk_centre[chunk] : a.centre;
+    int r = idx < nwork ? a.work[idx] : -1;
+    const bool active = r >= 0;
+    if (!active) r = c;
+    const int L1 = S.len[c], L2 = S.len[r];
+    const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
+    const int W = lband + rband + 1;
+    const int sft = lband & 1, lbs = lband + sft;          // phase cell
+    const int T = active ? L1 + L2 : -1;
+    if (!ghost) {
+      for (int p = g; p < L1; p += GL) cbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)c * S.W2, p);
+      for (int p = g; p < L2; p += GL) rbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)r * S.W2, p);
+    }
+    int Tmax = T;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
+    if (Tmax >= 0) {
+      int d[8];
+      uint32_t pw[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 8; q++) d[q] = SENT;
+      uint32_t kmask = 0;
+      if (!ghost)
+        for (int q = 0; q < 8; q++) kmask |= (uint32_t)(8 * g + q >= sft && 8 * g + q < W + sft) << q;
+      const bool g_first = g == 0, g_last = ghost || g == GL - 1;
+      int I = (lbs >> 1) - 4 * g, J = -I;
+      uint32_t cwin = 0, rwin = 0;
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        cwin |= (uint32_t)cbytes[I - m - 1] << (8 * m);
+        rwin |= (uint32_t)rbytes[J + m - 1] << (8 * m);
+      }
+      // steady state [tA, tB): every in-band cell of every alignment of the wave is interior and off the last row / column
+      int tA = (lband > rband ? lband : rband) + 2, tB = min(2 * L1 - lband, 2 * L2 - rband);
+      if (T < 0) { tA = 0; tB = 0x3FFFFFFF; }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
+      tA = __builtin_amdgcn_readfirstlane(tA);
+      tB = __builtin_amdgcn_readfirstlane(tB);
+      Tmax = __builtin_amdgcn_readfirstlane(Tmax);
+#define ADW_EVEN(LEANV, FS)                                                                                              \
+  {                                                                                                                      \
+    const uint32_t nxt = rbytes[J + 3];                                                                                  \
+    int nb = __builtin_amdgcn_update_dpp(SENT, d[7], 0x138, 0xF, 0xF, false);   /* lane-1's last cell (wave_shr:1) */    \
+    if (g_first) nb = SENT;                                                                                              \
+    adw_step<0, LEANV, DEF>(d, pw, (FS), cwin ^ rwin, nb, kmask, I, J, L1, L2, SENT, MATCH, MISMATCH, GAP);              \
+    rwin = (rwin >> 8) | (nxt << 24);                                                                                    \
+  }
+#define ADW_ODD(LEANV, FS)                                                                                               \
+  {                                                                                                                      \
+    const uint32_t nxt = cbytes[I];                                                                                      \
+    int nb = __builtin_amdgcn_update_dpp(SENT, d[0], 0x130, 0xF, 0xF, false);   /* lane+1's first cell (wave_shl:1) */   \
+    if (g_last) nb = SENT;                                                                                               \
+    adw_step<1, LEANV, DEF>(d, pw, (FS), cwin ^ rwin, nb, kmask, I, J + 1, L1, L2, SENT, MATCH, MISMATCH, GAP);          \
+    cwin = (cwin << 8) | nxt;                                                                                            \
+    I++; J++;                                                                                                            \
+  }
+#define ADW_FLUSH(TT)                                                                                                    \
+  {                                                                                                                      \
+    uint32_t *dst = pg + (size_t)((TT) >> 4) * 256 + lane;                                                               \
+    dst[0] = pw[0]; dst[64] = pw[1]; dst[128] = pw[2]; dst[192] = pw[3];                                                 \
+    pw[0] = pw[1] = pw[2] = pw[3] = 0;                                                                                   \
+  }
+      int t = 0;
+      // leading steps with the matrix-edge logic, up to the first 16-step boundary inside the steady state
+      for (; t <= Tmax && (t < tA || (t & 15) != 0); t++) {
+        if ((t & 1) == 0) ADW_EVEN(false, (t & 15) << 1) else ADW_ODD(false, (t & 15) << 1)
+        if ((t & 15) == 15) ADW_FLUSH(t)
+      }
+      for (; t + 16 <= tB && t + 15 <= Tmax; t += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+          ADW_EVEN(true, 2 * u)
+          ADW_ODD(true, 2 * u + 2)
+        }
+        ADW_FLUSH(t)
+      }
+      for (; t <= Tmax; t++) {
+        if ((t & 1) == 0) ADW_EVEN(false, (t & 15) << 1) else ADW_ODD(false, (t & 15) << 1)
+        if ((t & 15) == 15) ADW_FLUSH(t)
+      }
+      if (((t - 1) & 15) != 15) ADW_FLUSH(t - 1)
+#undef ADW_EVEN
+#undef ADW_ODD
+#undef ADW_FLUSH
+    }
+    // ---- traceback (first lane of each group) in chunks of <= AD_RCAP merged runs; all lanes expand the runs
+    //      into one transition code per raw position (run format as in k_nw_ad)
+    int ti = L1, tj = L2;
+    bool done = !active;
+    uint32_t h = 0;
+    int guard = L1 + L2 + 2;
+    const int gl0 = al * GL;
+    while (true) {
+      int nruns = 0;
+      if (g == 0 && !done && !ghost) {
+        uint32_t last = 0;
+        auto push = [&](int lo, int n, int dl) {
+          if (last) {
+            const int llo = last & 4095, ln = (last >> 12) & 4095, ldl = (int)(last >> 24);
+            if (ldl == dl && lo + n == llo) { last = (uint32_t)lo | ((uint32_t)(ln + n) << 12) | ((uint32_t)dl << 24); return; }
+            runs[nruns++] = last;
+          }
+          last = (uint32_t)lo | ((uint32_t)n << 12) | ((uint32_t)dl << 24);
+        };
+        while ((ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard-- > 0) {
+          const int t = ti + tj, kk = tj - ti + lbs;
+          const uint32_t *wp = pg + ((kk >> 1) & 3) * 64 + gl0 + (kk >> 3);
+          const int f = t & 15;
+          const uint32_t word = wp[(size_t)(t >> 4) * 256];
+          const uint32_t x = word ^ 0x55555555u;              // non-diagonal fields of this cell's parity at positions <= f
+          uint32_t nz = (x | (x >> 1)) & 0x55555555u;
+          nz &= (f & 1) ? 0x44444444u : 0x11111111u;
+          nz &= (f == 15) ? 0xFFFFFFFFu : ((1u << ((f + 1) << 1)) - 1u);
+          int n;
+          bool stop;
+          if (nz) { const int fb = (31 - __clz(nz)) >> 1; n = (f - fb) >> 1; stop = true; }
+          else { n = (f >> 1) + 1; stop = false; }
+          if (n > 0) {
+            push(tj - n, n, ti - tj + 128);
+            ti -= n; tj -= n;
+          }
+          if (stop && (ti > 0 || tj > 0)) {
+            const int t2s = ti + tj;
+            const uint32_t w2 = (t2s >> 4) == (t >> 4) ? word : wp[(size_t)(t2s >> 4) * 256];
+            const uint32_t p = (w2 >> ((t2s & 15) << 1)) & 3u;
+            if (p == 2u) { tj--; push(tj, 1, 255); }
+            else ti--;
+          }
+        }
+        if (last) runs[nruns++] = last;
+        if (!(ti > 0 || tj > 0) || guard <= 0) done = true;
+      }
+      nruns = __shfl(nruns, gl0, 64);
+      done = __shfl((int)done, gl0, 64) != 0;
+      int nrmax = nruns;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) nrmax = max(nrmax, __shfl_xor(nrmax, o, 64));
+      for (int ri = 0; ri < nrmax; ri++) {
+        if (ri < nruns && !ghost) {
+          const uint32_t dsc = runs[ri];
+          const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
+          for (int pj = lo + g; pj < lo + n; pj += GL) {
+            const uint32_t rb = rbytes[pj];
+            uint32_t tc = 5u * rb;
+            if (dl != 255) {
+              const uint32_t cb = cbytes[pj + dl - 128];
+              tc = 4u * cb + rb;
+              h += (cb != rb);
+            }
+            tcode[pj] = (uint8_t)tc;
+          }
+        }
+      }
+      if (__all(done)) break;
+    }
+    if (g == 0 && !ghost) runs[0] = 0;
+    if (!ghost && h) atomicAdd(&runs[0], h);
+    h = runs[0];
+    // ---- lambda: factors in chunks of G.fch positions (all lanes), multiplied in raw-position order by one lane ----
+    int L2max = active ? L2 : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) L2max = max(L2max, __shfl_xor(L2max, o, 64));
+    double l = 1.0;
+    const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
+    for (int base = 0; base < L2max; base += G.fch) {
+      const int hi = min(L2, base + G.fch);
+      if (!ghost && active)
+        for (int pj = base + g; pj < hi; pj += GL) {
+          const uint32_t q = a.ap.use_quals ? qrow[pj] : 0u;
+          fac[pj - base] = s_err[(uint32_t)tcode[pj] * a.ap.ncol + q];
+        }
+      if (g == 0 && active && !ghost) {
+        const int n = hi - base;
+        int x = 0;
+        for (; x + 8 <= n; x += 8) {
+          const double f0 = fac[x], f1 = fac[x + 1], f2 = fac[x + 2], f3 = fac[x + 3];
+          const double f4 = fac[x + 4], f5 = fac[x + 5], f6 = fac[x + 6], f7 = fac[x + 7];
+          l = l * f0; l = l * f1; l = l * f2; l = l * f3; l = l * f4; l = l * f5; l = l * f6; l = l * f7;
+        }
+        for (; x < n; x++) l = l * fac[x];
+      }
+    }
+    if (g == 0 && active && !ghost) { a.lam[r] = l; a.ham[r] = h; }
+  }
+}
+
+// Does the wide anti-diagonal kernel apply to this sample / band?  (run descriptors hold 12-bit positions)
+bool nw_adw_ok(const SampleDev &S, const AlignParams &ap) {
+  return ap.band > 0 && S.maxlen <= 4095 && 2 * ap.band + (S.maxlen - S.minlen) + 2 <= 512;
+}
+size_t nw_adw_ptr_words_per_wave(const SampleDev &S, const AlignParams &ap) {
+  return (size_t)adw_geom(ap.band, S.maxlen, S.minlen).nblk16 * 256;
+}
+int nw_adw_waves(const SampleDev &S, const AlignParams &ap, int nwork) {
+  const AdwGeom G = adw_geom(ap.band, S.maxlen, S.minlen);
+  return ((nwork + G.APW - 1) / G.APW + 3) & ~3;
+}
+void launch_nw_adw(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work, const int32_t *d_nwork,
+                   int nwork_host, const AlignParams &ap, const double *d_err, uint32_t *d_ptr_scr, size_t ptr_wpw,
+                   int scr_waves, double *d_lambda, uint32_t *d_ham, hipStream_t st) {
+  const int maxwork = d_nwork ? S.N : nwork_host;
+  if (maxwork <= 0) return;
+  NwArgs a;
+  memset(&a, 0, sizeof a);
+  a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
+  a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
+  a.ptr_scr = d_ptr_scr; a.ptr_wpw = ptr_wpw;
+  const AdwGeom G = adw_geom(ap.band, S.maxlen, S.minlen);
+  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.APW * G.per_al_bytes;
+  const int waves = (maxwork + G.APW - 1) / G.APW;
+  const int grid = std::max(1, std::min((waves + 3) / 4, scr_waves / 4));
+  const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
+#define D2_LAUNCH_ADW(GLV, DEFV)                                                                                          \
+  do {                                                                                                                    \
+    static size_t attr_set = 0;                                                                                           \
+    if (lds > attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void *)k_nw_adw<GLV, DEFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set = lds;                                                                                                     \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((k_nw_adw<GLV, DEFV>), dim3(grid), dim3(256), lds, st, a, G);                                      \
+  } while (0)
+  if (G.GL == 21) { if (def) D2_LAUNCH_ADW(21, true); else D2_LAUNCH_ADW(21, false); }
+  else if (G.GL == 32) { if (def) D2_LAUNCH_ADW(32, true); else D2_LAUNCH_ADW(32, false); }
+  else { if (def) D2_LAUNCH_ADW(64, true); else D2_LAUNCH_ADW(64, false); }
+#undef D2_LAUNCH_ADW
+}
+size_t nw_adw_lds_bytes(const SampleDev &S, const AlignParams &ap) {
+  const AdwGeom G = adw_geom(ap.band, S.maxlen, S.minlen);
+  return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.APW * G.per_al_bytes;
+}
+
 int nw_class(int band, int maxlen, int minlen) {
   if (band < 0) return 0;
   const int W = 2 * band + (maxlen - minlen) + 1;

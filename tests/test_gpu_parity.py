@@ -22,7 +22,7 @@ def api():
     return a
 
 
-@pytest.mark.parametrize("nw_kernel", ["coop", "lane"])
+@pytest.mark.parametrize("nw_kernel", ["coop", "lane", "wide"])
 @pytest.mark.parametrize("name", WHOLE_PATH_CASES)
 def test_whole_path_matches_reference_goldens(api, oracle_c, name, nw_kernel, monkeypatch):
     """Both NW kernels (cooperative anti-diagonal k_nw_ad / lane-per-alignment k_nw) must give the
@@ -83,7 +83,7 @@ def _sample(seed, n, L=120, G=8, Lmin=None, indel=0.0):
     (10, dict(BAND_SIZE=0)), (11, dict(BAND_SIZE=-1)), (12, dict(BAND_SIZE=40)),
 ])
 def test_seeded_samples_match_oracle(api, oracle_c, seed, kw, monkeypatch):
-    monkeypatch.setenv("DADA2HIP_NW_KERNEL", "coop" if seed % 3 else "lane")
+    monkeypatch.setenv("DADA2HIP_NW_KERNEL", ("lane", "coop", "wide")[seed % 3])
     ragged = seed % 2 == 0
     d = _sample(seed, 800, Lmin=100 if ragged else None, indel=2e-3 if ragged else 0.0)
     o = DadaOpts(**kw)
@@ -93,10 +93,14 @@ def test_seeded_samples_match_oracle(api, oracle_c, seed, kw, monkeypatch):
     assert_results_equal(got, want, p_rtol=P_RTOL, check_birth_from=pri is None)
 
 
+@pytest.mark.parametrize("nw_kernel", ["auto", "lane"])
 @pytest.mark.parametrize("L,Lmin,band", [(300, 200, 32), (300, 160, 32), (260, 100, 64)])
-def test_ragged_wide_band_classes(api, oracle_c, L, Lmin, band):
-    """Ragged long-read shaped inputs: band + length spread of 165 / 205 / 289 cells -> the 193- and 257-cell
-    register classes of the lane kernel and the generic any-width kernel."""
+def test_ragged_wide_band_classes(api, oracle_c, L, Lmin, band, nw_kernel, monkeypatch):
+    """Ragged long-read shaped inputs: band + length spread of 165 / 205 / 289 cells -> the wide anti-diagonal kernel
+    with 21 / 32 / 64 lanes per alignment (auto), and the 193- / 257-cell register classes of the lane kernel and the
+    generic any-width kernel (lane)."""
+    if nw_kernel != "auto":
+        monkeypatch.setenv("DADA2HIP_NW_KERNEL", nw_kernel)
     d = _sample(40 + band + Lmin, 400, L=L, G=8, Lmin=Lmin, indel=1e-3)
     o = DadaOpts(BAND_SIZE=band)
     got = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)
