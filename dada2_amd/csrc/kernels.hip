@@ -640,9 +640,9 @@ constexpr int AD_RCAP = 64;   // run descriptors buffered per alignment between 
 // one anti-diagonal step of one lane's live cell.  PAR is the cell parity (k = 2g + PAR).
 // LEAN: steady-state step — every in-band cell of the wave is an interior cell away from the last
 // row/column, so the matrix-edge logic (axis cells, free end gaps) is compiled out.
-template <int GL, int PAR, bool DEF, bool LEAN>
+template <int GL, int PAR, bool DEF, bool LEAN, bool EDGE>
 static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
-                                               const uint8_t *cbytes, const uint8_t *rbytes, int t, bool g_first, bool g_last,
+                                               const uint8_t *cbytes, const uint8_t *rbytes, int fs, bool g_first, bool g_last,
                                                bool kok, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
   // DEF: the reference's default scoring (MATCH 5, MISMATCH -4, GAP -8, vectorized sentinel) as literals
   const int SENT = DEF ? -32760 : SENT_, MATCH = DEF ? 5 : MATCH_, MISMATCH = DEF ? -4 : MISMATCH_, GAP = DEF ? -8 : GAP_;
@@ -651,10 +651,10 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
   int left_src, up_src, own;
   if (PAR == 0) {
     const int lft = __builtin_amdgcn_update_dpp(SENT, d1, 0x138, 0xF, 0xF, false);   // lane-1's odd cell (wave_shr:1)
-    own = d0; left_src = g_first ? SENT : lft; up_src = d1;
+    own = d0; left_src = (EDGE && g_first) ? SENT : lft; up_src = d1;
   } else {
     const int upn = __builtin_amdgcn_update_dpp(SENT, d0, 0x130, 0xF, 0xF, false);   // lane+1's even cell (wave_shl:1)
-    own = d1; left_src = d0; up_src = g_last ? SENT : upn;
+    own = d1; left_src = d0; up_src = (EDGE && g_last) ? SENT : upn;
   }
   const int diag = own + (cb == rb ? MATCH : MISMATCH);
   const int up = up_src + ((!LEAN && j == L2) ? 0 : GAP);      // free moves along the last column
@@ -674,24 +674,30 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
     if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
   }
   if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
-  pw |= p << ((t & 15) << 1);
+  pw |= p << fs;
 }
 
 // LDS geometry of k_nw_ad, shared by host and device
 struct AdGeom {
-  int GL, APW, NCOL;        // lanes per alignment, alignments per wave, pointer columns per alignment (= ceil(W/2))
+  int GL, APW, NCOL;        // lanes per alignment, alignments per wave, pointer columns per alignment
+  int edge;                 // 1: group-boundary lanes must mask their DPP neighbour (band fills the group's cells)
   int nwords;               // pointer words per column (16 steps each)
   int area_words;           // per alignment: max(pointer words, 2*maxlen for the fp64 factors that later alias them)
   int seqbytes;             // bytes per staged sequence incl. guards (multiple of 8)
   int tbytes;               // bytes per transition-code / quality row (multiple of 8)
   int per_wave_words;
 };
+// Lane g of a group owns cells k' = 2g, 2g+1; an alignment's band cell k sits at k' = k + o.  The origin shift o makes
+// lband + o even, so every alignment of a wave is in phase (even cells live on even steps) whatever its length
+// difference.  When the group has room (W + 4 <= 2 GL) o is 2 or 3: the first two cells and the last cell of every
+// group are then never in band, always hold the sentinel, and the cross-group DPP reads need no masking.
 static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minlen) {
   AdGeom G;
   const int W = 2 * band + (maxlen - minlen) + 1;
-  G.GL = W <= 42 ? 21 : (W <= 64 ? 32 : 64);   // 21 lanes x 2 cells cover the default band (W = 33): 3 alignments per wave
+  G.GL = W + 1 <= 42 ? 21 : (W + 1 <= 64 ? 32 : 64);   // 21 lanes x 2 cells cover the default band (W = 33): 3 alignments per wave
   G.APW = 64 / G.GL;
-  G.NCOL = (W + 1) / 2;
+  G.edge = (W + 4 > 2 * G.GL) ? 1 : 0;
+  G.NCOL = (W + (G.edge ? 1 : 3) + 1) / 2;
   G.nwords = (2 * maxlen + 1 + 15) / 16;
   G.area_words = G.nwords * G.NCOL;
   if (G.area_words < 2 * maxlen) G.area_words = 2 * maxlen;
@@ -702,7 +708,7 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   return G;
 }
 
-template <int GL, bool DEF>
+template <int GL, bool DEF, bool EDGE>
 __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                AdGeom G) {
   constexpr int APW = 64 / GL;
@@ -754,60 +760,47 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
     const int dbg = a.moves_stride;
+    Tmax = __builtin_amdgcn_readfirstlane(Tmax);
+    const int org = (EDGE ? 0 : 2) + (lband & 1), lbo = lband + org;   // origin shift: lbo is even
     if (Tmax >= 0 && !(dbg & 1)) {
       int d0 = SENT, d1 = SENT;
       uint32_t pw = 0;
-      const int par0 = lband & 1;
-      int k = 2 * g + par0;
-      int i = (0 - k + lband) >> 1, j = 0 - i;
+      int i = (lbo >> 1) - g, j = -i;                        // the lane's even cell on step 0
       uint32_t cb = cbytes[i - 1], rb = rbytes[j - 1];
-      const bool g_first = g == 0, g_last = ghost || (g == GL - 1 && lane != 62);   // lane 62's neighbour may be the ghost (all SENT)
-      const bool kok0 = !ghost && 2 * g < W, kok1 = !ghost && 2 * g + 1 < W;
+      const bool g_first = g == 0, g_last = ghost || g == GL - 1;
+      const bool kok0 = !ghost && 2 * g >= org && 2 * g < W + org, kok1 = !ghost && 2 * g + 1 >= org && 2 * g + 1 < W + org;
       const bool colok = !ghost && g < NCOL;
-      const bool uniform_even = __all(par0 == 0), uniform_odd = __all(par0 == 1);
-      int t = 0;
-#define AD_FLUSH(TT) if (((TT) & 15) == 15) { if (colok) ptr[((TT) >> 4) * NCOL + g] = pw; pw = 0; }
-      if (uniform_even || uniform_odd) {
-        // all alignments of the wave are in phase: steps alternate even / odd cells for every lane.
-        // Steady state [tA, tB): every in-band cell of every alignment in the wave is interior and off the
-        // last row / column (i >= 1, j >= 1, i < L1, j < L2 for all k in the band).
-        int tA = (lband > rband ? lband : rband) + 2, tB = min(2 * L1 - lband, 2 * L2 - rband);
-        if (T < 0) { tA = 0; tB = 0x3FFFFFFF; }             // idle / gapless slot: no constraint
+      // Steady state [tA, tB): every in-band cell of every alignment in the wave is interior and off the
+      // last row / column (i >= 1, j >= 1, i < L1, j < L2 for all k in the band).
+      int tA = (lband > rband ? lband : rband) + 2, tB = min(2 * L1 - lband, 2 * L2 - rband);
+      if (T < 0) { tA = 0; tB = 0x3FFFFFFF; }               // idle / gapless slot: no constraint
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
-        tA = __builtin_amdgcn_readfirstlane(tA);
-        tB = __builtin_amdgcn_readfirstlane(tB);
-        const int p0 = uniform_odd ? 1 : 0;                  // parity of step t is (t + p0) & 1
-        if (((tA + p0) & 1) != 0) tA++;                      // the lean loop starts on an even cell
+      for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
+      tA = __builtin_amdgcn_readfirstlane(tA);
+      tB = __builtin_amdgcn_readfirstlane(tB);
+#define AD_FLUSH(TT) { if (colok) ptr[((TT) >> 4) * NCOL + g] = pw; pw = 0; }
 #define AD_FULL_STEP(TT)                                                                                                        \
   {                                                                                                                             \
-    if ((((TT) + p0) & 1) == 0)                                                                                                 \
-      ad_step<GL, 0, DEF, false>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, (TT), g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    if (((TT) & 1) == 0)                                                                                                        \
+      ad_step<GL, 0, DEF, false, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, ((TT) & 15) << 1, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
     else                                                                                                                        \
-      ad_step<GL, 1, DEF, false>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, (TT), g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
-    AD_FLUSH(TT)                                                                                                                \
+      ad_step<GL, 1, DEF, false, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, ((TT) & 15) << 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    if (((TT) & 15) == 15) AD_FLUSH(TT)                                                                                         \
   }
-        const int tA_end = min(tA, Tmax + 1);
-        for (; t < tA_end; t++) AD_FULL_STEP(t)
-        for (; t + 1 < tB && t + 1 <= Tmax; t += 2) {
-          ad_step<GL, 0, DEF, true>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          AD_FLUSH(t)
-          ad_step<GL, 1, DEF, true>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t + 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          AD_FLUSH(t + 1)
+      int t = 0;
+      // leading steps with the matrix-edge logic, up to the first 16-step boundary inside the steady state
+      for (; t <= Tmax && (t < tA || (t & 15) != 0); t++) AD_FULL_STEP(t)
+      // steady state in blocks of 16 steps = one pointer word per column: constant field shifts, one flush per block
+      for (; t + 16 <= tB && t + 15 <= Tmax; t += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+          ad_step<GL, 0, DEF, true, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, 2 * u, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          ad_step<GL, 1, DEF, true, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, 2 * u + 2, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
         }
-        for (; t <= Tmax; t++) AD_FULL_STEP(t)
-#undef AD_FULL_STEP
-      } else {
-        // mixed phases (ragged lengths): per-lane parity, both variants evaluated under the lane's own mask
-        int par = par0;
-        for (; t <= Tmax; t++) {
-          if (par == 0) ad_step<GL, 0, DEF, false>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          // (DPP reads of inactive lanes return `old`, and group-boundary reads are masked anyway)
-          if (par == 1) ad_step<GL, 1, DEF, false>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, t, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          AD_FLUSH(t)
-          par ^= 1;
-        }
+        AD_FLUSH(t)
       }
+      for (; t <= Tmax; t++) AD_FULL_STEP(t)
+#undef AD_FULL_STEP
 #undef AD_FLUSH
       if (((t - 1) & 15) != 15 && colok) ptr[((t - 1) >> 4) * NCOL + g] = pw;
     }
@@ -838,7 +831,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
           done = true;
         } else {
           while ((ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard-- > 0) {
-            const int t = ti + tj, kk = tj - ti + lband;
+            const int t = ti + tj, kk = tj - ti + lbo;
             const int col = kk >> 1;
             const int f = t & 15;
             const uint32_t word = ptr[(t >> 4) * NCOL + col];
@@ -932,18 +925,24 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   if (d_gl_work) waves = (S.N + G.APW - 1) / G.APW;
   int grid = std::min((waves + 3) / 4, 256 * 8);
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
-#define D2_LAUNCH_AD(GLV, DEFV)                                                                                          \
+#define D2_LAUNCH_AD(GLV, DEFV, EDGEV)                                                                                   \
   do {                                                                                                                   \
     static size_t attr_set = 0;                                                                                          \
     if (lds > attr_set) {                                                                                                \
-      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_set = lds;                                                                                                    \
     }                                                                                                                    \
-    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);               \
+    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);        \
   } while (0)
-  if (G.GL == 21) { if (def) D2_LAUNCH_AD(21, true); else D2_LAUNCH_AD(21, false); }
-  else if (G.GL == 32) { if (def) D2_LAUNCH_AD(32, true); else D2_LAUNCH_AD(32, false); }
-  else { if (def) D2_LAUNCH_AD(64, true); else D2_LAUNCH_AD(64, false); }
+#define D2_LAUNCH_AD2(GLV)                                                                                               \
+  do {                                                                                                                   \
+    if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true); else D2_LAUNCH_AD(GLV, true, false); }                         \
+    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true); else D2_LAUNCH_AD(GLV, false, false); }                           \
+  } while (0)
+  if (G.GL == 21) D2_LAUNCH_AD2(21);
+  else if (G.GL == 32) D2_LAUNCH_AD2(32);
+  else D2_LAUNCH_AD2(64);
+#undef D2_LAUNCH_AD2
 #undef D2_LAUNCH_AD
 }
 
@@ -951,7 +950,7 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   if (ap.band <= 0 || S.maxlen > 2047) return 0;
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
-  if (W > 128) return 0;
+  if (W > 127) return 0;
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
   return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
 }
