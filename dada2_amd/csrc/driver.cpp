@@ -423,6 +423,7 @@ struct Run {
     D2_HIP(hipMemsetAsync(d_ncount.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(d_errflag.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(d_totals.p, 0, 32, stq));
+    have_pending_store = false;
     D2_HIP(hipMemsetAsync(d_pool.p, 0, POOL_INTS * 4, stq));
     pool_next = 0;
     D2_HIP(hipMemcpyAsync(d_thresh_one.p, thresh_one.data(), thresh_one.size() * 4, hipMemcpyHostToDevice, stq));
@@ -550,8 +551,13 @@ struct Run {
                   s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
     }
     if (timed) D2_HIP(hipEventRecord(evn.second, stq));
-    launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p,
-                 d_rout.p->cnt, stq);
+    if (ci == 0)   // round 0 is followed by b_p_update directly (Rmain.cpp:309-311)
+      launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p,
+                   d_rout.p->cnt, stq);
+    else {         // later rounds: the store filter rides in front of the round's first shuffle
+      pending_store = StoreRound{ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p};
+      have_pending_store = true;
+    }
     n_round_launches++;
     st.ncompare += (uint64_t)N;
     st.ms_screen += ms_since(t0);
@@ -593,13 +599,17 @@ struct Run {
   int32_t *enqueue_shuffle(int slot) {
     hipStream_t stq = s->stream;
     RoundOut *ro = d_rout.p;
-    launch_shuffle(P, s->D, d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot], stq);
+    launch_shuffle(P, s->D, d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot],
+                   have_pending_store ? &pending_store : nullptr, stq);
+    have_pending_store = false;
     // partition reads may have changed: refresh the snapshot the next arg-max uses (reads as of call start)
     D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)nclust_dev * 4, hipMemcpyDeviceToDevice, stq));
     st.nshuffle++;
     return ro->cnt + slot;
   }
   int nclust_dev = 1;   // partitions the device knows about (the host mirror may lag by one birth)
+  StoreRound pending_store{};
+  bool have_pending_store = false;
 
   void fetch_round_out() {
     D2_HIP(hipMemcpyAsync(h_rout.p, d_rout.p, sizeof(RoundOut), hipMemcpyDeviceToHost, s->stream));
@@ -753,7 +763,7 @@ struct Run {
     const int raw = b.c.raw;
     if (b.newi >= ccap) grow_clusters(std::max(ccap * 2, b.newi + 1));
     launch_apply_bud(P, s->D, d_creads_snap.p, raw, b.newi, b.c.from, s->h_reads[raw], b.c.from_reads - s->h_reads[raw],
-                     s->d_ctab.p, s->stream);
+                     s->d_ctab.p, d_rout.p->cnt, s->stream);
     nclust_dev = b.newi + 1;
   }
 

@@ -95,8 +95,17 @@ struct BudParams {
 void launch_fill_null(int n, const uint8_t *d_cls, double *d_lam, uint32_t *d_ham, hipStream_t st);
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
                   const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, int32_t *d_zero2, hipStream_t st);
-void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
-                    int32_t *d_inline, hipStream_t st);
+// The store filter of a round (ci >= 1) rides in front of the round's first shuffle: pass its arguments here.
+struct StoreRound {
+  int ci, centre;
+  double total_reads;
+  const double *lam;
+  const uint32_t *ham;
+  const int32_t *round_counters;
+  const uint8_t *cls;
+};
+void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers,
+                    int32_t *d_nmovers, int32_t *d_inline, const StoreRound *store, hipStream_t st);
 // result block of one b_bud evaluation, fetched by the host in a single copy
 constexpr int BUD_TIES = 16;
 struct BudTie { int32_t raw, comp_i; uint32_t comp_ham; int32_t from; uint32_t from_reads, pad; double comp_lam; };
@@ -111,18 +120,18 @@ struct BudOut {
 // Everything the host needs from one round tail, fetched with a single copy.
 constexpr int MOVERS_INLINE = 512;
 struct RoundOut {
-  int32_t cnt[2];              // movers of the two speculative shuffles (zeroed by k_store of the same round)
+  int32_t cnt[2];              // movers of the two speculative shuffles (zeroed by k_apply_bud ahead of the round)
   int32_t pad[2];
   BudOut bud;
   int32_t mov[2][3 * MOVERS_INLINE];   // first movers of each shuffle (raw, from, to); the full lists stay on the device
 };
-// fused b_p_update + first stage of b_bud, then the two small bud stages
+// fused b_p_update + first stage of b_bud, then the reduction + tie listing
 void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const BudParams &bp,
                         double init_p, uint32_t init_reads, void *d_partial, BudOut *d_out, int32_t *d_over0, int32_t *d_over1,
                         int nclust, const int32_t *d_guard, hipStream_t st);
 // birth + the new centre's k-mer record for the coming round (one launch)
 void launch_apply_bud(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, int raw, int newi, int from,
-                      uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, hipStream_t st);
+                      uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, int32_t *d_zero2, hipStream_t st);
 void launch_centre_table(const SampleDev &S, int centre, uint32_t *d_ctab, hipStream_t st);
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st);
 void launch_posthoc(const PartState &P, const SampleDev &S, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam,

@@ -1388,28 +1388,88 @@ __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci,
     atomicAdd((unsigned long long *)&P.totals[2 + threadIdx.x], (unsigned long long)s_cls[threadIdx.x]);
 }
 
+// Arguments of the store filter when it rides in front of the round's first shuffle (k_shuffle<true>)
+struct StoreArgs {
+  int ci, centre;
+  double total_reads;
+  const double *lam;
+  const uint32_t *ham;
+  const int32_t *round_counters;
+  const uint8_t *cls;
+};
+
 // b_shuffle2 (cluster.cpp:210-266): per unique, the stored comparison with the largest expected
 // reads lambda * bi[i].reads (reads as of the start of the call; ties go to the lowest cluster),
 // then the move unless the unique is its partition's centre.  Movers are reported to the host,
 // which replays them in the reference's order to maintain slots.
+// STORE: the round's store filter (k_store's body, cluster.cpp:179-201) runs first on the same unique - the new
+// comparison is the head of the unique's list, so the arg-max starts from it in registers.
+// (No "last block refreshes the snapshot" here: a device-scope fence per block writes back and invalidates the
+// XCD's L2 on this part - measured 1.7x slower at 1e6 uniques - so the snapshot stays a copy between launches.)
+template <bool STORE>
 __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const uint32_t *__restrict__ creads_snap,
                                                  int32_t *__restrict__ movers, int32_t *__restrict__ nmovers,
-                                                 int32_t *__restrict__ inl) {
-  __shared__ int s_n, s_base;
+                                                 int32_t *__restrict__ inl, StoreArgs sa) {
+  __shared__ int s_n, s_base, s_sn, s_sbase, s_cls[2];
+  uint32_t screads = 0;
+  int my_shroud = 0, my_skip = 0;
+  if (STORE) {
+    screads = S.reads[sa.centre];
+    if (blockIdx.x == 0 && threadIdx.x < 2)   // fold this round's work-list sizes into the run totals
+      atomicAdd((unsigned long long *)&P.totals[threadIdx.x], (unsigned long long)sa.round_counters[threadIdx.x]);
+    if (threadIdx.x < 2) s_cls[threadIdx.x] = 0;
+  }
   for (int base = blockIdx.x * 256; base < S.N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) { s_n = 0; s_sn = 0; }
     __syncthreads();
+    double best_e = -1.0, best_l = 0.0;
+    int best_i = 0x7FFFFFFF;
+    uint32_t best_h = 0;
+    int head = -1;
+    if (r < S.N) head = P.head[r];
+    // ---- store filter of this round's comparison ----
+    bool keep = false;
+    double l = 0.0;
+    uint32_t h = 0;
+    int spos = 0;
+    if (STORE && r < S.N) {
+      const uint8_t cl = sa.cls[r];
+      my_shroud += (cl == CLS_SHROUD);
+      my_skip += (cl == CLS_SKIP);
+      if (cl == CLS_SHROUD || cl == CLS_SKIP) { l = 0.0; h = 0xFFFFFFFFu; }   // NULL sub (cluster.cpp:139-143)
+      else { l = sa.lam[r]; h = sa.ham[r]; }
+      if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);          // "Lambda out-of-range error." (cluster.cpp:184)
+      const double em = P.E_minmax[r];
+      keep = l * sa.total_reads > em;                                  // this cluster could attract this raw
+      if (keep) {
+        if (l * screads > em) P.E_minmax[r] = l * screads;
+        spos = atomicAdd(&s_sn, 1);
+        if (r == sa.centre) { P.comp_i[r] = sa.ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
+        best_e = l * creads_snap[sa.ci]; best_i = sa.ci; best_l = l; best_h = h;
+      }
+    }
+    if (STORE) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_sbase = s_sn ? atomicAdd(P.node_count, s_sn) : 0;
+      __syncthreads();
+      if (keep) {
+        const int n = s_sbase + spos;
+        if (n < P.node_cap) {
+          P.node_i[n] = sa.ci; P.node_lam[n] = l; P.node_ham[n] = h;
+          P.node_next[n] = head;
+          P.head[r] = n;
+        } else atomicOr(P.err_flag, 2);
+      }
+    }
+    // ---- arg-max over the stored comparisons and the move ----
     bool move = false;
     int from = 0, to = 0, pos = 0;
     if (r < S.N) {
-      double best_e = -1.0, best_l = 0.0;
-      int best_i = 0x7FFFFFFF;
-      uint32_t best_h = 0;
-      for (int n = P.head[r]; n >= 0; n = P.node_next[n]) {
+      for (int n = head; n >= 0; n = P.node_next[n]) {
         const int i = P.node_i[n];
-        const double l = P.node_lam[n], e = l * creads_snap[i];
-        if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = l; best_h = P.node_ham[n]; }
+        const double nl = P.node_lam[n], e = nl * creads_snap[i];
+        if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_h = P.node_ham[n]; }
       }
       from = P.clust_of[r];
       if (best_i != 0x7FFFFFFF && best_i != from && r != P.centre_of[from]) {
@@ -1433,6 +1493,14 @@ __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const
       if (inl && k < MOVERS_INLINE) { inl[3 * k] = r; inl[3 * k + 1] = from; inl[3 * k + 2] = to; }
     }
     __syncthreads();
+  }
+  if (STORE) {   // class statistics of the round (nshroud / greedy skips, dada.h:113-114)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { my_shroud += __shfl_xor(my_shroud, o, 64); my_skip += __shfl_xor(my_skip, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cls[0], my_shroud); atomicAdd(&s_cls[1], my_skip); }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cls[threadIdx.x])
+      atomicAdd((unsigned long long *)&P.totals[2 + threadIdx.x], (unsigned long long)s_cls[threadIdx.x]);
   }
 }
 
@@ -1461,12 +1529,18 @@ static __device__ __forceinline__ bool bud_candidate(const PartState &P, const S
 }
 
 // b_p_update fused with the first stage of b_bud: every thread refreshes p / lock of its uniques (pval.cpp:14-40)
-// and folds them straight into the block's (p, reads) minimum.
+// and folds them straight into the block's (p, reads) minimum.  Block 0 also resets the result block's tie counters
+// (or marks the evaluation cancelled).
 __global__ __launch_bounds__(256) void k_pupdate_budmin(PartState P, SampleDev S, int greedy, int detect_singletons, BudParams bp,
-                                                        BudKey init, BudKey *__restrict__ partial,
+                                                        BudKey init, BudKey *__restrict__ partial, BudOut *__restrict__ out,
                                                         const int32_t *__restrict__ guard) {
   __shared__ BudKey s_k[2][4];
-  if (guard && *guard != 0) return;   // speculative launch: a later shuffle still moved uniques, redo after it
+  const bool cancelled = guard && *guard != 0;   // speculative launch: a later shuffle still moved uniques, redo after it
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out->nties[0] = 0; out->nties[1] = 0;
+    if (cancelled) { out->valid = 0; out->found[0] = 0; out->found[1] = 0; }
+  }
+  if (cancelled) return;
   BudKey b0 = init, b1 = init;
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
     const int cl = P.clust_of[r];
@@ -1505,19 +1579,21 @@ __global__ __launch_bounds__(256) void k_pupdate_budmin(PartState P, SampleDev S
   }
 }
 
-// second stage: reduce the block partials (one block), publish best keys; also gathers the error flag
-// and the comparison-store fill level into the result block and clears the per-partition flags that
-// k_pupdate has just consumed (pval.cpp:24,37).
-__global__ __launch_bounds__(256) void k_bud_final(PartState P, const BudKey *__restrict__ partial, int nblocks, BudKey init,
-                                                   BudOut *__restrict__ out, int nclust, const int32_t *__restrict__ guard) {
-  __shared__ BudKey s_k[2][256];
-  if (guard && *guard != 0) { if (threadIdx.x == 0) { out->valid = 0; out->nties[0] = 0; out->nties[1] = 0; out->found[0] = 0; out->found[1] = 0; } return; }
+// second stage: EVERY block reduces the block partials to the best keys (a few KB from L2 - cheaper than a launch of
+// its own), then lists the candidates of its uniques whose key equals the best one (normally exactly one in the
+// whole grid) as tie records.  Block 0 publishes the keys, gathers the error flag and the comparison-store fill
+// level into the result block and clears the per-partition flags k_pupdate_budmin has consumed (pval.cpp:24,37).
+__global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudParams bp, const BudKey *__restrict__ partial,
+                                                  int nblocks, BudKey init, int nclust, BudOut *__restrict__ out,
+                                                  int32_t *__restrict__ overflow0, int32_t *__restrict__ overflow1,
+                                                  const int32_t *__restrict__ guard) {
+  __shared__ BudKey s_k[2][4];
+  if (guard && *guard != 0) return;
   BudKey b0 = init, b1 = init;
   for (int k = threadIdx.x; k < nblocks; k += 256) {
     if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
     if (bud_better(partial[2 * k + 1].p, partial[2 * k + 1].reads, b1)) b1 = partial[2 * k + 1];
   }
-  for (int k = threadIdx.x; k < nclust; k += 256) { P.update_e[k] = 0; P.check_locks[k] = 0; }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     BudKey t;
@@ -1528,48 +1604,49 @@ __global__ __launch_bounds__(256) void k_bud_final(PartState P, const BudKey *__
   }
   if ((threadIdx.x & 63) == 0) { s_k[0][threadIdx.x >> 6] = b0; s_k[1][threadIdx.x >> 6] = b1; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; k++) {
-      if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
-      if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
-    }
-    out->best_p[0] = b0.p; out->best_p[1] = b1.p;
-    out->best_reads[0] = b0.reads; out->best_reads[1] = b1.reads;
-    out->found[0] = bud_better(b0.p, b0.reads, init); out->found[1] = bud_better(b1.p, b1.reads, init);
-    out->nties[0] = 0; out->nties[1] = 0;
-    out->err_flag = *P.err_flag;
-    out->node_count = *P.node_count;
-    out->valid = 1;
+  b0 = s_k[0][0]; b1 = s_k[1][0];
+  for (int k = 1; k < 4; k++) {
+    if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
+    if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
   }
-}
-
-// third stage: every candidate whose key equals the best one (normally exactly one) -> tie records
-__global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudParams bp, BudOut *__restrict__ out,
-                                                  int32_t *__restrict__ overflow0, int32_t *__restrict__ overflow1,
-                                                  const int32_t *__restrict__ guard) {
-  if (guard && *guard != 0) return;
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= S.N || !bud_candidate(P, S, r, bp)) return;
-  const double p = P.p[r];
-  const uint32_t reads = S.reads[r];
-  for (int track = 0; track < 2; track++) {
-    if (track == 1 && !S.prior[r]) continue;
-    if (!out->found[track] || p != out->best_p[track] || reads != out->best_reads[track]) continue;
-    const int k = atomicAdd(&out->nties[track], 1);
-    if (k < BUD_TIES) {
-      BudTie &t = out->ties[track][k];
-      t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
-      t.from = P.clust_of[r]; t.from_reads = P.creads[t.from];
+  const bool found0 = bud_better(b0.p, b0.reads, init), found1 = bud_better(b1.p, b1.reads, init);
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < nclust; k += 256) { P.update_e[k] = 0; P.check_locks[k] = 0; }
+    if (threadIdx.x == 0) {
+      out->best_p[0] = b0.p; out->best_p[1] = b1.p;
+      out->best_reads[0] = b0.reads; out->best_reads[1] = b1.reads;
+      out->found[0] = found0; out->found[1] = found1;
+      out->err_flag = *P.err_flag;
+      out->node_count = *P.node_count;
+      out->valid = 1;
     }
-    (track ? overflow1 : overflow0)[k] = r;
+  }
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+    if (!bud_candidate(P, S, r, bp)) continue;
+    const double p = P.p[r];
+    const uint32_t reads = S.reads[r];
+    for (int track = 0; track < 2; track++) {
+      if (track == 1 && !S.prior[r]) continue;
+      const BudKey &bk = track ? b1 : b0;
+      if (!(track ? found1 : found0) || p != bk.p || reads != bk.reads) continue;
+      const int k = atomicAdd(&out->nties[track], 1);
+      if (k < BUD_TIES) {
+        BudTie &t = out->ties[track][k];
+        t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
+        t.from = P.clust_of[r]; t.from_reads = P.creads[t.from];
+      }
+      (track ? overflow1 : overflow0)[k] = r;
+    }
   }
 }
 
 // Applies a birth decided by the host (cluster.cpp:313-347): the unique leaves `from`, becomes the only
 // member and centre of the new partition; bi_assign_center unlocks it; both partitions are flagged.
 __global__ __launch_bounds__(256) void k_apply_bud(PartState P, SampleDev S, uint32_t *creads_snap, int raw, int newi, int from,
-                                                   uint32_t reads_new, uint32_t reads_from, uint32_t *__restrict__ ctab) {
+                                                   uint32_t reads_new, uint32_t reads_from, uint32_t *__restrict__ ctab,
+                                                   int32_t *__restrict__ zero2) {
   __shared__ uint32_t cnt[NKMER];
+  if (threadIdx.x < 2 && zero2) zero2[threadIdx.x] = 0;   // the coming round's shuffle counters
   if (threadIdx.x == 0) {
     P.clust_of[raw] = newi;
     P.lock[raw] = 0;
@@ -1631,10 +1708,15 @@ void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, do
   hipLaunchKernelGGL(k_store, dim3(grid), dim3(256), 0, st, P, S, ci, centre, total_reads, d_lam, d_ham, d_round_counters, d_cls,
                      d_zero2);
 }
-void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers, int32_t *d_nmovers,
-                    int32_t *d_inline, hipStream_t st) {
+void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers,
+                    int32_t *d_nmovers, int32_t *d_inline, const StoreRound *store, hipStream_t st) {
   int grid = std::min((S.N + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_shuffle, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers, d_inline);
+  StoreArgs sa{};
+  if (store) {
+    sa = StoreArgs{store->ci, store->centre, store->total_reads, store->lam, store->ham, store->round_counters, store->cls};
+    hipLaunchKernelGGL(k_shuffle<true>, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers, d_inline, sa);
+  } else
+    hipLaunchKernelGGL(k_shuffle<false>, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers, d_inline, sa);
 }
 void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const BudParams &bp,
                         double init_p, uint32_t init_reads, void *d_partial, BudOut *d_out, int32_t *d_over0, int32_t *d_over1,
@@ -1642,13 +1724,14 @@ void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int 
   BudKey init{init_p, init_reads};
   int grid = std::min((S.N + 255) / 256, 1024);
   hipLaunchKernelGGL(k_pupdate_budmin, dim3(grid), dim3(256), 0, st, P, S, greedy, detect_singletons, bp, init, (BudKey *)d_partial,
-                     d_guard);
-  hipLaunchKernelGGL(k_bud_final, dim3(1), dim3(256), 0, st, P, (const BudKey *)d_partial, grid, init, d_out, nclust, d_guard);
-  hipLaunchKernelGGL(k_bud_ties, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, bp, d_out, d_over0, d_over1, d_guard);
+                     d_out, d_guard);
+  hipLaunchKernelGGL(k_bud_ties, dim3(std::min((S.N + 255) / 256, 512)), dim3(256), 0, st, P, S, bp, (const BudKey *)d_partial, grid,
+                     init, nclust, d_out, d_over0, d_over1, d_guard);
 }
 void launch_apply_bud(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, int raw, int newi, int from,
-                      uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, hipStream_t st) {
-  hipLaunchKernelGGL(k_apply_bud, dim3(1), dim3(256), 0, st, P, S, d_creads_snap, raw, newi, from, reads_new, reads_from, d_ctab);
+                      uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, int32_t *d_zero2, hipStream_t st) {
+  hipLaunchKernelGGL(k_apply_bud, dim3(1), dim3(256), 0, st, P, S, d_creads_snap, raw, newi, from, reads_new, reads_from, d_ctab,
+                     d_zero2);
 }
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st) {
   hipLaunchKernelGGL(k_final_p, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, omegaC, d_correct);
