@@ -787,9 +787,17 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       ad_step<GL, 1, DEF, false, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, ((TT) & 15) << 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
     if (((TT) & 15) == 15) AD_FLUSH(TT)                                                                                         \
   }
+#define AD_LEAN_PAIR(TT)                                                                                                        \
+  {                                                                                                                             \
+    ad_step<GL, 0, DEF, true, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, ((TT) & 15) << 1, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    ad_step<GL, 1, DEF, true, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, (((TT) + 1) & 15) << 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    if ((((TT) + 1) & 15) == 15) AD_FLUSH((TT) + 1)                                                                             \
+  }
       int t = 0;
-      // leading steps with the matrix-edge logic, up to the first 16-step boundary inside the steady state
-      for (; t <= Tmax && (t < tA || (t & 15) != 0); t++) AD_FULL_STEP(t)
+      // leading steps with the matrix-edge logic up to the steady state, then steady-state pairs up to a 16-step boundary
+      const int tA2 = (tA + 1) & ~1;
+      for (; t <= Tmax && t < tA2; t++) AD_FULL_STEP(t)
+      for (; (t & 15) != 0 && t + 2 <= tB && t + 1 <= Tmax; t += 2) AD_LEAN_PAIR(t)
       // steady state in blocks of 16 steps = one pointer word per column: constant field shifts, one flush per block
       for (; t + 16 <= tB && t + 15 <= Tmax; t += 16) {
 #pragma unroll
@@ -799,7 +807,9 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
         }
         AD_FLUSH(t)
       }
+      for (; t + 2 <= tB && t + 1 <= Tmax; t += 2) AD_LEAN_PAIR(t)
       for (; t <= Tmax; t++) AD_FULL_STEP(t)
+#undef AD_LEAN_PAIR
 #undef AD_FULL_STEP
 #undef AD_FLUSH
       if (((t - 1) & 15) != 15 && colok) ptr[((t - 1) >> 4) * NCOL + g] = pw;
