@@ -424,6 +424,7 @@ struct Run {
     D2_HIP(hipMemsetAsync(d_errflag.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(d_totals.p, 0, 32, stq));
     have_pending_store = false;
+    snap_fresh = true;   // sample_run copies partition 0's reads into the snapshot right after
     D2_HIP(hipMemsetAsync(d_pool.p, 0, POOL_INTS * 4, stq));
     pool_next = 0;
     D2_HIP(hipMemcpyAsync(d_thresh_one.p, thresh_one.data(), thresh_one.size() * 4, hipMemcpyHostToDevice, stq));
@@ -595,15 +596,20 @@ struct Run {
     if (slot0_changed) push_slot0();
   }
 
-  // enqueue one b_shuffle2 (device arg-max + move); count and first movers go to slot `slot` of the round's result block
-  int32_t *enqueue_shuffle(int slot) {
+  // enqueue one b_shuffle2 (device arg-max + move); count and first movers go to slot `slot` of the round's result block.
+  // The arg-max uses the partition reads as of the start of the call: a snapshot, refreshed by k_apply_bud ahead of
+  // every round and by an explicit copy before any further real shuffle.  check = count would-be movers only (the
+  // speculative second shuffle): nothing moves, so it reads the live reads and needs no snapshot.
+  bool snap_fresh = true;
+  int32_t *enqueue_shuffle(int slot, bool check = false) {
     hipStream_t stq = s->stream;
     RoundOut *ro = d_rout.p;
-    launch_shuffle(P, s->D, d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot],
-                   have_pending_store ? &pending_store : nullptr, stq);
+    if (!check && !snap_fresh)
+      D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)nclust_dev * 4, hipMemcpyDeviceToDevice, stq));
+    launch_shuffle(P, s->D, check ? P.creads : d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot],
+                   have_pending_store ? &pending_store : nullptr, check ? 1 : 0, nclust_dev, stq);
     have_pending_store = false;
-    // partition reads may have changed: refresh the snapshot the next arg-max uses (reads as of call start)
-    D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)nclust_dev * 4, hipMemcpyDeviceToDevice, stq));
+    if (!check) snap_fresh = false;
     st.nshuffle++;
     return ro->cnt + slot;
   }
@@ -649,21 +655,39 @@ struct Run {
     auto t0 = clk::now();
     int nsh = 0;
     const int32_t *guard = nullptr;
+    static const bool no_spec = getenv("DADA2HIP_NO_SPECULATION") != nullptr;   // test knob: the reference's plain loop
+    if (do_shuffle && no_spec) {
+      bool shuffled = true;
+      while (shuffled && nsh < MAX_SHUFFLE) {
+        D2_HIP(hipMemsetAsync(d_rout.p->cnt, 0, 8, s->stream));
+        enqueue_shuffle(0);
+        fetch_round_out();
+        shuffled = h_rout.p->cnt[0] > 0;
+        apply_shuffle_result(0);
+        nsh++;
+      }
+      enqueue_pupdate_bud(nullptr);
+      fetch_round_out();
+      pending_slots = 0;
+      st.ms_bookkeep += ms_since(t0);
+      return;
+    }
     if (do_shuffle) {
       enqueue_shuffle(0);
-      guard = enqueue_shuffle(1);
+      guard = enqueue_shuffle(1, /*check=*/true);
       nsh = 2;
     }
     enqueue_pupdate_bud(guard);
     fetch_round_out();
-    pending_slots = do_shuffle ? 2 : 0;
+    pending_slots = do_shuffle ? 1 : 0;
     if (do_shuffle) {
       const int nm1 = h_rout.p->cnt[0], nm2 = h_rout.p->cnt[1];
       if (nm1 == 0) st.nshuffle--;                     // the reference stops after the first unmoving shuffle
       if (nm2 > 0) {                                    // speculation cancelled: keep shuffling like the reference
         apply_shuffle_result(0);
-        apply_shuffle_result(1);
         pending_slots = 0;
+        st.nshuffle--;                                  // the check stood for a call that does move: redo it for real
+        nsh = 1;
         bool shuffled = true;
         while (shuffled && nsh < MAX_SHUFFLE) {
           D2_HIP(hipMemsetAsync(d_rout.p->cnt, 0, 8, s->stream));
@@ -765,6 +789,7 @@ struct Run {
     launch_apply_bud(P, s->D, d_creads_snap.p, raw, b.newi, b.c.from, s->h_reads[raw], b.c.from_reads - s->h_reads[raw],
                      s->d_ctab.p, d_rout.p->cnt, s->stream);
     nclust_dev = b.newi + 1;
+    snap_fresh = true;                                   // k_apply_bud rewrote the whole snapshot
   }
 
   // host mirror of the same birth: bi_pop_raw from its partition, new Bi with the unique as only member and centre

@@ -104,8 +104,9 @@ struct StoreRound {
   const int32_t *round_counters;
   const uint8_t *cls;
 };
+// check_only: count would-be movers, apply nothing (d_creads_snap may then be the live reads)
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers,
-                    int32_t *d_nmovers, int32_t *d_inline, const StoreRound *store, hipStream_t st);
+                    int32_t *d_nmovers, int32_t *d_inline, const StoreRound *store, int check_only, int nclust, hipStream_t st);
 // result block of one b_bud evaluation, fetched by the host in a single copy
 constexpr int BUD_TIES = 16;
 struct BudTie { int32_t raw, comp_i; uint32_t comp_ham; int32_t from; uint32_t from_reads, pad; double comp_lam; };

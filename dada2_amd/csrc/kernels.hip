@@ -1416,11 +1416,20 @@ struct StoreArgs {
 // comparison is the head of the unique's list, so the arg-max starts from it in registers.
 // (No "last block refreshes the snapshot" here: a device-scope fence per block writes back and invalidates the
 // XCD's L2 on this part - measured 1.7x slower at 1e6 uniques - so the snapshot stays a copy between launches.)
+// check_only: count the uniques that WOULD move, apply nothing (then the live partition reads can stand in for the
+// snapshot: nothing changes them during the kernel).  The speculative second shuffle of a round is such a check.
+// Reads deltas of the movers are accumulated per block in LDS (partitions < DELTA_TAB) and flushed with one global
+// atomic per touched partition: thousands of movers join the same new partition in a round, and same-address
+// device atomics serialise.
+constexpr int DELTA_TAB = 2048;
 template <bool STORE>
 __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const uint32_t *__restrict__ creads_snap,
                                                  int32_t *__restrict__ movers, int32_t *__restrict__ nmovers,
-                                                 int32_t *__restrict__ inl, StoreArgs sa) {
+                                                 int32_t *__restrict__ inl, int check_only, int nclust, StoreArgs sa) {
   __shared__ int s_n, s_base, s_sn, s_sbase, s_cls[2];
+  __shared__ int32_t s_delta[DELTA_TAB];
+  const int ntab = nclust < DELTA_TAB ? nclust : DELTA_TAB;
+  if (!check_only) for (int k = threadIdx.x; k < ntab; k += 256) s_delta[k] = 0;
   uint32_t screads = 0;
   int my_shroud = 0, my_skip = 0;
   if (STORE) {
@@ -1483,14 +1492,17 @@ __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const
       }
       from = P.clust_of[r];
       if (best_i != 0x7FFFFFFF && best_i != from && r != P.centre_of[from]) {
-        move = true;
+        move = !check_only;
         to = best_i;
-        P.clust_of[r] = to;
-        P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
-        atomicAdd(&P.creads[to], S.reads[r]);
-        atomicSub(&P.creads[from], S.reads[r]);
-        P.update_e[to] = 1; P.update_e[from] = 1;
         pos = atomicAdd(&s_n, 1);
+        if (move) {
+          P.clust_of[r] = to;
+          P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
+          const uint32_t rd = S.reads[r];
+          if (to < ntab) atomicAdd(&s_delta[to], (int32_t)rd); else atomicAdd(&P.creads[to], rd);
+          if (from < ntab) atomicSub(&s_delta[from], (int32_t)rd); else atomicSub(&P.creads[from], rd);
+          P.update_e[to] = 1; P.update_e[from] = 1;
+        }
       }
     }
     __syncthreads();
@@ -1503,6 +1515,12 @@ __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const
       if (inl && k < MOVERS_INLINE) { inl[3 * k] = r; inl[3 * k + 1] = from; inl[3 * k + 2] = to; }
     }
     __syncthreads();
+  }
+  if (!check_only) {   // (the loop ends on a barrier: every delta of the block is in the table)
+    for (int k = threadIdx.x; k < ntab; k += 256) {
+      const int32_t dlt = s_delta[k];
+      if (dlt) atomicAdd(&P.creads[k], (uint32_t)dlt);
+    }
   }
   if (STORE) {   // class statistics of the round (nshroud / greedy skips, dada.h:113-114)
 #pragma unroll
@@ -1657,6 +1675,8 @@ __global__ __launch_bounds__(256) void k_apply_bud(PartState P, SampleDev S, uin
                                                    int32_t *__restrict__ zero2) {
   __shared__ uint32_t cnt[NKMER];
   if (threadIdx.x < 2 && zero2) zero2[threadIdx.x] = 0;   // the coming round's shuffle counters
+  // the coming round's first shuffle reads the partition reads as of its start: refresh the whole snapshot here
+  for (int k = threadIdx.x; k < newi; k += 256) if (k != from) creads_snap[k] = P.creads[k];
   if (threadIdx.x == 0) {
     P.clust_of[raw] = newi;
     P.lock[raw] = 0;
@@ -1719,14 +1739,16 @@ void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, do
                      d_zero2);
 }
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers,
-                    int32_t *d_nmovers, int32_t *d_inline, const StoreRound *store, hipStream_t st) {
+                    int32_t *d_nmovers, int32_t *d_inline, const StoreRound *store, int check_only, int nclust, hipStream_t st) {
   int grid = std::min((S.N + 255) / 256, 2048);
   StoreArgs sa{};
   if (store) {
     sa = StoreArgs{store->ci, store->centre, store->total_reads, store->lam, store->ham, store->round_counters, store->cls};
-    hipLaunchKernelGGL(k_shuffle<true>, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers, d_inline, sa);
+    hipLaunchKernelGGL(k_shuffle<true>, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers, d_inline, check_only,
+                       nclust, sa);
   } else
-    hipLaunchKernelGGL(k_shuffle<false>, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers, d_inline, sa);
+    hipLaunchKernelGGL(k_shuffle<false>, dim3(grid), dim3(256), 0, st, P, S, d_creads_snap, d_movers, d_nmovers, d_inline,
+                       check_only, nclust, sa);
 }
 void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const BudParams &bp,
                         double init_p, uint32_t init_reads, void *d_partial, BudOut *d_out, int32_t *d_over0, int32_t *d_over1,

@@ -108,6 +108,28 @@ def test_ragged_wide_band_classes(api, oracle_c, L, Lmin, band, nw_kernel, monke
     assert_results_equal(got, want, p_rtol=P_RTOL)
 
 
+def test_plain_shuffle_loop_equals_speculative_round_tail(oracle_c):
+    """The round tail normally enqueues shuffle + a check-only second shuffle + p-update + bud speculatively; the plain
+    loop of Rmain.cpp:320-325 (one shuffle per device round trip, snapshot refreshed by a copy) is what it falls back to
+    when the second shuffle still moves uniques.  Both must give the reference's result (run in a subprocess: the knob is
+    read once per process)."""
+    import subprocess, sys
+    code = (
+        "import numpy as np, sys\n"
+        "root = %r\n"
+        "sys.path[:0] = [root, root + '/tests']\n"
+        "from helpers import case_inputs, assert_results_equal, P_RTOL\n"
+        "from dada2_amd import api\n"
+        "for name in ('sam1F_default', 'sam2F_nogreedy', 'synth3000_default'):\n"
+        "    d, err, pri, o, exp, meta = case_inputs(name)\n"
+        "    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"
+        "    assert_results_equal(got, exp, p_rtol=P_RTOL, check_birth_from=pri is None)\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DADA2HIP_NO_SPECULATION="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_resident_sample_reuse_and_selfconsist(api, oracle_c):
     """selfConsist loop (R/dada.R:256-405): the resident sample is reused across passes with only err
     changing; every pass must equal the oracle run with the same err."""
