@@ -325,6 +325,9 @@ struct Bi {
 
 struct BudKeyH { double p; uint32_t reads; uint32_t pad; };
 
+// below this many alignments in one launch the cooperative (anti-diagonal) kernel beats one-alignment-per-lane
+constexpr int COOP_MAX_BATCH = 262144;
+
 struct Run {
   dada2hip_sample *s;
   dada2hip_opts o;
@@ -530,7 +533,7 @@ struct Run {
     if (timed) { evn = new_events(nw_events, nw_ev_used); D2_HIP(hipEventRecord(evn.first, stq)); }
     const char *f = getenv("DADA2HIP_NW_KERNEL");
     const bool coop_ok = nw_ad_lds_bytes(D, ap) > 0 && nw_ad_lds_bytes(D, ap) <= 150 * 1024;
-    bool coop = coop_ok && (ci != 0 || N < 65536);
+    bool coop = coop_ok && (ci != 0 || N < COOP_MAX_BATCH);
     if (f && !strcmp(f, "lane")) coop = false;
     if (f && !strcmp(f, "coop") && coop_ok) coop = true;
     // band windows too wide for the LDS-pointer kernel (ragged long reads): eight cells per lane, pointers in HBM
@@ -540,7 +543,7 @@ struct Run {
     if (f && !strcmp(f, "wide")) wide = nw_adw_ok(D, ap) && nw_adw_lds_bytes(D, ap) <= 150 * 1024;
     if (coop && !wide)   // the gapless pairings of the round share the kernel's factor/product tail
       launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, ctr, 0, s->d_gl_list.p, ctr + 1, ap, s->d_err.p, s->d_lambda.p,
-                   s->d_ham.p, stq);
+                   s->d_ham.p, nullptr, 0, 0, stq);
     else {
       launch_gapless(D, centre, nullptr, s->d_gl_list.p, ctr + 1, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, nullptr, 0, 0, stq);
       if (wide) {
@@ -938,16 +941,24 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   auto t_final = clk::now();
   const int C = (int)run.bi.size();
   const int LV = D.maxlen;
+  // work slots grouped in chunks that share a centre: 64 (one wave of the lane kernel) or the cooperative kernel's
+  // alignments per wave
+  const char *fk = getenv("DADA2HIP_NW_KERNEL");
+  const bool coop_fin_ok = opts->band_size != 0 && nw_ad_lds_bytes(D, run.ap) > 0 && nw_ad_lds_bytes(D, run.ap) <= 150 * 1024;
+  bool coop_fin = coop_fin_ok && N < COOP_MAX_BATCH;
+  if (fk && !strcmp(fk, "lane")) coop_fin = false;
+  if (fk && !strcmp(fk, "coop") && coop_fin_ok) coop_fin = true;
+  const size_t per = coop_fin ? (size_t)nw_ad_apw(D, run.ap) : 64;
   std::vector<int32_t> work, chunk_centre, centre_of_cluster(C);
-  work.reserve((size_t)N + 64 * (size_t)C);
+  work.reserve((size_t)N + per * (size_t)C);
   for (int i = 0; i < C; i++) {
     centre_of_cluster[i] = (int32_t)run.bi[i].center;
     const auto &m = run.bi[i].raw;
     for (size_t k = 0; k < m.size(); k++) {
-      if (k % 64 == 0) chunk_centre.push_back((int32_t)run.bi[i].center);
+      if (k % per == 0) chunk_centre.push_back((int32_t)run.bi[i].center);
       work.push_back((int32_t)m[k]);
     }
-    while (work.size() % 64) work.push_back(-1);
+    while (work.size() % per) work.push_back(-1);
   }
   s->d_work.alloc(work.size()); s->d_chunk_centre.alloc(chunk_centre.size());
   s->d_view.alloc((size_t)N * LV);
@@ -963,8 +974,12 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   } else {
     auto evn = run.new_events(run.nw_events, run.nw_ev_used);
     D2_HIP(hipEventRecord(evn.first, stq));
-    launch_nw(D, run.wclass, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr,
-              s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, 0, nullptr, stq);
+    if (coop_fin)
+      launch_nw_ad(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), nullptr, nullptr, run.ap, s->d_err.p,
+                   s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, stq);
+    else
+      launch_nw(D, run.wclass, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr,
+                s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, 0, nullptr, stq);
     D2_HIP(hipEventRecord(evn.second, stq));
     run.st.nnw += (uint64_t)N;
   }
@@ -1031,11 +1046,14 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     std::vector<uint8_t> pair_cls(nb);
     D2_HIP(hipMemcpyAsync(pair_cls.data(), d_bcls.p, (size_t)nb, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
-    std::vector<int32_t> w_gl((size_t)nb * 64, -1), w_nw((size_t)nb * 64, -1);
+    bool coop_b = coop_fin_ok;                       // one pair per chunk: the cooperative kernel needs no 64-wide batch
+    if (fk && !strcmp(fk, "lane")) coop_b = false;
+    const size_t pern = coop_b ? (size_t)nw_ad_apw(D, run.ap) : 64;
+    std::vector<int32_t> w_gl((size_t)nb * 64, -1), w_nw((size_t)nb * pern, -1);
     int n_gl = 0, n_nw = 0;
     for (int k = 0; k < nb; k++) {
       if (pair_cls[k] == CLS_GAPLESS) { w_gl[(size_t)k * 64] = braw[k]; n_gl++; }
-      else { w_nw[(size_t)k * 64] = braw[k]; n_nw++; }
+      else { w_nw[(size_t)k * pern] = braw[k]; n_nw++; }
     }
     d_wgl.alloc(w_gl.size()); d_wnw.alloc(w_nw.size());
     s->d_view_b.alloc((size_t)nb * LV);
@@ -1044,8 +1062,12 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     D2_HIP(hipMemsetAsync(s->d_view_b.p, 0, (size_t)nb * LV * 2, stq));
     if (n_gl) launch_gapless(D, 0, d_bcc.p, d_wgl.p, nullptr, (int)w_gl.size(), run.ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
                              s->d_view_b.p, LV, 1, stq);
-    if (n_nw) launch_nw(D, run.wclass, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), run.ap, s->d_err.p, s->scr, s->d_lambda.p,
-                        s->d_ham.p, s->d_view_b.p, LV, 1, nullptr, 0, nullptr, stq);
+    if (n_nw && coop_b)
+      launch_nw_ad(D, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
+                   s->d_ham.p, s->d_view_b.p, LV, 1, stq);
+    else if (n_nw)
+      launch_nw(D, run.wclass, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), run.ap, s->d_err.p, s->scr, s->d_lambda.p,
+                s->d_ham.p, s->d_view_b.p, LV, 1, nullptr, 0, nullptr, stq);
     D2_HIP(hipMemcpyAsync(&bview[(size_t)LV], s->d_view_b.p, (size_t)nb * LV * 2, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
     run.st.ngapless += (uint64_t)n_gl;
@@ -1263,7 +1285,7 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
       D2_HIP(hipEventRecord(s->ev0, stq));
       if (coop)
         launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
-                     s->d_ham.p, stq);
+                     s->d_ham.p, nullptr, 0, 0, stq);
       else
         launch_nw(D, run.wclass, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, run.ap, s->d_err.p, s->scr, s->d_lambda.p,
                   s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);

@@ -168,9 +168,12 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
                int moves_stride, int32_t *d_nmoves, hipStream_t st);
 
 // d_gl_work/d_gl_nwork (optional): the round's gapless comparisons, processed by the same kernel
+// d_view (optional): aligned views, row = unique (or chunk when view_by_chunk); chunks are nw_ad_apw() work slots
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
-                  const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, hipStream_t st);
+                  const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,
+                  int view_by_chunk, hipStream_t st);
+int nw_ad_apw(const SampleDev &S, const AlignParams &ap);
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap);
 
 // wide-band / long-read anti-diagonal kernel (8 band cells per lane, pointers in an HBM ring of `scr_waves` wave slots)

@@ -756,6 +756,10 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       const uint32_t *qsrc = (const uint32_t *)(S.qual + (size_t)r * S.LQ);
       for (int w = g; w * 4 < L2; w += GL) ((uint32_t *)qlds)[w] = qsrc[w];
     }
+    // aligned view of the unique on its centre (final pass / birth substitutions): centre positions facing a gap stay 0
+    const size_t vr = a.view_by_chunk ? (size_t)chunk : (size_t)r;
+    if (a.view && active && !ghost)
+      for (int p = g; p < L1; p += GL) a.view[vr * a.LV + p] = 0;
     int Tmax = T;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
@@ -886,6 +890,8 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
               const uint32_t cb = cbytes[pj + dl - 128];
               tc = 4u * cb + rb;
               h += (cb != rb);
+              if (a.view && active)
+                a.view[vr * a.LV + pj + dl - 128] = (uint16_t)(0x8000u | (rb << 8) | (a.ap.use_quals ? qlds[pj] : 0));
             }
             tcode[pj] = (uint8_t)tc;
           }
@@ -921,13 +927,15 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
 
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
-                  const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, hipStream_t st) {
+                  const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,
+                  int view_by_chunk, hipStream_t st) {
   int maxwork = d_nwork ? S.N : nwork_host;
   if (maxwork <= 0 && !d_gl_work) return;
   NwArgs a;
   memset(&a, 0, sizeof a);
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
+  a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk;
   { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
   const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
@@ -957,6 +965,7 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
 }
 
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
+int nw_ad_apw(const SampleDev &S, const AlignParams &ap) { return ad_geom(ap.band, S.maxlen, S.minlen).APW; }
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   if (ap.band <= 0 || S.maxlen > 2047) return 0;
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
