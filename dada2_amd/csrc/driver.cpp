@@ -686,22 +686,26 @@ struct Run {
     if (do_shuffle) {
       const int nm1 = h_rout.p->cnt[0], nm2 = h_rout.p->cnt[1];
       if (nm1 == 0) st.nshuffle--;                     // the reference stops after the first unmoving shuffle
-      if (nm2 > 0) {                                    // speculation cancelled: keep shuffling like the reference
+      if (nm2 > 0) {
+        // Speculation cancelled: the second shuffle moves uniques too.  Keep shuffling like the reference, each
+        // further call again enqueued together with a check of the call after it and the p-update / bud evaluation.
         apply_shuffle_result(0);
         pending_slots = 0;
         st.nshuffle--;                                  // the check stood for a call that does move: redo it for real
         nsh = 1;
-        bool shuffled = true;
-        while (shuffled && nsh < MAX_SHUFFLE) {
+        for (;;) {
           D2_HIP(hipMemsetAsync(d_rout.p->cnt, 0, 8, s->stream));
           enqueue_shuffle(0);
-          fetch_round_out();
-          shuffled = h_rout.p->cnt[0] > 0;
-          apply_shuffle_result(0);
           nsh++;
+          const bool last = nsh >= MAX_SHUFFLE;         // Rmain.cpp:321: the loop stops at MAX_SHUFFLE calls regardless
+          const int32_t *g2 = nullptr;
+          if (!last) { g2 = enqueue_shuffle(1, /*check=*/true); nsh++; }
+          enqueue_pupdate_bud(g2);
+          fetch_round_out();
+          apply_shuffle_result(0);
+          if (last || h_rout.p->cnt[1] == 0) break;     // stable (or out of calls): the evaluation just fetched is valid
+          st.nshuffle--; nsh--;                          // that check moves again: it is redone as the next real call
         }
-        enqueue_pupdate_bud(nullptr);
-        fetch_round_out();
       }
     }
     st.ms_bookkeep += ms_since(t0);
