@@ -400,7 +400,11 @@ struct Run {
     P.E_minmax = d_Emin.p; P.comp_lam = d_clam.p; P.p = d_p.p; P.lock = d_lock.p; P.slot0 = d_slot0.p; P.clust_of = d_clof.p;
     P.comp_i = d_ci.p; P.comp_ham = d_cham.p; P.head = d_head.p; P.node_count = d_ncount.p; P.err_flag = d_errflag.p;
     P.totals = d_totals.p;
-    grow_nodes(std::max<size_t>(4 * n, 1u << 20));
+    {   // comparison store: grows by doubling (decide_bud); DADA2HIP_NODE_CAP shrinks the first allocation (test knob)
+      size_t cap0 = std::max<size_t>(4 * n, 1u << 20);
+      if (const char *e = getenv("DADA2HIP_NODE_CAP")) cap0 = std::max<size_t>((size_t)atoll(e), n + 16);
+      grow_nodes(cap0);
+    }
     grow_clusters(256);
     hipStream_t stq = s->stream;
     // (buffers persist across runs of the same sample: clear what a previous run left behind)

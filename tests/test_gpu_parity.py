@@ -108,6 +108,30 @@ def test_ragged_wide_band_classes(api, oracle_c, L, Lmin, band, nw_kernel, monke
     assert_results_equal(got, want, p_rtol=P_RTOL)
 
 
+def _golden_cases_in_subprocess(env_extra, names):
+    import subprocess, sys
+    code = (
+        "import numpy as np, sys\n"
+        "root = %r\n"
+        "sys.path[:0] = [root, root + '/tests']\n"
+        "from helpers import case_inputs, assert_results_equal, P_RTOL\n"
+        "from dada2_amd import api\n"
+        "for name in %r:\n"
+        "    d, err, pri, o, exp, meta = case_inputs(name)\n"
+        "    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"
+        "    assert_results_equal(got, exp, p_rtol=P_RTOL, check_birth_from=pri is None)\n"
+        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tuple(names))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_comparison_store_growth():
+    """The device-resident comparison store (Bi::comp of every partition) starts at 4 N entries and doubles on demand;
+    with the first allocation forced down to N + 16 it has to grow (and be copied) several times in a run."""
+    _golden_cases_in_subprocess({"DADA2HIP_NODE_CAP": "1"}, ("sam1F_default", "sam2F_nogreedy", "synth3000_default"))
+
+
 def test_plain_shuffle_loop_equals_speculative_round_tail(oracle_c):
     """The round tail normally enqueues shuffle + a check-only second shuffle + p-update + bud speculatively; the plain
     loop of Rmain.cpp:320-325 (one shuffle per device round trip, snapshot refreshed by a copy) is what it falls back to
