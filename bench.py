@@ -141,7 +141,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 DP + f64 lambda/p-value",
             "data": "synthetic",
-            "config": {"workload": f"{args.uniques} unique {L}-nt synthetic reads per GPU (BASELINE.json configs[1] recipe), "
+            "config": {"workload": f"{args.uniques} unique {L}-nt synthetic reads per GPU "
+                                   f"({'BASELINE.json configs[1] recipe' if L <= 500 else 'long-read shape of BASELINE.json configs[4]'}), "
                                    f"tperr1 fixed error matrix, BAND_SIZE {args.band}, dada() defaults",
                        "uniques_per_gpu": d.nraw, "reads_per_gpu": int(d.abundances.sum()), "partitions": res.nclust,
                        "comparisons": st["ncompare"], "nw": st["nnw"], "gapless": st["ngapless"],
