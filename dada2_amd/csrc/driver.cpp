@@ -553,7 +553,7 @@ struct Run {
       if (wide) {
         ensure_adw_scratch(s, ap);
         launch_nw_adw(D, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr_adw.p, s->scr_adw_wpw,
-                      s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, stq);
+                      s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, nullptr, 0, 0, stq);
       } else
         launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
                   s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
@@ -956,7 +956,13 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   bool coop_fin = coop_fin_ok && N < COOP_MAX_BATCH;
   if (fk && !strcmp(fk, "lane")) coop_fin = false;
   if (fk && !strcmp(fk, "coop") && coop_fin_ok) coop_fin = true;
-  const size_t per = coop_fin ? (size_t)nw_ad_apw(D, run.ap) : 64;
+  // band windows too wide for the LDS-pointer kernel: the wide anti-diagonal kernel (same rule as compare_round)
+  bool wide_fin = !coop_fin_ok && opts->band_size > 0 && nw_adw_ok(D, run.ap) && nw_adw_lds_bytes(D, run.ap) <= 150 * 1024 &&
+                  run.wclass != 33 && run.wclass != 65 && N < (1 << 20);
+  if (fk && !strcmp(fk, "lane")) wide_fin = false;
+  if (fk && !strcmp(fk, "wide")) wide_fin = opts->band_size > 0 && nw_adw_ok(D, run.ap) && nw_adw_lds_bytes(D, run.ap) <= 150 * 1024;
+  if (wide_fin) { coop_fin = false; ensure_adw_scratch(s, run.ap); }
+  const size_t per = coop_fin ? (size_t)nw_ad_apw(D, run.ap) : (wide_fin ? (size_t)nw_adw_apw(D, run.ap) : 64);
   std::vector<int32_t> work, chunk_centre, centre_of_cluster(C);
   work.reserve((size_t)N + per * (size_t)C);
   for (int i = 0; i < C; i++) {
@@ -985,6 +991,9 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     if (coop_fin)
       launch_nw_ad(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), nullptr, nullptr, run.ap, s->d_err.p,
                    s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, stq);
+    else if (wide_fin)
+      launch_nw_adw(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr_adw.p,
+                    s->scr_adw_wpw, s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, stq);
     else
       launch_nw(D, run.wclass, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr,
                 s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, 0, nullptr, stq);
@@ -1054,9 +1063,9 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     std::vector<uint8_t> pair_cls(nb);
     D2_HIP(hipMemcpyAsync(pair_cls.data(), d_bcls.p, (size_t)nb, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
-    bool coop_b = coop_fin_ok;                       // one pair per chunk: the cooperative kernel needs no 64-wide batch
+    bool coop_b = coop_fin_ok && !wide_fin;          // one pair per chunk: the cooperative kernels need no 64-wide batch
     if (fk && !strcmp(fk, "lane")) coop_b = false;
-    const size_t pern = coop_b ? (size_t)nw_ad_apw(D, run.ap) : 64;
+    const size_t pern = coop_b ? (size_t)nw_ad_apw(D, run.ap) : (wide_fin ? (size_t)nw_adw_apw(D, run.ap) : 64);
     std::vector<int32_t> w_gl((size_t)nb * 64, -1), w_nw((size_t)nb * pern, -1);
     int n_gl = 0, n_nw = 0;
     for (int k = 0; k < nb; k++) {
@@ -1073,6 +1082,9 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     if (n_nw && coop_b)
       launch_nw_ad(D, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
                    s->d_ham.p, s->d_view_b.p, LV, 1, stq);
+    else if (n_nw && wide_fin)
+      launch_nw_adw(D, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), run.ap, s->d_err.p, s->scr_adw.p, s->scr_adw_wpw,
+                    s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, s->d_view_b.p, LV, 1, stq);
     else if (n_nw)
       launch_nw(D, run.wclass, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), run.ap, s->d_err.p, s->scr, s->d_lambda.p,
                 s->d_ham.p, s->d_view_b.p, LV, 1, nullptr, 0, nullptr, stq);

@@ -183,7 +183,9 @@ int nw_adw_waves(const SampleDev &S, const AlignParams &ap, int nwork);
 size_t nw_adw_lds_bytes(const SampleDev &S, const AlignParams &ap);
 void launch_nw_adw(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work, const int32_t *d_nwork,
                    int nwork_host, const AlignParams &ap, const double *d_err, uint32_t *d_ptr_scr, size_t ptr_wpw,
-                   int scr_waves, double *d_lambda, uint32_t *d_ham, hipStream_t st);
+                   int scr_waves, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk,
+                   hipStream_t st);
+int nw_adw_apw(const SampleDev &S, const AlignParams &ap);
 
 void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint8_t *d_prior, double *d_out,
                     hipStream_t st);

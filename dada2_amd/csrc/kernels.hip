@@ -1073,6 +1073,11 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
       for (int p = g; p < L1; p += GL) cbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)c * S.W2, p);
       for (int p = g; p < L2; p += GL) rbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)r * S.W2, p);
     }
+    const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
+    // aligned view of the unique on its centre (final pass / birth substitutions): centre positions facing a gap stay 0
+    const size_t vr = a.view_by_chunk ? (size_t)chunk : (size_t)r;
+    if (a.view && active && !ghost)
+      for (int p = g; p < L1; p += GL) a.view[vr * a.LV + p] = 0;
     int Tmax = T;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
@@ -1209,6 +1214,8 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
               const uint32_t cb = cbytes[pj + dl - 128];
               tc = 4u * cb + rb;
               h += (cb != rb);
+              if (a.view && active)
+                a.view[vr * a.LV + pj + dl - 128] = (uint16_t)(0x8000u | (rb << 8) | (a.ap.use_quals ? qrow[pj] : 0));
             }
             tcode[pj] = (uint8_t)tc;
           }
@@ -1224,7 +1231,6 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) L2max = max(L2max, __shfl_xor(L2max, o, 64));
     double l = 1.0;
-    const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
     for (int base = 0; base < L2max; base += G.fch) {
       const int hi = min(L2, base + G.fch);
       if (!ghost && active)
@@ -1260,7 +1266,8 @@ int nw_adw_waves(const SampleDev &S, const AlignParams &ap, int nwork) {
 }
 void launch_nw_adw(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work, const int32_t *d_nwork,
                    int nwork_host, const AlignParams &ap, const double *d_err, uint32_t *d_ptr_scr, size_t ptr_wpw,
-                   int scr_waves, double *d_lambda, uint32_t *d_ham, hipStream_t st) {
+                   int scr_waves, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk,
+                   hipStream_t st) {
   const int maxwork = d_nwork ? S.N : nwork_host;
   if (maxwork <= 0) return;
   NwArgs a;
@@ -1268,6 +1275,7 @@ void launch_nw_adw(const SampleDev &S, int centre, const int32_t *d_chunk_centre
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
   a.ptr_scr = d_ptr_scr; a.ptr_wpw = ptr_wpw;
+  a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk;
   const AdwGeom G = adw_geom(ap.band, S.maxlen, S.minlen);
   const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.APW * G.per_al_bytes;
   const int waves = (maxwork + G.APW - 1) / G.APW;
@@ -1287,6 +1295,7 @@ void launch_nw_adw(const SampleDev &S, int centre, const int32_t *d_chunk_centre
   else { if (def) D2_LAUNCH_ADW(64, true); else D2_LAUNCH_ADW(64, false); }
 #undef D2_LAUNCH_ADW
 }
+int nw_adw_apw(const SampleDev &S, const AlignParams &ap) { return adw_geom(ap.band, S.maxlen, S.minlen).APW; }
 size_t nw_adw_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   const AdwGeom G = adw_geom(ap.band, S.maxlen, S.minlen);
   return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.APW * G.per_al_bytes;
