@@ -9,6 +9,7 @@
 // ordered, pointer-chasing integer/fp64-compare work and runs on the host from the dense device
 // output.  There is no CPU implementation of any kernel: without a GPU every entry point fails.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -351,7 +352,11 @@ struct Run {
   DevBuf<uint32_t> d_cham, d_nham, d_creads, d_creads_snap;
   DevBuf<unsigned long long> d_totals;
   DevBuf<BudKeyH> d_partial;
-  DevBuf<RoundOut> d_rout;
+  DevBuf<RoundOut> d_rout;                      // two blocks, alternating per round (k_auto_birth zeroes the next one)
+  int ri = 0;
+  RoundOut *ro() { return d_rout.p + ri; }
+  RoundOut *ro_next() { return d_rout.p + (ri ^ 1); }
+  DevBuf<int32_t> d_next;                       // [0] = centre of the speculatively launched next round, -1 = none
   PinBuf<RoundOut> h_rout;                      // the round tail's result block (one D2H per round)
   PinBuf<int32_t> h_big;                        // long mover lists
   DevBuf<int32_t> d_pool, d_thresh_one, d_thresh_round;   // zeroed counter pool; k-mer threshold tables
@@ -362,6 +367,8 @@ struct Run {
   int nw_n_sampled = 0, sc_n_sampled = 0, n_round_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nw_events, screen_events;
   size_t nw_ev_used = 0, screen_ev_used = 0;
+  std::vector<uint8_t> nw_ev_ok, screen_ev_ok;   // 0 = sample of a speculative round that turned out to be a no-op
+  long spec_ev_nw = -1, spec_ev_screen = -1;
   std::vector<uint64_t> nw_event_cells;
 
   ~Run() {
@@ -394,7 +401,7 @@ struct Run {
     const size_t n = (size_t)N;
     d_Emin.alloc(n); d_clam.alloc(n); d_p.alloc(n); d_lock.alloc(n); d_slot0.alloc(n); d_clof.alloc(n); d_ci.alloc(n);
     d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(6 * n); d_nmovers.alloc(1);
-    d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_rout.alloc(1);
+    d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_rout.alloc(2); d_next.alloc(4);
     h_rout.alloc(1); d_pool.alloc(POOL_INTS);
     d_thresh_one.alloc(thresh_one.size()); d_thresh_round.alloc(thresh_round.size());
     P.E_minmax = d_Emin.p; P.comp_lam = d_clam.p; P.p = d_p.p; P.lock = d_lock.p; P.slot0 = d_slot0.p; P.clust_of = d_clof.p;
@@ -415,8 +422,14 @@ struct Run {
     D2_HIP(hipMemsetAsync(P.check_locks, 0, (size_t)ccap, stq));
     bi.clear();
     nw_ev_used = screen_ev_used = 0;
+    nw_ev_ok.clear(); screen_ev_ok.clear();
     ev_round = 0; nw_ms_big = nw_ms_sampled = sc_ms_sampled = 0; nw_n_sampled = sc_n_sampled = n_round_launches = 0;
-    D2_HIP(hipMemsetAsync(d_rout.p, 0, sizeof(RoundOut), stq));
+    D2_HIP(hipMemsetAsync(d_rout.p, 0, 2 * sizeof(RoundOut), stq));
+    D2_HIP(hipMemsetAsync(d_next.p, 0xFF, 16, stq));
+    ri = 0;
+    spec_launched = false;
+    publish_pending = false;
+    h_rout.p->seq = 0;
     std::vector<double> em(n, -999.0);                           // containers.cpp:39
     D2_HIP(hipMemcpyAsync(d_Emin.p, em.data(), n * 8, hipMemcpyHostToDevice, stq));
     D2_HIP(hipMemsetAsync(d_clam.p, 0, n * 8, stq));
@@ -517,7 +530,25 @@ struct Run {
 
   // ---- one b_compare round, entirely on the device (cluster.cpp:90-204) ---------------------------
   // `centre` is passed explicitly: the host mirror of the new partition may be filled in after the launches.
-  void compare_round(int ci, int centre, double cutoff) {
+  // spec: launched behind k_auto_birth before the host has seen the bud decision; the kernels take the centre from
+  // d_next (and do nothing when it is -1); confirm_spec() books the round once the host knows the birth happened.
+  bool spec_launched = false;
+  int32_t *spec_ctr = nullptr;
+  bool rounds_use_coop() const {
+    const char *f = getenv("DADA2HIP_NW_KERNEL");
+    if (f && (!strcmp(f, "lane") || !strcmp(f, "wide"))) return false;
+    return nw_ad_lds_bytes(s->D, ap) > 0 && nw_ad_lds_bytes(s->D, ap) <= 150 * 1024;
+  }
+  void confirm_spec(int ci, int centre) {
+    pending_store = StoreRound{ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, spec_ctr, s->d_cls.p};
+    have_pending_store = true;
+    spec_launched = false;
+    if (spec_ev_screen >= 0) screen_ev_ok[spec_ev_screen] = 1;
+    if (spec_ev_nw >= 0) nw_ev_ok[spec_ev_nw] = 1;
+    n_round_launches++;
+    st.ncompare += (uint64_t)N;
+  }
+  void compare_round(int ci, int centre, double cutoff, bool spec = false) {
     SampleDev &D = s->D;
     hipStream_t stq = s->stream;
     auto t0 = clk::now();
@@ -527,14 +558,25 @@ struct Run {
     // four API calls on a host-enqueue-bound critical path
     const bool timed = ci == 0 || (ev_round++ % 8) == 0;
     std::pair<hipEvent_t, hipEvent_t> evs{}, evn{};
-    if (timed) { evs = new_events(screen_events, screen_ev_used); D2_HIP(hipEventRecord(evs.first, stq)); }
+    spec_ev_nw = spec_ev_screen = -1;
+    if (timed) {
+      evs = new_events(screen_events, screen_ev_used);
+      screen_ev_ok.resize(screen_ev_used, 1);
+      if (spec) { screen_ev_ok[screen_ev_used - 1] = 0; spec_ev_screen = (long)screen_ev_used - 1; }
+      D2_HIP(hipEventRecord(evs.first, stq));
+    }
     launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, th, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
-                  s->d_nw_list.p, s->d_gl_list.p, ctr, s->d_ctab.p, /*build_table=*/ci == 0, stq);
+                  s->d_nw_list.p, s->d_gl_list.p, ctr, s->d_ctab.p, /*build_table=*/ci == 0, spec ? d_next.p : nullptr, stq);
     if (timed) D2_HIP(hipEventRecord(evs.second, stq));
     // NW batch size is only known on the device: both kernels loop over the device-side count with a
     // fixed persistent grid.  Round 0 aligns every unique (lane-per-alignment kernel), later rounds a few
     // thousand (cooperative kernel).
-    if (timed) { evn = new_events(nw_events, nw_ev_used); D2_HIP(hipEventRecord(evn.first, stq)); }
+    if (timed) {
+      evn = new_events(nw_events, nw_ev_used);
+      nw_ev_ok.resize(nw_ev_used, 1);
+      if (spec) { nw_ev_ok[nw_ev_used - 1] = 0; spec_ev_nw = (long)nw_ev_used - 1; }
+      D2_HIP(hipEventRecord(evn.first, stq));
+    }
     const char *f = getenv("DADA2HIP_NW_KERNEL");
     const bool coop_ok = nw_ad_lds_bytes(D, ap) > 0 && nw_ad_lds_bytes(D, ap) <= 150 * 1024;
     bool coop = coop_ok && (ci != 0 || N < COOP_MAX_BATCH);
@@ -547,7 +589,7 @@ struct Run {
     if (f && !strcmp(f, "wide")) wide = nw_adw_ok(D, ap) && nw_adw_lds_bytes(D, ap) <= 150 * 1024;
     if (coop && !wide)   // the gapless pairings of the round share the kernel's factor/product tail
       launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, ctr, 0, s->d_gl_list.p, ctr + 1, ap, s->d_err.p, s->d_lambda.p,
-                   s->d_ham.p, nullptr, 0, 0, stq);
+                   s->d_ham.p, nullptr, 0, 0, spec ? d_next.p : nullptr, stq);
     else {
       launch_gapless(D, centre, nullptr, s->d_gl_list.p, ctr + 1, 0, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, nullptr, 0, 0, stq);
       if (wide) {
@@ -559,9 +601,10 @@ struct Run {
                   s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
     }
     if (timed) D2_HIP(hipEventRecord(evn.second, stq));
+    if (spec) { spec_ctr = ctr; spec_launched = true; st.ms_screen += ms_since(t0); return; }
     if (ci == 0)   // round 0 is followed by b_p_update directly (Rmain.cpp:309-311)
       launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p,
-                   d_rout.p->cnt, stq);
+                   ro()->cnt, stq);
     else {         // later rounds: the store filter rides in front of the round's first shuffle
       pending_store = StoreRound{ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p};
       have_pending_store = true;
@@ -610,7 +653,7 @@ struct Run {
   bool snap_fresh = true;
   int32_t *enqueue_shuffle(int slot, bool check = false) {
     hipStream_t stq = s->stream;
-    RoundOut *ro = d_rout.p;
+    RoundOut *ro = this->ro();
     if (!check && !snap_fresh)
       D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)nclust_dev * 4, hipMemcpyDeviceToDevice, stq));
     launch_shuffle(P, s->D, check ? P.creads : d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot],
@@ -625,29 +668,61 @@ struct Run {
   bool have_pending_store = false;
 
   void fetch_round_out() {
-    D2_HIP(hipMemcpyAsync(h_rout.p, d_rout.p, sizeof(RoundOut), hipMemcpyDeviceToHost, s->stream));
-    sync_spin(s->stream);
+    if (publish_pending) {
+      // k_auto_birth stores the block into h_rout itself and writes the sequence number last: poll it (the speculative
+      // kernels of the next round keep the stream busy meanwhile); look at the stream now and then so that a device
+      // fault cannot leave us spinning
+      volatile int32_t *seqp = &h_rout.p->seq;
+      for (unsigned spins = 0; *seqp != publish_seq; spins++) {
+        if ((spins & 0xFFFF) == 0xFFFF) {
+          hipError_t e = hipStreamQuery(s->stream);
+          if (e != hipSuccess && e != hipErrorNotReady)
+            throw d2::DeviceError{DADA2HIP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e) + " (round result)"};
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      publish_pending = false;
+    } else {
+      D2_HIP(hipMemcpyAsync(h_rout.p, ro(), sizeof(RoundOut), hipMemcpyDeviceToHost, s->stream));
+      sync_spin(s->stream);
+    }
     D2_HIP(hipGetLastError());
   }
+  bool publish_pending = false;
+  int32_t publish_seq = 0;
 
-  void apply_shuffle_result(int slot) {
-    const RoundOut &ro = *h_rout.p;
-    const int nm = ro.cnt[slot];
+  // replay the movers a real shuffle reported: `inl` = the first MOVERS_INLINE of them (host memory), the full list
+  // stays in d_movers slot `slot` when there are more
+  void apply_moves(int nm, const int32_t *inl, int slot) {
     if (nm <= 0) return;
     if (nm > MOVERS_INLINE) {
-      // the shuffle that wrote this list has completed (we synchronised on it); fetch it on the side stream so the
-      // copy does not wait for the next round's kernels already queued on the main stream
+      // the shuffle that wrote this list has completed (its result block has been fetched); copy it on the side stream
+      // so the copy does not wait for the kernels already queued on the main stream
       h_big.alloc((size_t)3 * nm);
       D2_HIP(hipMemcpyAsync(h_big.p, d_movers.p + (size_t)slot * 3 * N, (size_t)3 * nm * 4, hipMemcpyDeviceToHost, s->side));
       D2_HIP(hipStreamSynchronize(s->side));
       replay_moves(h_big.p, nm);
-    } else replay_moves(ro.mov[slot], nm);
+    } else replay_moves(inl, nm);
   }
+  void apply_shuffle_result(int slot) { apply_moves(h_rout.p->cnt[slot], h_rout.p->mov[slot], slot); }
 
+  // b_p_update + b_bud evaluation; when the rounds run on the cooperative kernel also: the unambiguous birth applied on
+  // the device (k_auto_birth) and the next round's screen + alignments queued behind it, so the GPU does not wait for
+  // the host's decision (the host confirms it afterwards from the same result block).
+  int max_clust_run = 0;
   void enqueue_pupdate_bud(const int32_t *guard) {
     BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
-    launch_pupdate_bud(P, s->D, o.greedy, o.detect_singletons, bp, 1.0, s->h_reads[bi[0].center], d_partial.p, &d_rout.p->bud,
+    static const bool no_auto = getenv("DADA2HIP_NO_AUTOBIRTH") != nullptr || getenv("DADA2HIP_NO_SPECULATION") != nullptr;
+    const bool autob = !no_auto && rounds_use_coop() && nclust_dev < max_clust_run;
+    if (autob && nclust_dev + 1 >= ccap) grow_clusters(std::max(ccap * 2, nclust_dev + 2));   // before anything is enqueued
+    launch_pupdate_bud(P, s->D, o.greedy, o.detect_singletons, bp, 1.0, s->h_reads[bi[0].center], d_partial.p, &ro()->bud,
                        d_ties0.p, d_ties1.p, nclust_dev, guard, s->stream);
+    if (!autob) return;
+    publish_seq = (publish_seq % 0x3FFFFFFF) + 1;
+    launch_auto_birth(P, s->D, d_creads_snap.p, ro(), o.omegaA, nclust_dev, s->d_ctab.p, ro_next()->cnt, d_next.p, h_rout.p,
+                      publish_seq, s->stream);
+    publish_pending = true;
+    compare_round(nclust_dev, -1, o.kdist_cutoff, /*spec=*/true);
   }
 
   // The tail of one divisive round (Rmain.cpp:320-329 + the b_bud of the next iteration, :316): shuffle until
@@ -656,8 +731,9 @@ struct Run {
   // with ONE synchronisation and ONE copy; the p-update/bud kernels cancel themselves on the device if the second
   // shuffle still moved something, and the host then continues shuffling exactly as the reference would.
   // On return h_rout holds a valid bud evaluation; moves not yet replayed on the host are described by
-  // pending_slots (the caller replays them after it has launched the next round).
-  int pending_slots = 0;
+  // pending_slot (the caller replays them after it has launched the next round).
+  int pending_slot = -1;   // list slot of the last real shuffle whose moves the host has not replayed yet
+  std::vector<int32_t> prev_inline;
   void round_tail(bool do_shuffle) {
     auto t0 = clk::now();
     int nsh = 0;
@@ -666,7 +742,7 @@ struct Run {
     if (do_shuffle && no_spec) {
       bool shuffled = true;
       while (shuffled && nsh < MAX_SHUFFLE) {
-        D2_HIP(hipMemsetAsync(d_rout.p->cnt, 0, 8, s->stream));
+        D2_HIP(hipMemsetAsync(ro()->cnt, 0, 8, s->stream));
         enqueue_shuffle(0);
         fetch_round_out();
         shuffled = h_rout.p->cnt[0] > 0;
@@ -675,48 +751,47 @@ struct Run {
       }
       enqueue_pupdate_bud(nullptr);
       fetch_round_out();
-      pending_slots = 0;
+      pending_slot = -1;
       st.ms_bookkeep += ms_since(t0);
       return;
     }
+    int slot = 0;
     if (do_shuffle) {
-      enqueue_shuffle(0);
-      guard = enqueue_shuffle(1, /*check=*/true);
+      enqueue_shuffle(slot);
+      guard = enqueue_shuffle(slot ^ 1, /*check=*/true);
       nsh = 2;
     }
     enqueue_pupdate_bud(guard);
     fetch_round_out();
-    pending_slots = do_shuffle ? 1 : 0;
+    pending_slot = do_shuffle ? slot : -1;
     if (do_shuffle) {
-      const int nm1 = h_rout.p->cnt[0], nm2 = h_rout.p->cnt[1];
-      if (nm1 == 0) st.nshuffle--;                     // the reference stops after the first unmoving shuffle
-      if (nm2 > 0) {
-        // Speculation cancelled: the second shuffle moves uniques too.  Keep shuffling like the reference, each
-        // further call again enqueued together with a check of the call after it and the p-update / bud evaluation.
-        apply_shuffle_result(0);
-        pending_slots = 0;
-        st.nshuffle--;                                  // the check stood for a call that does move: redo it for real
-        nsh = 1;
-        for (;;) {
-          D2_HIP(hipMemsetAsync(d_rout.p->cnt, 0, 8, s->stream));
-          enqueue_shuffle(0);
-          nsh++;
-          const bool last = nsh >= MAX_SHUFFLE;         // Rmain.cpp:321: the loop stops at MAX_SHUFFLE calls regardless
-          const int32_t *g2 = nullptr;
-          if (!last) { g2 = enqueue_shuffle(1, /*check=*/true); nsh++; }
-          enqueue_pupdate_bud(g2);
-          fetch_round_out();
-          apply_shuffle_result(0);
-          if (last || h_rout.p->cnt[1] == 0) break;     // stable (or out of calls): the evaluation just fetched is valid
-          st.nshuffle--; nsh--;                          // that check moves again: it is redone as the next real call
-        }
+      if (h_rout.p->cnt[slot] == 0) st.nshuffle--;     // the reference stops after the first unmoving shuffle
+      // Speculation cancelled: the check says the next call moves uniques too.  Keep shuffling like the reference, each
+      // further real call again enqueued together with a check of the call after it and the p-update / bud
+      // evaluation - and BEFORE the host replays the previous call's moves, so the GPU is not left waiting for that.
+      while (h_rout.p->cnt[slot ^ 1] > 0) {
+        const int nm_prev = h_rout.p->cnt[slot], slot_prev = slot;
+        prev_inline.assign(h_rout.p->mov[slot], h_rout.p->mov[slot] + 3 * std::min(nm_prev, MOVERS_INLINE));
+        st.nshuffle--; nsh--;                           // the check stood for a call that does move: redo it for real
+        slot ^= 1;
+        D2_HIP(hipMemsetAsync(ro()->cnt, 0, 8, s->stream));
+        enqueue_shuffle(slot);
+        nsh++;
+        const bool last = nsh >= MAX_SHUFFLE;           // Rmain.cpp:321: the loop stops at MAX_SHUFFLE calls regardless
+        const int32_t *g2 = nullptr;
+        if (!last) { g2 = enqueue_shuffle(slot ^ 1, /*check=*/true); nsh++; }
+        enqueue_pupdate_bud(g2);
+        apply_moves(nm_prev, prev_inline.data(), slot_prev);
+        fetch_round_out();
+        pending_slot = slot;
+        if (last) break;                                // out of calls: the evaluation just fetched is valid
       }
     }
     st.ms_bookkeep += ms_since(t0);
   }
   void replay_pending() {
-    for (int k = 0; k < pending_slots; k++) apply_shuffle_result(k);
-    pending_slots = 0;
+    if (pending_slot >= 0) apply_shuffle_result(pending_slot);
+    pending_slot = -1;
   }
 
   // last round when max_clust stops the loop (Rmain.cpp:316): only the shuffles matter for the outputs
@@ -725,7 +800,7 @@ struct Run {
     int nsh = 0;
     bool shuffled;
     do {
-      D2_HIP(hipMemsetAsync(d_rout.p->cnt, 0, 8, s->stream));
+      D2_HIP(hipMemsetAsync(ro()->cnt, 0, 8, s->stream));
       enqueue_shuffle(0);
       fetch_round_out();
       shuffled = h_rout.p->cnt[0] > 0;
@@ -798,9 +873,20 @@ struct Run {
     const int raw = b.c.raw;
     if (b.newi >= ccap) grow_clusters(std::max(ccap * 2, b.newi + 1));
     launch_apply_bud(P, s->D, d_creads_snap.p, raw, b.newi, b.c.from, s->h_reads[raw], b.c.from_reads - s->h_reads[raw],
-                     s->d_ctab.p, d_rout.p->cnt, s->stream);
+                     s->d_ctab.p, ro_next()->cnt, s->stream);
     nclust_dev = b.newi + 1;
     snap_fresh = true;                                   // k_apply_bud rewrote the whole snapshot
+    ri ^= 1;
+  }
+
+  // the same, already done by k_auto_birth (and the next round already launched behind it): just book it
+  void confirm_auto_birth(const Birth &b) {
+    if (b.type != 'A' || b.c.raw != h_rout.p->bud.ties[0][0].raw || !spec_launched)
+      throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: device and host bud decisions differ"};
+    nclust_dev = b.newi + 1;
+    snap_fresh = true;
+    ri ^= 1;
+    confirm_spec(b.newi, b.c.raw);
   }
 
   // host mirror of the same birth: bi_pop_raw from its partition, new Bi with the unique as only member and centre
@@ -923,6 +1009,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   run.nclust_dev = 1;
   run.compare_round(0, (int)run.bi[0].center, 1.0);   // Rmain.cpp:309-310: no k-mer screen in round 0
   int max_clust = opts->max_clust < 1 ? N : opts->max_clust;
+  run.max_clust_run = max_clust;
   // run_dada's loop (Rmain.cpp:312-331), rotated: every iteration ends with b_p_update + the b_bud that opens
   // the reference's next iteration, so one device round trip serves both.  After a decision the next round's
   // kernels are launched first; the host mirror (moves replay, birth record) is updated while the GPU works.
@@ -932,8 +1019,12 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       Run::Birth b = run.decide_bud();
       if (!b.yes) { run.replay_pending(); break; }
       run.logf("\nNew Cluster C%i:", b.newi);
-      run.launch_birth(b);
-      run.compare_round(b.newi, b.c.raw, opts->kdist_cutoff);
+      if (run.h_rout.p->bud.auto_applied) run.confirm_auto_birth(b);   // applied on the device, next round already running
+      else {
+        run.spec_launched = false;                     // (a speculative round, if any, found next = -1 and did nothing)
+        run.launch_birth(b);
+        run.compare_round(b.newi, b.c.raw, opts->kdist_cutoff);
+      }
       const bool more = run.nclust_dev < max_clust;
       run.replay_pending();                           // host mirror catches up while the GPU runs the round
       run.record_birth(b);
@@ -987,10 +1078,11 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     run.st.ngapless += (uint64_t)N;
   } else {
     auto evn = run.new_events(run.nw_events, run.nw_ev_used);
+    run.nw_ev_ok.resize(run.nw_ev_used, 1);
     D2_HIP(hipEventRecord(evn.first, stq));
     if (coop_fin)
       launch_nw_ad(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), nullptr, nullptr, run.ap, s->d_err.p,
-                   s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, stq);
+                   s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, stq);
     else if (wide_fin)
       launch_nw_adw(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr_adw.p,
                     s->scr_adw_wpw, s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, stq);
@@ -1081,7 +1173,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
                              s->d_view_b.p, LV, 1, stq);
     if (n_nw && coop_b)
       launch_nw_ad(D, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
-                   s->d_ham.p, s->d_view_b.p, LV, 1, stq);
+                   s->d_ham.p, s->d_view_b.p, LV, 1, nullptr, stq);
     else if (n_nw && wide_fin)
       launch_nw_adw(D, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), run.ap, s->d_err.p, s->scr_adw.p, s->scr_adw_wpw,
                     s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, s->d_view_b.p, LV, 1, stq);
@@ -1109,16 +1201,22 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     float ems;
     double nw_big = 0, nw_small = 0, sc_sum = 0;
     int n_small = 0;
+    int n_sc = 0;
     for (size_t k = 0; k < run.nw_ev_used; k++) {
+      if (!run.nw_ev_ok[k]) continue;                                  // speculative launch that found nothing to do
       D2_HIP(hipEventElapsedTime(&ems, run.nw_events[k].first, run.nw_events[k].second));
       if (k == 0 || k + 1 == run.nw_ev_used) nw_big += ems;           // round 0 and the final pass (every unique aligned)
       else { nw_small += ems; n_small++; }
     }
-    for (size_t k = 0; k < run.screen_ev_used; k++) { D2_HIP(hipEventElapsedTime(&ems, run.screen_events[k].first, run.screen_events[k].second)); sc_sum += ems; }
+    for (size_t k = 0; k < run.screen_ev_used; k++) {
+      if (!run.screen_ev_ok[k]) continue;
+      D2_HIP(hipEventElapsedTime(&ems, run.screen_events[k].first, run.screen_events[k].second));
+      sc_sum += ems; n_sc++;
+    }
     const int rounds = run.n_round_launches;
     run.st.nw_kernel_ms = nw_big + (n_small ? nw_small / n_small * (rounds - 1) : 0.0);
     run.st.nw_kernel_launches = (uint64_t)rounds + 1;
-    run.st.screen_kernel_ms = run.screen_ev_used ? sc_sum / run.screen_ev_used * rounds : 0.0;
+    run.st.screen_kernel_ms = n_sc ? sc_sum / n_sc * rounds : 0.0;
     run.st.screen_kernel_launches = (uint64_t)rounds;
     run.st.nw_cells = run.st.nnw * run.nw_cells_per_alignment();
   }
@@ -1279,7 +1377,7 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
     D2_HIP(hipMemsetAsync(s->d_counters.p, 0, 8 * 4, stq));
     D2_HIP(hipEventRecord(s->ev0, stq));
     launch_screen(D, centre, run.sp, skip ? s->d_skip.p : nullptr, nullptr, 0, s->d_thresh.p, s->d_cls.p, s->d_lambda.p,
-                  s->d_ham.p, s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, s->d_ctab.p, true, stq);
+                  s->d_ham.p, s->d_nw_list.p, s->d_gl_list.p, s->d_counters.p, s->d_ctab.p, true, nullptr, stq);
     D2_HIP(hipEventRecord(s->ev1, stq));
     launch_gapless(D, centre, nullptr, s->d_gl_list.p, s->d_counters.p + 1, 0, run.ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
                    nullptr, 0, 0, stq);
@@ -1305,7 +1403,7 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
       D2_HIP(hipEventRecord(s->ev0, stq));
       if (coop)
         launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
-                     s->d_ham.p, nullptr, 0, 0, stq);
+                     s->d_ham.p, nullptr, 0, 0, nullptr, stq);
       else
         launch_nw(D, run.wclass, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, run.ap, s->d_err.p, s->scr, s->d_lambda.p,
                   s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);

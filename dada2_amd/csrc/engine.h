@@ -115,16 +115,19 @@ struct BudOut {
   uint32_t best_reads[2];
   int32_t found[2], nties[2];
   int32_t err_flag, node_count;
-  int32_t valid, pad;          // 0 when a speculative evaluation was cancelled on the device
+  int32_t valid;               // 0 when a speculative evaluation was cancelled on the device
+  int32_t auto_applied;        // 1 when k_auto_birth applied the (unambiguous) birth on the device
   BudTie ties[2][BUD_TIES];
 };
 // Everything the host needs from one round tail, fetched with a single copy.
 constexpr int MOVERS_INLINE = 512;
 struct RoundOut {
   int32_t cnt[2];              // movers of the two speculative shuffles (zeroed by k_apply_bud ahead of the round)
-  int32_t pad[2];
+  int32_t seq;                 // host copy only: sequence number k_auto_birth writes last when it publishes the block
+  int32_t pad;
   BudOut bud;
   int32_t mov[2][3 * MOVERS_INLINE];   // first movers of each shuffle (raw, from, to); the full lists stay on the device
+  int32_t pad_tail[2];         // (size is a multiple of 16: the block is published as uint4s)
 };
 // fused b_p_update + first stage of b_bud, then the reduction + tie listing
 void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const BudParams &bp,
@@ -133,6 +136,10 @@ void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int 
 // birth + the new centre's k-mer record for the coming round (one launch)
 void launch_apply_bud(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, int raw, int newi, int from,
                       uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, int32_t *d_zero2, hipStream_t st);
+// the unambiguous birth applied on the device (d_next[0] = its unique, or -1): lets the next round start before the host looks
+// It finally publishes the round's result block to pinned host memory (h_block, seq written last): no copy, no sync.
+void launch_auto_birth(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, RoundOut *d_block, double omegaA, int newi,
+                       uint32_t *d_ctab, int32_t *d_zero2, int32_t *d_next, RoundOut *h_block, int seq, hipStream_t st);
 void launch_centre_table(const SampleDev &S, int centre, uint32_t *d_ctab, hipStream_t st);
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st);
 void launch_posthoc(const PartState &P, const SampleDev &S, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam,
@@ -145,7 +152,8 @@ void launch_build_kmers(const SampleDev &S, hipStream_t st);
 // counters: [0]=#NW work items, [1]=#gapless work items, [2]=#shrouded, [3]=#skipped
 void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,
                    int greedy, const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
-                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, bool build_table, hipStream_t st);
+                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, bool build_table, const int32_t *d_centre_dev,
+                   hipStream_t st);
 void launch_gapless(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                     const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err,
                     double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, hipStream_t st);
@@ -172,7 +180,7 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,
-                  int view_by_chunk, hipStream_t st);
+                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st);
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap);
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap);
 

@@ -137,8 +137,12 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
                                                 uint8_t *__restrict__ cls, double *__restrict__ lam,
                                                 uint32_t *__restrict__ ham, int32_t *__restrict__ nw_list,
                                                 int32_t *__restrict__ gl_list, int32_t *__restrict__ counters,
-                                                int cap, const uint32_t *__restrict__ ctab) {
+                                                int cap, const uint32_t *__restrict__ ctab,
+                                                const int32_t *__restrict__ centre_dev) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+  // speculative launch (enqueued before the host has seen the bud decision): the centre comes from the descriptor
+  // k_auto_birth wrote, -1 = no birth was applied on the device -> nothing to do
+  if (centre_dev) { centre = *centre_dev; if (centre < 0) return; }
   const uint8_t *csat = (const uint8_t *)s_mem;            // [1024] min(count, 63)
   const uint16_t *cfull = (const uint16_t *)(s_mem + CTAB_CNT);   // [1024] full counts
   int32_t *s_cnt = (int32_t *)(s_mem + CTAB_ORD);           // [8]
@@ -248,7 +252,8 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
 
 void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,
                    int greedy, const int32_t *d_thresh, uint8_t *d_cls, double *d_lambda, uint32_t *d_ham, int32_t *d_nw_list,
-                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, bool build_table, hipStream_t st) {
+                   int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, bool build_table, const int32_t *d_centre_dev,
+                   hipStream_t st) {
   if (build_table) hipLaunchKernelGGL(k_centre_table, dim3(1), dim3(256), 0, st, S, centre, d_ctab);
   int grid = std::min((S.N + 15) / 16, 2048);
   int iters = ((S.N + 15) / 16 + grid - 1) / grid;
@@ -261,7 +266,7 @@ void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const
     lds = (size_t)(CTAB_ORD + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 32;
   }
   hipLaunchKernelGGL(k_screen, dim3(grid), dim3(256), lds, st, S, centre, sp, d_skip, d_lock, greedy, d_thresh, d_cls, d_lambda,
-                     d_ham, d_nw_list, d_gl_list, d_counters, cap, (const uint32_t *)d_ctab);
+                     d_ham, d_nw_list, d_gl_list, d_counters, cap, (const uint32_t *)d_ctab, d_centre_dev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -384,6 +389,7 @@ void launch_gapless(const SampleDev &S, int centre, const int32_t *d_chunk_centr
 struct NwArgs {
   SampleDev S;
   int centre;
+  const int32_t *centre_dev;   // speculative round: centre read from the device descriptor (-1 = nothing to do)
   const int32_t *chunk_centre;
   const int32_t *work;
   const int32_t *nwork_dev;
@@ -738,9 +744,11 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
   const int n_gl = gl_work ? *gl_nwork_dev : 0;            // gapless items ride along: same factors/product tail
   const int nwork = n_nw + n_gl;
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
+  const int centre_v = a.centre_dev ? *a.centre_dev : a.centre;
+  if (centre_v < 0 && !a.chunk_centre) return;
   for (int chunk = gwave; chunk * APW < nwork; chunk += nwaves) {
     const int idx = chunk * APW + al;
-    const int c = a.chunk_centre ? a.chunk_centre[chunk] : a.centre;
+    const int c = a.chunk_centre ? a.chunk_centre[chunk] : centre_v;
     int r = idx < n_nw ? a.work[idx] : (idx < nwork ? gl_work[idx - n_nw] : -1);
     const bool gapless = idx >= n_nw;
     const bool active = r >= 0;
@@ -928,14 +936,14 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,
-                  int view_by_chunk, hipStream_t st) {
+                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st) {
   int maxwork = d_nwork ? S.N : nwork_host;
   if (maxwork <= 0 && !d_gl_work) return;
   NwArgs a;
   memset(&a, 0, sizeof a);
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
-  a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk;
+  a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev;
   { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
   const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
@@ -1330,6 +1338,7 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
   if (grid * 4 > scr.nwaves) grid = scr.nwaves / 4;
   if (grid < 1) grid = 1;
   NwArgs a;
+  memset(&a, 0, sizeof a);
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.ptr_scr = scr.ptr; a.t_scr = scr.tcode; a.row_scr = scr.rows;
   a.ptr_wpw = scr.ptr_words_per_wave; a.t_wpw = scr.t_words_per_wave; a.row_wpw = scr.row_words_per_wave;
@@ -1686,12 +1695,12 @@ __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudP
   }
 }
 
-// Applies a birth decided by the host (cluster.cpp:313-347): the unique leaves `from`, becomes the only
-// member and centre of the new partition; bi_assign_center unlocks it; both partitions are flagged.
-__global__ __launch_bounds__(256) void k_apply_bud(PartState P, SampleDev S, uint32_t *creads_snap, int raw, int newi, int from,
-                                                   uint32_t reads_new, uint32_t reads_from, uint32_t *__restrict__ ctab,
-                                                   int32_t *__restrict__ zero2) {
-  __shared__ uint32_t cnt[NKMER];
+// Applies a birth (cluster.cpp:313-347): the unique leaves `from`, becomes the only member and centre of the new
+// partition; bi_assign_center unlocks it; both partitions are flagged.  Also: the coming round's shuffle counters are
+// zeroed, the reads snapshot is refreshed, the new centre's k-mer record is built.  One block of 256 threads.
+static __device__ __forceinline__ void apply_bud_body(PartState &P, SampleDev &S, uint32_t *creads_snap, int raw, int newi, int from,
+                                                      uint32_t reads_new, uint32_t reads_from, uint32_t *ctab, int32_t *zero2,
+                                                      uint32_t *cnt) {
   if (threadIdx.x < 2 && zero2) zero2[threadIdx.x] = 0;   // the coming round's shuffle counters
   // the coming round's first shuffle reads the partition reads as of its start: refresh the whole snapshot here
   for (int k = threadIdx.x; k < newi; k += 256) if (k != from) creads_snap[k] = P.creads[k];
@@ -1706,6 +1715,53 @@ __global__ __launch_bounds__(256) void k_apply_bud(PartState P, SampleDev S, uin
     P.update_e[from] = 1;
   }
   centre_table_body(S, raw, ctab, cnt);   // the new centre's k-mer record for the round that follows
+}
+// ... decided by the host
+__global__ __launch_bounds__(256) void k_apply_bud(PartState P, SampleDev S, uint32_t *creads_snap, int raw, int newi, int from,
+                                                   uint32_t reads_new, uint32_t reads_from, uint32_t *__restrict__ ctab,
+                                                   int32_t *__restrict__ zero2) {
+  __shared__ uint32_t cnt[NKMER];
+  apply_bud_body(P, S, creads_snap, raw, newi, from, reads_new, reads_from, ctab, zero2, cnt);
+}
+// ... decided on the device: the unambiguous case of b_bud (cluster.cpp:300-330) - exactly one best candidate and
+// pA = p * nraw < OMEGA_A, evaluated with the host's own expression - so the next round's screen and alignments,
+// enqueued behind this kernel, can start without waiting for the host.  Anything else (no birth, exact ties, prior
+// births) is left to the host: next[0] = -1 turns the speculative kernels behind it into no-ops.
+__global__ __launch_bounds__(256) void k_auto_birth(PartState P, SampleDev S, uint32_t *creads_snap, RoundOut *__restrict__ blk,
+                                                    double omegaA, int newi, uint32_t *__restrict__ ctab,
+                                                    int32_t *__restrict__ zero2, int32_t *__restrict__ next,
+                                                    RoundOut *__restrict__ host_blk, int seq) {
+  __shared__ uint32_t cnt[NKMER];
+  __shared__ int s_ok;
+  BudOut *out = &blk->bud;
+  if (threadIdx.x == 0) {
+    const bool ok = out->valid && out->found[0] && out->nties[0] == 1 && (out->best_p[0] * S.N < omegaA);
+    s_ok = ok;
+    out->auto_applied = ok ? 1 : 0;
+    next[0] = ok ? out->ties[0][0].raw : -1;
+  }
+  __syncthreads();
+  if (s_ok) {
+    const BudTie t = out->ties[0][0];
+    const uint32_t reads_new = S.reads[t.raw];
+    apply_bud_body(P, S, creads_snap, t.raw, newi, t.from, reads_new, t.from_reads - reads_new, ctab, zero2, cnt);
+  }
+  // publish the round's result block (mover counts + first movers, bud evaluation) to the host: plain stores to pinned
+  // memory, then the sequence number - the host polls it instead of copying and synchronising
+  __syncthreads();
+  static_assert(sizeof(RoundOut) % 16 == 0, "RoundOut is copied as uint4");
+  const uint4 *src = (const uint4 *)blk;
+  uint4 *dst = (uint4 *)host_blk;
+  for (int i = threadIdx.x; i < (int)(sizeof(RoundOut) / 16); i += 256) {
+    uint4 v = src[i];
+    if (i == 0) v.z = (uint32_t)(seq - 1);              // (word 2 of the block is `seq`: not yet)
+    dst[i] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&host_blk->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252)
@@ -1782,6 +1838,11 @@ void launch_apply_bud(const PartState &P, const SampleDev &S, uint32_t *d_creads
                       uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, int32_t *d_zero2, hipStream_t st) {
   hipLaunchKernelGGL(k_apply_bud, dim3(1), dim3(256), 0, st, P, S, d_creads_snap, raw, newi, from, reads_new, reads_from, d_ctab,
                      d_zero2);
+}
+void launch_auto_birth(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, RoundOut *d_block, double omegaA, int newi,
+                       uint32_t *d_ctab, int32_t *d_zero2, int32_t *d_next, RoundOut *h_block, int seq, hipStream_t st) {
+  hipLaunchKernelGGL(k_auto_birth, dim3(1), dim3(256), 0, st, P, S, d_creads_snap, d_block, omegaA, newi, d_ctab, d_zero2, d_next,
+                     h_block, seq);
 }
 void launch_final_p(const PartState &P, const SampleDev &S, double omegaC, uint8_t *d_correct, hipStream_t st) {
   hipLaunchKernelGGL(k_final_p, dim3((S.N + 255) / 256), dim3(256), 0, st, P, S, omegaC, d_correct);

@@ -126,6 +126,12 @@ def _golden_cases_in_subprocess(env_extra, names):
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_host_applied_births_equal_device_applied():
+    """Unambiguous births are normally applied on the device (k_auto_birth) with the next round launched behind them;
+    DADA2HIP_NO_AUTOBIRTH=1 keeps every decision on the host (the path ties and prior births always take)."""
+    _golden_cases_in_subprocess({"DADA2HIP_NO_AUTOBIRTH": "1"}, ("sam1F_default", "sam1F_priors", "synth3000_default"))
+
+
 def test_comparison_store_growth():
     """The device-resident comparison store (Bi::comp of every partition) starts at 4 N entries and doubles on demand;
     with the first allocation forced down to N + 16 it has to grow (and be copied) several times in a run."""
