@@ -356,6 +356,7 @@ struct Run {
   int ri = 0;
   RoundOut *ro() { return d_rout.p + ri; }
   RoundOut *ro_next() { return d_rout.p + (ri ^ 1); }
+  DevBuf<uint8_t> d_lock_tmp;                   // b_p_update's lock decisions, committed by k_bud_ties
   DevBuf<int32_t> d_next;                       // [0] = centre of the speculatively launched next round, -1 = none
   PinBuf<RoundOut> h_rout;                      // the round tail's result block (one D2H per round)
   PinBuf<int32_t> h_big;                        // long mover lists
@@ -401,7 +402,7 @@ struct Run {
     const size_t n = (size_t)N;
     d_Emin.alloc(n); d_clam.alloc(n); d_p.alloc(n); d_lock.alloc(n); d_slot0.alloc(n); d_clof.alloc(n); d_ci.alloc(n);
     d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(6 * n); d_nmovers.alloc(1);
-    d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_rout.alloc(2); d_next.alloc(4);
+    d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * 1024); d_rout.alloc(2); d_next.alloc(4); d_lock_tmp.alloc(n);
     h_rout.alloc(1); d_pool.alloc(POOL_INTS);
     d_thresh_one.alloc(thresh_one.size()); d_thresh_round.alloc(thresh_round.size());
     P.E_minmax = d_Emin.p; P.comp_lam = d_clam.p; P.p = d_p.p; P.lock = d_lock.p; P.slot0 = d_slot0.p; P.clust_of = d_clof.p;
@@ -710,13 +711,13 @@ struct Run {
   // the device (k_auto_birth) and the next round's screen + alignments queued behind it, so the GPU does not wait for
   // the host's decision (the host confirms it afterwards from the same result block).
   int max_clust_run = 0;
-  void enqueue_pupdate_bud(const int32_t *guard) {
+  void enqueue_pupdate_bud(int32_t *check_cnt) {
     BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
     static const bool no_auto = getenv("DADA2HIP_NO_AUTOBIRTH") != nullptr || getenv("DADA2HIP_NO_SPECULATION") != nullptr;
     const bool autob = !no_auto && rounds_use_coop() && nclust_dev < max_clust_run;
     if (autob && nclust_dev + 1 >= ccap) grow_clusters(std::max(ccap * 2, nclust_dev + 2));   // before anything is enqueued
     launch_pupdate_bud(P, s->D, o.greedy, o.detect_singletons, bp, 1.0, s->h_reads[bi[0].center], d_partial.p, &ro()->bud,
-                       d_ties0.p, d_ties1.p, nclust_dev, guard, s->stream);
+                       d_ties0.p, d_ties1.p, nclust_dev, d_lock_tmp.p, check_cnt, s->stream);
     if (!autob) return;
     publish_seq = (publish_seq % 0x3FFFFFFF) + 1;
     launch_auto_birth(P, s->D, d_creads_snap.p, ro(), o.omegaA, nclust_dev, s->d_ctab.p, ro_next()->cnt, d_next.p, h_rout.p,
@@ -737,7 +738,7 @@ struct Run {
   void round_tail(bool do_shuffle) {
     auto t0 = clk::now();
     int nsh = 0;
-    const int32_t *guard = nullptr;
+    int32_t *guard = nullptr;
     static const bool no_spec = getenv("DADA2HIP_NO_SPECULATION") != nullptr;   // test knob: the reference's plain loop
     if (do_shuffle && no_spec) {
       bool shuffled = true;
@@ -758,7 +759,8 @@ struct Run {
     int slot = 0;
     if (do_shuffle) {
       enqueue_shuffle(slot);
-      guard = enqueue_shuffle(slot ^ 1, /*check=*/true);
+      guard = ro()->cnt + (slot ^ 1);                   // "would a second call move anything?" rides in the p-update kernel
+      st.nshuffle++;
       nsh = 2;
     }
     enqueue_pupdate_bud(guard);
@@ -778,8 +780,8 @@ struct Run {
         enqueue_shuffle(slot);
         nsh++;
         const bool last = nsh >= MAX_SHUFFLE;           // Rmain.cpp:321: the loop stops at MAX_SHUFFLE calls regardless
-        const int32_t *g2 = nullptr;
-        if (!last) { g2 = enqueue_shuffle(slot ^ 1, /*check=*/true); nsh++; }
+        int32_t *g2 = nullptr;
+        if (!last) { g2 = ro()->cnt + (slot ^ 1); st.nshuffle++; nsh++; }
         enqueue_pupdate_bud(g2);
         apply_moves(nm_prev, prev_inline.data(), slot_prev);
         fetch_round_out();
@@ -1101,7 +1103,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   D2_HIP(hipMemsetAsync(s->d_trans.p, 0, (size_t)16 * err_ncol * 4, stq));
   D2_HIP(hipMemsetAsync(s->d_qsum.p, 0, (size_t)C * D.maxlen * 8, stq));
   D2_HIP(hipMemsetAsync(s->d_qn.p, 0, (size_t)C * D.maxlen * 4, stq));
-  launch_final_tables(D, s->d_view.p, LV, run.P.clust_of, run.P.centre_of, s->d_correct.p, err_ncol, 1,
+  launch_final_tables(D, s->d_view.p, LV, s->d_work.p, (int)work.size(), run.P.clust_of, run.P.centre_of, s->d_correct.p, err_ncol, 1,
                       s->d_trans.p, s->d_qsum.p, s->d_qn.p, s->d_nsubs.p, C, stq);
   std::vector<int32_t> nsubs(N);
   std::vector<unsigned long long> qsum((size_t)C * D.maxlen);

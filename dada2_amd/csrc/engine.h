@@ -129,10 +129,12 @@ struct RoundOut {
   int32_t mov[2][3 * MOVERS_INLINE];   // first movers of each shuffle (raw, from, to); the full lists stay on the device
   int32_t pad_tail[2];         // (size is a multiple of 16: the block is published as uint4s)
 };
-// fused b_p_update + first stage of b_bud, then the reduction + tie listing
+// fused [would one more shuffle move anything? ->] b_p_update + first stage of b_bud, then the reduction + tie listing.
+// d_check_cnt (optional, zeroed): receives the number of uniques one more b_shuffle2 call would move; non-zero voids
+// the evaluation on the device.
 void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const BudParams &bp,
                         double init_p, uint32_t init_reads, void *d_partial, BudOut *d_out, int32_t *d_over0, int32_t *d_over1,
-                        int nclust, const int32_t *d_guard, hipStream_t st);
+                        int nclust, uint8_t *d_lock_tmp, int32_t *d_check_cnt, hipStream_t st);
 // birth + the new centre's k-mer record for the coming round (one launch)
 void launch_apply_bud(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, int raw, int newi, int from,
                       uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, int32_t *d_zero2, hipStream_t st);
@@ -199,9 +201,9 @@ void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint
                     hipStream_t st);
 
 // final tables from the per-unique aligned views (error.cpp:131-172, :225-258)
-void launch_final_tables(const SampleDev &S, const uint16_t *d_view, int LV, const int32_t *d_cluster_of,
-                         const int32_t *d_centre_of_cluster, const uint8_t *d_correct, int ncol, int has_quals,
-                         int32_t *d_trans, unsigned long long *d_qsum, uint32_t *d_qn, int32_t *d_nsubs, int nclust,
-                         hipStream_t st);
+void launch_final_tables(const SampleDev &S, const uint16_t *d_view, int LV, const int32_t *d_work, int nslots,
+                         const int32_t *d_cluster_of, const int32_t *d_centre_of_cluster, const uint8_t *d_correct, int ncol,
+                         int has_quals, int32_t *d_trans, unsigned long long *d_qsum, uint32_t *d_qn, int32_t *d_nsubs,
+                         int nclust, hipStream_t st);
 
 }  // namespace d2

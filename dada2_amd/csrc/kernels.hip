@@ -1584,34 +1584,59 @@ static __device__ __forceinline__ bool bud_candidate(const PartState &P, const S
 }
 
 // b_p_update fused with the first stage of b_bud: every thread refreshes p / lock of its uniques (pval.cpp:14-40)
-// and folds them straight into the block's (p, reads) minimum.  Block 0 also resets the result block's tie counters
-// (or marks the evaluation cancelled).
+// and folds them straight into the block's (p, reads) minimum.  Block 0 also resets the result block's tie counters.
+// check_cnt (optional): the same pass first asks, per unique, whether one more b_shuffle2 call would move it (arg-max
+// over its stored comparisons with the live partition reads - nothing moves in this kernel) and counts those uniques.
+// A non-zero count cancels the evaluation (k_bud_ties and k_auto_birth test it); what this kernel wrote is then either
+// recomputed by the evaluation that follows the real shuffle (p: the partitions' update flags are still set) or was
+// never committed (locks go to lock_tmp and are committed by k_bud_ties).
 __global__ __launch_bounds__(256) void k_pupdate_budmin(PartState P, SampleDev S, int greedy, int detect_singletons, BudParams bp,
                                                         BudKey init, BudKey *__restrict__ partial, BudOut *__restrict__ out,
+                                                        uint8_t *__restrict__ lock_tmp, int32_t *__restrict__ check_cnt,
                                                         const int32_t *__restrict__ guard) {
   __shared__ BudKey s_k[2][4];
+  __shared__ int s_would;
   const bool cancelled = guard && *guard != 0;   // speculative launch: a later shuffle still moved uniques, redo after it
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     out->nties[0] = 0; out->nties[1] = 0;
     if (cancelled) { out->valid = 0; out->found[0] = 0; out->found[1] = 0; }
   }
   if (cancelled) return;
+  if (threadIdx.x == 0) s_would = 0;
+  __syncthreads();
   BudKey b0 = init, b1 = init;
+  int would = 0;
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
     const int cl = P.clust_of[r];
+    if (check_cnt) {
+      double best_e = -1.0;
+      int best_i = 0x7FFFFFFF;
+      for (int n = P.head[r]; n >= 0; n = P.node_next[n]) {
+        const int i = P.node_i[n];
+        const double e = P.node_lam[n] * P.creads[i];
+        if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; }
+      }
+      would += (best_i != 0x7FFFFFFF && best_i != cl && r != P.centre_of[cl]);
+    }
     const double l = P.comp_lam[r];
     const uint32_t reads = S.reads[r];
     double p = P.p[r];
     if (P.update_e[cl]) { p = dev_get_pA(reads, S.prior[r] != 0, detect_singletons != 0, l, P.comp_ham[r], P.creads[cl]); P.p[r] = p; }
+    uint8_t lk = 0;
     if (greedy && P.check_locks[cl]) {
       const int c = P.centre_of[cl];
       const double E_center = S.reads[c] * l;
-      if (E_center > reads) P.lock[r] = 1;
-      if (r == c) P.lock[r] = 1;
+      lk = (E_center > reads) || (r == c);
     }
+    lock_tmp[r] = lk;
     if (!bud_candidate(P, S, r, bp)) continue;
     if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
     if (S.prior[r] && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
+  }
+  if (check_cnt) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) would += __shfl_xor(would, o, 64);
+    if ((threadIdx.x & 63) == 0 && would) atomicAdd(&s_would, would);
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -1631,6 +1656,7 @@ __global__ __launch_bounds__(256) void k_pupdate_budmin(PartState P, SampleDev S
     }
     partial[2 * blockIdx.x] = b0;
     partial[2 * blockIdx.x + 1] = b1;
+    if (check_cnt && s_would) atomicAdd(check_cnt, s_would);
   }
 }
 
@@ -1641,9 +1667,12 @@ __global__ __launch_bounds__(256) void k_pupdate_budmin(PartState P, SampleDev S
 __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudParams bp, const BudKey *__restrict__ partial,
                                                   int nblocks, BudKey init, int nclust, BudOut *__restrict__ out,
                                                   int32_t *__restrict__ overflow0, int32_t *__restrict__ overflow1,
-                                                  const int32_t *__restrict__ guard) {
+                                                  const uint8_t *__restrict__ lock_tmp, const int32_t *__restrict__ guard) {
   __shared__ BudKey s_k[2][4];
-  if (guard && *guard != 0) return;
+  if (guard && *guard != 0) {   // the evaluation is void (see k_pupdate_budmin): nothing is committed
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out->valid = 0; out->found[0] = 0; out->found[1] = 0; }
+    return;
+  }
   BudKey b0 = init, b1 = init;
   for (int k = threadIdx.x; k < nblocks; k += 256) {
     if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
@@ -1677,6 +1706,7 @@ __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudP
     }
   }
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+    if (lock_tmp[r]) P.lock[r] = 1;                                    // b_p_update's greedy locks (pval.cpp:26-36)
     if (!bud_candidate(P, S, r, bp)) continue;
     const double p = P.p[r];
     const uint32_t reads = S.reads[r];
@@ -1826,13 +1856,13 @@ void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_cr
 }
 void launch_pupdate_bud(const PartState &P, const SampleDev &S, int greedy, int detect_singletons, const BudParams &bp,
                         double init_p, uint32_t init_reads, void *d_partial, BudOut *d_out, int32_t *d_over0, int32_t *d_over1,
-                        int nclust, const int32_t *d_guard, hipStream_t st) {
+                        int nclust, uint8_t *d_lock_tmp, int32_t *d_check_cnt, hipStream_t st) {
   BudKey init{init_p, init_reads};
   int grid = std::min((S.N + 255) / 256, 1024);
   hipLaunchKernelGGL(k_pupdate_budmin, dim3(grid), dim3(256), 0, st, P, S, greedy, detect_singletons, bp, init, (BudKey *)d_partial,
-                     d_out, d_guard);
+                     d_out, d_lock_tmp, d_check_cnt, (const int32_t *)nullptr);
   hipLaunchKernelGGL(k_bud_ties, dim3(std::min((S.N + 255) / 256, 512)), dim3(256), 0, st, P, S, bp, (const BudKey *)d_partial, grid,
-                     init, nclust, d_out, d_over0, d_over1, d_guard);
+                     init, nclust, d_out, d_over0, d_over1, (const uint8_t *)d_lock_tmp, (const int32_t *)d_check_cnt);
 }
 void launch_apply_bud(const PartState &P, const SampleDev &S, uint32_t *d_creads_snap, int raw, int newi, int from,
                       uint32_t reads_new, uint32_t reads_from, uint32_t *d_ctab, int32_t *d_zero2, hipStream_t st) {
@@ -1915,14 +1945,90 @@ __global__ __launch_bounds__(256) void k_final_tables(SampleDev S, const uint16_
     if (s_hist[i]) atomicAdd((uint32_t *)&trans[i], s_hist[i]);
 }
 
-void launch_final_tables(const SampleDev &S, const uint16_t *d_view, int LV, const int32_t *d_cluster_of,
-                         const int32_t *d_centre_of_cluster, const uint8_t *d_correct, int ncol, int has_quals,
-                         int32_t *d_trans, unsigned long long *d_qsum, uint32_t *d_qn, int32_t *d_nsubs, int nclust,
-                         hipStream_t st) {
+// Same tables for reads of up to 256 nt, walking the final pass's work list (ordered by partition): a wave keeps the
+// per-position quality sums of the partition it is in in registers (4 positions per lane) and flushes them with one
+// atomic per position when the partition changes - the per-unique atomics of the kernel above all land on the few
+// hundred addresses of the largest partitions and serialise (1.07 ms at 100 k uniques).
+__global__ __launch_bounds__(256) void k_final_tables_seg(SampleDev S, const uint16_t *__restrict__ view, int LV,
+                                                          const int32_t *__restrict__ work, int nslots,
+                                                          const int32_t *__restrict__ cluster_of,
+                                                          const int32_t *__restrict__ centre_of_cluster,
+                                                          const uint8_t *__restrict__ correct, int ncol, int has_quals,
+                                                          int32_t *__restrict__ trans, unsigned long long *__restrict__ qsum,
+                                                          uint32_t *__restrict__ qn, int32_t *__restrict__ nsubs) {
+  extern __shared__ uint32_t s_hist[];   // [16*ncol]
+  const int nb = 16 * ncol;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s_hist[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int span = (nslots + nwaves - 1) / nwaves;
+  const int lo = gwave * span, hi = min(nslots, lo + span);
+  int cur = -1, Lc = 0;
+  const uint32_t *crow = nullptr;
+  unsigned long long qs[4] = {0, 0, 0, 0};
+  uint32_t qc[4] = {0, 0, 0, 0};
+  auto flush = [&]() {
+    if (cur < 0) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = lane + 64 * k;
+      if (qc[k]) {
+        atomicAdd(&qsum[(size_t)cur * S.maxlen + p], qs[k]);
+        atomicAdd(&qn[(size_t)cur * S.maxlen + p], qc[k]);
+      }
+      qs[k] = 0; qc[k] = 0;
+    }
+  };
+  for (int slot = lo; slot < hi; slot++) {
+    const int r = work[slot];
+    if (r < 0) continue;
+    const int cl = cluster_of[r];
+    if (cl != cur) {
+      flush();
+      cur = cl;
+      const int c = centre_of_cluster[cl];
+      Lc = S.len[c];
+      crow = S.seq2 + (size_t)c * S.W2;
+    }
+    const uint32_t reads = S.reads[r];
+    const bool corr = correct[r] != 0;
+    uint32_t ns = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = lane + 64 * k;
+      if (p >= Lc) continue;
+      const uint32_t v = view[(size_t)r * LV + p];
+      if (v & 0x8000u) {
+        const uint32_t rb = (v >> 8) & 3u, q = v & 255u, cb = base_at(crow, p);
+        ns += (cb != rb);
+        if (corr) {
+          atomicAdd(&s_hist[(has_quals ? q : 0u) * 16 + 4u * cb + rb], reads);
+          if (has_quals) { qs[k] += (unsigned long long)(q * reads); qc[k] += reads; }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ns += __shfl_xor(ns, o, 64);
+    if (lane == 0) nsubs[r] = (int32_t)ns;
+  }
+  flush();
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += blockDim.x)
+    if (s_hist[i]) atomicAdd((uint32_t *)&trans[i], s_hist[i]);
+}
+
+void launch_final_tables(const SampleDev &S, const uint16_t *d_view, int LV, const int32_t *d_work, int nslots,
+                         const int32_t *d_cluster_of, const int32_t *d_centre_of_cluster, const uint8_t *d_correct, int ncol,
+                         int has_quals, int32_t *d_trans, unsigned long long *d_qsum, uint32_t *d_qn, int32_t *d_nsubs,
+                         int nclust, hipStream_t st) {
   (void)nclust;
   int grid = std::min((S.N + 3) / 4, 2048);
-  hipLaunchKernelGGL(k_final_tables, dim3(grid), dim3(256), (size_t)16 * ncol * 4, st, S, d_view, LV, d_cluster_of,
-                     d_centre_of_cluster, d_correct, ncol, has_quals, d_trans, d_qsum, d_qn, d_nsubs);
+  if (d_work && S.maxlen <= 256)
+    hipLaunchKernelGGL(k_final_tables_seg, dim3(grid), dim3(256), (size_t)16 * ncol * 4, st, S, d_view, LV, d_work, nslots,
+                       d_cluster_of, d_centre_of_cluster, d_correct, ncol, has_quals, d_trans, d_qsum, d_qn, d_nsubs);
+  else
+    hipLaunchKernelGGL(k_final_tables, dim3(grid), dim3(256), (size_t)16 * ncol * 4, st, S, d_view, LV, d_cluster_of,
+                       d_centre_of_cluster, d_correct, ncol, has_quals, d_trans, d_qsum, d_qn, d_nsubs);
 }
 
 }  // namespace d2
