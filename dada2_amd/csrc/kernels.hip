@@ -835,52 +835,69 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
     int guard = L1 + L2 + 2;                               // bounded: never spin on bad pointers
     while (true) {
       int nruns = 0;
-      if (g == 0 && !done && !ghost) {
-        uint32_t last = 0;                                 // pending (mergeable) run, 0 = none
-        auto push = [&](int lo, int n, int dl) {
-          if (last) {
-            const int llo = last & 4095, ln = (last >> 12) & 4095, ldl = (int)(last >> 24);
-            if (ldl == dl && lo + n == llo) { last = (uint32_t)lo | ((uint32_t)(ln + n) << 12) | ((uint32_t)dl << 24); return; }
-            runs[nruns++] = last;
-          }
-          last = (uint32_t)lo | ((uint32_t)n << 12) | ((uint32_t)dl << 24);
-        };
-        if (gapless) {
-          // nwalign_gapless (nwalign_endsfree.cpp:539-555): position-wise pairing, a longer raw's tail faces gaps
-          const int n = L1 < L2 ? L1 : L2;
-          runs[nruns++] = 0u | ((uint32_t)n << 12) | (128u << 24);
-          if (L2 > n) runs[nruns++] = (uint32_t)n | ((uint32_t)(L2 - n) << 12) | (255u << 24);
-          done = true;
-        } else {
-          while ((ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard-- > 0) {
-            const int t = ti + tj, kk = tj - ti + lbo;
-            const int col = kk >> 1;
-            const int f = t & 15;
-            const uint32_t word = ptr[(t >> 4) * NCOL + col];
-            // fields of this cell's parity at positions <= f that are NOT diagonal (01)
-            const uint32_t x = word ^ 0x55555555u;
-            uint32_t nz = (x | (x >> 1)) & 0x55555555u;
-            nz &= (f & 1) ? 0x44444444u : 0x11111111u;
-            nz &= (f == 15) ? 0xFFFFFFFFu : ((1u << ((f + 1) << 1)) - 1u);
-            int n;                                           // diagonal moves available inside this word
-            bool stop;
-            if (nz) { const int fb = (31 - __clz(nz)) >> 1; n = (f - fb) >> 1; stop = true; }
-            else { n = (f >> 1) + 1; stop = false; }
-            if (n > 0) {   // (cells on the first row/column carry pointers 2/3, so a run never crosses them)
-              push(tj - n, n, ti - tj + 128);
-              ti -= n; tj -= n;
-            }
-            if (stop && (ti > 0 || tj > 0)) {                // (0,0) carries an axis pointer too: the path ends there
-              const int t2s = ti + tj;
-              const uint32_t w2 = (t2s >> 4) == (t >> 4) ? word : ptr[(t2s >> 4) * NCOL + col];
-              const uint32_t p = (w2 >> ((t2s & 15) << 1)) & 3u;
-              if (p == 2u) { tj--; push(tj, 1, 255); }
-              else ti--;                                     // p == 3 (p == 1 cannot be here)
-            }
-          }
-          if (last) runs[nruns++] = last;
-          if (!(ti > 0 || tj > 0) || guard <= 0) done = true;
+      uint32_t last = 0;                                   // the leader's pending (mergeable) run, 0 = none
+      auto push = [&](int lo, int n, int dl) {
+        if (last) {
+          const int llo = last & 4095, ln = (last >> 12) & 4095, ldl = (int)(last >> 24);
+          if (ldl == dl && lo + n == llo) { last = (uint32_t)lo | ((uint32_t)(ln + n) << 12) | ((uint32_t)dl << 24); return; }
+          runs[nruns++] = last;
         }
+        last = (uint32_t)lo | ((uint32_t)n << 12) | ((uint32_t)dl << 24);
+      };
+      const bool lead = g == 0 && !ghost;
+      if (lead && !done && gapless) {
+        // nwalign_gapless (nwalign_endsfree.cpp:539-555): position-wise pairing, a longer raw's tail faces gaps
+        const int n = L1 < L2 ? L1 : L2;
+        runs[nruns++] = 0u | ((uint32_t)n << 12) | (128u << 24);
+        if (L2 > n) runs[nruns++] = (uint32_t)n | ((uint32_t)(L2 - n) << 12) | (255u << 24);
+        done = true;
+      }
+      // The path is walked by the group's first lane, but every diagonal stretch is measured by the whole group at once:
+      // lane q looks at the pointer word q blocks of 16 steps further back in the path's column, so one round finds the
+      // next non-diagonal move up to 16 GL steps away (a gap-free 250-nt alignment takes 2 rounds instead of 32).
+      const int gl0 = al * GL;
+      for (;;) {
+        const bool act = lead && !done && (ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard > 0;
+        if (!__any(act)) break;
+        const int gact = __shfl((int)act, gl0, 64);
+        const int tt = __shfl(ti + tj, gl0, 64), col = __shfl((tj - ti + lbo) >> 1, gl0, 64);
+        const int f0 = tt & 15, widx = (tt >> 4) - g;
+        uint32_t word = 0x55555555u;                       // (before the matrix: never reached, the axis cells stop the run)
+        if (gact && !ghost && widx >= 0) word = ptr[widx * NCOL + col];
+        const int ftop = g == 0 ? f0 : 14 + (f0 & 1);
+        // fields of the path cell's parity at positions <= ftop that are NOT diagonal (01)
+        const uint32_t x = word ^ 0x55555555u;
+        uint32_t nz = (x | (x >> 1)) & 0x55555555u;
+        nz &= (f0 & 1) ? 0x44444444u : 0x11111111u;
+        nz &= (ftop == 15) ? 0xFFFFFFFFu : ((1u << ((ftop + 1) << 1)) - 1u);
+        const bool st = nz != 0;
+        const int fb = st ? (31 - __clz(nz)) >> 1 : 0;
+        const int ng = st ? (ftop - fb) >> 1 : (ftop >> 1) + 1;   // diagonal moves inside this word
+        const uint32_t pst = (word >> (fb << 1)) & 3u;            // the pointer that ends the stretch
+        const unsigned long long bal = (__ballot(st && !ghost) >> gl0) & (GL == 64 ? ~0ull : ((1ull << (GL & 63)) - 1ull));
+        const int qs = bal ? __builtin_ctzll(bal) : GL;           // first word (counting back) holding a stop
+        const int srcl = gl0 + (qs < GL ? qs : 0);
+        const int n0 = __shfl(ng, gl0, 64), nq = __shfl(ng, srcl, 64);
+        const uint32_t pq = (uint32_t)__shfl((int)pst, srcl, 64);
+        if (act) {
+          guard--;
+          int n = qs == 0 ? n0 : n0 + 8 * (qs - 1) + (qs < GL ? nq : 0);
+          const int room = ti < tj ? ti : tj;
+          const bool clamped = n > room;                   // (cannot happen: cells on the first row/column carry pointers 2/3)
+          if (clamped) n = room;
+          if (n > 0) {
+            push(tj - n, n, ti - tj + 128);
+            ti -= n; tj -= n;
+          }
+          if (qs < GL && !clamped && (ti > 0 || tj > 0)) {  // (0,0) carries an axis pointer too: the path ends there
+            if (pq == 2u) { tj--; push(tj, 1, 255); }
+            else ti--;                                     // 3 (1 cannot be here)
+          }
+        }
+      }
+      if (lead && !gapless && active) {
+        if (last) runs[nruns++] = last;
+        if (!(ti > 0 || tj > 0) || guard <= 0) done = true;
       }
       nruns = __shfl(nruns, al * GL, 64);
       done = __shfl((int)done, al * GL, 64) != 0;
