@@ -1185,41 +1185,58 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
     const int gl0 = al * GL;
     while (true) {
       int nruns = 0;
-      if (g == 0 && !done && !ghost) {
-        uint32_t last = 0;
-        auto push = [&](int lo, int n, int dl) {
-          if (last) {
-            const int llo = last & 4095, ln = (last >> 12) & 4095, ldl = (int)(last >> 24);
-            if (ldl == dl && lo + n == llo) { last = (uint32_t)lo | ((uint32_t)(ln + n) << 12) | ((uint32_t)dl << 24); return; }
-            runs[nruns++] = last;
-          }
-          last = (uint32_t)lo | ((uint32_t)n << 12) | ((uint32_t)dl << 24);
-        };
-        while ((ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard-- > 0) {
-          const int t = ti + tj, kk = tj - ti + lbs;
-          const uint32_t *wp = pg + ((kk >> 1) & 3) * 64 + gl0 + (kk >> 3);
-          const int f = t & 15;
-          const uint32_t word = wp[(size_t)(t >> 4) * 256];
-          const uint32_t x = word ^ 0x55555555u;              // non-diagonal fields of this cell's parity at positions <= f
-          uint32_t nz = (x | (x >> 1)) & 0x55555555u;
-          nz &= (f & 1) ? 0x44444444u : 0x11111111u;
-          nz &= (f == 15) ? 0xFFFFFFFFu : ((1u << ((f + 1) << 1)) - 1u);
-          int n;
-          bool stop;
-          if (nz) { const int fb = (31 - __clz(nz)) >> 1; n = (f - fb) >> 1; stop = true; }
-          else { n = (f >> 1) + 1; stop = false; }
+      uint32_t last = 0;                                   // the leader's pending (mergeable) run, 0 = none
+      auto push = [&](int lo, int n, int dl) {
+        if (last) {
+          const int llo = last & 4095, ln = (last >> 12) & 4095, ldl = (int)(last >> 24);
+          if (ldl == dl && lo + n == llo) { last = (uint32_t)lo | ((uint32_t)(ln + n) << 12) | ((uint32_t)dl << 24); return; }
+          runs[nruns++] = last;
+        }
+        last = (uint32_t)lo | ((uint32_t)n << 12) | ((uint32_t)dl << 24);
+      };
+      // as in k_nw_ad: the path is walked by the group's first lane, every diagonal stretch is measured by the whole group
+      // (lane q reads the pointer word q blocks of 16 steps further back in the path's cell pair) - here each of those
+      // reads is an HBM/L2 access, so one round replaces up to GL dependent memory round trips
+      const bool lead = g == 0 && !ghost;
+      for (;;) {
+        const bool act = lead && !done && (ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard > 0;
+        if (!__any(act)) break;
+        const int gact = __shfl((int)act, gl0, 64);
+        const int tt = __shfl(ti + tj, gl0, 64), kkb = __shfl(tj - ti + lbs, gl0, 64);
+        const int f0 = tt & 15, widx = (tt >> 4) - g;
+        uint32_t word = 0x55555555u;
+        if (gact && !ghost && widx >= 0) word = pg[(size_t)widx * 256 + ((kkb >> 1) & 3) * 64 + gl0 + (kkb >> 3)];
+        const int ftop = g == 0 ? f0 : 14 + (f0 & 1);
+        const uint32_t x = word ^ 0x55555555u;
+        uint32_t nz = (x | (x >> 1)) & 0x55555555u;
+        nz &= (f0 & 1) ? 0x44444444u : 0x11111111u;
+        nz &= (ftop == 15) ? 0xFFFFFFFFu : ((1u << ((ftop + 1) << 1)) - 1u);
+        const bool st = nz != 0;
+        const int fb = st ? (31 - __clz(nz)) >> 1 : 0;
+        const int ng = st ? (ftop - fb) >> 1 : (ftop >> 1) + 1;
+        const uint32_t pst = (word >> (fb << 1)) & 3u;
+        const unsigned long long bal = (__ballot(st && !ghost) >> gl0) & (GL == 64 ? ~0ull : ((1ull << (GL & 63)) - 1ull));
+        const int qs = bal ? __builtin_ctzll(bal) : GL;
+        const int srcl = gl0 + (qs < GL ? qs : 0);
+        const int n0 = __shfl(ng, gl0, 64), nq = __shfl(ng, srcl, 64);
+        const uint32_t pq = (uint32_t)__shfl((int)pst, srcl, 64);
+        if (act) {
+          guard--;
+          int n = qs == 0 ? n0 : n0 + 8 * (qs - 1) + (qs < GL ? nq : 0);
+          const int room = ti < tj ? ti : tj;
+          const bool clamped = n > room;
+          if (clamped) n = room;
           if (n > 0) {
             push(tj - n, n, ti - tj + 128);
             ti -= n; tj -= n;
           }
-          if (stop && (ti > 0 || tj > 0)) {
-            const int t2s = ti + tj;
-            const uint32_t w2 = (t2s >> 4) == (t >> 4) ? word : wp[(size_t)(t2s >> 4) * 256];
-            const uint32_t p = (w2 >> ((t2s & 15) << 1)) & 3u;
-            if (p == 2u) { tj--; push(tj, 1, 255); }
+          if (qs < GL && !clamped && (ti > 0 || tj > 0)) {
+            if (pq == 2u) { tj--; push(tj, 1, 255); }
             else ti--;
           }
         }
+      }
+      if (lead && active) {
         if (last) runs[nruns++] = last;
         if (!(ti > 0 || tj > 0) || guard <= 0) done = true;
       }
