@@ -255,7 +255,8 @@ void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const
                    int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, bool build_table, const int32_t *d_centre_dev,
                    hipStream_t st) {
   if (build_table) hipLaunchKernelGGL(k_centre_table, dim3(1), dim3(256), 0, st, S, centre, d_ctab);
-  int grid = std::min((S.N + 15) / 16, 2048);
+  static const int grid_cap = [] { const char *e = getenv("DADA2HIP_SCREEN_GRID"); return e ? atoi(e) : 2048; }();
+  int grid = std::min((S.N + 15) / 16, grid_cap);
   int iters = ((S.N + 15) / 16 + grid - 1) / grid;
   int cap = iters * 16;
   size_t lds = (size_t)(CTAB_ORD + 8) * 4 + (size_t)cap * 8 + (size_t)S.LK * 2 + 32;
@@ -721,6 +722,12 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double *s_err = s_dyn;
   const int nerr = 16 * a.ap.ncol;
+  {   // the per-round grid is sized for the worst case (the batch size is only known on the device): blocks past the
+      // work leave before touching anything, also when a speculative round turned out to have no centre
+    const int n_all = (a.nwork_dev ? *a.nwork_dev : a.nwork_host) + (gl_work ? *gl_nwork_dev : 0);
+    if ((int)blockIdx.x * 4 * APW >= n_all) return;
+    if (a.centre_dev && *a.centre_dev < 0) return;
+  }
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // alignment slot in the wave / lane in the group.  With GL = 21 lane 63 is a ghost: it rides along the DP as an
@@ -1067,6 +1074,7 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double *s_err = s_dyn;
   const int nerr = 16 * a.ap.ncol;
+  if ((int)blockIdx.x * 4 * APW >= (a.nwork_dev ? *a.nwork_dev : a.nwork_host)) return;   // grid sized for the worst case
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool ghost = lane / GL >= APW;                     // GL = 21: lane 63 rides along with no cells of its own
