@@ -27,6 +27,17 @@ if dbs:
     for n, c, tot, avg, pct in rows:
         L.append(f"| `{short(n)}` | {c} | {tot / 1e3:.3f} | {avg:.2f} | {pct:.2f} |")
     L.append("")
+    # The per-round screen / NW kernels are also launched speculatively behind k_auto_birth, before the host has seen the
+    # bud decision; when no birth was applied on the device those launches find nothing to do and return in a few us.
+    # bench.py's HIP-event averages exclude them, so the comparable rocprofv3 average is over the working launches.
+    L += ["## Hot kernels without the no-op speculative launches (duration >= 8 us)", "",
+          "| kernel | working launches | avg us | no-op launches | avg us |", "|---|---|---|---|---|"]
+    for pat in ("%k_nw_ad<%", "%k_nw_adw<%", "%k_screen(%"):
+        for n, c1, a1, c0, a0 in db.execute(
+                "select name, sum(d >= 8000), avg(case when d >= 8000 then d end), sum(d < 8000), avg(case when d < 8000 then d end) "
+                "from (select name, (end - start) as d from kernels where name like ?) group by name", (pat,)):
+            L.append(f"| `{short(n)}` | {c1} | {(a1 or 0) / 1e3:.2f} | {c0} | {(a0 or 0) / 1e3:.2f} |")
+    L.append("")
     res = list(db.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
                           "max(workgroup_x), avg(grid_x) from kernels where name like 'd2::%' or name like 'void d2::%' group by name"))
     L += ["## Dispatch resources", "", "| kernel | VGPR | AGPR | SGPR | LDS B | scratch B | wg | avg grid threads |", "|---|---|---|---|---|---|---|---|"]
@@ -54,8 +65,11 @@ for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     if not dbs:
         continue
     db = sqlite3.connect(dbs[0])
+    # (dispatches shorter than 8 us are the no-op speculative launches of the per-round kernels: not part of the average)
     for k, n, a in db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? and "
-                              "(kernel_name like 'd2::%' or kernel_name like 'void d2::%') group by kernel_name", (cname,)):
+                              "(kernel_name like 'd2::%' or kernel_name like 'void d2::%') and "
+                              "(duration >= 8000 or (kernel_name not like '%k_nw_ad%' and kernel_name not like '%k_screen%')) "
+                              "group by kernel_name", (cname,)):
         traffic.setdefault(short(k), {})[cname + "_KB_avg"] = a
         traffic[short(k)]["dispatches"] = n
 for k, v in traffic.items():
