@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
   if (tid < 8) s_cnt[tid] = 0;
   __syncthreads();
   const int sub = tid & 15, grp = tid >> 4;
-  const int nchunk = S.LK >> 3;                               // 16-byte chunks (8 k-mer records) per row
+  const int nchunk = (S.maxlen - KMER_SIZE + 1 + 7) >> 3;     // 16-byte chunks (8 k-mer records) per row; rows may be padded to 128 B
   const bool two = nchunk <= 32;                              // each lane owns <= 2 chunks: keep them in registers
   for (int base = blockIdx.x * 16; base < S.N; base += gridDim.x * 16) {
     const int r = base + grp;
