@@ -653,21 +653,20 @@ struct Run {
   }
 
   // enqueue one b_shuffle2 (device arg-max + move); count and first movers go to slot `slot` of the round's result block.
-  // The arg-max uses the partition reads as of the start of the call: a snapshot, refreshed by k_apply_bud ahead of
-  // every round and by an explicit copy before any further real shuffle.  check = count would-be movers only (the
-  // speculative second shuffle): nothing moves, so it reads the live reads and needs no snapshot.
+  // The arg-max uses the partition reads as of the start of the call: a snapshot, refreshed by k_apply_bud /
+  // k_auto_birth ahead of every round and by an explicit copy before any further shuffle of the same round.
+  // (Whether a further call would move anything is asked inside k_pupdate_budmin, which needs no snapshot.)
   bool snap_fresh = true;
-  int32_t *enqueue_shuffle(int slot, bool check = false) {
+  void enqueue_shuffle(int slot) {
     hipStream_t stq = s->stream;
     RoundOut *ro = this->ro();
-    if (!check && !snap_fresh)
+    if (!snap_fresh)
       D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)nclust_dev * 4, hipMemcpyDeviceToDevice, stq));
-    launch_shuffle(P, s->D, check ? P.creads : d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot],
-                   have_pending_store ? &pending_store : nullptr, check ? 1 : 0, nclust_dev, stq);
+    launch_shuffle(P, s->D, d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot],
+                   have_pending_store ? &pending_store : nullptr, 0, nclust_dev, stq);
     have_pending_store = false;
-    if (!check) snap_fresh = false;
+    snap_fresh = false;
     st.nshuffle++;
-    return ro->cnt + slot;
   }
   int nclust_dev = 1;   // partitions the device knows about (the host mirror may lag by one birth)
   StoreRound pending_store{};
