@@ -332,7 +332,8 @@ struct Bi {
 struct BudKeyH { double p; uint32_t reads; uint32_t pad; };
 
 // below this many alignments in one launch the cooperative (anti-diagonal) kernel beats one-alignment-per-lane
-constexpr int COOP_MAX_BATCH = 262144;
+// (measured up to 1e6 alignments: 1M-unique pass 358 -> 349 ms; beyond 4e6 untested, the lane kernel takes over)
+static const int COOP_MAX_BATCH = [] { const char *e = getenv("DADA2HIP_COOP_MAX"); return e ? atoi(e) : 4000000; }();
 
 struct Run {
   dada2hip_sample *s;
