@@ -122,7 +122,8 @@ struct BudOut {
 // Everything the host needs from one round tail, fetched with a single copy.
 constexpr int MOVERS_INLINE = 512;
 struct RoundOut {
-  int32_t cnt[2];              // movers of the two speculative shuffles (zeroed by k_apply_bud ahead of the round)
+  int32_t cnt[2];              // [slot of the real shuffle] = its movers, [other] = uniques one more call would move (zeroed by
+                               // k_apply_bud / k_auto_birth ahead of the round)
   int32_t seq;                 // host copy only: sequence number k_auto_birth writes last when it publishes the block
   int32_t pad;
   BudOut bud;
