@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json's metric: unique reads denoised / s of dada() wall-clock.
 
-One "step" = one full dada_uniques pass (all divisive rounds + final alignments + output
-tables) over one synthetic sample whose reads, qualities and k-mer records are already
-resident in HBM (dada2_amd.api.Sample) when the timed region starts.  Workload at N=1 is
-BASELINE.json configs[1]: 100 k unique 250-nt synthetic reads, fixed error matrix (tperr1).
-With --gpus N every rank denoises its own sample of the same size (weak scaling: the path
-shards at sample granularity) and the only collective is the RCCL all-reduce of
-the 16 x Q transition-count matrix (accumulateTrans, R/errorModels.R:462-471), inside the
-timed region.
+One "step" = ONE BOUNDARY CALL `dada2hip_dada_uniques` (include/dada2hip.h) on host inputs — the marshalling of
+the R-side vectors, H2D upload, k-mer build, every divisive round, the final alignments, the output tables and
+the D2H of the six result objects — exactly what SURVEY.md §8(d) defines as the metric's wall clock ("inputs
+already on host, includes H2D, all kernels, D2H of results").  Workload by --config (SURVEY.md §8 numbering):
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel by HIP-event time, algorithmic work / measured duration vs peak
-  cpu_baseline  the reference's own C++ (oracle/_ref, multithread=TRUE on all host cores, and
-                1 thread) timed on the same box on the same sample (bounded)
+  3 (default)  1 000 000 unique 250-nt synthetic reads, tperr1 fixed error matrix   <- the headline (BASELINE.json)
+               (--selfconsist runs configs[2]'s learnErrors-style loop on it: err from all-ones, noqual refit)
+  2            100 000 unique 250-nt reads                                          (BASELINE.json configs[1])
+  4            8 samples x 250 000 uniques, samples sharded round-robin over the ranks (strong scaling, configs[3])
+  5            200 000 unique ~1 500-nt reads, BAND_SIZE 32, 94 quality columns     (configs[4])
+
+With --gpus N (configs 2/3/5) every rank denoises its own sample of the same size (weak scaling: the path shards
+at sample granularity); the only collective is the RCCL all-reduce of the 16 x Q transition-count
+matrix (accumulateTrans, R/errorModels.R:462-471), inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with, besides the contract's keys:
+  roofline        dominant kernel of a fully event-timed pass (DADA2HIP_PROFILE=1: every launch timed, nothing
+                  extrapolated): algorithmic work / measured duration vs the guide's peak and the measured peak
+  cpu_baseline    the reference's own C++ (oracle/_ref: -O2 as R builds it, and -O3) on this box's host cores
+  resident        the same pass on a sample already resident in HBM (what selfConsist passes 2..n cost)
 """
 import argparse
 import json
@@ -26,9 +33,63 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PEAK_VALU_TOPS = 39.3       # 256 CU x 4 SIMD x 16... = 256 x 64 lanes x 2.4 GHz 32-bit lane-ops/s
+# MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy); integer VALU = 256 CU x 4 SIMD-32 x
+# 2.4 GHz = 78.6 T 32-bit lane-ops/s (the FP32 vector rate, 157.3 TFLOPS, counts an FMA as 2)
+PEAK_HBM_GBS = 8000.0
+PEAK_VALU_TOPS = 78.6
 INT_OPS_PER_CELL = 8        # fixed algorithmic constant, SURVEY.md §8d
+
+CONFIGS = {
+    2: dict(uniques=100_000, length=250, variants=256, band=16, samples=1),
+    3: dict(uniques=1_000_000, length=250, variants=2048, band=16, samples=1),
+    4: dict(uniques=250_000, length=250, variants=512, band=16, samples=8),
+    5: dict(uniques=200_000, length=1510, variants=128, band=32, samples=1, lmin=1450, q_hi=93.0, q_lo=30.0, q_max=93,
+            indel=1e-4),
+}
+
+
+def measured_peaks():
+    """Peaks pinned by tools/microbench on the GPU box (profiles/peaks_*.json), if a record is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "peaks_*.json")))
+    if not files:
+        return None
+    try:
+        p = json.load(open(files[-1]))
+        p["_file"] = os.path.relpath(files[-1], ROOT)
+        return p
+    except Exception:
+        return None
+
+
+def make_inputs(cfg, args, rank):
+    """Synthetic samples of this rank (SURVEY.md §8d recipe) as HostInput objects + the error matrix."""
+    from dada2_amd.api import HostInput
+    from dada2_amd.io import extend_err
+    from dada2_amd.synth import make_sample, true_variants
+    tperr1 = np.load(os.path.join(ROOT, "tests", "golden", "tperr1.npy"))
+    c = CONFIGS[cfg]
+    n, L, G = args.uniques or c["uniques"], args.length or c["length"], args.variants or c["variants"]
+    err = extend_err(tperr1, c.get("q_max", 40))
+    kw = dict(L=L, G=G, Lmin=c.get("lmin"), q_hi=c.get("q_hi", 38.0), q_lo=c.get("q_lo", 22.0), q_max=c.get("q_max", 40),
+              indel_rate=c.get("indel", 0.0), chunk=200_000 if L <= 500 else 20_000)
+    dereps = []
+    if c["samples"] == 1:
+        dereps.append(make_sample(err, n, seed=20260925 + cfg + 1000 * rank, **kw))
+        mine = [0]
+    else:
+        # configs[3]: 8 samples, half of each sample's true variants shared across samples
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rng = np.random.default_rng(20260925 + cfg)
+        shared = true_variants(rng, G // 2, L)
+        mine = list(range(rank, c["samples"], world))
+        for i in mine:
+            own = true_variants(np.random.default_rng(20260925 + cfg + 17 * (i + 1)), G - G // 2, L)
+            tv = np.concatenate([shared[0], own[0]])
+            tl = np.concatenate([shared[1], own[1]])
+            perm = np.random.default_rng(99 + i).permutation(tv.shape[0])   # abundance ranks differ per sample
+            dereps.append(make_sample(err, n, seed=20260925 + cfg + 1000 * (i + 1), variants=(tv[perm], tl[perm]), **kw))
+    return dereps, [HostInput.from_derep(d) for d in dereps], err, mine, c
 
 
 def main():
@@ -36,16 +97,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--uniques", type=int, default=100_000)
-    ap.add_argument("--length", type=int, default=250)
-    ap.add_argument("--variants", type=int, default=256)
-    ap.add_argument("--band", type=int, default=16)
-    ap.add_argument("--lmin", type=int, default=0, help="ragged true-variant lengths in [lmin, length] (long-read configs)")
-    ap.add_argument("--q-hi", type=float, default=38.0)
-    ap.add_argument("--q-lo", type=float, default=22.0)
-    ap.add_argument("--q-sd", type=float, default=4.0)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--uniques", type=int, default=0, help="override the config's uniques per sample")
+    ap.add_argument("--length", type=int, default=0)
+    ap.add_argument("--variants", type=int, default=0)
+    ap.add_argument("--band", type=int, default=0)
+    ap.add_argument("--selfconsist", action="store_true", help="configs[2]: err from all-ones, noqual refit, resident passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-uniques", type=int, default=0, help="prefix of the sample timed on the CPU (0 = auto)")
+    ap.add_argument("--cpu-uniques", type=int, default=0, help="prefix of the sample timed on the CPU (0 = auto, bounded)")
+    ap.add_argument("--cpu-full", action="store_true", help="time the reference on the WHOLE sample and check every output against the GPU's")
+    ap.add_argument("--cpu-repeats", type=int, default=1)
+    ap.add_argument("--no-profile-pass", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -55,159 +117,255 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from dada2_amd import api
     from dada2_amd.opts import DadaOpts
-    from dada2_amd.synth import make_sample
 
-    tperr1 = np.load(os.path.join(ROOT, "tests", "golden", "tperr1.npy"))
-    opts = DadaOpts(BAND_SIZE=args.band)
     t0 = time.time()
-    d = make_sample(tperr1, args.uniques, L=args.length, G=args.variants, seed=20260925 + 2 + 1000 * rank,
-                    Lmin=args.lmin or None, q_hi=args.q_hi, q_lo=args.q_lo, q_sd=args.q_sd,
-                    chunk=200_000 if args.length <= 500 else 20_000)
+    dereps, inputs, err, mine, c = make_inputs(args.config, args, rank)
     t_gen = time.time() - t0
-    smp = api.Sample.from_derep(d, device=local)
+    band = args.band or c["band"]
+    opts = DadaOpts(BAND_SIZE=band)
+    strong = c["samples"] > 1
+    maxcol = err.shape[1]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        r = smp.run(tperr1, opts)
+    def allreduce_trans(results):
+        local_t = np.zeros((16, maxcol), dtype=np.int64)
+        for r in results:
+            local_t[:, : r.subqual.shape[1]] += r.subqual
         if world > 1:   # accumulateTrans across samples: the path's only exchange (int64, <= 12 KB)
-            t = torch.from_numpy(r.subqual.astype(np.int64)).cuda()
+            t = torch.from_numpy(local_t).cuda()
             dist.all_reduce(t)
-            t.cpu()
-        return r
+            local_t = t.cpu().numpy()
+        return local_t
+
+    sc_info = None
+
+    def step():
+        """One boundary call per sample of this rank (host inputs in, six result objects out)."""
+        nonlocal sc_info
+        if args.selfconsist:
+            tm = []
+            res, err_out, errs = api.dada(dereps[0], None, self_consist=True, opts=opts, device=local, timings=tm,
+                                          host_input=inputs[0])
+            sc_info = {"passes": len(tm) - 1, "ms_create": tm[0], "ms_per_pass": tm[1:], "partitions_last": res.nclust}
+            results = [res]
+        else:
+            results = [api.dada_uniques(hi, None, None, err, None, opts, device=local) for hi in inputs]
+        allreduce_trans(results)
+        return results
 
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        results = step()
     barrier()
     dt = time.perf_counter() - t0
+    n_local = sum(d.nraw for d in dereps)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        nn = torch.tensor([d.nraw], dtype=torch.int64, device="cuda")
+        nn = torch.tensor([n_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(nn)
         total_uniques = int(nn.item())
     else:
-        total_uniques = d.nraw
+        total_uniques = n_local
 
     if rank == 0:
+        res, d = results[0], dereps[0]
         st = res.stats
         value = total_uniques * args.steps / dt
-        # ---- roofline of the dominant kernel (per launch, from the HIP-event sums of the last step) ----
-        nw_ms, nw_n = st["nw_kernel_ms"], max(1, st["nw_kernel_launches"])
-        sc_ms, sc_n = st["screen_kernel_ms"], max(1, st["screen_kernel_launches"])
-        L = args.length
-        nw_ops = st["nw_cells"] * INT_OPS_PER_CELL
-        screen_bytes = st["ncompare"] * (2 * (L - 4) + 6) - st["nskipped"] * 2 * (L - 4)
-        roof_nw = {"kernel": "k_nw", "bound": "valu", "achieved": nw_ops / (nw_ms * 1e-3) / 1e12 if nw_ms > 0 else 0.0,
-                   "peak": PEAK_VALU_TOPS, "unit": "Tops/s", "traffic": None,
-                   "avg_launch_ms": nw_ms / nw_n, "launches": st["nw_kernel_launches"]}
-        roof_nw["frac"] = roof_nw["achieved"] / roof_nw["peak"]
-        roof_sc = {"kernel": "k_screen", "bound": "hbm", "achieved": screen_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0,
-                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None,
-                   "avg_launch_ms": sc_ms / sc_n, "launches": st["screen_kernel_launches"]}
-        roof_sc["frac"] = roof_sc["achieved"] / roof_sc["peak"]
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_traffic.json;
-        # bench.py cannot run the profiler on itself) — null when no matching profile is committed
-        tr = load_traffic()
-        if tr and args.uniques == 100_000 and args.length == 250:
-            coop = [v for k, v in tr.items() if k.startswith("void k_nw_ad") and isinstance(v, dict)]   # the per-round NW kernel
-            roof_nw["traffic"] = max(coop, key=lambda v: v.get("dispatches", 0)).get("hbm_bytes_per_launch") if coop else None
-            roof_sc["traffic"] = tr.get("k_screen", {}).get("hbm_bytes_per_launch")
-            roof_nw["traffic_source"] = roof_sc["traffic_source"] = tr.get("_file")
-        roofline = roof_nw if nw_ms >= sc_ms else roof_sc
-        other = roof_sc if nw_ms >= sc_ms else roof_nw
+        L = max(len(s) for s in d.seqs[:256])
 
-        # ---- CPU baseline: the reference itself on this box's host cores, same sample (bounded) ----
+        # ---- secondary: the same pass on a resident sample + a fully event-timed pass for the roofline --------------
+        resident, prof = None, None
+        if not args.selfconsist:
+            smp = api.Sample(inputs[0], None, None, None, device=local)
+            smp.run(err, opts)
+            tr0 = time.perf_counter()
+            nres = max(1, min(args.steps, 5))
+            for _ in range(nres):
+                rr = smp.run(err, opts)
+            resident = {"ms_per_pass": (time.perf_counter() - tr0) / nres * 1e3, "ms_upload": rr.stats["ms_upload"],
+                        "uniques_per_s": d.nraw * nres / (time.perf_counter() - tr0),
+                        "note": "sample already resident in HBM (dada2hip_sample_run): what selfConsist passes 2..n cost"}
+            if not args.no_profile_pass:
+                os.environ["DADA2HIP_PROFILE"] = "1"
+                prof = smp.run(err, opts).stats
+                del os.environ["DADA2HIP_PROFILE"]
+            smp.close()
+        pst = prof or st
+        roofline, other = rooflines(pst, L, band, args.config)
+
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(d, tperr1, opts, args.cpu_uniques, res)
+        if not args.no_cpu_baseline and world == 1 and not args.selfconsist:
+            cpu = cpu_baseline(d, err, opts, args, res)
 
         out = {
             "metric": "unique reads denoised/sec (dada() wall-clock)", "value": value, "unit": "uniques/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 DP + f64 lambda/p-value",
-            "data": "synthetic",
-            "config": {"workload": f"{args.uniques} unique {L}-nt synthetic reads per GPU "
-                                   f"({'BASELINE.json configs[1] recipe' if L <= 500 else 'long-read shape of BASELINE.json configs[4]'}), "
-                                   f"tperr1 fixed error matrix, BAND_SIZE {args.band}, dada() defaults",
-                       "uniques_per_gpu": d.nraw, "reads_per_gpu": int(d.abundances.sum()), "partitions": res.nclust,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "int32 DP + f64 lambda/p-value", "data": "synthetic",
+            "timed_region": "dada2hip_dada_uniques boundary call: host inputs -> marshalling, H2D, k-mer build, all rounds, "
+                            "final pass, tables, D2H of the six outputs" + ("; selfConsist loop incl. sample upload" if args.selfconsist else ""),
+            "config": {"workload": workload_name(args.config, d.nraw, L, band, c, args.selfconsist),
+                       "baseline_config": args.config, "uniques_per_sample": d.nraw, "samples_total": c["samples"],
+                       "samples_this_rank": len(mine), "reads_per_sample": int(d.abundances.sum()), "partitions": res.nclust,
                        "comparisons": st["ncompare"], "nw": st["nnw"], "gapless": st["ngapless"],
-                       "shrouded": st["nshroud"], "greedy_skipped": st["nskipped"], "parallelism": f"sample-per-gpu x{world}"},
+                       "shrouded": st["nshroud"], "greedy_skipped": st["nskipped"], "shuffles": st["nshuffle"],
+                       "host_input_bytes": inputs[0].nbytes,
+                       "parallelism": (f"{c['samples']} samples round-robin over {world} rank(s)" if strong else f"sample-per-gpu x{world}")},
             "roofline": roofline, "roofline_secondary": other,
             "cpu_baseline": cpu,
-            "phases_ms_last_step": {k: st[k] for k in ("ms_total", "ms_screen", "ms_nw", "ms_bookkeep", "ms_pval", "ms_final")},
-            "comparisons_per_s": st["ncompare"] * world * args.steps / dt if world == 1 else None,
+            "resident": resident,
+            "selfconsist": sc_info,
+            "phases_ms_last_step": phases(st, pst if prof else None),
+            "comparisons_per_s": st["ncompare"] * len(inputs) * world * args.steps / dt,
             "gen_s": t_gen,
         }
         print(json.dumps(out))
-    smp.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def load_traffic():
+def workload_name(cfg, n, L, band, c, selfconsist):
+    names = {2: "BASELINE.json configs[1]", 3: "BASELINE.json configs[2] size (the headline: 1M uniques x 250 nt)",
+             4: "BASELINE.json configs[3]", 5: "BASELINE.json configs[4]"}
+    s = f"{c['samples']} x " if c["samples"] > 1 else ""
+    return (f"{s}{n} unique {L}-nt synthetic reads ({names[cfg]}), "
+            + ("selfConsist loop from an all-ones error matrix with the noqual refit" if selfconsist else "tperr1 fixed error matrix")
+            + f", BAND_SIZE {band}, dada() defaults")
+
+
+def phases(st, prof):
+    """Host wall split of the last timed call, and (from the event-timed pass) device time per kernel class."""
+    out = {"host_wall_ms": {k: st[k] for k in ("ms_total", "ms_upload", "ms_screen", "ms_bookkeep", "ms_final")},
+           "host_wall_note": "upload = marshalling + H2D + k-mer build; screen = enqueue of the compare kernels; "
+                             "bookkeep = round tails incl. waiting for the device; final = final pass + outputs"}
+    if prof:
+        out["device_ms_profiled_pass"] = {k[7:]: prof[k] for k in ("dev_ms_screen", "dev_ms_nw", "dev_ms_shuffle", "dev_ms_pval",
+                                                                   "dev_ms_birth", "dev_ms_final")}
+        out["device_ms_note"] = "HIP-event time of EVERY launch of a resident pass under DADA2HIP_PROFILE=1, summed per kernel class"
+    return out
+
+
+def rooflines(st, L, band, cfg):
+    """Per-launch rooflines of the two hot kernels from HIP-event times (exact sums under DADA2HIP_PROFILE=1)."""
+    peaks = measured_peaks()
+    nw_ms, nw_n = st["nw_kernel_ms"], max(1, st["nw_kernel_launches"])
+    sc_ms, sc_n = st["screen_kernel_ms"], max(1, st["screen_kernel_launches"])
+    nw_ops = st["nw_cells"] * INT_OPS_PER_CELL
+    # algorithmic bytes the screen must read per compared unique: its ordered k-mer record row 2*(L-4) B + 6 B of
+    # scalars (DESIGN.md §3; the reference streams 1 544 B for the same decision) - none for greedy-skipped uniques
+    screen_bytes = st["ncompare"] * (2 * (L - 4) + 6) - st["nskipped"] * 2 * (L - 4)
+    sampled = bool(st.get("kernel_times_sampled", 1))
+    timing = "extrapolated from sampled launches" if sampled else "every launch event-timed (DADA2HIP_PROFILE=1)"
+    roof_nw = {"kernel": "k_nw_ad / k_nw_adw (banded NW + traceback + lambda)", "bound": "valu",
+               "achieved": nw_ops / (nw_ms * 1e-3) / 1e12 if nw_ms > 0 else 0.0, "peak": PEAK_VALU_TOPS, "unit": "Tops/s",
+               "traffic": None, "avg_launch_ms": nw_ms / nw_n, "launches": st["nw_kernel_launches"], "kernel_ms": nw_ms,
+               "timing": timing, "algorithmic_ops_per_launch": nw_ops / nw_n}
+    roof_sc = {"kernel": "k_screen (k-mer screen)", "bound": "hbm",
+               "achieved": screen_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "traffic": None, "avg_launch_ms": sc_ms / sc_n, "launches": st["screen_kernel_launches"], "kernel_ms": sc_ms,
+               "timing": timing, "algorithmic_bytes_per_launch": screen_bytes / sc_n}
+    for r, key in ((roof_nw, "valu_int32_tops"), (roof_sc, "hbm_read_gbs")):
+        r["frac"] = r["achieved"] / r["peak"]
+        if peaks and key in peaks:
+            r["peak_measured"] = peaks[key]
+            r["frac_of_measured_peak"] = r["achieved"] / peaks[key]
+            r["peak_measured_source"] = peaks["_file"]
+    tr = load_traffic(cfg)
+    if tr:
+        roof_nw["traffic"] = tr.get("nw", {}).get("hbm_bytes_per_launch")
+        roof_sc["traffic"] = tr.get("screen", {}).get("hbm_bytes_per_launch")
+        roof_nw["traffic_source"] = roof_sc["traffic_source"] = "committed rocprofv3 PMC pass of this command: " + tr["_file"]
+    return (roof_nw, roof_sc) if nw_ms >= sc_ms else (roof_sc, roof_nw)
+
+
+def load_traffic(cfg):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic_cfgN.json) of this same command;
+    bench.py cannot run the profiler on itself.  None when no profile of this config is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_traffic_cfg{cfg}.json")))
     if not files:
         return None
     t = json.load(open(files[-1]))
-    k = dict(t.get("kernels", {}))
-    k["_file"] = os.path.relpath(files[-1], ROOT)
-    return k
+    t["_file"] = os.path.relpath(files[-1], ROOT)
+    return t
 
 
-def cpu_baseline(d, err, opts, cpu_uniques, gpu_res):
-    """Reference C++ (oracle/_ref; falls back to the C restatement, kind 'port') on the host cores."""
+def cpu_baseline(d, err, opts, args, gpu_res):
+    """Reference C++ (oracle/_ref; falls back to the C restatement, kind 'port') on this box's host cores."""
     from oracle import ref, cport
     ncores = os.cpu_count() or 1
-    n = cpu_uniques or min(d.nraw, 100_000)
+    L = max(len(x) for x in d.seqs[:64])
+    if args.cpu_full:
+        n = d.nraw
+    elif args.cpu_uniques:
+        n = min(d.nraw, args.cpu_uniques)
+    else:   # ~10-20 s of all-core CPU work: N x C grows roughly as N^1.5 on these samples
+        n = min(d.nraw, 200_000 if L <= 500 else 6_000)
     seqs, ab, q = d.seqs[:n], d.abundances[:n], d.quals[:n]
     out = {"unit": "uniques/s", "cores": ncores,
-           "sample": f"first {n} uniques of the bench sample (abundance-sorted prefix), full dada_uniques"}
-    if ref.available():
-        out["kind"] = "reference"
-        ref.set_threads(ncores)
-        t0 = time.perf_counter()
-        r = ref.dada_uniques(seqs, ab, None, err, q, opts, multithread=True)
-        t_all = time.perf_counter() - t0
-        out["value"] = n / t_all
-        out["seconds"] = t_all
-        out["partitions"] = r.nclust
-        # single thread on a smaller prefix so the default run stays within minutes
-        L = max(len(x) for x in seqs[:64])
-        n1 = min(n, max(500, int(20_000 * (250.0 / max(L, 250)) ** 2)))   # ~10-30 s of scalar CPU work at any read length
-        ref.set_threads(1)
-        t0 = time.perf_counter()
-        r1 = ref.dada_uniques(seqs[:n1], ab[:n1], None, err, q[:n1], opts, multithread=False)
-        t1 = time.perf_counter() - t0
-        out["single_thread"] = {"value": n1 / t1, "seconds": t1, "sample_uniques": n1, "partitions": r1.nclust}
-        if n == d.nraw:   # same input as the GPU run: parity of the headline outputs, for the record
-            out["parity_vs_gpu"] = bool(r.clustering["sequence"] == gpu_res.clustering["sequence"]
-                                        and np.array_equal(r.map, gpu_res.map))
-    else:
+           "sample": ("the whole bench sample" if n == d.nraw else f"first {n} uniques of the bench sample (abundance-sorted prefix)")
+                     + ", full dada_uniques, multithread=TRUE"}
+    if not ref.available():
         out["kind"] = "port"
         out["cores"] = 1
         n1 = min(n, 20_000)
         t0 = time.perf_counter()
-        r1 = cport.dada_uniques(seqs[:n1], ab[:n1], None, err, q[:n1], opts)
+        cport.dada_uniques(seqs[:n1], ab[:n1], None, err, q[:n1], opts)
         t1 = time.perf_counter() - t0
-        out["value"] = n1 / t1
-        out["seconds"] = t1
-        out["sample"] = f"first {n1} uniques of the bench sample, full dada_uniques, scalar C port"
+        out.update(value=n1 / t1, seconds=t1, sample=f"first {n1} uniques of the bench sample, full dada_uniques, scalar C port")
+        return out
+    out["kind"] = "reference"
+
+    packed = ref.pack_inputs(seqs, ab, None, err, q)     # marshalling outside the timed call, as for the GPU side
+
+    def timed(flavour):
+        best, r = None, None
+        for _ in range(max(1, args.cpu_repeats)):
+            ref.set_threads(ncores)
+            cs = []
+            r = ref.dada_uniques(seqs, ab, None, err, q, opts, multithread=True, flavour=flavour, packed=packed, call_seconds=cs)
+            best = cs[-1] if best is None else min(best, cs[-1])
+        return best, r
+
+    t_all, r = timed("O2")
+    out.update(value=n / t_all, seconds=t_all, partitions=r.nclust, build="-O2 (R's default flags)", repeats=max(1, args.cpu_repeats),
+               comparisons_per_s=n * r.nclust / t_all)
+    if ref.available("O3"):
+        t3, r3 = timed("O3")
+        out["O3"] = {"value": n / t3, "seconds": t3, "build": "-O3 -march=x86-64-v3"}
+    # single thread on a smaller prefix so the default run stays within minutes
+    n1 = min(n, max(500, int(20_000 * (250.0 / max(L, 250)) ** 2)))   # ~5-20 s of scalar CPU work at any read length
+    ref.set_threads(1)
+    cs = []
+    r1 = ref.dada_uniques(seqs[:n1], ab[:n1], None, err, q[:n1], opts, multithread=False, call_seconds=cs)
+    t1 = cs[-1]
+    out["single_thread"] = {"value": n1 / t1, "seconds": t1, "sample_uniques": n1, "partitions": r1.nclust}
+    if n == d.nraw:   # same input as the GPU run: EVERY output compared (tests/helpers.assert_results_equal)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import assert_results_equal
+        try:
+            assert_results_equal(gpu_res, r)
+            out["parity_vs_gpu"] = True
+            out["parity_check"] = "full: all six outputs (bit-exact integers/strings, p-values within 1e-10)"
+        except AssertionError as e:
+            out["parity_vs_gpu"] = False
+            out["parity_error"] = str(e)[:300]
     return out
 
 

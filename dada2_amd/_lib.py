@@ -23,11 +23,13 @@ class CStats(C.Structure):
     _fields_ = [
         ("ncompare", C.c_uint64), ("nskipped", C.c_uint64), ("nshroud", C.c_uint64), ("ngapless", C.c_uint64),
         ("nnw", C.c_uint64), ("nshuffle", C.c_uint64), ("nstored", C.c_uint64),
-        ("rounds", C.c_uint32), ("reserved", C.c_uint32),
+        ("rounds", C.c_uint32), ("kernel_times_sampled", C.c_uint32),
         ("ms_total", C.c_double), ("ms_upload", C.c_double), ("ms_screen", C.c_double), ("ms_nw", C.c_double),
         ("ms_gapless", C.c_double), ("ms_bookkeep", C.c_double), ("ms_pval", C.c_double), ("ms_final", C.c_double),
         ("nw_kernel_ms", C.c_double), ("nw_kernel_launches", C.c_uint64), ("nw_cells", C.c_uint64),
         ("screen_kernel_ms", C.c_double), ("screen_kernel_launches", C.c_uint64), ("screen_bytes", C.c_uint64),
+        ("dev_ms_screen", C.c_double), ("dev_ms_nw", C.c_double), ("dev_ms_shuffle", C.c_double),
+        ("dev_ms_pval", C.c_double), ("dev_ms_birth", C.c_double), ("dev_ms_final", C.c_double),
     ]
 
     def as_dict(self):
@@ -45,8 +47,14 @@ EXPORTS = [
     "dada2hip_result_bs_pos", "dada2hip_result_bs_ref", "dada2hip_result_bs_sub", "dada2hip_result_bs_qual",
     "dada2hip_result_bs_clust", "dada2hip_result_subqual", "dada2hip_result_clusterquals", "dada2hip_result_map",
     "dada2hip_result_pval", "dada2hip_result_stats", "dada2hip_result_free", "dada2hip_nwalign", "dada2hip_nwvec",
-    "dada2hip_sample_compare", "dada2hip_calc_pA", "dada2hip_version",
+    "dada2hip_sample_compare", "dada2hip_calc_pA", "dada2hip_version", "dada2hip_run_multi", "dada2hip_trim_cache",
 ]
+
+
+class CSampleInput(C.Structure):
+    """dada2hip_sample_input"""
+    _fields_ = [("nraw", C.c_int32), ("quals_nrow", C.c_int32), ("seqs", C.POINTER(C.c_char_p)),
+                ("abundances", C.c_void_p), ("priors", C.c_void_p), ("quals", C.c_void_p)]
 
 
 def lib():
@@ -59,13 +67,13 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, ip, cp = C.c_void_p, C.c_int32, C.c_char_p
     L.dada2hip_version.restype = cp
-    L.dada2hip_sample_create.argtypes = [ip, C.POINTER(cp), vp, vp, vp, ip, ip, C.POINTER(vp), cp, C.c_size_t]
+    L.dada2hip_sample_create.argtypes = [ip, vp, vp, vp, vp, ip, ip, C.POINTER(vp), cp, C.c_size_t]
     L.dada2hip_sample_set_priors.argtypes = [vp, vp, cp, C.c_size_t]
     L.dada2hip_sample_run.argtypes = [vp, vp, ip, C.POINTER(COpts), vp, C.POINTER(vp), cp, C.c_size_t]
     L.dada2hip_sample_free.argtypes = [vp]
     L.dada2hip_sample_nraw.argtypes = [vp]
     L.dada2hip_sample_maxlen.argtypes = [vp]
-    L.dada2hip_dada_uniques.argtypes = [ip, C.POINTER(cp), vp, vp, vp, ip, vp, ip, C.POINTER(COpts), ip, vp,
+    L.dada2hip_dada_uniques.argtypes = [ip, vp, vp, vp, vp, ip, vp, ip, C.POINTER(COpts), ip, vp,
                                         C.POINTER(vp), cp, C.c_size_t]
     for name in ("nclust", "nraw", "maxlen", "ncol", "nbirth_subs"):
         getattr(L, "dada2hip_result_" + name).argtypes = [vp]
@@ -92,6 +100,10 @@ def lib():
     L.dada2hip_sample_compare.argtypes = [vp, ip, vp, ip, C.POINTER(COpts), C.c_double, vp, vp, vp, vp,
                                           C.POINTER(CStats), cp, C.c_size_t]
     L.dada2hip_calc_pA.argtypes = [ip, vp, vp, vp, ip, vp, cp, C.c_size_t]
+    L.dada2hip_run_multi.argtypes = [ip, C.POINTER(CSampleInput), vp, ip, C.POINTER(COpts), ip, vp, C.POINTER(vp), cp,
+                                     C.c_size_t]
+    L.dada2hip_trim_cache.argtypes = []
+    L.dada2hip_trim_cache.restype = None
     _lib = L
     return L
 

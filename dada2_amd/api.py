@@ -24,15 +24,46 @@ from .opts import COpts, DadaOpts, DadaResult
 _EB = 2048
 
 
+class HostInput:
+    """Host-side inputs of one ``dada_uniques`` call laid out as the C ABI takes them — what R already holds in its
+    own vectors when it issues the ``.Call``: ``char**`` strings, int32 abundances, uint8 priors and the column-major
+    ``maxlen x nraw`` double quality matrix (here: row-major [nraw, maxlen], the same bytes).  Built once; timing a
+    call on a ``HostInput`` measures the boundary call itself, not Python's marshalling."""
+
+    def __init__(self, seqs, abundances, priors, quals):
+        n = len(seqs)
+        self.n = n
+        if n and isinstance(seqs[0], bytes):
+            parts = seqs
+        else:
+            parts = [s.encode("ascii") for s in seqs]
+        self._blob = b"\0".join(parts) + b"\0"
+        lens = np.fromiter((len(x) for x in parts), dtype=np.int64, count=n)
+        off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            np.cumsum(lens[:-1] + 1, out=off[1:])
+        base = np.frombuffer(self._blob, dtype=np.uint8).ctypes.data
+        self._ptrs = (off + base).astype(np.uint64)             # const char *const *
+        self.seqs_p = self._ptrs.ctypes.data if n else None
+        self.ab = np.ascontiguousarray(abundances, dtype=np.int32)
+        self.pr = None if priors is None else np.ascontiguousarray(priors, dtype=np.uint8)
+        self.q = None if quals is None else np.ascontiguousarray(quals, dtype=np.float64)
+        if self.q is not None and self.q.ndim == 2 and self.q.shape[0] != n:
+            raise ValueError("derep$quals matrices must have one row for each derep$unique sequence.")
+        self.qn = 0 if self.q is None else self.q.shape[1]
+
+    @classmethod
+    def from_derep(cls, d: Derep, priors=None):
+        return cls(d.seqs, d.abundances, priors, d.quals)
+
+    @property
+    def nbytes(self):
+        return len(self._blob) + self.ab.nbytes + (0 if self.q is None else self.q.nbytes) + 8 * self.n
+
+
 def _pack(seqs, abundances, priors, quals):
-    n = len(seqs)
-    arr = (C.c_char_p * max(n, 1))(*[s.encode("ascii") for s in seqs])
-    ab = np.ascontiguousarray(abundances, dtype=np.int32)
-    pr = None if priors is None else np.ascontiguousarray(priors, dtype=np.uint8)
-    q = None if quals is None else np.ascontiguousarray(quals, dtype=np.float64)
-    if q is not None and q.ndim == 2 and q.shape[0] != n:
-        raise ValueError("derep$quals matrices must have one row for each derep$unique sequence.")
-    return arr, ab, pr, q, (0 if q is None else q.shape[1])
+    h = seqs if isinstance(seqs, HostInput) else HostInput(seqs, abundances, priors, quals)
+    return h
 
 
 def _err_colmajor(err):
@@ -90,12 +121,12 @@ def dada_uniques(seqs, abundances, priors, err, quals, opts: DadaOpts = None, *,
     [N, maxlen] matrix (NaN past a short read's end); ``err`` is 16 x Q."""
     L = _lib.lib()
     co = _copts(opts, max_clust, multithread, verbose, copts)
-    arr, ab, pr, q, qn = _pack(seqs, abundances, priors, quals)
+    hi = _pack(seqs, abundances, priors, quals)
     e, ncol = _err_colmajor(err)
     eb = C.create_string_buffer(_EB)
     h = C.c_void_p()
-    rc = L.dada2hip_dada_uniques(len(seqs), arr, ab.ctypes.data, pr.ctypes.data if pr is not None else None,
-                                 e.ctypes.data, ncol, q.ctypes.data if q is not None else None, qn, C.byref(co),
+    rc = L.dada2hip_dada_uniques(hi.n, hi.seqs_p, hi.ab.ctypes.data, hi.pr.ctypes.data if hi.pr is not None else None,
+                                 e.ctypes.data, ncol, hi.q.ctypes.data if hi.q is not None else None, hi.qn, C.byref(co),
                                  device, None, C.byref(h), eb, _EB)
     _lib.check(rc, eb)
     try:
@@ -104,19 +135,51 @@ def dada_uniques(seqs, abundances, priors, err, quals, opts: DadaOpts = None, *,
         L.dada2hip_result_free(h)
 
 
+def dada_uniques_multi(inputs, err, opts: DadaOpts = None, *, devices=(0,), copts: COpts = None):
+    """``dada2hip_run_multi``: the per-sample loop of R/dada.R:266 over the GPUs of the node, one host thread per entry
+    of ``devices`` inside the library.  ``inputs``: list of HostInput (or Derep).  Returns list[DadaResult]."""
+    L = _lib.lib()
+    co = _copts(opts, None, False, False, copts)
+    his = [x if isinstance(x, HostInput) else HostInput.from_derep(x) for x in inputs]
+    n = len(his)
+    arr = (_lib.CSampleInput * max(n, 1))()
+    for i, hi in enumerate(his):
+        arr[i].nraw = hi.n
+        arr[i].quals_nrow = hi.qn
+        arr[i].seqs = C.cast(C.c_void_p(hi.seqs_p), C.POINTER(C.c_char_p))
+        arr[i].abundances = hi.ab.ctypes.data
+        arr[i].priors = hi.pr.ctypes.data if hi.pr is not None else None
+        arr[i].quals = hi.q.ctypes.data if hi.q is not None else None
+    e, ncol = _err_colmajor(err)
+    devs = np.ascontiguousarray(devices, dtype=np.int32)
+    outs = (C.c_void_p * max(n, 1))()
+    eb = C.create_string_buffer(_EB)
+    rc = L.dada2hip_run_multi(n, arr, e.ctypes.data, ncol, C.byref(co), devs.size, devs.ctypes.data, outs, eb, _EB)
+    _lib.check(rc, eb)
+    res = []
+    try:
+        for i in range(n):
+            res.append(_collect(L, C.c_void_p(outs[i])))
+    finally:
+        for i in range(n):
+            if outs[i]:
+                L.dada2hip_result_free(C.c_void_p(outs[i]))
+    return res
+
+
 class Sample:
     """Uniques of one sample resident in HBM (dada2hip_sample_*): 2-bit reads, rounded
     qualities and k-mer records are uploaded/built once and reused by every ``run``."""
 
     def __init__(self, seqs, abundances, priors, quals, device: int = 0):
         L = _lib.lib()
-        arr, ab, pr, q, qn = _pack(seqs, abundances, priors, quals)
+        hi = _pack(seqs, abundances, priors, quals)
         eb = C.create_string_buffer(_EB)
         self._h = C.c_void_p()
-        rc = L.dada2hip_sample_create(len(seqs), arr, ab.ctypes.data, pr.ctypes.data if pr is not None else None,
-                                      q.ctypes.data if q is not None else None, qn, device, C.byref(self._h), eb, _EB)
+        rc = L.dada2hip_sample_create(hi.n, hi.seqs_p, hi.ab.ctypes.data, hi.pr.ctypes.data if hi.pr is not None else None,
+                                      hi.q.ctypes.data if hi.q is not None else None, hi.qn, device, C.byref(self._h), eb, _EB)
         _lib.check(rc, eb)
-        self.nraw = len(seqs)
+        self.nraw = hi.n
         self.device = device
 
     @classmethod
@@ -237,7 +300,7 @@ def noqual_errfun(trans, pseudocount=1):
 
 
 def dada(dereps, err=None, *, self_consist=False, err_fun=noqual_errfun, opts: DadaOpts = None, priors=None,
-         device: int = 0, verbose=False, samples=None):
+         device: int = 0, verbose=False, samples=None, timings: list = None, host_input=None):
     """The sample loop and selfConsist loop of R/dada.R:256-405 over resident samples.
 
     ``err_fun`` maps the accumulated 16 x Q transition counts to a new error matrix; the
@@ -248,9 +311,16 @@ def dada(dereps, err=None, *, self_consist=False, err_fun=noqual_errfun, opts: D
     single = isinstance(dereps, Derep)
     if single:
         dereps = [dereps]
+    import time
     own = samples is None
+    t_create = time.perf_counter()
     if own:
-        samples = [Sample.from_derep(d, None if priors is None else priors[i], device) for i, d in enumerate(dereps)]
+        if host_input is not None and single:          # inputs already marshalled (bench.py): one resident sample from them
+            samples = [Sample(host_input, None, None, None, device)]
+        else:
+            samples = [Sample.from_derep(d, None if priors is None else priors[i], device) for i, d in enumerate(dereps)]
+    if timings is not None:
+        timings.append((time.perf_counter() - t_create) * 1e3)   # [0] = making the samples resident (upload), then one entry per pass
     initialize = self_consist and err is None
     nconsist = 0 if initialize else 1
     errs = []
@@ -259,10 +329,13 @@ def dada(dereps, err=None, *, self_consist=False, err_fun=noqual_errfun, opts: D
             if nconsist > 0:
                 errs.append(np.array(err, copy=True))
             results = []
+            t_pass = time.perf_counter()
             for d, smp in zip(dereps, samples):
                 qmax = int(np.ceil(np.nanmax(d.quals)))
                 erri = np.ones((16, max(41, qmax + 1))) if initialize else extend_err(err, qmax)   # R/dada.R:297-313
                 results.append(smp.run(erri, o, max_clust=1 if initialize else None, verbose=verbose))
+            if timings is not None:
+                timings.append((time.perf_counter() - t_pass) * 1e3)
             cur = accumulate_trans([r.subqual for r in results])
             new_err = err_fun(cur) if err_fun is not None else None
             if initialize:

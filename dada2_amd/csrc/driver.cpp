@@ -15,10 +15,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <memory>
+#include <thread>
 #include <unordered_map>
 
 #include "engine.h"
+#include "hostpar.h"
 #include "ppois.h"
 
 namespace d2 {
@@ -35,18 +38,19 @@ static double na_real() {
 struct InputError { std::string msg; };
 struct RuntimeErr { int code; std::string msg; };
 
+// device / pinned buffers; the memory comes from (and returns to) the per-process allocation cache (hostpar.h)
 template <typename T> struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
   DevBuf() {}
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) AllocCache::get().dev_release(p); }
   void alloc(size_t count) {
     if (count <= n && p) return;
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { AllocCache::get().dev_release(p); p = nullptr; }
     n = count;
-    D2_HIP(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
+    D2_HIP(AllocCache::get().dev_alloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
   }
   void zero(hipStream_t st) { D2_HIP(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
 };
@@ -54,12 +58,15 @@ template <typename T> struct DevBuf {
 template <typename T> struct PinBuf {
   T *p = nullptr;
   size_t n = 0;
-  ~PinBuf() { if (p) (void)hipHostFree(p); }
+  PinBuf() {}
+  PinBuf(const PinBuf &) = delete;
+  PinBuf &operator=(const PinBuf &) = delete;
+  ~PinBuf() { if (p) AllocCache::get().pin_release(p); }
   void alloc(size_t count) {
     if (count <= n && p) return;
-    if (p) { (void)hipHostFree(p); p = nullptr; }
+    if (p) { AllocCache::get().pin_release(p); p = nullptr; }
     n = count;
-    D2_HIP(hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+    D2_HIP(AllocCache::get().pin_alloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
   }
 };
 
@@ -76,8 +83,8 @@ struct dada2hip_sample {
   DevBuf<uint32_t> seq2, heavy, reads;
   DevBuf<uint8_t> qual, nheavy, prior;
   DevBuf<uint16_t> kord;
-  DevBuf<int32_t> len;
-  std::vector<std::string> seqs;
+  DevBuf<int32_t> len, nwflag;
+  PinBuf<uint32_t> h_seq2;          // host mirror of the packed sequences (pinned: it is the upload source)
   std::vector<int32_t> h_len;
   std::vector<uint32_t> h_reads;
   std::vector<uint8_t> h_prior;
@@ -114,11 +121,29 @@ namespace {
 
 // Wait for the stream by polling: the per-round decision points (shuffle movers, bud result) sit on
 // the critical path, and a polled wait returns microseconds sooner than a blocking one.
+// DADA2HIP_WAIT=block (or more resident samples / ranks than host cores): sleep between polls instead of spinning.
+static bool wait_blocks() {
+  static const bool b = [] { const char *e = getenv("DADA2HIP_WAIT"); return e && !strcmp(e, "block"); }();
+  return b;
+}
+static double wait_timeout_s() {
+  static const double t = [] { const char *e = getenv("DADA2HIP_WAIT_TIMEOUT_S"); return e ? atof(e) : 600.0; }();
+  return t;
+}
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
 void sync_spin(hipStream_t st) {
-  static const int mode = [] { const char *e = getenv("DADA2HIP_WAIT"); return (e && !strcmp(e, "block")) ? 0 : 1; }();
-  if (mode == 0) { D2_HIP(hipStreamSynchronize(st)); return; }
+  if (wait_blocks()) { D2_HIP(hipStreamSynchronize(st)); return; }
   hipError_t e;
-  while ((e = hipStreamQuery(st)) == hipErrorNotReady) {}
+  const auto t0 = clk::now();
+  for (unsigned spins = 0; (e = hipStreamQuery(st)) == hipErrorNotReady; spins++) {
+    cpu_relax();
+    if ((spins & 0x3FFF) == 0x3FFF && ms_since(t0) > wait_timeout_s() * 1e3)
+      throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: timed out waiting for the device (stream wait)"};
+  }
   if (e != hipSuccess)
     throw d2::DeviceError{DADA2HIP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e) + " (stream wait)"};
 }
@@ -164,31 +189,49 @@ int nw_sentinel(const dada2hip_opts &o) {
 }
 
 // ---- sample creation: validate (Rmain.cpp:52-78), pack, upload, build k-mer records -------------
+// The reference copies its inputs out of the R objects serially (Rmain.cpp:102-120).  At 10^6 uniques x 250 nt the
+// boundary hands over 250 MB of characters and 2 GB of doubles, so the marshalling is spread over the host pool:
+//   pass 1  strlen / abundance / prior per unique                                  (threads)
+//   pass 2  2-bit packing + ACGT validation straight into a pinned buffer          (threads)  -> one async H2D
+//   pass 3  quality rows copied chunk-wise into a ring of pinned staging buffers   (threads)  -> H2D + k_round_quals
+//           per chunk on the side stream, overlapping the next chunk's host copy and the k-mer build on the main stream
+// lite = nwalign / nwvec helper samples: no qualities, no k-mer records, any length >= 1.
 void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, const int32_t *abund,
-                   const uint8_t *priors, const double *quals, int32_t quals_nrow, int device) {
+                   const uint8_t *priors, const double *quals, int32_t quals_nrow, int device, bool lite = false) {
   auto t0 = clk::now();
   if (nraw <= 0) throw InputError{"Zero input sequences."};
   if (!seqs || !abund) throw InputError{"Sequence and abundance vectors had different lengths."};
-  int maxlen = 0, minlen = SEQLEN;
-  s->seqs.resize(nraw);
   s->h_len.resize(nraw);
   s->h_reads.resize(nraw);
   s->h_prior.assign(nraw, 0);
-  for (int i = 0; i < nraw; i++) {
-    s->seqs[i] = seqs[i];
-    int l = (int)s->seqs[i].size();
-    s->h_len[i] = l;
-    maxlen = std::max(maxlen, l);
-    minlen = std::min(minlen, l);
-    s->h_reads[i] = (uint32_t)abund[i];
-    s->total_reads += (uint32_t)abund[i];
-    if (priors) s->h_prior[i] = priors[i] ? 1 : 0;
-  }
+  std::atomic<int> amax{0}, amin{SEQLEN};
+  std::atomic<uint64_t> atot{0};
+  parallel_for((size_t)nraw, 8192, [&](size_t lo, size_t hi) {
+    int mx = 0, mn = SEQLEN;
+    uint64_t tot = 0;
+    for (size_t i = lo; i < hi; i++) {
+      const int l = (int)strnlen(seqs[i], (size_t)SEQLEN + 1);
+      s->h_len[i] = l;
+      mx = std::max(mx, l); mn = std::min(mn, l);
+      s->h_reads[i] = (uint32_t)abund[i];
+      tot += (uint32_t)abund[i];
+      if (priors) s->h_prior[i] = priors[i] ? 1 : 0;
+    }
+    int cur = amax.load();
+    while (mx > cur && !amax.compare_exchange_weak(cur, mx)) {}
+    cur = amin.load();
+    while (mn < cur && !amin.compare_exchange_weak(cur, mn)) {}
+    atot += tot;
+  });
+  const int maxlen = amax.load(), minlen = amin.load();
+  s->total_reads = atot.load();
   if (maxlen >= SEQLEN) throw InputError{"Input sequences exceed the maximum allowed string length."};
-  if (minlen <= KMER_SIZE) throw InputError{"Input sequences must all be longer than the kmer-size (5)."};
-  if (!quals)
-    throw InputError{"dada2hip: a quality matrix is required (the reference reads it unconditionally, src/error.cpp:158)."};
-  if (quals_nrow != maxlen) throw InputError{"Sequence must have associated qualities for each nucleotide position."};
+  if (!lite) {
+    if (minlen <= KMER_SIZE) throw InputError{"Input sequences must all be longer than the kmer-size (5)."};
+    if (!quals)
+      throw InputError{"dada2hip: a quality matrix is required (the reference reads it unconditionally, src/error.cpp:158)."};
+    if (quals_nrow != maxlen) throw InputError{"Sequence must have associated qualities for each nucleotide position."};
+  } else if (minlen < 1) throw InputError{"dada2hip: empty sequence."};
 
   select_device(device);
   s->device = device;
@@ -200,66 +243,137 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
   D.N = nraw; D.maxlen = maxlen; D.minlen = minlen;
   D.W2 = (((maxlen + 15) / 16) + 3) & ~3;
   D.LQ = (maxlen + 15) & ~15;
-  D.LK = (maxlen - KMER_SIZE + 1 + 7) & ~7;
+  D.LK = (std::max(maxlen - KMER_SIZE + 1, 1) + 7) & ~7;
   {   // DADA2HIP_KORD_ALIGN=1: rows of k-mer records padded to 128-B cache lines (the screen's two 256-B reads per row then
       // touch 2 lines each instead of 3).  Measured 2 % on the screen at 1e6 uniques for 3 % more memory: off by default.
     static const bool aligned = [] { const char *e = getenv("DADA2HIP_KORD_ALIGN"); return e && !strcmp(e, "1"); }();
     if (aligned) D.LK = (D.LK + 63) & ~63;
   }
-  D.HMAX = (maxlen - KMER_SIZE + 1) / (RANK_SAT + 1);
+  D.HMAX = std::max(0, (maxlen - KMER_SIZE + 1) / (RANK_SAT + 1));
 
-  // 2-bit packing on the host (validates ACGT: R checks C_isACGT before the call, R/dada.R:269)
-  std::vector<uint32_t> packed((size_t)nraw * D.W2, 0u);
-  for (int i = 0; i < nraw; i++) {
-    const std::string &q = s->seqs[i];
-    uint32_t *row = &packed[(size_t)i * D.W2];
-    for (int p = 0; p < (int)q.size(); p++) {
-      uint32_t c;
-      switch (q[p]) {
-        case 'A': c = 0; break;
-        case 'C': c = 1; break;
-        case 'G': c = 2; break;
-        case 'T': c = 3; break;
-        default: throw InputError{"Invalid derep$uniques vector. Sequences must be made up only of A/C/G/T."};
+  // 2-bit packing on the host pool, straight into pinned memory (validates ACGT: R checks C_isACGT before the call,
+  // R/dada.R:269); the pinned rows stay as the host mirror of the sequences (result strings are decoded from them)
+  s->h_seq2.alloc((size_t)nraw * D.W2);
+  std::atomic<int> bad{0};
+  const int W2 = D.W2;
+  uint32_t *packed = s->h_seq2.p;
+  parallel_for((size_t)nraw, 2048, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      const char *q = seqs[i];
+      uint32_t *row = packed + i * W2;
+      const int l = s->h_len[i];
+      int p = 0;
+      for (int w = 0; w < W2; w++) {
+        uint32_t word = 0;
+        const int e = std::min(l - p, 16);
+        for (int k = 0; k < e; k++, p++) {
+          uint32_t c;
+          switch (q[p]) {
+            case 'A': c = 0; break;
+            case 'C': c = 1; break;
+            case 'G': c = 2; break;
+            case 'T': c = 3; break;
+            default: c = 0; bad.store(1, std::memory_order_relaxed);
+          }
+          word |= c << (k << 1);
+        }
+        row[w] = word;
       }
-      row[p >> 4] |= c << ((p & 15) << 1);
     }
-  }
-  s->seq2.alloc(packed.size());
+  });
+  if (bad.load()) throw InputError{"Invalid derep$uniques vector. Sequences must be made up only of A/C/G/T."};
+  s->seq2.alloc((size_t)nraw * D.W2);
+  s->nwflag.alloc(1);
+  D.nw_flag = s->nwflag.p;
+  D2_HIP(hipMemsetAsync(D.nw_flag, 0, 4, s->stream));
   s->len.alloc(nraw); s->reads.alloc(nraw); s->prior.alloc(nraw); s->nheavy.alloc(nraw);
   s->qual.alloc((size_t)nraw * D.LQ);
-  s->kord.alloc((size_t)nraw * D.LK);
-  s->heavy.alloc((size_t)nraw * std::max(D.HMAX, 1));
   D.seq2 = s->seq2.p; D.len = s->len.p; D.reads = s->reads.p; D.prior = s->prior.p; D.nheavy = s->nheavy.p;
-  D.qual = s->qual.p; D.kord = s->kord.p; D.heavy = s->heavy.p;
-  D2_HIP(hipMemcpyAsync(D.seq2, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, s->stream));
+  D.qual = s->qual.p;
+  D2_HIP(hipMemcpyAsync(D.seq2, packed, (size_t)nraw * D.W2 * 4, hipMemcpyHostToDevice, s->stream));
   D2_HIP(hipMemcpyAsync(D.len, s->h_len.data(), (size_t)nraw * 4, hipMemcpyHostToDevice, s->stream));
   D2_HIP(hipMemcpyAsync(D.reads, s->h_reads.data(), (size_t)nraw * 4, hipMemcpyHostToDevice, s->stream));
   D2_HIP(hipMemcpyAsync(D.prior, s->h_prior.data(), (size_t)nraw, hipMemcpyHostToDevice, s->stream));
+  if (lite) {
+    D2_HIP(hipMemsetAsync(D.qual, 0, (size_t)nraw * D.LQ, s->stream));
+    D2_HIP(hipStreamSynchronize(s->stream));
+    s->qmax = 0;
+    s->ms_upload = ms_since(t0);
+    return;
+  }
+  s->kord.alloc((size_t)nraw * D.LK);
+  s->heavy.alloc((size_t)nraw * std::max(D.HMAX, 1));
+  D.kord = s->kord.p; D.heavy = s->heavy.p;
+  launch_build_kmers(D, s->stream);          // overlaps the quality upload below (side stream)
 
-  // qualities: stream the double matrix through a staging buffer, round on the device
+  // qualities: the R double matrix goes through a ring of pinned staging buffers, rounded on the device
   DevBuf<int32_t> flags;
   flags.alloc(2);
-  flags.zero(s->stream);
+  D2_HIP(hipMemsetAsync(flags.p, 0, 8, s->side));
   {
-    const size_t rows_per = std::max<size_t>(1, (size_t)(256u << 20) / ((size_t)maxlen * 8));
-    DevBuf<double> stage;
-    stage.alloc(std::min<size_t>(rows_per, nraw) * maxlen);
-    for (size_t r0 = 0; r0 < (size_t)nraw; r0 += rows_per) {
-      size_t nr = std::min<size_t>(rows_per, nraw - r0);
-      D2_HIP(hipMemcpyAsync(stage.p, quals + r0 * maxlen, nr * maxlen * 8, hipMemcpyHostToDevice, s->stream));
-      launch_round_quals(stage.p, (int)nr, maxlen, D.len + r0, D.qual + r0 * D.LQ, D.LQ, flags.p, s->stream);
-      D2_HIP(hipStreamSynchronize(s->stream));
+    constexpr int NB = 3;
+    const size_t chunk_bytes = (size_t)32 << 20;
+    const size_t rows_per = std::max<size_t>(1, chunk_bytes / ((size_t)maxlen * 8));
+    const size_t stage_elems = std::min<size_t>(rows_per, nraw) * maxlen;
+    PinBuf<double> hst[NB];
+    DevBuf<double> dst[NB];
+    hipEvent_t ev[NB];
+    const int nb_used = (int)std::min<size_t>(NB, ((size_t)nraw + rows_per - 1) / rows_per);
+    for (int b = 0; b < nb_used; b++) {
+      hst[b].alloc(stage_elems); dst[b].alloc(stage_elems);
+      D2_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
     }
+    // the row lengths are needed by the rounding kernel: they were queued on the main stream
+    D2_HIP(hipEventRecord(s->ev0, s->stream));
+    D2_HIP(hipStreamWaitEvent(s->side, s->ev0, 0));
+    size_t c = 0;
+    try {
+      for (size_t r0 = 0; r0 < (size_t)nraw; r0 += rows_per, c++) {
+        const int b = (int)(c % NB);
+        const size_t nr = std::min<size_t>(rows_per, nraw - r0);
+        if (c >= (size_t)NB) D2_HIP(hipEventSynchronize(ev[b]));   // the kernel that read this pair of buffers is done
+        const double *src = quals + r0 * maxlen;
+        double *dstp = hst[b].p;
+        const size_t total = nr * (size_t)maxlen;
+        parallel_for(total, (size_t)1 << 17, [&](size_t lo, size_t hi) { memcpy(dstp + lo, src + lo, (hi - lo) * 8); });
+        D2_HIP(hipMemcpyAsync(dst[b].p, hst[b].p, total * 8, hipMemcpyHostToDevice, s->side));
+        launch_round_quals(dst[b].p, (int)nr, maxlen, D.len + r0, D.qual + r0 * D.LQ, D.LQ, flags.p, s->side);
+        D2_HIP(hipEventRecord(ev[b], s->side));
+      }
+      D2_HIP(hipStreamSynchronize(s->side));
+    } catch (...) {
+      (void)hipStreamSynchronize(s->side);
+      for (int b = 0; b < nb_used; b++) (void)hipEventDestroy(ev[b]);
+      throw;
+    }
+    for (int b = 0; b < nb_used; b++) (void)hipEventDestroy(ev[b]);
   }
   int32_t hf[2] = {0, 0};
   D2_HIP(hipMemcpy(hf, flags.p, 8, hipMemcpyDeviceToHost));
   if (hf[0]) throw InputError{"Invalid derep$quals matrix. Quality values must be positive integers."};
   s->qmax = hf[1];
-  launch_build_kmers(D, s->stream);
   D2_HIP(hipStreamSynchronize(s->stream));
   D2_HIP(hipGetLastError());
   s->ms_upload = ms_since(t0);
+}
+
+// a traceback that left its bounds (cannot happen with valid pointers; nwalign_endsfree.cpp:185 raises the same way)
+void check_nw_flag(dada2hip_sample *s) {
+  int32_t f = 0;
+  D2_HIP(hipMemcpy(&f, s->D.nw_flag, 4, hipMemcpyDeviceToHost));
+  if (f) {
+    (void)hipMemset(s->D.nw_flag, 0, 4);
+    throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "N-W Align out of range."};
+  }
+}
+
+// sequence of unique i as a string, decoded from the packed host mirror
+std::string seq_string(const dada2hip_sample *s, int i) {
+  const int l = s->h_len[i];
+  std::string out((size_t)l, 'A');
+  const uint32_t *row = s->h_seq2.p + (size_t)i * s->D.W2;
+  for (int p = 0; p < l; p++) out[p] = "ACGT"[(row[p >> 4] >> ((p & 15) << 1)) & 3u];
+  return out;
 }
 
 void ensure_scratch(dada2hip_sample *s, int band) {
@@ -369,18 +483,34 @@ struct Run {
   DevBuf<int32_t> d_pool, d_thresh_one, d_thresh_round;   // zeroed counter pool; k-mer threshold tables
   size_t pool_next = 0;
   static constexpr size_t POOL_INTS = 1 << 18;
-  int ev_round = 0;                             // rounds since the last event-timed one (kernel timing is sampled)
-  double nw_ms_big = 0, nw_ms_sampled = 0, sc_ms_sampled = 0;
-  int nw_n_sampled = 0, sc_n_sampled = 0, n_round_launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> nw_events, screen_events;
-  size_t nw_ev_used = 0, screen_ev_used = 0;
-  std::vector<uint8_t> nw_ev_ok, screen_ev_ok;   // 0 = sample of a speculative round that turned out to be a no-op
+  // ---- kernel timing with HIP events on the run's stream.  Default: sampled (round 0, every 8th round, the final pass)
+  // and extrapolated, because an event pair per kernel per round costs four API calls on an enqueue-bound critical
+  // path.  DADA2HIP_PROFILE=1: every launch of every kernel class is timed (stats.kernel_times_sampled = 0).
+  enum { EV_SCREEN = 0, EV_NW, EV_SHUFFLE, EV_PVAL, EV_BIRTH, EV_FINAL, EV_NCLS };
+  struct EvRec { hipEvent_t a, b; int cls; uint8_t ok, big; };
+  std::vector<EvRec> evs;
+  size_t ev_used = 0;
+  int ev_round = 0;                             // rounds since the last event-timed one
+  int n_round_launches = 0;
+  bool profile_all = false;
   long spec_ev_nw = -1, spec_ev_screen = -1;
-  std::vector<uint64_t> nw_event_cells;
+  int ev_begin(int cls, bool on, bool spec = false, bool big = false) {
+    if (!on) return -1;
+    if (ev_used == evs.size()) {
+      EvRec r{};
+      D2_HIP(hipEventCreate(&r.a));
+      D2_HIP(hipEventCreate(&r.b));
+      evs.push_back(r);
+    }
+    EvRec &r = evs[ev_used];
+    r.cls = cls; r.ok = spec ? 0 : 1; r.big = big ? 1 : 0;
+    D2_HIP(hipEventRecord(r.a, s->stream));
+    return (int)ev_used++;
+  }
+  void ev_end(int idx) { if (idx >= 0) D2_HIP(hipEventRecord(evs[idx].b, s->stream)); }
 
   ~Run() {
-    for (auto &e : nw_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (auto &e : screen_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   }
 
   void logf(const char *fmt, ...) {
@@ -391,16 +521,6 @@ struct Run {
     vsnprintf(buf, sizeof buf, fmt, a);
     va_end(a);
     hooks->log(buf, hooks->user);
-  }
-
-  std::pair<hipEvent_t, hipEvent_t> new_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t &used) {
-    if (used == v.size()) {
-      hipEvent_t a, b;
-      D2_HIP(hipEventCreate(&a));
-      D2_HIP(hipEventCreate(&b));
-      v.push_back({a, b});
-    }
-    return v[used++];
   }
 
   // ---- device state -----------------------------------------------------------------------------
@@ -428,17 +548,16 @@ struct Run {
     D2_HIP(hipMemsetAsync(P.update_e, 0, (size_t)ccap, stq));
     D2_HIP(hipMemsetAsync(P.check_locks, 0, (size_t)ccap, stq));
     bi.clear();
-    nw_ev_used = screen_ev_used = 0;
-    nw_ev_ok.clear(); screen_ev_ok.clear();
-    ev_round = 0; nw_ms_big = nw_ms_sampled = sc_ms_sampled = 0; nw_n_sampled = sc_n_sampled = n_round_launches = 0;
+    ev_used = 0;
+    ev_round = 0; n_round_launches = 0;
+    profile_all = [] { const char *e = getenv("DADA2HIP_PROFILE"); return e && atoi(e) != 0; }();
     D2_HIP(hipMemsetAsync(d_rout.p, 0, 2 * sizeof(RoundOut), stq));
     D2_HIP(hipMemsetAsync(d_next.p, 0xFF, 16, stq));
     ri = 0;
     spec_launched = false;
     publish_pending = false;
     h_rout.p->seq = 0;
-    std::vector<double> em(n, -999.0);                           // containers.cpp:39
-    D2_HIP(hipMemcpyAsync(d_Emin.p, em.data(), n * 8, hipMemcpyHostToDevice, stq));
+    launch_fill_f64(d_Emin.p, n, -999.0, stq);                   // containers.cpp:39
     D2_HIP(hipMemsetAsync(d_clam.p, 0, n * 8, stq));
     D2_HIP(hipMemsetAsync(d_p.p, 0, n * 8, stq));
     D2_HIP(hipMemsetAsync(d_lock.p, 0, n, stq));
@@ -456,7 +575,7 @@ struct Run {
     pool_next = 0;
     D2_HIP(hipMemcpyAsync(d_thresh_one.p, thresh_one.data(), thresh_one.size() * 4, hipMemcpyHostToDevice, stq));
     D2_HIP(hipMemcpyAsync(d_thresh_round.p, thresh_round.data(), thresh_round.size() * 4, hipMemcpyHostToDevice, stq));
-    D2_HIP(hipStreamSynchronize(stq));                           // `em` goes out of scope
+    D2_HIP(hipStreamSynchronize(stq));                           // the threshold vectors may be rebuilt by the next run
   }
 
   void grow_nodes(size_t cap) {
@@ -550,8 +669,8 @@ struct Run {
     pending_store = StoreRound{ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, spec_ctr, s->d_cls.p};
     have_pending_store = true;
     spec_launched = false;
-    if (spec_ev_screen >= 0) screen_ev_ok[spec_ev_screen] = 1;
-    if (spec_ev_nw >= 0) nw_ev_ok[spec_ev_nw] = 1;
+    if (spec_ev_screen >= 0) evs[spec_ev_screen].ok = 1;
+    if (spec_ev_nw >= 0) evs[spec_ev_nw].ok = 1;
     n_round_launches++;
     st.ncompare += (uint64_t)N;
   }
@@ -561,29 +680,17 @@ struct Run {
     auto t0 = clk::now();
     const int32_t *th = (cutoff == 1.0) ? d_thresh_one.p : d_thresh_round.p;
     int32_t *ctr = pool8();
-    // kernel timing with HIP events is sampled (round 0 and every 8th round): an event pair per kernel per round costs
-    // four API calls on a host-enqueue-bound critical path
-    const bool timed = ci == 0 || (ev_round++ % 8) == 0;
-    std::pair<hipEvent_t, hipEvent_t> evs{}, evn{};
-    spec_ev_nw = spec_ev_screen = -1;
-    if (timed) {
-      evs = new_events(screen_events, screen_ev_used);
-      screen_ev_ok.resize(screen_ev_used, 1);
-      if (spec) { screen_ev_ok[screen_ev_used - 1] = 0; spec_ev_screen = (long)screen_ev_used - 1; }
-      D2_HIP(hipEventRecord(evs.first, stq));
-    }
+    const bool timed = profile_all || ci == 0 || (ev_round++ % 8) == 0;
+    const int evs_i = ev_begin(EV_SCREEN, timed, spec);
+    spec_ev_screen = spec ? evs_i : -1;
     launch_screen(D, centre, sp, nullptr, P.lock, o.greedy, th, s->d_cls.p, s->d_lambda.p, s->d_ham.p,
                   s->d_nw_list.p, s->d_gl_list.p, ctr, s->d_ctab.p, /*build_table=*/ci == 0, spec ? d_next.p : nullptr, stq);
-    if (timed) D2_HIP(hipEventRecord(evs.second, stq));
+    ev_end(evs_i);
     // NW batch size is only known on the device: both kernels loop over the device-side count with a
     // fixed persistent grid.  Round 0 aligns every unique (lane-per-alignment kernel), later rounds a few
     // thousand (cooperative kernel).
-    if (timed) {
-      evn = new_events(nw_events, nw_ev_used);
-      nw_ev_ok.resize(nw_ev_used, 1);
-      if (spec) { nw_ev_ok[nw_ev_used - 1] = 0; spec_ev_nw = (long)nw_ev_used - 1; }
-      D2_HIP(hipEventRecord(evn.first, stq));
-    }
+    const int evn_i = ev_begin(EV_NW, timed, spec, /*big=*/ci == 0);
+    spec_ev_nw = spec ? evn_i : -1;
     const char *f = getenv("DADA2HIP_NW_KERNEL");
     const bool coop_ok = nw_ad_lds_bytes(D, ap) > 0 && nw_ad_lds_bytes(D, ap) <= 150 * 1024;
     bool coop = coop_ok && (ci != 0 || N < COOP_MAX_BATCH);
@@ -603,15 +710,20 @@ struct Run {
         ensure_adw_scratch(s, ap);
         launch_nw_adw(D, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr_adw.p, s->scr_adw_wpw,
                       s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, nullptr, 0, 0, stq);
-      } else
+      } else {
+        ensure_scratch(s, ap.band);
         launch_nw(D, wclass, centre, nullptr, s->d_nw_list.p, ctr, 0, ap, s->d_err.p, s->scr, s->d_lambda.p,
                   s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
+      }
     }
-    if (timed) D2_HIP(hipEventRecord(evn.second, stq));
+    ev_end(evn_i);
     if (spec) { spec_ctr = ctr; spec_launched = true; st.ms_screen += ms_since(t0); return; }
-    if (ci == 0)   // round 0 is followed by b_p_update directly (Rmain.cpp:309-311)
+    if (ci == 0) {   // round 0 is followed by b_p_update directly (Rmain.cpp:309-311)
+      const int ev = ev_begin(EV_SHUFFLE, profile_all);
       launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p,
                    ro()->cnt, stq);
+      ev_end(ev);
+    }
     else {         // later rounds: the store filter rides in front of the round's first shuffle
       pending_store = StoreRound{ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p};
       have_pending_store = true;
@@ -663,8 +775,10 @@ struct Run {
     RoundOut *ro = this->ro();
     if (!snap_fresh)
       D2_HIP(hipMemcpyAsync(d_creads_snap.p, P.creads, (size_t)nclust_dev * 4, hipMemcpyDeviceToDevice, stq));
+    const int ev = ev_begin(EV_SHUFFLE, profile_all);
     launch_shuffle(P, s->D, d_creads_snap.p, d_movers.p + (size_t)slot * 3 * N, ro->cnt + slot, ro->mov[slot],
                    have_pending_store ? &pending_store : nullptr, 0, nclust_dev, stq);
+    ev_end(ev);
     have_pending_store = false;
     snap_fresh = false;
     st.nshuffle++;
@@ -679,11 +793,19 @@ struct Run {
       // kernels of the next round keep the stream busy meanwhile); look at the stream now and then so that a device
       // fault cannot leave us spinning
       volatile int32_t *seqp = &h_rout.p->seq;
+      const auto tw = clk::now();
+      const bool polite = wait_blocks();
       for (unsigned spins = 0; *seqp != publish_seq; spins++) {
-        if ((spins & 0xFFFF) == 0xFFFF) {
+        cpu_relax();
+        if (polite && spins > 64) { struct timespec ts{0, 20000}; nanosleep(&ts, nullptr); }
+        if ((spins & 0xFFFF) == 0xFFFF || (polite && (spins & 0xFF) == 0xFF)) {
           hipError_t e = hipStreamQuery(s->stream);
           if (e != hipSuccess && e != hipErrorNotReady)
             throw d2::DeviceError{DADA2HIP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e) + " (round result)"};
+          if (e == hipSuccess && *seqp != publish_seq)     // the stream drained and the block never came
+            throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: the device did not publish the round result"};
+          if (ms_since(tw) > wait_timeout_s() * 1e3)
+            throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: timed out waiting for the round result"};
         }
       }
       std::atomic_thread_fence(std::memory_order_acquire);
@@ -717,16 +839,19 @@ struct Run {
   // the host's decision (the host confirms it afterwards from the same result block).
   int max_clust_run = 0;
   void enqueue_pupdate_bud(int32_t *check_cnt) {
-    BudParams bp{o.min_fold, o.min_hamming, o.min_abund};
-    static const bool no_auto = getenv("DADA2HIP_NO_AUTOBIRTH") != nullptr || getenv("DADA2HIP_NO_SPECULATION") != nullptr;
+    BudParams bp{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
     const bool autob = !no_auto && rounds_use_coop() && nclust_dev < max_clust_run;
     if (autob && nclust_dev + 1 >= ccap) grow_clusters(std::max(ccap * 2, nclust_dev + 2));   // before anything is enqueued
+    int ev = ev_begin(EV_PVAL, profile_all);
     launch_pupdate_bud(P, s->D, o.greedy, o.detect_singletons, bp, 1.0, s->h_reads[bi[0].center], d_partial.p, &ro()->bud,
                        d_ties0.p, d_ties1.p, nclust_dev, d_lock_tmp.p, check_cnt, s->stream);
+    ev_end(ev);
     if (!autob) return;
     publish_seq = (publish_seq % 0x3FFFFFFF) + 1;
+    ev = ev_begin(EV_BIRTH, profile_all);
     launch_auto_birth(P, s->D, d_creads_snap.p, ro(), o.omegaA, nclust_dev, s->d_ctab.p, ro_next()->cnt, d_next.p, h_rout.p,
                       publish_seq, s->stream);
+    ev_end(ev);
     publish_pending = true;
     compare_round(nclust_dev, -1, o.kdist_cutoff, /*spec=*/true);
   }
@@ -738,14 +863,18 @@ struct Run {
   // shuffle still moved something, and the host then continues shuffling exactly as the reference would.
   // On return h_rout holds a valid bud evaluation; moves not yet replayed on the host are described by
   // pending_slot (the caller replays them after it has launched the next round).
+  // plain: one shuffle per host round trip, every evaluation enqueued after the host mirror (and slot0[]) is current.
+  // Forced by DADA2HIP_NO_SPECULATION and whenever partition 0's first slot is not its centre (input that is not
+  // abundance-sorted): b_bud's "slot 0 is the centre" quirk (cluster.cpp:285) then depends on the slot order, which only
+  // the host maintains, so nothing may be evaluated ahead of the host's replay.
+  bool plain = false, no_auto = false;
   int pending_slot = -1;   // list slot of the last real shuffle whose moves the host has not replayed yet
   std::vector<int32_t> prev_inline;
   void round_tail(bool do_shuffle) {
     auto t0 = clk::now();
     int nsh = 0;
     int32_t *guard = nullptr;
-    static const bool no_spec = getenv("DADA2HIP_NO_SPECULATION") != nullptr;   // test knob: the reference's plain loop
-    if (do_shuffle && no_spec) {
+    if (do_shuffle && plain) {                          // the reference's plain loop (test knob, and unsorted input)
       bool shuffled = true;
       while (shuffled && nsh < MAX_SHUFFLE) {
         D2_HIP(hipMemsetAsync(ro()->cnt, 0, 8, s->stream));
@@ -816,18 +945,32 @@ struct Run {
     st.ms_bookkeep += ms_since(t0);
   }
 
-  void push_slot0() {   // only reachable when a slot-0 unique is not its partition's centre (unsorted input)
+  void push_slot0() {   // only reachable when a slot-0 unique is not its partition's centre (unsorted input: plain mode)
     std::vector<uint8_t> f(N, 0);
     for (auto &b : bi) if (!b.raw.empty()) f[b.raw[0]] = 1;
-    D2_HIP(hipMemcpy(P.slot0, f.data(), (size_t)N, hipMemcpyHostToDevice));
+    D2_HIP(hipMemcpyAsync(P.slot0, f.data(), (size_t)N, hipMemcpyHostToDevice, s->stream));   // ordered with the evaluations
+    D2_HIP(hipStreamSynchronize(s->stream));                                                    // `f` is a local
   }
 
   // ---- b_bud (cluster.cpp:274-350): device arg-min, host tie-break in (partition, slot) order ------
   struct Birth { bool yes = false; char type = 'A'; BudTie c{}; double pval = 0; int newi = 0; };
 
-  // Decide from the fetched evaluation.  With a single best candidate (the normal case) everything needed comes
-  // from the device (its partition, that partition's reads), so the next round can be launched before the host
-  // mirror is brought up to date; exact (p, reads) ties need the host's slot order and force the replay first.
+  // get_pA (pval.cpp:67-89) on the host, i.e. with the CPU reference's libm
+  double host_get_pA(const BudTie &t) const {
+    const uint32_t reads = s->h_reads[t.raw];
+    const bool prior = s->h_prior[t.raw] != 0;
+    if (reads == 1 && !prior && !o.detect_singletons) return 1.;
+    if (t.comp_ham == 0) return 1.;
+    if (t.comp_lam == 0) return 0.;
+    return pp::calc_pA((int)reads, t.comp_lam * t.from_reads, prior || o.detect_singletons);
+  }
+
+  // Decide from the fetched evaluation.  The device lists the exact ties of its best key and every candidate whose
+  // p-value is within BUD_NEAR of it (engine.h).  With a single listed candidate (the normal case) everything needed
+  // comes from the device, so the next round can be launched before the host mirror is brought up to date.  With
+  // several, the host recomputes their p-values with its own libm and applies b_bud's rule itself (cluster.cpp:284-308:
+  // p ascending, reads descending, first in (partition, slot) scan order), which needs the slot order to be current.
+  // The birth p-value reported is always the host's (bit-identical to the CPU reference given the same pgamma source).
   Birth decide_bud() {
     const BudOut &h = h_rout.p->bud;
     if (!h.valid) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: bud evaluation not valid"};
@@ -835,40 +978,58 @@ struct Run {
     st.nstored = (uint64_t)h.node_count;
     if ((size_t)h.node_count + (size_t)N > (size_t)P.node_cap)
       grow_nodes(std::max((size_t)P.node_cap * 2, (size_t)h.node_count + 2 * (size_t)N));
-    // first tied candidate in scan order (partition ascending, slot ascending)
-    auto pick = [&](int track, BudTie &out) -> bool {
+    auto pick = [&](int track, BudTie &out, double &p_out) -> bool {
       const int n = h.nties[track];
       if (!h.found[track] || n <= 0) return false;
-      if (n == 1) { out = h.ties[track][0]; return true; }
-      replay_pending();                                   // slot order must be current
-      auto before = [&](int a, int b) { return clust_of[a] < clust_of[b] || (clust_of[a] == clust_of[b] && slot_of[a] < slot_of[b]); };
-      if (n <= BUD_TIES) {
-        int bk = 0;
-        for (int k = 1; k < n; k++) if (before(h.ties[track][k].raw, h.ties[track][bk].raw)) bk = k;
-        out = h.ties[track][bk];
-        return true;
+      if (n == 1) { out = h.ties[track][0]; p_out = host_get_pA(out); return true; }
+      replay_pending();                                   // slot order and partition reads must be current
+      std::vector<BudTie> cand;
+      if (n <= BUD_TIES) cand.assign(h.ties[track], h.ties[track] + n);
+      else {   // long list (e.g. many p == 0 with equal reads): fetch it and the fields of its members
+        std::vector<int32_t> t(n);
+        sync_spin(s->stream);
+        D2_HIP(hipMemcpy(t.data(), track ? d_ties1.p : d_ties0.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::vector<double> lam(N);
+        std::vector<uint32_t> ham(N);
+        std::vector<int32_t> ci(N);
+        D2_HIP(hipMemcpy(lam.data(), P.comp_lam, (size_t)N * 8, hipMemcpyDeviceToHost));
+        D2_HIP(hipMemcpy(ham.data(), P.comp_ham, (size_t)N * 4, hipMemcpyDeviceToHost));
+        D2_HIP(hipMemcpy(ci.data(), P.comp_i, (size_t)N * 4, hipMemcpyDeviceToHost));
+        cand.resize(n);
+        for (int k = 0; k < n; k++) {
+          BudTie &c = cand[k];
+          c.raw = t[k]; c.from = clust_of[t[k]]; c.from_reads = bi[c.from].reads;
+          c.comp_i = ci[t[k]]; c.comp_lam = lam[t[k]]; c.comp_ham = ham[t[k]]; c.p = 0; c.pad = 0;
+        }
       }
-      std::vector<int32_t> t(n);   // mass tie (e.g. many p == 0 with equal reads): fetch the full list
-      D2_HIP(hipMemcpy(t.data(), track ? d_ties1.p : d_ties0.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-      int best = t[0];
-      for (int k = 1; k < n; k++) if (before(t[k], best)) best = t[k];
-      out.raw = best;
-      out.from = clust_of[best];
-      out.from_reads = bi[out.from].reads;
-      D2_HIP(hipMemcpy(&out.comp_i, P.comp_i + best, 4, hipMemcpyDeviceToHost));
-      D2_HIP(hipMemcpy(&out.comp_lam, P.comp_lam + best, 8, hipMemcpyDeviceToHost));
-      D2_HIP(hipMemcpy(&out.comp_ham, P.comp_ham + best, 4, hipMemcpyDeviceToHost));
+      auto before = [&](int a, int b) { return clust_of[a] < clust_of[b] || (clust_of[a] == clust_of[b] && slot_of[a] < slot_of[b]); };
+      int bk = -1;
+      double bp = 0;
+      for (int k = 0; k < n; k++) {
+        const double pk = host_get_pA(cand[k]);
+        const uint32_t rk = s->h_reads[cand[k].raw];
+        bool better = bk < 0;
+        if (!better) {
+          const uint32_t rb = s->h_reads[cand[bk].raw];
+          better = pk < bp || (pk == bp && (rk > rb || (rk == rb && before(cand[k].raw, cand[bk].raw))));
+        }
+        if (better) { bk = k; bp = pk; }
+      }
+      out = cand[bk];
+      p_out = bp;
       return true;
     };
     Birth b;
     BudTie c;
-    const bool have = pick(0, c);
-    const double pA = (have ? h.best_p[0] : 1.0) * N;               // minraw stays the cluster-0 centre (p = 1) otherwise
+    double p0 = 1.0;
+    const bool have = pick(0, c, p0);
+    const double pA = (have ? p0 : 1.0) * N;                        // minraw stays the cluster-0 centre (p = 1) otherwise
     if (pA < o.omegaA && have) { b.yes = true; b.type = 'A'; b.c = c; b.pval = pA; }
     else {
       BudTie cp;
-      const bool havep = pick(1, cp);
-      const double pP = havep ? h.best_p[1] : 1.0;
+      double p1 = 1.0;
+      const bool havep = pick(1, cp, p1);
+      const double pP = havep ? p1 : 1.0;
       if (pP < o.omegaP && havep) { b.yes = true; b.type = 'P'; b.c = cp; b.pval = pP; }
     }
     if (b.yes) b.newi = nclust_dev;
@@ -879,8 +1040,10 @@ struct Run {
   void launch_birth(const Birth &b) {
     const int raw = b.c.raw;
     if (b.newi >= ccap) grow_clusters(std::max(ccap * 2, b.newi + 1));
+    const int ev = ev_begin(EV_BIRTH, profile_all);
     launch_apply_bud(P, s->D, d_creads_snap.p, raw, b.newi, b.c.from, s->h_reads[raw], b.c.from_reads - s->h_reads[raw],
                      s->d_ctab.p, ro_next()->cnt, s->stream);
+    ev_end(ev);
     nclust_dev = b.newi + 1;
     snap_fresh = true;                                   // k_apply_bud rewrote the whole snapshot
     ri ^= 1;
@@ -960,7 +1123,8 @@ void check_opts(const dada2hip_opts &o, int qmax, int ncol) {
     throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED,
                      "dada2hip: HOMOPOLYMER_GAP_PENALTY != GAP_PENALTY (nwalign_endsfree_homo) is outside the implemented path."};
   if (ncol < 1) throw InputError{"Error matrix must have 16 rows."};
-  if (o.use_quals && qmax > ncol - 1) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "Rounded quality exceeded range of err lookup table."};
+  // (checked whatever USE_QUALS says: the output tables index err's columns by quality, error.cpp:152-167)
+  if (qmax > ncol - 1) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "Rounded quality exceeded range of err lookup table."};
 }
 
 void init_run(Run &run, dada2hip_sample *s, const double *err, int err_ncol, const dada2hip_opts *opts, double cutoff) {
@@ -968,8 +1132,7 @@ void init_run(Run &run, dada2hip_sample *s, const double *err, int err_ncol, con
   memset(&run.st, 0, sizeof run.st);
   upload_err(s, err, err_ncol, run.err_rowmajor);
   alloc_round_buffers(s);
-  ensure_scratch(s, opts->band_size);
-  run.wclass = s->scr_class;
+  run.wclass = nw_class(opts->band_size, s->D.maxlen, s->D.minlen);   // (the lane kernel's scratch ring is allocated on first use)
   run.ap = AlignParams{opts->match, opts->mismatch, opts->gap, opts->band_size, nw_sentinel(*opts), opts->use_quals, err_ncol};
   run.sp = ScreenParams{opts->use_kmers, opts->gapless, opts->band_size, opts->SSE};
   run.thresh_round = make_thresh(s->D.maxlen, cutoff);
@@ -1007,6 +1170,8 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       b0.reads += s->h_reads[i];
       if (s->h_reads[i] > mx) { b0.center = (uint32_t)i; mx = s->h_reads[i]; }
     }
+    run.plain = getenv("DADA2HIP_NO_SPECULATION") != nullptr || b0.raw[0] != b0.center;
+    run.no_auto = run.plain || getenv("DADA2HIP_NO_AUTOBIRTH") != nullptr;
     const uint8_t one = 1;
     D2_HIP(hipMemcpy(run.P.slot0, &one, 1, hipMemcpyHostToDevice));   // unique 0 sits in slot 0 of partition 0
     run.push_cluster(0, true, true);
@@ -1084,22 +1249,23 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
                    s->d_ham.p, s->d_view.p, LV, 0, stq);
     run.st.ngapless += (uint64_t)N;
   } else {
-    auto evn = run.new_events(run.nw_events, run.nw_ev_used);
-    run.nw_ev_ok.resize(run.nw_ev_used, 1);
-    D2_HIP(hipEventRecord(evn.first, stq));
+    const int evn_i = run.ev_begin(Run::EV_NW, true, false, /*big=*/true);
     if (coop_fin)
       launch_nw_ad(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), nullptr, nullptr, run.ap, s->d_err.p,
                    s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, stq);
     else if (wide_fin)
       launch_nw_adw(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr_adw.p,
                     s->scr_adw_wpw, s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, stq);
-    else
+    else {
+      ensure_scratch(s, run.ap.band);
       launch_nw(D, run.wclass, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->scr,
                 s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, 0, nullptr, stq);
-    D2_HIP(hipEventRecord(evn.second, stq));
+    }
+    run.ev_end(evn_i);
     run.st.nnw += (uint64_t)N;
   }
   // final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252), on the device
+  const int ev_fin = run.ev_begin(Run::EV_FINAL, run.profile_all);
   launch_final_p(run.P, D, opts->omegaC, s->d_correct.p, stq);
   std::vector<uint8_t> correct(N);
   R->pval.assign(N, 0.0);
@@ -1110,6 +1276,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   D2_HIP(hipMemsetAsync(s->d_qn.p, 0, (size_t)C * D.maxlen * 4, stq));
   launch_final_tables(D, s->d_view.p, LV, s->d_work.p, (int)work.size(), run.P.clust_of, run.P.centre_of, s->d_correct.p, err_ncol, 1,
                       s->d_trans.p, s->d_qsum.p, s->d_qn.p, s->d_nsubs.p, C, stq);
+  run.ev_end(ev_fin);
   std::vector<int32_t> nsubs(N);
   std::vector<unsigned long long> qsum((size_t)C * D.maxlen);
   std::vector<uint32_t> qn((size_t)C * D.maxlen);
@@ -1184,9 +1351,11 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     else if (n_nw && wide_fin)
       launch_nw_adw(D, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), run.ap, s->d_err.p, s->scr_adw.p, s->scr_adw_wpw,
                     s->scr_adw_waves, s->d_lambda.p, s->d_ham.p, s->d_view_b.p, LV, 1, stq);
-    else if (n_nw)
+    else if (n_nw) {
+      ensure_scratch(s, run.ap.band);
       launch_nw(D, run.wclass, 0, d_bcc.p, d_wnw.p, nullptr, (int)w_nw.size(), run.ap, s->d_err.p, s->scr, s->d_lambda.p,
                 s->d_ham.p, s->d_view_b.p, LV, 1, nullptr, 0, nullptr, stq);
+    }
     D2_HIP(hipMemcpyAsync(&bview[(size_t)LV], s->d_view_b.p, (size_t)nb * LV * 2, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
     run.st.ngapless += (uint64_t)n_gl;
@@ -1200,31 +1369,42 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     D2_HIP(hipMemcpy(&ef, run.P.err_flag, 4, hipMemcpyDeviceToHost));
     D2_HIP(hipMemcpy(tot, run.P.totals, 32, hipMemcpyDeviceToHost));
     run.check_errflag(ef);
+    check_nw_flag(s);
     run.st.nnw += tot[0]; run.st.ngapless += tot[1]; run.st.nshroud = tot[2]; run.st.nskipped = tot[3];
     int32_t cnt = 0;
     D2_HIP(hipMemcpy(&cnt, run.P.node_count, 4, hipMemcpyDeviceToHost));
     run.st.nstored = (uint64_t)cnt;
-    // kernel times: event-timed launches (round 0, every 8th round, the final pass) extrapolated to all launches
+    // kernel times: event-timed launches, summed per kernel class.  Sampled mode: the per-round NW and screen launches
+    // are extrapolated from the sampled ones; DADA2HIP_PROFILE=1: every launch was timed, the sums are exact.
     float ems;
+    double cls_ms[Run::EV_NCLS] = {0, 0, 0, 0, 0, 0};
     double nw_big = 0, nw_small = 0, sc_sum = 0;
-    int n_small = 0;
-    int n_sc = 0;
-    for (size_t k = 0; k < run.nw_ev_used; k++) {
-      if (!run.nw_ev_ok[k]) continue;                                  // speculative launch that found nothing to do
-      D2_HIP(hipEventElapsedTime(&ems, run.nw_events[k].first, run.nw_events[k].second));
-      if (k == 0 || k + 1 == run.nw_ev_used) nw_big += ems;           // round 0 and the final pass (every unique aligned)
-      else { nw_small += ems; n_small++; }
-    }
-    for (size_t k = 0; k < run.screen_ev_used; k++) {
-      if (!run.screen_ev_ok[k]) continue;
-      D2_HIP(hipEventElapsedTime(&ems, run.screen_events[k].first, run.screen_events[k].second));
-      sc_sum += ems; n_sc++;
+    int n_small = 0, n_sc = 0, n_big = 0;
+    for (size_t k = 0; k < run.ev_used; k++) {
+      const Run::EvRec &e = run.evs[k];
+      if (!e.ok) continue;                                             // speculative launch that found nothing to do
+      D2_HIP(hipEventElapsedTime(&ems, e.a, e.b));
+      cls_ms[e.cls] += ems;
+      if (e.cls == Run::EV_NW) { if (e.big) { nw_big += ems; n_big++; } else { nw_small += ems; n_small++; } }
+      if (e.cls == Run::EV_SCREEN) { sc_sum += ems; n_sc++; }
     }
     const int rounds = run.n_round_launches;
-    run.st.nw_kernel_ms = nw_big + (n_small ? nw_small / n_small * (rounds - 1) : 0.0);
-    run.st.nw_kernel_launches = (uint64_t)rounds + 1;
-    run.st.screen_kernel_ms = n_sc ? sc_sum / n_sc * rounds : 0.0;
-    run.st.screen_kernel_launches = (uint64_t)rounds;
+    if (run.profile_all) {
+      run.st.nw_kernel_ms = nw_big + nw_small;
+      run.st.nw_kernel_launches = (uint64_t)(n_big + n_small);
+      run.st.screen_kernel_ms = sc_sum;
+      run.st.screen_kernel_launches = (uint64_t)n_sc;
+      run.st.kernel_times_sampled = 0;
+      run.st.dev_ms_screen = cls_ms[Run::EV_SCREEN]; run.st.dev_ms_nw = cls_ms[Run::EV_NW];
+      run.st.dev_ms_shuffle = cls_ms[Run::EV_SHUFFLE]; run.st.dev_ms_pval = cls_ms[Run::EV_PVAL];
+      run.st.dev_ms_birth = cls_ms[Run::EV_BIRTH]; run.st.dev_ms_final = cls_ms[Run::EV_FINAL];
+    } else {
+      run.st.nw_kernel_ms = nw_big + (n_small ? nw_small / n_small * (rounds - 1) : 0.0);
+      run.st.nw_kernel_launches = (uint64_t)rounds + 1;
+      run.st.screen_kernel_ms = n_sc ? sc_sum / n_sc * rounds : 0.0;
+      run.st.screen_kernel_launches = (uint64_t)rounds;
+      run.st.kernel_times_sampled = 1;
+    }
     run.st.nw_cells = run.st.nnw * run.nw_cells_per_alignment();
   }
 
@@ -1239,7 +1419,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     uint32_t max_reads = 0;
     int max_raw = -1;
     for (uint32_t raw : b.raw) if (s->h_reads[raw] > max_reads) { max_raw = (int)raw; max_reads = s->h_reads[raw]; }
-    R->sequence[i] = max_raw >= 0 ? s->seqs[max_raw] : std::string("");
+    R->sequence[i] = max_raw >= 0 ? seq_string(s, max_raw) : std::string("");
     R->center[i] = (int32_t)b.center;
     for (uint32_t raw : b.raw) {
       if (!correct[raw]) continue;
@@ -1270,7 +1450,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   // birth_subs data.frame (error.cpp:261-300) + birth_qave (error.cpp:83-92)
   for (int i = 1; i < C; i++) {
     const uint32_t pc = run.bi[run.bi[i].birth_comp.i].center;
-    const std::string &cs = s->seqs[pc];
+    const std::string cs = seq_string(s, (int)pc);
     double q_ave = 0.0;
     int nsb = 0;
     for (int p0 = 0; p0 < (int)cs.size(); p0++) {
@@ -1366,6 +1546,51 @@ int dada2hip_dada_uniques(int32_t nraw, const char *const *seqs, const int32_t *
   return rc;
 }
 
+// ---- batch form: the sample loop of R/dada.R:266-366 spread over the GPUs of the node ------------------------
+// One host thread per entry of device_ids (the same ordinal may appear twice: two streams of samples on one GPU);
+// thread t runs samples t, t + n_devices, ... in order.  Samples are independent given err, so there is
+// no exchange between the threads; the caller sums the $subqual matrices afterwards (accumulateTrans,
+// R/errorModels.R:462-471).
+int dada2hip_run_multi(int32_t n_samples, const dada2hip_sample_input *samples, const double *err, int32_t err_ncol,
+                       const dada2hip_opts *opts, int32_t n_devices, const int32_t *device_ids, dada2hip_result **out,
+                       char *errbuf, size_t errlen) {
+  if (n_samples < 0 || (n_samples > 0 && (!samples || !out))) { set_err(errbuf, errlen, "dada2hip: bad sample list"); return DADA2HIP_ERR_INPUT; }
+  for (int i = 0; i < n_samples; i++) out[i] = nullptr;
+  if (n_samples == 0) return DADA2HIP_OK;
+  const int32_t dev0 = 0;
+  if (n_devices <= 0 || !device_ids) { n_devices = 1; device_ids = &dev0; }
+  const int nthr = std::min(n_devices, n_samples);
+  std::vector<int> rcs(n_samples, DADA2HIP_OK);
+  std::vector<std::string> msgs(n_samples);
+  std::atomic<int> failed{0};
+  auto worker = [&](int t) {
+    for (int i = t; i < n_samples; i += nthr) {
+      if (failed.load()) return;                        // one sample failed: R would have stopped the whole call
+      char eb[1024];
+      eb[0] = 0;
+      const dada2hip_sample_input &in = samples[i];
+      rcs[i] = dada2hip_dada_uniques(in.nraw, in.seqs, in.abundances, in.priors, err, err_ncol, in.quals, in.quals_nrow,
+                                     opts, device_ids[t], nullptr, &out[i], eb, sizeof eb);
+      if (rcs[i] != DADA2HIP_OK) { msgs[i] = eb; failed.store(1); }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthr; t++) th.emplace_back(worker, t);
+  worker(0);
+  for (auto &x : th) x.join();
+  for (int i = 0; i < n_samples; i++)
+    if (rcs[i] != DADA2HIP_OK) {
+      char m[1200];
+      snprintf(m, sizeof m, "sample %d: %s", i + 1, msgs[i].c_str());
+      set_err(errbuf, errlen, m);
+      for (int k = 0; k < n_samples; k++) { if (out[k]) dada2hip_result_free(out[k]); out[k] = nullptr; }
+      return rcs[i];
+    }
+  return DADA2HIP_OK;
+}
+
+void dada2hip_trim_cache(void) { AllocCache::get().trim(); }
+
 int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *err, int32_t err_ncol,
                             const dada2hip_opts *opts, double kdist_cutoff, const uint8_t *skip, double *lambda,
                             uint32_t *hamming, uint8_t *cls, dada2hip_stats *stats, char *errbuf, size_t errlen) {
@@ -1411,9 +1636,11 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
       if (coop)
         launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
                      s->d_ham.p, nullptr, 0, 0, nullptr, stq);
-      else
+      else {
+        ensure_scratch(s, run.ap.band);
         launch_nw(D, run.wclass, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, run.ap, s->d_err.p, s->scr, s->d_lambda.p,
                   s->d_ham.p, nullptr, 0, 0, nullptr, 0, nullptr, stq);
+      }
       D2_HIP(hipEventRecord(s->ev1, stq));
       D2_HIP(hipStreamSynchronize(stq));
       D2_HIP(hipEventElapsedTime(&ems, s->ev0, s->ev1));
@@ -1423,6 +1650,7 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
     }
     launch_fill_null(N, s->d_cls.p, s->d_lambda.p, s->d_ham.p, stq);
     D2_HIP(hipStreamSynchronize(stq));
+    check_nw_flag(s);
     if (lambda) D2_HIP(hipMemcpy(lambda, s->d_lambda.p, (size_t)N * 8, hipMemcpyDeviceToHost));
     if (hamming) D2_HIP(hipMemcpy(hamming, s->d_ham.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     if (cls) D2_HIP(hipMemcpy(cls, s->d_cls.p, (size_t)N, hipMemcpyDeviceToHost));
@@ -1464,10 +1692,15 @@ int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int3
       seqs[2 * i] = s1[i]; seqs[2 * i + 1] = s2[i];
       maxlen = std::max<int>(maxlen, (int)std::max(strlen(s1[i]), strlen(s2[i])));
     }
-    std::vector<double> q((size_t)2 * n * maxlen, 0.0);
+    // helper sample without qualities / k-mer records / length checks (C_nwvec accepts any strings; only A/C/G/T can
+    // be represented in the 2-bit rows, anything else is reported as the real limitation)
+    for (int i = 0; i < 2 * n; i++)
+      for (const char *c = seqs[i]; *c; c++)
+        if (*c != 'A' && *c != 'C' && *c != 'G' && *c != 'T')
+          throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: nwalign on the device takes A/C/G/T only (N and IUPAC codes are not representable in 2 bits)."};
     dada2hip_sample *s = new dada2hip_sample();
     std::unique_ptr<dada2hip_sample, void (*)(dada2hip_sample *)> guard(s, dada2hip_sample_free);
-    sample_create(s, 2 * n, seqs.data(), ab.data(), nullptr, q.data(), maxlen, device);
+    sample_create(s, 2 * n, seqs.data(), ab.data(), nullptr, nullptr, 0, device, /*lite=*/true);
     ensure_scratch(s, band);
     std::vector<double> errm(16, 1.0), rowm;
     upload_err(s, errm.data(), 1, rowm);
@@ -1491,6 +1724,7 @@ int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int3
     D2_HIP(hipMemcpyAsync(nm.data(), s->d_nmoves.p, nm.size() * 4, hipMemcpyDeviceToHost, s->stream));
     D2_HIP(hipStreamSynchronize(s->stream));
     D2_HIP(hipGetLastError());
+    check_nw_flag(s);
     for (int i = 0; i < n; i++) {
       const uint8_t *mv = &moves[(size_t)i * 64 * stride];
       const int len = nm[(size_t)i * 64];

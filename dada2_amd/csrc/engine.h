@@ -51,6 +51,7 @@ struct SampleDev {
   int32_t *len = nullptr;     // [N]
   uint32_t *reads = nullptr;  // [N]
   uint8_t *prior = nullptr;   // [N]
+  int32_t *nw_flag = nullptr; // [1] set by the NW kernels when a traceback leaves its bounds (never silently wrong)
 };
 
 struct AlignParams {
@@ -88,10 +89,11 @@ struct PartState {
 };
 
 struct BudParams {
-  double min_fold;
+  double min_fold, omegaA, omegaP;
   int32_t min_hamming, min_abund;
 };
 
+void launch_fill_f64(double *d_p, size_t n, double v, hipStream_t st);
 void launch_fill_null(int n, const uint8_t *d_cls, double *d_lam, uint32_t *d_ham, hipStream_t st);
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,
                   const uint32_t *d_ham, const int32_t *d_round_counters, const uint8_t *d_cls, int32_t *d_zero2, hipStream_t st);
@@ -109,7 +111,12 @@ void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_cr
                     int32_t *d_nmovers, int32_t *d_inline, const StoreRound *store, int check_only, int nclust, hipStream_t st);
 // result block of one b_bud evaluation, fetched by the host in a single copy
 constexpr int BUD_TIES = 16;
-struct BudTie { int32_t raw, comp_i; uint32_t comp_ham; int32_t from; uint32_t from_reads, pad; double comp_lam; };
+struct BudTie { int32_t raw, comp_i; uint32_t comp_ham; int32_t from; uint32_t from_reads, pad; double comp_lam; double p; };
+// Candidates listed by k_bud_ties: the exact (p, reads) ties of the device's best key AND every other candidate whose
+// device p-value lies within BUD_NEAR (relative) of the best one.  Device and host libm differ in the last ulp of
+// exp / log / lgamma, so the order of two DIFFERENT candidates that close is not trusted: the host re-evaluates the
+// listed candidates with its own libm (the CPU reference's arithmetic) and takes b_bud's decision itself.
+constexpr double BUD_NEAR = 1e-9;
 struct BudOut {
   double best_p[2];
   uint32_t best_reads[2];

@@ -1,0 +1,221 @@
+// hostpar.h — host-side plumbing of libdada2hip.so that is not the algorithm: a small worker pool for the
+// input marshalling of the boundary call (the reference copies its R inputs serially, Rmain.cpp:102-120; at
+// 10^6 uniques that is 2 GB of doubles and 250 MB of characters, so here it is spread over host threads), and
+// caches of device / pinned allocations so that back-to-back boundary calls do not pay hipMalloc / hipFree /
+// hipHostMalloc again ("no global state except an optional per-device context cache").
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+namespace d2 {
+
+// ---- worker pool ---------------------------------------------------------------------------------
+class HostPool {
+ public:
+  static HostPool &get() {
+    static HostPool p;
+    return p;
+  }
+  int nthreads() const { return nthreads_; }
+  // f(lo, hi) over [0, n) in pieces of `grain`; the caller takes part, returns when all pieces are done
+  void run(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f) {
+    if (n == 0) return;
+    if (grain == 0) grain = 1;
+    if (nthreads_ <= 1 || n <= grain) { f(0, n); return; }
+    std::unique_lock<std::mutex> job_lock(job_mu_);   // one job at a time
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      fn_ = &f; n_ = n; grain_ = grain; next_.store(0); pending_ = (int)workers_.size(); gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> l(mu_);
+    done_cv_.wait(l, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  HostPool() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    if (n > 32) n = 32;                                  // memory-bound copies: more threads do not help
+    if (const char *e = getenv("DADA2HIP_HOST_THREADS")) n = std::max(1, atoi(e));
+    nthreads_ = n;
+    for (int i = 1; i < n; i++) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true; gen_++;
+    }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  void work() {
+    for (;;) {
+      const size_t lo = next_.fetch_add(grain_);
+      if (lo >= n_) break;
+      (*fn_)(lo, std::min(n_, lo + grain_));
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (--pending_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  int nthreads_ = 1;
+  std::vector<std::thread> workers_;
+  std::mutex mu_, job_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(size_t, size_t)> *fn_ = nullptr;
+  size_t n_ = 0, grain_ = 1;
+  std::atomic<size_t> next_{0};
+  int pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+inline void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f) { HostPool::get().run(n, grain, f); }
+
+// ---- allocation caches ---------------------------------------------------------------------------
+// Size classes: multiples of 1/4 of the power of two below the request (<= 25 % slack), at least 256 B; a freed block
+// goes back to its class and is handed out again to the next request of the same class on the same device.
+inline size_t alloc_class(size_t bytes) {
+  if (bytes < 256) return 256;
+  size_t p = 256;
+  while ((p << 1) <= bytes) p <<= 1;
+  const size_t step = p >> 2;
+  return (bytes + step - 1) / step * step;
+}
+
+class AllocCache {
+ public:
+  static AllocCache &get() {
+    static AllocCache *c = new AllocCache();   // leaked on purpose: the HIP runtime may be gone at static destruction
+    return *c;
+  }
+  hipError_t dev_alloc(void **p, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t cls = alloc_class(bytes);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto &fl = dev_free_[dev];
+      auto it = fl.find(cls);
+      if (it != fl.end()) {
+        *p = it->second;
+        fl.erase(it);
+        dev_cached_ -= cls;
+        dev_live_[*p] = {dev, cls};
+        return hipSuccess;
+      }
+    }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {   // out of memory: give the cache back and retry once
+      trim();
+      (void)hipGetLastError();
+      e = hipMalloc(p, cls);
+      if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> g(mu_);
+    dev_live_[*p] = {dev, cls};
+    return hipSuccess;
+  }
+  void dev_release(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = dev_live_.find(p);
+    if (it == dev_live_.end()) { (void)hipFree(p); return; }
+    const Blk b = it->second;
+    dev_live_.erase(it);
+    if (!enabled_ || dev_cached_ + b.cls > cap_) { (void)hipFree(p); return; }
+    dev_free_[b.dev].emplace(b.cls, p);
+    dev_cached_ += b.cls;
+  }
+  hipError_t pin_alloc(void **p, size_t bytes) {
+    const size_t cls = alloc_class(bytes);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto it = pin_free_.find(cls);
+      if (it != pin_free_.end()) {
+        *p = it->second;
+        pin_free_.erase(it);
+        pin_cached_ -= cls;
+        pin_live_[*p] = cls;
+        return hipSuccess;
+      }
+    }
+    hipError_t e = hipHostMalloc(p, cls, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu_);
+    pin_live_[*p] = cls;
+    return hipSuccess;
+  }
+  void pin_release(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = pin_live_.find(p);
+    if (it == pin_live_.end()) { (void)hipHostFree(p); return; }
+    const size_t cls = it->second;
+    pin_live_.erase(it);
+    if (!enabled_ || pin_cached_ + cls > pin_cap_) { (void)hipHostFree(p); return; }
+    pin_free_.emplace(cls, p);
+    pin_cached_ += cls;
+  }
+  // hand every cached block back to the runtime (dada2hip_trim_cache)
+  void trim() {
+    std::lock_guard<std::mutex> g(mu_);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &d : dev_free_) {
+      (void)hipSetDevice(d.first);
+      for (auto &b : d.second) (void)hipFree(b.second);
+      d.second.clear();
+    }
+    (void)hipSetDevice(cur);
+    dev_cached_ = 0;
+    for (auto &b : pin_free_) (void)hipHostFree(b.second);
+    pin_free_.clear();
+    pin_cached_ = 0;
+  }
+  size_t cached_bytes() {
+    std::lock_guard<std::mutex> g(mu_);
+    return dev_cached_ + pin_cached_;
+  }
+
+ private:
+  AllocCache() {
+    if (const char *e = getenv("DADA2HIP_ALLOC_CACHE")) enabled_ = atoi(e) != 0;
+    if (const char *e = getenv("DADA2HIP_ALLOC_CACHE_GB")) cap_ = (size_t)atoll(e) << 30;
+  }
+  struct Blk { int dev; size_t cls; };
+  std::mutex mu_;
+  std::map<int, std::multimap<size_t, void *>> dev_free_;
+  std::map<void *, Blk> dev_live_;
+  std::multimap<size_t, void *> pin_free_;
+  std::map<void *, size_t> pin_live_;
+  size_t dev_cached_ = 0, pin_cached_ = 0;
+  size_t cap_ = (size_t)96 << 30, pin_cap_ = (size_t)8 << 30;   // of 288 GB HBM / host RAM
+  bool enabled_ = true;
+};
+
+}  // namespace d2

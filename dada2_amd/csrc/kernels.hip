@@ -23,26 +23,41 @@ static __device__ __forceinline__ uint32_t base_at(const uint32_t *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // quality upload: double mean quality -> (uint8) round()   (containers.cpp:34); NA/NaN past the end.
-__global__ void k_round_quals(const double *__restrict__ q, int n, int maxlen, const int32_t *__restrict__ len,
-                              uint8_t *__restrict__ out, int LQ, int32_t *__restrict__ flags) {
+__global__ __launch_bounds__(256) void k_round_quals(const double *__restrict__ q, int n, int maxlen, const int32_t *__restrict__ len,
+                                                     uint8_t *__restrict__ out, int LQ, int32_t *__restrict__ flags) {
+  // one thread per 4 output bytes (LQ is a multiple of 16): 4 doubles in, one packed word out
+  const int LQ4 = LQ >> 2;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)n * (size_t)LQ;
+  const size_t total = (size_t)n * (size_t)LQ4;
+  int mx = 0, bad = 0;
   for (; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    int r = (int)(idx / LQ), p = (int)(idx % LQ);
-    uint8_t v = 0;
-    if (p < len[r]) {
-      double x = round(q[(size_t)r * maxlen + p]);
-      if (!(x >= 0.0 && x <= 255.0)) { atomicOr(flags, 1); x = 0.0; }
-      v = (uint8_t)x;
-      atomicMax(flags + 1, (int)v);
+    const int r = (int)(idx / LQ4), p0 = (int)(idx % LQ4) << 2;
+    const int L = len[r];
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = p0 + k;
+      if (p < L) {
+        double x = round(q[(size_t)r * maxlen + p]);
+        if (!(x >= 0.0 && x <= 255.0)) { bad = 1; x = 0.0; }
+        const int v = (int)x;
+        mx = max(mx, v);
+        w |= (uint32_t)v << (8 * k);
+      }
     }
-    out[idx] = v;
+    ((uint32_t *)out)[idx] = w;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); bad |= __shfl_xor(bad, o, 64); }
+  if ((threadIdx.x & 63) == 0) {   // one atomic per wave (per element they all hit one address and serialise)
+    if (bad) atomicOr(flags, 1);
+    if (mx > 0) atomicMax(flags + 1, mx);
   }
 }
 
 void launch_round_quals(const double *d_q, int n, int maxlen, const int32_t *d_len, uint8_t *d_out, int LQ,
                         int32_t *d_flags, hipStream_t st) {
-  size_t total = (size_t)n * LQ;
+  size_t total = (size_t)n * (LQ / 4);
   int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(k_round_quals, dim3(grid), dim3(256), 0, st, d_q, n, maxlen, d_len, d_out, LQ, d_flags);
 }
@@ -891,7 +906,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
           int n = qs == 0 ? n0 : n0 + 8 * (qs - 1) + (qs < GL ? nq : 0);
           const int room = ti < tj ? ti : tj;
           const bool clamped = n > room;                   // (cannot happen: cells on the first row/column carry pointers 2/3)
-          if (clamped) n = room;
+          if (clamped) { n = room; atomicOr(S.nw_flag, 1); }
           if (n > 0) {
             push(tj - n, n, ti - tj + 128);
             ti -= n; tj -= n;
@@ -904,7 +919,8 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       }
       if (lead && !gapless && active) {
         if (last) runs[nruns++] = last;
-        if (!(ti > 0 || tj > 0) || guard <= 0) done = true;
+        if (!(ti > 0 || tj > 0)) done = true;
+        else if (guard <= 0) { done = true; atomicOr(S.nw_flag, 1); }   // bounded walk tripped: report it
       }
       nruns = __shfl(nruns, al * GL, 64);
       done = __shfl((int)done, al * GL, 64) != 0;
@@ -977,10 +993,12 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
 #define D2_LAUNCH_AD(GLV, DEFV, EDGEV)                                                                                   \
   do {                                                                                                                   \
-    static size_t attr_set = 0;                                                                                          \
-    if (lds > attr_set) {                                                                                                \
+    static size_t attr_set[64] = {0};   /* per device: the attribute belongs to the function ON a device */            \
+    int dev_ = 0;                                                                                                        \
+    (void)hipGetDevice(&dev_);                                                                                           \
+    if (lds > attr_set[dev_ & 63]) {                                                                                     \
       (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_set = lds;                                                                                                    \
+      attr_set[dev_ & 63] = lds;                                                                                         \
     }                                                                                                                    \
     hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);        \
   } while (0)
@@ -1021,6 +1039,7 @@ size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
 struct AdwGeom {
   int GL, APW, pad, seqbytes, tbytes, fch, per_al_bytes, nblk16;
 };
+constexpr uint32_t ADW_DL0 = 8192, ADW_GAP = 0xFFFFFFFFu;   // run descriptor word y: (pi - pj) + ADW_DL0, or "gap in the centre"
 static __host__ __device__ inline AdwGeom adw_geom(int band, int maxlen, int minlen) {
   AdwGeom G;
   const int We = 2 * band + (maxlen - minlen) + 2;        // widest window + the phase cell
@@ -1030,7 +1049,7 @@ static __host__ __device__ inline AdwGeom adw_geom(int band, int maxlen, int min
   G.seqbytes = (maxlen + 2 * G.pad + 7) & ~7;
   G.tbytes = (maxlen + 7) & ~7;
   G.fch = (G.seqbytes / 8) & ~7;                          // fp64 factors per chunk (they alias the centre bytes)
-  G.per_al_bytes = AD_RCAP * 4 + 2 * G.seqbytes + G.tbytes;
+  G.per_al_bytes = AD_RCAP * 8 + 2 * G.seqbytes + G.tbytes;
   G.nblk16 = (2 * maxlen + 1 + 15) / 16 + 1;
   return G;
 }
@@ -1080,11 +1099,14 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
   const bool ghost = lane / GL >= APW;                     // GL = 21: lane 63 rides along with no cells of its own
   const int al = ghost ? APW - 1 : lane / GL, g = ghost ? GL : lane % GL;
   uint8_t *abase = (uint8_t *)(s_dyn + nerr) + ((size_t)wib * APW + al) * G.per_al_bytes;
-  uint32_t *runs = (uint32_t *)abase;
-  double *fac = (double *)(abase + AD_RCAP * 4);           // aliases the centre bytes once the transition codes exist
-  uint8_t *cbytes = abase + AD_RCAP * 4 + G.pad;
+  // run descriptors are two words here: x = pj_lo | n << 12, y = (pi - pj) + ADW_DL0, ADW_GAP = gap in the centre.  Band
+  // windows reach 512 cells, so |pi - pj| reaches ~500 (a 1 300-nt read that is a suffix of a 1 500-nt centre): the
+  // one-word format of k_nw_ad (8-bit delta, windows <= 127 cells) does not hold it.
+  uint2 *runs = (uint2 *)abase;
+  double *fac = (double *)(abase + AD_RCAP * 8);           // aliases the centre bytes once the transition codes exist
+  uint8_t *cbytes = abase + AD_RCAP * 8 + G.pad;
   uint8_t *rbytes = cbytes + G.seqbytes;
-  uint8_t *tcode = abase + AD_RCAP * 4 + 2 * G.seqbytes;
+  uint8_t *tcode = abase + AD_RCAP * 8 + 2 * G.seqbytes;
   __syncthreads();
   const SampleDev &S = a.S;
   const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
@@ -1193,14 +1215,14 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
     const int gl0 = al * GL;
     while (true) {
       int nruns = 0;
-      uint32_t last = 0;                                   // the leader's pending (mergeable) run, 0 = none
-      auto push = [&](int lo, int n, int dl) {
-        if (last) {
-          const int llo = last & 4095, ln = (last >> 12) & 4095, ldl = (int)(last >> 24);
-          if (ldl == dl && lo + n == llo) { last = (uint32_t)lo | ((uint32_t)(ln + n) << 12) | ((uint32_t)dl << 24); return; }
+      uint2 last = make_uint2(0u, 0u);                     // the leader's pending (mergeable) run, n == 0: none
+      auto push = [&](int lo, int n, uint32_t dl) {
+        const int llo = last.x & 4095, ln = (last.x >> 12) & 4095;
+        if (ln) {
+          if (last.y == dl && lo + n == llo) { last.x = (uint32_t)lo | ((uint32_t)(ln + n) << 12); return; }
           runs[nruns++] = last;
         }
-        last = (uint32_t)lo | ((uint32_t)n << 12) | ((uint32_t)dl << 24);
+        last = make_uint2((uint32_t)lo | ((uint32_t)n << 12), dl);
       };
       // as in k_nw_ad: the path is walked by the group's first lane, every diagonal stretch is measured by the whole group
       // (lane q reads the pointer word q blocks of 16 steps further back in the path's cell pair) - here each of those
@@ -1234,19 +1256,21 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
           const int room = ti < tj ? ti : tj;
           const bool clamped = n > room;
           if (clamped) n = room;
+          if (clamped) atomicOr(S.nw_flag, 1);             // (cannot happen: first row / column cells carry axis pointers)
           if (n > 0) {
-            push(tj - n, n, ti - tj + 128);
+            push(tj - n, n, (uint32_t)(ti - tj + ADW_DL0));
             ti -= n; tj -= n;
           }
           if (qs < GL && !clamped && (ti > 0 || tj > 0)) {
-            if (pq == 2u) { tj--; push(tj, 1, 255); }
+            if (pq == 2u) { tj--; push(tj, 1, ADW_GAP); }
             else ti--;
           }
         }
       }
       if (lead && active) {
-        if (last) runs[nruns++] = last;
-        if (!(ti > 0 || tj > 0) || guard <= 0) done = true;
+        if ((last.x >> 12) & 4095) runs[nruns++] = last;
+        if (!(ti > 0 || tj > 0)) done = true;
+        else if (guard <= 0) { done = true; atomicOr(S.nw_flag, 1); }   // bounded walk tripped: report, never return a wrong lambda silently
       }
       nruns = __shfl(nruns, gl0, 64);
       done = __shfl((int)done, gl0, 64) != 0;
@@ -1255,17 +1279,18 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
       for (int o = 32; o >= 1; o >>= 1) nrmax = max(nrmax, __shfl_xor(nrmax, o, 64));
       for (int ri = 0; ri < nrmax; ri++) {
         if (ri < nruns && !ghost) {
-          const uint32_t dsc = runs[ri];
-          const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
+          const uint2 dsc = runs[ri];
+          const int lo = dsc.x & 4095, n = (dsc.x >> 12) & 4095;
+          const int dl = (int)dsc.y - ADW_DL0;
           for (int pj = lo + g; pj < lo + n; pj += GL) {
             const uint32_t rb = rbytes[pj];
             uint32_t tc = 5u * rb;
-            if (dl != 255) {
-              const uint32_t cb = cbytes[pj + dl - 128];
+            if (dsc.y != ADW_GAP) {
+              const uint32_t cb = cbytes[pj + dl];
               tc = 4u * cb + rb;
               h += (cb != rb);
               if (a.view && active)
-                a.view[vr * a.LV + pj + dl - 128] = (uint16_t)(0x8000u | (rb << 8) | (a.ap.use_quals ? qrow[pj] : 0));
+                a.view[vr * a.LV + pj + dl] = (uint16_t)(0x8000u | (rb << 8) | (a.ap.use_quals ? qrow[pj] : 0));
             }
             tcode[pj] = (uint8_t)tc;
           }
@@ -1273,9 +1298,10 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
       }
       if (__all(done)) break;
     }
-    if (g == 0 && !ghost) runs[0] = 0;
-    if (!ghost && h) atomicAdd(&runs[0], h);
-    h = runs[0];
+    uint32_t *hsum = (uint32_t *)runs;                      // the run buffer is free by now
+    if (g == 0 && !ghost) hsum[0] = 0;
+    if (!ghost && h) atomicAdd(&hsum[0], h);
+    h = hsum[0];
     // ---- lambda: factors in chunks of G.fch positions (all lanes), multiplied in raw-position order by one lane ----
     int L2max = active ? L2 : 0;
 #pragma unroll
@@ -1333,10 +1359,12 @@ void launch_nw_adw(const SampleDev &S, int centre, const int32_t *d_chunk_centre
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
 #define D2_LAUNCH_ADW(GLV, DEFV)                                                                                          \
   do {                                                                                                                    \
-    static size_t attr_set = 0;                                                                                           \
-    if (lds > attr_set) {                                                                                                 \
+    static size_t attr_set[64] = {0};                                                                                     \
+    int dev_ = 0;                                                                                                         \
+    (void)hipGetDevice(&dev_);                                                                                            \
+    if (lds > attr_set[dev_ & 63]) {                                                                                      \
       (void)hipFuncSetAttribute((const void *)k_nw_adw<GLV, DEFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_set = lds;                                                                                                     \
+      attr_set[dev_ & 63] = lds;                                                                                          \
     }                                                                                                                     \
     hipLaunchKernelGGL((k_nw_adw<GLV, DEFV>), dim3(grid), dim3(256), lds, st, a, G);                                      \
   } while (0)
@@ -1747,6 +1775,12 @@ __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudP
       out->valid = 1;
     }
   }
+  // candidates to list: exact ties of the best key, plus any other candidate whose non-zero p is within BUD_NEAR of it
+  // (their order against the best one is the host's call, engine.h).  p == 0 (lambda == 0, pval.cpp:78, or a Poisson
+  // tail below the smallest denormal) is taken as exact: a zero only ties with zeros, by reads.
+  // (no window when the best p-value is clearly not significant: b_bud then gives no birth whatever the order)
+  const bool sig0 = b0.p * S.N < 2.0 * bp.omegaA, sig1 = b1.p < 2.0 * bp.omegaP;
+  const double thr0 = sig0 ? b0.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0, thr1 = sig1 ? b1.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0;
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
     if (lock_tmp[r]) P.lock[r] = 1;                                    // b_p_update's greedy locks (pval.cpp:26-36)
     if (!bud_candidate(P, S, r, bp)) continue;
@@ -1755,12 +1789,15 @@ __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudP
     for (int track = 0; track < 2; track++) {
       if (track == 1 && !S.prior[r]) continue;
       const BudKey &bk = track ? b1 : b0;
-      if (!(track ? found1 : found0) || p != bk.p || reads != bk.reads) continue;
+      if (!(track ? found1 : found0)) continue;
+      const bool exact = p == bk.p && reads == bk.reads;
+      const bool near = !exact && p != 0.0 && p <= (track ? thr1 : thr0);
+      if (!exact && !near) continue;
       const int k = atomicAdd(&out->nties[track], 1);
       if (k < BUD_TIES) {
         BudTie &t = out->ties[track][k];
         t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
-        t.from = P.clust_of[r]; t.from_reads = P.creads[t.from];
+        t.from = P.clust_of[r]; t.from_reads = P.creads[t.from]; t.p = p;
       }
       (track ? overflow1 : overflow0)[k] = r;
     }
@@ -1807,7 +1844,8 @@ __global__ __launch_bounds__(256) void k_auto_birth(PartState P, SampleDev S, ui
   __shared__ int s_ok;
   BudOut *out = &blk->bud;
   if (threadIdx.x == 0) {
-    const bool ok = out->valid && out->found[0] && out->nties[0] == 1 && (out->best_p[0] * S.N < omegaA);
+    // (the margin keeps the decision on the host whenever the device p-value is within libm noise of OMEGA_A)
+    const bool ok = out->valid && out->found[0] && out->nties[0] == 1 && (out->best_p[0] * S.N < omegaA * (1.0 - 1e-9));
     s_ok = ok;
     out->auto_applied = ok ? 1 : 0;
     next[0] = ok ? out->ties[0][0].raw : -1;
@@ -1873,6 +1911,13 @@ __global__ __launch_bounds__(256) void k_posthoc(PartState P, SampleDev S, int n
 __global__ void k_fill_null(int n, const uint8_t *__restrict__ cls, double *__restrict__ lam, uint32_t *__restrict__ ham) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n && (cls[r] == CLS_SHROUD || cls[r] == CLS_SKIP)) { lam[r] = 0.0; ham[r] = 0xFFFFFFFFu; }
+}
+__global__ void k_fill_f64(double *__restrict__ p, size_t n, double v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_f64(double *d_p, size_t n, double v, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, d_p, n, v);
 }
 void launch_fill_null(int n, const uint8_t *d_cls, double *d_lam, uint32_t *d_ham, hipStream_t st) {
   hipLaunchKernelGGL(k_fill_null, dim3((n + 255) / 256), dim3(256), 0, st, n, d_cls, d_lam, d_ham);

@@ -16,9 +16,12 @@ from .io import Derep
 _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
-def true_variants(rng, G: int, L: int, Lmin: int = None):
+def true_variants(rng, G: int, L: int, Lmin: int = None, Lmin5: int = None):
     """G/8 roots at divergence U(0.03,0.25) from one ancestor; each root + 7 variants at
-    Hamming 1..7 from it.  Returns uint8 codes 0..3, shape [G, L] and lengths [G]."""
+    Hamming 1..7 from it.  Returns uint8 codes 0..3, shape [G, L] and lengths [G].
+    ``Lmin``: 3'-ragged variants (lengths U{Lmin..L}, the tail cut off).  ``Lmin5``: 5'-ragged variants (a variant is
+    the SUFFIX of its full-length sequence, start offset U{0..L-Lmin5}) — primer-trim variation, ordinary for long
+    amplicons: the alignment of such a read to a full-length centre runs |i - j| = offset cells off the main diagonal."""
     nroot = max(1, G // 8)
     anc = rng.integers(0, 4, size=L, dtype=np.uint8)
     out = np.empty((nroot * 8, L), dtype=np.uint8)
@@ -36,6 +39,14 @@ def true_variants(rng, G: int, L: int, Lmin: int = None):
     lens = np.full(nroot * 8, L, dtype=np.int32)
     if Lmin is not None and Lmin < L:
         lens = rng.integers(Lmin, L + 1, size=nroot * 8).astype(np.int32)
+    if Lmin5 is not None and Lmin5 < L:
+        off = rng.integers(0, L - Lmin5 + 1, size=nroot * 8)
+        off[::8] = 0                                  # the roots stay full length at the 5' end
+        for g in range(nroot * 8):
+            o = int(min(off[g], max(0, lens[g] - max(8, Lmin5 // 4))))
+            if o > 0:
+                out[g, : L - o] = out[g, o:].copy()
+                lens[g] -= o
     return out[:G], lens[:G]
 
 
@@ -78,12 +89,12 @@ def _derep_codes(codes: np.ndarray, lens: np.ndarray, quals: np.ndarray) -> Dere
 
 def make_sample(err: np.ndarray, n_uniques: int, L: int = 250, G: int = 256, seed: int = 0, Lmin: int = None,
                 q_hi: float = 38.0, q_lo: float = 22.0, q_sd: float = 4.0, q_max: int = 40, indel_rate: float = 0.0,
-                zipf: float = 1.1, variants=None, chunk: int = 200_000) -> Derep:
+                zipf: float = 1.1, variants=None, chunk: int = 200_000, Lmin5: int = None, ins_rate: float = 0.0) -> Derep:
     """Draw reads until the dereplicated unique count reaches ``n_uniques`` (then trim the
     rarest uniques so N is exact), and dereplicate.  ``err`` is the 16 x Q matrix errors are
     drawn from.  ``variants`` (codes, lens) may be passed to share truth across samples."""
     rng = np.random.default_rng(seed)
-    tv, tl = variants if variants is not None else true_variants(rng, G, L, Lmin)
+    tv, tl = variants if variants is not None else true_variants(rng, G, L, Lmin, Lmin5)
     G = tv.shape[0]
     w = (np.arange(1, G + 1, dtype=np.float64)) ** (-zipf)
     w /= w.sum()
@@ -119,6 +130,15 @@ def make_sample(err: np.ndarray, n_uniques: int, L: int = 250, G: int = 256, see
                 codes[r, p:-1] = codes[r, p + 1:]
                 q[r, p:-1] = q[r, p + 1:]
                 lens[r] -= 1
+        if ins_rate > 0:
+            # rare single-base insertions (a read at full length keeps its length: its last base falls off)
+            has = rng.random(chunk) < ins_rate * lens
+            for r in np.nonzero(has)[0]:
+                p = int(rng.integers(1, lens[r] - 1))
+                codes[r, p + 1:] = codes[r, p:-1].copy()
+                q[r, p + 1:] = q[r, p:-1].copy()
+                codes[r, p] = rng.integers(0, 4)
+                lens[r] = min(L, lens[r] + 1)
         pad = np.arange(L)[None, :] >= lens[:, None]
         codes[pad] = 255
         q[pad] = 0

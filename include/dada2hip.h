@@ -68,14 +68,19 @@ typedef struct dada2hip_stats {
   uint64_t nshuffle;     /* b_shuffle2 calls                                                     */
   uint64_t nstored;      /* Comparisons kept (cluster.cpp:189-199)                               */
   uint32_t rounds;       /* b_compare rounds = final number of partitions                        */
-  uint32_t reserved;
+  uint32_t kernel_times_sampled;  /* 1: nw/screen_kernel_ms are EXTRAPOLATED from sampled launches (round 0, every 8th
+                                     round, the final pass); 0: every launch was event-timed (DADA2HIP_PROFILE=1)  */
+  /* host wall-clock split of the call: upload = sample creation (marshalling + H2D + k-mer build), screen = enqueue
+   * of the compare kernels, bookkeep = round tails incl. waiting for the device, final = final pass + outputs */
   double ms_total, ms_upload, ms_screen, ms_nw, ms_gapless, ms_bookkeep, ms_pval, ms_final;
-  double nw_kernel_ms;   /* summed HIP-event time of the NW kernel launches                      */
+  double nw_kernel_ms;   /* HIP-event time of the NW kernel launches (see kernel_times_sampled)  */
   uint64_t nw_kernel_launches;
   uint64_t nw_cells;     /* DP cells those launches filled (algorithmic work)      */
   double screen_kernel_ms;
   uint64_t screen_kernel_launches;
   uint64_t screen_bytes; /* algorithmic bytes the screen launches had to read                     */
+  /* device time per kernel class, summed over every launch; filled only under DADA2HIP_PROFILE=1 (else 0) */
+  double dev_ms_screen, dev_ms_nw, dev_ms_shuffle, dev_ms_pval, dev_ms_birth, dev_ms_final;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------
@@ -90,6 +95,28 @@ int dada2hip_dada_uniques(int32_t nraw, const char *const *seqs, const int32_t *
                           const uint8_t *priors, const double *err, int32_t err_ncol, const double *quals,
                           int32_t quals_nrow, const dada2hip_opts *opts, int32_t device,
                           const dada2hip_hooks *hooks, dada2hip_result **out, char *errbuf, size_t errlen);
+
+/* ---- batch form: the per-sample loop of dada() (R/dada.R:266-366 calls dada_uniques once per sample, serially)
+ * spread over the GPUs of one node.  Samples only share `err`, so sample i simply runs on
+ * device_ids[i % n_devices], one host thread per entry of device_ids, the samples of a thread in order; out[i]
+ * receives sample i's result (all NULL on failure; errbuf then names the first failing sample).  The caller sums
+ * the results' $subqual matrices (accumulateTrans, R/errorModels.R:462-471).  n_devices <= 0: device 0 only. */
+typedef struct dada2hip_sample_input {
+  int32_t nraw;
+  int32_t quals_nrow;
+  const char *const *seqs;
+  const int32_t *abundances;
+  const uint8_t *priors;      /* may be NULL */
+  const double *quals;
+} dada2hip_sample_input;
+int dada2hip_run_multi(int32_t n_samples, const dada2hip_sample_input *samples, const double *err, int32_t err_ncol,
+                       const dada2hip_opts *opts, int32_t n_devices, const int32_t *device_ids, dada2hip_result **out,
+                       char *errbuf, size_t errlen);
+
+/* Device and pinned-host allocations are cached per process between calls (the "per-device context cache" of a
+ * drop-in replacement: back-to-back dada_uniques calls do not pay hipMalloc / hipFree again); this hands every cached
+ * block back to the runtime.  DADA2HIP_ALLOC_CACHE=0 disables the cache. */
+void dada2hip_trim_cache(void);
 
 /* ---- resident form --------------------------------------------------------------------------- */
 int dada2hip_sample_create(int32_t nraw, const char *const *seqs, const int32_t *abundances,

@@ -13,20 +13,21 @@ import numpy as np
 from dada2_amd.opts import COpts, DadaOpts, DadaResult, CLUSTERING_COLS, BIRTH_SUBS_COLS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "_ref", "libdada2ref.so")
-_lib = None
+# two builds of the same sources: -O2 (R's default flags; the parity target) and -O3 -march=x86-64-v3 (bench baseline)
+_PATHS = {"O2": os.path.join(_HERE, "_ref", "libdada2ref.so"), "O3": os.path.join(_HERE, "_ref", "libdada2ref_o3.so")}
+_PATH = _PATHS["O2"]
+_libs = {}
 
 
-def available() -> bool:
-    return os.path.exists(_PATH)
+def available(flavour: str = "O2") -> bool:
+    return os.path.exists(_PATHS[flavour])
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not available():
-            raise RuntimeError("oracle/_ref/libdada2ref.so missing: run `make -C oracle` where /root/reference exists")
-        L = C.CDLL(_PATH)
+def lib(flavour: str = "O2"):
+    if flavour not in _libs:
+        if not available(flavour):
+            raise RuntimeError(f"{_PATHS[flavour]} missing: run `make -C oracle` where /root/reference exists")
+        L = C.CDLL(_PATHS[flavour])
         L.ref_dada_uniques.restype = C.c_void_p
         L.ref_dada_uniques.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_int, C.POINTER(COpts), C.c_char_p, C.c_int]
@@ -45,16 +46,18 @@ def lib():
         L.dada2_oracle_ppois.restype = C.c_double
         L.dada2_oracle_ppois.argtypes = [C.c_double, C.c_double, C.c_int]
         L.dada2_shim_set_threads.argtypes = [C.c_int]
-        _lib = L
-    return _lib
+        _libs[flavour] = L
+    return _libs[flavour]
 
 
 def set_threads(n: int):
-    lib().dada2_shim_set_threads(int(n))
+    for f in _PATHS:
+        if available(f):
+            lib(f).dada2_shim_set_threads(int(n))
 
 
-def _get(h, a, b=None):
-    L = lib()
+def _get(h, a, b=None, L=None):
+    L = L or lib()
     kind, nr, nc, data = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
     n = L.ref_result_get(h, a.encode(), (b or "").encode(), C.byref(kind), C.byref(nr), C.byref(nc), C.byref(data))
     if n < 0:
@@ -72,12 +75,27 @@ def _get(h, a, b=None):
     return arr
 
 
+class _CharPP:
+    """`char **` over one NUL-separated blob (a ctypes array of a million c_char_p takes seconds to build)."""
+
+    def __init__(self, seqs):
+        parts = [s.encode("ascii") for s in seqs]
+        self.blob = b"\0".join(parts) + b"\0"
+        n = len(parts)
+        lens = np.fromiter((len(x) for x in parts), dtype=np.int64, count=n)
+        off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            np.cumsum(lens[:-1] + 1, out=off[1:])
+        self.ptrs = (off + np.frombuffer(self.blob, dtype=np.uint8).ctypes.data).astype(np.uint64)
+        self._as_parameter_ = C.cast(C.c_void_p(self.ptrs.ctypes.data if n else None), C.POINTER(C.c_char_p))
+
+
 def pack_inputs(seqs, abundances, priors, err, quals):
     """Common marshalling: quals is the R-side [N, maxlen] matrix (one row per unique, NaN
     padded) or None; the boundary wants it transposed, maxlen x N column-major
     (R/dada.R:337 `t(drpi$quals)`, Rmain.cpp:69,113) == the same C-contiguous [N, maxlen] buffer."""
     n = len(seqs)
-    arr = (C.c_char_p * n)(*[s.encode("ascii") for s in seqs])
+    arr = _CharPP(seqs)
     ab = np.ascontiguousarray(abundances, dtype=np.int32)
     pr = np.ascontiguousarray(priors if priors is not None else np.zeros(n), dtype=np.uint8)
     e = np.asarray(err, dtype=np.float64)
@@ -93,22 +111,28 @@ def pack_inputs(seqs, abundances, priors, err, quals):
 
 
 def dada_uniques(seqs, abundances, priors, err, quals, opts: DadaOpts = None, *, max_clust=None,
-                 multithread=False, verbose=False, copts: COpts = None) -> DadaResult:
-    """Run the reference's dada_uniques (Rmain.cpp:30)."""
-    L = lib()
+                 multithread=False, verbose=False, copts: COpts = None, flavour: str = "O2", packed=None,
+                 call_seconds: list = None) -> DadaResult:
+    """Run the reference's dada_uniques (Rmain.cpp:30).  ``packed`` = a pack_inputs() tuple prepared beforehand;
+    ``call_seconds`` (a list) receives the wall time of the C call alone (no Python marshalling)."""
+    import time
+    L = lib(flavour)
     co = copts if copts is not None else (opts or DadaOpts()).to_c(max_clust=max_clust, multithread=multithread,
                                                                   verbose=verbose)
-    arr, ab, pr, ef, ncol, q, qn = pack_inputs(seqs, abundances, priors, err, quals)
+    arr, ab, pr, ef, ncol, q, qn = packed if packed is not None else pack_inputs(seqs, abundances, priors, err, quals)
     eb = C.create_string_buffer(1024)
+    t0 = time.perf_counter()
     h = L.ref_dada_uniques(len(seqs), arr, ab.ctypes.data, pr.ctypes.data, ef.ctypes.data, ncol,
                            q.ctypes.data if q is not None else None, qn, C.byref(co), eb, 1024)
+    if call_seconds is not None:
+        call_seconds.append(time.perf_counter() - t0)
     if not h:
         raise RuntimeError(eb.value.decode())
     try:
-        clustering = {c: _get(h, "clustering", c) for c in CLUSTERING_COLS}
-        birth_subs = {c: _get(h, "birth_subs", c) for c in BIRTH_SUBS_COLS}
-        return DadaResult(clustering, birth_subs, _get(h, "subqual"), _get(h, "clusterquals"), _get(h, "map"),
-                          _get(h, "pval"))
+        clustering = {c: _get(h, "clustering", c, L) for c in CLUSTERING_COLS}
+        birth_subs = {c: _get(h, "birth_subs", c, L) for c in BIRTH_SUBS_COLS}
+        return DadaResult(clustering, birth_subs, _get(h, "subqual", None, L), _get(h, "clusterquals", None, L),
+                          _get(h, "map", None, L), _get(h, "pval", None, L))
     finally:
         L.ref_result_free(h)
 

@@ -1,0 +1,226 @@
+"""GPU parity tests (-m gpu), part 2: the sizes and shapes BASELINE.json's configs name, and the edge cases the
+round-1 review found untested — 5'-offset long-read alignments (|i - j| far beyond 127 on the wide anti-diagonal
+kernel), unsorted inputs over several seeds, near-tied bud candidates, the batch C entry point, and the RCCL path
+of the sample-sharded driver.  Everything goes through the C ABI; the checker is the oracle / the reference binary."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import P_RTOL, assert_results_equal, tperr1
+from dada2_amd.io import Derep, extend_err
+from dada2_amd.opts import DadaOpts
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dada2_amd import api as a
+    return a
+
+
+def _mutate(rng, s, nsub=0, dels=(), ins=()):
+    s = list(s)
+    for _ in range(nsub):
+        p = int(rng.integers(0, len(s)))
+        s[p] = "ACGT"[("ACGT".index(s[p]) + int(rng.integers(1, 4))) & 3]
+    for p in sorted(dels, reverse=True):
+        del s[p]
+    for p in sorted(ins, reverse=True):
+        s.insert(p, "ACGT"[int(rng.integers(0, 4))])
+    return "".join(s)
+
+
+# ---- 5'-truncated reads: raw = suffix of the centre, the path runs |i - j| = offset cells off the main diagonal ---------
+@pytest.mark.parametrize("nw_kernel", ["wide", "lane"])
+@pytest.mark.parametrize("L,offsets", [(700, (64, 130, 250, 400)), (1500, (127, 128, 200, 440))])
+def test_five_prime_offsets_alignment_level(api, oracle_c, L, offsets, nw_kernel, monkeypatch):
+    """One b_compare round (sub_new + compute_lambda) of suffix / prefix / indel-carrying reads against a full-length
+    centre, band 32: lambda bits and hamming must equal the oracle's for every pair.  `wide` = k_nw_adw (run descriptors
+    used to hold the diagonal offset in 8 bits), `lane` = k_nw<WMAX> / k_nw_gen."""
+    monkeypatch.setenv("DADA2HIP_NW_KERNEL", nw_kernel)
+    rng = np.random.default_rng(L)
+    centre = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=L))
+    seqs = [centre]
+    for off in offsets:
+        seqs.append(_mutate(rng, centre[off:], nsub=3))                                  # 5' truncation
+        seqs.append(_mutate(rng, centre[off:], nsub=2, dels=(50, 51), ins=(200,)))       # ... with internal indels
+        seqs.append(_mutate(rng, centre[off // 2: L - off // 2], nsub=4))                # both ends ragged
+        seqs.append(_mutate(rng, centre[: L - off], nsub=1, ins=(30, 31, 32)))           # 3' truncation + insertion
+    seqs = list(dict.fromkeys(seqs))
+    n = len(seqs)
+    maxlen = max(len(s) for s in seqs)
+    quals = np.full((n, maxlen), np.nan)
+    for i, s in enumerate(seqs):
+        quals[i, : len(s)] = rng.integers(5, 41, size=len(s))
+    ab = np.array([1000] + [5] * (n - 1), dtype=np.int32)
+    err = tperr1()
+    o = DadaOpts(BAND_SIZE=32)
+    smp = api.Sample(seqs, ab, None, quals)
+    try:
+        lam, ham, cls, st = smp.compare(0, err, o, kdist_cutoff=1.0)
+    finally:
+        smp.close()
+    for i in range(1, n):
+        wl, wh, kd, ko = oracle_c.compare(seqs[0], quals[0, : len(seqs[0])], seqs[i], quals[i, : len(seqs[i])], err, o, kdist_cutoff=1.0)
+        assert ham[i] == wh, (i, len(seqs[i]), int(ham[i]), wh)
+        assert lam[i] == wl, (i, len(seqs[i]), lam[i], wl)
+
+
+@pytest.mark.parametrize("nw_kernel", ["wide", "lane", "auto"])
+def test_five_prime_ragged_sample_whole_path(api, oracle_c, nw_kernel, monkeypatch):
+    """Whole dada_uniques on a long-read-shaped sample whose true variants are 5'-ragged (start offsets up to 400 nt) and
+    carry internal indels at long-read rates."""
+    if nw_kernel != "auto":
+        monkeypatch.setenv("DADA2HIP_NW_KERNEL", nw_kernel)
+    from dada2_amd.synth import make_sample
+    d = make_sample(tperr1(), 350, L=620, G=16, seed=4242, Lmin5=220, indel_rate=2e-3, ins_rate=2e-3, chunk=3000)
+    assert max(len(s) for s in d.seqs) - min(len(s) for s in d.seqs) > 300
+    o = DadaOpts(BAND_SIZE=32)
+    got = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)
+    want = oracle_c.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+# ---- unsorted input: b_bud's "slot 0 is the centre" quirk depends on the slot order (cluster.cpp:285) -------------------
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_randomly_permuted_input_matches_oracle(api, oracle_c, seed):
+    from dada2_amd.synth import make_sample
+    d = make_sample(tperr1(), 600, L=110, G=12, seed=500 + seed, chunk=4000)
+    perm = np.random.default_rng(seed).permutation(d.nraw)
+    seqs = [d.seqs[i] for i in perm]
+    ab, q = d.abundances[perm].copy(), d.quals[perm].copy()
+    o = DadaOpts(GREEDY=bool(seed & 1))
+    got = api.dada_uniques(seqs, ab, None, tperr1(), q, o)
+    want = oracle_c.dada_uniques(seqs, ab, None, tperr1(), q, o)
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+# ---- near-tied bud candidates: the host must take the reference's decision with the CPU's arithmetic --------------------
+def test_near_tied_bud_candidates_follow_cpu_order(api, oracle_c):
+    """A flat error matrix and constant qualities make the lambdas of equally abundant Hamming-2 variants products of
+    the SAME factors in a different order: their p-values agree to ~1e-15 without being bit-equal, and device libm
+    differs from the host's in the last ulp.  b_bud's arg-min among them must still be the CPU reference's."""
+    rng = np.random.default_rng(77)
+    L = 120
+    centre = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=L))
+    seqs, ab = [centre], [4000]
+    for k in range(14):
+        seqs.append(_mutate(rng, centre, nsub=2))
+        ab.append(60)
+    for k in range(40):
+        seqs.append(_mutate(rng, centre, nsub=1))
+        ab.append(int(rng.integers(1, 4)))
+    seqs = list(dict.fromkeys(seqs))
+    ab = np.array(ab[: len(seqs)], dtype=np.int32)
+    order = np.argsort(-ab, kind="stable")
+    seqs, ab = [seqs[i] for i in order], ab[order]
+    quals = np.full((len(seqs), L), 30.0)
+    err = np.full((16, 41), 1e-3)
+    err[[0, 5, 10, 15], :] = 1.0 - 3e-3
+    for o in (DadaOpts(), DadaOpts(OMEGA_A=1e-10, MIN_HAMMING=2)):
+        got = api.dada_uniques(seqs, ab, None, err, quals, o)
+        want = oracle_c.dada_uniques(seqs, ab, None, err, quals, o)
+        assert got.nclust == want.nclust >= 3
+        assert_results_equal(got, want, p_rtol=P_RTOL)
+        # the birth p-values are recomputed on the host with the reference's arithmetic: bit-equal, not just close
+        assert np.array_equal(got.clustering["birth_pval"][1:], want.clustering["birth_pval"][1:])
+
+
+# ---- batch C entry point (dada2hip_run_multi): one host thread per device entry ------------------------------------------
+def test_run_multi_equals_per_sample_calls(api, oracle_c):
+    from dada2_amd.synth import make_sample
+    dereps = [make_sample(tperr1(), 500 + 40 * i, L=100, G=8, seed=900 + i, chunk=3000) for i in range(5)]
+    res = api.dada_uniques_multi(dereps, tperr1(), DadaOpts(), devices=(0, 0))   # two host threads share the one GPU here
+    assert len(res) == 5
+    for d, r in zip(dereps, res):
+        want = oracle_c.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())
+        assert_results_equal(r, want, p_rtol=P_RTOL)
+    from dada2_amd import _lib
+    bad = Derep(["ACGTNACGTA", "ACGTAACGTA"], np.array([5, 1], dtype=np.int32), np.full((2, 10), 30.0), np.zeros(0, dtype=np.int32))
+    with pytest.raises(_lib.Dada2HipError, match="sample 2"):
+        api.dada_uniques_multi([dereps[0], bad], tperr1(), DadaOpts(), devices=(0,))
+
+
+def test_nwalign_short_strings_and_limits(api):
+    """C_nwalign / C_nwvec accept any length (evaluate.cpp:18); the device helper path has no k-mer-size limit."""
+    from oracle import cport
+    for a, b in (("ACG", "AG"), ("A", "A"), ("ACGTT", "ACGT"), ("TTACGTACGTAA", "ACGTACGT")):
+        assert api.nwalign(a, b, band=-1) == cport.nwalign(a, b, band=-1), (a, b)
+    from dada2_amd import _lib
+    with pytest.raises(_lib.Dada2HipError) as ei:
+        api.nwalign("ACGTN", "ACGTA", band=-1)
+    assert ei.value.code == 4 and "A/C/G/T" in str(ei.value)
+
+
+def test_use_quals_off_still_checks_the_err_range(api):
+    """The output tables index err's columns by quality whatever USE_QUALS says: narrower err -> the reference's error."""
+    from dada2_amd import _lib
+    from dada2_amd.synth import make_sample
+    d = make_sample(tperr1(), 100, L=60, G=4, seed=302, chunk=2000)
+    co = DadaOpts().to_c()
+    co.use_quals = 0
+    with pytest.raises(_lib.Dada2HipError, match="exceeded range of err lookup table"):
+        api.dada_uniques(d.seqs, d.abundances, None, tperr1()[:, :20], d.quals, copts=co)
+
+
+# ---- the RCCL path of the sample-sharded driver, real resident-sample runner, world_size 1 -------------------------------
+def test_dada_multi_with_real_runner_under_nccl(api):
+    import socket
+    import torch
+    import torch.distributed as dist
+    from dada2_amd.multi import dada_multi
+    from dada2_amd.synth import make_sample
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dereps = [make_sample(tperr1(), 400, L=100, G=8, seed=100 + i, chunk=2000) for i in range(3)]
+        o = DadaOpts(OMEGA_C=0, MAX_CONSIST=3)
+        res, err, errs = dada_multi(dereps, None, self_consist=True, opts=o, dist=dist, device=torch.device("cuda", 0))
+        res1, err1, errs1 = api.dada(dereps, None, self_consist=True, opts=o)
+        assert np.array_equal(err, err1) and len(errs) == len(errs1)
+        for i in range(3):
+            assert_results_equal(res[i], res1[i], exact_float=True)
+    finally:
+        dist.destroy_process_group()
+
+
+# ---- BASELINE.json's sizes ------------------------------------------------------------------------------------------------
+def test_headline_1M_uniques_full_parity_vs_reference_itself(api):
+    """BASELINE.json's headline size: 1 000 000 unique 250-nt reads (bench.py's default workload, same seed).  EVERY output
+    of the GPU run against the reference's own C++ on all host cores (~1 min of CPU).  Skipped without oracle/_ref."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not present")
+    from dada2_amd.synth import make_sample
+    d = make_sample(tperr1(), 1_000_000, L=250, G=2048, seed=20260925 + 3)
+    got = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())
+    ref.set_threads(os.cpu_count() or 1)
+    want = ref.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts(), multithread=True)
+    ref.set_threads(1)
+    assert got.nclust == want.nclust > 300
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+def test_config5_long_reads_parity_vs_reference_itself(api):
+    """BASELINE.json configs[4] shape: ~1 500-nt reads (1 450..1 510, 3'-ragged), band 32, 94 quality columns, indels; sized
+    (50 k uniques, MAX_CLUST 16) so that the all-core reference finishes in about a minute."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not present")
+    from dada2_amd.synth import make_sample
+    err = extend_err(tperr1(), 93)
+    d = make_sample(err, 50_000, L=1510, G=128, seed=20260925 + 5, Lmin=1450, q_hi=93.0, q_lo=30.0, q_max=93, indel_rate=1e-4,
+                    ins_rate=1e-4, chunk=10_000)
+    o = DadaOpts(BAND_SIZE=32, MAX_CLUST=16)
+    got = api.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
+    ref.set_threads(os.cpu_count() or 1)
+    want = ref.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o, multithread=True)
+    ref.set_threads(1)
+    assert got.nclust == want.nclust == 16
+    assert_results_equal(got, want, p_rtol=P_RTOL)

@@ -1,0 +1,47 @@
+#!/bin/bash
+# One GPU-box session: parity tests, peak micro-benchmark, headline bench, rocprofv3 summaries.
+# Usage (through gpurun, from the repo root):  bash tools/gpu_round.sh <tag> [steps...]
+# Everything lands in gpurun_out/<tag>/ ; the summaries worth judging are copied into profiles/ afterwards.
+set -u
+TAG=${1:-r02a}; shift || true
+STEPS=${*:-"tests peaks bench3 bench2 prof3"}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+for s in $STEPS; do
+  t0=$(date +%s)
+  case $s in
+    tests)   timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=15 > $OUT/gputests.log 2>&1; echo "tests rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests.log ;;
+    tests_fast) timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not 1M and not config5 and not config2" --durations=10 > $OUT/gputests_fast.log 2>&1; echo "tests_fast rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_fast.log ;;
+    peaks)   timeout 300 tools/microbench peaks > $OUT/peaks.json 2> $OUT/peaks.err; echo "peaks rc=$?" >> $OUT/steps.log; cat $OUT/peaks.json ;;
+    bench3)  timeout 900 python bench.py --steps 5 --warmup 2 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; echo "bench3 rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3.json ;;
+    bench3full) timeout 1200 python bench.py --steps 5 --warmup 2 --cpu-full > $OUT/bench_cfg3_cpufull.json 2> $OUT/bench_cfg3_cpufull.err; echo "bench3full rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_cpufull.json ;;
+    bench3sc) timeout 900 python bench.py --steps 2 --warmup 1 --selfconsist > $OUT/bench_cfg3_selfconsist.json 2> $OUT/bench_cfg3_selfconsist.err; echo "bench3sc rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_selfconsist.json ;;
+    bench2)  timeout 600 python bench.py --config 2 --steps 10 --warmup 2 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; echo "bench2 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2.json ;;
+    bench4)  timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; echo "bench4 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg4.json ;;
+    bench5)  timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; echo "bench5 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg5.json ;;
+    prof3|prof2)
+             CFG=${s#prof}; P=$OUT/prof$CFG; mkdir -p $P
+             CMD="python $ROOT/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass"
+             ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $P/trace -o trace -- $CMD > $P/trace.log 2>&1 ); echo "$s rc=$?" >> $OUT/steps.log
+             python3 profiles/summarize.py $P ${TAG}_cfg$CFG $OUT/summaries "python bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass" > $P/summarize.log 2>&1 ;;
+    pmc3|pmc2)
+             CFG=${s#pmc}; P=$OUT/prof$CFG; mkdir -p $P
+             CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass"
+             ( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $P/pmc_fetch -o fetch -- $CMD > $P/pmc_fetch.log 2>&1 )
+             ( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d $P/pmc_write -o write -- $CMD > $P/pmc_write.log 2>&1 )
+             ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $P/pmc_valu -o valu -- $CMD > $P/pmc_valu.log 2>&1 )
+             python3 profiles/summarize.py $P ${TAG}_cfg$CFG $OUT/summaries "python bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass" > $P/summarize.log 2>&1
+             echo "$s done" >> $OUT/steps.log ;;
+    wcal)    for m in store_bytes store_wide read_wide; do ( cd /tmp && timeout 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/wcal_${m}_W -o pmc -- $ROOT/tools/microbench $m 268435456 > $OUT/wcal_${m}_W.log 2>&1 )
+               ( cd /tmp && timeout 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/wcal_${m}_F -o pmc -- $ROOT/tools/microbench $m 268435456 > $OUT/wcal_${m}_F.log 2>&1 ); done
+             echo "wcal done" >> $OUT/steps.log ;;
+  esac
+  echo "$s took $(( $(date +%s) - t0 )) s" >> $OUT/steps.log
+done
+# keep the pulled directory small: rocprof's raw databases are large, the CSVs are what is summarised
+find $OUT -name "*.db" -size +4M -delete 2>/dev/null
+du -sh $OUT
+cat $OUT/steps.log

@@ -1,0 +1,182 @@
+// microbench.hip — pins the two peaks bench.py's roofline fractions are quoted against, on the box itself
+// ("confirm peaks with a micro-benchmark on the box"), and provides known-byte-count store patterns for
+// calibrating rocprofv3's WRITE_SIZE counter (MI355X_MICROARCH.md §HBM: "WRITE_SIZE uncalibrated").
+//
+//   microbench peaks            -> one JSON object: int32 VALU lane-ops/s (add / max / cndmask / the NW step mix),
+//                                  HBM read GB/s (uint4 stream over 4 GiB), HBM copy GB/s
+//   microbench store_bytes N    -> the k_screen class-byte pattern: one lane in 16 stores ONE byte, N bytes in all
+//   microbench store_wide N     -> fully coalesced uint4 stores, N bytes in all
+//   microbench read_wide N      -> fully coalesced uint4 loads, N bytes in all   (FETCH_SIZE check: expect 1/2)
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip   (done by __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x)                                                                                    \
+  do {                                                                                           \
+    hipError_t e_ = (x);                                                                         \
+    if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } \
+  } while (0)
+
+// ---- integer VALU: 16 independent accumulators per lane, ITER x 16 instructions of one kind, written in asm so the
+// instruction count is exactly what is stated.  8 waves per SIMD resident (256-thread blocks, 8 blocks per CU).
+template <int KIND>
+__global__ __launch_bounds__(256) void k_valu(int *out, int a, int b, int iters) {
+  int x[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) x[k] = threadIdx.x + k * a;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (KIND == 0) asm volatile("v_add_u32 %0, %1, %2" : "=v"(x[k]) : "v"(x[k]), "v"(b));
+      if (KIND == 1) asm volatile("v_max_i32 %0, %1, %2" : "=v"(x[k]) : "v"(x[k]), "v"(b));
+      if (KIND == 2) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x[k]) : "v"(x[k]), "v"(b));
+      if (KIND == 3) {   // the shape of one NW cell: 3 adds, 2 max, 2 compare+select pairs -> 9 VALU, counted as 9
+        int d, u, l, e1, e;
+        asm volatile("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(x[k]), "v"(a));
+        asm volatile("v_add_u32 %0, %1, %2" : "=v"(u) : "v"(x[(k + 1) & 15]), "v"(b));
+        asm volatile("v_add_u32 %0, %1, %2" : "=v"(l) : "v"(x[(k + 15) & 15]), "v"(b));
+        asm volatile("v_max_i32 %0, %1, %2" : "=v"(e1) : "v"(l), "v"(d));
+        asm volatile("v_max_i32 %0, %1, %2" : "=v"(e) : "v"(u), "v"(e1));
+        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc" : "=v"(d) : "v"(l), "v"(d), "v"(a), "v"(b) : "vcc");
+        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc" : "=v"(u) : "v"(u), "v"(e1), "v"(d), "v"(b) : "vcc");
+        x[k] = e + u;
+      }
+    }
+  }
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) s += x[k];
+  if (s == 0x7fffffff) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_read(const uint4 *__restrict__ p, size_t n, uint32_t *out) {
+  uint32_t acc = 0;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+    acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  }
+  for (; i < n; i += stride) { const uint4 a = p[i]; acc += a.x ^ a.y ^ a.z ^ a.w; }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void k_copy(const uint4 *__restrict__ p, uint4 *__restrict__ q, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) q[i] = p[i];
+}
+__global__ __launch_bounds__(256) void k_store_wide(uint4 *__restrict__ q, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    q[i] = make_uint4((uint32_t)i, 1u, 2u, 3u);
+}
+// k_screen's class bytes: 16 lanes per unique, lane 0 of each group stores one byte; consecutive groups -> consecutive bytes
+__global__ __launch_bounds__(256) void k_store_bytes(uint8_t *__restrict__ q, size_t n) {
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (size_t base = (size_t)blockIdx.x * 16; base < n; base += (size_t)gridDim.x * 16) {
+    const size_t r = base + grp;
+    if (r < n && sub == 0) q[r] = (uint8_t)(r & 3);
+  }
+}
+
+static float time_ms(void (*launch)(void *), void *ctx, int reps) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  launch(ctx);
+  CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < reps; r++) {
+    CK(hipEventRecord(a, 0));
+    launch(ctx);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (ms < best) best = ms;
+  }
+  CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+  return best;
+}
+
+struct ValuCtx { int *out; int kind, iters, grid; };
+static void launch_valu(void *c) {
+  ValuCtx *v = (ValuCtx *)c;
+  switch (v->kind) {
+    case 0: hipLaunchKernelGGL(k_valu<0>, dim3(v->grid), dim3(256), 0, 0, v->out, 3, 5, v->iters); break;
+    case 1: hipLaunchKernelGGL(k_valu<1>, dim3(v->grid), dim3(256), 0, 0, v->out, 3, 5, v->iters); break;
+    case 2: hipLaunchKernelGGL(k_valu<2>, dim3(v->grid), dim3(256), 0, 0, v->out, 3, 5, v->iters); break;
+    default: hipLaunchKernelGGL(k_valu<3>, dim3(v->grid), dim3(256), 0, 0, v->out, 3, 5, v->iters);
+  }
+}
+struct MemCtx { uint4 *p, *q; size_t n; uint32_t *out; int grid; };
+static void launch_read(void *c) { MemCtx *m = (MemCtx *)c; hipLaunchKernelGGL(k_read, dim3(m->grid), dim3(256), 0, 0, m->p, m->n, m->out); }
+static void launch_copy(void *c) { MemCtx *m = (MemCtx *)c; hipLaunchKernelGGL(k_copy, dim3(m->grid), dim3(256), 0, 0, m->p, m->q, m->n); }
+
+int main(int argc, char **argv) {
+  const char *mode = argc > 1 ? argv[1] : "peaks";
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  if (!strcmp(mode, "peaks")) {
+    int *out;
+    CK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
+    const int iters = 4096;
+    double tops[4];
+    const int per_iter[4] = {16, 16, 16, 16 * 9};
+    for (int kind = 0; kind < 4; kind++) {
+      ValuCtx v{out, kind, iters, cus * 8};
+      const float ms = time_ms(launch_valu, &v, 5);
+      tops[kind] = (double)v.grid * 256.0 * iters * per_iter[kind] / (ms * 1e-3) / 1e12;
+    }
+    const size_t bytes = (size_t)4 << 30;   // 4 GiB >> 256 MiB Infinity Cache
+    MemCtx m{};
+    CK(hipMalloc(&m.p, bytes)); CK(hipMalloc(&m.q, bytes)); CK(hipMalloc(&m.out, 4));
+    CK(hipMemset(m.p, 1, bytes)); CK(hipMemset(m.q, 0, bytes));
+    m.n = bytes / 16;
+    double best_read = 0, best_copy = 0;
+    int best_grid = 0;
+    for (int mult : {4, 8, 16, 32}) {
+      m.grid = cus * mult;
+      const float ms = time_ms(launch_read, &m, 5);
+      const double gbs = (double)bytes / (ms * 1e-3) / 1e9;
+      if (gbs > best_read) { best_read = gbs; best_grid = m.grid; }
+      const float mc = time_ms(launch_copy, &m, 3);
+      const double cg = 2.0 * (double)bytes / (mc * 1e-3) / 1e9;
+      if (cg > best_copy) best_copy = cg;
+    }
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"valu_int32_tops\": %.2f, \"valu_add_tops\": %.2f, "
+           "\"valu_max_tops\": %.2f, \"valu_cndmask_tops\": %.2f, \"valu_nw_cell_mix_tops\": %.2f, \"hbm_read_gbs\": %.1f, "
+           "\"hbm_copy_gbs\": %.1f, \"hbm_read_grid\": %d, \"note\": \"valu_int32_tops = mean of add/max/cndmask lane-ops/s, 16 "
+           "independent chains per lane, 8 waves/SIMD; hbm_read = uint4 stream over 4 GiB, best of 5\"}\n",
+           prop.gcnArchName, cus, prop.clockRate / 1000, (tops[0] + tops[1] + tops[2]) / 3.0, tops[0], tops[1], tops[2], tops[3],
+           best_read, best_copy, best_grid);
+    return 0;
+  }
+  const size_t n = argc > 2 ? (size_t)atoll(argv[2]) : ((size_t)1 << 28);
+  if (!strcmp(mode, "store_bytes")) {
+    uint8_t *q;
+    CK(hipMalloc(&q, n));
+    hipLaunchKernelGGL(k_store_bytes, dim3(2048), dim3(256), 0, 0, q, n);
+    CK(hipDeviceSynchronize());
+    printf("{\"mode\": \"store_bytes\", \"algorithmic_bytes\": %zu}\n", n);
+  } else if (!strcmp(mode, "store_wide")) {
+    uint4 *q;
+    CK(hipMalloc(&q, n));
+    hipLaunchKernelGGL(k_store_wide, dim3(cus * 8), dim3(256), 0, 0, q, n / 16);
+    CK(hipDeviceSynchronize());
+    printf("{\"mode\": \"store_wide\", \"algorithmic_bytes\": %zu}\n", n);
+  } else if (!strcmp(mode, "read_wide")) {
+    uint4 *p;
+    uint32_t *out;
+    CK(hipMalloc(&p, n)); CK(hipMalloc(&out, 4));
+    CK(hipMemset(p, 1, n));
+    hipLaunchKernelGGL(k_read, dim3(cus * 8), dim3(256), 0, 0, p, n / 16, out);
+    CK(hipDeviceSynchronize());
+    printf("{\"mode\": \"read_wide\", \"algorithmic_bytes\": %zu}\n", n);
+  } else {
+    fprintf(stderr, "usage: microbench peaks | store_bytes N | store_wide N | read_wide N\n");
+    return 1;
+  }
+  return 0;
+}
