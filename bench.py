@@ -269,7 +269,7 @@ def rooflines(st, L, band, cfg):
     nw_ops = st["nw_cells"] * INT_OPS_PER_CELL
     # algorithmic bytes the screen must read per compared unique: its ordered k-mer record row 2*(L-4) B + 6 B of
     # scalars (the reference streams 1 544 B for the same decision) - none for greedy-skipped uniques
-    screen_bytes = st["ncompare"] * (2 * (L - 4) + 6) - st["nskipped"] * 2 * (L - 4)
+    screen_bytes = st["screen_bytes"]      # counted by the library: bytes its screen launches had to read (see dada2hip.h)
     sampled = bool(st.get("kernel_times_sampled", 1))
     timing = "extrapolated from sampled launches" if sampled else "every launch event-timed (DADA2HIP_PROFILE=1)"
     roof_nw = {"kernel": "k_nw_ad / k_nw_adw (banded NW + traceback + lambda)", "bound": "valu",

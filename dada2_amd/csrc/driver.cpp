@@ -720,8 +720,9 @@ struct Run {
     if (spec) { spec_ctr = ctr; spec_launched = true; st.ms_screen += ms_since(t0); return; }
     if (ci == 0) {   // round 0 is followed by b_p_update directly (Rmain.cpp:309-311)
       const int ev = ev_begin(EV_SHUFFLE, profile_all);
-      launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p,
-                   ro()->cnt, stq);
+      if (use_v2) launch2_store0(E2, s->d_lambda.p, s->d_ham.p, s->d_cls.p, ctr, stq);
+      else launch_store(P, D, ci, centre, (double)(uint32_t)s->total_reads, s->d_lambda.p, s->d_ham.p, ctr, s->d_cls.p,
+                        ro()->cnt, stq);
       ev_end(ev);
     }
     else {         // later rounds: the store filter rides in front of the round's first shuffle
@@ -971,12 +972,12 @@ struct Run {
   // several, the host recomputes their p-values with its own libm and applies b_bud's rule itself (cluster.cpp:284-308:
   // p ascending, reads descending, first in (partition, slot) scan order), which needs the slot order to be current.
   // The birth p-value reported is always the host's (bit-identical to the CPU reference given the same pgamma source).
-  Birth decide_bud() {
-    const BudOut &h = h_rout.p->bud;
+  Birth decide_bud() { return decide_bud(h_rout.p->bud); }
+  Birth decide_bud(const BudOut &h) {
     if (!h.valid) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: bud evaluation not valid"};
     check_errflag(h.err_flag);
-    st.nstored = (uint64_t)h.node_count;
-    if ((size_t)h.node_count + (size_t)N > (size_t)P.node_cap)
+    if (!use_v2) st.nstored = (uint64_t)h.node_count;
+    if (!use_v2 && (size_t)h.node_count + (size_t)N > (size_t)P.node_cap)
       grow_nodes(std::max((size_t)P.node_cap * 2, (size_t)h.node_count + 2 * (size_t)N));
     auto pick = [&](int track, BudTie &out, double &p_out) -> bool {
       const int n = h.nties[track];
@@ -1094,6 +1095,248 @@ struct Run {
     if (f & 2) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: comparison store overflow"};
   }
 
+  // =================================================================================================================
+  // Round engine v2 (engine.h): batched multi-centre compares, device-driven rounds, the host trailing the device.
+  // Used when the rounds run on the cooperative NW kernel and nothing forces the plain loop; DADA2HIP_ENGINE=classic
+  // keeps the round-1 loop (the parity tests run both).
+  bool use_v2 = false;
+  Eng2 E2{};
+  DevBuf<double> v2_lam0, v2_clam;
+  DevBuf<uint32_t> v2_ham0, v2_cham;
+  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn;
+  DevBuf<CompBlk> v2_blk;
+  DevBuf<Ctl2> v2_ctl;
+  DevBuf<Round2Out> v2_dblk;
+  DevBuf<uint16_t> v2_bcls, v2_full, v2_ord;
+  DevBuf<uint2> v2_tab8;
+  DevBuf<unsigned long long> v2_nwl, v2_gll;
+  PinBuf<Round2Out> v2_hblk;
+  int v2_nbuf = 8, v2_depth = 2;
+  long v2_enq = 0, v2_cons = 0;
+  uint64_t v2_miss_launches = 0;
+  struct EnqRec { int ev_screen, ev_nw; };
+  std::vector<EnqRec> v2_enqrec;      // per enqueued block (index = sequence number - 1)
+
+  bool want_v2() const {
+    const char *e = getenv("DADA2HIP_ENGINE");
+    if (e && !strcmp(e, "classic")) return false;
+    if (plain || no_auto || !rounds_use_coop()) return false;
+    if (s->D.N < 2) return false;
+    return true;
+  }
+  void v2_bind() {   // (re)build the by-value kernel argument block after any (re)allocation
+    E2.P = P; E2.S = s->D;
+    E2.T.lam0 = v2_lam0.p; E2.T.ham0 = v2_ham0.p; E2.T.head = v2_head.p; E2.T.blk = v2_blk.p; E2.T.blk_count = v2_blkcount.p;
+    E2.T.blk_cap = (int32_t)std::min<size_t>(v2_blk.n, 0x7FFFFFF0u);
+    E2.C.NBUF = v2_nbuf; E2.C.lam = v2_clam.p; E2.C.ham = v2_cham.p; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
+    E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.nw_list = v2_nwl.p; E2.C.gl_list = v2_gll.p;
+    E2.C.list_n = v2_listn.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15; E2.C.list_cap = v2_nwl.n;
+    E2.ctl = v2_ctl.p; E2.dblk = v2_dblk.p; E2.hblk = v2_hblk.p; E2.dlt = v2_dlt.p; E2.movers = v2_movers.p;
+    E2.partial = d_partial.p; E2.ties0 = d_ties0.p; E2.ties1 = d_ties1.p; E2.ccap = ccap;
+    E2.greedy = o.greedy; E2.detect_singletons = o.detect_singletons;
+    E2.total_reads = (double)(uint32_t)s->total_reads; E2.omegaA = o.omegaA; E2.omegaP = o.omegaP;
+    E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
+    E2.sp = sp; E2.thresh = d_thresh_round.p; E2.max_shuffle = MAX_SHUFFLE;
+  }
+  void v2_alloc(int max_clust) {
+    const size_t n = (size_t)N;
+    if (const char *e = getenv("DADA2HIP_V2_NBUF")) v2_nbuf = std::max(1, std::min(32, atoi(e)));   // (k2_birth keeps the slot table in LDS)
+    if (const char *e = getenv("DADA2HIP_V2_DEPTH")) v2_depth = std::max(1, std::min(RING2 - 1, atoi(e)));
+    hipStream_t stq = s->stream;
+    v2_lam0.alloc(n); v2_ham0.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
+    {
+      size_t cap0 = std::max<size_t>(2 * n, (size_t)1 << 16);
+      if (const char *e = getenv("DADA2HIP_NODE_CAP")) cap0 = std::max<size_t>((size_t)atoll(e), n + 16);   // test knob: forces growth
+      if (v2_blk.n < cap0) v2_blk.alloc(cap0);
+    }
+    v2_ctl.alloc(1); v2_dblk.alloc(RING2); v2_hblk.alloc(RING2);
+    v2_dlt.alloc((size_t)SH_CHAIN * ccap);
+    v2_movers.alloc((size_t)RING2 * SH_CHAIN * 3 * n);
+    const size_t slots = (size_t)v2_nbuf * KB_MAX;
+    v2_clam.alloc(slots * n); v2_cham.alloc(slots * n); v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
+    v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
+    v2_nwl.alloc((size_t)KB_MAX * n); v2_gll.alloc((size_t)KB_MAX * n); v2_listn.alloc(2);
+    D2_HIP(hipMemsetAsync(v2_blkcount.p, 0, 4, stq));
+    D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));
+    D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_CHAIN * ccap * 4, stq));
+    D2_HIP(hipMemsetAsync(v2_slotc.p, 0xFF, slots * 4, stq));
+    D2_HIP(hipMemsetAsync(v2_listn.p, 0, 8, stq));
+    for (int k = 0; k < RING2; k++) v2_hblk.p[k].seq = 0;
+    Ctl2 c;
+    memset(&c, 0, sizeof c);
+    c.nclust = 1; c.centre = (int32_t)bi[0].center; c.slot = 0; c.max_clust = max_clust;
+    for (int k = 0; k < KB_MAX; k++) c.bcentre[k] = -1;
+    D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipStreamSynchronize(stq));   // `c` is a local
+    v2_enq = v2_cons = 0;
+    v2_miss_launches = 0;
+    v2_enqrec.clear();
+    v2_bind();
+  }
+
+  // one chain: [shuffle x nlev][b_p_update + b_bud arg-min + ties][birth / plan / publish]; a full round is a chain with the
+  // batch compare in front (no-ops on a cache hit) and the round's store filter in its first shuffle
+  void v2_enqueue_chain(int nlev, bool with_compare, bool store) {
+    hipStream_t stq = s->stream;
+    EnqRec rec{-1, -1};
+    if (with_compare) {
+      rec.ev_screen = ev_begin(EV_SCREEN, profile_all, /*spec=*/true);
+      launch2_screen_multi(E2, stq);
+      ev_end(rec.ev_screen);
+      rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
+      launch_nw_ad_multi(E2, ap, s->d_err.p, stq);
+      ev_end(rec.ev_nw);
+    }
+    int ev = ev_begin(EV_SHUFFLE, profile_all && nlev > 0);
+    for (int l = 0; l < nlev; l++) launch2_shuffle(E2, l, store && l == 0, stq);
+    ev_end(ev);
+    ev = ev_begin(EV_PVAL, profile_all);
+    launch2_eval(E2, nlev, s->h_reads[bi[0].center], stq);
+    ev_end(ev);
+    ev = ev_begin(EV_BIRTH, profile_all);
+    launch2_birth(E2, nlev, stq);
+    ev_end(ev);
+    v2_enqrec.push_back(rec);
+    v2_enq++;
+  }
+
+  const Round2Out &v2_wait_block() {
+    const int ring = (int)(v2_cons % RING2);
+    const int32_t want = (int32_t)(v2_cons + 1);
+    volatile int32_t *seqp = &v2_hblk.p[ring].seq;
+    const auto tw = clk::now();
+    const bool polite = wait_blocks();
+    for (unsigned spins = 0; *seqp != want; spins++) {
+      cpu_relax();
+      if (polite && spins > 64) { struct timespec ts{0, 20000}; nanosleep(&ts, nullptr); }
+      if ((spins & 0xFFFF) == 0xFFFF || (polite && (spins & 0xFF) == 0xFF)) {
+        hipError_t e = hipStreamQuery(s->stream);
+        if (e != hipSuccess && e != hipErrorNotReady)
+          throw d2::DeviceError{DADA2HIP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e) + " (round result)"};
+        if (e == hipSuccess && *seqp != want)
+          throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: the device did not publish the round result"};
+        if (ms_since(tw) > wait_timeout_s() * 1e3)
+          throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: timed out waiting for the round result"};
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    v2_cons++;
+    return v2_hblk.p[ring];
+  }
+
+  // bring the host mirror up to date with one published block: the chain's moves in call order, then the counters
+  void v2_replay(const Round2Out &b, long seq) {
+    int tot = 0;
+    for (int l = 0; l < b.nsh; l++) tot += b.cnt[l];
+    if (tot <= MOV_INLINE2) {
+      int off = 0;
+      for (int l = 0; l < b.nsh; l++) { replay_moves(b.mov + 3 * off, b.cnt[l]); off += b.cnt[l]; }
+    } else {
+      const int ring = (int)((seq - 1) % RING2);
+      for (int l = 0; l < b.nsh; l++) {
+        const int nm = b.cnt[l];
+        if (!nm) continue;
+        h_big.alloc((size_t)3 * nm);
+        D2_HIP(hipMemcpyAsync(h_big.p, v2_movers.p + ((size_t)(ring * SH_CHAIN + l)) * 3 * N, (size_t)3 * nm * 4, hipMemcpyDeviceToHost,
+                              s->side));
+        D2_HIP(hipStreamSynchronize(s->side));
+        replay_moves(h_big.p, nm);
+      }
+    }
+    st.nshuffle += (uint64_t)b.nsh;
+    st.nnw += b.stat[0]; st.ngapless += b.stat[1]; st.nshroud += b.stat[2]; st.nskipped += b.stat[3];
+    st.nstored = (uint64_t)N + (uint64_t)b.blk_count;     // (blocks, not entries: an upper bound of 3 entries each)
+    if (b.err_flag & 4) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "N-W Align out of range."};
+    if (b.err_flag & 8) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: a cached compare lacks a comparison its round needs"};
+    check_errflag(b.err_flag);
+  }
+
+  void v2_grow(const Round2Out &b) {
+    sync_spin(s->stream);
+    if (nclust_dev + 2 > ccap) {
+      grow_clusters(std::max(ccap * 2, nclust_dev + 2));
+      v2_dlt.alloc((size_t)SH_CHAIN * ccap);                       // (deltas are all zero between chains)
+      D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_CHAIN * ccap * 4, s->stream));
+    }
+    if ((size_t)b.blk_count + (size_t)N > v2_blk.n) {
+      const size_t cap = std::max(v2_blk.n * 2, (size_t)b.blk_count + 2 * (size_t)N);
+      DevBuf<CompBlk> nb;
+      nb.alloc(cap);
+      D2_HIP(hipMemcpyAsync(nb.p, v2_blk.p, (size_t)b.blk_count * sizeof(CompBlk), hipMemcpyDeviceToDevice, s->stream));
+      D2_HIP(hipStreamSynchronize(s->stream));
+      std::swap(v2_blk.p, nb.p); std::swap(v2_blk.n, nb.n);
+    }
+    v2_bind();
+  }
+
+  // run_dada's loop (Rmain.cpp:312-331) with the device in charge of the rounds
+  void run_v2(int max_clust) {
+    auto t0 = clk::now();
+    v2_enqueue_chain(0, false, false);                        // b_p_update after round 0 + the first b_bud
+    bool done = false;
+    while (!done) {
+      while (v2_enq - v2_cons < v2_depth) v2_enqueue_chain(SH_CHAIN, true, true);
+      const long seq = v2_cons + 1;
+      const Round2Out &b = v2_wait_block();
+      if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
+        throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
+      v2_replay(b, seq);
+      const EnqRec &rec = v2_enqrec[seq - 1];
+      if (b.nbatch > 0 && b.nlev > 0 && b.nsh > 0) {           // (this chain's compare really ran: a miss)
+        v2_miss_launches++;
+        if (rec.ev_screen >= 0) evs[rec.ev_screen].ok = 1;
+        if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
+      }
+      if (b.nlev > 0 && b.halt != H2_SHUFFLE_MORE) { }        // (a round's commit is complete)
+      switch (b.halt) {
+        case H2_NONE: {                                        // birth applied on the device: book it
+          Birth bb = decide_bud(b.bud);
+          if (!bb.yes || bb.type != 'A' || bb.c.raw != b.bud.ties[0][0].raw)
+            throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: device and host bud decisions differ"};
+          logf("\nNew Cluster C%i:", bb.newi);
+          nclust_dev = bb.newi + 1;
+          record_birth(bb);
+          st.ncompare += (uint64_t)N;
+          break;
+        }
+        case H2_NO_BIRTH: {
+          Birth bb = decide_bud(b.bud);
+          if (bb.yes) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: device and host bud decisions differ"};
+          done = true;
+          break;
+        }
+        case H2_MAXCLUST: done = true; break;
+        case H2_HOST_DECIDE:
+        case H2_CAPACITY: {
+          sync_spin(s->stream);                                // the launches queued behind the halt are no-ops: drain them
+          v2_enq = v2_cons;
+          v2_enqrec.resize((size_t)v2_cons);
+          if (b.halt == H2_CAPACITY) v2_grow(b);
+          Birth bb = decide_bud(b.bud);
+          if (!bb.yes) { done = true; break; }
+          if (bb.newi + 2 > ccap) v2_grow(b);
+          logf("\nNew Cluster C%i:", bb.newi);
+          launch2_host_birth(E2, bb.c.raw, bb.c.from, s->stream);
+          nclust_dev = bb.newi + 1;
+          record_birth(bb);
+          st.ncompare += (uint64_t)N;
+          break;
+        }
+        case H2_SHUFFLE_MORE: {                                // more than SH_CHAIN moving shuffles: continue the same round
+          sync_spin(s->stream);
+          v2_enq = v2_cons;
+          v2_enqrec.resize((size_t)v2_cons);
+          launch2_resume(E2, s->stream);
+          v2_enqueue_chain(SH_CHAIN, false, false);
+          break;
+        }
+        default: throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: unknown halt code"};
+      }
+    }
+    sync_spin(s->stream);                                      // no-op launches queued behind the final halt
+    st.ms_bookkeep += ms_since(t0);
+  }
+
   uint64_t nw_cells_per_alignment() const {
     // algorithmic DP cells of one alignment: (L1 + L2 + 1) anti-diagonals x (band + 1)
     const int L = s->D.maxlen;
@@ -1179,13 +1422,16 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   }
 
   run.nclust_dev = 1;
-  run.compare_round(0, (int)run.bi[0].center, 1.0);   // Rmain.cpp:309-310: no k-mer screen in round 0
   int max_clust = opts->max_clust < 1 ? N : opts->max_clust;
   run.max_clust_run = max_clust;
+  run.use_v2 = max_clust > 1 && run.want_v2();
+  if (run.use_v2) run.v2_alloc(max_clust);
+  run.compare_round(0, (int)run.bi[0].center, 1.0);   // Rmain.cpp:309-310: no k-mer screen in round 0
   // run_dada's loop (Rmain.cpp:312-331), rotated: every iteration ends with b_p_update + the b_bud that opens
   // the reference's next iteration, so one device round trip serves both.  After a decision the next round's
   // kernels are launched first; the host mirror (moves replay, birth record) is updated while the GPU works.
-  if (run.nclust_dev < max_clust) {
+  if (run.use_v2) run.run_v2(max_clust);
+  else if (run.nclust_dev < max_clust) {
     run.round_tail(false);                            // b_p_update after round 0, then the first b_bud
     for (;;) {
       Run::Birth b = run.decide_bud();
@@ -1296,14 +1542,18 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     run.d_cl_of_centre.alloc(N); run.d_ph_ji.alloc(2 * (size_t)cap); run.d_ph_lam.alloc(cap); run.d_ph_n.alloc(1);
     D2_HIP(hipMemcpyAsync(run.d_cl_of_centre.p, cl_of_centre.data(), (size_t)N * 4, hipMemcpyHostToDevice, stq));
     D2_HIP(hipMemsetAsync(run.d_ph_n.p, 0, 4, stq));
-    launch_posthoc(run.P, D, run.d_cl_of_centre.p, run.d_ph_ji.p, run.d_ph_lam.p, run.d_ph_n.p, cap, stq);
+    auto posthoc = [&](int capv) {
+      if (run.use_v2) launch2_posthoc(run.E2, run.d_cl_of_centre.p, run.d_ph_ji.p, run.d_ph_lam.p, run.d_ph_n.p, capv, stq);
+      else launch_posthoc(run.P, D, run.d_cl_of_centre.p, run.d_ph_ji.p, run.d_ph_lam.p, run.d_ph_n.p, capv, stq);
+    };
+    posthoc(cap);
     int32_t n = 0;
     D2_HIP(hipMemcpyAsync(&n, run.d_ph_n.p, 4, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
     if (n > cap) {   // dense centre-vs-centre store: retry with the exact size
       run.d_ph_ji.alloc(2 * (size_t)n); run.d_ph_lam.alloc(n);
       D2_HIP(hipMemsetAsync(run.d_ph_n.p, 0, 4, stq));
-      launch_posthoc(run.P, D, run.d_cl_of_centre.p, run.d_ph_ji.p, run.d_ph_lam.p, run.d_ph_n.p, n, stq);
+      posthoc(n);
       D2_HIP(hipStreamSynchronize(stq));
     }
     ph_ji.resize(2 * (size_t)n); ph_lam.resize(n);
@@ -1370,10 +1620,12 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     D2_HIP(hipMemcpy(tot, run.P.totals, 32, hipMemcpyDeviceToHost));
     run.check_errflag(ef);
     check_nw_flag(s);
-    run.st.nnw += tot[0]; run.st.ngapless += tot[1]; run.st.nshroud = tot[2]; run.st.nskipped = tot[3];
-    int32_t cnt = 0;
-    D2_HIP(hipMemcpy(&cnt, run.P.node_count, 4, hipMemcpyDeviceToHost));
-    run.st.nstored = (uint64_t)cnt;
+    run.st.nnw += tot[0]; run.st.ngapless += tot[1]; run.st.nshroud += tot[2]; run.st.nskipped += tot[3];
+    if (!run.use_v2) {
+      int32_t cnt = 0;
+      D2_HIP(hipMemcpy(&cnt, run.P.node_count, 4, hipMemcpyDeviceToHost));
+      run.st.nstored = (uint64_t)cnt;
+    }
     // kernel times: event-timed launches, summed per kernel class.  Sampled mode: the per-round NW and screen launches
     // are extrapolated from the sampled ones; DADA2HIP_PROFILE=1: every launch was timed, the sums are exact.
     float ems;
@@ -1406,6 +1658,13 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       run.st.kernel_times_sampled = 1;
     }
     run.st.nw_cells = run.st.nnw * run.nw_cells_per_alignment();
+    {   // algorithmic bytes the screen launches had to read: a unique's ordered k-mer record + 6 B of scalars
+      const uint64_t row = 2 * (uint64_t)(D.maxlen - KMER_SIZE + 1);
+      if (run.use_v2) {
+        run.st.screen_bytes = (uint64_t)N * (row + 6) * (1 + run.v2_miss_launches);   // round 0 + one pass per batch compare
+        if (!run.profile_all) run.st.screen_kernel_launches = 1 + run.v2_miss_launches;
+      } else run.st.screen_bytes = (run.st.ncompare - run.st.nskipped) * row + run.st.ncompare * 6;
+    }
   }
 
   // ---- assemble the six outputs -------------------------------------------------------------------

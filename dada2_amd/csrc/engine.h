@@ -205,6 +205,132 @@ void launch_nw_adw(const SampleDev &S, int centre, const int32_t *d_chunk_centre
                    hipStream_t st);
 int nw_adw_apw(const SampleDev &S, const AlignParams &ap);
 
+// =================================================================================================================
+// Round engine v2: batched multi-centre compares + device-driven rounds.
+//
+//  * A compare is no longer tied to its round: when the centre of the coming round has no comparisons yet, ONE pass
+//    over the k-mer records screens every unique against up to KB_MAX centres at once - the coming centre plus the
+//    candidates that the bud ordering makes likely to be born next - and one NW launch aligns all surviving pairs.
+//    The results (class, lambda, hamming per unique) stay in a cache of NBUF batches; the round of a cached centre
+//    commits them without touching the k-mer records or the aligner again (HBM bytes per comparison / KB_MAX, aligner
+//    launches with KB_MAX rounds of work).  Exactness: a comparison depends only on the two uniques, err and the
+//    options; the greedy skip (cluster.cpp:127-130) is re-applied at commit time with the lock state of that moment
+//    (locks only grow between a compare and its commit, except for the centre itself).
+//  * A round is a fixed sequence of launches whose parameters (centre, partition count, cache slot, which shuffles
+//    still have to run) live in a device control block: the host enqueues rounds AHEAD of the results it has seen and
+//    trails the device, replaying the published moves / births on its mirror.  Whenever the decision is not the
+//    device's to take (exact or near ties, prior births, no birth, more than SH_CHAIN shuffles, capacity) the device
+//    halts - every later launch becomes a no-op - and the host takes over as in the classic loop.
+constexpr int KB_MAX = 8;          // centres per batch compare (one byte lane each in the packed count table)
+constexpr int SH_CHAIN = 4;        // b_shuffle2 calls enqueued per chain (the first unconditional, the rest guarded)
+constexpr int RING2 = 4;           // result blocks / mover lists in flight
+constexpr int MOV_INLINE2 = 1024;  // movers published inline per chain (all its shuffles, concatenated)
+
+// stored comparisons of one unique (Bi::comp entries that name it): the round-0 entry lives in lam0/ham0 (every
+// unique has one, containers.cpp:39 + cluster.cpp:189), later ones in a chain of 64-byte blocks, newest block first
+struct alignas(64) CompBlk {
+  int32_t next, cnt;
+  int32_t i[3];
+  uint32_t ham[3];
+  double lam[3];
+  int32_t pad[2];
+};
+static_assert(sizeof(CompBlk) == 64, "CompBlk is one 64-byte line");
+struct Store2 {
+  double *lam0 = nullptr;
+  uint32_t *ham0 = nullptr;
+  int32_t *head = nullptr;
+  CompBlk *blk = nullptr;
+  int32_t *blk_count = nullptr;
+  int32_t blk_cap = 0;
+};
+
+enum : int32_t { H2_NONE = 0, H2_NO_BIRTH, H2_HOST_DECIDE, H2_SHUFFLE_MORE, H2_CAPACITY, H2_MAXCLUST };
+
+struct Ctl2 {
+  int32_t state;        // 0 = running, 1 = halted (every launch returns at once)
+  int32_t halt;         // H2_* of the last halt
+  int32_t nclust;       // partitions that exist
+  int32_t centre;       // centre (unique index) of the round in flight = centre_of[nclust - 1]
+  int32_t slot;         // cache slot holding the comparisons against `centre`
+  int32_t nbatch;       // centres the round's batch compare has to process (0 = cache hit, nothing to launch)
+  int32_t bbuf;         // batch buffer it fills (slot = bbuf * KB_MAX + position)
+  int32_t next_bbuf;    // FIFO cursor over the batch buffers
+  int32_t pub_seq;      // result blocks published so far
+  int32_t nsh_base;     // shuffles of the round in flight executed by earlier chains
+  int32_t max_clust;
+  int32_t scan_hint;    // (reserved)
+  int32_t bcentre[KB_MAX];
+  uint32_t breads[KB_MAX];
+  int32_t blen[KB_MAX];
+};
+
+struct Cache2 {
+  int32_t NBUF = 0;               // batch buffers
+  double *lam = nullptr;          // [NBUF * KB_MAX][N]
+  uint32_t *ham = nullptr;        // [NBUF * KB_MAX][N]
+  uint16_t *bcls = nullptr;       // [NBUF][Npad]  2 bits per batch position: CLS_*
+  int32_t *slot_centre = nullptr; // [NBUF * KB_MAX]  unique index or -1
+  uint2 *tab8 = nullptr;          // [1024]  byte k = min(count of the 5-mer in batch centre k, 63)
+  uint16_t *full = nullptr;       // [KB_MAX][1024] full counts (heavy k-mer correction)
+  uint16_t *ord = nullptr;        // [KB_MAX][LK] ordered 5-mers, 0xFFFF past the end
+  unsigned long long *nw_list = nullptr, *gl_list = nullptr;   // unique | position << 32
+  int32_t *list_n = nullptr;      // [2]
+  size_t Npad = 0, list_cap = 0;
+};
+
+struct Round2Out {
+  int32_t seq;                    // host copy only: written last by k2_birth when it publishes the block
+  int32_t halt;                   // H2_*
+  int32_t nclust;                 // partitions after this block's birth, if any
+  int32_t birth_applied;          // 1: bud.ties[0][0] became partition nclust - 1 on the device
+  int32_t nlev;                   // shuffle launches of the chain
+  int32_t nsh;                    // ... of which executed
+  int32_t cnt[SH_CHAIN];          // movers of each
+  int32_t nbatch;                 // centres compared by this round's batch launch (0 = hit)
+  int32_t slot;
+  int32_t err_flag, blk_count;
+  int32_t pad0[4];
+  unsigned long long stat[4];     // commit-time classes of the round's comparisons: NW, gapless, shrouded, greedy-skipped
+  BudOut bud;
+  int32_t mov[3 * MOV_INLINE2];   // (unique, from, to) of the chain's movers, shuffles concatenated
+};
+static_assert(sizeof(Round2Out) % 16 == 0, "Round2Out is published as uint4s");
+
+struct Eng2 {   // everything the v2 kernels share, passed by value
+  PartState P;
+  SampleDev S;
+  Store2 T;
+  Cache2 C;
+  Ctl2 *ctl;
+  Round2Out *dblk;                // [RING2] device-side result blocks
+  Round2Out *hblk;                // [RING2] pinned host copies
+  int32_t *dlt;                   // [SH_CHAIN][ccap] partition-read deltas of the chain's shuffles
+  int32_t *movers;                // [RING2][SH_CHAIN][3 N]
+  void *partial;                  // block partials of the bud arg-min
+  int32_t *ties0, *ties1;         // full tie lists
+  int32_t ccap;
+  int32_t greedy, detect_singletons;
+  double total_reads, omegaA, omegaP;
+  BudParams bp;
+  ScreenParams sp;
+  const int32_t *thresh;
+  int32_t max_shuffle;
+};
+
+void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
+                    hipStream_t st);
+void launch2_screen_multi(const Eng2 &E, hipStream_t st);
+void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
+void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);     // b_p_update + b_bud arg-min + tie listing
+void launch2_birth(const Eng2 &E, int nlev, hipStream_t st);                          // decide / apply / plan / publish
+void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st);            // the host's decision applied + plan; resumes
+void launch2_resume(const Eng2 &E, hipStream_t st);
+void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
+                     int cap, hipStream_t st);
+// NW over the batch work lists (pairs of unique and batch position): k_nw_ad with per-alignment centres
+void launch_nw_ad_multi(const Eng2 &E, const AlignParams &ap, const double *d_err, hipStream_t st);
+
 void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint8_t *d_prior, double *d_out,
                     hipStream_t st);
 

@@ -1,0 +1,742 @@
+// rounds2.inc.hip — kernels of round engine v2 (engine.h); included by kernels.hip inside namespace d2.
+//   k2_screen_multi   kmer_dist_SSEi_8 / kord_dist_SSEi + raw_align's dispatch against up to KB_MAX centres per pass
+//                     (kmers.cpp:29-150, nwalign_endsfree.cpp:10-73)
+//   k2_store0         store filter of round 0 (cluster.cpp:179-201, every unique is kept: E_minmax starts at -999)
+//   k2_shuffle        store filter of a later round at commit time + b_shuffle2 (cluster.cpp:179-266)
+//   k2_pupdate/_ties  b_p_update + b_bud's arg-min (pval.cpp:14-40, cluster.cpp:274-310)
+//   k2_birth          the unambiguous birth (cluster.cpp:313-347), the plan of the coming round's compare, publication
+// Every launch reads what it has to do from the device control block (Ctl2): the host enqueues rounds ahead of the
+// results it has seen.
+
+// ---- chain bookkeeping: which shuffle launches of the chain ran, and whether the evaluation after them stands -------
+struct Chain2 { int nexec; bool eval_ok; };
+static __device__ __forceinline__ Chain2 chain_state(const Ctl2 *ctl, const Round2Out *out, int nlev, int max_shuffle) {
+  int nexec = 0;
+  for (int j = 0; j < nlev; j++) {
+    if (ctl->nsh_base + j >= max_shuffle) break;          // Rmain.cpp:321: at most MAX_SHUFFLE calls per round
+    if (j > 0 && out->cnt[j - 1] == 0) break;             // the previous call moved nothing: the loop has ended
+    nexec = j + 1;
+  }
+  bool ok = nlev == 0;                                     // (the chain after round 0 has no shuffle)
+  if (nexec > 0 && out->cnt[nexec - 1] == 0) ok = true;
+  if (nlev > 0 && ctl->nsh_base + nexec >= max_shuffle) ok = true;
+  return Chain2{nexec, ok};
+}
+// partition reads as of the start of shuffle `nlv` of the chain (= after its first nlv calls)
+static __device__ __forceinline__ uint32_t reads_at(const Eng2 &E, int i, int nlv) {
+  uint32_t v = E.P.creads[i];
+  for (int l = 0; l < nlv; l++) v += (uint32_t)E.dlt[(size_t)l * E.ccap + i];
+  return v;
+}
+
+// ---- round 0: every unique keeps its comparison with the first centre -----------------------------------------------
+__global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restrict__ lam, const uint32_t *__restrict__ ham,
+                                                 const uint8_t *__restrict__ cls, const int32_t *__restrict__ round_counters) {
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  const int centre = E.ctl->centre;
+  const uint32_t creads = S.reads[centre];
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    Round2Out *out = E.dblk + (E.ctl->pub_seq % RING2);
+    atomicAdd(&out->stat[threadIdx.x], (unsigned long long)round_counters[threadIdx.x]);
+  }
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+    const uint8_t cl = cls[r];
+    double l = 0.0;
+    uint32_t h = 0xFFFFFFFFu;                                          // NULL sub (cluster.cpp:139-143)
+    if (cl == CLS_GAPLESS || cl == CLS_NW) { l = lam[r]; h = ham[r]; }
+    if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);              // "Lambda out-of-range error." (cluster.cpp:184)
+    const double em = P.E_minmax[r];
+    if (l * E.total_reads > em) {                                      // always: E_minmax starts at -999
+      if (l * creads > em) P.E_minmax[r] = l * creads;
+      P.comp_i[r] = 0; P.comp_lam[r] = l; P.comp_ham[r] = h;           // i == 0: Raw::comp is refreshed (cluster.cpp:197)
+    }
+    E.T.lam0[r] = l; E.T.ham0[r] = h;
+    E.T.head[r] = -1;
+  }
+}
+
+// ---- commit of a round's comparisons + b_shuffle2 ----------------------------------------------------------------------
+// STORE (first shuffle of a round): the store filter of cluster.cpp:179-201 on the cached comparisons against the round's
+// centre, with the greedy skip of cluster.cpp:127-130 evaluated NOW (lock state of the commit, not of the compare).
+template <bool STORE>
+__global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
+  const Ctl2 *ctl = E.ctl;
+  if (ctl->state != 0) return;
+  const int ring = ctl->pub_seq % RING2;
+  Round2Out *out = E.dblk + ring;
+  if (ctl->nsh_base + level >= E.max_shuffle) return;
+  int moved_before = 0;
+  for (int l = 0; l < level; l++) {
+    const int c = out->cnt[l];
+    if (c == 0) return;                                                // an earlier call moved nothing: the loop has ended
+    moved_before += c;
+  }
+  __shared__ int s_n, s_base, s_an, s_abase;
+  __shared__ int32_t s_delta[DELTA_TAB];
+  __shared__ unsigned int s_stat[4];
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  const Store2 &T = E.T;
+  const int N = S.N;
+  const int nclust = ctl->nclust, ci = nclust - 1, centre = ctl->centre;
+  const int ntab = nclust < DELTA_TAB ? nclust : DELTA_TAB;
+  for (int k = threadIdx.x; k < ntab; k += 256) s_delta[k] = 0;
+  if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+  int my_stat[4] = {0, 0, 0, 0};                                        // classes of this thread's uniques (STORE)
+  int32_t *mv = E.movers + ((size_t)(ring * SH_CHAIN + level)) * 3 * (size_t)N;
+  int32_t *dl = E.dlt + (size_t)level * E.ccap;
+  // STORE: where the round's comparisons are
+  const int slot = ctl->slot, kpos = slot % KB_MAX;
+  const uint16_t *bcls = E.C.bcls + (size_t)(slot / KB_MAX) * E.C.Npad;
+  const double *lamc = E.C.lam + (size_t)slot * N;
+  const uint32_t *hamc = E.C.ham + (size_t)slot * N;
+  const uint32_t creads_c = S.reads[centre];
+  const uint32_t reads_ci = STORE ? reads_at(E, ci, level) : 0u;
+  for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
+    const int r = base + threadIdx.x;
+    if (threadIdx.x == 0) { s_n = 0; s_an = 0; }
+    __syncthreads();
+    bool keep = false, need_new = false, move = false;
+    double l = 0.0, best_l = 0.0;
+    uint32_t h = 0, best_h = 0;
+    int head = -1, hcnt = 3, apos = 0, pos = 0, from = 0, to = 0;
+    if (r < N) {
+      head = T.head[r];
+      from = P.clust_of[r];
+      // arg-max of lambda * reads over the stored comparisons; ties go to the lowest partition (cluster.cpp:229-239)
+      int best_i = 0;
+      best_l = T.lam0[r]; best_h = T.ham0[r];
+      double best_e = best_l * reads_at(E, 0, level);
+      for (int b = head, first = 1; b >= 0; first = 0) {
+        const CompBlk *cb = T.blk + b;
+        const int cnt = cb->cnt;
+        if (first) hcnt = cnt;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+          if (k < cnt) {
+            const int i = cb->i[k];
+            const double nl = cb->lam[k], e = nl * reads_at(E, i, level);
+            if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_h = cb->ham[k]; }
+          }
+        b = cb->next;
+      }
+      if (STORE) {
+        const uint32_t code = (bcls[r] >> (2 * kpos)) & 3u;
+        const uint32_t rd = S.reads[r];
+        const bool skip = E.greedy && (rd > creads_c || P.lock[r]);
+        if (skip) my_stat[3]++;
+        else if (code == CLS_SKIP) atomicOr(P.err_flag, 8);            // the cache lacks a comparison the round needs
+        else my_stat[code == CLS_NW ? 0 : (code == CLS_GAPLESS ? 1 : 2)]++;
+        if (!skip && code >= CLS_GAPLESS) {
+          l = lamc[r]; h = hamc[r];
+          if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);        // "Lambda out-of-range error." (cluster.cpp:184)
+          const double em = P.E_minmax[r];
+          keep = l * E.total_reads > em;                               // this partition could attract this unique
+          if (keep) {
+            if (l * creads_c > em) P.E_minmax[r] = l * creads_c;
+            if (r == centre) { P.comp_i[r] = ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
+            need_new = head < 0 || hcnt >= 3;
+            if (need_new) apos = atomicAdd(&s_an, 1);
+            const double e = l * reads_ci;
+            if (e > best_e) { best_e = e; best_i = ci; best_l = l; best_h = h; }   // (ci is the highest index: only strictly)
+          }
+        }
+      }
+      if (best_i != from && r != P.centre_of[from]) {
+        move = true;
+        to = best_i;
+        pos = atomicAdd(&s_n, 1);
+        P.clust_of[r] = to;
+        P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
+        const uint32_t rd = S.reads[r];
+        if (to < ntab) atomicAdd(&s_delta[to], (int32_t)rd); else atomicAdd(&dl[to], (int32_t)rd);
+        if (from < ntab) atomicSub(&s_delta[from], (int32_t)rd); else atomicSub(&dl[from], (int32_t)rd);
+        P.update_e[to] = 1; P.update_e[from] = 1;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_base = s_n ? atomicAdd(&out->cnt[level], s_n) : 0;
+      s_abase = s_an ? atomicAdd(T.blk_count, s_an) : 0;
+    }
+    __syncthreads();
+    if (keep) {
+      if (need_new) {
+        const int nb = s_abase + apos;
+        if (nb < T.blk_cap) {
+          CompBlk *cb = T.blk + nb;
+          cb->next = head; cb->cnt = 1; cb->i[0] = ci; cb->ham[0] = h; cb->lam[0] = l;
+          T.head[r] = nb;
+        } else atomicOr(P.err_flag, 2);
+      } else {
+        CompBlk *cb = T.blk + head;
+        cb->i[hcnt] = ci; cb->ham[hcnt] = h; cb->lam[hcnt] = l; cb->cnt = hcnt + 1;
+      }
+    }
+    if (move) {
+      const int k = s_base + pos;
+      int32_t *m = mv + 3 * (size_t)k;
+      m[0] = r; m[1] = from; m[2] = to;
+      const int ki = moved_before + k;
+      if (ki < MOV_INLINE2) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
+    }
+    __syncthreads();
+  }
+  for (int k = threadIdx.x; k < ntab; k += 256) {
+    const int32_t d = s_delta[k];
+    if (d) atomicAdd(&dl[k], d);
+  }
+  if (STORE) {   // class statistics of the round (nalign / nshroud, dada.h:113-114), counted at commit time
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int v = my_stat[q];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stat[q], (unsigned int)v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_stat[threadIdx.x]) atomicAdd(&out->stat[threadIdx.x], (unsigned long long)s_stat[threadIdx.x]);
+  }
+}
+
+// ---- b_p_update + first stage of b_bud (no "would another shuffle move" pass: the chain's shuffles are real calls) -----
+static __device__ __forceinline__ bool bud_candidate2(const Eng2 &E, int r, int nlv) {
+  const PartState &P = E.P;
+  if (P.slot0[r]) return false;                                          // r = 0 is skipped as "the centre" (cluster.cpp:285)
+  const uint32_t reads = E.S.reads[r];
+  if (reads < (uint32_t)E.bp.min_abund) return false;
+  if ((int)P.comp_ham[r] < E.bp.min_hamming) return false;
+  if (!(E.bp.min_fold <= 1 || ((double)reads) >= E.bp.min_fold * P.comp_lam[r] * reads_at(E, P.clust_of[r], nlv))) return false;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init, BudKey *__restrict__ partial) {
+  const Ctl2 *ctl = E.ctl;
+  if (ctl->state != 0) return;
+  Round2Out *out = E.dblk + (ctl->pub_seq % RING2);
+  const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
+  if (!cs.eval_ok) return;
+  __shared__ BudKey s_k[2][4];
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  BudKey b0 = init, b1 = init;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+    const int cl = P.clust_of[r];
+    const double l = P.comp_lam[r];
+    const uint32_t reads = S.reads[r];
+    double p = P.p[r];
+    if (P.update_e[cl]) {
+      p = dev_get_pA(reads, S.prior[r] != 0, E.detect_singletons != 0, l, P.comp_ham[r], reads_at(E, cl, cs.nexec));
+      P.p[r] = p;
+    }
+    if (E.greedy && P.check_locks[cl]) {                                 // pval.cpp:29-36
+      const int c = P.centre_of[cl];
+      if ((S.reads[c] * l > reads) || r == c) P.lock[r] = 1;
+    }
+    if (!bud_candidate2(E, r, cs.nexec)) continue;
+    if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
+    if (S.prior[r] && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    BudKey t;
+    t.p = __shfl_xor(b0.p, o, 64); t.reads = __shfl_xor(b0.reads, o, 64);
+    if (bud_better(t.p, t.reads, b0)) b0 = t;
+    t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
+    if (bud_better(t.p, t.reads, b1)) b1 = t;
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_k[0][w] = b0; s_k[1][w] = b1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; k++) {
+      if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
+      if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
+    }
+    partial[2 * blockIdx.x] = b0;
+    partial[2 * blockIdx.x + 1] = b1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k2_ties(Eng2 E, int nlev, BudKey init, const BudKey *__restrict__ partial, int nblocks) {
+  const Ctl2 *ctl = E.ctl;
+  if (ctl->state != 0) return;
+  Round2Out *outb = E.dblk + (ctl->pub_seq % RING2);
+  const Chain2 cs = chain_state(ctl, outb, nlev, E.max_shuffle);
+  if (!cs.eval_ok) return;
+  BudOut *out = &outb->bud;
+  __shared__ BudKey s_k[2][4];
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  BudKey b0 = init, b1 = init;
+  for (int k = threadIdx.x; k < nblocks; k += 256) {
+    if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
+    if (bud_better(partial[2 * k + 1].p, partial[2 * k + 1].reads, b1)) b1 = partial[2 * k + 1];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    BudKey t;
+    t.p = __shfl_xor(b0.p, o, 64); t.reads = __shfl_xor(b0.reads, o, 64);
+    if (bud_better(t.p, t.reads, b0)) b0 = t;
+    t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
+    if (bud_better(t.p, t.reads, b1)) b1 = t;
+  }
+  if ((threadIdx.x & 63) == 0) { s_k[0][threadIdx.x >> 6] = b0; s_k[1][threadIdx.x >> 6] = b1; }
+  __syncthreads();
+  b0 = s_k[0][0]; b1 = s_k[1][0];
+  for (int k = 1; k < 4; k++) {
+    if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
+    if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
+  }
+  const bool found0 = bud_better(b0.p, b0.reads, init), found1 = bud_better(b1.p, b1.reads, init);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out->best_p[0] = b0.p; out->best_p[1] = b1.p;
+    out->best_reads[0] = b0.reads; out->best_reads[1] = b1.reads;
+    out->found[0] = found0; out->found[1] = found1;
+    out->valid = 1;
+  }
+  // listing rule: exact ties + the near window (see k_bud_ties / engine.h BUD_NEAR)
+  const bool sig0 = b0.p * S.N < 2.0 * E.bp.omegaA, sig1 = b1.p < 2.0 * E.bp.omegaP;
+  const double thr0 = sig0 ? b0.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0, thr1 = sig1 ? b1.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+    if (!bud_candidate2(E, r, cs.nexec)) continue;
+    const double p = P.p[r];
+    const uint32_t reads = S.reads[r];
+    for (int track = 0; track < 2; track++) {
+      if (track == 1 && !S.prior[r]) continue;
+      const BudKey &bk = track ? b1 : b0;
+      if (!(track ? found1 : found0)) continue;
+      const bool exact = p == bk.p && reads == bk.reads;
+      const bool near = !exact && p != 0.0 && p <= (track ? thr1 : thr0);
+      if (!exact && !near) continue;
+      const int k = atomicAdd(&out->nties[track], 1);
+      if (k < BUD_TIES) {
+        BudTie &t = out->ties[track][k];
+        t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
+        t.from = P.clust_of[r]; t.from_reads = reads_at(E, t.from, cs.nexec); t.p = p; t.pad = 0;
+      }
+      (track ? E.ties1 : E.ties0)[k] = r;
+    }
+  }
+}
+
+// ---- the birth, the plan of the coming round's compare, and the publication of the round's result block -----------------
+constexpr int PLAN_STRIPS = 16;   // the prediction looks at the first PLAN_STRIPS x 1024 uniques (abundance order)
+
+// (one block of 1024 threads)  Applies the birth of `raw` out of partition `from`, then plans the compare of the round that
+// follows: a cache hit needs nothing; a miss takes the next batch buffer and fills it with `raw` plus the first significant
+// bud candidates in index order that are not cached yet (input is abundance-sorted: those are the likely next centres -
+// a wrong guess only costs its share of one batched launch), and builds the batch's k-mer tables.
+static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc) {
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  Ctl2 *ctl = E.ctl;
+  const Cache2 &C = E.C;
+  const int tid = threadIdx.x;
+  const int nslots = C.NBUF * KB_MAX;
+  int *s_nb = s_misc, *s_hit = s_misc + 1, *s_wcnt = s_misc + 2;   // s_wcnt[16]
+  int *s_bc = s_misc + 20;                                          // [KB_MAX]
+  int *s_tab = s_misc + 32;                                         // [nslots] copy of slot_centre
+  if (tid == 0) {
+    const int newi = ctl->nclust;
+    const uint32_t reads_new = S.reads[raw];
+    P.clust_of[raw] = newi;
+    P.lock[raw] = 0;                                                // bi_assign_center unlocks the members (cluster.cpp:377)
+    P.slot0[raw] = 1;
+    P.creads[newi] = reads_new;
+    P.creads[from] -= reads_new;
+    P.centre_of[newi] = raw;
+    P.update_e[newi] = 1; P.check_locks[newi] = 1;
+    P.update_e[from] = 1;
+    ctl->nclust = newi + 1;
+    ctl->centre = raw;
+    ctl->nsh_base = 0;
+    int hit = -1;
+    for (int s = 0; s < nslots; s++) if (C.slot_centre[s] == raw) hit = s;
+    *s_hit = hit;
+    if (hit >= 0) { ctl->slot = hit; ctl->nbatch = 0; *s_nb = 0; }
+    else {
+      const int bbuf = ctl->next_bbuf;
+      ctl->next_bbuf = (bbuf + 1) % C.NBUF;
+      for (int k = 0; k < KB_MAX; k++) C.slot_centre[bbuf * KB_MAX + k] = -1;
+      ctl->bbuf = bbuf;
+      ctl->slot = bbuf * KB_MAX;
+      s_bc[0] = raw;
+      *s_nb = 1;
+    }
+  }
+  __syncthreads();
+  if (*s_hit >= 0) return;
+  for (int s = tid; s < nslots; s += blockDim.x) s_tab[s] = C.slot_centre[s];
+  __syncthreads();
+  // ---- prediction: first significant candidates in index order ----
+  for (int strip = 0; strip < PLAN_STRIPS && *s_nb < KB_MAX && strip * 1024 < S.N; strip++) {
+    const int r = strip * 1024 + tid;
+    bool ok = false;
+    if (r < S.N && r != raw && bud_candidate2(E, r, 0)) {
+      const double p = P.p[r];
+      ok = (p * S.N < E.omegaA) || (S.prior[r] && p < E.omegaP);
+      for (int s = 0; ok && s < nslots; s++) if (s_tab[s] == r) ok = false;
+    }
+    const unsigned long long bal = __ballot(ok);
+    const int w = tid >> 6, lane = tid & 63;
+    if (lane == 0) s_wcnt[w] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < w; k++) before += s_wcnt[k];
+    int total = 0;
+    for (int k = 0; k < 16; k++) total += s_wcnt[k];
+    const int nb0 = *s_nb;
+    if (ok) {
+      const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
+      if (nb0 + rank < KB_MAX) s_bc[nb0 + rank] = r;
+    }
+    __syncthreads();
+    if (tid == 0) *s_nb = min(KB_MAX, nb0 + total);
+    __syncthreads();
+  }
+  const int nb = *s_nb;
+  // ---- k-mer tables of the batch: byte k of tab8[id] = min(count of 5-mer id in centre k, 63) ----
+  for (int k = tid; k < KB_MAX * NKMER; k += blockDim.x) s_cnt[k] = 0;
+  __syncthreads();
+  for (int k = 0; k < nb; k++) {
+    const int c = s_bc[k];
+    const int nkc = S.len[c] - KMER_SIZE + 1;
+    const uint16_t *crow = S.kord + (size_t)c * S.LK;
+    uint16_t *ko = C.ord + (size_t)k * S.LK;
+    for (int i = tid; i < S.LK; i += blockDim.x) {
+      const uint32_t km = crow[i] & 1023u;
+      if (i < nkc) atomicAdd(&s_cnt[k * NKMER + km], 1u);
+      ko[i] = i < nkc ? (uint16_t)km : (uint16_t)0xFFFF;
+    }
+  }
+  __syncthreads();
+  for (int id = tid; id < NKMER; id += blockDim.x) {
+    uint32_t lo = 0, hi = 0;
+    for (int k = 0; k < KB_MAX; k++) {
+      const uint32_t c = k < nb ? s_cnt[k * NKMER + id] : 0u;
+      const uint32_t sat = c < RANK_SAT ? c : RANK_SAT;
+      if (k < 4) lo |= sat << (8 * k); else hi |= sat << (8 * (k - 4));
+      C.full[(size_t)k * NKMER + id] = (uint16_t)c;
+    }
+    C.tab8[id] = make_uint2(lo, hi);
+  }
+  if (tid < KB_MAX) {
+    const int k = tid;
+    if (k < nb) {
+      const int c = s_bc[k];
+      ctl->bcentre[k] = c; ctl->breads[k] = S.reads[c]; ctl->blen[k] = S.len[c];
+      C.slot_centre[ctl->bbuf * KB_MAX + k] = c;
+    } else { ctl->bcentre[k] = -1; ctl->breads[k] = 0; ctl->blen[k] = 0; }
+  }
+  if (tid == 0) { ctl->nbatch = nb; C.list_n[0] = 0; C.list_n[1] = 0; }
+}
+
+static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
+  // plain stores to pinned host memory, then the sequence number: the host polls it instead of copying and synchronising
+  Ctl2 *ctl = E.ctl;
+  __syncthreads();
+  int tot = 0;
+  for (int l = 0; l < SH_CHAIN; l++) tot += out->cnt[l];
+  if (tot > MOV_INLINE2) tot = MOV_INLINE2;
+  const int used16 = (int)((offsetof(Round2Out, mov) + (size_t)12 * tot + 15) / 16);
+  const int seq = ctl->pub_seq + 1;
+  const uint4 *src = (const uint4 *)out;
+  uint4 *dst = (uint4 *)(E.hblk + ring);
+  for (int i = threadIdx.x; i < used16; i += blockDim.x) {
+    uint4 v = src[i];
+    if (i == 0) v.x = (uint32_t)(seq - 1);               // (word 0 of the block is `seq`: not yet)
+    dst[i] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&E.hblk[ring].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ctl->pub_seq = seq;
+  }
+}
+
+static __device__ void clear_block(Round2Out *nx) {
+  if (threadIdx.x < SH_CHAIN) nx->cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 4) nx->stat[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    nx->bud.nties[0] = 0; nx->bud.nties[1] = 0; nx->bud.valid = 0; nx->bud.found[0] = 0; nx->bud.found[1] = 0;
+    nx->bud.auto_applied = 0; nx->halt = H2_NONE; nx->birth_applied = 0; nx->nsh = 0; nx->nlev = 0; nx->nbatch = 0;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev) {
+  Ctl2 *ctl = E.ctl;
+  if (ctl->state != 0) return;
+  __shared__ uint32_t s_cnt[KB_MAX * NKMER];
+  __shared__ int s_misc[32 + 256];
+  __shared__ int s_halt, s_raw, s_from, s_evalok;
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  const int ring = ctl->pub_seq % RING2;
+  Round2Out *out = E.dblk + ring;
+  const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
+  const int nclust = ctl->nclust;
+  // fold the chain's partition-read deltas into the reads
+  for (int i = threadIdx.x; i < nclust; i += blockDim.x) {
+    int32_t d = 0;
+    for (int l = 0; l < SH_CHAIN; l++) { d += E.dlt[(size_t)l * E.ccap + i]; E.dlt[(size_t)l * E.ccap + i] = 0; }
+    if (d) P.creads[i] += (uint32_t)d;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out->nlev = nlev; out->nsh = cs.nexec; out->slot = ctl->slot; out->nbatch = ctl->nbatch;
+    out->err_flag = *P.err_flag | (*S.nw_flag ? 4 : 0);
+    out->blk_count = *E.T.blk_count;
+    const BudOut &b = out->bud;
+    int halt = H2_NONE, raw = -1, from = 0;
+    if (!cs.eval_ok) { halt = H2_SHUFFLE_MORE; ctl->nsh_base += cs.nexec; }
+    else if (nclust >= ctl->max_clust) halt = H2_MAXCLUST;
+    else {
+      // the unambiguous case of b_bud (cluster.cpp:300-330) is the device's; the margins keep every decision that depends
+      // on the last ulp of a p-value on the host
+      const double pA = b.best_p[0] * S.N;
+      const bool birthA = b.valid && b.found[0] && b.nties[0] == 1 && pA < E.omegaA * (1.0 - 1e-9);
+      const bool noA = !b.found[0] || pA >= E.omegaA * (1.0 + 1e-9);
+      const bool noP = !b.found[1] || b.best_p[1] >= E.omegaP * (1.0 + 1e-9);
+      if (birthA) { raw = b.ties[0][0].raw; from = b.ties[0][0].from; }
+      else if (b.valid && noA && noP) halt = H2_NO_BIRTH;
+      else halt = H2_HOST_DECIDE;
+      if (halt == H2_NONE && (nclust + 2 > E.ccap || out->blk_count + S.N > E.T.blk_cap)) halt = H2_CAPACITY;
+    }
+    out->halt = halt;
+    out->birth_applied = halt == H2_NONE ? 1 : 0;
+    out->nclust = nclust + (halt == H2_NONE ? 1 : 0);
+    s_halt = halt; s_raw = raw; s_from = from; s_evalok = cs.eval_ok ? 1 : 0;
+    if (halt != H2_NONE) { ctl->state = 1; ctl->halt = halt; }
+  }
+  __syncthreads();
+  if (s_evalok)   // b_p_update has consumed the flags (pval.cpp:24,37)
+    for (int k = threadIdx.x; k < nclust; k += blockDim.x) { P.update_e[k] = 0; P.check_locks[k] = 0; }
+  __syncthreads();
+  if (s_halt == H2_NONE) apply_birth_and_plan(E, s_raw, s_from, s_cnt, s_misc);
+  clear_block(E.dblk + ((ring + 1) % RING2));
+  publish_block(E, out, ring);
+}
+
+// the host's own b_bud decision (ties, near ties, prior births, capacity) applied, the coming round planned, the device resumed
+__global__ __launch_bounds__(1024) void k2_host_birth(Eng2 E, int raw, int from) {
+  __shared__ uint32_t s_cnt[KB_MAX * NKMER];
+  __shared__ int s_misc[32 + 256];
+  if (threadIdx.x == 0) { E.ctl->state = 0; E.ctl->halt = H2_NONE; }
+  __syncthreads();
+  apply_birth_and_plan(E, raw, from, s_cnt, s_misc);
+}
+__global__ void k2_resume(Eng2 E) { E.ctl->state = 0; E.ctl->halt = H2_NONE; }
+
+// ---- k-mer screen against the batch's centres ---------------------------------------------------------------------------
+// 16 lanes per unique as in k_screen, but one pass over the unique's k-mer record serves up to KB_MAX centres: the centre
+// tables are interleaved (byte k of tab8[id] = min(count_k[id], 63)), so one 8-byte LDS read + two SWAR compares give
+// "rank < count" for all centres.  A wave owns 16 consecutive uniques per macro-iteration (lane group g takes uniques
+// 4g..4g+3 in turn) and writes their class words (2 bits per centre) as one 32-byte store.
+__global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E, int cap) {
+  const Ctl2 *ctl = E.ctl;
+  const int nb = ctl->nbatch;
+  if (ctl->state != 0 || nb == 0) return;
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+  const SampleDev &S = E.S;
+  const Cache2 &C = E.C;
+  const ScreenParams sp = E.sp;
+  uint2 *tab = (uint2 *)s_mem;                               // [1024]
+  unsigned long long *s_nw = (unsigned long long *)(tab + NKMER);   // [cap]
+  unsigned long long *s_gl = s_nw + cap;                     // [cap]
+  uint16_t *cord = (uint16_t *)(s_gl + cap);                 // [KB_MAX][LK]
+  __shared__ int s_cnt[8];
+  __shared__ int cL[KB_MAX], cC[KB_MAX];
+  __shared__ uint32_t cR[KB_MAX];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NKMER; i += 256) tab[i] = C.tab8[i];
+  {
+    const int n16 = (nb * S.LK * 2 + 15) / 16;
+    const uint4 *src = (const uint4 *)C.ord;
+    for (int i = tid; i < n16; i += 256) ((uint4 *)cord)[i] = src[i];
+  }
+  if (tid < KB_MAX) { cL[tid] = ctl->blen[tid]; cC[tid] = ctl->bcentre[tid]; cR[tid] = ctl->breads[tid]; }
+  if (tid < 8) s_cnt[tid] = 0;
+  __syncthreads();
+  uint16_t *bcls = C.bcls + (size_t)ctl->bbuf * C.Npad;
+  const int sub = tid & 15, g = (tid & 63) >> 4;
+  const int gwave = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
+  const int nchunk = (S.maxlen - KMER_SIZE + 1 + 7) >> 3;
+  const uint4 pad4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (int base16 = gwave * 16; base16 < S.N; base16 += nwaves * 16) {
+    unsigned long long clsacc = 0;
+    for (int it = 0; it < 4; it++) {
+      const int r = base16 + 4 * g + it;
+      if (r >= S.N) continue;
+      const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
+      const int Lr = S.len[r];
+      const uint32_t rd = S.reads[r];
+      const bool lk = E.greedy && E.P.lock[r];
+      // ---- pass 1: unordered overlap with every centre of the batch ----
+      uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;               // 16-bit fields: centres (0,2) (1,3) (4,6) (5,7)
+      uint4 c0 = pad4, c1 = pad4;
+      if (sp.use_kmers) {
+        for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
+          const uint4 v = row[ch];
+          if (j == 0) c0 = v; else if (j == 1) c1 = v;
+          uint32_t ax = 0, ay = 0;
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int hlf = 0; hlf < 2; hlf++) {
+              const uint32_t x = hlf ? (w[e] >> 16) : (w[e] & 0xFFFFu);
+              const uint2 t = tab[x & 1023u];
+              const uint32_t rr = ((x >> 10) + 1u) * 0x01010101u;       // rank + 1 in every byte (1..64)
+              ax += (((t.x | 0x80808080u) - rr) >> 7) & 0x01010101u;    // byte k: rank < min(count_k, 63)
+              ay += (((t.y | 0x80808080u) - rr) >> 7) & 0x01010101u;
+            }
+          }
+          w0 += ax & 0x00FF00FFu; w1 += (ax >> 8) & 0x00FF00FFu;
+          w2 += ay & 0x00FF00FFu; w3 += (ay >> 8) & 0x00FF00FFu;
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+          w0 += __shfl_xor(w0, o, 16); w1 += __shfl_xor(w1, o, 16);
+          w2 += __shfl_xor(w2, o, 16); w3 += __shfl_xor(w3, o, 16);
+        }
+      }
+      uint32_t code16 = 0;
+      for (int k = 0; k < nb; k++) {
+        uint32_t dot = ((k & 4) ? ((k & 1) ? w3 : w2) : ((k & 1) ? w1 : w0)) >> ((k & 2) ? 16 : 0) & 0xFFFFu;
+        const int Lc = cL[k];
+        const bool skipped = E.greedy && (rd > cR[k] || (lk && r != cC[k]));
+        uint32_t c = CLS_SKIP;
+        if (!skipped) {
+          if (sp.use_kmers && S.HMAX > 0) {                   // k-mers occurring > 63 times: exact correction
+            const int nh = S.nheavy[r];
+            for (int hh = 0; hh < nh; hh++) {
+              const uint32_t e = S.heavy[(size_t)r * S.HMAX + hh], cr = e >> 16, cc = C.full[(size_t)k * NKMER + (e & 1023u)];
+              const uint32_t m = cr < cc ? cr : cc;
+              if (m > RANK_SAT) dot += m - RANK_SAT;
+            }
+            dot &= 0xFFFFu;                                   // the reference accumulates in uint16_t (kmers.cpp:16,34,69)
+          }
+          const int d = (Lc < Lr ? Lc : Lr) - KMER_SIZE + 1;
+          const bool shroud = sp.use_kmers && (int)dot < E.thresh[d];   // kdist > kdist_cutoff
+          if (shroud) c = CLS_SHROUD;
+          else {
+            const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || Lr == Lc);
+            bool gapless = sp.band == 0;
+            if (!gapless && gl_ok) {
+              // ---- pass 2 (survivors only): ordered overlap over the first d positions ----
+              const uint16_t *ck = cord + (size_t)k * S.LK;
+              uint32_t ord = 0;
+              for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
+                const uint4 v = j == 0 ? c0 : (j == 1 ? c1 : row[ch]);
+                const uint4 ck4 = ((const uint4 *)ck)[ch];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w}, cw[4] = {ck4.x, ck4.y, ck4.z, ck4.w};
+                const int i0 = ch << 3;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  const uint32_t t = (w[e] ^ cw[e]) & 0x03FF03FFu;
+                  ord += ((t & 0xFFFFu) == 0 && i0 + 2 * e < d);
+                  ord += ((t >> 16) == 0 && i0 + 2 * e + 1 < d);
+                }
+              }
+#pragma unroll
+              for (int o = 8; o >= 1; o >>= 1) ord += __shfl_xor(ord, o, 16);
+              gapless = (ord & 0xFFFFu) == dot;               // kodist == kdist
+            }
+            c = gapless ? CLS_GAPLESS : CLS_NW;
+          }
+        }
+        code16 |= c << (2 * k);
+        if (sub == 0 && c >= CLS_GAPLESS) {
+          const unsigned long long ent = (unsigned long long)(uint32_t)r | ((unsigned long long)k << 32);
+          if (c == CLS_NW) {
+            const int q = atomicAdd(&s_cnt[0], 1);
+            if (q < cap) s_nw[q] = ent; else C.nw_list[atomicAdd(&C.list_n[0], 1)] = ent;
+          } else {
+            const int q = atomicAdd(&s_cnt[1], 1);
+            if (q < cap) s_gl[q] = ent; else C.gl_list[atomicAdd(&C.list_n[1], 1)] = ent;
+          }
+        }
+      }
+      clsacc |= (unsigned long long)code16 << (16 * it);
+    }
+    if (sub == 0 && base16 + 4 * g < S.N) *(unsigned long long *)(bcls + base16 + 4 * g) = clsacc;
+  }
+  __syncthreads();
+  if (tid < 2) {
+    const int n = min(s_cnt[tid], cap);
+    s_cnt[2 + tid] = n;
+    s_cnt[4 + tid] = n ? atomicAdd(&C.list_n[tid], n) : 0;   // one global atomic per list per block
+  }
+  __syncthreads();
+  for (int i = tid; i < s_cnt[2]; i += 256) C.nw_list[s_cnt[4] + i] = s_nw[i];
+  for (int i = tid; i < s_cnt[3]; i += 256) C.gl_list[s_cnt[5] + i] = s_gl[i];
+}
+
+// post-hoc partition p-value inputs (error.cpp:101-119) from the v2 store
+__global__ __launch_bounds__(256) void k2_posthoc(Eng2 E, const int32_t *__restrict__ cluster_of_centre, int32_t *__restrict__ out_ji,
+                                                  double *__restrict__ out_lam, int32_t *__restrict__ nout, int cap) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= E.S.N) return;
+  const int j = cluster_of_centre[r];
+  if (j < 0) return;
+  if (j != 0) {
+    const int k = atomicAdd(nout, 1);
+    if (k < cap) { out_ji[2 * k] = j; out_ji[2 * k + 1] = 0; out_lam[k] = E.T.lam0[r]; }
+  }
+  for (int b = E.T.head[r]; b >= 0; b = E.T.blk[b].next) {
+    const CompBlk *cb = E.T.blk + b;
+    for (int q = 0; q < cb->cnt; q++) {
+      const int i = cb->i[q];
+      if (i == j) continue;
+      const int k = atomicAdd(nout, 1);
+      if (k < cap) { out_ji[2 * k] = j; out_ji[2 * k + 1] = i; out_lam[k] = cb->lam[q]; }
+    }
+  }
+}
+
+// ---- launch wrappers ------------------------------------------------------------------------------------------------------
+void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
+                    hipStream_t st) {
+  const int grid = std::min((E.S.N + 255) / 256, 2048);
+  hipLaunchKernelGGL(k2_store0, dim3(grid), dim3(256), 0, st, E, d_lam, d_ham, d_cls, d_round_counters);
+}
+static size_t screen_multi_lds(const SampleDev &S, int cap) {
+  return (size_t)NKMER * 8 + (size_t)cap * 16 + (size_t)KB_MAX * S.LK * 2 + 64;
+}
+void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
+  int cap = 1024;
+  while (cap > 64 && screen_multi_lds(E.S, cap) > 60 * 1024) cap >>= 1;
+  const size_t lds = screen_multi_lds(E.S, cap);
+  static size_t attr_set[64] = {0};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (lds > attr_set[dev_ & 63]) {
+    (void)hipFuncSetAttribute((const void *)k2_screen_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev_ & 63] = lds;
+  }
+  const int grid = std::min((E.S.N + 63) / 64, 2048);
+  hipLaunchKernelGGL(k2_screen_multi, dim3(grid), dim3(256), lds, st, E, cap);
+}
+void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st) {
+  const int grid = std::min((E.S.N + 255) / 256, 2048);
+  if (store) hipLaunchKernelGGL(k2_shuffle<true>, dim3(grid), dim3(256), 0, st, E, level);
+  else hipLaunchKernelGGL(k2_shuffle<false>, dim3(grid), dim3(256), 0, st, E, level);
+}
+void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st) {
+  BudKey init{1.0, init_reads};
+  const int grid = std::min((E.S.N + 255) / 256, 1024);
+  hipLaunchKernelGGL(k2_pupdate, dim3(grid), dim3(256), 0, st, E, nlev, init, (BudKey *)E.partial);
+  hipLaunchKernelGGL(k2_ties, dim3(std::min((E.S.N + 255) / 256, 512)), dim3(256), 0, st, E, nlev, init, (const BudKey *)E.partial, grid);
+}
+void launch2_birth(const Eng2 &E, int nlev, hipStream_t st) { hipLaunchKernelGGL(k2_birth, dim3(1), dim3(1024), 0, st, E, nlev); }
+void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st) {
+  hipLaunchKernelGGL(k2_host_birth, dim3(1), dim3(1024), 0, st, E, raw, from);
+}
+void launch2_resume(const Eng2 &E, hipStream_t st) { hipLaunchKernelGGL(k2_resume, dim3(1), dim3(1), 0, st, E); }
+void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
+                     int cap, hipStream_t st) {
+  hipLaunchKernelGGL(k2_posthoc, dim3((E.S.N + 255) / 256), dim3(256), 0, st, E, d_cluster_of_centre, d_out_ji, d_out_lam, d_nout, cap);
+}
