@@ -1111,7 +1111,8 @@ struct Run {
   DevBuf<uint2> v2_tab8;
   DevBuf<unsigned long long> v2_nwl, v2_gll;
   PinBuf<Round2Out> v2_hblk;
-  int v2_nbuf = 8, v2_depth = 2;
+  int v2_nbuf = 8, v2_depth = 2, v2_chain = SH_CHAIN;
+  bool v2_debug = false;
   long v2_enq = 0, v2_cons = 0;
   uint64_t v2_miss_launches = 0;
   struct EnqRec { int ev_screen, ev_nw; };
@@ -1142,6 +1143,9 @@ struct Run {
     const size_t n = (size_t)N;
     if (const char *e = getenv("DADA2HIP_V2_NBUF")) v2_nbuf = std::max(1, std::min(32, atoi(e)));   // (k2_birth keeps the slot table in LDS)
     if (const char *e = getenv("DADA2HIP_V2_DEPTH")) v2_depth = std::max(1, std::min(RING2 - 1, atoi(e)));
+    v2_chain = SH_CHAIN;
+    if (const char *e = getenv("DADA2HIP_V2_CHAIN")) v2_chain = std::max(1, std::min(SH_CHAIN, atoi(e)));   // test knob: shorter shuffle chains
+    v2_debug = getenv("DADA2HIP_V2_DEBUG") != nullptr;
     hipStream_t stq = s->stream;
     v2_lam0.alloc(n); v2_ham0.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
     {
@@ -1275,11 +1279,15 @@ struct Run {
     v2_enqueue_chain(0, false, false);                        // b_p_update after round 0 + the first b_bud
     bool done = false;
     while (!done) {
-      while (v2_enq - v2_cons < v2_depth) v2_enqueue_chain(SH_CHAIN, true, true);
+      while (v2_enq - v2_cons < v2_depth) v2_enqueue_chain(v2_chain, true, true);
       const long seq = v2_cons + 1;
       const Round2Out &b = v2_wait_block();
       if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
         throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
+      if (v2_debug)
+        fprintf(stderr, "[v2] blk %ld halt %d nclust %d nlev %d nsh %d cnt %d %d %d %d nbatch %d slot %d birth %d found %d nties %d p %.3e blk %d\n", seq,
+                b.halt, b.nclust, b.nlev, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],
+                b.bud.nties[0], b.bud.best_p[0], b.blk_count);
       v2_replay(b, seq);
       const EnqRec &rec = v2_enqrec[seq - 1];
       if (b.nbatch > 0 && b.nlev > 0 && b.nsh > 0) {           // (this chain's compare really ran: a miss)
@@ -1327,7 +1335,7 @@ struct Run {
           v2_enq = v2_cons;
           v2_enqrec.resize((size_t)v2_cons);
           launch2_resume(E2, s->stream);
-          v2_enqueue_chain(SH_CHAIN, false, false);
+          v2_enqueue_chain(v2_chain, false, false);
           break;
         }
         default: throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: unknown halt code"};

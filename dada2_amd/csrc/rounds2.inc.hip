@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
       int best_i = 0;
       best_l = T.lam0[r]; best_h = T.ham0[r];
       double best_e = best_l * reads_at(E, 0, level);
-      for (int b = head, first = 1; b >= 0; first = 0) {
+      for (int b = head, first = 1, hops = 0; b >= 0 && hops < (1 << 22); first = 0, hops++) {   // (bounded: never spin on a bad link)
         const CompBlk *cb = T.blk + b;
         const int cnt = cb->cnt;
         if (first) hcnt = cnt;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void k2_posthoc(Eng2 E, const int32_t *__restr
     const int k = atomicAdd(nout, 1);
     if (k < cap) { out_ji[2 * k] = j; out_ji[2 * k + 1] = 0; out_lam[k] = E.T.lam0[r]; }
   }
-  for (int b = E.T.head[r]; b >= 0; b = E.T.blk[b].next) {
+  for (int b = E.T.head[r], hops = 0; b >= 0 && hops < (1 << 22); b = E.T.blk[b].next, hops++) {
     const CompBlk *cb = E.T.blk + b;
     for (int q = 0; q < cb->cnt; q++) {
       const int i = cb->i[q];

@@ -168,6 +168,53 @@ def test_use_quals_off_still_checks_the_err_range(api):
         api.dada_uniques(d.seqs, d.abundances, None, tperr1()[:, :20], d.quals, copts=co)
 
 
+# ---- the two round engines: classic host-stepped rounds vs batched compares + device-driven rounds ----------
+def _run_cases_in_subprocess(env_extra, names, seeded=()):
+    import subprocess, sys
+    code = (
+        "import numpy as np, sys\n"
+        "root = %r\n"
+        "sys.path[:0] = [root, root + '/tests']\n"
+        "from helpers import case_inputs, assert_results_equal, P_RTOL, tperr1\n"
+        "from dada2_amd import api\n"
+        "from dada2_amd.opts import DadaOpts\n"
+        "from dada2_amd.synth import make_sample\n"
+        "from oracle import cport\n"
+        "for name in %r:\n"
+        "    d, err, pri, o, exp, meta = case_inputs(name)\n"
+        "    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"
+        "    assert_results_equal(got, exp, p_rtol=P_RTOL, check_birth_from=pri is None)\n"
+        "for seed, n, L, G in %r:\n"
+        "    d = make_sample(tperr1(), n, L=L, G=G, seed=seed, chunk=20000)\n"
+        "    got = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())\n"
+        "    want = cport.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())\n"
+        "    assert_results_equal(got, want, p_rtol=P_RTOL)\n"
+        "    assert got.stats['ncompare'] - got.stats['nskipped'] == want.stats['nalign'] and got.stats['nshroud'] == want.stats['nshroud']\n"
+        "print('ok')\n") % (ROOT, tuple(names), tuple(seeded))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+_ALL = ("sam1F_default", "sam1F_band32_omega20_inflate3", "sam1R_default", "sam2F_nogreedy", "sam1F_nokmers", "sam2R_singletons",
+        "sam1F_priors", "synth3000_default")
+_SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
+
+
+@pytest.mark.parametrize("env", [
+    {"DADA2HIP_ENGINE": "classic"},                       # round-1 loop
+    {},                                                   # v2 defaults: 8 batch buffers x 8 centres, 2 chains in flight, 4 shuffles per chain
+    {"DADA2HIP_V2_NBUF": "1"},                            # one batch buffer: every miss evicts everything
+    {"DADA2HIP_V2_DEPTH": "1"},                           # host in lockstep with the device
+    {"DADA2HIP_V2_DEPTH": "3"},
+    {"DADA2HIP_V2_CHAIN": "1"},                           # one shuffle per chain: rounds continue through the host (H2_SHUFFLE_MORE)
+    {"DADA2HIP_V2_CHAIN": "2", "DADA2HIP_NODE_CAP": "1"}, # comparison store starts at N + 16 blocks: growth through H2_CAPACITY
+], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow"])
+def test_round_engines_agree_with_the_reference(env):
+    """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
+    20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""
+    _run_cases_in_subprocess(env, _ALL, _SEEDED)
+
+
 # ---- the RCCL path of the sample-sharded driver, real resident-sample runner, world_size 1 -------------------------------
 def test_dada_multi_with_real_runner_under_nccl(api):
     import socket

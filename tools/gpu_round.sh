@@ -10,6 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
+export DADA2HIP_WAIT_TIMEOUT_S=${DADA2HIP_WAIT_TIMEOUT_S:-90}
 for s in $STEPS; do
   t0=$(date +%s)
   case $s in
