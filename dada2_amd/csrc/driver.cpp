@@ -1115,7 +1115,7 @@ struct Run {
   bool v2_debug = false;
   long v2_enq = 0, v2_cons = 0;
   uint64_t v2_miss_launches = 0;
-  struct EnqRec { int ev_screen, ev_nw; };
+  struct EnqRec { int ev_screen, ev_nw; bool compare; };
   std::vector<EnqRec> v2_enqrec;      // per enqueued block (index = sequence number - 1)
 
   bool want_v2() const {
@@ -1182,7 +1182,7 @@ struct Run {
   // batch compare in front (no-ops on a cache hit) and the round's store filter in its first shuffle
   void v2_enqueue_chain(int nlev, bool with_compare, bool store) {
     hipStream_t stq = s->stream;
-    EnqRec rec{-1, -1};
+    EnqRec rec{-1, -1, with_compare};
     if (with_compare) {
       rec.ev_screen = ev_begin(EV_SCREEN, profile_all, /*spec=*/true);
       launch2_screen_multi(E2, stq);
@@ -1290,7 +1290,7 @@ struct Run {
                 b.bud.nties[0], b.bud.best_p[0], b.blk_count);
       v2_replay(b, seq);
       const EnqRec &rec = v2_enqrec[seq - 1];
-      if (b.nbatch > 0 && b.nlev > 0 && b.nsh > 0) {           // (this chain's compare really ran: a miss)
+      if (rec.compare && b.nbatch > 0) {                       // (this chain's batch compare really ran: a cache miss)
         v2_miss_launches++;
         if (rec.ev_screen >= 0) evs[rec.ev_screen].ok = 1;
         if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
