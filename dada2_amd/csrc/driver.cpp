@@ -1101,17 +1101,16 @@ struct Run {
   // keeps the round-1 loop (the parity tests run both).
   bool use_v2 = false;
   Eng2 E2{};
-  DevBuf<double> v2_lam0, v2_clam;
-  DevBuf<uint32_t> v2_ham0, v2_cham;
+  DevBuf<double> v2_lam0;
+  DevBuf<uint32_t> v2_ham0;
   DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn;
   DevBuf<CompBlk> v2_blk;
   DevBuf<Ctl2> v2_ctl;
   DevBuf<Round2Out> v2_dblk;
   DevBuf<uint16_t> v2_bcls, v2_full, v2_ord;
   DevBuf<uint2> v2_tab8;
-  DevBuf<unsigned long long> v2_nwl, v2_gll;
   PinBuf<Round2Out> v2_hblk;
-  int v2_nbuf = 8, v2_depth = 2, v2_chain = SH_CHAIN;
+  int v2_nbuf = 32, v2_depth = 2, v2_chain = SH_CHAIN;
   bool v2_debug = false;
   long v2_enq = 0, v2_cons = 0;
   uint64_t v2_miss_launches = 0;
@@ -1129,9 +1128,10 @@ struct Run {
     E2.P = P; E2.S = s->D;
     E2.T.lam0 = v2_lam0.p; E2.T.ham0 = v2_ham0.p; E2.T.head = v2_head.p; E2.T.blk = v2_blk.p; E2.T.blk_count = v2_blkcount.p;
     E2.T.blk_cap = (int32_t)std::min<size_t>(v2_blk.n, 0x7FFFFFF0u);
-    E2.C.NBUF = v2_nbuf; E2.C.lam = v2_clam.p; E2.C.ham = v2_cham.p; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
-    E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.nw_list = v2_nwl.p; E2.C.gl_list = v2_gll.p;
-    E2.C.list_n = v2_listn.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15; E2.C.list_cap = v2_nwl.n;
+    E2.C.NBUF = v2_nbuf; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
+    E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15;
+    E2.cls = s->d_cls.p; E2.lam = s->d_lambda.p; E2.ham = s->d_ham.p;
+    E2.nw_list = s->d_nw_list.p; E2.gl_list = s->d_gl_list.p; E2.list_n = v2_listn.p;
     E2.ctl = v2_ctl.p; E2.dblk = v2_dblk.p; E2.hblk = v2_hblk.p; E2.dlt = v2_dlt.p; E2.movers = v2_movers.p;
     E2.partial = d_partial.p; E2.ties0 = d_ties0.p; E2.ties1 = d_ties1.p; E2.ccap = ccap;
     E2.greedy = o.greedy; E2.detect_singletons = o.detect_singletons;
@@ -1141,7 +1141,8 @@ struct Run {
   }
   void v2_alloc(int max_clust) {
     const size_t n = (size_t)N;
-    if (const char *e = getenv("DADA2HIP_V2_NBUF")) v2_nbuf = std::max(1, std::min(32, atoi(e)));   // (k2_birth keeps the slot table in LDS)
+    v2_nbuf = 32;
+    if (const char *e = getenv("DADA2HIP_V2_NBUF")) v2_nbuf = std::max(1, std::min(64, atoi(e)));   // (k2_birth keeps the slot table in LDS)
     if (const char *e = getenv("DADA2HIP_V2_DEPTH")) v2_depth = std::max(1, std::min(RING2 - 1, atoi(e)));
     v2_chain = SH_CHAIN;
     if (const char *e = getenv("DADA2HIP_V2_CHAIN")) v2_chain = std::max(1, std::min(SH_CHAIN, atoi(e)));   // test knob: shorter shuffle chains
@@ -1157,9 +1158,9 @@ struct Run {
     v2_dlt.alloc((size_t)SH_CHAIN * ccap);
     v2_movers.alloc((size_t)RING2 * SH_CHAIN * 3 * n);
     const size_t slots = (size_t)v2_nbuf * KB_MAX;
-    v2_clam.alloc(slots * n); v2_cham.alloc(slots * n); v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
+    v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
-    v2_nwl.alloc((size_t)KB_MAX * n); v2_gll.alloc((size_t)KB_MAX * n); v2_listn.alloc(2);
+    v2_listn.alloc(2);
     D2_HIP(hipMemsetAsync(v2_blkcount.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));
     D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_CHAIN * ccap * 4, stq));
@@ -1184,11 +1185,15 @@ struct Run {
     hipStream_t stq = s->stream;
     EnqRec rec{-1, -1, with_compare};
     if (with_compare) {
+      // the round's comparisons: a batch screen if its centre is not cached (no-op otherwise), the work lists of the centre
+      // with the greedy skip as of now, the aligner on them (centre read from the control block)
       rec.ev_screen = ev_begin(EV_SCREEN, profile_all, /*spec=*/true);
       launch2_screen_multi(E2, stq);
       ev_end(rec.ev_screen);
-      rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
-      launch_nw_ad_multi(E2, ap, s->d_err.p, stq);
+      launch2_lists(E2, stq);
+      rec.ev_nw = ev_begin(EV_NW, profile_all);
+      launch_nw_ad(s->D, -1, nullptr, s->d_nw_list.p, v2_listn.p, 0, s->d_gl_list.p, v2_listn.p + 1, ap, s->d_err.p, s->d_lambda.p,
+                   s->d_ham.p, nullptr, 0, 0, &v2_ctl.p->centre, stq, &v2_ctl.p->state);
       ev_end(rec.ev_nw);
     }
     int ev = ev_begin(EV_SHUFFLE, profile_all && nlev > 0);
@@ -1293,7 +1298,6 @@ struct Run {
       if (rec.compare && b.nbatch > 0) {                       // (this chain's batch compare really ran: a cache miss)
         v2_miss_launches++;
         if (rec.ev_screen >= 0) evs[rec.ev_screen].ok = 1;
-        if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
       }
       if (b.nlev > 0 && b.halt != H2_SHUFFLE_MORE) { }        // (a round's commit is complete)
       switch (b.halt) {

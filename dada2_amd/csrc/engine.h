@@ -190,7 +190,7 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,
-                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st);
+                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st, const int32_t *d_stop_dev = nullptr);
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap);
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap);
 
@@ -265,18 +265,17 @@ struct Ctl2 {
   int32_t blen[KB_MAX];
 };
 
+// Screen results of the batch compares, kept until their centre's round comes (or the batch buffer is recycled): 2 bits
+// per (unique, batch position).  The aligner runs at commit time, on the round's centre only: a wrong guess costs its
+// share of one pass over the k-mer records, never an alignment.
 struct Cache2 {
   int32_t NBUF = 0;               // batch buffers
-  double *lam = nullptr;          // [NBUF * KB_MAX][N]
-  uint32_t *ham = nullptr;        // [NBUF * KB_MAX][N]
-  uint16_t *bcls = nullptr;       // [NBUF][Npad]  2 bits per batch position: CLS_*
+  uint16_t *bcls = nullptr;       // [NBUF][Npad]  2 bits per batch position: CLS_* as of the compare
   int32_t *slot_centre = nullptr; // [NBUF * KB_MAX]  unique index or -1
   uint2 *tab8 = nullptr;          // [1024]  byte k = min(count of the 5-mer in batch centre k, 63)
   uint16_t *full = nullptr;       // [KB_MAX][1024] full counts (heavy k-mer correction)
   uint16_t *ord = nullptr;        // [KB_MAX][LK] ordered 5-mers, 0xFFFF past the end
-  unsigned long long *nw_list = nullptr, *gl_list = nullptr;   // unique | position << 32
-  int32_t *list_n = nullptr;      // [2]
-  size_t Npad = 0, list_cap = 0;
+  size_t Npad = 0;
 };
 
 struct Round2Out {
@@ -307,6 +306,11 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   Round2Out *hblk;                // [RING2] pinned host copies
   int32_t *dlt;                   // [SH_CHAIN][ccap] partition-read deltas of the chain's shuffles
   int32_t *movers;                // [RING2][SH_CHAIN][3 N]
+  // the round's comparisons (cluster.cpp:90-149): class per unique, work lists, then lambda / hamming from the aligner
+  uint8_t *cls;
+  double *lam;
+  uint32_t *ham;
+  int32_t *nw_list, *gl_list, *list_n;
   void *partial;                  // block partials of the bud arg-min
   int32_t *ties0, *ties1;         // full tie lists
   int32_t ccap;
@@ -321,6 +325,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
                     hipStream_t st);
 void launch2_screen_multi(const Eng2 &E, hipStream_t st);
+void launch2_lists(const Eng2 &E, hipStream_t st);                                    // cached classes + commit-time greedy skip -> work lists
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);     // b_p_update + b_bud arg-min + tie listing
 void launch2_birth(const Eng2 &E, int nlev, hipStream_t st);                          // decide / apply / plan / publish
@@ -328,8 +333,6 @@ void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st);      
 void launch2_resume(const Eng2 &E, hipStream_t st);
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st);
-// NW over the batch work lists (pairs of unique and batch position): k_nw_ad with per-alignment centres
-void launch_nw_ad_multi(const Eng2 &E, const AlignParams &ap, const double *d_err, hipStream_t st);
 
 void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint8_t *d_prior, double *d_out,
                     hipStream_t st);

@@ -424,12 +424,7 @@ struct NwArgs {
   uint8_t *moves;
   int moves_stride;
   int32_t *nmoves;
-  // batch mode of round engine v2 (k_nw_ad only): work items are (unique | batch position << 32), the centre of an item is
-  // the batch's centre at that position, results go to the cache slot of (batch buffer, position)
-  const Ctl2 *ctl2;
-  const unsigned long long *work64, *gl_work64;
-  const int32_t *list_n;
-  size_t out_n;
+  const int32_t *stop_dev;     // round engine v2: non-zero = the device has halted, nothing to do
 };
 
 // shared tail: traceback + lambda.  NPW = pointer words per row.
@@ -745,14 +740,10 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
   const int nerr = 16 * a.ap.ncol;
   {   // the per-round grid is sized for the worst case (the batch size is only known on the device): blocks past the
       // work leave before touching anything, also when a speculative round turned out to have no centre
-    if (a.ctl2) {
-      if (a.ctl2->state != 0 || a.ctl2->nbatch == 0) return;
-      if ((int)blockIdx.x * 4 * APW >= a.list_n[0] + a.list_n[1]) return;
-    } else {
-      const int n_all = (a.nwork_dev ? *a.nwork_dev : a.nwork_host) + (gl_work ? *gl_nwork_dev : 0);
-      if ((int)blockIdx.x * 4 * APW >= n_all) return;
-      if (a.centre_dev && *a.centre_dev < 0) return;
-    }
+    if (a.stop_dev && *a.stop_dev != 0) return;
+    const int n_all = (a.nwork_dev ? *a.nwork_dev : a.nwork_host) + (gl_work ? *gl_nwork_dev : 0);
+    if ((int)blockIdx.x * 4 * APW >= n_all) return;
+    if (a.centre_dev && *a.centre_dev < 0) return;
   }
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -773,29 +764,16 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
   __syncthreads();
   const SampleDev &S = a.S;
   const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
-  const bool multi = a.ctl2 != nullptr;
-  const int n_nw = multi ? a.list_n[0] : (a.nwork_dev ? *a.nwork_dev : a.nwork_host);
-  const int n_gl = multi ? a.list_n[1] : (gl_work ? *gl_nwork_dev : 0);   // gapless items ride along: same factors/product tail
+  const int n_nw = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
+  const int n_gl = gl_work ? *gl_nwork_dev : 0;            // gapless items ride along: same factors/product tail
   const int nwork = n_nw + n_gl;
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
-  const int centre_v = multi ? 0 : (a.centre_dev ? *a.centre_dev : a.centre);
+  const int centre_v = a.centre_dev ? *a.centre_dev : a.centre;
   if (centre_v < 0 && !a.chunk_centre) return;
-  const size_t out_base = multi ? (size_t)a.ctl2->bbuf * KB_MAX * a.out_n : 0;
   for (int chunk = gwave; chunk * APW < nwork; chunk += nwaves) {
     const int idx = chunk * APW + al;
-    int c, r;
-    size_t oidx;
-    if (multi) {
-      const unsigned long long e = idx < n_nw ? a.work64[idx] : (idx < nwork ? a.gl_work64[idx - n_nw] : ~0ull);
-      r = idx < nwork ? (int)(uint32_t)e : -1;
-      const int kp = idx < nwork ? (int)(e >> 32) : 0;
-      c = a.ctl2->bcentre[kp];
-      oidx = out_base + (size_t)kp * a.out_n + (size_t)(r < 0 ? 0 : r);
-    } else {
-      c = a.chunk_centre ? a.chunk_centre[chunk] : centre_v;
-      r = idx < n_nw ? a.work[idx] : (idx < nwork ? gl_work[idx - n_nw] : -1);
-      oidx = (size_t)(r < 0 ? 0 : r);
-    }
+    const int c = a.chunk_centre ? a.chunk_centre[chunk] : centre_v;
+    int r = idx < n_nw ? a.work[idx] : (idx < nwork ? gl_work[idx - n_nw] : -1);
     const bool gapless = idx >= n_nw;
     const bool active = r >= 0;
     if (!active) r = c;
@@ -991,8 +969,8 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
         l = l * f0; l = l * f1; l = l * f2; l = l * f3; l = l * f4; l = l * f5; l = l * f6; l = l * f7;
       }
       for (; pj < L2; pj++) l = l * fac[pj];
-      a.lam[oidx] = l;
-      a.ham[oidx] = h;
+      a.lam[r] = l;
+      a.ham[r] = h;
     }
   }
 }
@@ -1000,14 +978,14 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,
-                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st) {
+                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st, const int32_t *d_stop_dev) {
   int maxwork = d_nwork ? S.N : nwork_host;
   if (maxwork <= 0 && !d_gl_work) return;
   NwArgs a;
   memset(&a, 0, sizeof a);
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
-  a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev;
+  a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev; a.stop_dev = d_stop_dev;
   { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
   const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
@@ -1046,41 +1024,6 @@ size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   if (W > 127) return 0;
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
   return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
-}
-
-// batch mode: the work lists of k2_screen_multi (engine v2)
-void launch_nw_ad_multi(const Eng2 &E, const AlignParams &ap, const double *d_err, hipStream_t st) {
-  const SampleDev &S = E.S;
-  NwArgs a;
-  memset(&a, 0, sizeof a);
-  a.S = S; a.ap = ap; a.err = d_err; a.lam = E.C.lam; a.ham = E.C.ham;
-  a.ctl2 = E.ctl; a.work64 = E.C.nw_list; a.gl_work64 = E.C.gl_list; a.list_n = E.C.list_n; a.out_n = (size_t)S.N;
-  const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
-  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
-  const int grid = 256 * 8;   // persistent: blocks past the device-side list sizes leave at once
-  const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
-#define D2_LAUNCH_ADM(GLV, DEFV, EDGEV)                                                                                  \
-  do {                                                                                                                   \
-    static size_t attr_set[64] = {0};                                                                                    \
-    int dev_ = 0;                                                                                                        \
-    (void)hipGetDevice(&dev_);                                                                                           \
-    if (lds > attr_set[dev_ & 63]) {                                                                                     \
-      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_set[dev_ & 63] = lds;                                                                                         \
-    }                                                                                                                    \
-    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV>), dim3(grid), dim3(256), lds, st, a, (const int32_t *)nullptr,         \
-                       (const int32_t *)nullptr, G);                                                                     \
-  } while (0)
-#define D2_LAUNCH_ADM2(GLV)                                                                                              \
-  do {                                                                                                                   \
-    if (def) { if (G.edge) D2_LAUNCH_ADM(GLV, true, true); else D2_LAUNCH_ADM(GLV, true, false); }                       \
-    else { if (G.edge) D2_LAUNCH_ADM(GLV, false, true); else D2_LAUNCH_ADM(GLV, false, false); }                         \
-  } while (0)
-  if (G.GL == 21) D2_LAUNCH_ADM2(21);
-  else if (G.GL == 32) D2_LAUNCH_ADM2(32);
-  else D2_LAUNCH_ADM2(64);
-#undef D2_LAUNCH_ADM2
-#undef D2_LAUNCH_ADM
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -56,9 +56,11 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
   }
 }
 
-// ---- commit of a round's comparisons + b_shuffle2 ----------------------------------------------------------------------
-// STORE (first shuffle of a round): the store filter of cluster.cpp:179-201 on the cached comparisons against the round's
-// centre, with the greedy skip of cluster.cpp:127-130 evaluated NOW (lock state of the commit, not of the compare).
+// ---- store filter of a round + b_shuffle2 ------------------------------------------------------------------------------
+// STORE (first shuffle of a round): the store filter of cluster.cpp:179-201 on the round's comparisons (classes from
+// k2_lists - greedy skip already applied with the lock state of the commit - lambda / hamming from the aligner).
+// Most uniques of a large sample never get a second stored comparison: for them the arg-max is partition 0 whatever the
+// reads are, and the pass touches 8 bytes of their state.
 template <bool STORE>
 __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   const Ctl2 *ctl = E.ctl;
@@ -74,7 +76,6 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   }
   __shared__ int s_n, s_base, s_an, s_abase;
   __shared__ int32_t s_delta[DELTA_TAB];
-  __shared__ unsigned int s_stat[4];
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   const Store2 &T = E.T;
@@ -82,17 +83,11 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   const int nclust = ctl->nclust, ci = nclust - 1, centre = ctl->centre;
   const int ntab = nclust < DELTA_TAB ? nclust : DELTA_TAB;
   for (int k = threadIdx.x; k < ntab; k += 256) s_delta[k] = 0;
-  if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
-  int my_stat[4] = {0, 0, 0, 0};                                        // classes of this thread's uniques (STORE)
   int32_t *mv = E.movers + ((size_t)(ring * SH_CHAIN + level)) * 3 * (size_t)N;
   int32_t *dl = E.dlt + (size_t)level * E.ccap;
-  // STORE: where the round's comparisons are
-  const int slot = ctl->slot, kpos = slot % KB_MAX;
-  const uint16_t *bcls = E.C.bcls + (size_t)(slot / KB_MAX) * E.C.Npad;
-  const double *lamc = E.C.lam + (size_t)slot * N;
-  const uint32_t *hamc = E.C.ham + (size_t)slot * N;
   const uint32_t creads_c = S.reads[centre];
   const uint32_t reads_ci = STORE ? reads_at(E, ci, level) : 0u;
+  const uint32_t reads_0 = reads_at(E, 0, level);
   for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
     if (threadIdx.x == 0) { s_n = 0; s_an = 0; }
@@ -104,48 +99,52 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
     if (r < N) {
       head = T.head[r];
       from = P.clust_of[r];
-      // arg-max of lambda * reads over the stored comparisons; ties go to the lowest partition (cluster.cpp:229-239)
-      int best_i = 0;
-      best_l = T.lam0[r]; best_h = T.ham0[r];
-      double best_e = best_l * reads_at(E, 0, level);
-      for (int b = head, first = 1, hops = 0; b >= 0 && hops < (1 << 22); first = 0, hops++) {   // (bounded: never spin on a bad link)
-        const CompBlk *cb = T.blk + b;
-        const int cnt = cb->cnt;
-        if (first) hcnt = cnt;
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-          if (k < cnt) {
-            const int i = cb->i[k];
-            const double nl = cb->lam[k], e = nl * reads_at(E, i, level);
-            if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_h = cb->ham[k]; }
-          }
-        b = cb->next;
-      }
       if (STORE) {
-        const uint32_t code = (bcls[r] >> (2 * kpos)) & 3u;
-        const uint32_t rd = S.reads[r];
-        const bool skip = E.greedy && (rd > creads_c || P.lock[r]);
-        if (skip) my_stat[3]++;
-        else if (code == CLS_SKIP) atomicOr(P.err_flag, 8);            // the cache lacks a comparison the round needs
-        else my_stat[code == CLS_NW ? 0 : (code == CLS_GAPLESS ? 1 : 2)]++;
-        if (!skip && code >= CLS_GAPLESS) {
-          l = lamc[r]; h = hamc[r];
+        const uint8_t cl = E.cls[r];
+        if (cl >= CLS_GAPLESS) {
+          l = E.lam[r]; h = E.ham[r];
           if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);        // "Lambda out-of-range error." (cluster.cpp:184)
           const double em = P.E_minmax[r];
           keep = l * E.total_reads > em;                               // this partition could attract this unique
           if (keep) {
             if (l * creads_c > em) P.E_minmax[r] = l * creads_c;
             if (r == centre) { P.comp_i[r] = ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
-            need_new = head < 0 || hcnt >= 3;
-            if (need_new) apos = atomicAdd(&s_an, 1);
-            const double e = l * reads_ci;
-            if (e > best_e) { best_e = e; best_i = ci; best_l = l; best_h = h; }   // (ci is the highest index: only strictly)
           }
+        }
+      }
+      // arg-max of lambda * reads over the stored comparisons; ties go to the lowest partition (cluster.cpp:229-239)
+      int best_i = 0;
+      const CompBlk *best_cb = nullptr;
+      int best_k = 0;
+      if (head >= 0 || keep) {
+        best_l = T.lam0[r];
+        double best_e = best_l * reads_0;
+        for (int b = head, first = 1, hops = 0; b >= 0 && hops < (1 << 22); first = 0, hops++) {   // (bounded: never spin on a bad link)
+          const CompBlk *cb = T.blk + b;
+          const int cnt = cb->cnt;
+          if (first) hcnt = cnt;
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+            if (k < cnt) {
+              const int i = cb->i[k];
+              const double nl = cb->lam[k], e = nl * reads_at(E, i, level);
+              if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_cb = cb; best_k = k; }
+            }
+          b = cb->next;
+        }
+        if (keep) {
+          need_new = head < 0 || hcnt >= 3;
+          if (need_new) apos = atomicAdd(&s_an, 1);
+          const double e = l * reads_ci;
+          if (e > best_e) { best_e = e; best_i = ci; best_l = l; best_cb = nullptr; }   // (ci is the highest index: only strictly)
         }
       }
       if (best_i != from && r != P.centre_of[from]) {
         move = true;
         to = best_i;
+        if (best_i == 0) { best_l = T.lam0[r]; best_h = T.ham0[r]; }
+        else if (best_cb) best_h = best_cb->ham[best_k];
+        else best_h = h;
         pos = atomicAdd(&s_n, 1);
         P.clust_of[r] = to;
         P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
@@ -187,17 +186,61 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
     const int32_t d = s_delta[k];
     if (d) atomicAdd(&dl[k], d);
   }
-  if (STORE) {   // class statistics of the round (nalign / nshroud, dada.h:113-114), counted at commit time
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      int v = my_stat[q];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stat[q], (unsigned int)v);
+}
+
+// ---- commit of a cached compare: classes of the round's centre from the batch buffer, the greedy skip of cluster.cpp:127-130
+// evaluated NOW (lock state of the commit, not of the compare), the aligner's work lists, and the round's class statistics ----
+__global__ __launch_bounds__(256) void k2_lists(Eng2 E, int cap) {
+  const Ctl2 *ctl = E.ctl;
+  if (ctl->state != 0) return;
+  extern __shared__ int32_t s_lists[];                                   // [2][cap]
+  __shared__ int s_cnt[8];
+  __shared__ unsigned int s_stat[4];
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  const int slot = ctl->slot, kpos = slot % KB_MAX, centre = ctl->centre;
+  const uint16_t *bcls = E.C.bcls + (size_t)(slot / KB_MAX) * E.C.Npad;
+  const uint32_t creads_c = S.reads[centre];
+  int32_t *s_nw = s_lists, *s_gl = s_lists + cap;
+  if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+  __syncthreads();
+  int my_stat[4] = {0, 0, 0, 0};
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+    uint32_t code = (bcls[r] >> (2 * kpos)) & 3u;
+    const bool skip = E.greedy && (S.reads[r] > creads_c || P.lock[r]);
+    if (skip) code = CLS_SKIP;
+    else if (code == CLS_SKIP) atomicOr(P.err_flag, 8);                  // the cache lacks a comparison the round needs
+    my_stat[code == CLS_NW ? 0 : (code == CLS_GAPLESS ? 1 : (code == CLS_SHROUD ? 2 : 3))]++;
+    E.cls[r] = (uint8_t)code;
+    if (code == CLS_NW) {
+      const int q = atomicAdd(&s_cnt[0], 1);
+      if (q < cap) s_nw[q] = r; else E.nw_list[atomicAdd(&E.list_n[0], 1)] = r;
+    } else if (code == CLS_GAPLESS) {
+      const int q = atomicAdd(&s_cnt[1], 1);
+      if (q < cap) s_gl[q] = r; else E.gl_list[atomicAdd(&E.list_n[1], 1)] = r;
     }
-    __syncthreads();
-    if (threadIdx.x < 4 && s_stat[threadIdx.x]) atomicAdd(&out->stat[threadIdx.x], (unsigned long long)s_stat[threadIdx.x]);
   }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    int v = my_stat[q];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stat[q], (unsigned int)v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int n = min(s_cnt[threadIdx.x], cap);
+    s_cnt[2 + threadIdx.x] = n;
+    s_cnt[4 + threadIdx.x] = n ? atomicAdd(&E.list_n[threadIdx.x], n) : 0;   // one global atomic per list per block
+  }
+  if (threadIdx.x < 4 && s_stat[threadIdx.x]) {
+    Round2Out *out = E.dblk + (ctl->pub_seq % RING2);
+    atomicAdd(&out->stat[threadIdx.x], (unsigned long long)s_stat[threadIdx.x]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < s_cnt[2]; i += 256) E.nw_list[s_cnt[4] + i] = s_nw[i];
+  for (int i = threadIdx.x; i < s_cnt[3]; i += 256) E.gl_list[s_cnt[5] + i] = s_gl[i];
 }
 
 // ---- b_p_update + first stage of b_bud (no "would another shuffle move" pass: the chain's shuffles are real calls) -----
@@ -323,11 +366,13 @@ __global__ __launch_bounds__(256) void k2_ties(Eng2 E, int nlev, BudKey init, co
 
 // ---- the birth, the plan of the coming round's compare, and the publication of the round's result block -----------------
 constexpr int PLAN_STRIPS = 16;   // the prediction looks at the first PLAN_STRIPS x 1024 uniques (abundance order)
+constexpr int NBUF_MAX = 64;      // batch buffers (NBUF_MAX x KB_MAX cached centres at most)
 
 // (one block of 1024 threads)  Applies the birth of `raw` out of partition `from`, then plans the compare of the round that
 // follows: a cache hit needs nothing; a miss takes the next batch buffer and fills it with `raw` plus the first significant
-// bud candidates in index order that are not cached yet (input is abundance-sorted: those are the likely next centres -
-// a wrong guess only costs its share of one batched launch), and builds the batch's k-mer tables.
+// bud candidates in index order that are not cached yet (input is abundance-sorted: while p-values underflow to 0 - most
+// of a run - that IS the bud order; a wrong guess only costs its share of one pass over the k-mer records), and builds the
+// batch's k-mer tables.
 static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -338,6 +383,7 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
   int *s_nb = s_misc, *s_hit = s_misc + 1, *s_wcnt = s_misc + 2;   // s_wcnt[16]
   int *s_bc = s_misc + 20;                                          // [KB_MAX]
   int *s_tab = s_misc + 32;                                         // [nslots] copy of slot_centre
+  uint32_t *s_bits = s_cnt;                                         // [PLAN_STRIPS * 32] cached uniques among the scanned prefix
   if (tid == 0) {
     const int newi = ctl->nclust;
     const uint32_t reads_new = S.reads[raw];
@@ -352,32 +398,40 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
     ctl->nclust = newi + 1;
     ctl->centre = raw;
     ctl->nsh_base = 0;
-    int hit = -1;
-    for (int s = 0; s < nslots; s++) if (C.slot_centre[s] == raw) hit = s;
-    *s_hit = hit;
-    if (hit >= 0) { ctl->slot = hit; ctl->nbatch = 0; *s_nb = 0; }
-    else {
-      const int bbuf = ctl->next_bbuf;
-      ctl->next_bbuf = (bbuf + 1) % C.NBUF;
-      for (int k = 0; k < KB_MAX; k++) C.slot_centre[bbuf * KB_MAX + k] = -1;
-      ctl->bbuf = bbuf;
-      ctl->slot = bbuf * KB_MAX;
-      s_bc[0] = raw;
-      *s_nb = 1;
-    }
+    E.list_n[0] = 0; E.list_n[1] = 0;                               // the coming round's work lists
+    *s_hit = -1;
   }
   __syncthreads();
-  if (*s_hit >= 0) return;
-  for (int s = tid; s < nslots; s += blockDim.x) s_tab[s] = C.slot_centre[s];
+  for (int q = tid; q < nslots; q += blockDim.x) if (C.slot_centre[q] == raw) *s_hit = q;   // (at most one slot holds it)
+  __syncthreads();
+  if (*s_hit >= 0) {
+    if (tid == 0) { ctl->slot = *s_hit; ctl->nbatch = 0; }
+    return;
+  }
+  if (tid == 0) {
+    const int bbuf = ctl->next_bbuf;
+    ctl->next_bbuf = (bbuf + 1) % C.NBUF;
+    for (int k = 0; k < KB_MAX; k++) C.slot_centre[bbuf * KB_MAX + k] = -1;
+    ctl->bbuf = bbuf;
+    ctl->slot = bbuf * KB_MAX;
+    s_bc[0] = raw;
+    *s_nb = 1;
+  }
+  for (int q = tid; q < PLAN_STRIPS * 32; q += blockDim.x) s_bits[q] = 0;
+  __syncthreads();
+  for (int q = tid; q < nslots; q += blockDim.x) {
+    const int c = C.slot_centre[q];
+    s_tab[q] = c;
+    if (c >= 0 && c < PLAN_STRIPS * 1024) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
+  }
   __syncthreads();
   // ---- prediction: first significant candidates in index order ----
   for (int strip = 0; strip < PLAN_STRIPS && *s_nb < KB_MAX && strip * 1024 < S.N; strip++) {
     const int r = strip * 1024 + tid;
     bool ok = false;
-    if (r < S.N && r != raw && bud_candidate2(E, r, 0)) {
+    if (r < S.N && r != raw && !((s_bits[r >> 5] >> (r & 31)) & 1u) && bud_candidate2(E, r, 0)) {
       const double p = P.p[r];
       ok = (p * S.N < E.omegaA) || (S.prior[r] && p < E.omegaP);
-      for (int s = 0; ok && s < nslots; s++) if (s_tab[s] == r) ok = false;
     }
     const unsigned long long bal = __ballot(ok);
     const int w = tid >> 6, lane = tid & 63;
@@ -430,7 +484,7 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
       C.slot_centre[ctl->bbuf * KB_MAX + k] = c;
     } else { ctl->bcentre[k] = -1; ctl->breads[k] = 0; ctl->blen[k] = 0; }
   }
-  if (tid == 0) { ctl->nbatch = nb; C.list_n[0] = 0; C.list_n[1] = 0; }
+  if (tid == 0) ctl->nbatch = nb;
 }
 
 static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
@@ -470,7 +524,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev) {
   Ctl2 *ctl = E.ctl;
   if (ctl->state != 0) return;
   __shared__ uint32_t s_cnt[KB_MAX * NKMER];
-  __shared__ int s_misc[32 + 256];
+  __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
   __shared__ int s_halt, s_raw, s_from, s_evalok;
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -523,7 +577,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev) {
 // the host's own b_bud decision (ties, near ties, prior births, capacity) applied, the coming round planned, the device resumed
 __global__ __launch_bounds__(1024) void k2_host_birth(Eng2 E, int raw, int from) {
   __shared__ uint32_t s_cnt[KB_MAX * NKMER];
-  __shared__ int s_misc[32 + 256];
+  __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
   if (threadIdx.x == 0) { E.ctl->state = 0; E.ctl->halt = H2_NONE; }
   __syncthreads();
   apply_birth_and_plan(E, raw, from, s_cnt, s_misc);
@@ -534,8 +588,10 @@ __global__ void k2_resume(Eng2 E) { E.ctl->state = 0; E.ctl->halt = H2_NONE; }
 // 16 lanes per unique as in k_screen, but one pass over the unique's k-mer record serves up to KB_MAX centres: the centre
 // tables are interleaved (byte k of tab8[id] = min(count_k[id], 63)), so one 8-byte LDS read + two SWAR compares give
 // "rank < count" for all centres.  A wave owns 16 consecutive uniques per macro-iteration (lane group g takes uniques
-// 4g..4g+3 in turn) and writes their class words (2 bits per centre) as one 32-byte store.
-__global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E, int cap) {
+// 4g..4g+3 in turn): the four rows and their scalars are requested together before any of them is used, and the class
+// words of the 16 uniques (2 bits per centre) leave as one 32-byte store.  Only classes are produced: the aligner runs
+// when (and if) a centre's round comes.
+__global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E) {
   const Ctl2 *ctl = E.ctl;
   const int nb = ctl->nbatch;
   if (ctl->state != 0 || nb == 0) return;
@@ -544,10 +600,8 @@ __global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E, int cap) {
   const Cache2 &C = E.C;
   const ScreenParams sp = E.sp;
   uint2 *tab = (uint2 *)s_mem;                               // [1024]
-  unsigned long long *s_nw = (unsigned long long *)(tab + NKMER);   // [cap]
-  unsigned long long *s_gl = s_nw + cap;                     // [cap]
-  uint16_t *cord = (uint16_t *)(s_gl + cap);                 // [KB_MAX][LK]
-  __shared__ int s_cnt[8];
+  uint16_t *cord = (uint16_t *)(tab + NKMER);                // [KB_MAX][LK]
+  int32_t *thr = (int32_t *)(cord + (size_t)KB_MAX * S.LK);  // [maxlen + 2] kdist > cutoff <=> dot < thr[d]
   __shared__ int cL[KB_MAX], cC[KB_MAX];
   __shared__ uint32_t cR[KB_MAX];
   const int tid = threadIdx.x;
@@ -557,30 +611,44 @@ __global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E, int cap) {
     const uint4 *src = (const uint4 *)C.ord;
     for (int i = tid; i < n16; i += 256) ((uint4 *)cord)[i] = src[i];
   }
+  for (int i = tid; i < S.maxlen + 2; i += 256) thr[i] = E.thresh[i];
   if (tid < KB_MAX) { cL[tid] = ctl->blen[tid]; cC[tid] = ctl->bcentre[tid]; cR[tid] = ctl->breads[tid]; }
-  if (tid < 8) s_cnt[tid] = 0;
   __syncthreads();
   uint16_t *bcls = C.bcls + (size_t)ctl->bbuf * C.Npad;
   const int sub = tid & 15, g = (tid & 63) >> 4;
   const int gwave = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
   const int nchunk = (S.maxlen - KMER_SIZE + 1 + 7) >> 3;
   const uint4 pad4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  const bool heavy_on = sp.use_kmers && S.HMAX > 0;
   for (int base16 = gwave * 16; base16 < S.N; base16 += nwaves * 16) {
+    // ---- request everything the four uniques of this lane group need ----
+    uint4 c0[4], c1[4];
+    int Lr[4], nh[4];
+    uint32_t rd[4];
+    bool lk[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = base16 + 4 * g + it;
+      const bool on = r < S.N;
+      const uint4 *row = (const uint4 *)(S.kord + (size_t)(on ? r : 0) * S.LK);
+      c0[it] = (on && sp.use_kmers && sub < nchunk) ? row[sub] : pad4;
+      c1[it] = (on && sp.use_kmers && sub + 16 < nchunk) ? row[sub + 16] : pad4;
+      Lr[it] = on ? S.len[r] : 0;
+      rd[it] = on ? S.reads[r] : 0u;
+      lk[it] = on && E.greedy && E.P.lock[r];
+      nh[it] = (on && heavy_on) ? S.nheavy[r] : 0;
+    }
     unsigned long long clsacc = 0;
+#pragma unroll
     for (int it = 0; it < 4; it++) {
       const int r = base16 + 4 * g + it;
       if (r >= S.N) continue;
       const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
-      const int Lr = S.len[r];
-      const uint32_t rd = S.reads[r];
-      const bool lk = E.greedy && E.P.lock[r];
       // ---- pass 1: unordered overlap with every centre of the batch ----
       uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;               // 16-bit fields: centres (0,2) (1,3) (4,6) (5,7)
-      uint4 c0 = pad4, c1 = pad4;
       if (sp.use_kmers) {
         for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
-          const uint4 v = row[ch];
-          if (j == 0) c0 = v; else if (j == 1) c1 = v;
+          const uint4 v = j == 0 ? c0[it] : (j == 1 ? c1[it] : row[ch]);
           uint32_t ax = 0, ay = 0;
           const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -605,32 +673,31 @@ __global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E, int cap) {
       }
       uint32_t code16 = 0;
       for (int k = 0; k < nb; k++) {
-        uint32_t dot = ((k & 4) ? ((k & 1) ? w3 : w2) : ((k & 1) ? w1 : w0)) >> ((k & 2) ? 16 : 0) & 0xFFFFu;
+        uint32_t dot = (((k & 4) ? ((k & 1) ? w3 : w2) : ((k & 1) ? w1 : w0)) >> ((k & 2) ? 16 : 0)) & 0xFFFFu;
         const int Lc = cL[k];
-        const bool skipped = E.greedy && (rd > cR[k] || (lk && r != cC[k]));
+        const bool skipped = E.greedy && (rd[it] > cR[k] || (lk[it] && r != cC[k]));
         uint32_t c = CLS_SKIP;
         if (!skipped) {
-          if (sp.use_kmers && S.HMAX > 0) {                   // k-mers occurring > 63 times: exact correction
-            const int nh = S.nheavy[r];
-            for (int hh = 0; hh < nh; hh++) {
+          if (nh[it] > 0) {                                   // k-mers occurring > 63 times: exact correction
+            for (int hh = 0; hh < nh[it]; hh++) {
               const uint32_t e = S.heavy[(size_t)r * S.HMAX + hh], cr = e >> 16, cc = C.full[(size_t)k * NKMER + (e & 1023u)];
               const uint32_t m = cr < cc ? cr : cc;
               if (m > RANK_SAT) dot += m - RANK_SAT;
             }
             dot &= 0xFFFFu;                                   // the reference accumulates in uint16_t (kmers.cpp:16,34,69)
           }
-          const int d = (Lc < Lr ? Lc : Lr) - KMER_SIZE + 1;
-          const bool shroud = sp.use_kmers && (int)dot < E.thresh[d];   // kdist > kdist_cutoff
+          const int d = (Lc < Lr[it] ? Lc : Lr[it]) - KMER_SIZE + 1;
+          const bool shroud = sp.use_kmers && (int)dot < thr[d];   // kdist > kdist_cutoff
           if (shroud) c = CLS_SHROUD;
           else {
-            const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || Lr == Lc);
+            const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || Lr[it] == Lc);
             bool gapless = sp.band == 0;
             if (!gapless && gl_ok) {
               // ---- pass 2 (survivors only): ordered overlap over the first d positions ----
               const uint16_t *ck = cord + (size_t)k * S.LK;
               uint32_t ord = 0;
               for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
-                const uint4 v = j == 0 ? c0 : (j == 1 ? c1 : row[ch]);
+                const uint4 v = j == 0 ? c0[it] : (j == 1 ? c1[it] : row[ch]);
                 const uint4 ck4 = ((const uint4 *)ck)[ch];
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w}, cw[4] = {ck4.x, ck4.y, ck4.z, ck4.w};
                 const int i0 = ch << 3;
@@ -649,30 +716,11 @@ __global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E, int cap) {
           }
         }
         code16 |= c << (2 * k);
-        if (sub == 0 && c >= CLS_GAPLESS) {
-          const unsigned long long ent = (unsigned long long)(uint32_t)r | ((unsigned long long)k << 32);
-          if (c == CLS_NW) {
-            const int q = atomicAdd(&s_cnt[0], 1);
-            if (q < cap) s_nw[q] = ent; else C.nw_list[atomicAdd(&C.list_n[0], 1)] = ent;
-          } else {
-            const int q = atomicAdd(&s_cnt[1], 1);
-            if (q < cap) s_gl[q] = ent; else C.gl_list[atomicAdd(&C.list_n[1], 1)] = ent;
-          }
-        }
       }
       clsacc |= (unsigned long long)code16 << (16 * it);
     }
     if (sub == 0 && base16 + 4 * g < S.N) *(unsigned long long *)(bcls + base16 + 4 * g) = clsacc;
   }
-  __syncthreads();
-  if (tid < 2) {
-    const int n = min(s_cnt[tid], cap);
-    s_cnt[2 + tid] = n;
-    s_cnt[4 + tid] = n ? atomicAdd(&C.list_n[tid], n) : 0;   // one global atomic per list per block
-  }
-  __syncthreads();
-  for (int i = tid; i < s_cnt[2]; i += 256) C.nw_list[s_cnt[4] + i] = s_nw[i];
-  for (int i = tid; i < s_cnt[3]; i += 256) C.gl_list[s_cnt[5] + i] = s_gl[i];
 }
 
 // post-hoc partition p-value inputs (error.cpp:101-119) from the v2 store
@@ -703,13 +751,8 @@ void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, c
   const int grid = std::min((E.S.N + 255) / 256, 2048);
   hipLaunchKernelGGL(k2_store0, dim3(grid), dim3(256), 0, st, E, d_lam, d_ham, d_cls, d_round_counters);
 }
-static size_t screen_multi_lds(const SampleDev &S, int cap) {
-  return (size_t)NKMER * 8 + (size_t)cap * 16 + (size_t)KB_MAX * S.LK * 2 + 64;
-}
 void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
-  int cap = 1024;
-  while (cap > 64 && screen_multi_lds(E.S, cap) > 60 * 1024) cap >>= 1;
-  const size_t lds = screen_multi_lds(E.S, cap);
+  const size_t lds = (size_t)NKMER * 8 + (size_t)KB_MAX * E.S.LK * 2 + (size_t)(E.S.maxlen + 2) * 4 + 16;
   static size_t attr_set[64] = {0};
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
@@ -718,7 +761,13 @@ void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
     attr_set[dev_ & 63] = lds;
   }
   const int grid = std::min((E.S.N + 63) / 64, 2048);
-  hipLaunchKernelGGL(k2_screen_multi, dim3(grid), dim3(256), lds, st, E, cap);
+  hipLaunchKernelGGL(k2_screen_multi, dim3(grid), dim3(256), lds, st, E);
+}
+void launch2_lists(const Eng2 &E, hipStream_t st) {
+  const int grid = std::min((E.S.N + 255) / 256, 1024);
+  const int iters = ((E.S.N + 255) / 256 + grid - 1) / grid;
+  const int cap = std::min(iters * 256, 4096);
+  hipLaunchKernelGGL(k2_lists, dim3(grid), dim3(256), (size_t)cap * 8, st, E, cap);
 }
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st) {
   const int grid = std::min((E.S.N + 255) / 256, 2048);
