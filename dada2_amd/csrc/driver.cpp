@@ -193,8 +193,8 @@ int nw_sentinel(const dada2hip_opts &o) {
 // boundary hands over 250 MB of characters and 2 GB of doubles, so the marshalling is spread over the host pool:
 //   pass 1  strlen / abundance / prior per unique                                  (threads)
 //   pass 2  2-bit packing + ACGT validation straight into a pinned buffer          (threads)  -> one async H2D
-//   pass 3  quality rows copied chunk-wise into a ring of pinned staging buffers   (threads)  -> H2D + k_round_quals
-//           per chunk on the side stream, overlapping the next chunk's host copy and the k-mer build on the main stream
+//   pass 3  (uint8) round(mean quality) of raw_new (containers.cpp:34), chunk-wise into pinned bytes (threads) -> H2D per
+//           chunk on the side stream, overlapping the next chunk's conversion and the k-mer build on the main stream
 // lite = nwalign / nwvec helper samples: no qualities, no k-mer records, any length >= 1.
 void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, const int32_t *abund,
                    const uint8_t *priors, const double *quals, int32_t quals_nrow, int device, bool lite = false) {
@@ -306,52 +306,46 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
   D.kord = s->kord.p; D.heavy = s->heavy.p;
   launch_build_kmers(D, s->stream);          // overlaps the quality upload below (side stream)
 
-  // qualities: the R double matrix goes through a ring of pinned staging buffers, rounded on the device
-  DevBuf<int32_t> flags;
-  flags.alloc(2);
-  D2_HIP(hipMemsetAsync(flags.p, 0, 8, s->side));
+  // qualities: raw_new's (uint8) round(mean quality) (containers.cpp:34) is part of the marshalling here as it is in the
+  // reference: the host pool turns the R double matrix (8 B per base, 2 GB at 10^6 uniques) into the byte matrix the
+  // device keeps, straight into pinned memory, and each finished chunk goes out while the next is being converted.
+  // NA/NaN past a read's end are never looked at (Rmain.cpp:113 copies only the first `length` entries).
   {
-    constexpr int NB = 3;
-    const size_t chunk_bytes = (size_t)32 << 20;
-    const size_t rows_per = std::max<size_t>(1, chunk_bytes / ((size_t)maxlen * 8));
-    const size_t stage_elems = std::min<size_t>(rows_per, nraw) * maxlen;
-    PinBuf<double> hst[NB];
-    DevBuf<double> dst[NB];
-    hipEvent_t ev[NB];
-    const int nb_used = (int)std::min<size_t>(NB, ((size_t)nraw + rows_per - 1) / rows_per);
-    for (int b = 0; b < nb_used; b++) {
-      hst[b].alloc(stage_elems); dst[b].alloc(stage_elems);
-      D2_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    const int LQ = D.LQ;
+    PinBuf<uint8_t> hq;
+    hq.alloc((size_t)nraw * LQ);
+    std::atomic<int> badq{0}, qmax{0};
+    const size_t rows_per = std::max<size_t>(1, ((size_t)16 << 20) / (size_t)LQ);
+    for (size_t r0 = 0; r0 < (size_t)nraw; r0 += rows_per) {
+      const size_t nr = std::min<size_t>(rows_per, nraw - r0);
+      parallel_for(nr, 512, [&](size_t lo, size_t hi) {
+        int mx = 0, bad = 0;
+        for (size_t r = r0 + lo; r < r0 + hi; r++) {
+          const double *src = quals + r * (size_t)maxlen;
+          uint8_t *dst = hq.p + r * (size_t)LQ;
+          const int L = s->h_len[r];
+          for (int p = 0; p < L; p++) {
+            const double x = src[p];
+            double xr;
+            if (x >= 0.0 && x < 256.0) { const int t = (int)x; xr = (double)(t + ((x - (double)t) >= 0.5 ? 1 : 0)); }   // round(): half away from zero
+            else xr = std::round(x);
+            if (!(xr >= 0.0 && xr <= 255.0)) { bad = 1; xr = 0.0; }
+            const int v = (int)xr;
+            mx = std::max(mx, v);
+            dst[p] = (uint8_t)v;
+          }
+          memset(dst + L, 0, (size_t)(LQ - L));
+        }
+        if (bad) badq.store(1, std::memory_order_relaxed);
+        int cur = qmax.load();
+        while (mx > cur && !qmax.compare_exchange_weak(cur, mx)) {}
+      });
+      D2_HIP(hipMemcpyAsync(D.qual + r0 * LQ, hq.p + r0 * LQ, nr * (size_t)LQ, hipMemcpyHostToDevice, s->side));
     }
-    // the row lengths are needed by the rounding kernel: they were queued on the main stream
-    D2_HIP(hipEventRecord(s->ev0, s->stream));
-    D2_HIP(hipStreamWaitEvent(s->side, s->ev0, 0));
-    size_t c = 0;
-    try {
-      for (size_t r0 = 0; r0 < (size_t)nraw; r0 += rows_per, c++) {
-        const int b = (int)(c % NB);
-        const size_t nr = std::min<size_t>(rows_per, nraw - r0);
-        if (c >= (size_t)NB) D2_HIP(hipEventSynchronize(ev[b]));   // the kernel that read this pair of buffers is done
-        const double *src = quals + r0 * maxlen;
-        double *dstp = hst[b].p;
-        const size_t total = nr * (size_t)maxlen;
-        parallel_for(total, (size_t)1 << 17, [&](size_t lo, size_t hi) { memcpy(dstp + lo, src + lo, (hi - lo) * 8); });
-        D2_HIP(hipMemcpyAsync(dst[b].p, hst[b].p, total * 8, hipMemcpyHostToDevice, s->side));
-        launch_round_quals(dst[b].p, (int)nr, maxlen, D.len + r0, D.qual + r0 * D.LQ, D.LQ, flags.p, s->side);
-        D2_HIP(hipEventRecord(ev[b], s->side));
-      }
-      D2_HIP(hipStreamSynchronize(s->side));
-    } catch (...) {
-      (void)hipStreamSynchronize(s->side);
-      for (int b = 0; b < nb_used; b++) (void)hipEventDestroy(ev[b]);
-      throw;
-    }
-    for (int b = 0; b < nb_used; b++) (void)hipEventDestroy(ev[b]);
+    D2_HIP(hipStreamSynchronize(s->side));                    // (the pinned buffer goes back to the cache)
+    if (badq.load()) throw InputError{"Invalid derep$quals matrix. Quality values must be positive integers."};
+    s->qmax = qmax.load();
   }
-  int32_t hf[2] = {0, 0};
-  D2_HIP(hipMemcpy(hf, flags.p, 8, hipMemcpyDeviceToHost));
-  if (hf[0]) throw InputError{"Invalid derep$quals matrix. Quality values must be positive integers."};
-  s->qmax = hf[1];
   D2_HIP(hipStreamSynchronize(s->stream));
   D2_HIP(hipGetLastError());
   s->ms_upload = ms_since(t0);
@@ -1320,7 +1314,8 @@ struct Run {
         case H2_MAXCLUST: done = true; break;
         case H2_HOST_DECIDE:
         case H2_CAPACITY: {
-          sync_spin(s->stream);                                // the launches queued behind the halt are no-ops: drain them
+          // the launches already queued behind the halt are no-ops (they neither touch state nor publish): the host's birth
+          // is simply queued behind them, no drain needed unless buffers have to grow
           v2_enq = v2_cons;
           v2_enqrec.resize((size_t)v2_cons);
           if (b.halt == H2_CAPACITY) v2_grow(b);

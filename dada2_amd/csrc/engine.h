@@ -156,8 +156,6 @@ void launch_posthoc(const PartState &P, const SampleDev &S, const int32_t *d_clu
                     int32_t *d_nout, int cap, hipStream_t st);
 
 // launch wrappers implemented in kernels.hip -----------------------------------------------------
-void launch_round_quals(const double *d_q, int n, int maxlen, const int32_t *d_len, uint8_t *d_out, int LQ,
-                        int32_t *d_flags, hipStream_t st);
 void launch_build_kmers(const SampleDev &S, hipStream_t st);
 // counters: [0]=#NW work items, [1]=#gapless work items, [2]=#shrouded, [3]=#skipped
 void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const uint8_t *d_skip, const uint8_t *d_lock,

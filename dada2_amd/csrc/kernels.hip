@@ -22,47 +22,6 @@ static __device__ __forceinline__ uint32_t base_at(const uint32_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// quality upload: double mean quality -> (uint8) round()   (containers.cpp:34); NA/NaN past the end.
-__global__ __launch_bounds__(256) void k_round_quals(const double *__restrict__ q, int n, int maxlen, const int32_t *__restrict__ len,
-                                                     uint8_t *__restrict__ out, int LQ, int32_t *__restrict__ flags) {
-  // one thread per 4 output bytes (LQ is a multiple of 16): 4 doubles in, one packed word out
-  const int LQ4 = LQ >> 2;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)n * (size_t)LQ4;
-  int mx = 0, bad = 0;
-  for (; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / LQ4), p0 = (int)(idx % LQ4) << 2;
-    const int L = len[r];
-    uint32_t w = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int p = p0 + k;
-      if (p < L) {
-        double x = round(q[(size_t)r * maxlen + p]);
-        if (!(x >= 0.0 && x <= 255.0)) { bad = 1; x = 0.0; }
-        const int v = (int)x;
-        mx = max(mx, v);
-        w |= (uint32_t)v << (8 * k);
-      }
-    }
-    ((uint32_t *)out)[idx] = w;
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); bad |= __shfl_xor(bad, o, 64); }
-  if ((threadIdx.x & 63) == 0) {   // one atomic per wave (per element they all hit one address and serialise)
-    if (bad) atomicOr(flags, 1);
-    if (mx > 0) atomicMax(flags + 1, mx);
-  }
-}
-
-void launch_round_quals(const double *d_q, int n, int maxlen, const int32_t *d_len, uint8_t *d_out, int LQ,
-                        int32_t *d_flags, hipStream_t st) {
-  size_t total = (size_t)n * (LQ / 4);
-  int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_round_quals, dim3(grid), dim3(256), 0, st, d_q, n, maxlen, d_len, d_out, LQ, d_flags);
-}
-
-// ------------------------------------------------------------------------------------------------
 // k-mer records, one thread per unique with a private 1024-entry u16 count table in LDS
 // (table[km][lane], 128 KiB per 64-thread block).  For every position i < len-4 it emits the
 // ordered k-mer id (kmers.cpp:246-279) together with its occurrence rank = number of earlier

@@ -90,8 +90,6 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   const uint32_t reads_0 = reads_at(E, 0, level);
   for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
-    if (threadIdx.x == 0) { s_n = 0; s_an = 0; }
-    __syncthreads();
     bool keep = false, need_new = false, move = false;
     double l = 0.0, best_l = 0.0;
     uint32_t h = 0, best_h = 0;
@@ -134,7 +132,10 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
         }
         if (keep) {
           need_new = head < 0 || hcnt >= 3;
-          if (need_new) apos = atomicAdd(&s_an, 1);
+          if (!need_new) {                                             // room in the newest block: append in place
+            CompBlk *cb = T.blk + head;
+            cb->i[hcnt] = ci; cb->ham[hcnt] = h; cb->lam[hcnt] = l; cb->cnt = hcnt + 1;
+          }
           const double e = l * reads_ci;
           if (e > best_e) { best_e = e; best_i = ci; best_l = l; best_cb = nullptr; }   // (ci is the highest index: only strictly)
         }
@@ -145,7 +146,6 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
         if (best_i == 0) { best_l = T.lam0[r]; best_h = T.ham0[r]; }
         else if (best_cb) best_h = best_cb->ham[best_k];
         else best_h = h;
-        pos = atomicAdd(&s_n, 1);
         P.clust_of[r] = to;
         P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
         const uint32_t rd = S.reads[r];
@@ -154,24 +154,25 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
         P.update_e[to] = 1; P.update_e[from] = 1;
       }
     }
+    // movers and new store blocks are rare in most blocks of most calls: the bookkeeping below only runs where there are any
+    if (!__syncthreads_or(move || need_new)) continue;
+    if (threadIdx.x == 0) { s_n = 0; s_an = 0; }
+    __syncthreads();
+    if (move) pos = atomicAdd(&s_n, 1);
+    if (need_new) apos = atomicAdd(&s_an, 1);
     __syncthreads();
     if (threadIdx.x == 0) {
       s_base = s_n ? atomicAdd(&out->cnt[level], s_n) : 0;
       s_abase = s_an ? atomicAdd(T.blk_count, s_an) : 0;
     }
     __syncthreads();
-    if (keep) {
-      if (need_new) {
-        const int nb = s_abase + apos;
-        if (nb < T.blk_cap) {
-          CompBlk *cb = T.blk + nb;
-          cb->next = head; cb->cnt = 1; cb->i[0] = ci; cb->ham[0] = h; cb->lam[0] = l;
-          T.head[r] = nb;
-        } else atomicOr(P.err_flag, 2);
-      } else {
-        CompBlk *cb = T.blk + head;
-        cb->i[hcnt] = ci; cb->ham[hcnt] = h; cb->lam[hcnt] = l; cb->cnt = hcnt + 1;
-      }
+    if (need_new) {
+      const int nb = s_abase + apos;
+      if (nb < T.blk_cap) {
+        CompBlk *cb = T.blk + nb;
+        cb->next = head; cb->cnt = 1; cb->i[0] = ci; cb->ham[0] = h; cb->lam[0] = l;
+        T.head[r] = nb;
+      } else atomicOr(P.err_flag, 2);
     }
     if (move) {
       const int k = s_base + pos;
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
       const int ki = moved_before + k;
       if (ki < MOV_INLINE2) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
     }
-    __syncthreads();
   }
+  __syncthreads();                                                       // every delta of the block is in the table
   for (int k = threadIdx.x; k < ntab; k += 256) {
     const int32_t d = s_delta[k];
     if (d) atomicAdd(&dl[k], d);
@@ -591,7 +592,9 @@ __global__ void k2_resume(Eng2 E) { E.ctl->state = 0; E.ctl->halt = H2_NONE; }
 // 4g..4g+3 in turn): the four rows and their scalars are requested together before any of them is used, and the class
 // words of the 16 uniques (2 bits per centre) leave as one 32-byte store.  Only classes are produced: the aligner runs
 // when (and if) a centre's round comes.
-__global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E) {
+struct ScrIn { uint4 c0, c1; int Lr, nh; uint32_t rd; bool lk; };
+
+__global__ __launch_bounds__(256, 4) void k2_screen_multi(Eng2 E) {
   const Ctl2 *ctl = E.ctl;
   const int nb = ctl->nbatch;
   if (ctl->state != 0 || nb == 0) return;
@@ -615,111 +618,116 @@ __global__ __launch_bounds__(256) void k2_screen_multi(Eng2 E) {
   if (tid < KB_MAX) { cL[tid] = ctl->blen[tid]; cC[tid] = ctl->bcentre[tid]; cR[tid] = ctl->breads[tid]; }
   __syncthreads();
   uint16_t *bcls = C.bcls + (size_t)ctl->bbuf * C.Npad;
-  const int sub = tid & 15, g = (tid & 63) >> 4;
+  const int lane = tid & 63, sub = tid & 15, g = lane >> 4;
   const int gwave = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
   const int nchunk = (S.maxlen - KMER_SIZE + 1 + 7) >> 3;
   const uint4 pad4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
   const bool heavy_on = sp.use_kmers && S.HMAX > 0;
+  // after the unordered pass every lane of a group holds all eight overlaps: lane k (< 8) then takes the decisions of centre k
+  const int kc = sub & 7;
+  const bool kvalid = sub < 8 && kc < nb;
+  const int Lc = cL[kc], Cc = cC[kc];
+  const uint32_t Rc = cR[kc];
+  auto load = [&](int r) __attribute__((always_inline)) {
+    ScrIn in;
+    const bool on = r < S.N;
+    const uint4 *row = (const uint4 *)(S.kord + (size_t)(on ? r : 0) * S.LK);
+    in.c0 = (on && sp.use_kmers && sub < nchunk) ? row[sub] : pad4;
+    in.c1 = (on && sp.use_kmers && sub + 16 < nchunk) ? row[sub + 16] : pad4;
+    in.Lr = on ? S.len[r] : 0;
+    in.rd = on ? S.reads[r] : 0u;
+    in.lk = on && E.greedy && E.P.lock[r];
+    in.nh = (on && heavy_on) ? S.nheavy[r] : 0;
+    return in;
+  };
+  auto one = [&](int r, const ScrIn in) __attribute__((always_inline)) -> uint32_t {   // class word (2 bits per centre) of unique r, valid in the group's lane 0
+    if (r >= S.N) return 0u;
+    const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
+    // ---- pass 1: unordered overlap with every centre of the batch ----
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;                 // 16-bit fields: centres (0,2) (1,3) (4,6) (5,7)
+    if (sp.use_kmers) {
+      for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
+        const uint4 v = j == 0 ? in.c0 : (j == 1 ? in.c1 : row[ch]);
+        uint32_t ax = 0, ay = 0;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+          for (int hlf = 0; hlf < 2; hlf++) {
+            const uint32_t x = hlf ? (w[e] >> 16) : (w[e] & 0xFFFFu);
+            const uint2 t = tab[x & 1023u];
+            const uint32_t rk = x >> 10;                               // rank 0..63; want rank < count  <=>  (count | 0x80) - rank - 1 >= 0x80
+            const uint32_t rr = (rk | (rk << 8) | (rk << 16) | (rk << 24)) + 0x01010101u;
+            ax += (((t.x | 0x80808080u) - rr) >> 7) & 0x01010101u;    // byte k: rank < min(count_k, 63)
+            ay += (((t.y | 0x80808080u) - rr) >> 7) & 0x01010101u;
+          }
+        }
+        w0 += ax & 0x00FF00FFu; w1 += (ax >> 8) & 0x00FF00FFu;
+        w2 += ay & 0x00FF00FFu; w3 += (ay >> 8) & 0x00FF00FFu;
+      }
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {
+        w0 += __shfl_xor(w0, o, 16); w1 += __shfl_xor(w1, o, 16);
+        w2 += __shfl_xor(w2, o, 16); w3 += __shfl_xor(w3, o, 16);
+      }
+    }
+    // ---- lane k of the group: the dispatch of raw_align against centre k (nwalign_endsfree.cpp:10-73) ----
+    uint32_t dot = (((kc & 4) ? ((kc & 1) ? w3 : w2) : ((kc & 1) ? w1 : w0)) >> ((kc & 2) ? 16 : 0)) & 0xFFFFu;
+    const bool skipped = E.greedy && (in.rd > Rc || (in.lk && r != Cc));
+    if (in.nh > 0 && kvalid && !skipped) {                   // k-mers occurring > 63 times: exact correction
+      for (int hh = 0; hh < in.nh; hh++) {
+        const uint32_t e = S.heavy[(size_t)r * S.HMAX + hh], cr = e >> 16, cc = C.full[(size_t)kc * NKMER + (e & 1023u)];
+        const uint32_t m = cr < cc ? cr : cc;
+        if (m > RANK_SAT) dot += m - RANK_SAT;
+      }
+      dot &= 0xFFFFu;                                        // the reference accumulates in uint16_t (kmers.cpp:16,34,69)
+    }
+    const int d = (Lc < in.Lr ? Lc : in.Lr) - KMER_SIZE + 1;
+    const bool shroud = sp.use_kmers && (int)dot < thr[d > 0 ? d : 0];   // kdist > kdist_cutoff
+    const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || in.Lr == Lc);
+    bool gapless = sp.band == 0;
+    // ---- pass 2 (surviving pairs only): ordered overlap over the first d positions, the whole group per pair ----
+    const bool need2 = kvalid && !skipped && !shroud && !gapless && gl_ok;
+    uint32_t mask = (uint32_t)((__ballot(need2) >> (16 * g)) & 0xFFull);
+    while (mask) {
+      const int kk = __builtin_ctz(mask);
+      mask &= mask - 1;
+      const int dk = __shfl(d, (lane & 48) | kk, 64);
+      const uint32_t dotk = (uint32_t)__shfl((int)dot, (lane & 48) | kk, 64);
+      const uint16_t *ck = cord + (size_t)kk * S.LK;
+      uint32_t ord = 0;
+      for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
+        const uint4 v = j == 0 ? in.c0 : (j == 1 ? in.c1 : row[ch]);
+        const uint4 ck4 = ((const uint4 *)ck)[ch];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w}, cw[4] = {ck4.x, ck4.y, ck4.z, ck4.w};
+        const int i0 = ch << 3;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t t = (w[e] ^ cw[e]) & 0x03FF03FFu;   // k-mer ids only (rank bits masked off)
+          ord += ((t & 0xFFFFu) == 0 && i0 + 2 * e < dk);
+          ord += ((t >> 16) == 0 && i0 + 2 * e + 1 < dk);
+        }
+      }
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) ord += __shfl_xor(ord, o, 16);
+      if (kc == kk && sub < 8) gapless = (ord & 0xFFFFu) == dotk;      // kodist == kdist
+    }
+    uint32_t c = !kvalid ? 0u : (skipped ? (uint32_t)CLS_SKIP : (shroud ? (uint32_t)CLS_SHROUD : (gapless ? (uint32_t)CLS_GAPLESS : (uint32_t)CLS_NW)));
+    uint32_t code = c << (2 * kc);
+    code |= __shfl_xor(code, 1, 16); code |= __shfl_xor(code, 2, 16); code |= __shfl_xor(code, 4, 16);
+    return code & 0xFFFFu;
+  };
   for (int base16 = gwave * 16; base16 < S.N; base16 += nwaves * 16) {
-    // ---- request everything the four uniques of this lane group need ----
-    uint4 c0[4], c1[4];
-    int Lr[4], nh[4];
-    uint32_t rd[4];
-    bool lk[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int r = base16 + 4 * g + it;
-      const bool on = r < S.N;
-      const uint4 *row = (const uint4 *)(S.kord + (size_t)(on ? r : 0) * S.LK);
-      c0[it] = (on && sp.use_kmers && sub < nchunk) ? row[sub] : pad4;
-      c1[it] = (on && sp.use_kmers && sub + 16 < nchunk) ? row[sub + 16] : pad4;
-      Lr[it] = on ? S.len[r] : 0;
-      rd[it] = on ? S.reads[r] : 0u;
-      lk[it] = on && E.greedy && E.P.lock[r];
-      nh[it] = (on && heavy_on) ? S.nheavy[r] : 0;
-    }
-    unsigned long long clsacc = 0;
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int r = base16 + 4 * g + it;
-      if (r >= S.N) continue;
-      const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
-      // ---- pass 1: unordered overlap with every centre of the batch ----
-      uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;               // 16-bit fields: centres (0,2) (1,3) (4,6) (5,7)
-      if (sp.use_kmers) {
-        for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
-          const uint4 v = j == 0 ? c0[it] : (j == 1 ? c1[it] : row[ch]);
-          uint32_t ax = 0, ay = 0;
-          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-#pragma unroll
-            for (int hlf = 0; hlf < 2; hlf++) {
-              const uint32_t x = hlf ? (w[e] >> 16) : (w[e] & 0xFFFFu);
-              const uint2 t = tab[x & 1023u];
-              const uint32_t rr = ((x >> 10) + 1u) * 0x01010101u;       // rank + 1 in every byte (1..64)
-              ax += (((t.x | 0x80808080u) - rr) >> 7) & 0x01010101u;    // byte k: rank < min(count_k, 63)
-              ay += (((t.y | 0x80808080u) - rr) >> 7) & 0x01010101u;
-            }
-          }
-          w0 += ax & 0x00FF00FFu; w1 += (ax >> 8) & 0x00FF00FFu;
-          w2 += ay & 0x00FF00FFu; w3 += (ay >> 8) & 0x00FF00FFu;
-        }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) {
-          w0 += __shfl_xor(w0, o, 16); w1 += __shfl_xor(w1, o, 16);
-          w2 += __shfl_xor(w2, o, 16); w3 += __shfl_xor(w3, o, 16);
-        }
-      }
-      uint32_t code16 = 0;
-      for (int k = 0; k < nb; k++) {
-        uint32_t dot = (((k & 4) ? ((k & 1) ? w3 : w2) : ((k & 1) ? w1 : w0)) >> ((k & 2) ? 16 : 0)) & 0xFFFFu;
-        const int Lc = cL[k];
-        const bool skipped = E.greedy && (rd[it] > cR[k] || (lk[it] && r != cC[k]));
-        uint32_t c = CLS_SKIP;
-        if (!skipped) {
-          if (nh[it] > 0) {                                   // k-mers occurring > 63 times: exact correction
-            for (int hh = 0; hh < nh[it]; hh++) {
-              const uint32_t e = S.heavy[(size_t)r * S.HMAX + hh], cr = e >> 16, cc = C.full[(size_t)k * NKMER + (e & 1023u)];
-              const uint32_t m = cr < cc ? cr : cc;
-              if (m > RANK_SAT) dot += m - RANK_SAT;
-            }
-            dot &= 0xFFFFu;                                   // the reference accumulates in uint16_t (kmers.cpp:16,34,69)
-          }
-          const int d = (Lc < Lr[it] ? Lc : Lr[it]) - KMER_SIZE + 1;
-          const bool shroud = sp.use_kmers && (int)dot < thr[d];   // kdist > kdist_cutoff
-          if (shroud) c = CLS_SHROUD;
-          else {
-            const bool gl_ok = sp.gapless && sp.use_kmers && (sp.sse >= 1 || Lr[it] == Lc);
-            bool gapless = sp.band == 0;
-            if (!gapless && gl_ok) {
-              // ---- pass 2 (survivors only): ordered overlap over the first d positions ----
-              const uint16_t *ck = cord + (size_t)k * S.LK;
-              uint32_t ord = 0;
-              for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
-                const uint4 v = j == 0 ? c0[it] : (j == 1 ? c1[it] : row[ch]);
-                const uint4 ck4 = ((const uint4 *)ck)[ch];
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w}, cw[4] = {ck4.x, ck4.y, ck4.z, ck4.w};
-                const int i0 = ch << 3;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                  const uint32_t t = (w[e] ^ cw[e]) & 0x03FF03FFu;
-                  ord += ((t & 0xFFFFu) == 0 && i0 + 2 * e < d);
-                  ord += ((t >> 16) == 0 && i0 + 2 * e + 1 < d);
-                }
-              }
-#pragma unroll
-              for (int o = 8; o >= 1; o >>= 1) ord += __shfl_xor(ord, o, 16);
-              gapless = (ord & 0xFFFFu) == dot;               // kodist == kdist
-            }
-            c = gapless ? CLS_GAPLESS : CLS_NW;
-          }
-        }
-        code16 |= c << (2 * k);
-      }
-      clsacc |= (unsigned long long)code16 << (16 * it);
-    }
-    if (sub == 0 && base16 + 4 * g < S.N) *(unsigned long long *)(bcls + base16 + 4 * g) = clsacc;
+    // request everything the four uniques of this lane group need, then work through them
+    const int r0 = base16 + 4 * g;
+    const ScrIn i0 = load(r0), i1 = load(r0 + 1);
+    unsigned long long clsacc = one(r0, i0);
+    const ScrIn i2 = load(r0 + 2);
+    clsacc |= (unsigned long long)one(r0 + 1, i1) << 16;
+    const ScrIn i3 = load(r0 + 3);
+    clsacc |= (unsigned long long)one(r0 + 2, i2) << 32;
+    clsacc |= (unsigned long long)one(r0 + 3, i3) << 48;
+    if (sub == 0 && r0 < S.N) *(unsigned long long *)(bcls + r0) = clsacc;
   }
 }
 
