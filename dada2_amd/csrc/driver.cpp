@@ -1097,7 +1097,7 @@ struct Run {
   Eng2 E2{};
   DevBuf<double> v2_lam0;
   DevBuf<uint32_t> v2_ham0;
-  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn;
+  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn, v2_sig;
   DevBuf<CompBlk> v2_blk;
   DevBuf<Ctl2> v2_ctl;
   DevBuf<Round2Out> v2_dblk;
@@ -1128,6 +1128,7 @@ struct Run {
     E2.nw_list = s->d_nw_list.p; E2.gl_list = s->d_gl_list.p; E2.list_n = v2_listn.p;
     E2.ctl = v2_ctl.p; E2.dblk = v2_dblk.p; E2.hblk = v2_hblk.p; E2.dlt = v2_dlt.p; E2.movers = v2_movers.p;
     E2.partial = d_partial.p; E2.ties0 = d_ties0.p; E2.ties1 = d_ties1.p; E2.ccap = ccap;
+    E2.sig_list = v2_sig.p + 4; E2.sig_n = v2_sig.p;
     E2.greedy = o.greedy; E2.detect_singletons = o.detect_singletons;
     E2.total_reads = (double)(uint32_t)s->total_reads; E2.omegaA = o.omegaA; E2.omegaP = o.omegaP;
     E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
@@ -1154,7 +1155,8 @@ struct Run {
     const size_t slots = (size_t)v2_nbuf * KB_MAX;
     v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
-    v2_listn.alloc(2);
+    v2_listn.alloc(2); v2_sig.alloc(n + 4);
+    D2_HIP(hipMemsetAsync(v2_sig.p, 0, 16, stq));
     D2_HIP(hipMemsetAsync(v2_blkcount.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));
     D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_CHAIN * ccap * 4, stq));
@@ -1195,9 +1197,6 @@ struct Run {
     ev_end(ev);
     ev = ev_begin(EV_PVAL, profile_all);
     launch2_eval(E2, nlev, s->h_reads[bi[0].center], stq);
-    ev_end(ev);
-    ev = ev_begin(EV_BIRTH, profile_all);
-    launch2_birth(E2, nlev, stq);
     ev_end(ev);
     v2_enqrec.push_back(rec);
     v2_enq++;
@@ -1283,6 +1282,8 @@ struct Run {
       const Round2Out &b = v2_wait_block();
       if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
         throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
+      // keep the device fed before the host mirror catches up with this block
+      if (b.halt == H2_NONE) while (v2_enq - v2_cons < v2_depth) v2_enqueue_chain(v2_chain, true, true);
       if (v2_debug)
         fprintf(stderr, "[v2] blk %ld halt %d nclust %d nlev %d nsh %d cnt %d %d %d %d nbatch %d slot %d birth %d found %d nties %d p %.3e blk %d\n", seq,
                 b.halt, b.nclust, b.nlev, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],

@@ -222,7 +222,7 @@ int nw_adw_apw(const SampleDev &S, const AlignParams &ap);
 constexpr int KB_MAX = 8;          // centres per batch compare (one byte lane each in the packed count table)
 constexpr int SH_CHAIN = 4;        // b_shuffle2 calls enqueued per chain (the first unconditional, the rest guarded)
 constexpr int RING2 = 4;           // result blocks / mover lists in flight
-constexpr int MOV_INLINE2 = 1024;  // movers published inline per chain (all its shuffles, concatenated)
+constexpr int MOV_INLINE2 = 8192;  // movers published inline per chain (all its shuffles, concatenated)
 
 // stored comparisons of one unique (Bi::comp entries that name it): the round-0 entry lives in lam0/ham0 (every
 // unique has one, containers.cpp:39 + cluster.cpp:189), later ones in a chain of 64-byte blocks, newest block first
@@ -311,6 +311,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   int32_t *nw_list, *gl_list, *list_n;
   void *partial;                  // block partials of the bud arg-min
   int32_t *ties0, *ties1;         // full tie lists
+  int32_t *sig_list, *sig_n;      // significant bud candidates of the last evaluation (k2_pupdate)
   int32_t ccap;
   int32_t greedy, detect_singletons;
   double total_reads, omegaA, omegaP;
@@ -325,8 +326,8 @@ void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, c
 void launch2_screen_multi(const Eng2 &E, hipStream_t st);
 void launch2_lists(const Eng2 &E, hipStream_t st);                                    // cached classes + commit-time greedy skip -> work lists
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
-void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);     // b_p_update + b_bud arg-min + tie listing
-void launch2_birth(const Eng2 &E, int nlev, hipStream_t st);                          // decide / apply / plan / publish
+// b_p_update + b_bud arg-min (grid) ; ties, decision, birth, plan of the coming round, publication (one block)
+void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st);            // the host's decision applied + plan; resumes
 void launch2_resume(const Eng2 &E, hipStream_t st);
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,

@@ -76,18 +76,21 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   }
   __shared__ int s_n, s_base, s_an, s_abase;
   __shared__ int32_t s_delta[DELTA_TAB];
+  __shared__ uint32_t s_reads[DELTA_TAB];                                // partition reads as of the start of this call
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   const Store2 &T = E.T;
   const int N = S.N;
   const int nclust = ctl->nclust, ci = nclust - 1, centre = ctl->centre;
   const int ntab = nclust < DELTA_TAB ? nclust : DELTA_TAB;
-  for (int k = threadIdx.x; k < ntab; k += 256) s_delta[k] = 0;
+  for (int k = threadIdx.x; k < ntab; k += 256) { s_delta[k] = 0; s_reads[k] = reads_at(E, k, level); }
+  __syncthreads();
+  auto rd_at = [&](int i) __attribute__((always_inline)) -> uint32_t { return i < ntab ? s_reads[i] : reads_at(E, i, level); };
   int32_t *mv = E.movers + ((size_t)(ring * SH_CHAIN + level)) * 3 * (size_t)N;
   int32_t *dl = E.dlt + (size_t)level * E.ccap;
   const uint32_t creads_c = S.reads[centre];
-  const uint32_t reads_ci = STORE ? reads_at(E, ci, level) : 0u;
-  const uint32_t reads_0 = reads_at(E, 0, level);
+  const uint32_t reads_ci = STORE ? rd_at(ci) : 0u;
+  const uint32_t reads_0 = rd_at(0);
   for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
     bool keep = false, need_new = false, move = false;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
           for (int k = 0; k < 3; k++)
             if (k < cnt) {
               const int i = cb->i[k];
-              const double nl = cb->lam[k], e = nl * reads_at(E, i, level);
+              const double nl = cb->lam[k], e = nl * rd_at(i);
               if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_cb = cb; best_k = k; }
             }
           b = cb->next;
@@ -255,6 +258,10 @@ static __device__ __forceinline__ bool bud_candidate2(const Eng2 &E, int r, int 
   return true;
 }
 
+// Besides the block minima, the candidates whose p-value is significant (within a factor 2 of the thresholds) are listed:
+// k2_birth looks for the ties / near ties of the best key and for the likely next centres among those few, not among all
+// uniques.
+constexpr int SIG_CAP = 1024;
 __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init, BudKey *__restrict__ partial) {
   const Ctl2 *ctl = E.ctl;
   if (ctl->state != 0) return;
@@ -262,6 +269,10 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
   if (!cs.eval_ok) return;
   __shared__ BudKey s_k[2][4];
+  __shared__ int32_t s_sig[SIG_CAP];
+  __shared__ int s_nsig, s_sbase;
+  if (threadIdx.x == 0) s_nsig = 0;
+  __syncthreads();
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   BudKey b0 = init, b1 = init;
@@ -279,8 +290,13 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
       if ((S.reads[c] * l > reads) || r == c) P.lock[r] = 1;
     }
     if (!bud_candidate2(E, r, cs.nexec)) continue;
+    const bool pr = S.prior[r] != 0;
     if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
-    if (S.prior[r] && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
+    if (pr && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
+    if (p * S.N < 2.0 * E.bp.omegaA || (pr && p < 2.0 * E.bp.omegaP)) {
+      const int q = atomicAdd(&s_nsig, 1);
+      if (q < SIG_CAP) s_sig[q] = r; else E.sig_list[atomicAdd(E.sig_n, 1)] = r;
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -300,80 +316,48 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
     }
     partial[2 * blockIdx.x] = b0;
     partial[2 * blockIdx.x + 1] = b1;
+    const int n = min(s_nsig, SIG_CAP);
+    s_sbase = n ? atomicAdd(E.sig_n, n) : 0;                           // one global atomic per block
   }
-}
-
-__global__ __launch_bounds__(256) void k2_ties(Eng2 E, int nlev, BudKey init, const BudKey *__restrict__ partial, int nblocks) {
-  const Ctl2 *ctl = E.ctl;
-  if (ctl->state != 0) return;
-  Round2Out *outb = E.dblk + (ctl->pub_seq % RING2);
-  const Chain2 cs = chain_state(ctl, outb, nlev, E.max_shuffle);
-  if (!cs.eval_ok) return;
-  BudOut *out = &outb->bud;
-  __shared__ BudKey s_k[2][4];
-  const PartState &P = E.P;
-  const SampleDev &S = E.S;
-  BudKey b0 = init, b1 = init;
-  for (int k = threadIdx.x; k < nblocks; k += 256) {
-    if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
-    if (bud_better(partial[2 * k + 1].p, partial[2 * k + 1].reads, b1)) b1 = partial[2 * k + 1];
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    BudKey t;
-    t.p = __shfl_xor(b0.p, o, 64); t.reads = __shfl_xor(b0.reads, o, 64);
-    if (bud_better(t.p, t.reads, b0)) b0 = t;
-    t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
-    if (bud_better(t.p, t.reads, b1)) b1 = t;
-  }
-  if ((threadIdx.x & 63) == 0) { s_k[0][threadIdx.x >> 6] = b0; s_k[1][threadIdx.x >> 6] = b1; }
   __syncthreads();
-  b0 = s_k[0][0]; b1 = s_k[1][0];
-  for (int k = 1; k < 4; k++) {
-    if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
-    if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
-  }
-  const bool found0 = bud_better(b0.p, b0.reads, init), found1 = bud_better(b1.p, b1.reads, init);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    out->best_p[0] = b0.p; out->best_p[1] = b1.p;
-    out->best_reads[0] = b0.reads; out->best_reads[1] = b1.reads;
-    out->found[0] = found0; out->found[1] = found1;
-    out->valid = 1;
-  }
-  // listing rule: exact ties + the near window (see k_bud_ties / engine.h BUD_NEAR)
-  const bool sig0 = b0.p * S.N < 2.0 * E.bp.omegaA, sig1 = b1.p < 2.0 * E.bp.omegaP;
-  const double thr0 = sig0 ? b0.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0, thr1 = sig1 ? b1.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0;
-  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
-    if (!bud_candidate2(E, r, cs.nexec)) continue;
-    const double p = P.p[r];
-    const uint32_t reads = S.reads[r];
-    for (int track = 0; track < 2; track++) {
-      if (track == 1 && !S.prior[r]) continue;
-      const BudKey &bk = track ? b1 : b0;
-      if (!(track ? found1 : found0)) continue;
-      const bool exact = p == bk.p && reads == bk.reads;
-      const bool near = !exact && p != 0.0 && p <= (track ? thr1 : thr0);
-      if (!exact && !near) continue;
-      const int k = atomicAdd(&out->nties[track], 1);
-      if (k < BUD_TIES) {
-        BudTie &t = out->ties[track][k];
-        t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
-        t.from = P.clust_of[r]; t.from_reads = reads_at(E, t.from, cs.nexec); t.p = p; t.pad = 0;
-      }
-      (track ? E.ties1 : E.ties0)[k] = r;
-    }
-  }
+  for (int i = threadIdx.x; i < min(s_nsig, SIG_CAP); i += 256) E.sig_list[s_sbase + i] = s_sig[i];
 }
 
 // ---- the birth, the plan of the coming round's compare, and the publication of the round's result block -----------------
-constexpr int PLAN_STRIPS = 16;   // the prediction looks at the first PLAN_STRIPS x 1024 uniques (abundance order)
 constexpr int NBUF_MAX = 64;      // batch buffers (NBUF_MAX x KB_MAX cached centres at most)
+constexpr int PLAN_PER = 8;       // significant candidates each thread of k2_birth looks at when it predicts (8192 in all)
+constexpr int PLAN_BITS = 65536;  // uniques below this index are looked up in a bitmap of the cached centres
+
+// block-wide arg-min of (p, reads, r) keys over the 1024 threads; returns the winning unique (or -1) to every thread
+static __device__ int block_best(double p, uint32_t reads, int r, double *s_p, uint32_t *s_rd, int *s_r) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double p2 = __shfl_xor(p, o, 64);
+    const uint32_t rd2 = __shfl_xor(reads, o, 64);
+    const int r2 = __shfl_xor(r, o, 64);
+    const bool take = r2 >= 0 && (r < 0 || p2 < p || (p2 == p && (rd2 > reads || (rd2 == reads && r2 < r))));
+    if (take) { p = p2; reads = rd2; r = r2; }
+  }
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_p[w] = p; s_rd[w] = reads; s_r[w] = r; }
+  __syncthreads();
+  p = s_p[0]; reads = s_rd[0]; r = s_r[0];
+  for (int k = 1; k < 16; k++) {
+    const double p2 = s_p[k];
+    const uint32_t rd2 = s_rd[k];
+    const int r2 = s_r[k];
+    const bool take = r2 >= 0 && (r < 0 || p2 < p || (p2 == p && (rd2 > reads || (rd2 == reads && r2 < r))));
+    if (take) { p = p2; reads = rd2; r = r2; }
+  }
+  return r;
+}
 
 // (one block of 1024 threads)  Applies the birth of `raw` out of partition `from`, then plans the compare of the round that
-// follows: a cache hit needs nothing; a miss takes the next batch buffer and fills it with `raw` plus the first significant
-// bud candidates in index order that are not cached yet (input is abundance-sorted: while p-values underflow to 0 - most
-// of a run - that IS the bud order; a wrong guess only costs its share of one pass over the k-mer records), and builds the
-// batch's k-mer tables.
+// follows: a cache hit needs nothing; a miss takes the next batch buffer and fills it with `raw` plus the best bud
+// candidates of the last evaluation (the significant ones k2_pupdate listed, in b_bud's own order: p ascending, reads
+// descending) that are not cached yet - they are the likely next centres, and a wrong guess only costs its share of one
+// pass over the k-mer records - and builds the batch's k-mer tables.
 static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -381,10 +365,13 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
   const Cache2 &C = E.C;
   const int tid = threadIdx.x;
   const int nslots = C.NBUF * KB_MAX;
-  int *s_nb = s_misc, *s_hit = s_misc + 1, *s_wcnt = s_misc + 2;   // s_wcnt[16]
-  int *s_bc = s_misc + 20;                                          // [KB_MAX]
+  int *s_nb = s_misc, *s_hit = s_misc + 1;
+  int *s_bc = s_misc + 4;                                           // [KB_MAX]
+  int *s_r = s_misc + 12;                                           // [16]
   int *s_tab = s_misc + 32;                                         // [nslots] copy of slot_centre
-  uint32_t *s_bits = s_cnt;                                         // [PLAN_STRIPS * 32] cached uniques among the scanned prefix
+  uint32_t *s_bits = s_cnt;                                         // [PLAN_BITS / 32] cached uniques among the low indices
+  double *s_p = (double *)(s_cnt + PLAN_BITS / 32);                 // [16]
+  uint32_t *s_rd = (uint32_t *)(s_p + 16);                          // [16]
   if (tid == 0) {
     const int newi = ctl->nclust;
     const uint32_t reads_new = S.reads[raw];
@@ -418,39 +405,51 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
     s_bc[0] = raw;
     *s_nb = 1;
   }
-  for (int q = tid; q < PLAN_STRIPS * 32; q += blockDim.x) s_bits[q] = 0;
+  for (int q = tid; q < PLAN_BITS / 32; q += blockDim.x) s_bits[q] = 0;
   __syncthreads();
   for (int q = tid; q < nslots; q += blockDim.x) {
     const int c = C.slot_centre[q];
     s_tab[q] = c;
-    if (c >= 0 && c < PLAN_STRIPS * 1024) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
+    if (c >= 0 && c < PLAN_BITS) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
   }
   __syncthreads();
-  // ---- prediction: first significant candidates in index order ----
-  for (int strip = 0; strip < PLAN_STRIPS && *s_nb < KB_MAX && strip * 1024 < S.N; strip++) {
-    const int r = strip * 1024 + tid;
-    bool ok = false;
-    if (r < S.N && r != raw && !((s_bits[r >> 5] >> (r & 31)) & 1u) && bud_candidate2(E, r, 0)) {
-      const double p = P.p[r];
-      ok = (p * S.N < E.omegaA) || (S.prior[r] && p < E.omegaP);
+  // ---- prediction: the best keys among the listed candidates ----
+  {
+    const int M = min(*E.sig_n, PLAN_PER * 1024);
+    double kp[PLAN_PER];
+    uint32_t krd[PLAN_PER];
+    int kr[PLAN_PER];
+#pragma unroll
+    for (int j = 0; j < PLAN_PER; j++) {
+      const int q = tid + j * 1024;
+      kr[j] = -1; kp[j] = 0.0; krd[j] = 0;
+      if (q < M) {
+        const int r = E.sig_list[q];
+        bool ok = r != raw && !P.slot0[r];
+        if (ok) {
+          if (r < PLAN_BITS) ok = !((s_bits[r >> 5] >> (r & 31)) & 1u);
+          else for (int t = 0; ok && t < nslots; t++) if (s_tab[t] == r) ok = false;
+        }
+        if (ok) { kr[j] = r; kp[j] = P.p[r]; krd[j] = S.reads[r]; }
+      }
     }
-    const unsigned long long bal = __ballot(ok);
-    const int w = tid >> 6, lane = tid & 63;
-    if (lane == 0) s_wcnt[w] = __popcll(bal);
-    __syncthreads();
-    int before = 0;
-    for (int k = 0; k < w; k++) before += s_wcnt[k];
-    int total = 0;
-    for (int k = 0; k < 16; k++) total += s_wcnt[k];
-    const int nb0 = *s_nb;
-    if (ok) {
-      const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
-      if (nb0 + rank < KB_MAX) s_bc[nb0 + rank] = r;
+    for (int sel = 1; sel < KB_MAX; sel++) {
+      double bp = 0.0;
+      uint32_t brd = 0;
+      int br = -1;
+#pragma unroll
+      for (int j = 0; j < PLAN_PER; j++)
+        if (kr[j] >= 0 && (br < 0 || kp[j] < bp || (kp[j] == bp && (krd[j] > brd || (krd[j] == brd && kr[j] < br))))) {
+          bp = kp[j]; brd = krd[j]; br = kr[j];
+        }
+      const int win = block_best(bp, brd, br, s_p, s_rd, s_r);
+      if (win < 0) break;
+#pragma unroll
+      for (int j = 0; j < PLAN_PER; j++) if (kr[j] == win) kr[j] = -1;
+      if (tid == 0) { s_bc[sel] = win; *s_nb = sel + 1; }
     }
-    __syncthreads();
-    if (tid == 0) *s_nb = min(KB_MAX, nb0 + total);
-    __syncthreads();
   }
+  __syncthreads();
   const int nb = *s_nb;
   // ---- k-mer tables of the batch: byte k of tab8[id] = min(count of 5-mer id in centre k, 63) ----
   for (int k = tid; k < KB_MAX * NKMER; k += blockDim.x) s_cnt[k] = 0;
@@ -521,12 +520,13 @@ static __device__ void clear_block(Round2Out *nx) {
   }
 }
 
-__global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev) {
+__global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, const BudKey *__restrict__ partial, int nblocks) {
   Ctl2 *ctl = E.ctl;
   if (ctl->state != 0) return;
-  __shared__ uint32_t s_cnt[KB_MAX * NKMER];
+  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
   __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
-  __shared__ int s_halt, s_raw, s_from, s_evalok;
+  __shared__ int s_halt, s_raw, s_from, s_evalok, s_nt[2];
+  __shared__ BudKey s_k[2][16];
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   const int ring = ctl->pub_seq % RING2;
@@ -538,6 +538,67 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev) {
     int32_t d = 0;
     for (int l = 0; l < SH_CHAIN; l++) { d += E.dlt[(size_t)l * E.ccap + i]; E.dlt[(size_t)l * E.ccap + i] = 0; }
     if (d) P.creads[i] += (uint32_t)d;
+  }
+  if (threadIdx.x < 2) s_nt[threadIdx.x] = 0;
+  __syncthreads();
+  // ---- second stage of b_bud's arg-min (cluster.cpp:284-308): the block minima of k2_pupdate, then the exact ties of the
+  //      best key and every other listed candidate whose non-zero p is within BUD_NEAR of it (engine.h) ----
+  if (cs.eval_ok) {
+    BudKey b0 = init, b1 = init;
+    for (int k = threadIdx.x; k < nblocks; k += blockDim.x) {
+      if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
+      if (bud_better(partial[2 * k + 1].p, partial[2 * k + 1].reads, b1)) b1 = partial[2 * k + 1];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      BudKey t;
+      t.p = __shfl_xor(b0.p, o, 64); t.reads = __shfl_xor(b0.reads, o, 64);
+      if (bud_better(t.p, t.reads, b0)) b0 = t;
+      t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
+      if (bud_better(t.p, t.reads, b1)) b1 = t;
+    }
+    if ((threadIdx.x & 63) == 0) { s_k[0][threadIdx.x >> 6] = b0; s_k[1][threadIdx.x >> 6] = b1; }
+    __syncthreads();
+    b0 = s_k[0][0]; b1 = s_k[1][0];
+    for (int k = 1; k < 16; k++) {
+      if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
+      if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
+    }
+    const bool found0 = bud_better(b0.p, b0.reads, init), found1 = bud_better(b1.p, b1.reads, init);
+    // (no window when the best p-value is clearly not significant: b_bud then gives no birth whatever the order; candidates
+    //  that are not significant were not listed, and an exact tie of a significant key is significant itself)
+    const bool sig0 = b0.p * S.N < 2.0 * E.bp.omegaA, sig1 = b1.p < 2.0 * E.bp.omegaP;
+    const double thr0 = sig0 ? b0.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0, thr1 = sig1 ? b1.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0;
+    const int M = *E.sig_n;
+    BudOut *bo = &out->bud;
+    for (int q = threadIdx.x; q < M; q += blockDim.x) {
+      const int r = E.sig_list[q];
+      const double p = P.p[r];
+      const uint32_t reads = S.reads[r];
+      for (int track = 0; track < 2; track++) {
+        if (track == 1 && !S.prior[r]) continue;
+        const BudKey &bk = track ? b1 : b0;
+        if (!(track ? (found1 && sig1) : (found0 && sig0))) continue;
+        const bool exact = p == bk.p && reads == bk.reads;
+        const bool near = !exact && p != 0.0 && p <= (track ? thr1 : thr0);
+        if (!exact && !near) continue;
+        const int k = atomicAdd(&s_nt[track], 1);
+        if (k < BUD_TIES) {
+          BudTie &t = bo->ties[track][k];
+          t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
+          t.from = P.clust_of[r]; t.from_reads = P.creads[t.from]; t.p = p; t.pad = 0;
+        }
+        (track ? E.ties1 : E.ties0)[k] = r;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      bo->best_p[0] = b0.p; bo->best_p[1] = b1.p;
+      bo->best_reads[0] = b0.reads; bo->best_reads[1] = b1.reads;
+      bo->found[0] = found0; bo->found[1] = found1;
+      bo->nties[0] = s_nt[0]; bo->nties[1] = s_nt[1];
+      bo->valid = 1;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -570,20 +631,26 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev) {
   if (s_evalok)   // b_p_update has consumed the flags (pval.cpp:24,37)
     for (int k = threadIdx.x; k < nclust; k += blockDim.x) { P.update_e[k] = 0; P.check_locks[k] = 0; }
   __syncthreads();
-  if (s_halt == H2_NONE) apply_birth_and_plan(E, s_raw, s_from, s_cnt, s_misc);
+  if (s_halt == H2_NONE) {
+    apply_birth_and_plan(E, s_raw, s_from, s_cnt, s_misc);
+    __syncthreads();
+    if (threadIdx.x == 0) *E.sig_n = 0;                      // consumed: the next evaluation lists afresh
+  }
   clear_block(E.dblk + ((ring + 1) % RING2));
   publish_block(E, out, ring);
 }
 
 // the host's own b_bud decision (ties, near ties, prior births, capacity) applied, the coming round planned, the device resumed
 __global__ __launch_bounds__(1024) void k2_host_birth(Eng2 E, int raw, int from) {
-  __shared__ uint32_t s_cnt[KB_MAX * NKMER];
+  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
   __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
   if (threadIdx.x == 0) { E.ctl->state = 0; E.ctl->halt = H2_NONE; }
   __syncthreads();
   apply_birth_and_plan(E, raw, from, s_cnt, s_misc);
+  __syncthreads();
+  if (threadIdx.x == 0) *E.sig_n = 0;
 }
-__global__ void k2_resume(Eng2 E) { E.ctl->state = 0; E.ctl->halt = H2_NONE; }
+__global__ void k2_resume(Eng2 E) { E.ctl->state = 0; E.ctl->halt = H2_NONE; *E.sig_n = 0; }
 
 // ---- k-mer screen against the batch's centres ---------------------------------------------------------------------------
 // 16 lanes per unique as in k_screen, but one pass over the unique's k-mer record serves up to KB_MAX centres: the centre
@@ -786,9 +853,8 @@ void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st) 
   BudKey init{1.0, init_reads};
   const int grid = std::min((E.S.N + 255) / 256, 1024);
   hipLaunchKernelGGL(k2_pupdate, dim3(grid), dim3(256), 0, st, E, nlev, init, (BudKey *)E.partial);
-  hipLaunchKernelGGL(k2_ties, dim3(std::min((E.S.N + 255) / 256, 512)), dim3(256), 0, st, E, nlev, init, (const BudKey *)E.partial, grid);
+  hipLaunchKernelGGL(k2_birth, dim3(1), dim3(1024), 0, st, E, nlev, init, (const BudKey *)E.partial, grid);
 }
-void launch2_birth(const Eng2 &E, int nlev, hipStream_t st) { hipLaunchKernelGGL(k2_birth, dim3(1), dim3(1024), 0, st, E, nlev); }
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st) {
   hipLaunchKernelGGL(k2_host_birth, dim3(1), dim3(1024), 0, st, E, raw, from);
 }
