@@ -251,7 +251,9 @@ def workload_name(cfg, n, L, band, c, selfconsist):
 
 def phases(st, prof):
     """Host wall split of the last timed call, and (from the event-timed pass) device time per kernel class."""
-    out = {"host_wall_ms": {k: st[k] for k in ("ms_total", "ms_upload", "ms_screen", "ms_bookkeep", "ms_final")},
+    out = {"host_wall_ms": {k: st[k] for k in ("ms_total", "ms_upload", "ms_screen", "ms_bookkeep", "ms_final", "ms_wait_device",
+                                                "ms_replay", "ms_enqueue")},
+           "moves": st["nmoves"], "batch_compares": st["batch_compares"],
            "host_wall_note": "upload = marshalling + H2D + k-mer build; screen = enqueue of the compare kernels; "
                              "bookkeep = round tails incl. waiting for the device; final = final pass + outputs"}
     if prof:

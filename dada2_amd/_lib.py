@@ -30,6 +30,8 @@ class CStats(C.Structure):
         ("screen_kernel_ms", C.c_double), ("screen_kernel_launches", C.c_uint64), ("screen_bytes", C.c_uint64),
         ("dev_ms_screen", C.c_double), ("dev_ms_nw", C.c_double), ("dev_ms_shuffle", C.c_double),
         ("dev_ms_pval", C.c_double), ("dev_ms_birth", C.c_double), ("dev_ms_final", C.c_double),
+        ("ms_wait_device", C.c_double), ("ms_replay", C.c_double), ("ms_enqueue", C.c_double),
+        ("nmoves", C.c_uint64), ("batch_compares", C.c_uint64),
     ]
 
     def as_dict(self):

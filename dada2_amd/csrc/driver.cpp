@@ -1095,8 +1095,9 @@ struct Run {
   // keeps the round-1 loop (the parity tests run both).
   bool use_v2 = false;
   Eng2 E2{};
-  DevBuf<double> v2_lam0;
-  DevBuf<uint32_t> v2_ham0;
+  DevBuf<double> v2_lam0, v2_lam1;
+  DevBuf<uint32_t> v2_ham0, v2_ham1;
+  DevBuf<int32_t> v2_i1;
   DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn, v2_sig;
   DevBuf<CompBlk> v2_blk;
   DevBuf<Ctl2> v2_ctl;
@@ -1120,7 +1121,7 @@ struct Run {
   }
   void v2_bind() {   // (re)build the by-value kernel argument block after any (re)allocation
     E2.P = P; E2.S = s->D;
-    E2.T.lam0 = v2_lam0.p; E2.T.ham0 = v2_ham0.p; E2.T.head = v2_head.p; E2.T.blk = v2_blk.p; E2.T.blk_count = v2_blkcount.p;
+    E2.T.lam0 = v2_lam0.p; E2.T.ham0 = v2_ham0.p; E2.T.lam1 = v2_lam1.p; E2.T.ham1 = v2_ham1.p; E2.T.i1 = v2_i1.p; E2.T.head = v2_head.p; E2.T.blk = v2_blk.p; E2.T.blk_count = v2_blkcount.p;
     E2.T.blk_cap = (int32_t)std::min<size_t>(v2_blk.n, 0x7FFFFFF0u);
     E2.C.NBUF = v2_nbuf; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
     E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15;
@@ -1143,7 +1144,7 @@ struct Run {
     if (const char *e = getenv("DADA2HIP_V2_CHAIN")) v2_chain = std::max(1, std::min(SH_CHAIN, atoi(e)));   // test knob: shorter shuffle chains
     v2_debug = getenv("DADA2HIP_V2_DEBUG") != nullptr;
     hipStream_t stq = s->stream;
-    v2_lam0.alloc(n); v2_ham0.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
+    v2_lam0.alloc(n); v2_ham0.alloc(n); v2_lam1.alloc(n); v2_ham1.alloc(n); v2_i1.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
     {
       size_t cap0 = std::max<size_t>(2 * n, (size_t)1 << 16);
       if (const char *e = getenv("DADA2HIP_NODE_CAP")) cap0 = std::max<size_t>((size_t)atoll(e), n + 16);   // test knob: forces growth
@@ -1179,6 +1180,7 @@ struct Run {
   // batch compare in front (no-ops on a cache hit) and the round's store filter in its first shuffle
   void v2_enqueue_chain(int nlev, bool with_compare, bool store) {
     hipStream_t stq = s->stream;
+    const auto t_enq = clk::now();
     EnqRec rec{-1, -1, with_compare};
     if (with_compare) {
       // the round's comparisons: a batch screen if its centre is not cached (no-op otherwise), the work lists of the centre
@@ -1200,6 +1202,7 @@ struct Run {
     ev_end(ev);
     v2_enqrec.push_back(rec);
     v2_enq++;
+    st.ms_enqueue += ms_since(t_enq);
   }
 
   const Round2Out &v2_wait_block() {
@@ -1223,13 +1226,16 @@ struct Run {
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     v2_cons++;
+    st.ms_wait_device += ms_since(tw);
     return v2_hblk.p[ring];
   }
 
   // bring the host mirror up to date with one published block: the chain's moves in call order, then the counters
   void v2_replay(const Round2Out &b, long seq) {
+    const auto t_rep = clk::now();
     int tot = 0;
     for (int l = 0; l < b.nsh; l++) tot += b.cnt[l];
+    st.nmoves += (uint64_t)tot;
     if (tot <= MOV_INLINE2) {
       int off = 0;
       for (int l = 0; l < b.nsh; l++) { replay_moves(b.mov + 3 * off, b.cnt[l]); off += b.cnt[l]; }
@@ -1247,7 +1253,8 @@ struct Run {
     }
     st.nshuffle += (uint64_t)b.nsh;
     st.nnw += b.stat[0]; st.ngapless += b.stat[1]; st.nshroud += b.stat[2]; st.nskipped += b.stat[3];
-    st.nstored = (uint64_t)N + (uint64_t)b.blk_count;     // (blocks, not entries: an upper bound of 3 entries each)
+    st.nstored += (uint64_t)b.pad0[0];                      // comparisons kept by the chain's store filter
+    st.ms_replay += ms_since(t_rep);
     if (b.err_flag & 4) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "N-W Align out of range."};
     if (b.err_flag & 8) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: a cached compare lacks a comparison its round needs"};
     check_errflag(b.err_flag);
@@ -1274,6 +1281,7 @@ struct Run {
   // run_dada's loop (Rmain.cpp:312-331) with the device in charge of the rounds
   void run_v2(int max_clust) {
     auto t0 = clk::now();
+    st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
     v2_enqueue_chain(0, false, false);                        // b_p_update after round 0 + the first b_bud
     bool done = false;
     while (!done) {
@@ -1670,6 +1678,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       const uint64_t row = 2 * (uint64_t)(D.maxlen - KMER_SIZE + 1);
       if (run.use_v2) {
         run.st.screen_bytes = (uint64_t)N * (row + 6) * (1 + run.v2_miss_launches);   // round 0 + one pass per batch compare
+        run.st.batch_compares = run.v2_miss_launches;
         if (!run.profile_all) run.st.screen_kernel_launches = 1 + run.v2_miss_launches;
       } else run.st.screen_bytes = (run.st.ncompare - run.st.nskipped) * row + run.st.ncompare * 6;
     }

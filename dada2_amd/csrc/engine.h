@@ -225,7 +225,9 @@ constexpr int RING2 = 4;           // result blocks / mover lists in flight
 constexpr int MOV_INLINE2 = 8192;  // movers published inline per chain (all its shuffles, concatenated)
 
 // stored comparisons of one unique (Bi::comp entries that name it): the round-0 entry lives in lam0/ham0 (every
-// unique has one, containers.cpp:39 + cluster.cpp:189), later ones in a chain of 64-byte blocks, newest block first
+// unique has one, containers.cpp:39 + cluster.cpp:189), the next one - for most uniques of a large sample the only other
+// one: the comparison with their own partition's centre - in i1/lam1/ham1 (read coalesced), any further ones in a chain of
+// 64-byte blocks, newest block first
 struct alignas(64) CompBlk {
   int32_t next, cnt;
   int32_t i[3];
@@ -235,8 +237,9 @@ struct alignas(64) CompBlk {
 };
 static_assert(sizeof(CompBlk) == 64, "CompBlk is one 64-byte line");
 struct Store2 {
-  double *lam0 = nullptr;
-  uint32_t *ham0 = nullptr;
+  double *lam0 = nullptr, *lam1 = nullptr;
+  uint32_t *ham0 = nullptr, *ham1 = nullptr;
+  int32_t *i1 = nullptr;          // partition of the second entry, -1 = none
   int32_t *head = nullptr;
   CompBlk *blk = nullptr;
   int32_t *blk_count = nullptr;

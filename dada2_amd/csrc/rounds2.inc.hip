@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
       P.comp_i[r] = 0; P.comp_lam[r] = l; P.comp_ham[r] = h;           // i == 0: Raw::comp is refreshed (cluster.cpp:197)
     }
     E.T.lam0[r] = l; E.T.ham0[r] = h;
+    E.T.i1[r] = -1;
     E.T.head[r] = -1;
   }
 }
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   const uint32_t creads_c = S.reads[centre];
   const uint32_t reads_ci = STORE ? rd_at(ci) : 0u;
   const uint32_t reads_0 = rd_at(0);
+  int my_keep = 0;                                                       // comparisons this thread stored (STORE)
   for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
     bool keep = false, need_new = false, move = false;
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
     uint32_t h = 0, best_h = 0;
     int head = -1, hcnt = 3, apos = 0, pos = 0, from = 0, to = 0;
     if (r < N) {
-      head = T.head[r];
+      const int i1 = T.i1[r];
+      head = i1 >= 0 ? T.head[r] : -1;                                   // (a chain only exists behind a used second entry)
       from = P.clust_of[r];
       if (STORE) {
         const uint8_t cl = E.cls[r];
@@ -108,18 +111,23 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
           const double em = P.E_minmax[r];
           keep = l * E.total_reads > em;                               // this partition could attract this unique
           if (keep) {
+            my_keep++;
             if (l * creads_c > em) P.E_minmax[r] = l * creads_c;
             if (r == centre) { P.comp_i[r] = ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
           }
         }
       }
       // arg-max of lambda * reads over the stored comparisons; ties go to the lowest partition (cluster.cpp:229-239)
-      int best_i = 0;
+      int best_i = 0, best_src = 0;                                      // 0: round-0 entry, 1: second entry, 2: chain block, 3: this round's
       const CompBlk *best_cb = nullptr;
       int best_k = 0;
-      if (head >= 0 || keep) {
+      if (i1 >= 0 || keep) {
         best_l = T.lam0[r];
         double best_e = best_l * reads_0;
+        if (i1 >= 0) {
+          const double nl = T.lam1[r], e = nl * rd_at(i1);
+          if (e > best_e || (e == best_e && i1 < best_i)) { best_e = e; best_i = i1; best_l = nl; best_src = 1; }
+        }
         for (int b = head, first = 1, hops = 0; b >= 0 && hops < (1 << 22); first = 0, hops++) {   // (bounded: never spin on a bad link)
           const CompBlk *cb = T.blk + b;
           const int cnt = cb->cnt;
@@ -129,25 +137,29 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
             if (k < cnt) {
               const int i = cb->i[k];
               const double nl = cb->lam[k], e = nl * rd_at(i);
-              if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_cb = cb; best_k = k; }
+              if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_cb = cb; best_k = k; best_src = 2; }
             }
           b = cb->next;
         }
         if (keep) {
-          need_new = head < 0 || hcnt >= 3;
-          if (!need_new) {                                             // room in the newest block: append in place
-            CompBlk *cb = T.blk + head;
-            cb->i[hcnt] = ci; cb->ham[hcnt] = h; cb->lam[hcnt] = l; cb->cnt = hcnt + 1;
+          if (i1 < 0) { T.i1[r] = ci; T.lam1[r] = l; T.ham1[r] = h; }  // the unique's second stored comparison: inline
+          else {
+            need_new = head < 0 || hcnt >= 3;
+            if (!need_new) {                                           // room in the newest block: append in place
+              CompBlk *cb = T.blk + head;
+              cb->i[hcnt] = ci; cb->ham[hcnt] = h; cb->lam[hcnt] = l; cb->cnt = hcnt + 1;
+            }
           }
           const double e = l * reads_ci;
-          if (e > best_e) { best_e = e; best_i = ci; best_l = l; best_cb = nullptr; }   // (ci is the highest index: only strictly)
+          if (e > best_e) { best_e = e; best_i = ci; best_l = l; best_src = 3; }   // (ci is the highest index: only strictly)
         }
       }
       if (best_i != from && r != P.centre_of[from]) {
         move = true;
         to = best_i;
-        if (best_i == 0) { best_l = T.lam0[r]; best_h = T.ham0[r]; }
-        else if (best_cb) best_h = best_cb->ham[best_k];
+        if (best_src == 0) { best_l = T.lam0[r]; best_h = T.ham0[r]; }
+        else if (best_src == 1) best_h = T.ham1[r];
+        else if (best_src == 2) best_h = best_cb->ham[best_k];
         else best_h = h;
         P.clust_of[r] = to;
         P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
@@ -186,6 +198,11 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
     }
   }
   __syncthreads();                                                       // every delta of the block is in the table
+  if (STORE) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) my_keep += __shfl_xor(my_keep, o, 64);
+    if ((threadIdx.x & 63) == 0 && my_keep) atomicAdd(&out->pad0[0], my_keep);   // Comparisons kept this round (cluster.cpp:189-199)
+  }
   for (int k = threadIdx.x; k < ntab; k += 256) {
     const int32_t d = s_delta[k];
     if (d) atomicAdd(&dl[k], d);
@@ -513,7 +530,7 @@ static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
 
 static __device__ void clear_block(Round2Out *nx) {
   if (threadIdx.x < SH_CHAIN) nx->cnt[threadIdx.x] = 0;
-  if (threadIdx.x < 4) nx->stat[threadIdx.x] = 0;
+  if (threadIdx.x < 4) { nx->stat[threadIdx.x] = 0; nx->pad0[threadIdx.x] = 0; }
   if (threadIdx.x == 0) {
     nx->bud.nties[0] = 0; nx->bud.nties[1] = 0; nx->bud.valid = 0; nx->bud.found[0] = 0; nx->bud.found[1] = 0;
     nx->bud.auto_applied = 0; nx->halt = H2_NONE; nx->birth_applied = 0; nx->nsh = 0; nx->nlev = 0; nx->nbatch = 0;
@@ -808,6 +825,11 @@ __global__ __launch_bounds__(256) void k2_posthoc(Eng2 E, const int32_t *__restr
   if (j != 0) {
     const int k = atomicAdd(nout, 1);
     if (k < cap) { out_ji[2 * k] = j; out_ji[2 * k + 1] = 0; out_lam[k] = E.T.lam0[r]; }
+  }
+  const int i1 = E.T.i1[r];
+  if (i1 >= 0 && i1 != j) {
+    const int k = atomicAdd(nout, 1);
+    if (k < cap) { out_ji[2 * k] = j; out_ji[2 * k + 1] = i1; out_lam[k] = E.T.lam1[r]; }
   }
   for (int b = E.T.head[r], hops = 0; b >= 0 && hops < (1 << 22); b = E.T.blk[b].next, hops++) {
     const CompBlk *cb = E.T.blk + b;

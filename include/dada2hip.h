@@ -81,6 +81,10 @@ typedef struct dada2hip_stats {
   uint64_t screen_bytes; /* algorithmic bytes the screen launches had to read                     */
   /* device time per kernel class, summed over every launch; filled only under DADA2HIP_PROFILE=1 (else 0) */
   double dev_ms_screen, dev_ms_nw, dev_ms_shuffle, dev_ms_pval, dev_ms_birth, dev_ms_final;
+  /* host side of the device-driven round loop: waiting for published round results (= the device is the bottleneck),
+   * replaying moves / births on the host mirror, enqueuing launches; uniques moved by b_shuffle2 over the run */
+  double ms_wait_device, ms_replay, ms_enqueue;
+  uint64_t nmoves, batch_compares;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------
