@@ -505,6 +505,7 @@ struct Run {
 
   ~Run() {
     for (auto &e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (v2_graph) (void)hipGraphExecDestroy(v2_graph);
   }
 
   void logf(const char *fmt, ...) {
@@ -1134,6 +1135,7 @@ struct Run {
     E2.total_reads = (double)(uint32_t)s->total_reads; E2.omegaA = o.omegaA; E2.omegaP = o.omegaP;
     E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
     E2.sp = sp; E2.thresh = d_thresh_round.p; E2.max_shuffle = MAX_SHUFFLE;
+    v2_drop_graph();                 // (captured launches hold the old argument block)
   }
   void v2_alloc(int max_clust) {
     const size_t n = (size_t)N;
@@ -1171,6 +1173,7 @@ struct Run {
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
     D2_HIP(hipStreamSynchronize(stq));   // `c` is a local
     v2_enq = v2_cons = 0;
+    v2_plain_rounds = 0;
     v2_miss_launches = 0;
     v2_enqrec.clear();
     v2_bind();
@@ -1178,9 +1181,46 @@ struct Run {
 
   // one chain: [shuffle x nlev][b_p_update + b_bud arg-min + ties][birth / plan / publish]; a full round is a chain with the
   // batch compare in front (no-ops on a cache hit) and the round's store filter in its first shuffle
-  void v2_enqueue_chain(int nlev, bool with_compare, bool store) {
+  // A full round is always the same launches with the same arguments (what differs lives in the control block), so it is
+  // captured once into a hipGraph and replayed: one API call per round instead of nine, and back-to-back dispatch on the
+  // device.  DADA2HIP_V2_GRAPH=0 keeps plain stream launches; profiling (events between launches) does too.
+  hipGraphExec_t v2_graph = nullptr;
+  int v2_graph_state = 0;            // 0: not tried yet, 1: in use, -1: unavailable
+  int v2_plain_rounds = 0;
+  void v2_drop_graph() {
+    if (v2_graph) { (void)hipGraphExecDestroy(v2_graph); v2_graph = nullptr; }
+    if (v2_graph_state == 1) v2_graph_state = 0;
+  }
+  bool v2_try_graph() {
+    static const bool off = [] { const char *e = getenv("DADA2HIP_V2_GRAPH"); return e && atoi(e) == 0; }();
+    if (off || profile_all || v2_graph_state < 0) return false;
+    if (v2_graph_state == 1) return true;
+    if (v2_plain_rounds < 1) return false;   // the first round goes out plainly (one-time function attributes are set by its launches)
     hipStream_t stq = s->stream;
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(stq, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); v2_graph_state = -1; return false; }
+    v2_round_launches(v2_chain, true, true, nullptr);
+    if (hipStreamEndCapture(stq, &g) != hipSuccess || !g) { (void)hipGetLastError(); v2_graph_state = -1; return false; }
+    const hipError_t e = hipGraphInstantiate(&v2_graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { (void)hipGetLastError(); v2_graph = nullptr; v2_graph_state = -1; return false; }
+    v2_graph_state = 1;
+    return true;
+  }
+  void v2_enqueue_chain(int nlev, bool with_compare, bool store) {
     const auto t_enq = clk::now();
+    EnqRec rec{-1, -1, with_compare};
+    if (nlev == v2_chain && with_compare && store && v2_try_graph()) D2_HIP(hipGraphLaunch(v2_graph, s->stream));
+    else {
+      v2_round_launches(nlev, with_compare, store, &rec);
+      if (with_compare) v2_plain_rounds++;
+    }
+    v2_enqrec.push_back(rec);
+    v2_enq++;
+    st.ms_enqueue += ms_since(t_enq);
+  }
+  void v2_round_launches(int nlev, bool with_compare, bool store, EnqRec *recp) {
+    hipStream_t stq = s->stream;
     EnqRec rec{-1, -1, with_compare};
     if (with_compare) {
       // the round's comparisons: a batch screen if its centre is not cached (no-op otherwise), the work lists of the centre
@@ -1200,9 +1240,7 @@ struct Run {
     ev = ev_begin(EV_PVAL, profile_all);
     launch2_eval(E2, nlev, s->h_reads[bi[0].center], stq);
     ev_end(ev);
-    v2_enqrec.push_back(rec);
-    v2_enq++;
-    st.ms_enqueue += ms_since(t_enq);
+    if (recp) *recp = rec;
   }
 
   const Round2Out &v2_wait_block() {
@@ -1284,8 +1322,12 @@ struct Run {
     st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
     v2_enqueue_chain(0, false, false);                        // b_p_update after round 0 + the first b_bud
     bool done = false;
+    double t_decide = 0, t_halt = 0, t_top = 0;
+    long n_halt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_big = 0;
     while (!done) {
+      const auto t_loop = clk::now();
       while (v2_enq - v2_cons < v2_depth) v2_enqueue_chain(v2_chain, true, true);
+      t_top += ms_since(t_loop);
       const long seq = v2_cons + 1;
       const Round2Out &b = v2_wait_block();
       if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
@@ -1297,6 +1339,9 @@ struct Run {
                 b.halt, b.nclust, b.nlev, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],
                 b.bud.nties[0], b.bud.best_p[0], b.blk_count);
       v2_replay(b, seq);
+      n_halt[b.halt & 7]++;
+      if (b.cnt[0] + b.cnt[1] + b.cnt[2] + b.cnt[3] > MOV_INLINE2) n_big++;
+      const auto t_dec = clk::now();
       const EnqRec &rec = v2_enqrec[seq - 1];
       if (rec.compare && b.nbatch > 0) {                       // (this chain's batch compare really ran: a cache miss)
         v2_miss_launches++;
@@ -1348,7 +1393,13 @@ struct Run {
         }
         default: throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: unknown halt code"};
       }
+      if (b.halt == H2_NONE) t_decide += ms_since(t_dec); else t_halt += ms_since(t_dec);
     }
+    if (getenv("DADA2HIP_V2_SUMMARY"))
+      fprintf(stderr, "[v2] blocks %ld  halts none/nobirth/host/more/cap/max %ld %ld %ld %ld %ld %ld  big-mover blocks %ld  ms: wait %.1f replay %.1f "
+                      "enqueue %.1f decide %.1f halt-handling %.1f top-up %.1f total %.1f  moves %llu misses %llu\n", v2_cons, n_halt[0], n_halt[1],
+              n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_big, st.ms_wait_device, st.ms_replay, st.ms_enqueue, t_decide, t_halt, t_top,
+              ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches);
     sync_spin(s->stream);                                      // no-op launches queued behind the final halt
     st.ms_bookkeep += ms_since(t0);
   }
