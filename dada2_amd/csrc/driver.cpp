@@ -981,7 +981,11 @@ struct Run {
       replay_pending();                                   // slot order and partition reads must be current
       std::vector<BudTie> cand;
       if (n <= BUD_TIES) cand.assign(h.ties[track], h.ties[track] + n);
-      else {   // long list (e.g. many p == 0 with equal reads): fetch it and the fields of its members
+      else if (use_v2 && n <= TIES_FULL) {   // the device keeps the full records (it is halted: nothing rewrites them)
+        cand.resize(n);
+        D2_HIP(hipMemcpyAsync(cand.data(), v2_tiesrec.p + (size_t)track * TIES_FULL, (size_t)n * sizeof(BudTie), hipMemcpyDeviceToHost, s->side));
+        D2_HIP(hipStreamSynchronize(s->side));
+      } else {   // long list (e.g. many p == 0 with equal reads): fetch it and the fields of its members
         std::vector<int32_t> t(n);
         sync_spin(s->stream);
         D2_HIP(hipMemcpy(t.data(), track ? d_ties1.p : d_ties0.p, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -1102,6 +1106,7 @@ struct Run {
   DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn, v2_sig;
   DevBuf<CompBlk> v2_blk;
   DevBuf<Ctl2> v2_ctl;
+  DevBuf<BudTie> v2_tiesrec;
   DevBuf<Round2Out> v2_dblk;
   DevBuf<uint16_t> v2_bcls, v2_full, v2_ord;
   DevBuf<uint2> v2_tab8;
@@ -1130,7 +1135,7 @@ struct Run {
     E2.nw_list = s->d_nw_list.p; E2.gl_list = s->d_gl_list.p; E2.list_n = v2_listn.p;
     E2.ctl = v2_ctl.p; E2.dblk = v2_dblk.p; E2.hblk = v2_hblk.p; E2.dlt = v2_dlt.p; E2.movers = v2_movers.p;
     E2.partial = d_partial.p; E2.ties0 = d_ties0.p; E2.ties1 = d_ties1.p; E2.ccap = ccap;
-    E2.sig_list = v2_sig.p + 4; E2.sig_n = v2_sig.p;
+    E2.sig_list = v2_sig.p + 4; E2.sig_n = v2_sig.p; E2.ties_rec = v2_tiesrec.p;
     E2.greedy = o.greedy; E2.detect_singletons = o.detect_singletons;
     E2.total_reads = (double)(uint32_t)s->total_reads; E2.omegaA = o.omegaA; E2.omegaP = o.omegaP;
     E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
@@ -1158,7 +1163,7 @@ struct Run {
     const size_t slots = (size_t)v2_nbuf * KB_MAX;
     v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
-    v2_listn.alloc(2); v2_sig.alloc(n + 4);
+    v2_listn.alloc(2); v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
     D2_HIP(hipMemsetAsync(v2_sig.p, 0, 16, stq));
     D2_HIP(hipMemsetAsync(v2_blkcount.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));
@@ -1384,8 +1389,7 @@ struct Run {
           break;
         }
         case H2_SHUFFLE_MORE: {                                // more than SH_CHAIN moving shuffles: continue the same round
-          sync_spin(s->stream);
-          v2_enq = v2_cons;
+          v2_enq = v2_cons;                                    // (the launches queued behind the halt are no-ops: no drain needed)
           v2_enqrec.resize((size_t)v2_cons);
           launch2_resume(E2, s->stream);
           v2_enqueue_chain(v2_chain, false, false);

@@ -110,7 +110,8 @@ struct StoreRound {
 void launch_shuffle(const PartState &P, const SampleDev &S, const uint32_t *d_creads_snap, int32_t *d_movers,
                     int32_t *d_nmovers, int32_t *d_inline, const StoreRound *store, int check_only, int nclust, hipStream_t st);
 // result block of one b_bud evaluation, fetched by the host in a single copy
-constexpr int BUD_TIES = 16;
+constexpr int BUD_TIES = 64;     // tie records published inline with the round result
+constexpr int TIES_FULL = 4096;  // ... and kept in full on the device (engine v2) for the host to fetch when there are more
 struct BudTie { int32_t raw, comp_i; uint32_t comp_ham; int32_t from; uint32_t from_reads, pad; double comp_lam; double p; };
 // Candidates listed by k_bud_ties: the exact (p, reads) ties of the device's best key AND every other candidate whose
 // device p-value lies within BUD_NEAR (relative) of the best one.  Device and host libm differ in the last ulp of
@@ -314,6 +315,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   int32_t *nw_list, *gl_list, *list_n;
   void *partial;                  // block partials of the bud arg-min
   int32_t *ties0, *ties1;         // full tie lists
+  BudTie *ties_rec;               // [2][TIES_FULL] full records of the first TIES_FULL listed candidates per track
   int32_t *sig_list, *sig_n;      // significant bud candidates of the last evaluation (k2_pupdate)
   int32_t ccap;
   int32_t greedy, detect_singletons;

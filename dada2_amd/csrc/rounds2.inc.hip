@@ -600,10 +600,12 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
         const bool near = !exact && p != 0.0 && p <= (track ? thr1 : thr0);
         if (!exact && !near) continue;
         const int k = atomicAdd(&s_nt[track], 1);
-        if (k < BUD_TIES) {
-          BudTie &t = bo->ties[track][k];
+        if (k < TIES_FULL) {
+          BudTie t;
           t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
           t.from = P.clust_of[r]; t.from_reads = P.creads[t.from]; t.p = p; t.pad = 0;
+          if (k < BUD_TIES) bo->ties[track][k] = t;
+          E.ties_rec[(size_t)track * TIES_FULL + k] = t;
         }
         (track ? E.ties1 : E.ties0)[k] = r;
       }
