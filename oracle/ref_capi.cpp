@@ -22,6 +22,12 @@ Rcpp::List dada_uniques(std::vector<std::string> seqs, std::vector<int> abundanc
                         int min_abund, bool use_quals, bool final_consensus, bool vectorized_alignment,
                         int homo_gap, bool multithread, bool verbose, int SSE, bool gapless, bool greedy);
 
+// chimera.cpp:18,192 (the step after dada(): bimera identification on the sequence table)
+bool C_is_bimera(std::string sq, std::vector<std::string> pars, bool allow_one_off, int min_one_off_par_dist, int match,
+                 int mismatch, int gap_p, int max_shift);
+Rcpp::DataFrame C_table_bimera2(Rcpp::IntegerMatrix mat, std::vector<std::string> seqs, double min_fold, int min_abund,
+                                bool allow_one_off, int min_one_off_par_dist, int match, int mismatch, int gap_p, int max_shift);
+
 extern "C" {
 
 int dada2_shim_verbose = 0;
@@ -168,5 +174,37 @@ int ref_compare(const char *cseq, const double *cq, const char *rseq, const doub
 }
 
 double ref_calc_pA(int reads, double E_reads, int prior) { return calc_pA(reads, E_reads, prior != 0); }
+
+// C_table_bimera2 (chimera.cpp:192): mat is nrow (samples) x ncol (sequences), column-major; fills nflag[ncol], nsam[ncol]
+int ref_table_bimera2(int nrow, int ncol, const int *mat, const char *const *seqs, double min_fold, int min_abund,
+                      int allow_one_off, int min_one_off_par_dist, int match, int mismatch, int gap_p, int max_shift,
+                      int *nflag, int *nsam, char *errbuf, int errlen) {
+  try {
+    Rcpp::IntegerMatrix M(nrow, ncol);
+    memcpy(M.v.data(), mat, sizeof(int) * (size_t)nrow * (size_t)ncol);
+    std::vector<std::string> s(ncol);
+    for (int i = 0; i < ncol; i++) s[i] = seqs[i];
+    Rcpp::DataFrame df = C_table_bimera2(M, s, min_fold, min_abund, allow_one_off != 0, min_one_off_par_dist, match, mismatch,
+                                         gap_p, max_shift);
+    const Rcpp::RObj *f = df.obj->get("nflag"), *n = df.obj->get("nsam");
+    for (int i = 0; i < ncol; i++) { nflag[i] = f->iv[i]; nsam[i] = n->iv[i]; }
+    return 0;
+  } catch (std::exception &e) {
+    if (errbuf && errlen > 0) snprintf(errbuf, errlen, "%s", e.what());
+    return 1;
+  }
+}
+
+// C_is_bimera (chimera.cpp:18); returns 0 / 1, or -1 on error
+int ref_is_bimera(const char *sq, int npars, const char *const *pars, int allow_one_off, int min_one_off_par_dist, int match,
+                  int mismatch, int gap_p, int max_shift) {
+  try {
+    std::vector<std::string> p(npars);
+    for (int i = 0; i < npars; i++) p[i] = pars[i];
+    return C_is_bimera(sq, p, allow_one_off != 0, min_one_off_par_dist, match, mismatch, gap_p, max_shift) ? 1 : 0;
+  } catch (std::exception &) {
+    return -1;
+  }
+}
 
 }  // extern "C"

@@ -2,7 +2,7 @@
 //
 // Minimal stand-in for <Rcpp.h> so that the reference's own hot-path sources
 // (/root/reference/src/{Rmain,cluster,containers,kmers,misc,pval,error,
-// nwalign_endsfree,nwalign_vectorized}.cpp) compile UNMODIFIED, in place, into
+// nwalign_endsfree,nwalign_vectorized,chimera}.cpp) compile UNMODIFIED, in place, into
 // oracle/_ref/libdada2ref.so (recipe: oracle/Makefile).  Nothing here is a copy
 // of Rcpp: it is a from-scratch value-semantics model of exactly the Rcpp
 // surface those nine files touch (SURVEY.md §8c lists it).  R and Rcpp are not
@@ -75,6 +75,7 @@ class IntegerVector : public Vec<int> {
 public:
   IntegerVector() {}
   explicit IntegerVector(size_t n) : Vec<int>(n) {}
+  IntegerVector(size_t n, int fill) : Vec<int>(n) { for (auto &x : v) x = fill; }   // chimera.cpp:195-196
 };
 class NumericVector : public Vec<double> {
 public:

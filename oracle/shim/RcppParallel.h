@@ -17,7 +17,29 @@
 
 extern "C" int dada2_shim_nthreads;
 
+#include <Rcpp.h>
+
 namespace RcppParallel {
+
+// read / write views of R objects handed to workers (chimera.cpp:66-71): thin wrappers over the shim's containers
+template <typename T> class RMatrix {
+  const T *p;
+  std::size_t nr, nc;
+public:
+  RMatrix(const Rcpp::Mat<T> &m) : p(m.v.data()), nr((std::size_t)m.nr), nc((std::size_t)m.nc) {}
+  const T *begin() const { return p; }
+  std::size_t nrow() const { return nr; }
+  std::size_t ncol() const { return nc; }
+};
+template <typename T> class RVector {
+  T *p;
+  std::size_t n;
+public:
+  RVector(Rcpp::Vec<T> &x) : p(x.v.data()), n(x.v.size()) {}
+  T &operator[](std::size_t i) { return p[i]; }
+  const T &operator[](std::size_t i) const { return p[i]; }
+  std::size_t size() const { return n; }
+};
 
 struct Worker {
   virtual ~Worker() {}

@@ -33,7 +33,7 @@ if dbs:
     # bench.py's HIP-event averages exclude them, so the comparable rocprofv3 average is over the working launches.
     L += ["## Hot kernels without the no-op speculative launches (duration >= 8 us)", "",
           "| kernel | working launches | avg us | no-op launches | avg us |", "|---|---|---|---|---|"]
-    for pat in ("%k_nw_ad<%", "%k_nw_adw<%", "%k_screen(%"):
+    for pat in ("%k_nw_ad<%", "%k_nw_adw<%", "%k_screen(%", "%k2_screen_multi%", "%k2_shuffle<%"):
         for n, c1, a1, c0, a0 in db.execute(
                 "select name, sum(d >= 8000), avg(case when d >= 8000 then d end), sum(d < 8000), avg(case when d < 8000 then d end) "
                 "from (select name, (end - start) as d from kernels where name like ?) group by name", (pat,)):
@@ -69,7 +69,7 @@ for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     # (dispatches shorter than 8 us are the no-op speculative launches of the per-round kernels: not part of the average)
     for k, n, a in db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? and "
                               "(kernel_name like 'd2::%' or kernel_name like 'void d2::%') and "
-                              "(duration >= 8000 or (kernel_name not like '%k_nw_ad%' and kernel_name not like '%k_screen%')) "
+                              "(duration >= 8000 or (kernel_name not like '%k_nw_ad%' and kernel_name not like '%k_screen%' and kernel_name not like '%k2_screen_multi%')) "
                               "group by kernel_name", (cname,)):
         traffic.setdefault(short(k), {})[cname + "_KB_avg"] = a
         traffic[short(k)]["dispatches"] = n
@@ -77,11 +77,11 @@ for k, v in traffic.items():
     v["hbm_bytes_per_launch"] = 2 * 1024 * v.get("FETCH_SIZE_KB_avg", 0.0) + 1024 * v.get("WRITE_SIZE_KB_avg", 0.0)
 if traffic:
     # the two hot kernels under the names bench.py looks up (profiles/*_traffic_cfgN.json)
-    for k, v in traffic.items():
-        if "k_screen" in k: traffic_hot = traffic.setdefault("_hot", {}); traffic_hot["screen"] = v
-    nw = [v for k, v in traffic.items() if k != "_hot" and ("k_nw_ad" in k or "k_nw_adw" in k)]
-    if nw: traffic.setdefault("_hot", {})["nw"] = max(nw, key=lambda v: v.get("dispatches", 0))
-    hot = traffic.pop("_hot", {})
+    hot = {}
+    sc = [v for k, v in traffic.items() if "k2_screen_multi" in k] or [v for k, v in traffic.items() if "k_screen" in k]
+    if sc: hot["screen"] = sc[0]
+    nw = [v for k, v in traffic.items() if "k_nw_ad" in k or "k_nw_adw" in k]
+    if nw: hot["nw"] = max(nw, key=lambda v: v.get("dispatches", 0))
     json.dump({"tag": tag, "command": desc, "screen": hot.get("screen"), "nw": hot.get("nw"),
                "note": "avg per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 half-count on wide reads)",
                "kernels": traffic}, open(os.path.join(root, f"{tag}_traffic.json"), "w"), indent=1)
