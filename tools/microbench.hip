@@ -58,6 +58,49 @@ __global__ __launch_bounds__(256) void k_valu(int *out, int a, int b, int iters)
   if (s == 0x7fffffff) out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---- per-instruction issue rates: 16 independent chains of ONE instruction form each (mode `rates`) -----------------
+// The DP step of the NW kernels is a dependent chain of adds, max, compares and selects; which of them the SIMD issues
+// at full rate decides how the step should be written.
+#define RATE_KERNEL(NAME, ASM, ...)                                                                    \
+  __global__ __launch_bounds__(256) void NAME(int *out, int a, int b, int iters) {                     \
+    int x[16];                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 16; k++) x[k] = threadIdx.x + k * a;                         \
+    int y = threadIdx.x ^ b;                                                                           \
+    for (int it = 0; it < iters; it++) {                                                               \
+      _Pragma("unroll") for (int k = 0; k < 16; k++) asm volatile(ASM : "+v"(x[k]) : "v"(y), "s"(b) __VA_ARGS__); \
+    }                                                                                                  \
+    int s = 0;                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 16; k++) s += x[k];                                          \
+    if (s == 0x7fffffff) out[blockIdx.x * 256 + threadIdx.x] = s;                                      \
+  }
+RATE_KERNEL(r_add_vv, "v_add_u32 %0, %0, %1")
+RATE_KERNEL(r_sub_vv, "v_sub_u32 %0, %0, %1")
+RATE_KERNEL(r_max_vv, "v_max_i32 %0, %0, %1")
+RATE_KERNEL(r_min_vv, "v_min_i32 %0, %0, %1")
+RATE_KERNEL(r_minu_vv, "v_min_u32 %0, %0, %1")
+RATE_KERNEL(r_and_vv, "v_and_b32 %0, %0, %1")
+RATE_KERNEL(r_xor_vv, "v_xor_b32 %0, %0, %1")
+RATE_KERNEL(r_lshl_or, "v_lshl_or_b32 %0, %0, 2, %1")
+RATE_KERNEL(r_lshl_add, "v_lshl_add_u32 %0, %0, 1, %1")
+RATE_KERNEL(r_add3, "v_add3_u32 %0, %0, %1, %1")
+RATE_KERNEL(r_max3, "v_max3_i32 %0, %0, %1, %1")
+RATE_KERNEL(r_mad_i24, "v_mad_i32_i24 %0, %0, 3, %1")
+RATE_KERNEL(r_bfe_i32, "v_bfe_i32 %0, %0, 2, 6")
+RATE_KERNEL(r_mov_dpp_shr, "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf")
+RATE_KERNEL(r_mov_dpp_rowshr, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+RATE_KERNEL(r_cndmask_vcc, "v_cndmask_b32 %0, %0, %1, vcc")
+RATE_KERNEL(r_cndmask_sgpr, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]", : "s20", "s21")
+RATE_KERNEL(r_cmp_vcc, "v_cmp_ge_i32 vcc, %0, %1\n\tv_add_u32 %0, %0, %1", : "vcc")
+RATE_KERNEL(r_cmp_sgpr, "v_cmp_ge_i32_e64 s[20:21], %0, %1\n\tv_add_u32 %0, %0, %1", : "s20", "s21")
+RATE_KERNEL(r_cmp_cndmask, "v_cmp_ge_i32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc", : "vcc")
+RATE_KERNEL(r_addc, "v_addc_co_u32 %0, vcc, %0, %0, vcc", : "vcc")
+RATE_KERNEL(r_pk_add_i16, "v_pk_add_i16 %0, %0, %1")
+RATE_KERNEL(r_pk_max_i16, "v_pk_max_i16 %0, %0, %1")
+RATE_KERNEL(r_pk_min_i16, "v_pk_min_i16 %0, %0, %1")
+RATE_KERNEL(r_cmp_eq_u16_sdwa, "v_cmp_eq_u16_sdwa vcc, %0, %1 src0_sel:BYTE_0 src1_sel:BYTE_1\n\tv_add_u32 %0, %0, %1", : "vcc")
+RATE_KERNEL(r_sad_u8, "v_sad_u8 %0, %0, %1, %0")
+RATE_KERNEL(r_perm, "v_perm_b32 %0, %0, %1, %1")
+
 __global__ __launch_bounds__(256) void k_read(const uint4 *__restrict__ p, size_t n, uint32_t *out) {
   uint32_t acc = 0;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -169,6 +212,53 @@ int main(int argc, char **argv) {
            "independent chains per lane, best of 4 and 8 waves per SIMD; hbm_read = uint4 stream over 4 GiB, best of 5\"}\n",
            prop.gcnArchName, cus, prop.clockRate / 1000, vmax, tops[0], tops[1], tops[2], tops[4], tops[7], tops[5], tops[6], tops[3],
            best_read, best_copy, best_grid);
+    return 0;
+  }
+  if (!strcmp(mode, "rates")) {
+    int *out;
+    CK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
+    struct R { const char *name; void (*k)(int *, int, int, int); int per; };
+    const R tab[] = {
+        {"v_add_u32 (vv)", r_add_vv, 1}, {"v_sub_u32", r_sub_vv, 1}, {"v_max_i32", r_max_vv, 1}, {"v_min_i32", r_min_vv, 1},
+        {"v_min_u32", r_minu_vv, 1}, {"v_and_b32", r_and_vv, 1}, {"v_xor_b32", r_xor_vv, 1}, {"v_lshl_or_b32", r_lshl_or, 1},
+        {"v_lshl_add_u32", r_lshl_add, 1}, {"v_add3_u32", r_add3, 1}, {"v_max3_i32", r_max3, 1}, {"v_mad_i32_i24", r_mad_i24, 1},
+        {"v_bfe_i32", r_bfe_i32, 1}, {"v_mov_b32_dpp wave_shr:1", r_mov_dpp_shr, 1}, {"v_mov_b32_dpp row_shr:1", r_mov_dpp_rowshr, 1},
+        {"v_cndmask_b32 (vcc)", r_cndmask_vcc, 1}, {"v_cndmask_b32_e64 (sgpr pair)", r_cndmask_sgpr, 1},
+        {"v_cmp_ge_i32 vcc + v_add", r_cmp_vcc, 2}, {"v_cmp_ge_i32 sgpr + v_add", r_cmp_sgpr, 2}, {"v_cmp vcc + v_cndmask", r_cmp_cndmask, 2},
+        {"v_addc_co_u32", r_addc, 1}, {"v_pk_add_i16", r_pk_add_i16, 1}, {"v_pk_max_i16", r_pk_max_i16, 1}, {"v_pk_min_i16", r_pk_min_i16, 1},
+        {"v_cmp_eq_u16_sdwa + v_add", r_cmp_eq_u16_sdwa, 2}, {"v_sad_u8", r_sad_u8, 1}, {"v_perm_b32", r_perm, 1}};
+    const int iters = 2048;
+    printf("{\"device\": \"%s\", \"unit\": \"SIMD cycles per wave64 instruction at the nominal %d MHz (8 and 1 waves per SIMD)\", \"rates\": {", prop.gcnArchName,
+           prop.clockRate / 1000);
+    bool first = true;
+    for (const R &r : tab) {
+      double cyc[2];
+      int q = 0;
+      for (int wps : {8, 1}) {
+        const int grid = cus * wps;
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        hipLaunchKernelGGL(r.k, dim3(grid), dim3(256), 0, 0, out, 3, 5, iters);
+        CK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {
+          CK(hipEventRecord(a, 0));
+          hipLaunchKernelGGL(r.k, dim3(grid), dim3(256), 0, 0, out, 3, 5, iters);
+          CK(hipEventRecord(b, 0));
+          CK(hipEventSynchronize(b));
+          float ms;
+          CK(hipEventElapsedTime(&ms, a, b));
+          if (ms < best) best = ms;
+        }
+        // wave-instructions per SIMD = (waves per SIMD) x iters x 16 x per ; cycles = time x clock
+        const double winstr = (double)wps * iters * 16.0 * r.per;
+        cyc[q++] = best * 1e-3 * (prop.clockRate * 1e3) / winstr;
+        CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+      }
+      printf("%s\"%s\": [%.2f, %.2f]", first ? "" : ", ", r.name, cyc[0], cyc[1]);
+      first = false;
+    }
+    printf("}}\n");
     return 0;
   }
   const size_t n = argc > 2 ? (size_t)atoll(argv[2]) : ((size_t)1 << 28);
