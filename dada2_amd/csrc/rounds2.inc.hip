@@ -75,9 +75,18 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
     if (c == 0) return;                                                // an earlier call moved nothing: the loop has ended
     moved_before += c;
   }
+  // movers and new store blocks are buffered per block in LDS and written out once at the end: ONE device atomic per block
+  // for each of the two counters (thousands of same-address atomics per launch were most of this kernel's time)
+  constexpr int MOVCAP = 1024, NEWCAP = 512;
   __shared__ int s_n, s_base, s_an, s_abase;
+  __shared__ int32_t s_mov[3 * MOVCAP];
+  __shared__ int32_t s_newr[NEWCAP], s_newhead[NEWCAP];
+  __shared__ uint32_t s_newh[NEWCAP];
+  __shared__ double s_newl[NEWCAP];
   __shared__ int32_t s_delta[DELTA_TAB];
   __shared__ uint32_t s_reads[DELTA_TAB];                                // partition reads as of the start of this call
+  __shared__ int s_keep;
+  if (threadIdx.x == 0) { s_n = 0; s_an = 0; s_keep = 0; }
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   const Store2 &T = E.T;
@@ -169,39 +178,59 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
         P.update_e[to] = 1; P.update_e[from] = 1;
       }
     }
-    // movers and new store blocks are rare in most blocks of most calls: the bookkeeping below only runs where there are any
-    if (!__syncthreads_or(move || need_new)) continue;
-    if (threadIdx.x == 0) { s_n = 0; s_an = 0; }
-    __syncthreads();
-    if (move) pos = atomicAdd(&s_n, 1);
-    if (need_new) apos = atomicAdd(&s_an, 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      s_base = s_n ? atomicAdd(&out->cnt[level], s_n) : 0;
-      s_abase = s_an ? atomicAdd(T.blk_count, s_an) : 0;
-    }
-    __syncthreads();
     if (need_new) {
-      const int nb = s_abase + apos;
-      if (nb < T.blk_cap) {
-        CompBlk *cb = T.blk + nb;
-        cb->next = head; cb->cnt = 1; cb->i[0] = ci; cb->ham[0] = h; cb->lam[0] = l;
-        T.head[r] = nb;
-      } else atomicOr(P.err_flag, 2);
+      apos = atomicAdd(&s_an, 1);
+      if (apos < NEWCAP) { s_newr[apos] = r; s_newhead[apos] = head; s_newh[apos] = h; s_newl[apos] = l; }
+      else {   // (more new blocks in one thread block than the buffer holds: straight to the device counter)
+        const int nb = atomicAdd(T.blk_count, 1);
+        if (nb < T.blk_cap) {
+          CompBlk *cb = T.blk + nb;
+          cb->next = head; cb->cnt = 1; cb->i[0] = ci; cb->ham[0] = h; cb->lam[0] = l;
+          T.head[r] = nb;
+        } else atomicOr(P.err_flag, 2);
+      }
     }
     if (move) {
-      const int k = s_base + pos;
-      int32_t *m = mv + 3 * (size_t)k;
-      m[0] = r; m[1] = from; m[2] = to;
-      const int ki = moved_before + k;
-      if (ki < MOV_INLINE2) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
+      pos = atomicAdd(&s_n, 1);
+      if (pos < MOVCAP) { s_mov[3 * pos] = r; s_mov[3 * pos + 1] = from; s_mov[3 * pos + 2] = to; }
+      else {
+        const int k = atomicAdd(&out->cnt[level], 1);
+        int32_t *m = mv + 3 * (size_t)k;
+        m[0] = r; m[1] = from; m[2] = to;
+        const int ki = moved_before + k;
+        if (ki < MOV_INLINE2) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
+      }
     }
+  }
+  __syncthreads();                                                       // the block's movers / new blocks are all buffered
+  const int nmov = min(s_n, MOVCAP), nnew = min(s_an, NEWCAP);
+  if (threadIdx.x == 0) {
+    s_base = nmov ? atomicAdd(&out->cnt[level], nmov) : 0;
+    s_abase = nnew ? atomicAdd(T.blk_count, nnew) : 0;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < nnew; q += 256) {
+    const int nb = s_abase + q;
+    if (nb < T.blk_cap) {
+      CompBlk *cb = T.blk + nb;
+      cb->next = s_newhead[q]; cb->cnt = 1; cb->i[0] = ci; cb->ham[0] = s_newh[q]; cb->lam[0] = s_newl[q];
+      T.head[s_newr[q]] = nb;
+    } else atomicOr(P.err_flag, 2);
+  }
+  for (int q = threadIdx.x; q < nmov; q += 256) {
+    const int k = s_base + q;
+    int32_t *m = mv + 3 * (size_t)k;
+    m[0] = s_mov[3 * q]; m[1] = s_mov[3 * q + 1]; m[2] = s_mov[3 * q + 2];
+    const int ki = moved_before + k;
+    if (ki < MOV_INLINE2) { out->mov[3 * ki] = s_mov[3 * q]; out->mov[3 * ki + 1] = s_mov[3 * q + 1]; out->mov[3 * ki + 2] = s_mov[3 * q + 2]; }
   }
   __syncthreads();                                                       // every delta of the block is in the table
   if (STORE) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) my_keep += __shfl_xor(my_keep, o, 64);
-    if ((threadIdx.x & 63) == 0 && my_keep) atomicAdd(&out->pad0[0], my_keep);   // Comparisons kept this round (cluster.cpp:189-199)
+    if ((threadIdx.x & 63) == 0 && my_keep) atomicAdd(&s_keep, my_keep);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_keep) atomicAdd(&out->pad0[0], s_keep);   // Comparisons kept this round (cluster.cpp:189-199)
   }
   for (int k = threadIdx.x; k < ntab; k += 256) {
     const int32_t d = s_delta[k];
@@ -863,13 +892,13 @@ void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
   hipLaunchKernelGGL(k2_screen_multi, dim3(grid), dim3(256), lds, st, E);
 }
 void launch2_lists(const Eng2 &E, hipStream_t st) {
-  const int grid = std::min((E.S.N + 255) / 256, 1024);
+  const int grid = std::min((E.S.N + 255) / 256, 512);     // (one device atomic per list per block: keep the blocks few)
   const int iters = ((E.S.N + 255) / 256 + grid - 1) / grid;
   const int cap = std::min(iters * 256, 4096);
   hipLaunchKernelGGL(k2_lists, dim3(grid), dim3(256), (size_t)cap * 8, st, E, cap);
 }
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st) {
-  const int grid = std::min((E.S.N + 255) / 256, 2048);
+  const int grid = std::min((E.S.N + 255) / 256, 768);      // 3 resident blocks per CU (LDS), one device atomic per counter per block
   if (store) hipLaunchKernelGGL(k2_shuffle<true>, dim3(grid), dim3(256), 0, st, E, level);
   else hipLaunchKernelGGL(k2_shuffle<false>, dim3(grid), dim3(256), 0, st, E, level);
 }
