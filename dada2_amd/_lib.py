@@ -50,6 +50,7 @@ EXPORTS = [
     "dada2hip_result_bs_clust", "dada2hip_result_subqual", "dada2hip_result_clusterquals", "dada2hip_result_map",
     "dada2hip_result_pval", "dada2hip_result_stats", "dada2hip_result_free", "dada2hip_nwalign", "dada2hip_nwvec",
     "dada2hip_sample_compare", "dada2hip_calc_pA", "dada2hip_version", "dada2hip_run_multi", "dada2hip_trim_cache",
+    "dada2hip_table_bimera2", "dada2hip_is_bimera",
 ]
 
 
@@ -104,6 +105,8 @@ def lib():
     L.dada2hip_calc_pA.argtypes = [ip, vp, vp, vp, ip, vp, cp, C.c_size_t]
     L.dada2hip_run_multi.argtypes = [ip, C.POINTER(CSampleInput), vp, ip, C.POINTER(COpts), ip, vp, C.POINTER(vp), cp,
                                      C.c_size_t]
+    L.dada2hip_table_bimera2.argtypes = [ip, ip, vp, C.POINTER(cp), C.c_double, ip, ip, ip, ip, ip, ip, ip, ip, vp, vp, cp, C.c_size_t]
+    L.dada2hip_is_bimera.argtypes = [cp, ip, C.POINTER(cp), ip, ip, ip, ip, ip, ip, ip, C.POINTER(ip), cp, C.c_size_t]
     L.dada2hip_trim_cache.argtypes = []
     L.dada2hip_trim_cache.restype = None
     _lib = L

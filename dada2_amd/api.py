@@ -262,6 +262,41 @@ def nwalign(s1, s2, match=5, mismatch=-4, gap=-8, homo_gap=None, band=-1, endsfr
     return o0.value.decode(), o1.value.decode()
 
 
+def table_bimera2(mat, seqs, min_fold=1.5, min_abund=2, allow_one_off=False, min_one_off_par_dist=4, match=5, mismatch=-4,
+                  gap_p=-8, max_shift=16, device: int = 0):
+    """C_table_bimera2 (src/chimera.cpp:192; called by isBimeraDenovoTable, R/chimeras.R:236): ``mat`` is the
+    [samples, sequences] count table; returns (nflag[nseq], nsam[nseq])."""
+    L = _lib.lib()
+    m = np.asfortranarray(np.asarray(mat, dtype=np.int32))
+    nrow, ncol = m.shape
+    if ncol != len(seqs):
+        raise ValueError("The sequence table must have one column per sequence.")
+    arr = (C.c_char_p * max(ncol, 1))(*[s.encode("ascii") for s in seqs])
+    nflag, nsam = np.zeros(ncol, dtype=np.int32), np.zeros(ncol, dtype=np.int32)
+    eb = C.create_string_buffer(_EB)
+    _lib.check(L.dada2hip_table_bimera2(nrow, ncol, m.ctypes.data, arr, float(min_fold), int(min_abund), int(allow_one_off),
+                                        int(min_one_off_par_dist), match, mismatch, gap_p, int(max_shift), device,
+                                        nflag.ctypes.data, nsam.ctypes.data, eb, _EB), eb)
+    return nflag, nsam
+
+
+def is_bimera(sq, parents, allow_one_off=False, min_one_off_par_dist=4, match=5, mismatch=-4, gap_p=-8, max_shift=16, device: int = 0):
+    """C_is_bimera (src/chimera.cpp:18; R/chimeras.R:43 isBimera)."""
+    L = _lib.lib()
+    arr = (C.c_char_p * max(len(parents), 1))(*[s.encode("ascii") for s in parents])
+    out = C.c_int32(0)
+    eb = C.create_string_buffer(_EB)
+    _lib.check(L.dada2hip_is_bimera(sq.encode("ascii"), len(parents), arr, int(allow_one_off), int(min_one_off_par_dist), match,
+                                    mismatch, gap_p, int(max_shift), device, C.byref(out), eb, _EB), eb)
+    return bool(out.value)
+
+
+def is_bimera_denovo_table(mat, seqs, min_sample_fraction=0.9, ignore_n_negatives=1, **kw):
+    """isBimeraDenovoTable (R/chimeras.R:220-247): the consensus decision over samples on top of C_table_bimera2."""
+    nflag, nsam = table_bimera2(mat, seqs, **kw)
+    return (nflag >= nsam) | ((nflag > 0) & (nflag >= (nsam - ignore_n_negatives) * min_sample_fraction))
+
+
 def calc_pA_device(reads, E, prior, device: int = 0):
     """calc_pA (src/pval.cpp:44-64) evaluated by the device kernel."""
     L = _lib.lib()

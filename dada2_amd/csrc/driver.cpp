@@ -2073,6 +2073,181 @@ int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int3
   });
 }
 
+// ---- bimera identification (chimera.cpp): the step after dada() ---------------------------------------------------
+namespace {
+struct BimPair { int32_t left, right, left_oo, right_oo, ham; };
+
+// Aligns every (query j, parent k) pair the table asks for on the device and returns, per query, its parents with the
+// get_lr / get_ham_endsfree results.  parents[j] lists the k's (ascending); res[j][t] belongs to parents[j][t].
+void bimera_pairs(int ncol, const char *const *seqs, const std::vector<std::vector<int32_t>> &parents, int match, int mismatch,
+                  int gap_p, int max_shift, int allow_one_off, int device, std::vector<std::vector<BimPair>> &res) {
+  res.assign(ncol, {});
+  size_t npairs = 0;
+  for (int j = 0; j < ncol; j++) { res[j].resize(parents[j].size()); npairs += parents[j].size(); }
+  if (!npairs) return;
+  for (int i = 0; i < ncol; i++)
+    for (const char *c = seqs[i]; *c; c++)
+      if (*c != 'A' && *c != 'C' && *c != 'G' && *c != 'T')
+        throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: bimera identification on the device takes A/C/G/T only."};
+  std::vector<int32_t> ab(ncol, 1);
+  dada2hip_sample *s = new dada2hip_sample();
+  std::unique_ptr<dada2hip_sample, void (*)(dada2hip_sample *)> guard(s, dada2hip_sample_free);
+  sample_create(s, ncol, seqs, ab.data(), nullptr, nullptr, 0, device, /*lite=*/true);
+  if (max_shift == 0) throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: maxShift 0 is outside the implemented path."};
+  ensure_scratch(s, max_shift);
+  std::vector<double> errm(16, 1.0), rowm;
+  upload_err(s, errm.data(), 1, rowm);
+  dada2hip_opts o;
+  memset(&o, 0, sizeof o);
+  o.match = match; o.mismatch = mismatch; o.gap = gap_p; o.vectorized_alignment = 1;   // nwalign_vectorized2 (chimera.cpp:26)
+  AlignParams ap{match, mismatch, gap_p, max_shift, nw_sentinel(o), 0, 1};
+  const int stride = 2 * s->D.maxlen + 2;
+  // batches of whole queries, each query's parents padded to the lane kernel's 64-alignment chunks
+  const size_t budget_slots = std::max<size_t>(4096, ((size_t)256 << 20) / (size_t)stride);
+  s->d_lambda.alloc(ncol); s->d_ham.alloc(ncol);
+  DevBuf<int32_t> d_out;
+  std::vector<int32_t> work, cc, h_out;
+  std::vector<std::pair<int, size_t>> where;   // (query, first slot) of the batch
+  hipStream_t stq = s->stream;
+  int j = 0;
+  while (j < ncol) {
+    work.clear(); cc.clear(); where.clear();
+    while (j < ncol && (work.empty() || work.size() + parents[j].size() + 64 <= budget_slots)) {
+      if (!parents[j].empty()) {
+        where.push_back({j, work.size()});
+        for (size_t t = 0; t < parents[j].size(); t++) {
+          if (t % 64 == 0) cc.push_back(j);
+          work.push_back(parents[j][t]);
+        }
+        while (work.size() % 64) work.push_back(-1);
+      }
+      j++;
+    }
+    if (work.empty()) continue;
+    const int nwork = (int)work.size();
+    s->d_work.alloc(work.size()); s->d_chunk_centre.alloc(cc.size()); s->d_moves.alloc(work.size() * (size_t)stride);
+    s->d_nmoves.alloc(work.size()); d_out.alloc(work.size() * 5);
+    D2_HIP(hipMemcpyAsync(s->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, stq));
+    D2_HIP(hipMemcpyAsync(s->d_chunk_centre.p, cc.data(), cc.size() * 4, hipMemcpyHostToDevice, stq));
+    launch_nw(s->D, s->scr_class, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, nwork, ap, s->d_err.p, s->scr, s->d_lambda.p, s->d_ham.p,
+              nullptr, 0, 0, s->d_moves.p, stride, s->d_nmoves.p, stq);
+    launch_bimera_lr(s->D, s->d_chunk_centre.p, s->d_work.p, nwork, s->d_moves.p, stride, s->d_nmoves.p, allow_one_off, max_shift,
+                     d_out.p, stq);
+    h_out.resize(work.size() * 5);
+    D2_HIP(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * 4, hipMemcpyDeviceToHost, stq));
+    D2_HIP(hipStreamSynchronize(stq));
+    D2_HIP(hipGetLastError());
+    check_nw_flag(s);
+    for (auto &w : where) {
+      const int q = w.first;
+      for (size_t t = 0; t < parents[q].size(); t++) {
+        const int32_t *o5 = &h_out[(w.second + t) * 5];
+        res[q][t] = BimPair{o5[0], o5[1], o5[2], o5[3], o5[4]};
+      }
+    }
+  }
+}
+}  // namespace
+
+// C_table_bimera2 (chimera.cpp:61-208).  mat: nrow (samples) x ncol (sequences), column-major as R's IntegerMatrix.
+int dada2hip_table_bimera2(int32_t nrow, int32_t ncol, const int32_t *mat, const char *const *seqs, double min_fold, int32_t min_abund,
+                           int32_t allow_one_off, int32_t min_one_off_par_dist, int32_t match, int32_t mismatch, int32_t gap_p,
+                           int32_t max_shift, int32_t device, int32_t *nflag, int32_t *nsam, char *errbuf, size_t errlen) {
+  return guarded(errbuf, errlen, [&] {
+    if (nrow < 0 || ncol < 0 || (ncol > 0 && (!mat || !seqs || !nflag || !nsam))) throw InputError{"dada2hip: bad sequence table"};
+    if (ncol == 0) return;
+    select_device(device);
+    // which (query, parent) pairs does the table ask for?  (chimera.cpp:117-118: a parent is more abundant than the query
+    // by min_fold and at least min_abund in some sample where the query is present)
+    std::vector<std::vector<int32_t>> parents(ncol);
+    parallel_for((size_t)ncol, 8, [&](size_t lo, size_t hi) {
+      std::vector<uint8_t> need(ncol);
+      for (size_t j = lo; j < hi; j++) {
+        std::fill(need.begin(), need.end(), 0);
+        for (int i = 0; i < nrow; i++) {
+          const int vj = mat[i + j * (size_t)nrow];
+          if (vj <= 0) continue;
+          for (int k = 0; k < ncol; k++) {
+            const int vk = mat[i + (size_t)k * nrow];
+            if (vk > (min_fold * vj) && vk >= min_abund) need[k] = 1;
+          }
+        }
+        for (int k = 0; k < ncol; k++) if (need[k]) parents[j].push_back(k);
+      }
+    });
+    std::vector<std::vector<BimPair>> res;
+    bimera_pairs(ncol, seqs, parents, match, mismatch, gap_p, max_shift, allow_one_off, device, res);
+    // per sequence and sample: is there a two-parent model?  (chimera.cpp:103-161)
+    parallel_for((size_t)ncol, 8, [&](size_t lo, size_t hi) {
+      std::vector<int32_t> lefts(ncol), rights(ncol), lefts_oo(ncol), rights_oo(ncol);
+      std::vector<uint8_t> allowed(ncol), have(ncol);
+      for (size_t j = lo; j < hi; j++) {
+        const int sqlen = (int)strlen(seqs[j]);
+        std::fill(have.begin(), have.end(), 0);
+        for (size_t t = 0; t < parents[j].size(); t++) {
+          const int k = parents[j][t];
+          const BimPair &b = res[j][t];
+          have[k] = 1;
+          allowed[k] = allow_one_off && b.ham >= min_one_off_par_dist;
+          if (b.left + b.right < sqlen) { lefts[k] = b.left; rights[k] = b.right; lefts_oo[k] = b.left_oo; rights_oo[k] = b.right_oo; }
+          else { lefts[k] = rights[k] = lefts_oo[k] = rights_oo[k] = 0; }   // id / pure-shift / internal-indel "parents"
+        }
+        int ns = 0, nf = 0;
+        for (int i = 0; i < nrow; i++) {
+          const int vj = mat[i + j * (size_t)nrow];
+          if (vj <= 0) continue;
+          ns++;
+          int max_left = 0, max_right = 0, oml = 0, omr = 0, omlo = 0, omro = 0;
+          for (int k = 0; k < ncol; k++) {
+            const int vk = mat[i + (size_t)k * nrow];
+            if (!(vk > (min_fold * vj) && vk >= min_abund) || !have[k]) continue;
+            max_left = std::max(max_left, lefts[k]); max_right = std::max(max_right, rights[k]);
+            if (allow_one_off && allowed[k]) {
+              oml = std::max(oml, lefts[k]); omr = std::max(omr, rights[k]);
+              omlo = std::max(omlo, lefts_oo[k]); omro = std::max(omro, rights_oo[k]);
+            }
+          }
+          if (max_right + max_left >= sqlen) nf++;
+          else if (allow_one_off && (oml + omro >= sqlen || omlo + omr >= sqlen)) nf++;
+        }
+        nflag[j] = nf; nsam[j] = ns;
+      }
+    });
+  });
+}
+
+// C_is_bimera (chimera.cpp:18-59): *out = 1 when sq is a two-parent bimera of `pars`
+int dada2hip_is_bimera(const char *sq, int32_t npars, const char *const *pars, int32_t allow_one_off, int32_t min_one_off_par_dist,
+                       int32_t match, int32_t mismatch, int32_t gap_p, int32_t max_shift, int32_t device, int32_t *out, char *errbuf,
+                       size_t errlen) {
+  return guarded(errbuf, errlen, [&] {
+    if (!sq || !out || (npars > 0 && !pars)) throw InputError{"dada2hip: bad arguments"};
+    *out = 0;
+    if (npars <= 0) return;
+    select_device(device);
+    std::vector<const char *> seqs(npars + 1);
+    seqs[0] = sq;
+    for (int i = 0; i < npars; i++) seqs[i + 1] = pars[i];
+    std::vector<std::vector<int32_t>> parents(npars + 1);
+    for (int i = 0; i < npars; i++) parents[0].push_back(i + 1);
+    std::vector<std::vector<BimPair>> res;
+    bimera_pairs(npars + 1, seqs.data(), parents, match, mismatch, gap_p, max_shift, allow_one_off, device, res);
+    const int sqlen = (int)strlen(sq);
+    int max_left = 0, max_right = 0, oml = 0, omr = 0, omlo = 0, omro = 0;
+    // (the reference stops at the first parent that completes a model; the maxima only grow, so the answer is the same)
+    for (const BimPair &b : res[0]) {
+      if (b.left + b.right >= sqlen) continue;
+      max_left = std::max(max_left, b.left); max_right = std::max(max_right, b.right);
+      if (allow_one_off && b.ham >= min_one_off_par_dist) {
+        oml = std::max(oml, b.left); omr = std::max(omr, b.right);
+        omlo = std::max(omlo, b.left_oo); omro = std::max(omro, b.right_oo);
+      }
+    }
+    if (max_right + max_left >= sqlen) *out = 1;
+    if (allow_one_off && (oml + omro >= sqlen || omlo + omr >= sqlen)) *out = 1;
+  });
+}
+
 int dada2hip_nwalign(const char *s1, const char *s2, int32_t match, int32_t mismatch, int32_t gap_p, int32_t homo_gap_p,
                      int32_t band, int32_t endsfree, int32_t device, char *out0, char *out1, char *errbuf, size_t errlen) {
   if (gap_p != homo_gap_p) {

@@ -338,6 +338,10 @@ void launch2_resume(const Eng2 &E, hipStream_t st);
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st);
 
+// get_lr + get_ham_endsfree (chimera.cpp:211-293) on the move strings k_nw left behind: out[slot] = {left, right, left_oo, right_oo, ham}
+void launch_bimera_lr(const SampleDev &S, const int32_t *d_chunk_centre, const int32_t *d_work, int nwork, const uint8_t *d_moves,
+                      int stride, const int32_t *d_nmoves, int allow_one_off, int max_shift, int32_t *d_out, hipStream_t st);
+
 void launch_calc_pA(int n, const int32_t *d_reads, const double *d_E, const uint8_t *d_prior, double *d_out,
                     hipStream_t st);
 

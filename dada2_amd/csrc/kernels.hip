@@ -2079,6 +2079,83 @@ void launch_final_tables(const SampleDev &S, const uint16_t *d_view, int LV, con
                        d_centre_of_cluster, d_correct, ncol, has_quals, d_trans, d_qsum, d_qn, d_nsubs);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bimera identification (the step after dada(): src/chimera.cpp).  The alignment of a query against a candidate
+// parent is the denoising path's own banded ends-free NW with band = max_shift (chimera.cpp:26,122), done by k_nw with
+// its move strings kept; this kernel turns one alignment into what C_is_bimera / C_table_bimera2 consume:
+// get_lr (chimera.cpp:243-293: left / right coverage, and the one-off variants) and get_ham_endsfree (:211-239).
+// One thread per work slot; query = the slot's chunk centre, parent = work[slot].  Moves were recorded from the END of
+// the alignment backwards: 1 = both bases, 2 = gap in the query, 3 = gap in the parent.
+__global__ __launch_bounds__(256) void k_bimera_lr(SampleDev S, const int32_t *__restrict__ chunk_centre, const int32_t *__restrict__ work,
+                                                   int nwork, const uint8_t *__restrict__ moves, int stride,
+                                                   const int32_t *__restrict__ nmoves, int allow_one_off, int max_shift,
+                                                   int32_t *__restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nwork) return;
+  const int k = work[idx];
+  if (k < 0) return;
+  const int q = chunk_centre[idx >> 6];
+  const uint32_t *qrow = S.seq2 + (size_t)q * S.W2, *prow = S.seq2 + (size_t)k * S.W2;
+  const uint8_t *mv = moves + (size_t)idx * stride;
+  const int len = nmoves[idx];
+  auto col = [&](int c) -> int { return mv[len - 1 - c]; };                       // move of forward column c
+  // ---- left (forward) ----
+  int pos = 0, i = 0, j = 0, left = 0, left_oo = 0;
+  auto eq_f = [&](int c) -> bool { return col(c) == 1 && base_at(qrow, i) == base_at(prow, j); };
+  auto adv_f = [&](int c) { const int p = col(c); if (p != 2) i++; if (p != 3) j++; };
+  while (pos < len && col(pos) == 2) { adv_f(pos); pos++; }                       // scan in until the query starts
+  while (pos < len && col(pos) == 3 && pos < max_shift) { adv_f(pos); pos++; left++; }   // ends-free until the parent starts
+  while (pos < len && eq_f(pos)) { adv_f(pos); pos++; left++; }                   // covered until a mismatch
+  if (allow_one_off) {
+    left_oo = left;
+    if (pos < len) adv_f(pos);
+    pos++;
+    if (pos < len && col(pos) != 2) left_oo++;
+    while (pos < len && eq_f(pos)) { adv_f(pos); pos++; left_oo++; }
+  }
+  // ---- right (backward): before column c is consumed the bases are (i - 1, j - 1) ----
+  int right = 0, right_oo = 0;
+  i = S.len[q]; j = S.len[k];
+  pos = len - 1;
+  auto eq_b = [&](int c) -> bool { return col(c) == 1 && base_at(qrow, i - 1) == base_at(prow, j - 1); };
+  auto adv_b = [&](int c) { const int p = col(c); if (p != 2) i--; if (p != 3) j--; };
+  while (pos >= 0 && col(pos) == 2) { adv_b(pos); pos--; }
+  // (the reference compares `pos > len - max_shift` in size_t: never true when the alignment is shorter than max_shift)
+  while (pos >= 0 && col(pos) == 3 && len >= max_shift && pos > len - max_shift) { adv_b(pos); pos--; right++; }
+  while (pos >= 0 && eq_b(pos)) { adv_b(pos); pos--; right++; }
+  if (allow_one_off) {
+    right_oo = right;
+    if (pos >= 0) adv_b(pos);
+    pos--;
+    if (pos >= 0 && col(pos) != 2) right_oo++;
+    while (pos >= 0 && eq_b(pos)) { adv_b(pos); pos--; right_oo++; }
+  }
+  // ---- get_ham_endsfree: mismatching columns between the two end-gap runs ----
+  int is = 0, je = len - 1;
+  {
+    bool g1 = col(0) == 2, g2 = col(0) == 3;
+    while (g1 || g2) { is++; g1 = g1 && col(is) == 2; g2 = g2 && col(is) == 3; }
+    g1 = col(je) == 2; g2 = col(je) == 3;
+    while (g1 || g2) { je--; g1 = g1 && col(je) == 2; g2 = g2 && col(je) == 3; }
+  }
+  int ham = 0;
+  i = 0; j = 0;
+  for (int c = 0; c < len; c++) {
+    const int p = col(c);
+    if (c >= is && c <= je && !(p == 1 && base_at(qrow, i) == base_at(prow, j))) ham++;
+    if (p != 2) i++;
+    if (p != 3) j++;
+  }
+  int32_t *o = out + (size_t)idx * 5;
+  o[0] = left; o[1] = right; o[2] = left_oo; o[3] = right_oo; o[4] = ham;
+}
+void launch_bimera_lr(const SampleDev &S, const int32_t *d_chunk_centre, const int32_t *d_work, int nwork, const uint8_t *d_moves,
+                      int stride, const int32_t *d_nmoves, int allow_one_off, int max_shift, int32_t *d_out, hipStream_t st) {
+  if (nwork <= 0) return;
+  hipLaunchKernelGGL(k_bimera_lr, dim3((nwork + 255) / 256), dim3(256), 0, st, S, d_chunk_centre, d_work, nwork, d_moves, stride,
+                     d_nmoves, allow_one_off, max_shift, d_out);
+}
+
 #include "rounds2.inc.hip"
 
 }  // namespace d2

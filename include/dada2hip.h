@@ -13,6 +13,8 @@
  *   dada2hip_nwalign        <- C_nwalign()         src/evaluate.cpp:18-62    (`_dada2_C_nwalign`, RcppExports.cpp:94)
  *   dada2hip_nwvec          <- C_nwvec()           src/nwalign_vectorized.cpp:321-343 (`_dada2_C_nwvec`, :227)
  *   dada2hip_result_*       <- the Rcpp::List of six objects built at src/Rmain.cpp:254-294 and src/error.cpp
+ *   dada2hip_table_bimera2  <- C_table_bimera2()   src/chimera.cpp:192-208   (`_dada2_C_table_bimera2`; R/chimeras.R:236)
+ *   dada2hip_is_bimera      <- C_is_bimera()       src/chimera.cpp:18-59     (`_dada2_C_is_bimera`; R/chimeras.R:44)
  *
  * Conventions: plain C, no exceptions cross the boundary.  Every call returns 0 on success or a
  * non-zero code with a NUL-terminated message in `errbuf` (the reference's Rcpp::stop texts are
@@ -179,6 +181,21 @@ int dada2hip_nwalign(const char *s1, const char *s2, int32_t match, int32_t mism
 int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int32_t match, int32_t mismatch,
                    int32_t gap_p, int32_t band, int32_t endsfree, int32_t device, char *const *out,
                    char *errbuf, size_t errlen);
+
+/* ---- bimera identification: the step after dada() ------------------------------------------
+ * dada2hip_table_bimera2 == C_table_bimera2(mat, seqs, min_fold, min_abund, allow_one_off, min_one_off_par_dist, match,
+ * mismatch, gap_p, max_shift) (src/chimera.cpp:192): mat is the nrow (samples) x ncol (sequences) integer table, column-major
+ * as R holds it; nflag[ncol] / nsam[ncol] receive the two columns of the returned data.frame.  Every (sequence, more abundant
+ * parent) alignment the table asks for runs on the device NW kernel (band = max_shift, ends-free: the denoising path's
+ * aligner, chimera.cpp:122), get_lr / get_ham_endsfree (:211-293) on the device too.
+ * dada2hip_is_bimera == C_is_bimera (src/chimera.cpp:18): *out = 1 / 0. */
+int dada2hip_table_bimera2(int32_t nrow, int32_t ncol, const int32_t *mat, const char *const *seqs, double min_fold,
+                           int32_t min_abund, int32_t allow_one_off, int32_t min_one_off_par_dist, int32_t match,
+                           int32_t mismatch, int32_t gap_p, int32_t max_shift, int32_t device, int32_t *nflag, int32_t *nsam,
+                           char *errbuf, size_t errlen);
+int dada2hip_is_bimera(const char *sq, int32_t npars, const char *const *pars, int32_t allow_one_off,
+                       int32_t min_one_off_par_dist, int32_t match, int32_t mismatch, int32_t gap_p, int32_t max_shift,
+                       int32_t device, int32_t *out, char *errbuf, size_t errlen);
 
 /* One b_compare round exposed for kernel-level parity tests and for bench.py's roofline leg:
  * compares every unique of `s` against unique `centre` exactly as CompareParallel does

@@ -133,3 +133,32 @@ def calc_pA(reads, E, prior):
 
 def ppois_upper(x, lam):
     return lib().dada2_oracle_ppois(float(x), float(lam), 0)
+
+
+# ---- bimera identification (restatement of src/chimera.cpp) ---------------------------------------
+def _bim_args(L):
+    L.oracle_table_bimera2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.c_double, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.oracle_is_bimera.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+
+
+def table_bimera2(mat, seqs, min_fold=1.5, min_abund=2, allow_one_off=False, min_one_off_par_dist=4, match=5, mismatch=-4,
+                  gap_p=-8, max_shift=16):
+    """C_table_bimera2: mat is [nsamples, nseqs]; returns (nflag[nseqs], nsam[nseqs])."""
+    L = lib()
+    _bim_args(L)
+    m = np.asfortranarray(np.asarray(mat, dtype=np.int32))
+    nrow, ncol = m.shape
+    arr = (C.c_char_p * ncol)(*[s.encode() for s in seqs])
+    nflag, nsam = np.zeros(ncol, dtype=np.int32), np.zeros(ncol, dtype=np.int32)
+    L.oracle_table_bimera2(nrow, ncol, m.ctypes.data, arr, float(min_fold), int(min_abund), int(allow_one_off),
+                           int(min_one_off_par_dist), match, mismatch, gap_p, int(max_shift), nflag.ctypes.data, nsam.ctypes.data)
+    return nflag, nsam
+
+
+def is_bimera(sq, pars, allow_one_off=False, min_one_off_par_dist=4, match=5, mismatch=-4, gap_p=-8, max_shift=16):
+    L = lib()
+    _bim_args(L)
+    arr = (C.c_char_p * max(1, len(pars)))(*[s.encode() for s in pars])
+    return bool(L.oracle_is_bimera(sq.encode(), len(pars), arr, int(allow_one_off), int(min_one_off_par_dist), match, mismatch,
+                                   gap_p, int(max_shift)))

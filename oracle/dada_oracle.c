@@ -704,3 +704,135 @@ int oracle_compare(const char *cseq, const double *cq, const char *rseq, const d
   free(s->seq); free(s->qual); free(s->len); free(s->k8); free(s->k16); free(s->kord);
   return out[0] < 0 ? 1 : 0;
 }
+
+/* ------------------------------------------------------------ bimera identification --- */
+/* Restatement of /root/reference/src/chimera.cpp (the step after dada(): isBimeraDenovo[Table] in R/chimeras.R):
+   C_is_bimera :18-59, BimeraTableParallel / C_table_bimera2 :61-208, get_ham_endsfree :211-239, get_lr :243-293.
+   The alignment is the same banded ends-free NW as the denoising path, band = max_shift (chimera.cpp:26,122). */
+
+/* get_lr (chimera.cpp:243-293).  al0 = gapped query, al1 = gapped parent, n columns. */
+static void bim_get_lr(const uint8_t *al0, const uint8_t *al1, int n, int *left, int *right, int *left_oo, int *right_oo,
+                       int allow_one_off, int max_shift)
+{
+  int pos = 0, l = 0, r = 0;
+  while (pos < n && al0[pos] == '-') pos++;                           /* scan in until the query starts          */
+  while (pos < n && al1[pos] == '-' && pos < max_shift) { pos++; l++; }   /* ends-free coverage until the parent starts */
+  while (pos < n && al0[pos] == al1[pos]) { pos++; l++; }              /* covered until a mismatch                 */
+  *left = l;
+  if (allow_one_off) {
+    int lo = l;
+    pos++;
+    if (pos < n && al0[pos] != '-') lo++;
+    while (pos < n && al0[pos] == al1[pos]) { pos++; lo++; }
+    *left_oo = lo;
+  }
+  pos = n - 1;
+  while (pos >= 0 && al0[pos] == '-') pos--;
+  /* (the reference compares `pos > len - max_shift` in size_t: never true when the alignment is shorter than max_shift) */
+  while (pos >= 0 && al1[pos] == '-' && n >= max_shift && pos > n - max_shift) { pos--; r++; }
+  while (pos >= 0 && al0[pos] == al1[pos]) { pos--; r++; }
+  *right = r;
+  if (allow_one_off) {
+    int ro = r;
+    pos--;
+    if (pos >= 0 && al0[pos] != '-') ro++;
+    while (pos >= 0 && al0[pos] == al1[pos]) { pos--; ro++; }
+    *right_oo = ro;
+  }
+}
+
+/* get_ham_endsfree (chimera.cpp:211-239): mismatching columns, end gaps not counted */
+static int bim_ham_endsfree(const uint8_t *a, const uint8_t *b, int n)
+{
+  int i = 0, j = n - 1, pos, ham = 0, g1, g2;
+  g1 = a[i] == '-'; g2 = b[i] == '-';
+  while (g1 || g2) { i++; g1 = g1 && a[i] == '-'; g2 = g2 && b[i] == '-'; }
+  g1 = a[j] == '-'; g2 = b[j] == '-';
+  while (g1 || g2) { j--; g1 = g1 && a[j] == '-'; g2 = g2 && b[j] == '-'; }
+  for (pos = i; pos <= j; pos++) if (a[pos] != b[pos]) ham++;
+  return ham;
+}
+
+typedef struct { int left, right, left_oo, right_oo, ham; } BimPair;
+
+static void bim_pair(const char *q, const char *p, int match, int mismatch, int gap_p, int max_shift, int allow_one_off, BimPair *o)
+{
+  int l1 = (int)strlen(q), l2 = (int)strlen(p), n;
+  uint8_t *a = (uint8_t *)malloc(l1 + 1), *b = (uint8_t *)malloc(l2 + 1);
+  uint8_t *al0 = (uint8_t *)malloc(l1 + l2 + 2), *al1 = (uint8_t *)malloc(l1 + l2 + 2);
+  encode(q, a, l1); encode(p, b, l2);
+  n = nw_endsfree(a, l1, b, l2, match, mismatch, gap_p, max_shift, -9999, al0, al1);
+  al0[n] = 0; al1[n] = 0;
+  o->left_oo = o->right_oo = 0;
+  bim_get_lr(al0, al1, n, &o->left, &o->right, &o->left_oo, &o->right_oo, allow_one_off, max_shift);
+  o->ham = bim_ham_endsfree(al0, al1, n);
+  free(a); free(b); free(al0); free(al1);
+}
+
+/* C_is_bimera (chimera.cpp:18-59) */
+int oracle_is_bimera(const char *sq, int npars, const char *const *pars, int allow_one_off, int min_one_off_par_dist, int match,
+                     int mismatch, int gap_p, int max_shift)
+{
+  int i, sqlen = (int)strlen(sq), rval = 0;
+  int max_left = 0, max_right = 0, oml = 0, omr = 0, omlo = 0, omro = 0;
+  for (i = 0; i < npars && !rval; i++) {
+    BimPair b;
+    bim_pair(sq, pars[i], match, mismatch, gap_p, max_shift, allow_one_off, &b);
+    if (b.left + b.right >= sqlen) continue;                         /* id / pure-shift / internal-indel "parents" */
+    if (b.left > max_left) max_left = b.left;
+    if (b.right > max_right) max_right = b.right;
+    if (allow_one_off && b.ham >= min_one_off_par_dist) {
+      if (b.left > oml) oml = b.left;
+      if (b.right > omr) omr = b.right;
+      if (b.left_oo > omlo) omlo = b.left_oo;
+      if (b.right_oo > omro) omro = b.right_oo;
+    }
+    if (max_right + max_left >= sqlen) rval = 1;
+    if (allow_one_off && (oml + omro >= sqlen || omlo + omr >= sqlen)) rval = 1;
+  }
+  return rval;
+}
+
+/* C_table_bimera2 (chimera.cpp:61-208): mat = nrow (samples) x ncol (sequences), column-major */
+int oracle_table_bimera2(int nrow, int ncol, const int *mat, const char *const *seqs, double min_fold, int min_abund,
+                         int allow_one_off, int min_one_off_par_dist, int match, int mismatch, int gap_p, int max_shift,
+                         int *nflag_out, int *nsam_out)
+{
+  int i, j, k;
+  int *lefts = (int *)malloc(sizeof(int) * ncol), *rights = (int *)malloc(sizeof(int) * ncol);
+  int *lefts_oo = (int *)malloc(sizeof(int) * ncol), *rights_oo = (int *)malloc(sizeof(int) * ncol);
+  char *allowed = (char *)malloc(ncol);
+  for (j = 0; j < ncol; j++) {
+    int nsam = 0, nflag = 0, sqlen = (int)strlen(seqs[j]);
+    for (k = 0; k < ncol; k++) { lefts[k] = rights[k] = lefts_oo[k] = rights_oo[k] = -1; allowed[k] = 0; }
+    for (i = 0; i < nrow; i++) {
+      int max_left = 0, max_right = 0, oml = 0, omr = 0, omlo = 0, omro = 0;
+      if (mat[i + (size_t)j * nrow] <= 0) continue;
+      nsam++;
+      for (k = 0; k < ncol; k++) {
+        if (mat[i + (size_t)k * nrow] > (min_fold * mat[i + (size_t)j * nrow]) && mat[i + (size_t)k * nrow] >= min_abund) {
+          if (lefts[k] < 0) {
+            BimPair b;
+            bim_pair(seqs[j], seqs[k], match, mismatch, gap_p, max_shift, allow_one_off, &b);
+            if (allow_one_off && b.ham >= min_one_off_par_dist) allowed[k] = 1;
+            if (b.left + b.right < sqlen) { lefts[k] = b.left; rights[k] = b.right; lefts_oo[k] = b.left_oo; rights_oo[k] = b.right_oo; }
+            else { lefts[k] = rights[k] = lefts_oo[k] = rights_oo[k] = 0; }
+          }
+          if (lefts[k] > max_left) max_left = lefts[k];
+          if (rights[k] > max_right) max_right = rights[k];
+          if (allow_one_off && allowed[k]) {
+            if (lefts[k] > oml) oml = lefts[k];
+            if (rights[k] > omr) omr = rights[k];
+            if (lefts_oo[k] > omlo) omlo = lefts_oo[k];
+            if (rights_oo[k] > omro) omro = rights_oo[k];
+          }
+        }
+      }
+      if (max_right + max_left >= sqlen) nflag++;
+      else if (allow_one_off && (oml + omro >= sqlen || omlo + omr >= sqlen)) nflag++;
+    }
+    nflag_out[j] = nflag; nsam_out[j] = nsam;
+  }
+  free(lefts); free(rights); free(lefts_oo); free(rights_oo); free(allowed);
+  return 0;
+}

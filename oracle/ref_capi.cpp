@@ -61,9 +61,9 @@ void *ref_dada_uniques(int nraw, const char *const *seqs, const int *abund, cons
       p[i] = priors ? priors[i] != 0 : false;
     }
     Rcpp::NumericMatrix E(16, err_ncol);
-    memcpy(E.v.data(), err, sizeof(double) * 16 * (size_t)err_ncol);
+    memcpy(E.v().data(), err, sizeof(double) * 16 * (size_t)err_ncol);
     Rcpp::NumericMatrix Q(quals ? quals_nrow : 0, quals ? nraw : 0);
-    if (quals) memcpy(Q.v.data(), quals, sizeof(double) * (size_t)quals_nrow * (size_t)nraw);
+    if (quals) memcpy(Q.v().data(), quals, sizeof(double) * (size_t)quals_nrow * (size_t)nraw);
     ref_result *r = new ref_result;
     r->res = dada_uniques(s, a, p, E, Q, o->match, o->mismatch, o->gap, o->use_kmers, o->kdist_cutoff,
                           o->band_size, o->omegaA, o->omegaP, o->omegaC, o->detect_singletons, o->max_clust,
@@ -181,7 +181,7 @@ int ref_table_bimera2(int nrow, int ncol, const int *mat, const char *const *seq
                       int *nflag, int *nsam, char *errbuf, int errlen) {
   try {
     Rcpp::IntegerMatrix M(nrow, ncol);
-    memcpy(M.v.data(), mat, sizeof(int) * (size_t)nrow * (size_t)ncol);
+    memcpy(M.v().data(), mat, sizeof(int) * (size_t)nrow * (size_t)ncol);
     std::vector<std::string> s(ncol);
     for (int i = 0; i < ncol; i++) s[i] = seqs[i];
     Rcpp::DataFrame df = C_table_bimera2(M, s, min_fold, min_abund, allow_one_off != 0, min_one_off_par_dist, match, mismatch,

@@ -58,24 +58,28 @@ inline void stop(const char *fmt, ...) {
 inline void stop(const std::string &s) { throw std::runtime_error(s); }
 inline void checkUserInterrupt() {}
 
+// R vectors are reference objects: copying an Rcpp vector copies the handle, not the data (chimera.cpp:80 hands
+// `flags` / `sams` to its worker BY VALUE and expects the worker's writes to land in the caller's vectors)
 template <typename T> class Vec {
 public:
-  std::vector<T> v;
-  Vec() {}
-  explicit Vec(size_t n) : v(n, T()) {}
-  size_t size() const { return v.size(); }
-  T &operator[](size_t i) { return v[i]; }
-  const T &operator[](size_t i) const { return v[i]; }
-  T &operator()(size_t i) { return v[i]; }
-  const T &operator()(size_t i) const { return v[i]; }
-  void push_back(const T &x) { v.push_back(x); }
+  std::shared_ptr<std::vector<T>> p;
+  Vec() : p(std::make_shared<std::vector<T>>()) {}
+  explicit Vec(size_t n) : p(std::make_shared<std::vector<T>>(n, T())) {}
+  std::vector<T> &v() { return *p; }
+  const std::vector<T> &v() const { return *p; }
+  size_t size() const { return p->size(); }
+  T &operator[](size_t i) { return (*p)[i]; }
+  const T &operator[](size_t i) const { return (*p)[i]; }
+  T &operator()(size_t i) { return (*p)[i]; }
+  const T &operator()(size_t i) const { return (*p)[i]; }
+  void push_back(const T &x) { p->push_back(x); }
 };
 
 class IntegerVector : public Vec<int> {
 public:
   IntegerVector() {}
   explicit IntegerVector(size_t n) : Vec<int>(n) {}
-  IntegerVector(size_t n, int fill) : Vec<int>(n) { for (auto &x : v) x = fill; }   // chimera.cpp:195-196
+  IntegerVector(size_t n, int fill) : Vec<int>(n) { for (auto &x : v()) x = fill; }   // chimera.cpp:195-196
 };
 class NumericVector : public Vec<double> {
 public:
@@ -89,16 +93,19 @@ public:
   explicit CharacterVector(size_t n) : Vec<std::string>(n) {}
 };
 
+// (matrices are reference objects too: chimera.cpp:76 keeps a view of a by-value IntegerMatrix parameter after it is gone)
 template <typename T> class Mat {
 public:
-  std::vector<T> v;
+  std::shared_ptr<std::vector<T>> p;
   int nr, nc;
-  Mat() : nr(0), nc(0) {}
-  Mat(int nrow, int ncol) : v((size_t)nrow * (size_t)ncol, T()), nr(nrow), nc(ncol) {}
+  Mat() : p(std::make_shared<std::vector<T>>()), nr(0), nc(0) {}
+  Mat(int nrow, int ncol) : p(std::make_shared<std::vector<T>>((size_t)nrow * (size_t)ncol, T())), nr(nrow), nc(ncol) {}
+  std::vector<T> &v() { return *p; }
+  const std::vector<T> &v() const { return *p; }
   int nrow() const { return nr; }
   int ncol() const { return nc; }
-  T &operator()(size_t r, size_t c) { return v[c * (size_t)nr + r]; }  // column-major, as R
-  const T &operator()(size_t r, size_t c) const { return v[c * (size_t)nr + r]; }
+  T &operator()(size_t r, size_t c) { return (*p)[c * (size_t)nr + r]; }  // column-major, as R
+  const T &operator()(size_t r, size_t c) const { return (*p)[c * (size_t)nr + r]; }
 };
 typedef Mat<double> NumericMatrix;
 typedef Mat<int> IntegerMatrix;
@@ -136,12 +143,12 @@ public:
 };
 typedef List DataFrame;
 
-inline RObjP wrap(const IntegerVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::INT; o->iv = x.v; return o; }
-inline RObjP wrap(const NumericVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::DBL; o->dv = x.v; return o; }
-inline RObjP wrap(const CharacterVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::STR; o->sv = x.v; return o; }
+inline RObjP wrap(const IntegerVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::INT; o->iv = x.v(); return o; }
+inline RObjP wrap(const NumericVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::DBL; o->dv = x.v(); return o; }
+inline RObjP wrap(const CharacterVector &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::STR; o->sv = x.v(); return o; }
 inline RObjP wrap(const std::vector<std::string> &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::STR; o->sv = x; return o; }
-inline RObjP wrap(const IntegerMatrix &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::IMAT; o->iv = x.v; o->nr = x.nr; o->nc = x.nc; return o; }
-inline RObjP wrap(const NumericMatrix &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::DMAT; o->dv = x.v; o->nr = x.nr; o->nc = x.nc; return o; }
+inline RObjP wrap(const IntegerMatrix &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::IMAT; o->iv = x.v(); o->nr = x.nr; o->nc = x.nc; return o; }
+inline RObjP wrap(const NumericMatrix &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::DMAT; o->dv = x.v(); o->nr = x.nr; o->nc = x.nc; return o; }
 inline RObjP wrap(const List &x) { return x.obj; }
 
 struct Named {

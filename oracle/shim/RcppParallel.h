@@ -23,19 +23,21 @@ namespace RcppParallel {
 
 // read / write views of R objects handed to workers (chimera.cpp:66-71): thin wrappers over the shim's containers
 template <typename T> class RMatrix {
+  std::shared_ptr<std::vector<T>> keep;   // the view keeps the object alive, as a protected SEXP would be
   const T *p;
   std::size_t nr, nc;
 public:
-  RMatrix(const Rcpp::Mat<T> &m) : p(m.v.data()), nr((std::size_t)m.nr), nc((std::size_t)m.nc) {}
+  RMatrix(const Rcpp::Mat<T> &m) : keep(m.p), p(m.p->data()), nr((std::size_t)m.nr), nc((std::size_t)m.nc) {}
   const T *begin() const { return p; }
   std::size_t nrow() const { return nr; }
   std::size_t ncol() const { return nc; }
 };
 template <typename T> class RVector {
+  std::shared_ptr<std::vector<T>> keep;
   T *p;
   std::size_t n;
 public:
-  RVector(Rcpp::Vec<T> &x) : p(x.v.data()), n(x.v.size()) {}
+  RVector(Rcpp::Vec<T> x) : keep(x.p), p(x.p->data()), n(x.p->size()) {}   // (shares the caller's storage, as an R vector does)
   T &operator[](std::size_t i) { return p[i]; }
   const T &operator[](std::size_t i) const { return p[i]; }
   std::size_t size() const { return n; }

@@ -271,3 +271,58 @@ def test_config5_long_reads_parity_vs_reference_itself(api):
     ref.set_threads(1)
     assert got.nclust == want.nclust == 16
     assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+# ---- bimera identification: the step after dada() ---------------------------------------------------
+def test_bimera_table_matches_reference_goldens(api):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bimera_table.npz"))
+    mat, seqs = z["mat"], [str(s) for s in z["seqs"]]
+    for oo in (0, 1):
+        for ms in (16, 4):
+            nflag, nsam = api.table_bimera2(mat, seqs, allow_one_off=bool(oo), max_shift=ms)
+            assert np.array_equal(nflag, z[f"nflag_oo{oo}_ms{ms}"]), (oo, ms, nflag.tolist())
+            assert np.array_equal(nsam, z[f"nsam_oo{oo}_ms{ms}"])
+        tot = mat.sum(axis=0)
+        for j, s in enumerate(seqs):
+            pars = [seqs[k] for k in range(len(seqs)) if tot[k] > 2 * tot[j] and tot[k] > 8]
+            assert api.is_bimera(s, pars, allow_one_off=bool(oo)) == bool(z[f"isbim_oo{oo}"][j]), (j, oo)
+
+
+@pytest.mark.parametrize("seed,nseq,nsam,L", [(1, 60, 3, 120), (2, 300, 6, 250), (3, 120, 2, 400)])
+def test_bimera_table_seeded_vs_oracle(api, oracle_c, seed, nseq, nsam, L):
+    """Random tables: true sequences at a few % divergence, bimeras / one-offs / shifted / indel-carrying mosaics of them at low
+    abundance, ragged lengths; every (sequence, parent) decision against the oracle."""
+    rng = np.random.default_rng(seed)
+    anc = rng.integers(0, 4, size=L)
+    true = []
+    for g in range(max(6, nseq // 5)):
+        s = anc.copy()
+        p = rng.choice(L, size=int(L * rng.uniform(0.03, 0.12)), replace=False)
+        s[p] = (s[p] + rng.integers(1, 4, size=p.size)) & 3
+        true.append("".join("ACGT"[x] for x in s[: L - int(rng.integers(0, 6))]))
+    seqs = list(dict.fromkeys(true))
+    while len(seqs) < nseq:
+        a, b = rng.choice(len(true), 2, replace=False)
+        cut = int(rng.integers(10, L - 10))
+        ch = true[a][:cut] + true[b][cut:]
+        kind = int(rng.integers(0, 5))
+        if kind == 1:
+            ch = _mutate(rng, ch, nsub=1)
+        elif kind == 2:
+            ch = ch[int(rng.integers(1, 20)):]
+        elif kind == 3:
+            ch = _mutate(rng, ch, dels=(min(len(ch) - 2, cut + 3),))
+        elif kind == 4:
+            ch = _mutate(rng, ch, nsub=3)
+        if ch not in seqs:
+            seqs.append(ch)
+    mat = np.zeros((nsam, len(seqs)), dtype=np.int32)
+    nt = len(dict.fromkeys(true))
+    mat[:, :nt] = rng.integers(0, 400, size=(nsam, nt)) * (rng.random((nsam, nt)) < 0.8)
+    mat[:, nt:] = rng.integers(0, 12, size=(nsam, len(seqs) - nt)) * (rng.random((nsam, len(seqs) - nt)) < 0.6)
+    for oo, mf, ma, ms in ((False, 1.5, 2, 16), (True, 1.5, 2, 16), (True, 2.0, 8, 8)):
+        got = api.table_bimera2(mat, seqs, min_fold=mf, min_abund=ma, allow_one_off=oo, max_shift=ms)
+        want = oracle_c.table_bimera2(mat, seqs, min_fold=mf, min_abund=ma, allow_one_off=oo, max_shift=ms)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (oo, mf, ma, ms)
+    flagged = api.is_bimera_denovo_table(mat, seqs)
+    assert flagged.dtype == bool and flagged.shape == (len(seqs),)

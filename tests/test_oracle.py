@@ -137,3 +137,19 @@ def test_nwalign_vs_both_reference_aligners(oracle_c, oracle_ref):
         want = oracle_ref.nwalign(s1, s2, 5, -4, g, band, "vectorized")
         assert want == oracle_ref.nwalign(s1, s2, 5, -4, g, band, "endsfree")
         assert oracle_c.nwalign(s1, s2, 5, -4, g, band) == want
+
+
+def test_bimera_restatement_matches_reference_goldens(oracle_c):
+    """Bimera identification (src/chimera.cpp): the C restatement against the vectors the reference itself produced
+    (tests/golden/make_bimera_golden.py) - the checker of the GPU path's dada2hip_table_bimera2 / dada2hip_is_bimera."""
+    z = np.load(os.path.join(GOLDEN, "bimera_table.npz"))
+    mat, seqs = z["mat"], [str(s) for s in z["seqs"]]
+    for oo in (0, 1):
+        for ms in (16, 4):
+            nflag, nsam = oracle_c.table_bimera2(mat, seqs, allow_one_off=bool(oo), max_shift=ms)
+            assert np.array_equal(nflag, z[f"nflag_oo{oo}_ms{ms}"]) and np.array_equal(nsam, z[f"nsam_oo{oo}_ms{ms}"])
+        tot = mat.sum(axis=0)
+        for j, s in enumerate(seqs):
+            pars = [seqs[k] for k in range(len(seqs)) if tot[k] > 2 * tot[j] and tot[k] > 8]
+            assert oracle_c.is_bimera(s, pars, allow_one_off=bool(oo)) == bool(z[f"isbim_oo{oo}"][j]), (j, oo)
+    assert z["nflag_oo0_ms16"].max() == 2 and z["nflag_oo1_ms16"].sum() > z["nflag_oo0_ms16"].sum()
