@@ -50,7 +50,9 @@ EXPORTS = [
     "dada2hip_result_bs_clust", "dada2hip_result_subqual", "dada2hip_result_clusterquals", "dada2hip_result_map",
     "dada2hip_result_pval", "dada2hip_result_stats", "dada2hip_result_free", "dada2hip_nwalign", "dada2hip_nwvec",
     "dada2hip_sample_compare", "dada2hip_calc_pA", "dada2hip_version", "dada2hip_run_multi", "dada2hip_trim_cache",
-    "dada2hip_table_bimera2", "dada2hip_is_bimera",
+    "dada2hip_table_bimera2", "dada2hip_is_bimera", "dada2hip_derep_fastq", "dada2hip_derep_nuniques",
+    "dada2hip_derep_nreads", "dada2hip_derep_maxlen", "dada2hip_derep_seqs", "dada2hip_derep_abundances",
+    "dada2hip_derep_quals", "dada2hip_derep_map", "dada2hip_derep_free", "dada2hip_sample_from_derep",
 ]
 
 
@@ -107,6 +109,15 @@ def lib():
                                      C.c_size_t]
     L.dada2hip_table_bimera2.argtypes = [ip, ip, vp, C.POINTER(cp), C.c_double, ip, ip, ip, ip, ip, ip, ip, ip, vp, vp, cp, C.c_size_t]
     L.dada2hip_is_bimera.argtypes = [cp, ip, C.POINTER(cp), ip, ip, ip, ip, ip, ip, ip, C.POINTER(ip), cp, C.c_size_t]
+    L.dada2hip_derep_fastq.argtypes = [cp, C.c_int64, ip, C.POINTER(vp), cp, C.c_size_t]
+    for name, rt in (("nuniques", ip), ("nreads", C.c_int64), ("maxlen", ip), ("seqs", C.POINTER(cp)),
+                     ("abundances", C.POINTER(C.c_int32)), ("quals", C.POINTER(C.c_double)), ("map", C.POINTER(C.c_int32))):
+        f = getattr(L, "dada2hip_derep_" + name)
+        f.argtypes = [vp]
+        f.restype = rt
+    L.dada2hip_derep_free.argtypes = [vp]
+    L.dada2hip_derep_free.restype = None
+    L.dada2hip_sample_from_derep.argtypes = [vp, vp, ip, C.POINTER(vp), cp, C.c_size_t]
     L.dada2hip_trim_cache.argtypes = []
     L.dada2hip_trim_cache.restype = None
     _lib = L

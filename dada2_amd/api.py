@@ -167,6 +167,52 @@ def dada_uniques_multi(inputs, err, opts: DadaOpts = None, *, devices=(0,), copt
     return res
 
 
+class NativeDerep:
+    """derepFastq through the library's host-side dereplicator (dada2hip_derep_fastq; R/sequenceIO.R:45-124): the object
+    stays in the library's memory; ``to_derep`` copies it into the numpy ``Derep`` mirror, ``Sample.from_native`` uploads it
+    as a resident sample without a Python-side copy."""
+
+    def __init__(self, path: str, n: int = 10**6, qual_offset: int = 0):
+        L = _lib.lib()
+        eb = C.create_string_buffer(_EB)
+        self._h = C.c_void_p()
+        _lib.check(L.dada2hip_derep_fastq(str(path).encode(), int(n), int(qual_offset), C.byref(self._h), eb, _EB), eb)
+        self.nuniques = L.dada2hip_derep_nuniques(self._h)
+        self.nreads = L.dada2hip_derep_nreads(self._h)
+        self.maxlen = L.dada2hip_derep_maxlen(self._h)
+
+    def to_derep(self) -> Derep:
+        L = _lib.lib()
+        n, ml = self.nuniques, self.maxlen
+        sp = L.dada2hip_derep_seqs(self._h)
+        seqs = [sp[i].decode("ascii") for i in range(n)]
+        ab = np.ctypeslib.as_array(L.dada2hip_derep_abundances(self._h), (n,)).copy()
+        q = np.ctypeslib.as_array(L.dada2hip_derep_quals(self._h), (n, ml)).copy()
+        mp = np.ctypeslib.as_array(L.dada2hip_derep_map(self._h), (self.nreads,)).copy() if self.nreads else np.zeros(0, np.int32)
+        mp[mp == np.iinfo(np.int32).min] = -1
+        return Derep(seqs, ab, q, mp)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().dada2hip_derep_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def derep_fastq(path: str, n: int = 10**6, qual_offset: int = 0) -> Derep:
+    """derepFastq(fl, n) (R/sequenceIO.R:45) -> Derep, through dada2hip_derep_fastq."""
+    nd = NativeDerep(path, n, qual_offset)
+    try:
+        return nd.to_derep()
+    finally:
+        nd.close()
+
+
 class Sample:
     """Uniques of one sample resident in HBM (dada2hip_sample_*): 2-bit reads, rounded
     qualities and k-mer records are uploaded/built once and reused by every ``run``."""
@@ -185,6 +231,19 @@ class Sample:
     @classmethod
     def from_derep(cls, d: Derep, priors=None, device: int = 0):
         return cls(d.seqs, d.abundances, priors, d.quals, device)
+
+    @classmethod
+    def from_native(cls, nd: "NativeDerep", priors=None, device: int = 0):
+        """dada2hip_sample_from_derep: the library's derep object -> resident sample, no host copy in between."""
+        self = cls.__new__(cls)
+        eb = C.create_string_buffer(_EB)
+        self._h = C.c_void_p()
+        pr = None if priors is None else np.ascontiguousarray(priors, dtype=np.uint8)
+        rc = _lib.lib().dada2hip_sample_from_derep(nd._h, pr.ctypes.data if pr is not None else None, device, C.byref(self._h), eb, _EB)
+        _lib.check(rc, eb)
+        self.nraw = nd.nuniques
+        self.device = device
+        return self
 
     def set_priors(self, priors):
         eb = C.create_string_buffer(_EB)

@@ -51,35 +51,47 @@ def read_fastq(path: str):
     return seqs, quals
 
 
-def derep_from_reads(seqs, quals_phred33) -> Derep:
-    """qtables2 + the tail of derepFastq for one chunk (sequenceIO.R:150-183, :95-101)."""
-    keep = [i for i, s in enumerate(seqs) if len(s) > 0]  # zero-length reads are ignored (:154-158)
-    first = {}
-    for i in keep:
-        first.setdefault(seqs[i], []).append(i)
-    uniq = sorted(first.keys())  # srsort: C-locale lexical order
+def derep_from_reads(seqs, quals_phred33, n: int = 10**6, offset: int = 33) -> Derep:
+    """qtables2 per chunk of ``n`` reads + derepFastq's merge and tail (sequenceIO.R:150-183, :57-101): inside a chunk
+    the new uniques are in C-locale lexical order, later chunks append theirs (:85-88)."""
+    order_seen, count, qsum = [], {}, {}
+    for c0 in range(0, len(seqs), n):
+        chunk = range(c0, min(c0 + n, len(seqs)))
+        fresh = sorted({seqs[i] for i in chunk if len(seqs[i]) > 0 and seqs[i] not in count})  # srsort: C-locale order
+        for s in fresh:
+            order_seen.append(s)
+            count[s] = 0
+            qsum[s] = np.zeros(len(s))
+        for i in chunk:
+            s = seqs[i]
+            if len(s) == 0:  # zero-length reads are ignored (:154-158)
+                continue
+            count[s] += 1
+            qsum[s] += np.frombuffer(quals_phred33[i], dtype=np.uint8).astype(np.float64) - float(offset)
+    if not order_seen:
+        raise ValueError("Only zero-length sequences detected during dereplication.")
+    uniq = order_seen
     maxlen = max(len(s) for s in uniq)
-    counts = np.array([len(first[s]) for s in uniq], dtype=np.int64)
+    counts = np.array([count[s] for s in uniq], dtype=np.int64)
     cum = np.full((len(uniq), maxlen), np.nan)
     for u, s in enumerate(uniq):
-        acc = np.zeros(len(s))
-        for i in first[s]:
-            acc += np.frombuffer(quals_phred33[i], dtype=np.uint8).astype(np.float64) - 33.0
-        cum[u, : len(s)] = acc
+        cum[u, : len(s)] = qsum[s]
     mean = cum / counts[:, None]                      # derepQuals/derepCounts (:95)
     order = np.argsort(-counts, kind="stable")        # order(derepCounts, decreasing=TRUE) (:98), stable
     rank_of = np.empty(len(uniq), dtype=np.int64)
     rank_of[order] = np.arange(len(uniq))
     uidx = {s: u for u, s in enumerate(uniq)}
     rmap = np.full(len(seqs), -1, dtype=np.int32)
-    for i in keep:
-        rmap[i] = rank_of[uidx[seqs[i]]]
+    for i, s in enumerate(seqs):
+        if len(s) > 0:
+            rmap[i] = rank_of[uidx[s]]
     return Derep([uniq[u] for u in order], counts[order].astype(np.int32), mean[order], rmap)
 
 
-def derep_fastq(path: str) -> Derep:
+def derep_fastq(path: str, n: int = 10**6) -> Derep:
+    """Python restatement (the checker of dada2hip_derep_fastq; small files only)."""
     s, q = read_fastq(path)
-    return derep_from_reads(s, q)
+    return derep_from_reads(s, q, n)
 
 
 TRANS_NAMES = [a + "2" + b for a in "ACGT" for b in "ACGT"]  # A2A, A2C, ..., T2T (R/dada.R:362)

@@ -15,6 +15,7 @@
  *   dada2hip_result_*       <- the Rcpp::List of six objects built at src/Rmain.cpp:254-294 and src/error.cpp
  *   dada2hip_table_bimera2  <- C_table_bimera2()   src/chimera.cpp:192-208   (`_dada2_C_table_bimera2`; R/chimeras.R:236)
  *   dada2hip_is_bimera      <- C_is_bimera()       src/chimera.cpp:18-59     (`_dada2_C_is_bimera`; R/chimeras.R:44)
+ *   dada2hip_derep_*        <- derepFastq() / qtables2()  R/sequenceIO.R:45-124, :150-183 (host-side C++, zlib)
  *
  * Conventions: plain C, no exceptions cross the boundary.  Every call returns 0 on success or a
  * non-zero code with a NUL-terminated message in `errbuf` (the reference's Rcpp::stop texts are
@@ -196,6 +197,31 @@ int dada2hip_table_bimera2(int32_t nrow, int32_t ncol, const int32_t *mat, const
 int dada2hip_is_bimera(const char *sq, int32_t npars, const char *const *pars, int32_t allow_one_off,
                        int32_t min_one_off_par_dist, int32_t match, int32_t mismatch, int32_t gap_p, int32_t max_shift,
                        int32_t device, int32_t *out, char *errbuf, size_t errlen);
+
+/* ---- dereplication front-end: the step before dada() ----------------------------------------
+ * dada2hip_derep_fastq == derepFastq(fl, n = chunk_reads, qualityType = "Auto" | offset) (R/sequenceIO.R:45-124 on top of
+ * qtables2, :150-183): reads one FASTQ file (plain or gzip), dereplicates it and returns the `derep-class` content:
+ *   seqs[nuniques]        the unique sequences, by decreasing abundance (ties: first chunk seen, then C-locale lexical)
+ *   abundances[nuniques]  $uniques
+ *   quals                 $quals as nuniques rows of maxlen doubles (row u = mean quality per position of unique u, NA past
+ *                         its length) — which IS the column-major maxlen x nuniques matrix dada2hip_dada_uniques takes
+ *   map[nreads]           $map, 0-BASED unique index per read (DADA2HIP_NA_INTEGER for zero-length reads)
+ * chunk_reads <= 0 means the reference's default 1e6; qual_offset 33 / 64, or 0 for "Auto" (ShortRead's rule: a character
+ * below ';' anywhere in the first chunk => Phred+33, else +64).  Host-side: no device is touched.
+ * dada2hip_sample_from_derep uploads the object as a resident sample without another host copy. */
+typedef struct dada2hip_derep dada2hip_derep;
+int dada2hip_derep_fastq(const char *path, int64_t chunk_reads, int32_t qual_offset, dada2hip_derep **out, char *errbuf,
+                         size_t errlen);
+int32_t dada2hip_derep_nuniques(const dada2hip_derep *d);
+int64_t dada2hip_derep_nreads(const dada2hip_derep *d);
+int32_t dada2hip_derep_maxlen(const dada2hip_derep *d);
+const char *const *dada2hip_derep_seqs(const dada2hip_derep *d);
+const int32_t *dada2hip_derep_abundances(const dada2hip_derep *d);
+const double *dada2hip_derep_quals(const dada2hip_derep *d);
+const int32_t *dada2hip_derep_map(const dada2hip_derep *d);
+void dada2hip_derep_free(dada2hip_derep *d);
+int dada2hip_sample_from_derep(const dada2hip_derep *d, const uint8_t *priors, int32_t device, dada2hip_sample **out,
+                               char *errbuf, size_t errlen);
 
 /* One b_compare round exposed for kernel-level parity tests and for bench.py's roofline leg:
  * compares every unique of `s` against unique `centre` exactly as CompareParallel does
