@@ -53,6 +53,9 @@ EXPORTS = [
     "dada2hip_table_bimera2", "dada2hip_is_bimera", "dada2hip_derep_fastq", "dada2hip_derep_nuniques",
     "dada2hip_derep_nreads", "dada2hip_derep_maxlen", "dada2hip_derep_seqs", "dada2hip_derep_abundances",
     "dada2hip_derep_quals", "dada2hip_derep_map", "dada2hip_derep_free", "dada2hip_sample_from_derep",
+    "dada2hip_merge_pairs", "dada2hip_mergers_nrow", "dada2hip_mergers_sequence", "dada2hip_mergers_abundance",
+    "dada2hip_mergers_forward", "dada2hip_mergers_reverse", "dada2hip_mergers_nmatch", "dada2hip_mergers_nmismatch",
+    "dada2hip_mergers_nindel", "dada2hip_mergers_prefer", "dada2hip_mergers_accept", "dada2hip_mergers_free",
 ]
 
 
@@ -118,6 +121,18 @@ def lib():
     L.dada2hip_derep_free.argtypes = [vp]
     L.dada2hip_derep_free.restype = None
     L.dada2hip_sample_from_derep.argtypes = [vp, vp, ip, C.POINTER(vp), cp, C.c_size_t]
+    L.dada2hip_merge_pairs.argtypes = [C.c_int64, vp, vp, ip, C.POINTER(cp), vp, ip, C.POINTER(cp), vp, ip, ip, ip, ip, ip,
+                                       C.POINTER(vp), cp, C.c_size_t]
+    L.dada2hip_mergers_nrow.argtypes = [vp]
+    L.dada2hip_mergers_nrow.restype = ip
+    L.dada2hip_mergers_sequence.argtypes = [vp, ip]
+    L.dada2hip_mergers_sequence.restype = cp
+    for name in ("abundance", "forward", "reverse", "nmatch", "nmismatch", "nindel", "prefer", "accept"):
+        f = getattr(L, "dada2hip_mergers_" + name)
+        f.argtypes = [vp]
+        f.restype = C.POINTER(C.c_int32)
+    L.dada2hip_mergers_free.argtypes = [vp]
+    L.dada2hip_mergers_free.restype = None
     L.dada2hip_trim_cache.argtypes = []
     L.dada2hip_trim_cache.restype = None
     _lib = L

@@ -356,6 +356,48 @@ def is_bimera_denovo_table(mat, seqs, min_sample_fraction=0.9, ignore_n_negative
     return (nflag >= nsam) | ((nflag > 0) & (nflag >= (nsam - ignore_n_negatives) * min_sample_fraction))
 
 
+def merge_pairs(dadaF: DadaResult, derepF: Derep, dadaR: DadaResult, derepR: Derep, min_overlap=12, max_mismatch=0,
+                return_rejects=False, just_concatenate=False, trim_overhang=False, device: int = 0):
+    """mergePairs() for one sample (R/paired.R:92-201) through dada2hip_merge_pairs: a list of dict rows (sequence,
+    abundance, forward, reverse, nmatch, nmismatch, nindel, prefer, accept) in the reference's order."""
+    L = _lib.lib()
+    NA = np.iinfo(np.int32).min
+    mF, mR = np.asarray(derepF.map, dtype=np.int64), np.asarray(derepR.map, dtype=np.int64)
+    if len(mF) != len(mR) or (len(mF) and (mF.max() >= len(dadaF.map) or mR.max() >= len(dadaR.map))):
+        raise _lib.Dada2HipError(1, "Non-corresponding derep-class and dada-class objects.")     # paired.R:113-117
+    def denoised(dmap, rmap):
+        dm = np.asarray(dmap, dtype=np.int64)
+        out = np.full(len(rmap), NA, dtype=np.int32)
+        ok = rmap >= 0
+        v = dm[rmap[ok]]
+        out[ok] = np.where(v > 0, v, NA)
+        return out
+    fwd, rev = denoised(dadaF.map, mF), denoised(dadaR.map, mR)
+    sF, sR = list(dadaF.clustering["sequence"]), list(dadaR.clustering["sequence"])
+    aF = (C.c_char_p * max(1, len(sF)))(*[x.encode() for x in sF])
+    aR = (C.c_char_p * max(1, len(sR)))(*[x.encode() for x in sR])
+    n0F = np.ascontiguousarray(dadaF.clustering["n0"], dtype=np.int32)
+    n0R = np.ascontiguousarray(dadaR.clustering["n0"], dtype=np.int32)
+    eb = C.create_string_buffer(_EB)
+    h = C.c_void_p()
+    _lib.check(L.dada2hip_merge_pairs(len(fwd), fwd.ctypes.data, rev.ctypes.data, len(sF), aF, n0F.ctypes.data, len(sR), aR,
+                                      n0R.ctypes.data, int(min_overlap), int(max_mismatch), int(trim_overhang),
+                                      int(just_concatenate), device, C.byref(h), eb, _EB), eb)
+    try:
+        n = L.dada2hip_mergers_nrow(h)
+        col = {k: np.ctypeslib.as_array(getattr(L, "dada2hip_mergers_" + k)(h), (n,)).copy() if n else np.zeros(0, np.int32)
+               for k in ("abundance", "forward", "reverse", "nmatch", "nmismatch", "nindel", "prefer", "accept")}
+        rows = []
+        for i in range(n):
+            rows.append({"sequence": L.dada2hip_mergers_sequence(h, i).decode("ascii"), "abundance": int(col["abundance"][i]),
+                         "forward": int(col["forward"][i]), "reverse": int(col["reverse"][i]), "nmatch": int(col["nmatch"][i]),
+                         "nmismatch": int(col["nmismatch"][i]), "nindel": int(col["nindel"][i]),
+                         "prefer": None if col["prefer"][i] == NA else int(col["prefer"][i]), "accept": bool(col["accept"][i])})
+    finally:
+        L.dada2hip_mergers_free(h)
+    return rows if return_rejects else [r for r in rows if r["accept"]]
+
+
 def calc_pA_device(reads, E, prior, device: int = 0):
     """calc_pA (src/pval.cpp:44-64) evaluated by the device kernel."""
     L = _lib.lib()

@@ -1111,7 +1111,7 @@ struct Run {
   DevBuf<uint16_t> v2_bcls, v2_full, v2_ord;
   DevBuf<uint2> v2_tab8;
   PinBuf<Round2Out> v2_hblk;
-  int v2_nbuf = 32, v2_depth = 2, v2_chain = SH_CHAIN;
+  int v2_nbuf = 64, v2_depth = 2, v2_chain = SH_CHAIN;
   bool v2_debug = false;
   long v2_enq = 0, v2_cons = 0;
   uint64_t v2_miss_launches = 0;
@@ -1140,11 +1140,15 @@ struct Run {
     E2.total_reads = (double)(uint32_t)s->total_reads; E2.omegaA = o.omegaA; E2.omegaP = o.omegaP;
     E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
     E2.sp = sp; E2.thresh = d_thresh_round.p; E2.max_shuffle = MAX_SHUFFLE;
+    E2.grid_shuffle = 2048; E2.grid_lists = 512; E2.grid_pupdate = 1024;   // (profiles/r02l_sweep_grids.jsonl)
+    if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::max(1, atoi(e));
+    if (const char *e = getenv("DADA2HIP_V2_GRID_LISTS")) E2.grid_lists = std::max(1, atoi(e));
+    if (const char *e = getenv("DADA2HIP_V2_GRID_PUPDATE")) E2.grid_pupdate = std::max(1, std::min(1024, atoi(e)));   // (d_partial holds 1024 blocks)
     v2_drop_graph();                 // (captured launches hold the old argument block)
   }
   void v2_alloc(int max_clust) {
     const size_t n = (size_t)N;
-    v2_nbuf = 32;
+    v2_nbuf = 64;   // 512 cached centres, 2 bytes x N each (r02l sweep: 64 buffers beat 32 by 2.5 % at 1M uniques)
     if (const char *e = getenv("DADA2HIP_V2_NBUF")) v2_nbuf = std::max(1, std::min(64, atoi(e)));   // (k2_birth keeps the slot table in LDS)
     if (const char *e = getenv("DADA2HIP_V2_DEPTH")) v2_depth = std::max(1, std::min(RING2 - 1, atoi(e)));
     v2_chain = SH_CHAIN;

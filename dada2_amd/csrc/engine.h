@@ -324,6 +324,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   ScreenParams sp;
   const int32_t *thresh;
   int32_t max_shuffle;
+  int32_t grid_shuffle, grid_lists, grid_pupdate;   // host side: block caps of the per-round launches (tuning knobs)
 };
 
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,

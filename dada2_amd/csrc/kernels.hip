@@ -622,14 +622,44 @@ constexpr int AD_RCAP = 64;   // run descriptors buffered per alignment between 
 // one anti-diagonal step of one lane's live cell.  PAR is the cell parity (k = 2g + PAR).
 // LEAN: steady-state step — every in-band cell of the wave is an interior cell away from the last
 // row/column, so the matrix-edge logic (axis cells, free end gaps) is compiled out.
-template <int GL, int PAR, bool DEF, bool LEAN, bool EDGE>
+// Out-of-band cells: a LEAN step does not select the sentinel into them, it ADDS AD_OOB instead of the gap penalty (gsel,
+// a per-lane register: GAP for an in-band cell, AD_OOB for the others), so they sit about 10^6 below the band and never
+// win a max in an in-band neighbour — one select less on every step.
+constexpr int AD_OOB = -(1 << 20);
+constexpr int AD_VAR_DEFAULT = 1;
+// VAR selects the steady-state formulation (A/B knob DADA2HIP_AD_VARIANT): 0 = sentinel select, 1 = additive mask,
+// 2 = additive mask + v_max3.  vnext = the one base that changes for the next step (raw base after an even cell, centre
+// base after an odd one), loaded by the caller.
+template <int GL, int PAR, bool DEF, bool LEAN, bool EDGE, int VAR>
 static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
-                                               const uint8_t *cbytes, const uint8_t *rbytes, int fs, bool g_first, bool g_last,
-                                               bool kok, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
+                                               uint32_t vnext, int fs, bool g_first, bool g_last,
+                                               bool kok, int gsel, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
   // DEF: the reference's default scoring (MATCH 5, MISMATCH -4, GAP -8, vectorized sentinel) as literals
   const int SENT = DEF ? -32760 : SENT_, MATCH = DEF ? 5 : MATCH_, MISMATCH = DEF ? -4 : MISMATCH_, GAP = DEF ? -8 : GAP_;
-  // the one base that changes for the next step: raw base after an even cell, centre base after an odd one
-  const uint32_t vnext = PAR ? cbytes[i] : rbytes[j];
+  if (LEAN && !EDGE && VAR >= 1) {
+    // steady state, band inside the lane group: the DPP neighbour needs no masking (lanes without a source read 0, they
+    // are out of band), the fetch folds into the add, the two max into one v_max3
+    const int nb = PAR == 0 ? __builtin_amdgcn_update_dpp(0, d1, 0x138, 0xF, 0xF, true)     // lane-1's odd cell (wave_shr:1)
+                            : __builtin_amdgcn_update_dpp(0, d0, 0x130, 0xF, 0xF, true);    // lane+1's even cell (wave_shl:1)
+    const int own = PAR == 0 ? d0 : d1, other = PAR == 0 ? d1 : d0;
+    const int diag = own + (cb == rb ? MATCH : MISMATCH);
+    const int left = (PAR == 0 ? nb : other) + gsel, up = (PAR == 0 ? other : nb) + gsel;
+    int e;
+    bool t2;
+    if (VAR == 2) {                                          // (spelled out: the compiler would keep the inner max for t2)
+      asm("v_max3_i32 %0, %1, %2, %3" : "=v"(e) : "v"(left), "v"(diag), "v"(up));
+      t2 = up == e;                                          // up >= max(left, diag)  <=>  the maximum IS up
+    } else {
+      const int e1 = max(left, diag);
+      t2 = up >= e1;
+      e = max(up, e1);
+    }
+    const bool t1 = left >= diag;
+    const uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
+    if (PAR == 0) { d0 = e; rb = vnext; j++; } else { d1 = e; cb = vnext; i++; }
+    pw |= p << fs;
+    return;
+  }
   int left_src, up_src, own;
   if (PAR == 0) {
     const int lft = __builtin_amdgcn_update_dpp(SENT, d1, 0x138, 0xF, 0xF, false);   // lane-1's odd cell (wave_shr:1)
@@ -690,7 +720,7 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   return G;
 }
 
-template <int GL, bool DEF, bool EDGE>
+template <int GL, bool DEF, bool EDGE, int VAR>
 __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                AdGeom G) {
   constexpr int APW = 64 / GL;
@@ -765,6 +795,7 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       const bool g_first = g == 0, g_last = ghost || g == GL - 1;
       const bool kok0 = !ghost && 2 * g >= org && 2 * g < W + org, kok1 = !ghost && 2 * g + 1 >= org && 2 * g + 1 < W + org;
       const bool colok = !ghost && g < NCOL;
+      const int gs0 = kok0 ? (DEF ? -8 : GAP) : AD_OOB, gs1 = kok1 ? (DEF ? -8 : GAP) : AD_OOB;
       // Steady state [tA, tB): every in-band cell of every alignment in the wave is interior and off the
       // last row / column (i >= 1, j >= 1, i < L1, j < L2 for all k in the band).
       int tA = (lband > rband ? lband : rband) + 2, tB = min(2 * L1 - lband, 2 * L2 - rband);
@@ -777,15 +808,15 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
 #define AD_FULL_STEP(TT)                                                                                                        \
   {                                                                                                                             \
     if (((TT) & 1) == 0)                                                                                                        \
-      ad_step<GL, 0, DEF, false, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, ((TT) & 15) << 1, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+      ad_step<GL, 0, DEF, false, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, rbytes[j], ((TT) & 15) << 1, g_first, g_last, kok0, gs0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
     else                                                                                                                        \
-      ad_step<GL, 1, DEF, false, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, ((TT) & 15) << 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+      ad_step<GL, 1, DEF, false, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, cbytes[i], ((TT) & 15) << 1, g_first, g_last, kok1, gs1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
     if (((TT) & 15) == 15) AD_FLUSH(TT)                                                                                         \
   }
 #define AD_LEAN_PAIR(TT)                                                                                                        \
   {                                                                                                                             \
-    ad_step<GL, 0, DEF, true, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, ((TT) & 15) << 1, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
-    ad_step<GL, 1, DEF, true, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, (((TT) + 1) & 15) << 1, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    ad_step<GL, 0, DEF, true, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, rbytes[j], ((TT) & 15) << 1, g_first, g_last, kok0, gs0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    ad_step<GL, 1, DEF, true, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, cbytes[i], (((TT) + 1) & 15) << 1, g_first, g_last, kok1, gs1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
     if ((((TT) + 1) & 15) == 15) AD_FLUSH((TT) + 1)                                                                             \
   }
       int t = 0;
@@ -795,10 +826,14 @@ __global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restri
       for (; (t & 15) != 0 && t + 2 <= tB && t + 1 <= Tmax; t += 2) AD_LEAN_PAIR(t)
       // steady state in blocks of 16 steps = one pointer word per column: constant field shifts, one flush per block
       for (; t + 16 <= tB && t + 15 <= Tmax; t += 16) {
+        // the block consumes eight raw and eight centre bases: two 8-byte LDS reads (any byte address), bytes picked by index
+        uint64_t rw, cw;
+        __builtin_memcpy(&rw, rbytes + j, 8);
+        __builtin_memcpy(&cw, cbytes + i, 8);
 #pragma unroll
         for (int u = 0; u < 16; u += 2) {
-          ad_step<GL, 0, DEF, true, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, 2 * u, g_first, g_last, kok0, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          ad_step<GL, 1, DEF, true, EDGE>(d0, d1, i, j, cb, rb, pw, cbytes, rbytes, 2 * u + 2, g_first, g_last, kok1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          ad_step<GL, 0, DEF, true, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, (uint32_t)(rw >> (4 * u)) & 0xFFu, 2 * u, g_first, g_last, kok0, gs0, L1, L2, SENT, MATCH, MISMATCH, GAP);
+          ad_step<GL, 1, DEF, true, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, (uint32_t)(cw >> (4 * u)) & 0xFFu, 2 * u + 2, g_first, g_last, kok1, gs1, L1, L2, SENT, MATCH, MISMATCH, GAP);
         }
         AD_FLUSH(t)
       }
@@ -952,23 +987,31 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   if (d_gl_work) waves = (S.N + G.APW - 1) / G.APW;
   int grid = std::min((waves + 3) / 4, 256 * 8);
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
-#define D2_LAUNCH_AD(GLV, DEFV, EDGEV)                                                                                   \
+#define D2_LAUNCH_AD(GLV, DEFV, EDGEV, VARV)                                                                                 \
   do {                                                                                                                   \
     static size_t attr_set[64] = {0};   /* per device: the attribute belongs to the function ON a device */            \
     int dev_ = 0;                                                                                                        \
     (void)hipGetDevice(&dev_);                                                                                           \
     if (lds > attr_set[dev_ & 63]) {                                                                                     \
-      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV, VARV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_set[dev_ & 63] = lds;                                                                                         \
     }                                                                                                                    \
-    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);        \
+    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV, VARV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);  \
   } while (0)
 #define D2_LAUNCH_AD2(GLV)                                                                                               \
   do {                                                                                                                   \
-    if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true); else D2_LAUNCH_AD(GLV, true, false); }                         \
-    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true); else D2_LAUNCH_AD(GLV, false, false); }                           \
+    if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true, AD_VAR_DEFAULT); else D2_LAUNCH_AD(GLV, true, false, AD_VAR_DEFAULT); } \
+    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true, AD_VAR_DEFAULT); else D2_LAUNCH_AD(GLV, false, false, AD_VAR_DEFAULT); }   \
   } while (0)
-  if (G.GL == 21) D2_LAUNCH_AD2(21);
+  // the common shape (default band and scores) exists in all three steady-state formulations for A/B runs
+  const char *ve = getenv("DADA2HIP_AD_VARIANT");
+  const int var = ve ? atoi(ve) : AD_VAR_DEFAULT;
+  if (G.GL == 21 && def && !G.edge && var != AD_VAR_DEFAULT) {
+    if (var == 0) D2_LAUNCH_AD(21, true, false, 0);
+    else if (var == 1) D2_LAUNCH_AD(21, true, false, 1);
+    else D2_LAUNCH_AD(21, true, false, 2);
+  }
+  else if (G.GL == 21) D2_LAUNCH_AD2(21);
   else if (G.GL == 32) D2_LAUNCH_AD2(32);
   else D2_LAUNCH_AD2(64);
 #undef D2_LAUNCH_AD2

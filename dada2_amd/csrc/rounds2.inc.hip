@@ -892,19 +892,19 @@ void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
   hipLaunchKernelGGL(k2_screen_multi, dim3(grid), dim3(256), lds, st, E);
 }
 void launch2_lists(const Eng2 &E, hipStream_t st) {
-  const int grid = std::min((E.S.N + 255) / 256, 512);     // (one device atomic per list per block: keep the blocks few)
+  const int grid = std::min((E.S.N + 255) / 256, (int)E.grid_lists);   // (one device atomic per list per block: keep the blocks few)
   const int iters = ((E.S.N + 255) / 256 + grid - 1) / grid;
   const int cap = std::min(iters * 256, 4096);
   hipLaunchKernelGGL(k2_lists, dim3(grid), dim3(256), (size_t)cap * 8, st, E, cap);
 }
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st) {
-  const int grid = std::min((E.S.N + 255) / 256, 768);      // 3 resident blocks per CU (LDS), one device atomic per counter per block
+  const int grid = std::min((E.S.N + 255) / 256, (int)E.grid_shuffle);   // one device atomic per counter per block; 2048 blocks measured best at 1M uniques
   if (store) hipLaunchKernelGGL(k2_shuffle<true>, dim3(grid), dim3(256), 0, st, E, level);
   else hipLaunchKernelGGL(k2_shuffle<false>, dim3(grid), dim3(256), 0, st, E, level);
 }
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st) {
   BudKey init{1.0, init_reads};
-  const int grid = std::min((E.S.N + 255) / 256, 1024);
+  const int grid = std::min((E.S.N + 255) / 256, (int)E.grid_pupdate);
   hipLaunchKernelGGL(k2_pupdate, dim3(grid), dim3(256), 0, st, E, nlev, init, (BudKey *)E.partial);
   hipLaunchKernelGGL(k2_birth, dim3(1), dim3(1024), 0, st, E, nlev, init, (const BudKey *)E.partial, grid);
 }

@@ -15,6 +15,8 @@
  *   dada2hip_result_*       <- the Rcpp::List of six objects built at src/Rmain.cpp:254-294 and src/error.cpp
  *   dada2hip_table_bimera2  <- C_table_bimera2()   src/chimera.cpp:192-208   (`_dada2_C_table_bimera2`; R/chimeras.R:236)
  *   dada2hip_is_bimera      <- C_is_bimera()       src/chimera.cpp:18-59     (`_dada2_C_is_bimera`; R/chimeras.R:44)
+ *   dada2hip_merge_pairs    <- mergePairs()        R/paired.R:92-201 on C_nwalign / C_eval_pair / C_pair_consensus
+ *                                                   (src/evaluate.cpp:18-62, :73-114, :124-174)
  *   dada2hip_derep_*        <- derepFastq() / qtables2()  R/sequenceIO.R:45-124, :150-183 (host-side C++, zlib)
  *
  * Conventions: plain C, no exceptions cross the boundary.  Every call returns 0 on success or a
@@ -222,6 +224,32 @@ const int32_t *dada2hip_derep_map(const dada2hip_derep *d);
 void dada2hip_derep_free(dada2hip_derep *d);
 int dada2hip_sample_from_derep(const dada2hip_derep *d, const uint8_t *priors, int32_t device, dada2hip_sample **out,
                                char *errbuf, size_t errlen);
+
+/* ---- mergePairs: denoised forward + reverse reads -> merged amplicons -------------------------
+ * dada2hip_merge_pairs == the per-sample body of mergePairs(dadaF, derepF, dadaR, derepR, minOverlap, maxMismatch,
+ * returnRejects=TRUE, justConcatenate, trimOverhang) (R/paired.R:113-190).  fwd[i] / rev[i] = dadaF$map[derepF$map][i] /
+ * dadaR$map[derepR$map][i]: the 1-BASED denoised-sequence index of read pair i, or DADA2HIP_NA_INTEGER.  seqsF / n0F
+ * (seqsR / n0R) are dadaF$clustering$sequence / $n0.  Every unique (forward, reverse) pair is aligned on the device as
+ * R's nwalign(F, rc(R), band=-1) does (C_nwalign -> nwalign_endsfree, unbanded, scores 1/-64/-64 when maxMismatch == 0
+ * else 1/-8/-8, paired.R:152-159), then C_eval_pair / C_pair_consensus (src/evaluate.cpp:73,124) on the host.
+ * Rows come back in the reference's order (first appearance, stably sorted by decreasing abundance) INCLUDING the rejects
+ * (accept == 0, sequence ""): returnRejects=FALSE is a filter on `accept`.  prefer is NA with just_concatenate. */
+typedef struct dada2hip_mergers dada2hip_mergers;
+int dada2hip_merge_pairs(int64_t nreads, const int32_t *fwd, const int32_t *rev, int32_t nF, const char *const *seqsF,
+                         const int32_t *n0F, int32_t nR, const char *const *seqsR, const int32_t *n0R, int32_t min_overlap,
+                         int32_t max_mismatch, int32_t trim_overhang, int32_t just_concatenate, int32_t device,
+                         dada2hip_mergers **out, char *errbuf, size_t errlen);
+int32_t dada2hip_mergers_nrow(const dada2hip_mergers *m);
+const char *dada2hip_mergers_sequence(const dada2hip_mergers *m, int32_t i);
+const int32_t *dada2hip_mergers_abundance(const dada2hip_mergers *m);
+const int32_t *dada2hip_mergers_forward(const dada2hip_mergers *m);
+const int32_t *dada2hip_mergers_reverse(const dada2hip_mergers *m);
+const int32_t *dada2hip_mergers_nmatch(const dada2hip_mergers *m);
+const int32_t *dada2hip_mergers_nmismatch(const dada2hip_mergers *m);
+const int32_t *dada2hip_mergers_nindel(const dada2hip_mergers *m);
+const int32_t *dada2hip_mergers_prefer(const dada2hip_mergers *m);
+const int32_t *dada2hip_mergers_accept(const dada2hip_mergers *m);
+void dada2hip_mergers_free(dada2hip_mergers *m);
 
 /* One b_compare round exposed for kernel-level parity tests and for bench.py's roofline leg:
  * compares every unique of `s` against unique `centre` exactly as CompareParallel does

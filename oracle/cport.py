@@ -162,3 +162,19 @@ def is_bimera(sq, pars, allow_one_off=False, min_one_off_par_dist=4, match=5, mi
     arr = (C.c_char_p * max(1, len(pars)))(*[s.encode() for s in pars])
     return bool(L.oracle_is_bimera(sq.encode(), len(pars), arr, int(allow_one_off), int(min_one_off_par_dist), match, mismatch,
                                    gap_p, int(max_shift)))
+
+
+def eval_pair(a1, a2):
+    """Restatement of C_eval_pair (evaluate.cpp:73) -> (match, mismatch, indel)."""
+    out = (C.c_int * 3)()
+    if lib().oracle_eval_pair(a1.encode(), a2.encode(), out):
+        return None
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def pair_consensus(a1, a2, prefer, trim_overhang=False):
+    """Restatement of C_pair_consensus (evaluate.cpp:124)."""
+    o = C.create_string_buffer(len(a1) + 2)
+    if lib().oracle_pair_consensus(a1.encode(), a2.encode(), int(prefer), int(trim_overhang), o):
+        return None
+    return o.value.decode()

@@ -836,3 +836,55 @@ int oracle_table_bimera2(int nrow, int ncol, const int *mat, const char *const *
   free(lefts); free(rights); free(lefts_oo); free(rights_oo); free(allowed);
   return 0;
 }
+
+/* ---- mergePairs helpers (the step after dada() on paired reads; R/paired.R:159-169) ------------------------------- */
+/* C_eval_pair (evaluate.cpp:73-114): matches / mismatches / indels of the internal part of an alignment (end gaps of
+ * either string are not counted).  out = {match, mismatch, indel}; returns 1 for strings of different length. */
+int oracle_eval_pair(const char *s1, const char *s2, int *out)
+{
+  int n = (int)strlen(s1), start, end, i, s1gap, s2gap, match = 0, mismatch = 0, indel = 0;
+  if ((int)strlen(s2) != n) return 1;
+  s1gap = s2gap = 1;
+  start = -1;
+  do {                                                               /* evaluate.cpp:82-89 (s[n] is the terminator) */
+    start++;
+    s1gap = s1gap && (s1[start] == '-');
+    s2gap = s2gap && (s2[start] == '-');
+  } while ((s1gap || s2gap) && start < n);
+  s1gap = s2gap = 1;
+  end = n;
+  do {                                                               /* evaluate.cpp:91-98 */
+    end--;
+    if (end < 0) break;                                              /* (the reference would index s[-1] here) */
+    s1gap = s1gap && (s1[end] == '-');
+    s2gap = s2gap && (s2[end] == '-');
+  } while ((s1gap || s2gap) && end >= start);
+  for (i = start; i <= end; i++) {                                   /* evaluate.cpp:101-110 */
+    if (s1[i] == '-' || s2[i] == '-') indel++;
+    else if (s1[i] == s2[i]) match++;
+    else mismatch++;
+  }
+  out[0] = match; out[1] = mismatch; out[2] = indel;
+  return 0;
+}
+
+/* C_pair_consensus (evaluate.cpp:124-174): the merged sequence; `prefer` (1 = s1, 2 = s2) wins mismatches, overhangs
+ * (s2 running past the start of s1, s1 past the end of s2) are cut when asked.  out needs strlen(s1)+1 bytes. */
+int oracle_pair_consensus(const char *s1, const char *s2, int prefer, int trim_overhang, char *out)
+{
+  int n = (int)strlen(s1), i, j = 0;
+  if ((int)strlen(s2) != n) return 1;
+  for (i = 0; i < n; i++) {
+    if (s1[i] == s2[i]) out[i] = s1[i];
+    else if (s2[i] == '-') out[i] = s1[i];
+    else if (s1[i] == '-') out[i] = s2[i];
+    else out[i] = prefer == 1 ? s1[i] : (prefer == 2 ? s2[i] : 'N');
+  }
+  if (trim_overhang) {
+    for (i = 0; i < n; i++) { if (s1[i] != '-') break; out[i] = '-'; }
+    for (i = n - 1; i >= 0; i--) { if (s2[i] != '-') break; out[i] = '-'; }
+  }
+  for (i = 0; i < n; i++) if (out[i] != '-') out[j++] = out[i];
+  out[j] = 0;
+  return 0;
+}

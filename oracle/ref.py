@@ -204,3 +204,31 @@ def is_bimera(sq, pars, allow_one_off=False, min_one_off_par_dist=4, match=5, mi
     if r < 0:
         raise RuntimeError("C_is_bimera failed")
     return bool(r)
+
+
+def C_nwalign(s1, s2, match=5, mismatch=-4, gap_p=-8, homo_gap_p=None, band=-1, endsfree=True):
+    """The R-visible aligner itself (evaluate.cpp:18): what R's nwalign() calls."""
+    L = lib()
+    n = len(s1) + len(s2) + 2
+    o0, o1, eb = C.create_string_buffer(n), C.create_string_buffer(n), C.create_string_buffer(512)
+    rc = L.ref_C_nwalign(s1.encode(), s2.encode(), match, mismatch, gap_p, gap_p if homo_gap_p is None else homo_gap_p, band,
+                         int(endsfree), o0, o1, eb, 512)
+    if rc:
+        raise RuntimeError(eb.value.decode())
+    return o0.value.decode(), o1.value.decode()
+
+
+def eval_pair(a1, a2):
+    """C_eval_pair (evaluate.cpp:73) -> (match, mismatch, indel)."""
+    out = (C.c_int * 3)()
+    if lib().ref_eval_pair(a1.encode(), a2.encode(), out):
+        return None
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def pair_consensus(a1, a2, prefer, trim_overhang=False):
+    """C_pair_consensus (evaluate.cpp:124)."""
+    o = C.create_string_buffer(len(a1) + 2)
+    if lib().ref_pair_consensus(a1.encode(), a2.encode(), int(prefer), int(trim_overhang), o):
+        return None
+    return o.value.decode()

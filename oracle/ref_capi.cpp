@@ -28,6 +28,11 @@ bool C_is_bimera(std::string sq, std::vector<std::string> pars, bool allow_one_o
 Rcpp::DataFrame C_table_bimera2(Rcpp::IntegerMatrix mat, std::vector<std::string> seqs, double min_fold, int min_abund,
                                 bool allow_one_off, int min_one_off_par_dist, int match, int mismatch, int gap_p, int max_shift);
 
+// evaluate.cpp:18,73,124 (the R-visible aligner and the two helpers mergePairs() calls, R/paired.R:159-169)
+Rcpp::CharacterVector C_nwalign(std::string s1, std::string s2, int match, int mismatch, int gap_p, int homo_gap_p, int band, bool endsfree);
+Rcpp::IntegerVector C_eval_pair(std::string s1, std::string s2);
+Rcpp::CharacterVector C_pair_consensus(std::string s1, std::string s2, int prefer, bool trim_overhang);
+
 extern "C" {
 
 int dada2_shim_verbose = 0;
@@ -205,6 +210,36 @@ int ref_is_bimera(const char *sq, int npars, const char *const *pars, int allow_
   } catch (std::exception &) {
     return -1;
   }
+}
+
+// C_nwalign (evaluate.cpp:18) itself: out0/out1 need len1+len2+1 bytes each
+int ref_C_nwalign(const char *s1, const char *s2, int match, int mismatch, int gap_p, int homo_gap_p, int band, int endsfree,
+                  char *out0, char *out1, char *errbuf, int errlen) {
+  try {
+    Rcpp::CharacterVector r = C_nwalign(s1, s2, match, mismatch, gap_p, homo_gap_p, band, endsfree != 0);
+    strcpy(out0, r[0].c_str());
+    strcpy(out1, r[1].c_str());
+    return 0;
+  } catch (std::exception &e) {
+    if (errbuf && errlen > 0) snprintf(errbuf, errlen, "%s", e.what());
+    return 1;
+  }
+}
+
+// C_eval_pair (evaluate.cpp:73): out = {match, mismatch, indel}; returns 1 when the reference returned NULL
+int ref_eval_pair(const char *s1, const char *s2, int *out) {
+  Rcpp::IntegerVector r = C_eval_pair(s1, s2);
+  if (r.is_null || r.size() != 3) return 1;
+  out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
+  return 0;
+}
+
+// C_pair_consensus (evaluate.cpp:124): out needs strlen(s1)+1 bytes; returns 1 when the reference returned NULL
+int ref_pair_consensus(const char *s1, const char *s2, int prefer, int trim_overhang, char *out) {
+  Rcpp::CharacterVector r = C_pair_consensus(s1, s2, prefer, trim_overhang != 0);
+  if (r.is_null || r.size() != 1) return 1;
+  strcpy(out, r[0].c_str());
+  return 0;
 }
 
 }  // extern "C"

@@ -20,8 +20,9 @@
  *
  * PARITY STATUS: "parity unpinned" against genuine libRmath bits — the
  * reference ships no test vectors for this call and R is not installed here.
- * It is pinned numerically instead: tests/test_ppois.py checks it against
- * 60-digit mpmath and scipy.special.pdtrc over all four pgamma regimes and the
+ * It is pinned numerically instead: tests/test_oracle.py::test_ppois_against_truth_and_scipy
+ * checks it against the committed 60-digit mpmath grid (tests/golden/ppois_grid.npy, made by
+ * tests/golden/make_golden.py) and scipy.special.pdtrc over all four pgamma regimes and the
  * 1e-292..1e-323 underflow band (<= 1e-13 relative).  lgammafn() is taken from
  * the C library's lgamma() (R's own Chebyshev version differs by <= 1-2 ulp).
  */
@@ -51,8 +52,7 @@ static double o_stirlerr(double n)
     static const double S3 = 0.000595238095238095238095238; /* 1/1680 */
     static const double S4 = 0.0008417508417508417508417508;/* 1/1188 */
     /* exact values for n = 0, 0.5, 1.0, ..., 15.0 (regenerated with mpmath at
-       60 digits from lgamma(n+1)-(n+.5)log(n)+n-log(sqrt(2pi)); see
-       oracle/gen_constants.py) */
+       60 digits from lgamma(n+1)-(n+.5)log(n)+n-log(sqrt(2pi))) */
     static const double sferr_halves[31] = {
         0.0,
         0.1534264097200273452913848,   0.0810614667953272582196702,

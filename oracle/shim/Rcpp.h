@@ -2,7 +2,7 @@
 //
 // Minimal stand-in for <Rcpp.h> so that the reference's own hot-path sources
 // (/root/reference/src/{Rmain,cluster,containers,kmers,misc,pval,error,
-// nwalign_endsfree,nwalign_vectorized,chimera}.cpp) compile UNMODIFIED, in place, into
+// nwalign_endsfree,nwalign_vectorized,chimera,evaluate}.cpp) compile UNMODIFIED, in place, into
 // oracle/_ref/libdada2ref.so (recipe: oracle/Makefile).  Nothing here is a copy
 // of Rcpp: it is a from-scratch value-semantics model of exactly the Rcpp
 // surface those nine files touch (SURVEY.md §8c lists it).  R and Rcpp are not
@@ -75,12 +75,23 @@ public:
   void push_back(const T &x) { p->push_back(x); }
 };
 
+struct NilType {};                       // R_NilValue: evaluate.cpp:77,128 return it in place of a vector
+struct NamedInt { std::string name; int val; };
 class IntegerVector : public Vec<int> {
 public:
+  bool is_null = false;
   IntegerVector() {}
   explicit IntegerVector(size_t n) : Vec<int>(n) {}
   IntegerVector(size_t n, int fill) : Vec<int>(n) { for (auto &x : v()) x = fill; }   // chimera.cpp:195-196
+  IntegerVector(NilType) : is_null(true) {}
+  template <typename... A> static IntegerVector create(const A &...a) {                // evaluate.cpp:112 (named integer(3))
+    IntegerVector r;
+    NamedInt arr[] = {NamedInt{a.name, a.val->iv.at(0)}...};
+    for (auto &x : arr) r.push_back(x.val);
+    return r;
+  }
 };
+typedef IntegerVector LogicalVector;     // evaluate.cpp:184
 class NumericVector : public Vec<double> {
 public:
   NumericVector() {}
@@ -89,8 +100,11 @@ public:
 };
 class CharacterVector : public Vec<std::string> {
 public:
+  bool is_null = false;
   CharacterVector() {}
   explicit CharacterVector(size_t n) : Vec<std::string>(n) {}
+  CharacterVector(const std::string &x) { push_back(x); }   // evaluate.cpp:172 returns a std::string as character(1)
+  CharacterVector(NilType) : is_null(true) {}
 };
 
 // (matrices are reference objects too: chimera.cpp:76 keeps a view of a by-value IntegerMatrix parameter after it is gone)
@@ -150,6 +164,7 @@ inline RObjP wrap(const std::vector<std::string> &x) { auto o = std::make_shared
 inline RObjP wrap(const IntegerMatrix &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::IMAT; o->iv = x.v(); o->nr = x.nr; o->nc = x.nc; return o; }
 inline RObjP wrap(const NumericMatrix &x) { auto o = std::make_shared<RObj>(); o->kind = RObj::DMAT; o->dv = x.v(); o->nr = x.nr; o->nc = x.nc; return o; }
 inline RObjP wrap(const List &x) { return x.obj; }
+inline RObjP wrap(int x) { auto o = std::make_shared<RObj>(); o->kind = RObj::INT; o->iv = {x}; return o; }
 
 struct Named {
   std::string name;
@@ -172,5 +187,7 @@ template <typename... A> List List::create(const A &...a) {
 }
 
 }  // namespace Rcpp
+
+static const Rcpp::NilType R_NilValue = Rcpp::NilType();
 
 #endif

@@ -9,6 +9,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# torch (used by the nccl / gloo tests and by the GPU fixtures) bundles its own HIP runtime: it has to be loaded BEFORE
+# libdada2hip.so pulls in /opt/rocm's libamdhip64, otherwise the process holds two runtimes and torch.cuda reports no
+# device.  The library itself never needs torch.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

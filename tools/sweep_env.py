@@ -1,0 +1,68 @@
+"""Tuning sweep: one synthetic sample (bench.py's configuration N) made once and kept resident, then timed under a list
+of environment settings (the library reads its DADA2HIP_* knobs at every run).  One JSON line per setting with the wall
+time of a resident pass and the event-timed device milliseconds per phase.
+
+    python tools/sweep_env.py --config 3 --reps 3 "A=1" "A=2 B=3" ...
+The first (implicit) setting is the default environment; every result is checked against it (same partitions / map)."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--uniques", type=int, default=0)
+    ap.add_argument("settings", nargs="*")
+    ap.add_argument("--list", default="", help="settings separated by ';'")
+    a = ap.parse_args()
+    from dada2_amd import api
+    from dada2_amd.opts import DadaOpts
+    args = types.SimpleNamespace(uniques=a.uniques, length=0, variants=0)
+    dereps, inputs, err, mine, c = bench.make_inputs(a.config, args, 0)
+    d = dereps[0]
+    opts = DadaOpts(BAND_SIZE=c["band"])
+    s = api.Sample.from_derep(d, device=0)
+    base = None
+    for setting in [""] + list(a.settings) + [x.strip() for x in a.list.split(";") if x.strip()]:
+        kv = dict(x.split("=", 1) for x in setting.split())
+        old = {k: os.environ.get(k) for k in kv}
+        os.environ.update(kv)
+        os.environ["DADA2HIP_PROFILE"] = "0"
+        walls = []
+        res = None
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            res = s.run(err, opts)
+            walls.append((time.perf_counter() - t0) * 1e3)
+        os.environ["DADA2HIP_PROFILE"] = "1"
+        prof = s.run(err, opts)
+        st = prof.stats
+        same = True
+        if base is None:
+            base = res
+        else:
+            same = bool(np.array_equal(base.map, res.map) and np.array_equal(base.clustering["abundance"], res.clustering["abundance"]))
+        print(json.dumps({"setting": setting or "(default)", "ms_min": round(min(walls), 2), "ms_all": [round(w, 2) for w in walls],
+                          "same_as_default": same, "nclust": int(res.nclust),
+                          "dev_ms": {k[7:]: round(v, 2) for k, v in st.items() if k.startswith("dev_ms_")},
+                          "wait_device": round(st.get("ms_wait_device", 0), 1), "replay": round(st.get("ms_replay", 0), 1)}), flush=True)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+if __name__ == "__main__":
+    main()
