@@ -626,7 +626,7 @@ constexpr int AD_RCAP = 64;   // run descriptors buffered per alignment between 
 // a per-lane register: GAP for an in-band cell, AD_OOB for the others), so they sit about 10^6 below the band and never
 // win a max in an in-band neighbour — one select less on every step.
 constexpr int AD_OOB = -(1 << 20);
-constexpr int AD_VAR_DEFAULT = 1;
+constexpr int AD_VAR_DEFAULT = 2;   // r02o A/B at 8 700 alignments: 69.7 (0) / 66.9 (1) / 63.3 us (2)
 // VAR selects the steady-state formulation (A/B knob DADA2HIP_AD_VARIANT): 0 = sentinel select, 1 = additive mask,
 // 2 = additive mask + v_max3.  vnext = the one base that changes for the next step (raw base after an even cell, centre
 // base after an odd one), loaded by the caller.
@@ -720,8 +720,10 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   return G;
 }
 
+// (256, 3): three blocks per CU is what the LDS footprint allows anyway; it caps the kernel at 168 VGPRs — a variant that
+// needed 171 ran at two waves per SIMD and lost 15 % (profiles/r02n_nw_variants.jsonl)
 template <int GL, bool DEF, bool EDGE, int VAR>
-__global__ __launch_bounds__(256) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
+__global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                AdGeom G) {
   constexpr int APW = 64 / GL;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
