@@ -209,6 +209,13 @@ def main():
             smp.close()
         pst = prof or st
         roofline, other = rooflines(pst, L, band, args.config)
+        if prof is None:
+            # without the event-timed pass the library only times a sample of the launches: no per-launch figure is claimed
+            for r in (roofline, other):
+                for k in ("achieved", "frac", "frac_of_measured_peak", "avg_launch_ms", "kernel_ms"):
+                    if k in r:
+                        r[k] = None
+                r["timing"] = "not measured in this run (--no-profile-pass / --selfconsist): see the default run's record"
 
         cpu = None
         if not args.no_cpu_baseline and world == 1 and not args.selfconsist:

@@ -46,7 +46,7 @@ class HostPool {
   HostPool() {
     int n = (int)std::thread::hardware_concurrency();
     if (n <= 0) n = 1;
-    if (n > 32) n = 32;                                  // memory-bound copies: more threads do not help
+    if (n > 64) n = 64;                                  // memory-bound copies: 16 / 32 / 64 threads = 55 / 34 / 25 ms for the 1M-unique upload (profiles/r02q_bench_cfg3_threads*.json)
     if (const char *e = getenv("DADA2HIP_HOST_THREADS")) n = std::max(1, atoi(e));
     nthreads_ = n;
     for (int i = 1; i < n; i++) workers_.emplace_back([this] { loop(); });

@@ -959,9 +959,15 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
     if (g == 0 && active && !(dbg & 8)) {
       double l = 1.0;
       int pj = 0;
-      for (; pj + 8 <= L2; pj += 8) {
-        const double f0 = fac[pj], f1 = fac[pj + 1], f2 = fac[pj + 2], f3 = fac[pj + 3];
-        const double f4 = fac[pj + 4], f5 = fac[pj + 5], f6 = fac[pj + 6], f7 = fac[pj + 7];
+      if (L2 >= 8) {   // the next eight factors are on their way from LDS while the current eight are multiplied (the product
+                       // itself stays strictly sequential: pval.cpp:188-192)
+        double f0 = fac[0], f1 = fac[1], f2 = fac[2], f3 = fac[3], f4 = fac[4], f5 = fac[5], f6 = fac[6], f7 = fac[7];
+        for (pj = 8; pj + 8 <= L2; pj += 8) {
+          const double n0 = fac[pj], n1 = fac[pj + 1], n2 = fac[pj + 2], n3 = fac[pj + 3];
+          const double n4 = fac[pj + 4], n5 = fac[pj + 5], n6 = fac[pj + 6], n7 = fac[pj + 7];
+          l = l * f0; l = l * f1; l = l * f2; l = l * f3; l = l * f4; l = l * f5; l = l * f6; l = l * f7;
+          f0 = n0; f1 = n1; f2 = n2; f3 = n3; f4 = n4; f5 = n5; f6 = n6; f7 = n7;
+        }
         l = l * f0; l = l * f1; l = l * f2; l = l * f3; l = l * f4; l = l * f5; l = l * f6; l = l * f7;
       }
       for (; pj < L2; pj++) l = l * fac[pj];
