@@ -122,6 +122,9 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    if world > 1 and "DADA2HIP_HOST_THREADS" not in os.environ:
+        # one process per GPU on one host: the marshalling threads of the ranks share the host's cores and memory channels
+        os.environ["DADA2HIP_HOST_THREADS"] = str(max(8, min(64, (os.cpu_count() or 64) // world)))
     from dada2_amd import api
     from dada2_amd.opts import DadaOpts
 

@@ -1069,8 +1069,27 @@ static __host__ __device__ inline AdwGeom adw_geom(int band, int maxlen, int min
 // one step of a lane's four live cells.  PAR = parity of the live cells; FS = 2 * (t & 15) (field shift).
 template <int PAR, bool LEAN, bool DEF>
 static __device__ __forceinline__ void adw_step(int (&d)[8], uint32_t (&pw)[4], int fs, uint32_t x, int nb, uint32_t kmask,
-                                                int I, int Jr, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
+                                                const int (&gs)[8], int I, int Jr, int L1, int L2, int SENT_, int MATCH_,
+                                                int MISMATCH_, int GAP_) {
   const int SENT = DEF ? -32760 : SENT_, MATCH = DEF ? 5 : MATCH_, MISMATCH = DEF ? -4 : MISMATCH_, GAP = DEF ? -8 : GAP_;
+  if (LEAN) {
+    // steady state as in k_nw_ad: out-of-band cells are pushed AD_OOB below the band by their own gap addend gs[c]
+    // (GAP in band) instead of being reset to the sentinel, and the three-way maximum is one v_max3
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const int c = 2 * m + PAR;
+      const int left_src = PAR ? d[c - 1] : (m == 0 ? nb : d[c - 1]);
+      const int up_src = PAR ? (m == 3 ? nb : d[c + 1]) : d[c + 1];
+      const int diag = d[c] + (((x >> (8 * m)) & 0xFFu) == 0 ? MATCH : MISMATCH);
+      const int left = left_src + gs[c], up = up_src + gs[c];
+      int e;
+      asm("v_max3_i32 %0, %1, %2, %3" : "=v"(e) : "v"(left), "v"(diag), "v"(up));
+      const bool t1 = left >= diag, t2 = up == e;            // up >= max(left, diag)  <=>  the maximum IS up
+      d[c] = e;
+      pw[m] |= (t2 ? 3u : (t1 ? 2u : 1u)) << fs;
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     const int c = 2 * m + PAR;
@@ -1100,7 +1119,7 @@ static __device__ __forceinline__ void adw_step(int (&d)[8], uint32_t (&pw)[4], 
 }
 
 template <int GL, bool DEF>
-__global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
+__global__ __launch_bounds__(256, 3) void k_nw_adw(NwArgs a, AdwGeom G) {
   constexpr int APW = 64 / GL;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double *s_err = s_dyn;
@@ -1156,6 +1175,9 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
       uint32_t kmask = 0;
       if (!ghost)
         for (int q = 0; q < 8; q++) kmask |= (uint32_t)(8 * g + q >= sft && 8 * g + q < W + sft) << q;
+      int gs[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) gs[q] = ((kmask >> q) & 1u) ? (DEF ? -8 : GAP) : AD_OOB;
       const bool g_first = g == 0, g_last = ghost || g == GL - 1;
       int I = (lbs >> 1) - 4 * g, J = -I;
       uint32_t cwin = 0, rwin = 0;
@@ -1177,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
     const uint32_t nxt = rbytes[J + 3];                                                                                  \
     int nb = __builtin_amdgcn_update_dpp(SENT, d[7], 0x138, 0xF, 0xF, false);   /* lane-1's last cell (wave_shr:1) */    \
     if (g_first) nb = SENT;                                                                                              \
-    adw_step<0, LEANV, DEF>(d, pw, (FS), cwin ^ rwin, nb, kmask, I, J, L1, L2, SENT, MATCH, MISMATCH, GAP);              \
+    adw_step<0, LEANV, DEF>(d, pw, (FS), cwin ^ rwin, nb, kmask, gs, I, J, L1, L2, SENT, MATCH, MISMATCH, GAP);              \
     rwin = (rwin >> 8) | (nxt << 24);                                                                                    \
   }
 #define ADW_ODD(LEANV, FS)                                                                                               \
@@ -1185,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_nw_adw(NwArgs a, AdwGeom G) {
     const uint32_t nxt = cbytes[I];                                                                                      \
     int nb = __builtin_amdgcn_update_dpp(SENT, d[0], 0x130, 0xF, 0xF, false);   /* lane+1's first cell (wave_shl:1) */   \
     if (g_last) nb = SENT;                                                                                               \
-    adw_step<1, LEANV, DEF>(d, pw, (FS), cwin ^ rwin, nb, kmask, I, J + 1, L1, L2, SENT, MATCH, MISMATCH, GAP);          \
+    adw_step<1, LEANV, DEF>(d, pw, (FS), cwin ^ rwin, nb, kmask, gs, I, J + 1, L1, L2, SENT, MATCH, MISMATCH, GAP);          \
     cwin = (cwin << 8) | nxt;                                                                                            \
     I++; J++;                                                                                                            \
   }

@@ -109,15 +109,20 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
     uint32_t h = 0, best_h = 0;
     int head = -1, hcnt = 3, apos = 0, pos = 0, from = 0, to = 0;
     if (r < N) {
+      // everything the common cases need is requested up front, independent of one another: ONE memory round trip instead
+      // of a chain of three (the kernel is latency-bound; by the later rounds most uniques hold a second comparison)
       const int i1 = T.i1[r];
-      head = i1 >= 0 ? T.head[r] : -1;                                   // (a chain only exists behind a used second entry)
+      const int head_raw = T.head[r];
+      const double lam0_r = T.lam0[r], lam1_r = T.lam1[r];
       from = P.clust_of[r];
+      const uint8_t cl = STORE ? E.cls[r] : (uint8_t)0;
+      const double l_raw = STORE ? E.lam[r] : 0.0, em = STORE ? P.E_minmax[r] : 0.0;
+      const uint32_t h_raw = STORE ? E.ham[r] : 0u;
+      head = i1 >= 0 ? head_raw : -1;                                    // (a chain only exists behind a used second entry)
       if (STORE) {
-        const uint8_t cl = E.cls[r];
         if (cl >= CLS_GAPLESS) {
-          l = E.lam[r]; h = E.ham[r];
+          l = l_raw; h = h_raw;
           if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);        // "Lambda out-of-range error." (cluster.cpp:184)
-          const double em = P.E_minmax[r];
           keep = l * E.total_reads > em;                               // this partition could attract this unique
           if (keep) {
             my_keep++;
@@ -131,10 +136,10 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
       const CompBlk *best_cb = nullptr;
       int best_k = 0;
       if (i1 >= 0 || keep) {
-        best_l = T.lam0[r];
+        best_l = lam0_r;
         double best_e = best_l * reads_0;
         if (i1 >= 0) {
-          const double nl = T.lam1[r], e = nl * rd_at(i1);
+          const double nl = lam1_r, e = nl * rd_at(i1);
           if (e > best_e || (e == best_e && i1 < best_i)) { best_e = e; best_i = i1; best_l = nl; best_src = 1; }
         }
         for (int b = head, first = 1, hops = 0; b >= 0 && hops < (1 << 22); first = 0, hops++) {   // (bounded: never spin on a bad link)
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
       if (best_i != from && r != P.centre_of[from]) {
         move = true;
         to = best_i;
-        if (best_src == 0) { best_l = T.lam0[r]; best_h = T.ham0[r]; }
+        if (best_src == 0) { best_l = lam0_r; best_h = T.ham0[r]; }
         else if (best_src == 1) best_h = T.ham1[r];
         else if (best_src == 2) best_h = best_cb->ham[best_k];
         else best_h = h;

@@ -36,7 +36,7 @@ for s in $STEPS; do
              ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $P/pmc_valu -o valu -- $CMD > $P/pmc_valu.log 2>&1 )
              python3 profiles/summarize.py $P ${TAG}_cfg$CFG $OUT/summaries "python bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass" > $P/summarize.log 2>&1
              echo "$s done" >> $OUT/steps.log ;;
-    bench3t16|bench3t64) T=${s#bench3t}; DADA2HIP_HOST_THREADS=$T timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile-pass > $OUT/bench_cfg3_threads$T.json 2> $OUT/bench_cfg3_threads$T.err; echo "$s rc=$?" >> $OUT/steps.log; cut -c1-300 $OUT/bench_cfg3_threads$T.json ;;
+    bench3t16|bench3t64|bench3t128) T=${s#bench3t}; DADA2HIP_HOST_THREADS=$T timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile-pass > $OUT/bench_cfg3_threads$T.json 2> $OUT/bench_cfg3_threads$T.err; echo "$s rc=$?" >> $OUT/steps.log; cut -c1-300 $OUT/bench_cfg3_threads$T.json ;;
     sweep)   timeout 600 python tools/sweep_env.py --config 3 --reps 3 --list "${SWEEP:-}" > $OUT/sweep.jsonl 2> $OUT/sweep.err; echo "sweep rc=$?" >> $OUT/steps.log; cut -c1-420 $OUT/sweep.jsonl ;;
     wcal)    for m in store_bytes store_wide read_wide; do ( cd /tmp && timeout 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/wcal_${m}_W -o pmc -- $ROOT/tools/microbench $m 268435456 > $OUT/wcal_${m}_W.log 2>&1 )
                ( cd /tmp && timeout 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/wcal_${m}_F -o pmc -- $ROOT/tools/microbench $m 268435456 > $OUT/wcal_${m}_F.log 2>&1 ); done
