@@ -313,6 +313,7 @@ static __device__ __forceinline__ bool bud_candidate2(const Eng2 &E, int r, int 
 // k2_birth looks for the ties / near ties of the best key and for the likely next centres among those few, not among all
 // uniques.
 constexpr int SIG_CAP = 1024;
+constexpr int PUPD_TAB = 1024;    // partitions whose per-partition facts k2_pupdate keeps in LDS
 __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init, BudKey *__restrict__ partial) {
   const Ctl2 *ctl = E.ctl;
   if (ctl->state != 0) return;
@@ -322,26 +323,49 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   __shared__ BudKey s_k[2][4];
   __shared__ int32_t s_sig[SIG_CAP];
   __shared__ int s_nsig, s_sbase;
-  if (threadIdx.x == 0) s_nsig = 0;
-  __syncthreads();
+  // what a unique needs from ITS PARTITION (reads, update / lock flags, the centre and its reads) sits in LDS: the loads
+  // behind clust_of[r] were a chain of three global round trips per unique in a latency-bound kernel
+  __shared__ uint32_t s_prd[PUPD_TAB], s_cread[PUPD_TAB];
+  __shared__ int32_t s_cen[PUPD_TAB];
+  __shared__ uint8_t s_upd[PUPD_TAB], s_chk[PUPD_TAB];
   const PartState &P = E.P;
   const SampleDev &S = E.S;
+  const int ntab = min(ctl->nclust, PUPD_TAB);
+  for (int k = threadIdx.x; k < ntab; k += 256) {
+    const int c = P.centre_of[k];
+    s_prd[k] = reads_at(E, k, cs.nexec);
+    s_cen[k] = c;
+    s_cread[k] = S.reads[c];
+    s_upd[k] = P.update_e[k];
+    s_chk[k] = P.check_locks[k];
+  }
+  if (threadIdx.x == 0) s_nsig = 0;
+  __syncthreads();
   BudKey b0 = init, b1 = init;
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
     const int cl = P.clust_of[r];
     const double l = P.comp_lam[r];
     const uint32_t reads = S.reads[r];
+    const uint32_t ham = P.comp_ham[r];
+    const bool pr = S.prior[r] != 0;
+    const bool s0 = P.slot0[r] != 0;
     double p = P.p[r];
-    if (P.update_e[cl]) {
-      p = dev_get_pA(reads, S.prior[r] != 0, E.detect_singletons != 0, l, P.comp_ham[r], reads_at(E, cl, cs.nexec));
+    const bool intab = cl < ntab;
+    const uint32_t prd = intab ? s_prd[cl] : reads_at(E, cl, cs.nexec);
+    if (intab ? s_upd[cl] : P.update_e[cl]) {
+      p = dev_get_pA(reads, pr, E.detect_singletons != 0, l, ham, prd);
       P.p[r] = p;
     }
-    if (E.greedy && P.check_locks[cl]) {                                 // pval.cpp:29-36
-      const int c = P.centre_of[cl];
-      if ((S.reads[c] * l > reads) || r == c) P.lock[r] = 1;
+    if (E.greedy && (intab ? s_chk[cl] : P.check_locks[cl])) {          // pval.cpp:29-36
+      const int c = intab ? s_cen[cl] : P.centre_of[cl];
+      const uint32_t cr = intab ? s_cread[cl] : S.reads[c];
+      if ((cr * l > reads) || r == c) P.lock[r] = 1;
     }
-    if (!bud_candidate2(E, r, cs.nexec)) continue;
-    const bool pr = S.prior[r] != 0;
+    // bud_candidate2 with the values at hand
+    if (s0) continue;                                                    // r = 0 is skipped as "the centre" (cluster.cpp:285)
+    if (reads < (uint32_t)E.bp.min_abund) continue;
+    if ((int)ham < E.bp.min_hamming) continue;
+    if (!(E.bp.min_fold <= 1 || ((double)reads) >= E.bp.min_fold * l * prd)) continue;
     if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
     if (pr && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
     if (p * S.N < 2.0 * E.bp.omegaA || (pr && p < 2.0 * E.bp.omegaP)) {
