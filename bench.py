@@ -73,6 +73,10 @@ def make_inputs(cfg, args, rank):
     err = extend_err(tperr1, c.get("q_max", 40))
     kw = dict(L=L, G=G, Lmin=c.get("lmin"), q_hi=c.get("q_hi", 38.0), q_lo=c.get("q_lo", 22.0), q_max=c.get("q_max", 40),
               indel_rate=c.get("indel", 0.0), chunk=200_000 if L <= 500 else 20_000)
+    if getattr(args, "deep", False):
+        # the recipe of SURVEY.md §8d gives ~1.1 reads per unique (90 % singletons that can never bud); this variant draws the
+        # reads at Q34-40, which gives ~14 reads per unique and several times the partitions for the same number of uniques
+        kw.update(q_hi=40.0, q_lo=34.0, q_sd=2.0)
     dereps = []
     if c["samples"] == 1:
         dereps.append(make_sample(err, n, seed=20260925 + cfg + 1000 * rank, **kw))
@@ -108,6 +112,7 @@ def main():
     ap.add_argument("--cpu-full", action="store_true", help="time the reference on the WHOLE sample and check every output against the GPU's")
     ap.add_argument("--cpu-repeats", type=int, default=1)
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--deep", action="store_true", help="workload variant with >= 5 reads per unique (reads drawn at Q34-40)")
     args = ap.parse_args()
 
     import torch
@@ -231,7 +236,8 @@ def main():
             "dtype": "int32 DP + f64 lambda/p-value", "data": "synthetic",
             "timed_region": "dada2hip_dada_uniques boundary call: host inputs -> marshalling, H2D, k-mer build, all rounds, "
                             "final pass, tables, D2H of the six outputs" + ("; selfConsist loop incl. sample upload" if args.selfconsist else ""),
-            "config": {"workload": workload_name(args.config, d.nraw, L, band, c, args.selfconsist),
+            "config": {"workload": workload_name(args.config, d.nraw, L, band, c, args.selfconsist) +
+                                   (" [deep variant: reads drawn at Q34-40, %.1f reads per unique]" % (float(d.abundances.sum()) / d.nraw) if args.deep else ""),
                        "baseline_config": args.config, "uniques_per_sample": d.nraw, "samples_total": c["samples"],
                        "samples_this_rank": len(mine), "reads_per_sample": int(d.abundances.sum()), "partitions": res.nclust,
                        "comparisons": st["ncompare"], "nw": st["nnw"], "gapless": st["ngapless"],

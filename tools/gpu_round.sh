@@ -21,6 +21,7 @@ for s in $STEPS; do
     bench3full) timeout 1200 python bench.py --steps 5 --warmup 2 --cpu-full > $OUT/bench_cfg3_cpufull.json 2> $OUT/bench_cfg3_cpufull.err; echo "bench3full rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_cpufull.json ;;
     bench3sc) timeout 900 python bench.py --steps 2 --warmup 1 --selfconsist > $OUT/bench_cfg3_selfconsist.json 2> $OUT/bench_cfg3_selfconsist.err; echo "bench3sc rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_selfconsist.json ;;
     bench2)  timeout 600 python bench.py --config 2 --steps 10 --warmup 2 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; echo "bench2 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2.json ;;
+    bench2deep) timeout 1200 python bench.py --config 2 --deep --steps 3 --warmup 1 > $OUT/bench_cfg2_deep.json 2> $OUT/bench_cfg2_deep.err; echo "bench2deep rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2_deep.json ;;
     bench4)  timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; echo "bench4 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg4.json ;;
     bench5)  timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; echo "bench5 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg5.json ;;
     prof3|prof2)

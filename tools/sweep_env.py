@@ -28,7 +28,7 @@ def main():
     a = ap.parse_args()
     from dada2_amd import api
     from dada2_amd.opts import DadaOpts
-    args = types.SimpleNamespace(uniques=a.uniques, length=0, variants=0)
+    args = types.SimpleNamespace(uniques=a.uniques, length=0, variants=0, deep=False)
     dereps, inputs, err, mine, c = bench.make_inputs(a.config, args, 0)
     d = dereps[0]
     opts = DadaOpts(BAND_SIZE=c["band"])
