@@ -1026,6 +1026,8 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
 #undef D2_LAUNCH_AD
 }
 
+#include "nwpair.inc.hip"
+
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap) { return ad_geom(ap.band, S.maxlen, S.minlen).APW; }
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {

@@ -208,11 +208,50 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V2_DEPTH": "3"},
     {"DADA2HIP_V2_CHAIN": "1"},                           # one shuffle per chain: rounds continue through the host (H2_SHUFFLE_MORE)
     {"DADA2HIP_V2_CHAIN": "2", "DADA2HIP_NODE_CAP": "1"}, # comparison store starts at N + 16 blocks: growth through H2_CAPACITY
-], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow"])
+    {"DADA2HIP_NW_PACKED": "0"},                          # per-round alignments on k_nw_ad instead of the packed-pair kernel
+], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-unpacked"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
     20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""
     _run_cases_in_subprocess(env, _ALL, _SEEDED)
+
+
+@pytest.mark.parametrize("L,band,n", [(250, 16, 30000), (100, 16, 8000), (251, 8, 8000), (333, 18, 6000), (120, 1, 4000)])
+@pytest.mark.parametrize("packed", ["1", "0"])
+def test_packed_pair_aligner_matches_oracle(L, band, n, packed):
+    """k_nw_ad2 (two alignments per lane, packed int16) on equal-length samples of several lengths and bands against the C
+    restatement; the same cases through k_nw_ad."""
+    import subprocess, sys
+    code = (
+        "import sys\n"
+        "root = %r\n"
+        "sys.path[:0] = [root, root + '/tests']\n"
+        "from helpers import assert_results_equal, P_RTOL, tperr1\n"
+        "from dada2_amd import api\n"
+        "from dada2_amd.opts import DadaOpts\n"
+        "from dada2_amd.synth import make_sample\n"
+        "from oracle import cport\n"
+        "import numpy as np\n"
+        "from dada2_amd.io import Derep\n"
+        "d0 = make_sample(tperr1(), %d, L=%d + 3, G=64, seed=%d, chunk=20000, indel_rate=0.0006, ins_rate=0.0006)\n"
+        "Lt = %d\n"   # truncLen: reads with an insertion / deletion keep their shifted tail, all uniques end up Lt long
+        "first, ab = {}, {}\n"
+        "for k, sq in enumerate(d0.seqs):\n"
+        "    if len(sq) < Lt: continue\n"
+        "    t = sq[:Lt]\n"
+        "    first.setdefault(t, k); ab[t] = ab.get(t, 0) + int(d0.abundances[k])\n"
+        "keys = sorted(ab, key=lambda t: (-ab[t], first[t]))\n"
+        "d = Derep(keys, np.array([ab[t] for t in keys], dtype=np.int32), np.stack([d0.quals[first[t], :Lt] for t in keys]), np.zeros(0, np.int32))\n"
+        "assert len(set(map(len, d.seqs))) == 1 and d.abundances[0] >= d.abundances[1]\n"
+        "o = DadaOpts(BAND_SIZE=%d)\n"
+        "got = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)\n"
+        "want = cport.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)\n"
+        "assert_results_equal(got, want, p_rtol=P_RTOL)\n"
+        "assert got.nclust > 5 and got.stats['nnw'] > 100\n"
+        "print('ok', got.nclust, got.stats['nnw'])\n") % (ROOT, n, L, 9000 + L + band, L, band)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DADA2HIP_NW_PACKED=packed), capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 # ---- the RCCL path of the sample-sharded driver, real resident-sample runner, world_size 1 -------------------------------
