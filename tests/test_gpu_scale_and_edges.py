@@ -208,8 +208,8 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V2_DEPTH": "3"},
     {"DADA2HIP_V2_CHAIN": "1"},                           # one shuffle per chain: rounds continue through the host (H2_SHUFFLE_MORE)
     {"DADA2HIP_V2_CHAIN": "2", "DADA2HIP_NODE_CAP": "1"}, # comparison store starts at N + 16 blocks: growth through H2_CAPACITY
-    {"DADA2HIP_NW_PACKED": "0"},                          # per-round alignments on k_nw_ad instead of the packed-pair kernel
-], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-unpacked"])
+    {"DADA2HIP_NW_PACKED": "1"},                          # per-round alignments on the packed-pair kernel k_nw_ad2 (equal-length samples)
+], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-packed"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
     20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""
