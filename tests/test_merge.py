@@ -69,6 +69,49 @@ def test_helpers_match_the_reference_on_random_alignments(oracle_c, oracle_ref):
                 assert oracle_ref.pair_consensus(a1, a2, prefer, trim) == cport.pair_consensus(a1, a2, prefer, trim)
 
 
+def _call_merge(c, **kw):
+    import ctypes as C
+    from dada2_amd import _lib
+    L = _lib.lib()
+    NA = np.iinfo(np.int32).min
+    fwd = np.where(c["fwd"] > 0, c["fwd"], NA).astype(np.int32)
+    rev = np.where(c["rev"] > 0, c["rev"], NA).astype(np.int32)
+    aF = (C.c_char_p * len(c["seqsF"]))(*[s.encode() for s in c["seqsF"]])
+    aR = (C.c_char_p * len(c["seqsR"]))(*[s.encode() for s in c["seqsR"]])
+    eb = C.create_string_buffer(512)
+    h = C.c_void_p()
+    rc = L.dada2hip_merge_pairs(len(fwd), fwd.ctypes.data, rev.ctypes.data, len(c["seqsF"]), aF, c["n0F"].ctypes.data, len(c["seqsR"]), aR,
+                                c["n0R"].ctypes.data, kw.get("min_overlap", 12), kw.get("max_mismatch", 0), int(kw.get("trim_overhang", False)),
+                                int(kw.get("just_concatenate", False)), 0, C.byref(h), eb, 512)
+    if rc:
+        return rc, eb.value.decode(), None
+    n = L.dada2hip_mergers_nrow(h)
+    col = {k: np.ctypeslib.as_array(getattr(L, "dada2hip_mergers_" + k)(h), (n,)).copy() if n else np.zeros(0, np.int32)
+           for k in ("abundance", "forward", "reverse", "nmatch", "nmismatch", "nindel", "prefer", "accept")}
+    rows = [{"sequence": L.dada2hip_mergers_sequence(h, i).decode(), **{k: int(col[k][i]) for k in col}} for i in range(n)]
+    L.dada2hip_mergers_free(h)
+    for r in rows:
+        r["prefer"] = None if r["prefer"] == NA else r["prefer"]
+        r["accept"] = bool(r["accept"])
+    return 0, "", rows
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_host_side_of_merge_pairs_without_a_device(seed):
+    """What dada2hip_merge_pairs does on the host alone: the unique-pair bookkeeping and justConcatenate (no alignment, so no
+    device is needed), the reference's input check, and the empty case."""
+    c = make_case(seed)
+    rc, msg, rows = _call_merge(c, just_concatenate=True)
+    assert rc == 0, msg
+    assert_rows_equal(rows, golden_rows(seed, "concat"))
+    bad = dict(c, fwd=np.where(c["fwd"] > 0, c["fwd"] + 100, c["fwd"]).astype(np.int32))
+    rc, msg, _ = _call_merge(bad, just_concatenate=True)
+    assert rc == 1 and "Non-corresponding derep-class and dada-class objects." in msg
+    none = dict(c, fwd=np.full_like(c["fwd"], -1))
+    rc, msg, rows = _call_merge(none)
+    assert rc == 0 and rows == []
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1, 2, 3])
 @pytest.mark.parametrize("name", sorted(OPTION_SETS))
