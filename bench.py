@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-uniques", type=int, default=0, help="prefix of the sample timed on the CPU (0 = auto, bounded)")
     ap.add_argument("--cpu-full", action="store_true", help="time the reference on the WHOLE sample and check every output against the GPU's")
-    ap.add_argument("--cpu-repeats", type=int, default=1)
+    ap.add_argument("--cpu-repeats", type=int, default=3, help="timed repetitions of the all-core reference run (best is reported)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the selfconsist / secondary_workload sub-records of the default line")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--deep", action="store_true", help="workload variant with >= 5 reads per unique (reads drawn at Q34-40)")
     args = ap.parse_args()
@@ -227,7 +228,22 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline and world == 1 and not args.selfconsist:
-            cpu = cpu_baseline(d, err, opts, args, res)
+            cpu = cpu_baseline(d, err, opts, args, res, gpu_cmp_per_s=st["ncompare"] * len(inputs) * world * args.steps / dt)
+
+        # ---- sub-records of the default line: BASELINE configs[2]'s selfConsist loop on this very sample, and a workload
+        #      whose comparisons are NOT 98 % shrouded (28 reads per unique) --------------------------------------------
+        secondary = None
+        if args.config == 3 and world == 1 and not args.selfconsist and not args.no_extras and not args.deep:
+            tm = []
+            t_sc = time.perf_counter()
+            res_sc, err_sc, errs_sc = api.dada(dereps[0], None, self_consist=True, opts=opts, device=local, timings=tm,
+                                               host_input=inputs[0])
+            sc_info = {"what": "BASELINE.json configs[2]: learnErrors-style selfConsist loop on the bench sample (err from all-ones with "
+                               "MAX_CLUST=1, noqualErrfun refit per pass, resident sample; R/dada.R:256-405)",
+                       "passes": len(tm) - 1, "ms_create": tm[0], "ms_per_pass": tm[1:], "ms_total": (time.perf_counter() - t_sc) * 1e3,
+                       "partitions_last": res_sc.nclust, "converged": bool(any(np.array_equal(e, err_sc) for e in errs_sc)),
+                       "uniques_per_s_whole_loop": d.nraw / (time.perf_counter() - t_sc)}
+            secondary = secondary_workload(api, opts, local, args)
 
         out = {
             "metric": "unique reads denoised/sec (dada() wall-clock)", "value": value, "unit": "uniques/s",
@@ -248,6 +264,7 @@ def main():
             "cpu_baseline": cpu,
             "resident": resident,
             "selfconsist": sc_info,
+            "secondary_workload": secondary,
             "phases_ms_last_step": phases(st, pst if prof else None),
             "comparisons_per_s": st["ncompare"] * len(inputs) * world * args.steps / dt,
             "gen_s": t_gen,
@@ -295,7 +312,7 @@ def rooflines(st, L, band, cfg):
                "achieved": nw_ops / (nw_ms * 1e-3) / 1e12 if nw_ms > 0 else 0.0, "peak": PEAK_VALU_TOPS, "unit": "Tops/s",
                "traffic": None, "avg_launch_ms": nw_ms / nw_n, "launches": st["nw_kernel_launches"], "kernel_ms": nw_ms,
                "timing": timing, "algorithmic_ops_per_launch": nw_ops / nw_n}
-    roof_sc = {"kernel": "k_screen (k-mer screen)", "bound": "hbm",
+    roof_sc = {"kernel": "k2_screen_multi (k-mer screen of every unique against <= 8 centres per pass; round 0: k_screen)", "bound": "hbm",
                "achieved": screen_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                "traffic": None, "avg_launch_ms": sc_ms / sc_n, "launches": st["screen_kernel_launches"], "kernel_ms": sc_ms,
                "timing": timing, "algorithmic_bytes_per_launch": screen_bytes / sc_n}
@@ -361,7 +378,46 @@ def load_traffic(cfg):
     return t
 
 
-def cpu_baseline(d, err, opts, args, gpu_res):
+def secondary_workload(api, opts, local, args):
+    """A second workload in the same line: BASELINE configs[1]'s 100 k uniques drawn at Q34-40 (28 reads per unique; the
+    survey recipe gives 1.1), where a third of the comparisons survive the k-mer screen instead of 1.7 %."""
+    from types import SimpleNamespace
+    a2 = SimpleNamespace(uniques=0, length=0, variants=0, deep=True)
+    t0 = time.time()
+    dereps, inputs, err, _, c = make_inputs(2, a2, 0)
+    gen_s = time.time() - t0
+    d = dereps[0]
+    r = api.dada_uniques(inputs[0], None, None, err, None, opts, device=local)   # warm-up
+    nst = 3
+    t0 = time.perf_counter()
+    for _ in range(nst):
+        r = api.dada_uniques(inputs[0], None, None, err, None, opts, device=local)
+    dt = (time.perf_counter() - t0) / nst
+    st = r.stats
+    smp = api.Sample(inputs[0], None, None, None, device=local)
+    smp.run(err, opts)
+    t0 = time.perf_counter()
+    smp.run(err, opts)
+    t_res = time.perf_counter() - t0
+    roof = None
+    if not args.no_profile_pass:
+        os.environ["DADA2HIP_PROFILE"] = "1"
+        pst = smp.run(err, opts).stats
+        del os.environ["DADA2HIP_PROFILE"]
+        roof, _ = rooflines(pst, 250, opts.BAND_SIZE, 2)
+        roof["traffic"] = None
+        roof.pop("traffic_source", None)
+    smp.close()
+    ncmp = st["ncompare"]
+    return {"workload": "%d unique 250-nt synthetic reads (BASELINE.json configs[1] size) drawn at Q34-40: %.1f reads per unique, "
+                        "tperr1 fixed error matrix, BAND_SIZE %d" % (d.nraw, float(d.abundances.sum()) / d.nraw, opts.BAND_SIZE),
+            "value": d.nraw / dt, "unit": "uniques/s", "ms_per_step": dt * 1e3, "steps": nst, "ms_resident_pass": t_res * 1e3,
+            "partitions": r.nclust, "comparisons": ncmp, "comparisons_per_s": ncmp / dt,
+            "shrouded_frac": st["nshroud"] / max(1, ncmp), "nw": st["nnw"], "gapless": st["ngapless"],
+            "greedy_skipped": st["nskipped"], "roofline_nw": roof, "gen_s": gen_s}
+
+
+def cpu_baseline(d, err, opts, args, gpu_res, gpu_cmp_per_s=None):
     """Reference C++ (oracle/_ref; falls back to the C restatement, kind 'port') on this box's host cores."""
     from oracle import ref, cport
     ncores = os.cpu_count() or 1
@@ -386,31 +442,52 @@ def cpu_baseline(d, err, opts, args, gpu_res):
         out.update(value=n1 / t1, seconds=t1, sample=f"first {n1} uniques of the bench sample, full dada_uniques, scalar C port")
         return out
     out["kind"] = "reference"
+    out["threading"] = ("the reference's own parallelFor call sites (b_compare_parallel, FinalSubsParallel) on a persistent worker "
+                        "pool (oracle/shim/RcppParallel.h + ref_capi.cpp), the stand-in for RcppParallel's TBB pool")
 
     packed = ref.pack_inputs(seqs, ab, None, err, q)     # marshalling outside the timed call, as for the GPU side
 
-    def timed(flavour):
+    def timed(flavour, nthreads, reps, sub=None):
         best, r = None, None
-        for _ in range(max(1, args.cpu_repeats)):
-            ref.set_threads(ncores)
+        for _ in range(max(1, reps)):
+            ref.set_threads(nthreads)
             cs = []
-            r = ref.dada_uniques(seqs, ab, None, err, q, opts, multithread=True, flavour=flavour, packed=packed, call_seconds=cs)
+            if sub is None:
+                r = ref.dada_uniques(seqs, ab, None, err, q, opts, multithread=True, flavour=flavour, packed=packed, call_seconds=cs)
+            else:
+                r = ref.dada_uniques(seqs[:sub], ab[:sub], None, err, q[:sub], opts, multithread=True, flavour=flavour, call_seconds=cs)
             best = cs[-1] if best is None else min(best, cs[-1])
         return best, r
 
-    t_all, r = timed("O2")
+    # thread-count sweep on a quarter of the sample (the memory-bound shuffles and the serial b_bud do not scale with cores)
+    cand = sorted({t for t in (32, 64, 128, 256, ncores) if t <= ncores} or {ncores})
+    nsw = n if n <= 20_000 else max(20_000, n // 4)
+    sweep = {}
+    for t in cand:
+        ts, _ = timed("O2", t, 1, sub=None if nsw == n else nsw)
+        sweep[str(t)] = nsw / ts
+    tbest = int(max(sweep, key=lambda k: sweep[k]))
+    out["sweep"] = {"uniques": nsw, "uniques_per_s_by_threads": sweep}
+    out["threads_best"] = tbest
+    out["cores_used"] = tbest
+
+    t_all, r = timed("O2", tbest, args.cpu_repeats)
     out.update(value=n / t_all, seconds=t_all, partitions=r.nclust, build="-O2 (R's default flags)", repeats=max(1, args.cpu_repeats),
                comparisons_per_s=n * r.nclust / t_all)
+    if gpu_cmp_per_s:
+        out["gpu_comparisons_per_s"] = gpu_cmp_per_s
+        out["comparisons_per_s_ratio_gpu_over_cpu"] = gpu_cmp_per_s / out["comparisons_per_s"]
     if ref.available("O3"):
-        t3, r3 = timed("O3")
-        out["O3"] = {"value": n / t3, "seconds": t3, "build": "-O3 -march=x86-64-v3"}
+        t3, r3 = timed("O3", tbest, 1)
+        out["O3"] = {"value": n / t3, "seconds": t3, "build": "-O3 -march=x86-64-v3", "comparisons_per_s": n * r3.nclust / t3}
     # single thread on a smaller prefix so the default run stays within minutes
     n1 = min(n, max(500, int(20_000 * (250.0 / max(L, 250)) ** 2)))   # ~5-20 s of scalar CPU work at any read length
     ref.set_threads(1)
     cs = []
     r1 = ref.dada_uniques(seqs[:n1], ab[:n1], None, err, q[:n1], opts, multithread=False, call_seconds=cs)
     t1 = cs[-1]
-    out["single_thread"] = {"value": n1 / t1, "seconds": t1, "sample_uniques": n1, "partitions": r1.nclust}
+    out["single_thread"] = {"value": n1 / t1, "seconds": t1, "sample_uniques": n1, "partitions": r1.nclust,
+                            "comparisons_per_s": n1 * r1.nclust / t1}
     if n == d.nraw:   # same input as the GPU run: EVERY output compared (tests/helpers.assert_results_equal)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import assert_results_equal

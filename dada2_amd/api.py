@@ -363,8 +363,13 @@ def merge_pairs(dadaF: DadaResult, derepF: Derep, dadaR: DadaResult, derepR: Der
     L = _lib.lib()
     NA = np.iinfo(np.int32).min
     mF, mR = np.asarray(derepF.map, dtype=np.int64), np.asarray(derepR.map, dtype=np.int64)
-    if len(mF) != len(mR) or (len(mF) and (mF.max() >= len(dadaF.map) or mR.max() >= len(dadaR.map))):
-        raise _lib.Dada2HipError(1, "Non-corresponding derep-class and dada-class objects.")     # paired.R:113-117
+    # paired.R:115-119: the maps must be as long as each other and their largest entry (1-based there, 0-based here) must
+    # name the LAST unique of the dada-class object - equality, not just "in range"
+    def _max_ok(m, n):
+        ok = m[m >= 0]
+        return ok.size > 0 and int(ok.max()) + 1 == n
+    if len(mF) != len(mR) or not _max_ok(mF, len(dadaF.map)) or not _max_ok(mR, len(dadaR.map)):
+        raise _lib.Dada2HipError(1, "Non-corresponding derep-class and dada-class objects.")
     def denoised(dmap, rmap):
         dm = np.asarray(dmap, dtype=np.int64)
         out = np.full(len(rmap), NA, dtype=np.int32)
@@ -436,13 +441,15 @@ def noqual_errfun(trans, pseudocount=1):
 
 
 def dada(dereps, err=None, *, self_consist=False, err_fun=noqual_errfun, opts: DadaOpts = None, priors=None,
-         device: int = 0, verbose=False, samples=None, timings: list = None, host_input=None):
+         device: int = 0, verbose=False, samples=None, timings: list = None, host_input=None, on_pass=None):
     """The sample loop and selfConsist loop of R/dada.R:256-405 over resident samples.
 
     ``err_fun`` maps the accumulated 16 x Q transition counts to a new error matrix; the
     reference's default is ``loessErrfun`` (stats::loess, third-party, not available here) so the
     deterministic ``noqualErrfun`` stands in.  Returns (list[DadaResult], err_out,
-    list of err matrices tried)."""
+    list of err matrices tried).  ``on_pass(k, errs_used, max_clust, results)`` is called after every pass with the
+    error matrix each sample was run with (the all-ones start of R/dada.R:298 included) - the parity tests check every
+    pass of the loop through it, not just the last."""
     o = (opts or DadaOpts()).normalised()
     single = isinstance(dereps, Derep)
     if single:
@@ -464,14 +471,17 @@ def dada(dereps, err=None, *, self_consist=False, err_fun=noqual_errfun, opts: D
         while True:
             if nconsist > 0:
                 errs.append(np.array(err, copy=True))
-            results = []
+            results, used = [], []
             t_pass = time.perf_counter()
             for d, smp in zip(dereps, samples):
                 qmax = int(np.ceil(np.nanmax(d.quals)))
                 erri = np.ones((16, max(41, qmax + 1))) if initialize else extend_err(err, qmax)   # R/dada.R:297-313
                 results.append(smp.run(erri, o, max_clust=1 if initialize else None, verbose=verbose))
+                used.append(erri)
             if timings is not None:
                 timings.append((time.perf_counter() - t_pass) * 1e3)
+            if on_pass is not None:
+                on_pass(len(errs) if not initialize else 0, used, 1 if initialize else None, results)
             cur = accumulate_trans([r.subqual for r in results])
             new_err = err_fun(cur) if err_fun is not None else None
             if initialize:

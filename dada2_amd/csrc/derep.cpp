@@ -55,6 +55,7 @@ struct LineReader {
   std::condition_variable cv;
   std::deque<std::vector<char>> ready;
   bool done = false, stop = false;
+  std::string zerr;               // non-empty: the stream ended on a zlib error (corrupt / truncated .gz), not at EOF
   std::vector<char> buf;
   size_t pos = 0, end = 0;
   bool eof = false;
@@ -64,7 +65,13 @@ struct LineReader {
         std::vector<char> piece(PIECE);
         const int got = gzread(f, piece.data(), (unsigned)PIECE);
         std::unique_lock<std::mutex> lk(mu);
-        if (got <= 0) { done = true; cv.notify_all(); return; }
+        if (got <= 0) {
+          // gzread returns 0 at a clean end of file AND at a stream cut short; -1 on a data / CRC error: ask gzerror
+          int zrc = Z_OK;
+          const char *zm = gzerror(f, &zrc);
+          if (got < 0 || (zrc != Z_OK && zrc != Z_STREAM_END)) zerr = zm && *zm ? zm : "read error";
+          done = true; cv.notify_all(); return;
+        }
         piece.resize((size_t)got);
         ready.push_back(std::move(piece));
         cv.notify_all();
@@ -95,6 +102,7 @@ struct LineReader {
     buf.swap(nb); pos = 0; end = buf.size();
     return true;
   }
+  std::string error() { std::lock_guard<std::mutex> lk(mu); return zerr; }
   // next line without its terminator as [*p, *p + *n); valid until the next call; false at EOF
   bool next(const char **p, size_t *n) {
     for (;;) {
@@ -148,8 +156,8 @@ void set_err(char *errbuf, size_t errlen, const char *m) {
 
 extern "C" {
 
-int dada2hip_derep_fastq(const char *path, int64_t chunk_reads, int32_t qual_offset, dada2hip_derep **out, char *errbuf,
-                         size_t errlen) {
+static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_offset, dada2hip_derep **out, char *errbuf,
+                            size_t errlen) {
   if (out) *out = nullptr;
   if (!path || !out) { set_err(errbuf, errlen, "File paths must be provided in character format."); return DADA2HIP_ERR_INPUT; }
   gzFile f = gzopen(path, "rb");
@@ -190,7 +198,9 @@ int dada2hip_derep_fastq(const char *path, int64_t chunk_reads, int32_t qual_off
     if (ok) s.assign(sp, sn);   // the window may move under the next two lines
     ok = ok && in.next(&pp, &pn) && pn > 0 && pp[0] == '+' && in.next(&qp, &qn) && qn == s.size();
     if (!ok) {
-      set_err(errbuf, errlen, "dada2hip: malformed FASTQ record");
+      const std::string ze = in.error();   // a record cut short by a damaged stream is a read error, not a format error
+      if (!ze.empty()) set_err(errbuf, errlen, ("dada2hip: error reading " + std::string(path) + ": " + ze).c_str());
+      else set_err(errbuf, errlen, "dada2hip: malformed FASTQ record");
       rc = DADA2HIP_ERR_INPUT;
       break;
     }
@@ -221,6 +231,13 @@ int dada2hip_derep_fastq(const char *path, int64_t chunk_reads, int32_t qual_off
     if (in_chunk >= chunk_reads) end_chunk();
   }
   if (rc != DADA2HIP_OK) return rc;
+  {
+    const std::string ze = in.error();
+    if (!ze.empty()) {   // never hand back a silently truncated object
+      set_err(errbuf, errlen, ("dada2hip: error reading " + std::string(path) + ": " + ze).c_str());
+      return DADA2HIP_ERR_INPUT;
+    }
+  }
   end_chunk();
   if (store.empty()) { set_err(errbuf, errlen, "Only zero-length sequences detected during dereplication."); return DADA2HIP_ERR_INPUT; }
   if (offset <= 0) offset = 33;
@@ -258,13 +275,29 @@ int dada2hip_derep_fastq(const char *path, int64_t chunk_reads, int32_t qual_off
   return DADA2HIP_OK;
 }
 
+// no exception crosses the C ABI (include/dada2hip.h): allocation failures and thread errors become error codes
+int dada2hip_derep_fastq(const char *path, int64_t chunk_reads, int32_t qual_offset, dada2hip_derep **out, char *errbuf,
+                         size_t errlen) {
+  try {
+    return derep_fastq_body(path, chunk_reads, qual_offset, out, errbuf, errlen);
+  } catch (const std::bad_alloc &) {
+    set_err(errbuf, errlen, "dada2hip: out of host memory during dereplication");
+  } catch (const std::exception &e) {
+    set_err(errbuf, errlen, (std::string("dada2hip: ") + e.what()).c_str());
+  } catch (...) {
+    set_err(errbuf, errlen, "dada2hip: unknown error during dereplication");
+  }
+  if (out) *out = nullptr;
+  return DADA2HIP_ERR_RUNTIME;
+}
+
 int32_t dada2hip_derep_nuniques(const dada2hip_derep *d) { return d ? (int32_t)d->seqs.size() : 0; }
 int64_t dada2hip_derep_nreads(const dada2hip_derep *d) { return d ? d->nreads : 0; }
 int32_t dada2hip_derep_maxlen(const dada2hip_derep *d) { return d ? d->maxlen : 0; }
-const char *const *dada2hip_derep_seqs(const dada2hip_derep *d) { return d->seq_ptrs.data(); }
-const int32_t *dada2hip_derep_abundances(const dada2hip_derep *d) { return d->abund.data(); }
-const double *dada2hip_derep_quals(const dada2hip_derep *d) { return d->quals.get(); }
-const int32_t *dada2hip_derep_map(const dada2hip_derep *d) { return d->map.data(); }
+const char *const *dada2hip_derep_seqs(const dada2hip_derep *d) { return d ? d->seq_ptrs.data() : nullptr; }
+const int32_t *dada2hip_derep_abundances(const dada2hip_derep *d) { return d ? d->abund.data() : nullptr; }
+const double *dada2hip_derep_quals(const dada2hip_derep *d) { return d ? d->quals.get() : nullptr; }
+const int32_t *dada2hip_derep_map(const dada2hip_derep *d) { return d ? d->map.data() : nullptr; }
 void dada2hip_derep_free(dada2hip_derep *d) { delete d; }
 
 int dada2hip_sample_from_derep(const dada2hip_derep *d, const uint8_t *priors, int32_t device, dada2hip_sample **out, char *errbuf,

@@ -1857,7 +1857,7 @@ int dada2hip_sample_set_priors(dada2hip_sample *s, const uint8_t *priors, char *
 void dada2hip_sample_free(dada2hip_sample *s) {
   if (!s) return;
   if (s->stream) { (void)hipSetDevice(s->device); (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
-  if (s->side) (void)hipStreamDestroy(s->side);
+  if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }   // (its buffers return to the allocation cache)
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;

@@ -7,88 +7,124 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include <hip/hip_runtime.h>
 
 namespace d2 {
 
 // ---- worker pool ---------------------------------------------------------------------------------
+// Workers are spawned once per PROCESS: a fork()ed child (Python multiprocessing's default start method, R's
+// parallel::mclapply) inherits the pool object but none of its threads, so the pool remembers the pid it spawned in
+// and rebuilds itself in a child.  A piece that throws stops the job and the exception is rethrown in the caller;
+// a parallel_for issued from inside a piece runs inline.
 class HostPool {
  public:
   static HostPool &get() {
-    static HostPool p;
-    return p;
+    static HostPool *p = new HostPool();   // leaked on purpose: no join at static destruction (a forked child has no threads to join)
+    return *p;
   }
   int nthreads() const { return nthreads_; }
   // f(lo, hi) over [0, n) in pieces of `grain`; the caller takes part, returns when all pieces are done
   void run(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f) {
     if (n == 0) return;
     if (grain == 0) grain = 1;
-    if (nthreads_ <= 1 || n <= grain) { f(0, n); return; }
-    std::unique_lock<std::mutex> job_lock(job_mu_);   // one job at a time
+    if (nthreads_ <= 1 || n <= grain || in_job()) { f(0, n); return; }
+    if (getpid() != pid_) respawn_after_fork();
+    std::unique_lock<std::mutex> job_lock(S->job_mu);   // one job at a time
     {
-      std::lock_guard<std::mutex> g(mu_);
-      fn_ = &f; n_ = n; grain_ = grain; next_.store(0); pending_ = (int)workers_.size(); gen_++;
+      std::lock_guard<std::mutex> g(S->mu);
+      fn_ = &f; n_ = n; grain_ = grain; next_.store(0); pending_ = (int)S->workers.size(); failed_.store(false); exc_ = nullptr;
+      gen_++;
     }
-    cv_.notify_all();
+    S->cv.notify_all();
     work();
-    std::unique_lock<std::mutex> l(mu_);
-    done_cv_.wait(l, [&] { return pending_ == 0; });
-    fn_ = nullptr;
+    {
+      std::unique_lock<std::mutex> l(S->mu);
+      S->done_cv.wait(l, [&] { return pending_ == 0; });
+      fn_ = nullptr;
+    }
+    if (exc_) { std::exception_ptr e = exc_; exc_ = nullptr; std::rethrow_exception(e); }
   }
 
  private:
+  // everything that cannot survive a fork lives behind one pointer and is simply abandoned in the child
+  struct Sync {
+    std::vector<std::thread> workers;
+    std::mutex mu, job_mu;
+    std::condition_variable cv, done_cv;
+  };
   HostPool() {
     int n = (int)std::thread::hardware_concurrency();
     if (n <= 0) n = 1;
     if (n > 64) n = 64;                                  // memory-bound copies: 16 / 32 / 64 threads = 55 / 34 / 25 ms for the 1M-unique upload (profiles/r02q_bench_cfg3_threads*.json)
     if (const char *e = getenv("DADA2HIP_HOST_THREADS")) n = std::max(1, atoi(e));
     nthreads_ = n;
-    for (int i = 1; i < n; i++) workers_.emplace_back([this] { loop(); });
+    spawn();
   }
-  ~HostPool() {
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      stop_ = true; gen_++;
-    }
-    cv_.notify_all();
-    for (auto &t : workers_) t.join();
+  void spawn() {
+    S = new Sync();
+    pid_ = getpid();
+    stop_ = false; pending_ = 0; fn_ = nullptr;
+    // workers start from the generation of their birth: a respawned pool must not replay the parent's last job
+    for (int i = 1; i < nthreads_; i++) S->workers.emplace_back([this, g0 = gen_] { loop(g0); });
   }
+  void respawn_after_fork() {
+    static std::mutex fork_mu;
+    std::lock_guard<std::mutex> g(fork_mu);
+    if (getpid() == pid_) return;
+    // the parent's Sync (thread handles of threads this process never had, mutexes in whatever state they were forked
+    // in) is leaked, not destroyed: ~thread on a joinable handle would terminate the process
+    spawn();
+  }
+  static bool &in_job() { static thread_local bool v = false; return v; }
   void work() {
+    in_job() = true;
     for (;;) {
       const size_t lo = next_.fetch_add(grain_);
       if (lo >= n_) break;
-      (*fn_)(lo, std::min(n_, lo + grain_));
+      if (failed_.load(std::memory_order_relaxed)) continue;   // drain the remaining pieces without running them
+      try {
+        (*fn_)(lo, std::min(n_, lo + grain_));
+      } catch (...) {
+        std::lock_guard<std::mutex> g(S->mu);
+        if (!exc_) exc_ = std::current_exception();
+        failed_.store(true);
+      }
     }
+    in_job() = false;
   }
-  void loop() {
-    uint64_t seen = 0;
+  void loop(uint64_t seen) {
+    Sync *my = S;
     for (;;) {
       {
-        std::unique_lock<std::mutex> l(mu_);
-        cv_.wait(l, [&] { return gen_ != seen; });
+        std::unique_lock<std::mutex> l(my->mu);
+        my->cv.wait(l, [&] { return gen_ != seen; });
         seen = gen_;
         if (stop_) return;
       }
       work();
       {
-        std::lock_guard<std::mutex> g(mu_);
-        if (--pending_ == 0) done_cv_.notify_all();
+        std::lock_guard<std::mutex> g(my->mu);
+        if (--pending_ == 0) my->done_cv.notify_all();
       }
     }
   }
   int nthreads_ = 1;
-  std::vector<std::thread> workers_;
-  std::mutex mu_, job_mu_;
-  std::condition_variable cv_, done_cv_;
+  pid_t pid_ = 0;
+  Sync *S = nullptr;
   const std::function<void(size_t, size_t)> *fn_ = nullptr;
   size_t n_ = 0, grain_ = 1;
   std::atomic<size_t> next_{0};
+  std::atomic<bool> failed_{false};
+  std::exception_ptr exc_ = nullptr;
   int pending_ = 0;
   uint64_t gen_ = 0;
   bool stop_ = false;
@@ -147,7 +183,10 @@ class AllocCache {
     if (it == dev_live_.end()) { (void)hipFree(p); return; }
     const Blk b = it->second;
     dev_live_.erase(it);
-    if (!enabled_ || dev_cached_ + b.cls > cap_) { (void)hipFree(p); return; }
+    // unwinding from an error (a timed-out wait, a failed launch): kernels that use this block may still be running, so it
+    // must not be handed to another call - hipFree synchronises the device first, the cache would not
+    if (std::uncaught_exceptions() > 0) { (void)hipDeviceSynchronize(); (void)hipFree(p); return; }
+    if (!enabled_ || dev_cached_ + b.cls > dev_cap()) { (void)hipFree(p); return; }
     dev_free_[b.dev].emplace(b.cls, p);
     dev_cached_ += b.cls;
   }
@@ -208,13 +247,21 @@ class AllocCache {
     if (const char *e = getenv("DADA2HIP_ALLOC_CACHE_GB")) cap_ = (size_t)atoll(e) << 30;
   }
   struct Blk { int dev; size_t cls; };
+  // cached device bytes are capped at a third of the device's memory (DADA2HIP_ALLOC_CACHE_GB overrides)
+  size_t dev_cap() {
+    if (cap_ == 0) {
+      size_t fr = 0, tot = 0;
+      cap_ = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? tot / 3 : ((size_t)32 << 30);
+    }
+    return cap_;
+  }
   std::mutex mu_;
   std::map<int, std::multimap<size_t, void *>> dev_free_;
   std::map<void *, Blk> dev_live_;
   std::multimap<size_t, void *> pin_free_;
   std::map<void *, size_t> pin_live_;
   size_t dev_cached_ = 0, pin_cached_ = 0;
-  size_t cap_ = (size_t)96 << 30, pin_cap_ = (size_t)8 << 30;   // of 288 GB HBM / host RAM
+  size_t cap_ = 0, pin_cap_ = (size_t)8 << 30;   // cap_ 0 = not yet derived from the device (dev_cap)
   bool enabled_ = true;
 };
 

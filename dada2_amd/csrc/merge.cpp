@@ -81,10 +81,10 @@ std::string pair_consensus(const std::string &s1, const std::string &s2, int pre
 
 extern "C" {
 
-int dada2hip_merge_pairs(int64_t nreads, const int32_t *fwd, const int32_t *rev, int32_t nF, const char *const *seqsF,
-                         const int32_t *n0F, int32_t nR, const char *const *seqsR, const int32_t *n0R, int32_t min_overlap,
-                         int32_t max_mismatch, int32_t trim_overhang, int32_t just_concatenate, int32_t device,
-                         dada2hip_mergers **out, char *errbuf, size_t errlen) {
+static int merge_pairs_body(int64_t nreads, const int32_t *fwd, const int32_t *rev, int32_t nF, const char *const *seqsF,
+                            const int32_t *n0F, int32_t nR, const char *const *seqsR, const int32_t *n0R, int32_t min_overlap,
+                            int32_t max_mismatch, int32_t trim_overhang, int32_t just_concatenate, int32_t device,
+                            dada2hip_mergers **out, char *errbuf, size_t errlen) {
   if (out) *out = nullptr;
   if (!out || nreads < 0 || (nreads > 0 && (!fwd || !rev)) || !seqsF || !seqsR || !n0F || !n0R) {
     set_err(errbuf, errlen, "dada2hip: merge_pairs needs the two read maps and both clustering tables.");
@@ -159,16 +159,37 @@ int dada2hip_merge_pairs(int64_t nreads, const int32_t *fwd, const int32_t *rev,
   return DADA2HIP_OK;
 }
 
+// no exception crosses the C ABI (include/dada2hip.h)
+int dada2hip_merge_pairs(int64_t nreads, const int32_t *fwd, const int32_t *rev, int32_t nF, const char *const *seqsF,
+                         const int32_t *n0F, int32_t nR, const char *const *seqsR, const int32_t *n0R, int32_t min_overlap,
+                         int32_t max_mismatch, int32_t trim_overhang, int32_t just_concatenate, int32_t device,
+                         dada2hip_mergers **out, char *errbuf, size_t errlen) {
+  try {
+    return merge_pairs_body(nreads, fwd, rev, nF, seqsF, n0F, nR, seqsR, n0R, min_overlap, max_mismatch, trim_overhang,
+                            just_concatenate, device, out, errbuf, errlen);
+  } catch (const std::bad_alloc &) {
+    set_err(errbuf, errlen, "dada2hip: out of host memory in merge_pairs");
+  } catch (const std::exception &e) {
+    set_err(errbuf, errlen, (std::string("dada2hip: ") + e.what()).c_str());
+  } catch (...) {
+    set_err(errbuf, errlen, "dada2hip: unknown error in merge_pairs");
+  }
+  if (out) *out = nullptr;
+  return DADA2HIP_ERR_RUNTIME;
+}
+
 int32_t dada2hip_mergers_nrow(const dada2hip_mergers *m) { return m ? (int32_t)m->abundance.size() : 0; }
-const char *dada2hip_mergers_sequence(const dada2hip_mergers *m, int32_t i) { return m->sequence[i].c_str(); }
-const int32_t *dada2hip_mergers_abundance(const dada2hip_mergers *m) { return m->abundance.data(); }
-const int32_t *dada2hip_mergers_forward(const dada2hip_mergers *m) { return m->forward.data(); }
-const int32_t *dada2hip_mergers_reverse(const dada2hip_mergers *m) { return m->reverse.data(); }
-const int32_t *dada2hip_mergers_nmatch(const dada2hip_mergers *m) { return m->nmatch.data(); }
-const int32_t *dada2hip_mergers_nmismatch(const dada2hip_mergers *m) { return m->nmismatch.data(); }
-const int32_t *dada2hip_mergers_nindel(const dada2hip_mergers *m) { return m->nindel.data(); }
-const int32_t *dada2hip_mergers_prefer(const dada2hip_mergers *m) { return m->prefer.data(); }
-const int32_t *dada2hip_mergers_accept(const dada2hip_mergers *m) { return m->accept.data(); }
+const char *dada2hip_mergers_sequence(const dada2hip_mergers *m, int32_t i) {
+  return (m && i >= 0 && (size_t)i < m->sequence.size()) ? m->sequence[i].c_str() : nullptr;
+}
+const int32_t *dada2hip_mergers_abundance(const dada2hip_mergers *m) { return m ? m->abundance.data() : nullptr; }
+const int32_t *dada2hip_mergers_forward(const dada2hip_mergers *m) { return m ? m->forward.data() : nullptr; }
+const int32_t *dada2hip_mergers_reverse(const dada2hip_mergers *m) { return m ? m->reverse.data() : nullptr; }
+const int32_t *dada2hip_mergers_nmatch(const dada2hip_mergers *m) { return m ? m->nmatch.data() : nullptr; }
+const int32_t *dada2hip_mergers_nmismatch(const dada2hip_mergers *m) { return m ? m->nmismatch.data() : nullptr; }
+const int32_t *dada2hip_mergers_nindel(const dada2hip_mergers *m) { return m ? m->nindel.data() : nullptr; }
+const int32_t *dada2hip_mergers_prefer(const dada2hip_mergers *m) { return m ? m->prefer.data() : nullptr; }
+const int32_t *dada2hip_mergers_accept(const dada2hip_mergers *m) { return m ? m->accept.data() : nullptr; }
 void dada2hip_mergers_free(dada2hip_mergers *m) { delete m; }
 
 }  // extern "C"

@@ -1,15 +1,10 @@
-"""Producers of the hot path's input, restated host-side (no GPU work here).
+"""Host-side containers and helpers around the hot path's input (no GPU work here).
 
-The reference builds ``dada_uniques``' arguments in R:
-
-* ``derepFastq`` / ``qtables2``  (/root/reference/R/sequenceIO.R:45-124, :150-183):
-  uniques in C-locale lexical order (ShortRead ``srsort``), per-unique mean quality
-  (``derepQuals/derepCounts`` :95), then a *stable* sort by decreasing abundance (:98).
-* the bundled error matrices ``data/{tperr1,errBalancedF,errBalancedR}.rda``
-  (gzip'd RDX2/XDR; 16 x 41 doubles, rows A2A..T2T, columns Q0..Q40).
-
-ShortRead/Biostrings are R packages and are not available here, so these ~60 lines
-restate just what the parity tests and ``bench.py`` need to reproduce the same inputs.
+* ``Derep`` mirrors the R ``derep-class`` object that ``dada()`` consumes; the product's dereplicator is
+  ``dada2hip_derep_fastq`` (csrc/derep.cpp, reached through ``dada2_amd.api.derep_fastq``).  The Python restatement
+  of ``derepFastq`` that CHECKS it lives under ``oracle/derep.py`` (test infrastructure, not in this package).
+* the bundled error matrices ``data/{tperr1,errBalancedF,errBalancedR}.rda`` (gzip'd RDX2/XDR; 16 x 41 doubles, rows
+  A2A..T2T, columns Q0..Q40) and the two error-matrix helpers of R/dada.R and R/errorModels.R.
 """
 from __future__ import annotations
 
@@ -32,66 +27,6 @@ class Derep:
     @property
     def nraw(self) -> int:
         return len(self.seqs)
-
-
-def read_fastq(path: str):
-    """Minimal 4-line FASTQ reader -> (list[str] seqs, list[bytes] quals). Phred+33."""
-    op = gzip.open if str(path).endswith(".gz") else open
-    seqs, quals = [], []
-    with op(path, "rb") as fh:
-        while True:
-            h = fh.readline()
-            if not h:
-                break
-            s = fh.readline().rstrip(b"\r\n")
-            fh.readline()
-            q = fh.readline().rstrip(b"\r\n")
-            seqs.append(s.decode("ascii"))
-            quals.append(q)
-    return seqs, quals
-
-
-def derep_from_reads(seqs, quals_phred33, n: int = 10**6, offset: int = 33) -> Derep:
-    """qtables2 per chunk of ``n`` reads + derepFastq's merge and tail (sequenceIO.R:150-183, :57-101): inside a chunk
-    the new uniques are in C-locale lexical order, later chunks append theirs (:85-88)."""
-    order_seen, count, qsum = [], {}, {}
-    for c0 in range(0, len(seqs), n):
-        chunk = range(c0, min(c0 + n, len(seqs)))
-        fresh = sorted({seqs[i] for i in chunk if len(seqs[i]) > 0 and seqs[i] not in count})  # srsort: C-locale order
-        for s in fresh:
-            order_seen.append(s)
-            count[s] = 0
-            qsum[s] = np.zeros(len(s))
-        for i in chunk:
-            s = seqs[i]
-            if len(s) == 0:  # zero-length reads are ignored (:154-158)
-                continue
-            count[s] += 1
-            qsum[s] += np.frombuffer(quals_phred33[i], dtype=np.uint8).astype(np.float64) - float(offset)
-    if not order_seen:
-        raise ValueError("Only zero-length sequences detected during dereplication.")
-    uniq = order_seen
-    maxlen = max(len(s) for s in uniq)
-    counts = np.array([count[s] for s in uniq], dtype=np.int64)
-    cum = np.full((len(uniq), maxlen), np.nan)
-    for u, s in enumerate(uniq):
-        cum[u, : len(s)] = qsum[s]
-    mean = cum / counts[:, None]                      # derepQuals/derepCounts (:95)
-    order = np.argsort(-counts, kind="stable")        # order(derepCounts, decreasing=TRUE) (:98), stable
-    rank_of = np.empty(len(uniq), dtype=np.int64)
-    rank_of[order] = np.arange(len(uniq))
-    uidx = {s: u for u, s in enumerate(uniq)}
-    rmap = np.full(len(seqs), -1, dtype=np.int32)
-    for i, s in enumerate(seqs):
-        if len(s) > 0:
-            rmap[i] = rank_of[uidx[s]]
-    return Derep([uniq[u] for u in order], counts[order].astype(np.int32), mean[order], rmap)
-
-
-def derep_fastq(path: str, n: int = 10**6) -> Derep:
-    """Python restatement (the checker of dada2hip_derep_fastq; small files only)."""
-    s, q = read_fastq(path)
-    return derep_from_reads(s, q, n)
 
 
 TRANS_NAMES = [a + "2" + b for a in "ACGT" for b in "ACGT"]  # A2A, A2C, ..., T2T (R/dada.R:362)

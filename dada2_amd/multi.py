@@ -37,7 +37,7 @@ def allreduce_trans(local_trans: np.ndarray, maxcol: int, dist=None, device=None
 
 
 def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts = None, make_runner=None, dist=None,
-               device=None, max_col: int = None):
+               device=None, max_col: int = None, on_pass=None):
     """dada() over many samples, sharded across the ranks of ``dist``.
 
     ``dereps``       all samples (every rank sees the list; only its shard is touched)
@@ -66,13 +66,17 @@ def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts 
             if nconsist > 0:
                 errs.append(np.array(err, copy=True))
             local = np.zeros((16, maxcol), dtype=np.int64)
+            used = {}
             for i in mine:
                 d = dereps[i]
                 qmax = int(np.ceil(np.nanmax(d.quals)))
                 erri = np.ones((16, max(41, qmax + 1))) if initialize else extend_err(err, qmax)
                 results[i] = runners[i].run(erri, o, max_clust=1 if initialize else None)
+                used[i] = erri
                 t = results[i].subqual
                 local[:, : t.shape[1]] += t
+            if on_pass is not None:   # (tests: every pass of the loop is checked, not just the last)
+                on_pass(0 if initialize else len(errs), used, 1 if initialize else None, dict(results))
             cur = allreduce_trans(local, maxcol, dist, device)
             new_err = err_fun(cur)
             if initialize:

@@ -37,8 +37,93 @@ extern "C" {
 
 int dada2_shim_verbose = 0;
 int dada2_shim_nthreads = 1;
-void dada2_shim_set_threads(int n) { dada2_shim_nthreads = n < 1 ? 1 : n; }
 void dada2_shim_set_verbose(int v) { dada2_shim_verbose = v; }
+
+}  // extern "C"
+
+// ---- persistent worker pool behind the shim's parallelFor (what TBB is behind the real RcppParallel) ----------------
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <unistd.h>
+namespace {
+struct ShimPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  unsigned long gen = 0;
+  int pending = 0;
+  bool stop = false;
+  pid_t pid = 0;
+  // the job
+  std::atomic<std::size_t> next{0};
+  std::size_t end = 0, chunk = 1;
+  void (*fn)(void *, std::size_t, std::size_t) = nullptr;
+  void *ctx = nullptr;
+  void work() {
+    for (;;) {
+      const std::size_t b = next.fetch_add(chunk);
+      if (b >= end) break;
+      fn(ctx, b, std::min(end, b + chunk));
+    }
+  }
+  void loop(unsigned long seen) {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return gen != seen; });
+        seen = gen;
+        if (stop) return;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (--pending == 0) done_cv.notify_all();
+      }
+    }
+  }
+  void start(int nthreads) {
+    pid = getpid();
+    for (int t = 1; t < nthreads; t++) th.emplace_back([this, g0 = gen] { loop(g0); });
+  }
+  void shutdown() {
+    { std::lock_guard<std::mutex> g(mu); stop = true; gen++; }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+  }
+};
+ShimPool *g_pool = nullptr;
+std::mutex g_pool_mu;
+}  // namespace
+
+extern "C" {
+
+void dada2_shim_set_threads(int n) {
+  n = n < 1 ? 1 : n;
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  if (g_pool && (g_pool->pid != getpid())) g_pool = nullptr;   // forked child: the parent's threads are not ours (leaked)
+  if (g_pool && (int)g_pool->th.size() + 1 != n) { g_pool->shutdown(); delete g_pool; g_pool = nullptr; }
+  if (!g_pool && n > 1) { g_pool = new ShimPool(); g_pool->start(n); }
+  dada2_shim_nthreads = n;
+}
+
+void dada2_shim_parallel_for(std::size_t begin, std::size_t end, std::size_t chunk, void (*fn)(void *, std::size_t, std::size_t),
+                             void *ctx) {
+  ShimPool *p = nullptr;
+  { std::lock_guard<std::mutex> g(g_pool_mu); p = (g_pool && g_pool->pid == getpid()) ? g_pool : nullptr; }
+  if (!p) { if (end > begin) fn(ctx, begin, end); return; }
+  {
+    std::lock_guard<std::mutex> g(p->mu);
+    p->next.store(begin); p->end = end; p->chunk = chunk ? chunk : 1; p->fn = fn; p->ctx = ctx;
+    p->pending = (int)p->th.size();
+    p->gen++;
+  }
+  p->cv.notify_all();
+  p->work();
+  std::unique_lock<std::mutex> l(p->mu);
+  p->done_cv.wait(l, [&] { return p->pending == 0; });
+}
 
 // Same layout as include/dada2hip.h : dada2hip_opts (the scalars of Rmain.cpp:33-47;
 // doubles first so there is no padding: 5*8 + 18*4 = 112 bytes).

@@ -4,8 +4,8 @@
 // uses exactly two things (src/cluster.cpp:90,176; src/Rmain.cpp:179,222):
 // RcppParallel::Worker and RcppParallel::parallelFor(begin, end, worker, grain).
 // Per-index results are independent in both call sites, so chunking across
-// std::thread workers gives output identical to TBB's; the thread count is a
-// process global set through dada2_shim_set_threads() (1 = run inline).
+// pooled std::thread workers gives output identical to TBB's; the thread count
+// is a process global set through dada2_shim_set_threads() (1 = run inline).
 #ifndef DADA2_ORACLE_SHIM_RCPPPARALLEL_H
 #define DADA2_ORACLE_SHIM_RCPPPARALLEL_H
 
@@ -48,6 +48,12 @@ struct Worker {
   virtual void operator()(std::size_t begin, std::size_t end) = 0;
 };
 
+// The workers are a PERSISTENT pool (oracle/ref_capi.cpp: created by dada2_shim_set_threads, parked on a condition
+// variable between calls), as TBB's are behind the real RcppParallel: a run_dada of ~700 rounds issues ~700 parallelFor
+// calls, and spawning + joining 255 threads for each of them was most of the "all cores" wall time of the first shim.
+extern "C" void dada2_shim_parallel_for(std::size_t begin, std::size_t end, std::size_t chunk,
+                                        void (*fn)(void *, std::size_t, std::size_t), void *ctx);
+
 inline void parallelFor(std::size_t begin, std::size_t end, Worker &worker, std::size_t grainSize = 1) {
   std::size_t n = end > begin ? end - begin : 0;
   int nt = dada2_shim_nthreads;
@@ -57,18 +63,7 @@ inline void parallelFor(std::size_t begin, std::size_t end, Worker &worker, std:
   }
   // dynamic chunks of a few grains each, handed out through an atomic cursor
   std::size_t chunk = std::max<std::size_t>(grainSize, std::min<std::size_t>(256, n / (std::size_t)(8 * nt) + 1));
-  std::atomic<std::size_t> next(begin);
-  auto body = [&]() {
-    for (;;) {
-      std::size_t b = next.fetch_add(chunk);
-      if (b >= end) break;
-      worker(b, std::min(end, b + chunk));
-    }
-  };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; t++) th.emplace_back(body);
-  body();
-  for (auto &t : th) t.join();
+  dada2_shim_parallel_for(begin, end, chunk, [](void *w, std::size_t b, std::size_t e) { (*static_cast<Worker *>(w))(b, e); }, &worker);
 }
 
 }  // namespace RcppParallel

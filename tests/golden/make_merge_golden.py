@@ -33,7 +33,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "merge_pairs.npz"), **out)
     REF = "/root/reference/inst/extdata"
     if os.path.isdir(REF):
-        from dada2_amd.io import derep_fastq
+        from oracle.derep import derep_fastq
         maps = {}
         for fq in ("sam1F", "sam1R"):
             maps[fq] = derep_fastq(f"{REF}/{fq}.fastq.gz").map

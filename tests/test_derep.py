@@ -1,5 +1,8 @@
-"""The dereplication front-end (dada2hip_derep_fastq, host-side C++; R/sequenceIO.R:45-124, :150-183) against the Python
-restatement in dada2_amd/io.py and, where the reference's fixtures are on disk, against the committed golden inputs.
+"""The dereplication front-end (dada2hip_derep_fastq, host-side C++; R/sequenceIO.R:45-124, :150-183) against
+  * the CPU restatement under oracle/derep.py (test infrastructure; cites the reference line by line),
+  * the committed golden inputs (tests/golden/sam*.input.npz: sequences, abundances, INTEGER quality sums; sam1_maps.npz),
+  * facts that do not come from this repo's author at all: the unique counts SURVEY.md records for the reference's
+    fixtures, and coreutils `sort | uniq -c` run on the fixture files (sequences, abundances and the tie order).
 No GPU is involved: everything here runs in the CPU suite."""
 import gzip
 import os
@@ -7,7 +10,8 @@ import os
 import numpy as np
 import pytest
 
-from dada2_amd import api, io as dio
+from dada2_amd import api
+from oracle import derep as dio
 from dada2_amd._lib import Dada2HipError
 from helpers import load_input
 
@@ -98,15 +102,116 @@ def test_errors_of_the_reference_are_kept(tmp_path):
         api.derep_fastq(str(bad))
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_EXT), reason="reference fixtures not on this machine")
-@pytest.mark.parametrize("name", ["sam1F", "sam1R", "sam2F", "sam2R"])
+FIXTURES = ["sam1F", "sam1R", "sam2F", "sam2R", "samPB"]
+needs_fixtures = pytest.mark.skipif(not os.path.isdir(REF_EXT), reason="reference fixtures not on this machine")
+
+
+@needs_fixtures
+@pytest.mark.parametrize("name", FIXTURES)
 def test_reference_fixtures_give_the_golden_inputs(name):
+    """Byte for byte: sequences, abundances and the integer per-position quality sums the goldens hold (the means the
+    library returns are sum / abundance in fp64: comparing sums is the stricter test)."""
+    import numpy as np
+    from helpers import GOLDEN
     got = api.derep_fastq(f"{REF_EXT}/{name}.fastq.gz")
-    want = load_input(name)
-    assert got.seqs == list(want.seqs)
-    np.testing.assert_array_equal(got.abundances, want.abundances)
-    np.testing.assert_array_equal(np.nan_to_num(got.quals, nan=-1.0), np.nan_to_num(want.quals, nan=-1.0))
+    z = np.load(os.path.join(GOLDEN, name + ".input.npz"))
+    assert got.seqs == [str(s) for s in z["seqs"]]
+    np.testing.assert_array_equal(got.abundances, z["abundances"])
+    qsum = z["qsum"]
+    back = np.rint(np.nan_to_num(got.quals, nan=0.0) * got.abundances[:, None]).astype(np.int64)
+    back[np.isnan(got.quals)] = -1
+    want = qsum.astype(np.int64)
+    want[qsum < 0] = -1
+    np.testing.assert_array_equal(back, want)
+    # ... and the means are exactly the quotient the reference forms (sequenceIO.R:95)
+    want_mean = load_input(name).quals
+    np.testing.assert_array_equal(np.nan_to_num(got.quals, nan=-1.0), np.nan_to_num(want_mean, nan=-1.0))
     assert len(got.map) == int(got.abundances.sum())
+    if name in ("sam1F", "sam1R"):
+        np.testing.assert_array_equal(got.map, np.load(os.path.join(GOLDEN, "sam1_maps.npz"))[name])
+
+
+@needs_fixtures
+def test_known_unique_counts_of_the_reference_fixtures():
+    """SURVEY.md §4/§6 (from the reference's own documentation run): sam1F.fastq.gz holds 1 500 reads in 896 uniques."""
+    d = api.derep_fastq(f"{REF_EXT}/sam1F.fastq.gz")
+    assert d.nraw == 896 and int(d.abundances.sum()) == 1500 and len(d.map) == 1500
+
+
+@needs_fixtures
+@pytest.mark.parametrize("name", FIXTURES)
+def test_uniques_and_order_against_coreutils(name, tmp_path):
+    """An implementation nobody here wrote: `sort | uniq -c` in the C locale, then a stable sort by count, is exactly
+    derepFastq's order for a one-chunk file (srsort order inside equal abundances, sequenceIO.R:98,161)."""
+    import shutil
+    import subprocess
+    if not all(shutil.which(t) for t in ("sh", "zcat", "awk", "sort", "uniq")):
+        pytest.skip("coreutils not available")
+    cmd = (f"zcat {REF_EXT}/{name}.fastq.gz | awk 'NR % 4 == 2' | LC_ALL=C sort | LC_ALL=C uniq -c | "
+           "LC_ALL=C sort -s -k1,1nr")
+    out = subprocess.run(["sh", "-c", cmd], capture_output=True, text=True, check=True).stdout.split("\n")
+    rows = [ln.split() for ln in out if ln.strip()]
+    got = api.derep_fastq(f"{REF_EXT}/{name}.fastq.gz")
+    assert got.seqs == [r[1] for r in rows]
+    assert got.abundances.tolist() == [int(r[0]) for r in rows]
+
+
+def test_chunk_boundaries_with_phred64_detection(tmp_path):
+    """Phred+64 file read in chunks smaller than the file: the encoding is decided on the first chunk (derep.cpp) and the
+    uniques of later chunks are appended behind the earlier ones (sequenceIO.R:85-88)."""
+    seqs, quals = random_reads(11, 900, qlo=66, qhi=104, zero_every=53)
+    p = tmp_path / "old64.fastq.gz"
+    write_fastq(p, seqs, quals, gz=True)
+    for n in (13, 250, 899):
+        assert_same(api.derep_fastq(str(p), n=n), dio.derep_from_reads(seqs, quals, n=n, offset=64))
+
+
+def test_corrupt_gzip_is_an_error_not_a_short_result(tmp_path):
+    """A damaged .gz must fail loudly: never a silently truncated derep object, never a misleading 'zero-length' message."""
+    seqs, quals = random_reads(12, 4000)
+    p = tmp_path / "r.fastq.gz"
+    write_fastq(p, seqs, quals, gz=True)
+    raw = bytearray(p.read_bytes())
+    cut = tmp_path / "cut.fastq.gz"
+    cut.write_bytes(bytes(raw[: len(raw) // 2]))                 # truncated stream (no trailer)
+    with pytest.raises(Dada2HipError, match="error reading"):
+        api.derep_fastq(str(cut))
+    flipped = bytearray(raw)
+    for k in (len(raw) // 2, len(raw) // 2 + 1):
+        flipped[k] ^= 0xFF
+    bad = tmp_path / "flip.fastq.gz"
+    bad.write_bytes(bytes(flipped))
+    with pytest.raises(Dada2HipError):                            # data error or (if the damage decodes) a malformed record
+        api.derep_fastq(str(bad))
+    notrailer = tmp_path / "notrailer.fastq.gz"
+    notrailer.write_bytes(bytes(raw[:-8]))                        # CRC32 + ISIZE trailer missing
+    with pytest.raises(Dada2HipError, match="error reading"):
+        api.derep_fastq(str(notrailer))
+
+
+def test_dereplication_works_in_a_forked_child(tmp_path):
+    """The marshalling pool spawns its threads once per process; a fork()ed child (multiprocessing's default start method,
+    R's mclapply) has none of them and must rebuild the pool instead of waiting for workers that do not exist."""
+    seqs, quals = random_reads(13, 20000, nvar=400, L=(200, 250))
+    p = tmp_path / "r.fastq"
+    write_fastq(p, seqs, quals)
+    want = api.derep_fastq(str(p))                                # the parent's pool exists from here on
+    rfd, wfd = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                                  # child
+        import signal
+        signal.alarm(60)
+        ok = b"0"
+        try:
+            got = api.derep_fastq(str(p))
+            ok = b"1" if got.seqs == want.seqs and np.array_equal(got.abundances, want.abundances) else b"2"
+        finally:
+            os.write(wfd, ok)
+            os._exit(0)
+    os.close(wfd)
+    _, status = os.waitpid(pid, 0)
+    assert os.read(rfd, 1) == b"1" and status == 0
+    os.close(rfd)
 
 
 @pytest.mark.gpu

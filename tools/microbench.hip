@@ -4,6 +4,8 @@
 //
 //   microbench peaks            -> one JSON object: int32 VALU lane-ops/s (add / max / cndmask / the NW step mix),
 //                                  HBM read GB/s (uint4 stream over 4 GiB), HBM copy GB/s
+//   microbench occ              -> cycles per instruction of a dependent DP-like chain at 1..8 waves per SIMD
+//   microbench launch           -> cost of an (empty / tiny) dependent launch by grid size, eager and from a hipGraph
 //   microbench store_bytes N    -> the k_screen class-byte pattern: one lane in 16 stores ONE byte, N bytes in all
 //   microbench store_wide N     -> fully coalesced uint4 stores, N bytes in all
 //   microbench read_wide N      -> fully coalesced uint4 loads, N bytes in all   (FETCH_SIZE check: expect 1/2)
@@ -126,6 +128,50 @@ __global__ __launch_bounds__(256) void k_store_bytes(uint8_t *__restrict__ q, si
     const size_t r = base + grp;
     if (r < n && sub == 0) q[r] = (uint8_t)(r & 3);
   }
+}
+
+
+// ---- occupancy curve of a dependent NW-like step (mode `occ`): ONE dependent chain per lane (as a DP lane has), w waves
+// per SIMD for w = 1..8: what a SIMD issues per cycle as a function of the waves it holds.
+__global__ __launch_bounds__(256) void k_chain(int *out, int a, int b, int iters) {
+  int x = threadIdx.x, y = threadIdx.x ^ b, z = a;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(y));
+      asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(z));
+      asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(z) : "v"(x), "v"(y) : "vcc");
+    }
+  }
+  if (x + z == 0x7fffffff) out[blockIdx.x * 256 + threadIdx.x] = x;
+}
+// the same with FOUR independent chains per lane (does instruction-level parallelism inside a wave buy issue slots?)
+__global__ __launch_bounds__(256) void k_chain4(int *out, int a, int b, int iters) {
+  int x[4], z[4];
+  const int y = threadIdx.x ^ b;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { x[q] = threadIdx.x + q; z[q] = a + q; }
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[q]) : "v"(y));
+#pragma unroll
+      for (int q = 0; q < 4; q++) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(x[q]) : "v"(y), "v"(z[q]));
+#pragma unroll
+      for (int q = 0; q < 4; q++) asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(z[q]) : "v"(x[q]), "v"(y) : "vcc");
+    }
+  }
+  int s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) s += x[q] + z[q];
+  if (s == 0x7fffffff) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// ---- launch costs (mode `launch`): a kernel whose blocks leave at their first instruction
+__global__ __launch_bounds__(256) void k_noop(const int *flag) { if (*flag) return; }
+__global__ __launch_bounds__(256) void k_touch(int *buf, const int *flag, int n) {   // one coalesced 4-byte read-modify-write per thread
+  if (*flag) return;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) buf[i] += 1;
 }
 
 static float time_ms(void (*launch)(void *), void *ctx, int reps) {
@@ -259,6 +305,88 @@ int main(int argc, char **argv) {
       first = false;
     }
     printf("}}\n");
+    return 0;
+  }
+  if (!strcmp(mode, "occ")) {
+    int *out;
+    CK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
+    const int iters = 1024;
+    printf("{\"device\": \"%s\", \"unit\": \"cycles at the nominal %d MHz; per_simd = SIMD cycles per wave-instruction, per_wave = cycles between two instructions of one wave\", \"instr_per_iter\": 64, \"curve\": {", prop.gcnArchName, prop.clockRate / 1000);
+    for (int variant = 0; variant < 2; variant++) {
+      printf("%s\"%s\": {", variant ? ", " : "", variant ? "four_chains_per_lane" : "one_chain_per_lane");
+      for (int wps = 1; wps <= 8; wps++) {
+        const int grid = cus * wps;
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; rep++) {
+          CK(hipEventRecord(a, 0));
+          if (variant) hipLaunchKernelGGL(k_chain4, dim3(grid), dim3(256), 0, 0, out, 3, 5, iters);
+          else hipLaunchKernelGGL(k_chain, dim3(grid), dim3(256), 0, 0, out, 3, 5, iters);
+          CK(hipEventRecord(b, 0));
+          CK(hipEventSynchronize(b));
+          float ms;
+          CK(hipEventElapsedTime(&ms, a, b));
+          if (rep && ms < best) best = ms;
+        }
+        const double cyc = best * 1e-3 * (prop.clockRate * 1e3);
+        const double per_wave_instr = (double)iters * 64.0;
+        printf("%s\"%d\": {\"per_simd\": %.2f, \"per_wave\": %.2f, \"us\": %.1f}", wps > 1 ? ", " : "", wps, cyc / (per_wave_instr * wps), cyc / per_wave_instr, best * 1e3);
+        CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+      }
+      printf("}");
+    }
+    printf("}}\n");
+    return 0;
+  }
+  if (!strcmp(mode, "launch")) {
+    int *flag, *buf;
+    const int n = 1 << 20;
+    CK(hipMalloc(&flag, 4)); CK(hipMalloc(&buf, (size_t)n * 4));
+    CK(hipMemset(buf, 0, (size_t)n * 4));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    printf("{\"device\": \"%s\", \"unit\": \"us per launch, 400 back-to-back launches on one stream between two events\", \"rows\": [", prop.gcnArchName);
+    bool first = true;
+    for (int work = 0; work < 2; work++)
+      for (int graph = 0; graph < 2; graph++)
+        for (int grid : {1, 64, 256, 512, 1024, 2048, 4096}) {
+          const int one = work ? 0 : 1;
+          CK(hipMemcpy(flag, &one, 4, hipMemcpyHostToDevice));
+          const int NL = 400;
+          hipGraphExec_t ge = nullptr;
+          if (graph) {
+            hipGraph_t g;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            for (int k = 0; k < 8; k++) {
+              if (work) hipLaunchKernelGGL(k_touch, dim3(grid), dim3(256), 0, st, buf, flag, n);
+              else hipLaunchKernelGGL(k_noop, dim3(grid), dim3(256), 0, st, flag);
+            }
+            CK(hipStreamEndCapture(st, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            CK(hipGraphDestroy(g));
+          }
+          float best = 1e30f;
+          for (int rep = 0; rep < 3; rep++) {
+            CK(hipEventRecord(a, st));
+            if (graph) for (int k = 0; k < NL / 8; k++) CK(hipGraphLaunch(ge, st));
+            else for (int k = 0; k < NL; k++) {
+              if (work) hipLaunchKernelGGL(k_touch, dim3(grid), dim3(256), 0, st, buf, flag, n);
+              else hipLaunchKernelGGL(k_noop, dim3(grid), dim3(256), 0, st, flag);
+            }
+            CK(hipEventRecord(b, st));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            if (ms < best) best = ms;
+          }
+          if (ge) CK(hipGraphExecDestroy(ge));
+          printf("%s{\"kernel\": \"%s\", \"graph\": %d, \"grid\": %d, \"us\": %.2f}", first ? "" : ", ", work ? "touch_4MB" : "noop", graph, grid, best * 1e3 / NL);
+          first = false;
+        }
+    printf("]}\n");
     return 0;
   }
   const size_t n = argc > 2 ? (size_t)atoll(argv[2]) : ((size_t)1 << 28);
