@@ -1112,7 +1112,6 @@ struct Run {
   DevBuf<uint2> v2_tab8;
   PinBuf<Round2Out> v2_hblk;
   int v2_nbuf = 64, v2_depth = 2, v2_chain = SH_CHAIN;
-  bool v2_packed = false;          // per-round alignments on k_nw_ad2 (two per lane, packed int16)
   bool v2_debug = false;
   long v2_enq = 0, v2_cons = 0;
   uint64_t v2_miss_launches = 0;
@@ -1155,10 +1154,6 @@ struct Run {
     v2_chain = SH_CHAIN;
     if (const char *e = getenv("DADA2HIP_V2_CHAIN")) v2_chain = std::max(1, std::min(SH_CHAIN, atoi(e)));   // test knob: shorter shuffle chains
     v2_debug = getenv("DADA2HIP_V2_DEBUG") != nullptr;
-    {
-      const char *e = getenv("DADA2HIP_NW_PACKED");
-      v2_packed = (e ? atoi(e) != 0 : false) && nw_ad2_ok(s->D, ap);
-    }
     hipStream_t stq = s->stream;
     v2_lam0.alloc(n); v2_ham0.alloc(n); v2_lam1.alloc(n); v2_ham1.alloc(n); v2_i1.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
     {
@@ -1244,12 +1239,8 @@ struct Run {
       ev_end(rec.ev_screen);
       launch2_lists(E2, stq);
       rec.ev_nw = ev_begin(EV_NW, profile_all);
-      if (v2_packed)
-        launch_nw_ad2(s->D, s->d_nw_list.p, v2_listn.p, s->d_gl_list.p, v2_listn.p + 1, ap, s->d_err.p, s->d_lambda.p, s->d_ham.p,
-                      &v2_ctl.p->centre, stq, &v2_ctl.p->state);
-      else
-        launch_nw_ad(s->D, -1, nullptr, s->d_nw_list.p, v2_listn.p, 0, s->d_gl_list.p, v2_listn.p + 1, ap, s->d_err.p, s->d_lambda.p,
-                     s->d_ham.p, nullptr, 0, 0, &v2_ctl.p->centre, stq, &v2_ctl.p->state);
+      launch_nw_ad(s->D, -1, nullptr, s->d_nw_list.p, v2_listn.p, 0, s->d_gl_list.p, v2_listn.p + 1, ap, s->d_err.p, s->d_lambda.p,
+                   s->d_ham.p, nullptr, 0, 0, &v2_ctl.p->centre, stq, &v2_ctl.p->state);
       ev_end(rec.ev_nw);
     }
     int ev = ev_begin(EV_SHUFFLE, profile_all && nlev > 0);
@@ -1977,11 +1968,7 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
       if (f && !strcmp(f, "lane")) coop = false;
       if (f && !strcmp(f, "coop") && coop_ok) coop = true;
       D2_HIP(hipEventRecord(s->ev0, stq));
-      const char *pk = getenv("DADA2HIP_NW_PACKED");
-      if (coop && pk && atoi(pk) != 0 && nw_ad2_ok(D, run.ap))   // (kernel-level timing of the packed-pair aligner)
-        launch_nw_ad2(D, s->d_nw_list.p, nullptr, nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p, s->d_ham.p, nullptr, stq, nullptr,
-                      centre, n_nw);
-      else if (coop)
+      if (coop)
         launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
                      s->d_ham.p, nullptr, 0, 0, nullptr, stq);
       else {

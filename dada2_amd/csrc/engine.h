@@ -186,12 +186,6 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
 
 // d_gl_work/d_gl_nwork (optional): the round's gapless comparisons, processed by the same kernel
 // d_view (optional): aligned views, row = unique (or chunk when view_by_chunk); chunks are nw_ad_apw() work slots
-// k_nw_ad2 (nwpair.inc.hip): the per-round aligner with two alignments per lane in packed int16; applies when every read
-// has the same length (<= 500), default scoring, band <= 18
-bool nw_ad2_ok(const SampleDev &S, const AlignParams &ap);
-void launch_nw_ad2(const SampleDev &S, const int32_t *d_work, const int32_t *d_nwork, const int32_t *d_gl_work,
-                   const int32_t *d_gl_nwork, const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham,
-                   const int32_t *d_centre_dev, hipStream_t st, const int32_t *d_stop_dev, int centre_host = -1, int nwork_host = 0);
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,

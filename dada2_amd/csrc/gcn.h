@@ -1,0 +1,31 @@
+// gcn.h — the handful of gfx950 instructions the kernels spell out themselves (wave64, CDNA4).  Everything here is a thin
+// name over ONE machine instruction, so that the kernels read as algorithms and the functional emulator under tests/emu
+// (test infrastructure: it runs the kernels lane by lane on the CPU) can supply the same names in plain C++.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace d2 {
+
+// max(a, b, c) in one VOP3 instruction (the compiler keeps an inner max when one of its results is also compared)
+static __device__ __forceinline__ int gcn_max3(int a, int b, int c) {
+  int e;
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(e) : "v"(a), "v"(b), "v"(c));
+  return e;
+}
+// DPP wave shifts by one lane: lane L reads `src` of lane L-1 (shr) / L+1 (shl); a lane without a source keeps `old`
+// (bound_ctrl = false) or reads 0 (bound_ctrl = true)
+template <bool BOUND_CTRL>
+static __device__ __forceinline__ int gcn_wave_shr1(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xF, 0xF, BOUND_CTRL);
+}
+template <bool BOUND_CTRL>
+static __device__ __forceinline__ int gcn_wave_shl1(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xF, 0xF, BOUND_CTRL);
+}
+static __device__ __forceinline__ int gcn_readfirstlane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// The lanes of a wave execute in lockstep, so data one lane leaves in LDS is there for the others at the next instruction;
+// this marks the places where a kernel relies on that.  No instruction: it only stops the compiler from moving memory
+// operations across the point (and gives the lane-by-lane emulator its rendezvous).
+static __device__ __forceinline__ void gcn_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+}  // namespace d2

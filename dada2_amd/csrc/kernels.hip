@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "engine.h"
+#include "gcn.h"
 #include "ppois.h"
 
 namespace d2 {
@@ -455,11 +456,11 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
   for (int chunk = gwave; chunk * 64 < nwork; chunk += nwaves) {
     const int idx = chunk * 64 + lane;
-    const int c = __builtin_amdgcn_readfirstlane(a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
+    const int c = gcn_readfirstlane(a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
     int r = idx < nwork ? a.work[idx] : -1;
     const bool active = r >= 0;
     if (!active) r = c;                       // idle lanes align the centre to itself, results dropped
-    const int L1 = __builtin_amdgcn_readfirstlane(S.len[c]);
+    const int L1 = gcn_readfirstlane(S.len[c]);
     const int L2 = S.len[r];
     const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
     const int W = lband + rband + 1;          // <= WMAX (host picks the kernel class)
@@ -639,15 +640,15 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
   if (LEAN && !EDGE && VAR >= 1) {
     // steady state, band inside the lane group: the DPP neighbour needs no masking (lanes without a source read 0, they
     // are out of band), the fetch folds into the add, the two max into one v_max3
-    const int nb = PAR == 0 ? __builtin_amdgcn_update_dpp(0, d1, 0x138, 0xF, 0xF, true)     // lane-1's odd cell (wave_shr:1)
-                            : __builtin_amdgcn_update_dpp(0, d0, 0x130, 0xF, 0xF, true);    // lane+1's even cell (wave_shl:1)
+    const int nb = PAR == 0 ? gcn_wave_shr1<true>(0, d1)     // lane-1's odd cell (wave_shr:1)
+                            : gcn_wave_shl1<true>(0, d0);    // lane+1's even cell (wave_shl:1)
     const int own = PAR == 0 ? d0 : d1, other = PAR == 0 ? d1 : d0;
     const int diag = own + (cb == rb ? MATCH : MISMATCH);
     const int left = (PAR == 0 ? nb : other) + gsel, up = (PAR == 0 ? other : nb) + gsel;
     int e;
     bool t2;
     if (VAR == 2) {                                          // (spelled out: the compiler would keep the inner max for t2)
-      asm("v_max3_i32 %0, %1, %2, %3" : "=v"(e) : "v"(left), "v"(diag), "v"(up));
+      e = gcn_max3(left, diag, up);
       t2 = up == e;                                          // up >= max(left, diag)  <=>  the maximum IS up
     } else {
       const int e1 = max(left, diag);
@@ -662,10 +663,10 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
   }
   int left_src, up_src, own;
   if (PAR == 0) {
-    const int lft = __builtin_amdgcn_update_dpp(SENT, d1, 0x138, 0xF, 0xF, false);   // lane-1's odd cell (wave_shr:1)
+    const int lft = gcn_wave_shr1<false>(SENT, d1);   // lane-1's odd cell (wave_shr:1)
     own = d0; left_src = (EDGE && g_first) ? SENT : lft; up_src = d1;
   } else {
-    const int upn = __builtin_amdgcn_update_dpp(SENT, d0, 0x130, 0xF, 0xF, false);   // lane+1's even cell (wave_shl:1)
+    const int upn = gcn_wave_shl1<false>(SENT, d0);   // lane+1's even cell (wave_shl:1)
     own = d1; left_src = d0; up_src = (EDGE && g_last) ? SENT : upn;
   }
   const int diag = own + (cb == rb ? MATCH : MISMATCH);
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
     const int dbg = a.moves_stride;
-    Tmax = __builtin_amdgcn_readfirstlane(Tmax);
+    Tmax = gcn_readfirstlane(Tmax);
     const int org = (EDGE ? 0 : 2) + (lband & 1), lbo = lband + org;   // origin shift: lbo is even
     if (Tmax >= 0 && !(dbg & 1)) {
       int d0 = SENT, d1 = SENT;
@@ -804,8 +805,8 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
       if (T < 0) { tA = 0; tB = 0x3FFFFFFF; }               // idle / gapless slot: no constraint
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
-      tA = __builtin_amdgcn_readfirstlane(tA);
-      tB = __builtin_amdgcn_readfirstlane(tB);
+      tA = gcn_readfirstlane(tA);
+      tB = gcn_readfirstlane(tB);
 #define AD_FLUSH(TT) { if (colok) ptr[((TT) >> 4) * NCOL + g] = pw; pw = 0; }
 #define AD_FULL_STEP(TT)                                                                                                        \
   {                                                                                                                             \
@@ -953,7 +954,9 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
       }
     // hamming: group sum through LDS (group sizes are not powers of two); the run buffer is free by now
     if (g == 0 && !ghost) runs[0] = 0;
+    gcn_wave_sync();
     if (!ghost && h) atomicAdd(&runs[0], h);
+    gcn_wave_sync();                                       // (also: every lane's factors are in LDS before one lane multiplies them)
     h = runs[0];
     // ---- lambda: sequential product in raw-position order (pval.cpp:188-192), one lane per alignment ---------
     if (g == 0 && active && !(dbg & 8)) {
@@ -1026,8 +1029,6 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
 #undef D2_LAUNCH_AD
 }
 
-#include "nwpair.inc.hip"
-
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap) { return ad_geom(ap.band, S.maxlen, S.minlen).APW; }
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
@@ -1084,8 +1085,7 @@ static __device__ __forceinline__ void adw_step(int (&d)[8], uint32_t (&pw)[4], 
       const int up_src = PAR ? (m == 3 ? nb : d[c + 1]) : d[c + 1];
       const int diag = d[c] + (((x >> (8 * m)) & 0xFFu) == 0 ? MATCH : MISMATCH);
       const int left = left_src + gs[c], up = up_src + gs[c];
-      int e;
-      asm("v_max3_i32 %0, %1, %2, %3" : "=v"(e) : "v"(left), "v"(diag), "v"(up));
+      const int e = gcn_max3(left, diag, up);
       const bool t1 = left >= diag, t2 = up == e;            // up >= max(left, diag)  <=>  the maximum IS up
       d[c] = e;
       pw[m] |= (t2 ? 3u : (t1 ? 2u : 1u)) << fs;
@@ -1193,13 +1193,13 @@ __global__ __launch_bounds__(256, 3) void k_nw_adw(NwArgs a, AdwGeom G) {
       if (T < 0) { tA = 0; tB = 0x3FFFFFFF; }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
-      tA = __builtin_amdgcn_readfirstlane(tA);
-      tB = __builtin_amdgcn_readfirstlane(tB);
-      Tmax = __builtin_amdgcn_readfirstlane(Tmax);
+      tA = gcn_readfirstlane(tA);
+      tB = gcn_readfirstlane(tB);
+      Tmax = gcn_readfirstlane(Tmax);
 #define ADW_EVEN(LEANV, FS)                                                                                              \
   {                                                                                                                      \
     const uint32_t nxt = rbytes[J + 3];                                                                                  \
-    int nb = __builtin_amdgcn_update_dpp(SENT, d[7], 0x138, 0xF, 0xF, false);   /* lane-1's last cell (wave_shr:1) */    \
+    int nb = gcn_wave_shr1<false>(SENT, d[7]);   /* lane-1's last cell (wave_shr:1) */                                   \
     if (g_first) nb = SENT;                                                                                              \
     adw_step<0, LEANV, DEF>(d, pw, (FS), cwin ^ rwin, nb, kmask, gs, I, J, L1, L2, SENT, MATCH, MISMATCH, GAP);              \
     rwin = (rwin >> 8) | (nxt << 24);                                                                                    \
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256, 3) void k_nw_adw(NwArgs a, AdwGeom G) {
 #define ADW_ODD(LEANV, FS)                                                                                               \
   {                                                                                                                      \
     const uint32_t nxt = cbytes[I];                                                                                      \
-    int nb = __builtin_amdgcn_update_dpp(SENT, d[0], 0x130, 0xF, 0xF, false);   /* lane+1's first cell (wave_shl:1) */   \
+    int nb = gcn_wave_shl1<false>(SENT, d[0]);   /* lane+1's first cell (wave_shl:1) */                                  \
     if (g_last) nb = SENT;                                                                                               \
     adw_step<1, LEANV, DEF>(d, pw, (FS), cwin ^ rwin, nb, kmask, gs, I, J + 1, L1, L2, SENT, MATCH, MISMATCH, GAP);          \
     cwin = (cwin << 8) | nxt;                                                                                            \
@@ -1335,8 +1335,11 @@ __global__ __launch_bounds__(256, 3) void k_nw_adw(NwArgs a, AdwGeom G) {
       if (__all(done)) break;
     }
     uint32_t *hsum = (uint32_t *)runs;                      // the run buffer is free by now
+    gcn_wave_sync();                                        // (the last run descriptors have been read by every lane)
     if (g == 0 && !ghost) hsum[0] = 0;
+    gcn_wave_sync();
     if (!ghost && h) atomicAdd(&hsum[0], h);
+    gcn_wave_sync();
     h = hsum[0];
     // ---- lambda: factors in chunks of G.fch positions (all lanes), multiplied in raw-position order by one lane ----
     int L2max = active ? L2 : 0;
@@ -1350,6 +1353,7 @@ __global__ __launch_bounds__(256, 3) void k_nw_adw(NwArgs a, AdwGeom G) {
           const uint32_t q = a.ap.use_quals ? qrow[pj] : 0u;
           fac[pj - base] = s_err[(uint32_t)tcode[pj] * a.ap.ncol + q];
         }
+      gcn_wave_sync();
       if (g == 0 && active && !ghost) {
         const int n = hi - base;
         int x = 0;
@@ -1360,6 +1364,7 @@ __global__ __launch_bounds__(256, 3) void k_nw_adw(NwArgs a, AdwGeom G) {
         }
         for (; x < n; x++) l = l * fac[x];
       }
+      gcn_wave_sync();                                      // (the next chunk's factors overwrite these)
     }
     if (g == 0 && active && !ghost) { a.lam[r] = l; a.ham[r] = h; }
   }

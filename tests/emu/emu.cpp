@@ -1,0 +1,265 @@
+// tests/emu/emu.cpp — TEST INFRASTRUCTURE ONLY (see tests/emu/hip/hip_runtime.h).
+//
+// Executes a "kernel launch" on the host: the blocks of the grid one after the other, the threads of a block as fibers
+// on one host thread.  A fiber runs until it finishes or reaches a rendezvous:
+//   * a cross-lane operation of its wave (shuffle / DPP shift / ballot / readfirstlane) over the lanes
+//     [base, base + width) - released when every LIVE lane of that group waits in an operation of the same width, and
+//     the scheduler computes each lane's result at that moment (lanes that have left the kernel count as inactive:
+//     their values read as invalid, as an EXEC-masked lane's would);
+//   * __syncthreads() - released when every live thread of the block waits in it.
+// Narrower groups are released before wider ones, which is the order a real wave executes divergent code in (the
+// 16-lane shuffles of one lane group inside a branch other groups do not take, then the wave-wide operation behind the
+// branch).  A state in which nobody can run and nobody can be released is reported as a deadlock with the waiting lanes.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <mutex>
+#include <sys/mman.h>
+#include <vector>
+
+namespace emu {
+
+Cur cur;
+
+namespace {
+
+constexpr size_t STACK_BYTES = 256 * 1024;
+constexpr int MAX_THREADS = 1024;
+
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_switch,.-emu_switch
+)");
+
+enum State : uint8_t { RUN, WAIT_WAVE, WAIT_BLOCK, DONE };
+
+struct Lane {
+  void *sp = nullptr;
+  State st = DONE;
+  // pending cross-lane operation
+  Op op;
+  int width, param;
+  uint64_t value, old, result;
+  bool bound_ctrl, pred;
+  Idx tid;
+};
+
+struct Block {
+  Lane lanes[MAX_THREADS];
+  int n = 0;
+  void *sched_sp = nullptr;
+  int running = -1;
+  const std::function<void()> *body = nullptr;
+  char *stacks = nullptr;
+};
+
+Block *B = nullptr;
+
+void fiber_main() {
+  Block *b = B;
+  Lane &me = b->lanes[b->running];
+  (*b->body)();
+  me.st = DONE;
+  emu_switch(&me.sp, b->sched_sp);
+  __builtin_trap();   // a finished fiber is never resumed
+}
+
+void yield_to_scheduler() {
+  Block *b = B;
+  Lane &me = b->lanes[b->running];
+  emu_switch(&me.sp, b->sched_sp);
+  cur.tid = me.tid;   // (the scheduler set the rest)
+}
+
+void init_fiber(Block *b, int t) {
+  char *top = b->stacks + (size_t)(t + 1) * STACK_BYTES;
+  void **sp = (void **)(((uintptr_t)top) & ~(uintptr_t)15);
+  sp -= 8;
+  for (int k = 0; k < 6; k++) sp[k] = nullptr;   // r15 r14 r13 r12 rbx rbp
+  sp[6] = (void *)&fiber_main;                    // return address of the first switch
+  sp[7] = nullptr;                                // (keeps rsp = 8 mod 16 at fiber_main's entry, as after a call)
+  b->lanes[t].sp = sp;
+  b->lanes[t].st = RUN;
+}
+
+// result of every lane of a released group
+void resolve_group(Block *b, int wave0, int base, int width) {
+  const int lo = wave0 + base, hi = wave0 + base + width;
+  auto live = [&](int l) { return l >= lo && l < hi && l < b->n && b->lanes[l].st == WAIT_WAVE; };
+  // ballot / readfirstlane look at the whole wave's live lanes (they are issued with width 64)
+  unsigned long long mask = 0;
+  int first = -1;
+  for (int l = lo; l < hi && l < b->n; l++)
+    if (b->lanes[l].st == WAIT_WAVE) {
+      if (b->lanes[l].pred) mask |= 1ull << (l - wave0);
+      if (first < 0) first = l;
+    }
+  for (int l = lo; l < hi && l < b->n; l++) {
+    Lane &x = b->lanes[l];
+    if (x.st != WAIT_WAVE) continue;
+    const int li = l - wave0;   // lane id in the wave
+    switch (x.op) {
+      case OP_SHFL: {
+        const int src = wave0 + base + (x.param & (width - 1));
+        x.result = live(src) ? b->lanes[src].value : x.value;
+        break;
+      }
+      case OP_SHFL_XOR: {
+        const int src = wave0 + base + (((li - base) ^ x.param) & (width - 1));
+        x.result = live(src) ? b->lanes[src].value : x.value;
+        break;
+      }
+      case OP_DPP_SHR1: {
+        const int src = l - 1;
+        const bool ok = li >= 1 && live(src);
+        x.result = ok ? b->lanes[src].value : (x.bound_ctrl ? 0 : x.old);
+        break;
+      }
+      case OP_DPP_SHL1: {
+        const int src = l + 1;
+        const bool ok = li <= 62 && live(src);
+        x.result = ok ? b->lanes[src].value : (x.bound_ctrl ? 0 : x.old);
+        break;
+      }
+      case OP_BALLOT: x.result = mask; break;
+      case OP_READFIRST: x.result = b->lanes[first].value; break;
+    }
+  }
+  for (int l = lo; l < hi && l < b->n; l++)
+    if (b->lanes[l].st == WAIT_WAVE) b->lanes[l].st = RUN;
+}
+
+bool release_waves(Block *b) {
+  bool any = false;
+  for (int w0 = 0; w0 < b->n; w0 += 64) {
+    // narrow groups first
+    for (int width = 2; width <= 64; width <<= 1) {
+      for (int base = 0; base < 64; base += width) {
+        int nwait = 0, nlive = 0;
+        bool same = true;
+        for (int l = w0 + base; l < w0 + base + width && l < b->n; l++) {
+          const Lane &x = b->lanes[l];
+          if (x.st == DONE) continue;
+          nlive++;
+          if (x.st == WAIT_WAVE && x.width == width) nwait++;
+          else same = false;
+        }
+        if (nlive > 0 && same && nwait == nlive) { resolve_group(b, w0, base, width); any = true; }
+      }
+    }
+  }
+  return any;
+}
+
+void run_block(Block *b) {
+  for (int t = 0; t < b->n; t++) init_fiber(b, t);
+  for (;;) {
+    bool progressed = false;
+    int ndone = 0;
+    for (int t = 0; t < b->n; t++) {
+      Lane &x = b->lanes[t];
+      if (x.st == DONE) { ndone++; continue; }
+      if (x.st != RUN) continue;
+      b->running = t;
+      cur.tid = x.tid;
+      emu_switch(&b->sched_sp, x.sp);
+      progressed = true;
+      if (x.st == DONE) ndone++;
+    }
+    if (ndone == b->n) break;
+    if (release_waves(b)) progressed = true;
+    {   // __syncthreads: every live thread waits in it
+      int nlive = 0, nbar = 0;
+      for (int t = 0; t < b->n; t++) {
+        if (b->lanes[t].st == DONE) continue;
+        nlive++;
+        if (b->lanes[t].st == WAIT_BLOCK) nbar++;
+      }
+      if (nlive > 0 && nbar == nlive) {
+        for (int t = 0; t < b->n; t++) if (b->lanes[t].st == WAIT_BLOCK) b->lanes[t].st = RUN;
+        progressed = true;
+      }
+    }
+    if (!progressed) {
+      fprintf(stderr, "[emu] DEADLOCK in block (%u,%u,%u): lanes wait for rendezvous that can never complete\n", cur.bid.x, cur.bid.y, cur.bid.z);
+      for (int t = 0; t < b->n; t++) {
+        const Lane &x = b->lanes[t];
+        if (x.st == DONE) continue;
+        fprintf(stderr, "  thread %d: %s op %d width %d\n", t, x.st == WAIT_BLOCK ? "barrier" : "wave-op", (int)x.op, x.width);
+        if (t > 80) { fprintf(stderr, "  ...\n"); break; }
+      }
+      abort();
+    }
+  }
+}
+
+}  // namespace
+
+uint64_t wave_op(Op op, int width, uint64_t value, int param, uint64_t old, bool bound_ctrl, bool pred) {
+  Block *b = B;
+  Lane &me = b->lanes[b->running];
+  if (op != OP_SHFL && op != OP_SHFL_XOR) width = 64;
+  if (width <= 1) return value;
+  me.op = op; me.width = width; me.value = value; me.param = param; me.old = old; me.bound_ctrl = bound_ctrl; me.pred = pred;
+  me.st = WAIT_WAVE;
+  yield_to_scheduler();
+  return me.result;
+}
+
+void block_barrier() {
+  Block *b = B;
+  Lane &me = b->lanes[b->running];
+  me.st = WAIT_BLOCK;
+  yield_to_scheduler();
+}
+
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body) {
+  static std::mutex mu;   // host threads of dada2hip_run_multi: one emulated launch at a time
+  std::lock_guard<std::mutex> guard(mu);
+  static Block *blk = nullptr;
+  static void *lds = nullptr;
+  if (!blk) {
+    blk = new Block();
+    blk->stacks = (char *)mmap(nullptr, STACK_BYTES * MAX_THREADS, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (blk->stacks == (char *)MAP_FAILED) { perror("[emu] mmap"); abort(); }
+    lds = std::aligned_alloc(64, 160 * 1024);
+  }
+  if (B) { fprintf(stderr, "[emu] nested launch\n"); abort(); }
+  const unsigned nthreads = block.x * block.y * block.z;
+  if (nthreads == 0 || nthreads > (unsigned)MAX_THREADS || lds_bytes > 160 * 1024) { fprintf(stderr, "[emu] bad launch geometry\n"); abort(); }
+  B = blk;
+  blk->n = (int)nthreads;
+  blk->body = &body;
+  cur.bdim = Idx{block.x, block.y, block.z};
+  cur.gdim = Idx{grid.x, grid.y, grid.z};
+  cur.dyn_lds = lds;
+  for (unsigned t = 0; t < nthreads; t++) blk->lanes[t].tid = Idx{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+  for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+      for (unsigned bx = 0; bx < grid.x; bx++) {
+        cur.bid = Idx{bx, by, bz};
+        run_block(blk);
+      }
+  B = nullptr;
+}
+
+}  // namespace emu

@@ -1,0 +1,18 @@
+// tests/emu/gcn.h — TEST INFRASTRUCTURE ONLY: the emulator's spelling of dada2_amd/csrc/gcn.h (same names, plain C++ over
+// the fiber rendezvous of tests/emu/emu.cpp).  tests/emu/build.py puts it in place of the real header in the build copy.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace d2 {
+
+static inline int gcn_max3(int a, int b, int c) { return std::max(a, std::max(b, c)); }
+template <bool BOUND_CTRL> static inline int gcn_wave_shr1(int old, int src) {
+  return (int)(uint32_t)emu::wave_op(emu::OP_DPP_SHR1, 64, (uint32_t)src, 0, (uint32_t)old, BOUND_CTRL, false);
+}
+template <bool BOUND_CTRL> static inline int gcn_wave_shl1(int old, int src) {
+  return (int)(uint32_t)emu::wave_op(emu::OP_DPP_SHL1, 64, (uint32_t)src, 0, (uint32_t)old, BOUND_CTRL, false);
+}
+static inline void gcn_wave_sync() { (void)emu::wave_op(emu::OP_BALLOT, 64, 0, 0, 0, false, false); }
+static inline int gcn_readfirstlane(int v) { return (int)(uint32_t)emu::wave_op(emu::OP_READFIRST, 64, (uint32_t)v, 0, 0, false, false); }
+
+}  // namespace d2

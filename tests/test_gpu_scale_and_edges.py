@@ -208,8 +208,7 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V2_DEPTH": "3"},
     {"DADA2HIP_V2_CHAIN": "1"},                           # one shuffle per chain: rounds continue through the host (H2_SHUFFLE_MORE)
     {"DADA2HIP_V2_CHAIN": "2", "DADA2HIP_NODE_CAP": "1"}, # comparison store starts at N + 16 blocks: growth through H2_CAPACITY
-    {"DADA2HIP_NW_PACKED": "1"},                          # per-round alignments on the packed-pair kernel k_nw_ad2 (equal-length samples)
-], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-packed"])
+], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
     20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""
@@ -217,10 +216,9 @@ def test_round_engines_agree_with_the_reference(env):
 
 
 @pytest.mark.parametrize("L,band,n", [(250, 16, 30000), (100, 16, 8000), (251, 8, 8000), (333, 18, 6000), (120, 1, 4000)])
-@pytest.mark.parametrize("packed", ["1", "0"])
-def test_packed_pair_aligner_matches_oracle(L, band, n, packed):
-    """k_nw_ad2 (two alignments per lane, packed int16) on equal-length samples of several lengths and bands against the C
-    restatement; the same cases through k_nw_ad."""
+def test_equal_length_samples_of_several_lengths_and_bands_match_oracle(L, band, n):
+    """Equal-length samples (the per-round aligner's steady state covers the whole matrix interior) of several lengths and
+    bands - odd lengths, a band of one cell - against the C restatement."""
     import subprocess, sys
     code = (
         "import sys\n"
@@ -249,7 +247,7 @@ def test_packed_pair_aligner_matches_oracle(L, band, n, packed):
         "assert_results_equal(got, want, p_rtol=P_RTOL)\n"
         "assert got.nclust > 5 and got.stats['nnw'] > 100\n"
         "print('ok', got.nclust, got.stats['nnw'])\n") % (ROOT, n, L, 9000 + L + band, L, band)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DADA2HIP_NW_PACKED=packed), capture_output=True, text=True,
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 

@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--uniques", type=int, default=300000)
     ap.add_argument("--sizes", default="2000,4000,8700,18000,36000")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--packed", default="", help="comma list of DADA2HIP_NW_PACKED values (1 = the packed-pair kernel k_nw_ad2)")
     ap.add_argument("--variants", default="", help="comma list of DADA2HIP_AD_VARIANT values to compare (A/B of the DP step)")
     a = ap.parse_args()
     from dada2_amd import api
@@ -42,12 +41,9 @@ def main():
         keep = rng.choice(nw_idx, size=size, replace=False)
         skip = np.ones(d.nraw, dtype=np.uint8)
         skip[keep] = 0
-        combos = [(v, None) for v in a.variants.split(",") if v] + [(None, p) for p in a.packed.split(",") if p] or [(None, None)]
+        combos = [(v, None) for v in a.variants.split(",") if v] or [(None, None)]
         for var, pk in combos:
             row = {"batch": size}
-            os.environ["DADA2HIP_NW_PACKED"] = pk or "0"
-            if pk is not None:
-                row["packed"] = int(pk)
             if var is not None:
                 os.environ["DADA2HIP_AD_VARIANT"] = var
                 row["variant"] = int(var)
