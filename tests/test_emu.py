@@ -1,0 +1,57 @@
+"""The product's OWN kernels and driver, executed lane by lane on the CPU by the functional emulator under tests/emu
+(TEST INFRASTRUCTURE: fibers per GPU thread, the cross-lane operations and barriers as rendezvous; see
+tests/emu/hip/hip_runtime.h).  This is how kernel logic is debugged in the authoring container, which has no GPU; the
+-m gpu tests remain the parity tests proper.  The emulated library is opened explicitly here (a subprocess that points
+dada2_amd._lib at tests/emu/build/libdada2hip_emu.so) - nothing in dada2_amd/ knows it exists."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+pytestmark = pytest.mark.skipif(not (os.path.exists(CXX) or shutil.which(CXX)), reason="no host clang++ for the emulator build")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    import build as emu_build
+    return emu_build.build()
+
+
+def run_cases(emu_lib, names, env=None, timeout=900):
+    code = (
+        "import sys\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from dada2_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "from helpers import case_inputs, assert_results_equal\n"
+        "from dada2_amd import api\n"
+        "from oracle import cport\n"
+        "for name in %r:\n"
+        "    d, err, pri, o, exp, meta = case_inputs(name)\n"
+        "    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"
+        "    assert_results_equal(got, exp, check_birth_from=pri is None)\n"
+        "    st = got.stats\n"
+        "    print('ok', name, got.nclust, st['nnw'], st['ngapless'], st['nshroud'])\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib, tuple(names))
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0 and out.stdout.count("ok ") == len(names), out.stdout[-2000:] + out.stderr[-4000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("env", [{}, {"DADA2HIP_ENGINE": "classic"}, {"DADA2HIP_NW_KERNEL": "lane"}, {"DADA2HIP_NW_KERNEL": "wide"}],
+                         ids=["default", "classic-engine", "lane-kernel", "wide-kernel"])
+def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
+    out = run_cases(emu_lib, ("sam1F_default", "sam1R_default"), env)
+    assert "ok sam1F_default 10 " in out
+
+
+def test_emulated_long_read_band32_case(emu_lib):
+    run_cases(emu_lib, ("samPB_band32",))
