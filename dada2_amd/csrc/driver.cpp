@@ -96,7 +96,7 @@ struct dada2hip_sample {
   // per-run device work buffers (kept across runs: selfConsist passes reuse them)
   DevBuf<uint8_t> d_skip, d_cls, d_correct, d_moves;
   DevBuf<double> d_lambda, d_err;
-  DevBuf<uint32_t> d_ham, scr_ptr, scr_t, d_qn, d_ctab, scr_adw;
+  DevBuf<uint32_t> d_ham, scr_ptr, scr_t, d_qn, d_ctab, scr_adw, scr_ad;
   int scr_adw_waves = 0, scr_adw_band = -999;
   size_t scr_adw_wpw = 0;
   DevBuf<int32_t> d_nw_list, d_gl_list, d_counters, d_thresh, scr_rows, d_work, d_chunk_centre, d_cluster_of,
@@ -287,6 +287,14 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
   s->seq2.alloc((size_t)nraw * D.W2);
   s->nwflag.alloc(1);
   D.nw_flag = s->nwflag.p;
+  {   // pointer ring of k_nw_ad (kernels.hip): 8 192 wave slots of 8 KB at 250 nt; fewer, never below 1 024, for long reads
+    D.ad_wpw = 64 * ((2 * maxlen + 1 + 15) / 16);
+    int waves = 8192;
+    while (waves > 1024 && (size_t)waves * D.ad_wpw * 4 > ((size_t)256 << 20)) waves /= 2;
+    s->scr_ad.alloc((size_t)waves * D.ad_wpw);
+    D.ad_ptr = s->scr_ad.p;
+    D.ad_waves = waves;
+  }
   D2_HIP(hipMemsetAsync(D.nw_flag, 0, 4, s->stream));
   s->len.alloc(nraw); s->reads.alloc(nraw); s->prior.alloc(nraw); s->nheavy.alloc(nraw);
   s->qual.alloc((size_t)nraw * D.LQ);

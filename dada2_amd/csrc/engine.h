@@ -52,6 +52,11 @@ struct SampleDev {
   uint32_t *reads = nullptr;  // [N]
   uint8_t *prior = nullptr;   // [N]
   int32_t *nw_flag = nullptr; // [1] set by the NW kernels when a traceback leaves its bounds (never silently wrong)
+  // traceback-pointer ring of the anti-diagonal aligner k_nw_ad: one slot per wave of its grid, [16-step block][lane]
+  // (every flush is one coalesced 256-byte store per wave)
+  uint32_t *ad_ptr = nullptr;
+  int32_t ad_waves = 0;       // wave slots (a multiple of 4)
+  int32_t ad_wpw = 0;         // words per wave slot = 64 * ceil((2 * maxlen + 1) / 16)
 };
 
 struct AlignParams {

@@ -690,15 +690,18 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
   pw |= p << fs;
 }
 
-// LDS geometry of k_nw_ad, shared by host and device
+// LDS geometry of k_nw_ad, shared by host and device.  Per alignment: run descriptors, the two staged sequences (one base
+// per byte, guard bytes either side), one u16 per raw position (byte offset of its error-model factor in the LDS copy of
+// err) and the raw's qualities.  The 2-bit traceback pointers are NOT here: they go to the HBM ring SampleDev::ad_ptr, one
+// coalesced 256-byte store per wave per 16 steps (they took 2.3 of the 4.1 KB per alignment of round 2's kernel and, with
+// the fp64 factor array that aliased them, held the kernel at three blocks per CU).
 struct AdGeom {
   int GL, APW, NCOL;        // lanes per alignment, alignments per wave, pointer columns per alignment
   int edge;                 // 1: group-boundary lanes must mask their DPP neighbour (band fills the group's cells)
-  int nwords;               // pointer words per column (16 steps each)
-  int area_words;           // per alignment: max(pointer words, 2*maxlen for the fp64 factors that later alias them)
+  int nwords;               // 16-step blocks of a sweep (pointer words per lane)
   int seqbytes;             // bytes per staged sequence incl. guards (multiple of 8)
-  int tbytes;               // bytes per transition-code / quality row (multiple of 8)
-  int per_wave_words;
+  int tbytes;               // bytes per quality row (multiple of 16); the factor-offset row has 2 * tbytes
+  int per_al_bytes;
 };
 // Lane g of a group owns cells k' = 2g, 2g+1; an alignment's band cell k sits at k' = k + o.  The origin shift o makes
 // lband + o even, so every alignment of a wave is in phase (even cells live on even steps) whatever its length
@@ -712,19 +715,14 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   G.edge = (W + 4 > 2 * G.GL) ? 1 : 0;
   G.NCOL = (W + (G.edge ? 1 : 3) + 1) / 2;
   G.nwords = (2 * maxlen + 1 + 15) / 16;
-  G.area_words = G.nwords * G.NCOL;
-  if (G.area_words < 2 * maxlen) G.area_words = 2 * maxlen;
-  G.area_words = (G.area_words + 1) & ~1;
   G.seqbytes = (maxlen + 2 * (G.GL + 11) + 7) & ~7;
-  G.tbytes = (maxlen + 7) & ~7;
-  G.per_wave_words = G.APW * (G.area_words + AD_RCAP + (2 * G.seqbytes + 2 * G.tbytes) / 4);
+  G.tbytes = (maxlen + 15) & ~15;
+  G.per_al_bytes = AD_RCAP * 4 + 2 * G.seqbytes + 3 * G.tbytes;
   return G;
 }
 
-// (256, 3): three blocks per CU is what the LDS footprint allows anyway; it caps the kernel at 168 VGPRs — a variant that
-// needed 171 ran at two waves per SIMD and lost 15 % (profiles/r02n_nw_variants.jsonl)
 template <int GL, bool DEF, bool EDGE, int VAR>
-__global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
+__global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                AdGeom G) {
   constexpr int APW = 64 / GL;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -743,19 +741,17 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
   // extra, always-out-of-band lane of the last group and is excluded from everything else.
   const bool ghost = lane / GL >= APW;
   const int al = ghost ? APW - 1 : lane / GL, g = ghost ? GL : lane % GL;
-  // per-alignment LDS: [pointer words | later: fp64 factors][run descriptors][centre bytes][raw bytes][tcodes][quals]
-  uint32_t *abase = (uint32_t *)(s_dyn + nerr) + ((size_t)wib * APW + al) * (G.per_wave_words / APW);
-  uint32_t *ptr = abase;                                   // [nwords][NCOL]
-  double *fac = (double *)abase;
-  uint32_t *runs = abase + G.area_words;
-  uint8_t *cbytes = (uint8_t *)(runs + AD_RCAP) + (GL + 11);
+  // per-alignment LDS: [run descriptors][centre bytes][raw bytes][factor offsets u16][quals]
+  uint8_t *abase = (uint8_t *)(s_dyn + nerr) + ((size_t)wib * APW + al) * G.per_al_bytes;
+  uint32_t *runs = (uint32_t *)abase;
+  uint8_t *cbytes = abase + AD_RCAP * 4 + (GL + 11);
   uint8_t *rbytes = cbytes + G.seqbytes;
-  uint8_t *tcode = (uint8_t *)(runs + AD_RCAP) + 2 * G.seqbytes;
-  uint8_t *qlds = tcode + G.tbytes;
-  const int NCOL = G.NCOL;
+  uint16_t *foff = (uint16_t *)(abase + AD_RCAP * 4 + 2 * G.seqbytes);   // byte offset into s_err of every raw position's factor
+  uint8_t *qlds = abase + AD_RCAP * 4 + 2 * G.seqbytes + 2 * G.tbytes;
   __syncthreads();
   const SampleDev &S = a.S;
   const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
+  uint32_t *pg = S.ad_ptr + (size_t)gwave * S.ad_wpw;      // this wave's slot of the pointer ring: [16-step block][lane]
   const int n_nw = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
   const int n_gl = gl_work ? *gl_nwork_dev : 0;            // gapless items ride along: same factors/product tail
   const int nwork = n_nw + n_gl;
@@ -797,7 +793,6 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
       uint32_t cb = cbytes[i - 1], rb = rbytes[j - 1];
       const bool g_first = g == 0, g_last = ghost || g == GL - 1;
       const bool kok0 = !ghost && 2 * g >= org && 2 * g < W + org, kok1 = !ghost && 2 * g + 1 >= org && 2 * g + 1 < W + org;
-      const bool colok = !ghost && g < NCOL;
       const int gs0 = kok0 ? (DEF ? -8 : GAP) : AD_OOB, gs1 = kok1 ? (DEF ? -8 : GAP) : AD_OOB;
       // Steady state [tA, tB): every in-band cell of every alignment in the wave is interior and off the
       // last row / column (i >= 1, j >= 1, i < L1, j < L2 for all k in the band).
@@ -807,7 +802,7 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
       for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
       tA = gcn_readfirstlane(tA);
       tB = gcn_readfirstlane(tB);
-#define AD_FLUSH(TT) { if (colok) ptr[((TT) >> 4) * NCOL + g] = pw; pw = 0; }
+#define AD_FLUSH(TT) { pg[(size_t)((TT) >> 4) * 64 + lane] = pw; pw = 0; }   /* every lane, unconditionally: one 256-byte store */
 #define AD_FULL_STEP(TT)                                                                                                        \
   {                                                                                                                             \
     if (((TT) & 1) == 0)                                                                                                        \
@@ -845,7 +840,7 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
 #undef AD_LEAN_PAIR
 #undef AD_FULL_STEP
 #undef AD_FLUSH
-      if (((t - 1) & 15) != 15 && colok) ptr[((t - 1) >> 4) * NCOL + g] = pw;
+      if (((t - 1) & 15) != 15) pg[(size_t)((t - 1) >> 4) * 64 + lane] = pw;
     }
     // ---- traceback (first lane of each group) in chunks of <= AD_RCAP merged runs, expanded by all lanes into one
     //      transition code per raw position.  Run: pj_lo (12 b) | n (12 b) << 12 | (delta + 128) << 24, delta = pi - pj;
@@ -884,7 +879,7 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
         const int tt = __shfl(ti + tj, gl0, 64), col = __shfl((tj - ti + lbo) >> 1, gl0, 64);
         const int f0 = tt & 15, widx = (tt >> 4) - g;
         uint32_t word = 0x55555555u;                       // (before the matrix: never reached, the axis cells stop the run)
-        if (gact && !ghost && widx >= 0) word = ptr[widx * NCOL + col];
+        if (gact && !ghost && widx >= 0) word = pg[(size_t)widx * 64 + gl0 + col];
         const int ftop = g == 0 ? f0 : 14 + (f0 & 1);
         // fields of the path cell's parity at positions <= ftop that are NOT diagonal (01)
         const uint32_t x = word ^ 0x55555555u;
@@ -940,40 +935,47 @@ __global__ __launch_bounds__(256, 3) void k_nw_ad(NwArgs a, const int32_t *__res
               if (a.view && active)
                 a.view[vr * a.LV + pj + dl - 128] = (uint16_t)(0x8000u | (rb << 8) | (a.ap.use_quals ? qlds[pj] : 0));
             }
-            tcode[pj] = (uint8_t)tc;
+            foff[pj] = (uint16_t)((tc * (uint32_t)a.ap.ncol + (a.ap.use_quals ? qlds[pj] : 0u)) << 3);   // &err[t(pj)][q(pj)] - err, in bytes
           }
         }
       }
       if (__all(done)) break;
     }
-    // ---- factors e[pj] = err[t(pj)][q(pj)] (they overwrite the pointer area, no longer needed) ----------------
-    if (!(dbg & 4) && !ghost)
-      for (int pj = g; pj < L2; pj += GL) {
-        const uint32_t q = a.ap.use_quals ? qlds[pj] : 0u;
-        fac[pj] = s_err[(uint32_t)tcode[pj] * a.ap.ncol + q];
-      }
     // hamming: group sum through LDS (group sizes are not powers of two); the run buffer is free by now
     if (g == 0 && !ghost) runs[0] = 0;
     gcn_wave_sync();
     if (!ghost && h) atomicAdd(&runs[0], h);
     gcn_wave_sync();                                       // (also: every lane's factors are in LDS before one lane multiplies them)
     h = runs[0];
-    // ---- lambda: sequential product in raw-position order (pval.cpp:188-192), one lane per alignment ---------
+    // ---- lambda: sequential product in raw-position order (pval.cpp:188-192), one lane per alignment.  The factors are
+    //      fetched straight from the LDS copy of err through the offsets the expansion left: eight offsets per 16-byte read,
+    //      the next eight factors on their way while the current eight are multiplied (the product itself stays strictly
+    //      sequential) ---------
     if (g == 0 && active && !(dbg & 8)) {
+      const char *eb = (const char *)s_err;
+      auto fetch8 = [&](int pj, double (&f)[8]) __attribute__((always_inline)) {
+        const uint4 o = *(const uint4 *)(foff + pj);
+        f[0] = *(const double *)(eb + (o.x & 0xFFFFu)); f[1] = *(const double *)(eb + (o.x >> 16));
+        f[2] = *(const double *)(eb + (o.y & 0xFFFFu)); f[3] = *(const double *)(eb + (o.y >> 16));
+        f[4] = *(const double *)(eb + (o.z & 0xFFFFu)); f[5] = *(const double *)(eb + (o.z >> 16));
+        f[6] = *(const double *)(eb + (o.w & 0xFFFFu)); f[7] = *(const double *)(eb + (o.w >> 16));
+      };
       double l = 1.0;
       int pj = 0;
-      if (L2 >= 8) {   // the next eight factors are on their way from LDS while the current eight are multiplied (the product
-                       // itself stays strictly sequential: pval.cpp:188-192)
-        double f0 = fac[0], f1 = fac[1], f2 = fac[2], f3 = fac[3], f4 = fac[4], f5 = fac[5], f6 = fac[6], f7 = fac[7];
+      if (L2 >= 8) {
+        double f[8], n[8];
+        fetch8(0, f);
         for (pj = 8; pj + 8 <= L2; pj += 8) {
-          const double n0 = fac[pj], n1 = fac[pj + 1], n2 = fac[pj + 2], n3 = fac[pj + 3];
-          const double n4 = fac[pj + 4], n5 = fac[pj + 5], n6 = fac[pj + 6], n7 = fac[pj + 7];
-          l = l * f0; l = l * f1; l = l * f2; l = l * f3; l = l * f4; l = l * f5; l = l * f6; l = l * f7;
-          f0 = n0; f1 = n1; f2 = n2; f3 = n3; f4 = n4; f5 = n5; f6 = n6; f7 = n7;
+          fetch8(pj, n);
+#pragma unroll
+          for (int k = 0; k < 8; k++) l = l * f[k];
+#pragma unroll
+          for (int k = 0; k < 8; k++) f[k] = n[k];
         }
-        l = l * f0; l = l * f1; l = l * f2; l = l * f3; l = l * f4; l = l * f5; l = l * f6; l = l * f7;
+#pragma unroll
+        for (int k = 0; k < 8; k++) l = l * f[k];
       }
-      for (; pj < L2; pj++) l = l * fac[pj];
+      for (; pj < L2; pj++) l = l * *(const double *)(eb + foff[pj]);
       a.lam[r] = l;
       a.ham[r] = h;
     }
@@ -993,10 +995,10 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev; a.stop_dev = d_stop_dev;
   { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
-  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
+  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.APW * G.per_al_bytes;
   int waves = (std::max(maxwork, 1) + G.APW - 1) / G.APW;
   if (d_gl_work) waves = (S.N + G.APW - 1) / G.APW;
-  int grid = std::min((waves + 3) / 4, 256 * 8);
+  int grid = std::max(1, std::min((waves + 3) / 4, std::min(256 * 8, S.ad_waves / 4)));   // one slot of the pointer ring per wave
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
 #define D2_LAUNCH_AD(GLV, DEFV, EDGEV, VARV)                                                                                 \
   do {                                                                                                                   \
@@ -1032,11 +1034,11 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap) { return ad_geom(ap.band, S.maxlen, S.minlen).APW; }
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
-  if (ap.band <= 0 || S.maxlen > 2047) return 0;
+  if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || !S.ad_ptr) return 0;   // (factor offsets are u16: 16 * ncol * 8 < 65 536)
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 127) return 0;
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
-  return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_words * 4;
+  return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.APW * G.per_al_bytes;
 }
 
 // ------------------------------------------------------------------------------------------------

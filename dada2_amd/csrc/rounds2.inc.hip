@@ -62,12 +62,6 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
 // k2_lists - greedy skip already applied with the lock state of the commit - lambda / hamming from the aligner).
 // Most uniques of a large sample never get a second stored comparison: for them the arg-max is partition 0 whatever the
 // reads are, and the pass touches 8 bytes of their state.
-// Streaming shape: one thread takes FOUR consecutive uniques; everything their common cases need is requested up front as
-// 16-byte vectors (second-entry partition, chain head, partition, the two inline lambdas; with STORE also class, lambda,
-// hamming and E_minmax of the round) - one memory round trip per thread - and the sample is a single wave of blocks (977
-// at 10^6 uniques), so the per-block prologue (partition reads into LDS) and epilogue (movers / new blocks / deltas out)
-// are paid once.
-constexpr int SH_PER = 4;
 template <bool STORE>
 __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   const Ctl2 *ctl = E.ctl;
@@ -83,7 +77,7 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   }
   // movers and new store blocks are buffered per block in LDS and written out once at the end: ONE device atomic per block
   // for each of the two counters (thousands of same-address atomics per launch were most of this kernel's time)
-  constexpr int MOVCAP = 256 * SH_PER, NEWCAP = 512;
+  constexpr int MOVCAP = 1024, NEWCAP = 512;
   __shared__ int s_n, s_base, s_an, s_abase;
   __shared__ int32_t s_mov[3 * MOVCAP];
   __shared__ int32_t s_newr[NEWCAP], s_newhead[NEWCAP];
@@ -99,32 +93,29 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   const int N = S.N;
   const int nclust = ctl->nclust, ci = nclust - 1, centre = ctl->centre;
   const int ntab = nclust < DELTA_TAB ? nclust : DELTA_TAB;
-  // ---- this thread's four uniques: every load of the common cases, independent of one another ----
-  const int r0 = (blockIdx.x * 256 + threadIdx.x) * SH_PER;
-  const bool on = r0 < N;
-  int4 v_i1 = make_int4(-1, -1, -1, -1), v_head = v_i1, v_from = make_int4(0, 0, 0, 0);
-  double v_lam0[SH_PER] = {0, 0, 0, 0}, v_lam1[SH_PER] = {0, 0, 0, 0}, v_l[SH_PER] = {0, 0, 0, 0}, v_em[SH_PER] = {0, 0, 0, 0};
-  uint4 v_h = make_uint4(0, 0, 0, 0);
-  uint32_t v_cls = 0;
-  if (on) {
-    v_i1 = *(const int4 *)(T.i1 + r0);
-    v_head = *(const int4 *)(T.head + r0);
-    v_from = *(const int4 *)(P.clust_of + r0);
-    const uint4 a0 = *(const uint4 *)(T.lam0 + r0), a1 = *(const uint4 *)(T.lam0 + r0 + 2);
-    const uint4 b0 = *(const uint4 *)(T.lam1 + r0), b1 = *(const uint4 *)(T.lam1 + r0 + 2);
-    __builtin_memcpy(&v_lam0[0], &a0, 16); __builtin_memcpy(&v_lam0[2], &a1, 16);
-    __builtin_memcpy(&v_lam1[0], &b0, 16); __builtin_memcpy(&v_lam1[2], &b1, 16);
-    if (STORE) {
-      v_cls = *(const uint32_t *)(E.cls + r0);
-      const uint4 c0 = *(const uint4 *)(E.lam + r0), c1 = *(const uint4 *)(E.lam + r0 + 2);
-      const uint4 d0 = *(const uint4 *)(P.E_minmax + r0), d1 = *(const uint4 *)(P.E_minmax + r0 + 2);
-      __builtin_memcpy(&v_l[0], &c0, 16); __builtin_memcpy(&v_l[2], &c1, 16);
-      __builtin_memcpy(&v_em[0], &d0, 16); __builtin_memcpy(&v_em[2], &d1, 16);
-      v_h = *(const uint4 *)(E.ham + r0);
+  // A call after the chain's first one only has to look at the uniques the PREVIOUS call can have unsettled.  After a call
+  // every unique that is not a centre sits in the arg-max of lambda * reads over its stored comparisons (it was moved there,
+  // or it was there already), so it can only want to move now if the reads of its own partition went DOWN in that call or
+  // the reads of another partition it holds a comparison with went UP (ties go to the lowest partition before and after:
+  // a falling rival or a rising home cannot change the winner).  s_sgn[k] = sign of partition k's net reads delta of the
+  // previous call; everybody else leaves after reading 12 bytes.
+  const bool filt = !STORE && level >= 1;
+  __shared__ int8_t s_sgn[DELTA_TAB];
+  __shared__ int s_anyinc;
+  const int32_t *dlp = E.dlt + (size_t)(level >= 1 ? level - 1 : 0) * E.ccap;
+  if (filt && threadIdx.x == 0) s_anyinc = 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < ntab; k += 256) {
+    s_delta[k] = 0; s_reads[k] = reads_at(E, k, level);
+    if (filt) {
+      const int32_t d = dlp[k];
+      s_sgn[k] = d < 0 ? -1 : (d > 0 ? 1 : 0);
+      if (d > 0) s_anyinc = 1;
     }
   }
-  for (int k = threadIdx.x; k < ntab; k += 256) { s_delta[k] = 0; s_reads[k] = reads_at(E, k, level); }
   __syncthreads();
+  const bool anyinc = filt ? (s_anyinc != 0 || nclust > ntab) : true;
+  auto sgn_of = [&](int i) __attribute__((always_inline)) -> int { if (i < ntab) return s_sgn[i]; const int32_t d = dlp[i]; return d < 0 ? -1 : (d > 0 ? 1 : 0); };
   auto rd_at = [&](int i) __attribute__((always_inline)) -> uint32_t { return i < ntab ? s_reads[i] : reads_at(E, i, level); };
   int32_t *mv = E.movers + ((size_t)(ring * SH_CHAIN + level)) * 3 * (size_t)N;
   int32_t *dl = E.dlt + (size_t)level * E.ccap;
@@ -132,87 +123,94 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   const uint32_t reads_ci = STORE ? rd_at(ci) : 0u;
   const uint32_t reads_0 = rd_at(0);
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
-  const int i1s[SH_PER] = {v_i1.x, v_i1.y, v_i1.z, v_i1.w}, heads[SH_PER] = {v_head.x, v_head.y, v_head.z, v_head.w};
-  const int froms[SH_PER] = {v_from.x, v_from.y, v_from.z, v_from.w};
-  const uint32_t hs[SH_PER] = {v_h.x, v_h.y, v_h.z, v_h.w};
-#pragma unroll
-  for (int q = 0; q < SH_PER; q++) {
-    const int r = r0 + q;
-    if (r >= N) break;
+  for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
+    const int r = base + threadIdx.x;
     bool keep = false, need_new = false, move = false;
     double l = 0.0, best_l = 0.0;
     uint32_t h = 0, best_h = 0;
-    int hcnt = 3, to = 0;
-    const int i1 = i1s[q], from = froms[q];
-    const double lam0_r = v_lam0[q], lam1_r = v_lam1[q];
-    const int head = i1 >= 0 ? heads[q] : -1;                            // (a chain only exists behind a used second entry)
-    if (STORE) {
-      const uint32_t cl = (v_cls >> (8 * q)) & 0xFFu;
-      if (cl >= CLS_GAPLESS) {
-        l = v_l[q]; h = hs[q];
-        const double em = v_em[q];
-        if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);          // "Lambda out-of-range error." (cluster.cpp:184)
-        keep = l * E.total_reads > em;                                 // this partition could attract this unique
-        if (keep) {
-          my_keep++;
-          if (l * creads_c > em) P.E_minmax[r] = l * creads_c;
-          if (r == centre) { P.comp_i[r] = ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
+    int head = -1, hcnt = 3, apos = 0, pos = 0, from = 0, to = 0;
+    if (r < N) {
+      // everything the common cases need is requested up front, independent of one another: ONE memory round trip instead
+      // of a chain of three (the kernel is latency-bound; by the later rounds most uniques hold a second comparison)
+      const int i1 = T.i1[r];
+      const int head_raw = T.head[r];
+      from = P.clust_of[r];
+      bool need = true;
+      if (filt)   // (a unique with one stored comparison never moves; chains are not walked for the test: any rise counts)
+        need = i1 >= 0 && (sgn_of(from) < 0 || (anyinc && ((from != 0 && sgn_of(0) > 0) || (i1 != from && sgn_of(i1) > 0) || head_raw >= 0)));
+      if (need) {
+      const double lam0_r = T.lam0[r], lam1_r = T.lam1[r];
+      const uint8_t cl = STORE ? E.cls[r] : (uint8_t)0;
+      const double l_raw = STORE ? E.lam[r] : 0.0, em = STORE ? P.E_minmax[r] : 0.0;
+      const uint32_t h_raw = STORE ? E.ham[r] : 0u;
+      head = i1 >= 0 ? head_raw : -1;                                    // (a chain only exists behind a used second entry)
+      if (STORE) {
+        if (cl >= CLS_GAPLESS) {
+          l = l_raw; h = h_raw;
+          if (!(l >= 0.0 && l <= 1.0)) atomicOr(P.err_flag, 1);        // "Lambda out-of-range error." (cluster.cpp:184)
+          keep = l * E.total_reads > em;                               // this partition could attract this unique
+          if (keep) {
+            my_keep++;
+            if (l * creads_c > em) P.E_minmax[r] = l * creads_c;
+            if (r == centre) { P.comp_i[r] = ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
+          }
         }
       }
-    }
-    // arg-max of lambda * reads over the stored comparisons; ties go to the lowest partition (cluster.cpp:229-239)
-    int best_i = 0, best_src = 0;                                        // 0: round-0 entry, 1: second entry, 2: chain block, 3: this round's
-    const CompBlk *best_cb = nullptr;
-    int best_k = 0;
-    if (i1 >= 0 || keep) {
-      best_l = lam0_r;
-      double best_e = best_l * reads_0;
-      if (i1 >= 0) {
-        const double nl = lam1_r, e = nl * rd_at(i1);
-        if (e > best_e || (e == best_e && i1 < best_i)) { best_e = e; best_i = i1; best_l = nl; best_src = 1; }
-      }
-      for (int b = head, first = 1, hops = 0; b >= 0 && hops < (1 << 22); first = 0, hops++) {   // (bounded: never spin on a bad link)
-        const CompBlk *cb = T.blk + b;
-        const int cnt = cb->cnt;
-        if (first) hcnt = cnt;
+      // arg-max of lambda * reads over the stored comparisons; ties go to the lowest partition (cluster.cpp:229-239)
+      int best_i = 0, best_src = 0;                                      // 0: round-0 entry, 1: second entry, 2: chain block, 3: this round's
+      const CompBlk *best_cb = nullptr;
+      int best_k = 0;
+      if (i1 >= 0 || keep) {
+        best_l = lam0_r;
+        double best_e = best_l * reads_0;
+        if (i1 >= 0) {
+          const double nl = lam1_r, e = nl * rd_at(i1);
+          if (e > best_e || (e == best_e && i1 < best_i)) { best_e = e; best_i = i1; best_l = nl; best_src = 1; }
+        }
+        for (int b = head, first = 1, hops = 0; b >= 0 && hops < (1 << 22); first = 0, hops++) {   // (bounded: never spin on a bad link)
+          const CompBlk *cb = T.blk + b;
+          const int cnt = cb->cnt;
+          if (first) hcnt = cnt;
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-          if (k < cnt) {
-            const int i = cb->i[k];
-            const double nl = cb->lam[k], e = nl * rd_at(i);
-            if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_cb = cb; best_k = k; best_src = 2; }
-          }
-        b = cb->next;
-      }
-      if (keep) {
-        if (i1 < 0) { T.i1[r] = ci; T.lam1[r] = l; T.ham1[r] = h; }    // the unique's second stored comparison: inline
-        else {
-          need_new = head < 0 || hcnt >= 3;
-          if (!need_new) {                                             // room in the newest block: append in place
-            CompBlk *cb = T.blk + head;
-            cb->i[hcnt] = ci; cb->ham[hcnt] = h; cb->lam[hcnt] = l; cb->cnt = hcnt + 1;
-          }
+          for (int k = 0; k < 3; k++)
+            if (k < cnt) {
+              const int i = cb->i[k];
+              const double nl = cb->lam[k], e = nl * rd_at(i);
+              if (e > best_e || (e == best_e && i < best_i)) { best_e = e; best_i = i; best_l = nl; best_cb = cb; best_k = k; best_src = 2; }
+            }
+          b = cb->next;
         }
-        const double e = l * reads_ci;
-        if (e > best_e) { best_e = e; best_i = ci; best_l = l; best_src = 3; }   // (ci is the highest index: only strictly)
+        if (keep) {
+          if (i1 < 0) { T.i1[r] = ci; T.lam1[r] = l; T.ham1[r] = h; }  // the unique's second stored comparison: inline
+          else {
+            need_new = head < 0 || hcnt >= 3;
+            if (!need_new) {                                           // room in the newest block: append in place
+              CompBlk *cb = T.blk + head;
+              cb->i[hcnt] = ci; cb->ham[hcnt] = h; cb->lam[hcnt] = l; cb->cnt = hcnt + 1;
+            }
+          }
+          const double e = l * reads_ci;
+          if (e > best_e) { best_e = e; best_i = ci; best_l = l; best_src = 3; }   // (ci is the highest index: only strictly)
+        }
       }
-    }
-    if (best_i != from && r != P.centre_of[from]) {
-      move = true;
-      to = best_i;
-      if (best_src == 0) { best_l = lam0_r; best_h = T.ham0[r]; }
-      else if (best_src == 1) best_h = T.ham1[r];
-      else if (best_src == 2) best_h = best_cb->ham[best_k];
-      else best_h = h;
-      P.clust_of[r] = to;
-      P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
-      const uint32_t rd = S.reads[r];
-      if (to < ntab) atomicAdd(&s_delta[to], (int32_t)rd); else atomicAdd(&dl[to], (int32_t)rd);
-      if (from < ntab) atomicSub(&s_delta[from], (int32_t)rd); else atomicSub(&dl[from], (int32_t)rd);
-      P.update_e[to] = 1; P.update_e[from] = 1;
+      if (best_i != from && r != P.centre_of[from]) {
+        move = true;
+        to = best_i;
+        if (best_src == 0) { best_l = lam0_r; best_h = T.ham0[r]; }
+        else if (best_src == 1) best_h = T.ham1[r];
+        else if (best_src == 2) best_h = best_cb->ham[best_k];
+        else best_h = h;
+        P.clust_of[r] = to;
+        P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
+        const uint32_t rd = S.reads[r];
+        if (to < ntab) atomicAdd(&s_delta[to], (int32_t)rd); else atomicAdd(&dl[to], (int32_t)rd);
+        if (from < ntab) atomicSub(&s_delta[from], (int32_t)rd); else atomicSub(&dl[from], (int32_t)rd);
+        P.update_e[to] = 1; P.update_e[from] = 1;
+      }
+      }   // need
     }
     if (need_new) {
-      const int apos = atomicAdd(&s_an, 1);
+      apos = atomicAdd(&s_an, 1);
       if (apos < NEWCAP) { s_newr[apos] = r; s_newhead[apos] = head; s_newh[apos] = h; s_newl[apos] = l; }
       else {   // (more new blocks in one thread block than the buffer holds: straight to the device counter)
         const int nb = atomicAdd(T.blk_count, 1);
@@ -224,12 +222,19 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
       }
     }
     if (move) {
-      const int pos = atomicAdd(&s_n, 1);                                // (< MOVCAP: a block holds MOVCAP uniques)
-      s_mov[3 * pos] = r; s_mov[3 * pos + 1] = from; s_mov[3 * pos + 2] = to;
+      pos = atomicAdd(&s_n, 1);
+      if (pos < MOVCAP) { s_mov[3 * pos] = r; s_mov[3 * pos + 1] = from; s_mov[3 * pos + 2] = to; }
+      else {
+        const int k = atomicAdd(&out->cnt[level], 1);
+        int32_t *m = mv + 3 * (size_t)k;
+        m[0] = r; m[1] = from; m[2] = to;
+        const int ki = moved_before + k;
+        if (ki < MOV_INLINE2) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
+      }
     }
   }
   __syncthreads();                                                       // the block's movers / new blocks are all buffered
-  const int nmov = s_n, nnew = min(s_an, NEWCAP);
+  const int nmov = min(s_n, MOVCAP), nnew = min(s_an, NEWCAP);
   if (threadIdx.x == 0) {
     s_base = nmov ? atomicAdd(&out->cnt[level], nmov) : 0;
     s_abase = nnew ? atomicAdd(T.blk_count, nnew) : 0;
@@ -364,9 +369,7 @@ static __device__ __forceinline__ bool bud_candidate2(const Eng2 &E, int r, int 
 // k2_birth looks for the ties / near ties of the best key and for the likely next centres among those few, not among all
 // uniques.
 constexpr int PUPD_TAB = 1024;    // partitions whose per-partition facts k2_pupdate keeps in LDS
-// Streaming shape as k2_shuffle: four consecutive uniques per thread, their nine per-unique fields requested up front as
-// vectors, the sample in one wave of blocks.
-constexpr int PU_PER = 4;
+constexpr int SIG_CAP = 1024;
 __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init, BudKey *__restrict__ partial) {
   const Ctl2 *ctl = E.ctl;
   if (ctl->state != 0) return;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
   if (!cs.eval_ok) return;
   __shared__ BudKey s_k[2][4];
-  __shared__ int32_t s_sig[256 * PU_PER];
+  __shared__ int32_t s_sig[SIG_CAP];
   __shared__ int s_nsig, s_sbase;
   // what a unique needs from ITS PARTITION (reads, update / lock flags, the centre and its reads) sits in LDS: the loads
   // behind clust_of[r] were a chain of three global round trips per unique in a latency-bound kernel
@@ -383,23 +386,6 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   __shared__ uint8_t s_upd[PUPD_TAB], s_chk[PUPD_TAB];
   const PartState &P = E.P;
   const SampleDev &S = E.S;
-  const int N = S.N;
-  const int r0 = (blockIdx.x * 256 + threadIdx.x) * PU_PER;
-  int4 v_cl = make_int4(0, 0, 0, 0);
-  uint4 v_rd = make_uint4(0, 0, 0, 0), v_ham = v_rd;
-  uint32_t v_pr = 0, v_s0 = 0;
-  double v_l[PU_PER] = {0, 0, 0, 0}, v_p[PU_PER] = {0, 0, 0, 0};
-  if (r0 < N) {
-    v_cl = *(const int4 *)(P.clust_of + r0);
-    v_rd = *(const uint4 *)(S.reads + r0);
-    v_ham = *(const uint4 *)(P.comp_ham + r0);
-    v_pr = *(const uint32_t *)(S.prior + r0);
-    v_s0 = *(const uint32_t *)(P.slot0 + r0);
-    const uint4 a0 = *(const uint4 *)(P.comp_lam + r0), a1 = *(const uint4 *)(P.comp_lam + r0 + 2);
-    const uint4 b0 = *(const uint4 *)(P.p + r0), b1 = *(const uint4 *)(P.p + r0 + 2);
-    __builtin_memcpy(&v_l[0], &a0, 16); __builtin_memcpy(&v_l[2], &a1, 16);
-    __builtin_memcpy(&v_p[0], &b0, 16); __builtin_memcpy(&v_p[2], &b1, 16);
-  }
   const int ntab = min(ctl->nclust, PUPD_TAB);
   for (int k = threadIdx.x; k < ntab; k += 256) {
     const int c = P.centre_of[k];
@@ -412,19 +398,14 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   if (threadIdx.x == 0) s_nsig = 0;
   __syncthreads();
   BudKey b0 = init, b1 = init;
-  const int cls_[PU_PER] = {v_cl.x, v_cl.y, v_cl.z, v_cl.w};
-  const uint32_t rds[PU_PER] = {v_rd.x, v_rd.y, v_rd.z, v_rd.w}, hams[PU_PER] = {v_ham.x, v_ham.y, v_ham.z, v_ham.w};
-#pragma unroll
-  for (int q = 0; q < PU_PER; q++) {
-    const int r = r0 + q;
-    if (r >= N) break;
-    const int cl = cls_[q];
-    const double l = v_l[q];
-    const uint32_t reads = rds[q];
-    const uint32_t ham = hams[q];
-    const bool pr = ((v_pr >> (8 * q)) & 0xFFu) != 0;
-    const bool s0 = ((v_s0 >> (8 * q)) & 0xFFu) != 0;
-    double p = v_p[q];
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+    const int cl = P.clust_of[r];
+    const double l = P.comp_lam[r];
+    const uint32_t reads = S.reads[r];
+    const uint32_t ham = P.comp_ham[r];
+    const bool pr = S.prior[r] != 0;
+    const bool s0 = P.slot0[r] != 0;
+    double p = P.p[r];
     const bool intab = cl < ntab;
     const uint32_t prd = intab ? s_prd[cl] : reads_at(E, cl, cs.nexec);
     if (intab ? s_upd[cl] : P.update_e[cl]) {
@@ -443,7 +424,10 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
     if (!(E.bp.min_fold <= 1 || ((double)reads) >= E.bp.min_fold * l * prd)) continue;
     if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
     if (pr && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
-    if (p * S.N < 2.0 * E.bp.omegaA || (pr && p < 2.0 * E.bp.omegaP)) s_sig[atomicAdd(&s_nsig, 1)] = r;   // (a block holds 256 * PU_PER uniques)
+    if (p * S.N < 2.0 * E.bp.omegaA || (pr && p < 2.0 * E.bp.omegaP)) {
+      const int q = atomicAdd(&s_nsig, 1);
+      if (q < SIG_CAP) s_sig[q] = r; else E.sig_list[atomicAdd(E.sig_n, 1)] = r;
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -463,10 +447,11 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
     }
     partial[2 * blockIdx.x] = b0;
     partial[2 * blockIdx.x + 1] = b1;
-    s_sbase = s_nsig ? atomicAdd(E.sig_n, s_nsig) : 0;                 // one global atomic per block
+    const int n = min(s_nsig, SIG_CAP);
+    s_sbase = n ? atomicAdd(E.sig_n, n) : 0;                           // one global atomic per block
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < s_nsig; i += 256) E.sig_list[s_sbase + i] = s_sig[i];
+  for (int i = threadIdx.x; i < min(s_nsig, SIG_CAP); i += 256) E.sig_list[s_sbase + i] = s_sig[i];
 }
 
 // ---- the birth, the plan of the coming round's compare, and the publication of the round's result block -----------------
@@ -998,11 +983,11 @@ void launch2_lists(const Eng2 &E, hipStream_t st) {
   hipLaunchKernelGGL(k2_lists, dim3(grid), dim3(256), 0, st, E);
 }
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st) {
-  const int grid = (E.S.N + 256 * SH_PER - 1) / (256 * SH_PER);          // one wave of blocks: four uniques per thread
+  const int grid = std::min((E.S.N + 255) / 256, 2048);   // one device atomic per counter per block; 2048 blocks measured best at 1M uniques
   if (store) hipLaunchKernelGGL(k2_shuffle<true>, dim3(grid), dim3(256), 0, st, E, level);
   else hipLaunchKernelGGL(k2_shuffle<false>, dim3(grid), dim3(256), 0, st, E, level);
 }
-int launch2_eval_blocks(int N) { return (N + 256 * PU_PER - 1) / (256 * PU_PER); }   // k2_pupdate's grid = entries of E.partial / 2
+int launch2_eval_blocks(int N) { return std::min((N + 255) / 256, 1024); }   // k2_pupdate's grid = entries of E.partial / 2
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st) {
   BudKey init{1.0, init_reads};
   const int grid = launch2_eval_blocks(E.S.N);

@@ -21,6 +21,8 @@ for s in $STEPS; do
     tests_iter) timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not at_size and not 1M" --durations=10 > $OUT/gputests_iter.log 2>&1; echo "tests_iter rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_iter.log ;;
     peaks)   timeout 300 tools/microbench peaks > $OUT/peaks.json 2> $OUT/peaks.err; echo "peaks rc=$?" >> $OUT/steps.log; cat $OUT/peaks.json ;;
     bench3)  timeout 1200 python bench.py --steps 5 --warmup 2 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; echo "bench3 rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3.json ;;
+    bench3q) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg3_quick.json 2> $OUT/bench_cfg3_quick.err; echo "bench3q rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg3_quick.json; python3 -c "import json;b=json.load(open('$OUT/bench_cfg3_quick.json'));print(b['resident']);print(b['phases_ms_last_step'])" ;;
+    nwphases) timeout 600 python tools/nw_phases.py --sizes 4000,8700,18000,36000 > $OUT/nw_phases.jsonl 2> $OUT/nw_phases.err; echo "nwphases rc=$?" >> $OUT/steps.log; cat $OUT/nw_phases.jsonl ;;
     bench3full) timeout 1200 python bench.py --steps 5 --warmup 2 --cpu-full > $OUT/bench_cfg3_cpufull.json 2> $OUT/bench_cfg3_cpufull.err; echo "bench3full rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_cpufull.json ;;
     bench3sc) timeout 900 python bench.py --steps 2 --warmup 1 --selfconsist > $OUT/bench_cfg3_selfconsist.json 2> $OUT/bench_cfg3_selfconsist.err; echo "bench3sc rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_selfconsist.json ;;
     bench2)  timeout 600 python bench.py --config 2 --steps 10 --warmup 2 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; echo "bench2 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2.json ;;
@@ -29,16 +31,16 @@ for s in $STEPS; do
     bench5)  timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; echo "bench5 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg5.json ;;
     prof3|prof2|prof5)
              CFG=${s#prof}; P=$OUT/prof$CFG; mkdir -p $P
-             CMD="python $ROOT/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass"
+             CMD="python $ROOT/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras"
              ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $P/trace -o trace -- $CMD > $P/trace.log 2>&1 ); echo "$s rc=$?" >> $OUT/steps.log
-             python3 profiles/summarize.py $P ${TAG}_cfg$CFG $OUT/summaries "python bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass" > $P/summarize.log 2>&1 ;;
+             python3 profiles/summarize.py $P ${TAG}_cfg$CFG $OUT/summaries "python bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras" > $P/summarize.log 2>&1 ;;
     pmc3|pmc2)
              CFG=${s#pmc}; P=$OUT/prof$CFG; mkdir -p $P
-             CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass"
+             CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras"
              ( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $P/pmc_fetch -o fetch -- $CMD > $P/pmc_fetch.log 2>&1 )
              ( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d $P/pmc_write -o write -- $CMD > $P/pmc_write.log 2>&1 )
              ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $P/pmc_valu -o valu -- $CMD > $P/pmc_valu.log 2>&1 )
-             python3 profiles/summarize.py $P ${TAG}_cfg$CFG $OUT/summaries "python bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass" > $P/summarize.log 2>&1
+             python3 profiles/summarize.py $P ${TAG}_cfg$CFG $OUT/summaries "python bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras" > $P/summarize.log 2>&1
              echo "$s done" >> $OUT/steps.log ;;
     bench3t16|bench3t64|bench3t128) T=${s#bench3t}; DADA2HIP_HOST_THREADS=$T timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile-pass > $OUT/bench_cfg3_threads$T.json 2> $OUT/bench_cfg3_threads$T.err; echo "$s rc=$?" >> $OUT/steps.log; cut -c1-300 $OUT/bench_cfg3_threads$T.json ;;
     sweep)   timeout 600 python tools/sweep_env.py --config 3 --reps 3 --list "${SWEEP:-}" > $OUT/sweep.jsonl 2> $OUT/sweep.err; echo "sweep rc=$?" >> $OUT/steps.log; cut -c1-420 $OUT/sweep.jsonl ;;
