@@ -329,6 +329,8 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   ScreenParams sp;
   const int32_t *thresh;
   int32_t max_shuffle;
+  int32_t sh_filter;                                // later shuffle calls of a chain visit only the uniques the previous call can have unsettled
+  int32_t grid_shuffle, grid_pupdate;               // host side: block caps of the per-round launches (tuning knobs)
 };
 
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
@@ -338,7 +340,6 @@ void launch2_lists(const Eng2 &E, hipStream_t st);                              
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
 // b_p_update + b_bud arg-min (grid) ; ties, decision, birth, plan of the coming round, publication (one block)
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);
-int launch2_eval_blocks(int N);   // blocks of k2_pupdate = (p, reads) key pairs the run must provide in Eng2::partial
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st);            // the host's decision applied + plan; resumes
 void launch2_resume(const Eng2 &E, hipStream_t st);
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,

@@ -4,6 +4,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Cap on the scalar registers of a kernel (the excess is kept in lanes of a vector register): 256-thread blocks are admitted
+// per CU up to floor(800 / (ceil(sgpr / 16) * 16 + 16)), so a kernel that wants 8 blocks per CU has to stay at or below 80.
+#define GCN_SGPR_BUDGET(n) __attribute__((amdgpu_num_sgpr(n)))
+
 namespace d2 {
 
 // max(a, b, c) in one VOP3 instruction (the compiler keeps an inner max when one of its results is also compared)

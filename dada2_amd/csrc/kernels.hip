@@ -1561,7 +1561,7 @@ struct StoreArgs {
 // Reads deltas of the movers are accumulated per block in LDS (partitions < DELTA_TAB) and flushed with one global
 // atomic per touched partition: thousands of movers join the same new partition in a round, and same-address
 // device atomics serialise.
-constexpr int DELTA_TAB = 2048;
+constexpr int DELTA_TAB = 1024;
 template <bool STORE>
 __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const uint32_t *__restrict__ creads_snap,
                                                  int32_t *__restrict__ movers, int32_t *__restrict__ nmovers,

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
 // Most uniques of a large sample never get a second stored comparison: for them the arg-max is partition 0 whatever the
 // reads are, and the pass touches 8 bytes of their state.
 template <bool STORE>
-__global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
+__global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E, int level) {
   const Ctl2 *ctl = E.ctl;
   if (ctl->state != 0) return;
   const int ring = ctl->pub_seq % RING2;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   }
   // movers and new store blocks are buffered per block in LDS and written out once at the end: ONE device atomic per block
   // for each of the two counters (thousands of same-address atomics per launch were most of this kernel's time)
-  constexpr int MOVCAP = 1024, NEWCAP = 512;
+  constexpr int MOVCAP = 256, NEWCAP = 128;
   __shared__ int s_n, s_base, s_an, s_abase;
   __shared__ int32_t s_mov[3 * MOVCAP];
   __shared__ int32_t s_newr[NEWCAP], s_newhead[NEWCAP];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k2_shuffle(Eng2 E, int level) {
   // the reads of another partition it holds a comparison with went UP (ties go to the lowest partition before and after:
   // a falling rival or a rising home cannot change the winner).  s_sgn[k] = sign of partition k's net reads delta of the
   // previous call; everybody else leaves after reading 12 bytes.
-  const bool filt = !STORE && level >= 1;
+  const bool filt = !STORE && level >= 1 && E.sh_filter;
   __shared__ int8_t s_sgn[DELTA_TAB];
   __shared__ int s_anyinc;
   const int32_t *dlp = E.dlt + (size_t)(level >= 1 ? level - 1 : 0) * E.ccap;
@@ -983,14 +983,13 @@ void launch2_lists(const Eng2 &E, hipStream_t st) {
   hipLaunchKernelGGL(k2_lists, dim3(grid), dim3(256), 0, st, E);
 }
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st) {
-  const int grid = std::min((E.S.N + 255) / 256, 2048);   // one device atomic per counter per block; 2048 blocks measured best at 1M uniques
+  const int grid = std::min((E.S.N + 255) / 256, (int)E.grid_shuffle);   // one device atomic per counter per block
   if (store) hipLaunchKernelGGL(k2_shuffle<true>, dim3(grid), dim3(256), 0, st, E, level);
   else hipLaunchKernelGGL(k2_shuffle<false>, dim3(grid), dim3(256), 0, st, E, level);
 }
-int launch2_eval_blocks(int N) { return std::min((N + 255) / 256, 1024); }   // k2_pupdate's grid = entries of E.partial / 2
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st) {
   BudKey init{1.0, init_reads};
-  const int grid = launch2_eval_blocks(E.S.N);
+  const int grid = std::min((E.S.N + 255) / 256, std::min(8192, (int)E.grid_pupdate));   // (Eng2::partial holds 8192 key pairs)
   hipLaunchKernelGGL(k2_pupdate, dim3(grid), dim3(256), 0, st, E, nlev, init, (BudKey *)E.partial);
   hipLaunchKernelGGL(k2_birth, dim3(1), dim3(1024), 0, st, E, nlev, init, (const BudKey *)E.partial, grid);
 }

@@ -13,6 +13,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
 #include <mutex>
 #include <sys/mman.h>
 #include <vector>
@@ -20,6 +23,30 @@
 namespace emu {
 
 Cur cur;
+
+// a crash inside an emulated kernel: print the native frames before dying (fibers run on their own stacks, so the handler
+// gets an alternate one)
+static void on_segv(int sig) {
+  void *frames[48];
+  const int n = backtrace(frames, 48);
+  const char msg[] = "[emu] fatal signal inside the emulated library; native backtrace:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+static const int segv_installed = [] {
+  static char alt[64 * 1024];
+  stack_t ss{};
+  ss.ss_sp = alt; ss.ss_size = sizeof alt;
+  sigaltstack(&ss, nullptr);
+  struct sigaction sa{};
+  sa.sa_handler = on_segv;
+  sa.sa_flags = SA_ONSTACK;
+  sigaction(SIGSEGV, &sa, nullptr);
+  sigaction(SIGBUS, &sa, nullptr);
+  return 1;
+}();
 
 namespace {
 

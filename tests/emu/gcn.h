@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#define GCN_SGPR_BUDGET(n)
+
 namespace d2 {
 
 static inline int gcn_max3(int a, int b, int c) { return std::max(a, std::max(b, c)); }
