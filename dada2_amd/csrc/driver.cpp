@@ -1121,6 +1121,8 @@ struct Run {
   DevBuf<uint16_t> v2_bcls, v2_full, v2_ord;
   DevBuf<uint2> v2_tab8;
   PinBuf<Round2Out> v2_hblk;
+  DevBuf<unsigned long long> v2_trace;   // phase stamps of one traced round (DADA2HIP_V2_TRACE=<sequence number>[:<file>])
+  int v2_trace_seq = -1;
   int v2_nbuf = 64, v2_depth = 2, v2_chain = SH_CHAIN;
   bool v2_debug = false;
   long v2_enq = 0, v2_cons = 0;
@@ -1150,6 +1152,7 @@ struct Run {
     E2.total_reads = (double)(uint32_t)s->total_reads; E2.omegaA = o.omegaA; E2.omegaP = o.omegaP;
     E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
     E2.sp = sp; E2.thresh = d_thresh_round.p; E2.max_shuffle = MAX_SHUFFLE;
+    E2.trace = v2_trace.p; E2.trace_seq = v2_trace_seq;
     E2.sh_filter = 1; E2.grid_shuffle = 2048; E2.grid_pupdate = 1024;
     if (const char *e = getenv("DADA2HIP_V2_FILTER")) E2.sh_filter = atoi(e) != 0;
     if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::max(1, atoi(e));
@@ -1191,6 +1194,12 @@ struct Run {
     for (int k = 0; k < KB_MAX; k++) c.bcentre[k] = -1;
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
     D2_HIP(hipStreamSynchronize(stq));   // `c` is a local
+    v2_trace_seq = -1;
+    if (const char *e = getenv("DADA2HIP_V2_TRACE")) {
+      v2_trace_seq = atoi(e);
+      v2_trace.alloc((size_t)TRACE_KERNELS * TRACE_BLOCKS * 8);
+      D2_HIP(hipMemsetAsync(v2_trace.p, 0, (size_t)TRACE_KERNELS * TRACE_BLOCKS * 64, stq));
+    }
     v2_enq = v2_cons = 0;
     v2_plain_rounds = 0;
     v2_miss_launches = 0;
@@ -1419,6 +1428,13 @@ struct Run {
               n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_big, st.ms_wait_device, st.ms_replay, st.ms_enqueue, t_decide, t_halt, t_top,
               ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches);
     sync_spin(s->stream);                                      // no-op launches queued behind the final halt
+    if (v2_trace_seq >= 0 && v2_trace.p) {                     // dump the traced round's stamps (tools/trace_round.py reads them)
+      const char *e = getenv("DADA2HIP_V2_TRACE");
+      const char *colon = e ? strchr(e, ':') : nullptr;
+      std::vector<unsigned long long> h((size_t)TRACE_KERNELS * TRACE_BLOCKS * 8);
+      D2_HIP(hipMemcpy(h.data(), v2_trace.p, h.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(colon ? colon + 1 : "dada2hip_trace.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
     st.ms_bookkeep += ms_since(t0);
   }
 

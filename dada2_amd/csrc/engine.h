@@ -228,6 +228,7 @@ int nw_adw_apw(const SampleDev &S, const AlignParams &ap);
 constexpr int KB_MAX = 8;          // centres per batch compare (one byte lane each in the packed count table)
 constexpr int SH_CHAIN = 4;        // b_shuffle2 calls enqueued per chain (the first unconditional, the rest guarded)
 constexpr int RING2 = 4;           // result blocks / mover lists in flight
+constexpr int TRACE_BLOCKS = 4096, TRACE_KERNELS = 8;   // (lists, shuffle 0..3, p-update, birth, spare)
 constexpr int MOV_INLINE2 = 8192;  // movers published inline per chain (all its shuffles, concatenated)
 
 // stored comparisons of one unique (Bi::comp entries that name it): the round-0 entry lives in lam0/ham0 (every
@@ -329,6 +330,10 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   ScreenParams sp;
   const int32_t *thresh;
   int32_t max_shuffle;
+  // phase trace of ONE round (tools/trace_round.py; DADA2HIP_V2_TRACE=<block sequence number>): every block of the round's
+  // tail kernels stamps the shader clock at its phase boundaries into trace[(kernel * TRACE_BLOCKS + block) * 8 + phase]
+  unsigned long long *trace;
+  int32_t trace_seq;
   int32_t sh_filter;                                // later shuffle calls of a chain visit only the uniques the previous call can have unsettled
   int32_t grid_shuffle, grid_pupdate;               // host side: block caps of the per-round launches (tuning knobs)
 };

@@ -30,6 +30,8 @@ static __device__ __forceinline__ int gcn_readfirstlane(int v) { return __builti
 // The lanes of a wave execute in lockstep, so data one lane leaves in LDS is there for the others at the next instruction;
 // this marks the places where a kernel relies on that.  No instruction: it only stops the compiler from moving memory
 // operations across the point (and gives the lane-by-lane emulator its rendezvous).
+// shader-clock timestamp (s_memtime) for the in-kernel phase traces of tools/trace_round.py
+static __device__ __forceinline__ unsigned long long gcn_clock() { return __builtin_amdgcn_s_memtime(); }
 static __device__ __forceinline__ void gcn_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
 }  // namespace d2

@@ -8,6 +8,13 @@
 // Every launch reads what it has to do from the device control block (Ctl2): the host enqueues rounds ahead of the
 // results it has seen.
 
+// phase stamps of the traced round (Eng2::trace; nullptr in every normal run)
+#define D2_TRACE(KID, PHASE)                                                                                       \
+  do {                                                                                                             \
+    if (E.trace && threadIdx.x == 0 && (int)blockIdx.x < TRACE_BLOCKS && E.ctl->pub_seq == E.trace_seq)           \
+      E.trace[((size_t)(KID) * TRACE_BLOCKS + blockIdx.x) * 8 + (PHASE)] = gcn_clock();                            \
+  } while (0)
+
 // ---- chain bookkeeping: which shuffle launches of the chain ran, and whether the evaluation after them stands -------
 struct Chain2 { int nexec; bool eval_ok; };
 static __device__ __forceinline__ Chain2 chain_state(const Ctl2 *ctl, const Round2Out *out, int nlev, int max_shuffle) {
@@ -86,6 +93,7 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   __shared__ int32_t s_delta[DELTA_TAB];
   __shared__ uint32_t s_reads[DELTA_TAB];                                // partition reads as of the start of this call
   __shared__ int s_keep;
+  D2_TRACE(1 + level, 0);
   if (threadIdx.x == 0) { s_n = 0; s_an = 0; s_keep = 0; }
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   const uint32_t reads_ci = STORE ? rd_at(ci) : 0u;
   const uint32_t reads_0 = rd_at(0);
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
+  D2_TRACE(1 + level, 1);
   for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
     bool keep = false, need_new = false, move = false;
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
     }
   }
   __syncthreads();                                                       // the block's movers / new blocks are all buffered
+  D2_TRACE(1 + level, 2);
   const int nmov = min(s_n, MOVCAP), nnew = min(s_an, NEWCAP);
   if (threadIdx.x == 0) {
     s_base = nmov ? atomicAdd(&out->cnt[level], nmov) : 0;
@@ -263,10 +273,12 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
     __syncthreads();
     if (threadIdx.x == 0 && s_keep) atomicAdd(&out->pad0[0], s_keep);   // Comparisons kept this round (cluster.cpp:189-199)
   }
+  D2_TRACE(1 + level, 3);
   for (int k = threadIdx.x; k < ntab; k += 256) {
     const int32_t d = s_delta[k];
     if (d) atomicAdd(&dl[k], d);
   }
+  D2_TRACE(1 + level, 4);
 }
 
 // ---- commit of a cached compare: classes of the round's centre from the batch buffer, the greedy skip of cluster.cpp:127-130
@@ -287,6 +299,7 @@ __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
   const int slot = ctl->slot, kpos = slot % KB_MAX, centre = ctl->centre;
   const uint16_t *bcls = E.C.bcls + (size_t)(slot / KB_MAX) * E.C.Npad;
   const uint32_t creads_c = S.reads[centre];
+  D2_TRACE(0, 0);
   if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
   if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
   const int r0 = (blockIdx.x * 256 + threadIdx.x) * LISTS_PER_THREAD;
@@ -350,8 +363,10 @@ __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
     atomicAdd(&out->stat[threadIdx.x], (unsigned long long)s_stat[threadIdx.x]);
   }
   __syncthreads();
+  D2_TRACE(0, 1);
   for (int i = threadIdx.x; i < s_cnt[0]; i += 256) E.nw_list[s_cnt[4] + i] = s_nw[i];
   for (int i = threadIdx.x; i < s_cnt[1]; i += 256) E.gl_list[s_cnt[5] + i] = s_gl[i];
+  D2_TRACE(0, 2);
 }
 
 // ---- b_p_update + first stage of b_bud (no "would another shuffle move" pass: the chain's shuffles are real calls) -----
@@ -387,6 +402,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   const int ntab = min(ctl->nclust, PUPD_TAB);
+  D2_TRACE(5, 0);
   for (int k = threadIdx.x; k < ntab; k += 256) {
     const int c = P.centre_of[k];
     s_prd[k] = reads_at(E, k, cs.nexec);
@@ -398,6 +414,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   if (threadIdx.x == 0) s_nsig = 0;
   __syncthreads();
   BudKey b0 = init, b1 = init;
+  D2_TRACE(5, 1);
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
     const int cl = P.clust_of[r];
     const double l = P.comp_lam[r];
@@ -429,6 +446,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
       if (q < SIG_CAP) s_sig[q] = r; else E.sig_list[atomicAdd(E.sig_n, 1)] = r;
     }
   }
+  D2_TRACE(5, 2);
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     BudKey t;
@@ -452,6 +470,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   }
   __syncthreads();
   for (int i = threadIdx.x; i < min(s_nsig, SIG_CAP); i += 256) E.sig_list[s_sbase + i] = s_sig[i];
+  D2_TRACE(5, 3);
 }
 
 // ---- the birth, the plan of the coming round's compare, and the publication of the round's result block -----------------
@@ -666,6 +685,9 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
   Round2Out *out = E.dblk + ring;
   const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
   const int nclust = ctl->nclust;
+  const bool tr = E.trace && ctl->pub_seq == E.trace_seq && threadIdx.x == 0;
+#define D2_TRB(PHASE) do { if (tr) E.trace[((size_t)6 * TRACE_BLOCKS) * 8 + (PHASE)] = gcn_clock(); } while (0)
+  D2_TRB(0);
   // fold the chain's partition-read deltas into the reads
   for (int i = threadIdx.x; i < nclust; i += blockDim.x) {
     int32_t d = 0;
@@ -674,6 +696,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
   }
   if (threadIdx.x < 2) s_nt[threadIdx.x] = 0;
   __syncthreads();
+  D2_TRB(1);
   // ---- second stage of b_bud's arg-min (cluster.cpp:284-308): the block minima of k2_pupdate, then the exact ties of the
   //      best key and every other listed candidate whose non-zero p is within BUD_NEAR of it (engine.h) ----
   if (cs.eval_ok) {
@@ -736,6 +759,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
     }
   }
   __syncthreads();
+  D2_TRB(2);
   if (threadIdx.x == 0) {
     out->nlev = nlev; out->nsh = cs.nexec; out->slot = ctl->slot; out->nbatch = ctl->nbatch;
     out->err_flag = *P.err_flag | (*S.nw_flag ? 4 : 0);
@@ -763,6 +787,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
     if (halt != H2_NONE) { ctl->state = 1; ctl->halt = halt; }
   }
   __syncthreads();
+  D2_TRB(3);
   if (s_evalok)   // b_p_update has consumed the flags (pval.cpp:24,37)
     for (int k = threadIdx.x; k < nclust; k += blockDim.x) { P.update_e[k] = 0; P.check_locks[k] = 0; }
   __syncthreads();
@@ -771,8 +796,11 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
     __syncthreads();
     if (threadIdx.x == 0) *E.sig_n = 0;                      // consumed: the next evaluation lists afresh
   }
+  D2_TRB(4);
   clear_block(E.dblk + ((ring + 1) % RING2));
   publish_block(E, out, ring);
+  D2_TRB(5);
+#undef D2_TRB
 }
 
 // the host's own b_bud decision (ties, near ties, prior births, capacity) applied, the coming round planned, the device resumed

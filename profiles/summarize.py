@@ -39,6 +39,36 @@ if dbs:
                 "from (select name, (end - start) as d from kernels where name like ?) group by name", (pat,)):
             L.append(f"| `{short(n)}` | {c1} | {(a1 or 0) / 1e3:.2f} | {c0} | {(a0 or 0) / 1e3:.2f} |")
     L.append("")
+    # distribution of the per-launch durations and the idle gap the GPU shows AFTER each kernel (next start - this end):
+    # the round chain is a string of dependent launches, so the gaps are part of a round's latency
+    ks = list(db.execute("select name, start, end from kernels order by start"))
+    import collections
+    dur, gap = collections.defaultdict(list), collections.defaultdict(list)
+    for i, (n, st, en) in enumerate(ks):
+        dur[short(n)].append((en - st) / 1e3)
+        if i + 1 < len(ks):
+            g = (ks[i + 1][1] - en) / 1e3
+            if g < 200.0:
+                gap[short(n)].append(g)
+    edges = [0, 4, 6, 8, 10, 12, 15, 20, 25, 30, 40, 60, 100, 200, 10 ** 9]
+    L += ["## Per-launch duration histogram (us) and idle gap behind each kernel", "",
+          "| kernel | launches | " + " | ".join(f"<{e}" if e < 10 ** 9 else ">=200" for e in edges[1:]) + " | median us | avg gap after (us) | gaps total ms |", "|---|---|" + "---|" * (len(edges) + 2)]
+    for n, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        if len(v) < 50:
+            continue
+        h = [0] * (len(edges) - 1)
+        for x in v:
+            for b in range(len(edges) - 1):
+                if edges[b] <= x < edges[b + 1]:
+                    h[b] += 1
+                    break
+        sv = sorted(v)
+        g = gap.get(n, [])
+        L.append(f"| `{n}` | {len(v)} | " + " | ".join(str(x) for x in h) + f" | {sv[len(sv) // 2]:.1f} | {(sum(g) / len(g)) if g else 0:.2f} | {sum(g) / 1e3:.2f} |")
+    L.append("")
+    tot_busy = sum(sum(v) for v in dur.values()) / 1e3
+    tot_gap = sum(sum(v) for v in gap.values()) / 1e3
+    L += [f"GPU busy {tot_busy:.1f} ms, idle gaps between consecutive kernels (< 200 us each) {tot_gap:.1f} ms.", ""]
     res = list(db.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
                           "max(workgroup_x), avg(grid_x) from kernels where name like 'd2::%' or name like 'void d2::%' group by name"))
     L += ["## Dispatch resources", "", "| kernel | VGPR | AGPR | SGPR | LDS B | scratch B | wg | avg grid threads |", "|---|---|---|---|---|---|---|---|"]
