@@ -16,6 +16,17 @@ static __device__ __forceinline__ int gcn_max3(int a, int b, int c) {
   asm("v_max3_i32 %0, %1, %2, %3" : "=v"(e) : "v"(a), "v"(b), "v"(c));
   return e;
 }
+static __device__ __forceinline__ int gcn_min3(int a, int b, int c) {
+  int e;
+  asm("v_min3_i32 %0, %1, %2, %3" : "=v"(e) : "v"(a), "v"(b), "v"(c));
+  return e;
+}
+// acc + sum over the four bytes of |a.byte - b.byte| in one instruction (v_sad_u8)
+static __device__ __forceinline__ int gcn_sad_u8(uint32_t a, uint32_t b, int acc) {
+  int e;
+  asm("v_sad_u8 %0, %1, %2, %3" : "=v"(e) : "v"(a), "v"(b), "v"(acc));
+  return e;
+}
 // DPP wave shifts by one lane: lane L reads `src` of lane L-1 (shr) / L+1 (shl); a lane without a source keeps `old`
 // (bound_ctrl = false) or reads 0 (bound_ctrl = true)
 template <bool BOUND_CTRL>

@@ -690,18 +690,71 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
   pw |= p << fs;
 }
 
-// LDS geometry of k_nw_ad, shared by host and device.  Per alignment: run descriptors, the two staged sequences (one base
-// per byte, guard bytes either side), one u16 per raw position (byte offset of its error-model factor in the LDS copy of
-// err) and the raw's qualities.  The 2-bit traceback pointers are NOT here: they go to the HBM ring SampleDev::ad_ptr, one
-// coalesced 256-byte store per wave per 16 steps (they took 2.3 of the 4.1 KB per alignment of round 2's kernel and, with
-// the fp64 factor array that aliased them, held the kernel at three blocks per CU).
+// The same step for the reference's DEFAULT scores (match 5, mismatch -4, gap -8) in the COST domain K = 5 t - 2 H on
+// anti-diagonal t = i + j: every path into a cell has the same t, so arg-max and ties are exactly those of H, and
+//   a match costs 0, a mismatch 18, a gap 21, a free move along the last row / column 5, an axis cell is 5 t, out of band is BIG.
+// Bases are staged as one word each, 9 << (8 * code): the sum of absolute byte differences of two such words is 0 for equal
+// bases and 18 otherwise, so diag = own + substitution cost is ONE v_sad_u8 (it was compare + select + add), and the
+// three-way minimum is one v_min3.  Out-of-band cells take BIG instead of the gap cost (additive mask, as above).
+constexpr int ADK_BIG = 1 << 22, ADK_MIS = 18, ADK_GAP = 21, ADK_FREE = 5;
+template <int GL, int PAR, bool LEAN, bool EDGE>
+static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
+                                                 uint32_t vnext, int fs, bool g_first, bool g_last, bool kok, int gsel, int L1, int L2) {
+  if (LEAN && !EDGE) {
+    const int nb = PAR == 0 ? gcn_wave_shr1<true>(0, d1)     // lane-1's odd cell (wave_shr:1)
+                            : gcn_wave_shl1<true>(0, d0);    // lane+1's even cell (wave_shl:1)
+    const int own = PAR == 0 ? d0 : d1, other = PAR == 0 ? d1 : d0;
+    const int diag = gcn_sad_u8(cb, rb, own);
+    const int left = (PAR == 0 ? nb : other) + gsel, up = (PAR == 0 ? other : nb) + gsel;
+    const int e = gcn_min3(left, diag, up);
+    const bool t2 = up == e;                                  // up <= min(left, diag)  <=>  the minimum IS up
+    const bool t1 = left <= diag;
+    const uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
+    if (PAR == 0) { d0 = e; rb = vnext; j++; } else { d1 = e; cb = vnext; i++; }
+    pw |= p << fs;
+    return;
+  }
+  int left_src, up_src, own;
+  if (PAR == 0) {
+    const int lft = gcn_wave_shr1<false>(ADK_BIG, d1);
+    own = d0; left_src = (EDGE && g_first) ? ADK_BIG : lft; up_src = d1;
+  } else {
+    const int upn = gcn_wave_shl1<false>(ADK_BIG, d0);
+    own = d1; left_src = d0; up_src = (EDGE && g_last) ? ADK_BIG : upn;
+  }
+  const int diag = own + (cb == rb ? 0 : ADK_MIS);
+  const int up = up_src + ((!LEAN && j == L2) ? ADK_FREE : ADK_GAP);      // free moves along the last column
+  const int left = left_src + ((!LEAN && i == L1) ? ADK_FREE : ADK_GAP);  // ... and the last row
+  const bool t1 = left <= diag;
+  const int e1 = min(left, diag);
+  const bool t2 = up <= e1;
+  const int e = min(up, e1);
+  int val;
+  uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
+  if (LEAN) {
+    val = kok ? e : ADK_BIG;
+  } else {
+    const bool interior = kok && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
+    val = interior ? e : (kok ? ADK_FREE * (i + j) : ADK_BIG);  // axis cells: H = 0
+    if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
+  }
+  if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
+  pw |= p << fs;
+}
+
+// LDS geometry of k_nw_ad, shared by host and device.  Per WAVE: the staged centre (every alignment of a wave has the same
+// centre), one word per base with guard words either side.  Per alignment: run descriptors, the staged raw (one word per
+// base), one u16 per raw position (byte offset of its error-model factor in the LDS copy of err) and the raw's qualities.
+// The 2-bit traceback pointers are NOT here: they go to the HBM ring SampleDev::ad_ptr, one coalesced 256-byte store per wave
+// per 16 steps (they took 2.3 of the 4.1 KB per alignment of round 2's kernel and, with the fp64 factor array that aliased
+// them, held the kernel at three blocks per CU).
 struct AdGeom {
   int GL, APW, NCOL;        // lanes per alignment, alignments per wave, pointer columns per alignment
   int edge;                 // 1: group-boundary lanes must mask their DPP neighbour (band fills the group's cells)
   int nwords;               // 16-step blocks of a sweep (pointer words per lane)
-  int seqbytes;             // bytes per staged sequence incl. guards (multiple of 8)
+  int seqwords;             // words per staged sequence incl. guards (multiple of 4)
   int tbytes;               // bytes per quality row (multiple of 16); the factor-offset row has 2 * tbytes
-  int per_al_bytes;
+  int per_al_bytes, per_wave_bytes;
 };
 // Lane g of a group owns cells k' = 2g, 2g+1; an alignment's band cell k sits at k' = k + o.  The origin shift o makes
 // lband + o even, so every alignment of a wave is in phase (even cells live on even steps) whatever its length
@@ -715,9 +768,10 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   G.edge = (W + 4 > 2 * G.GL) ? 1 : 0;
   G.NCOL = (W + (G.edge ? 1 : 3) + 1) / 2;
   G.nwords = (2 * maxlen + 1 + 15) / 16;
-  G.seqbytes = (maxlen + 2 * (G.GL + 11) + 7) & ~7;
+  G.seqwords = (maxlen + 2 * (G.GL + 11) + 3) & ~3;
   G.tbytes = (maxlen + 15) & ~15;
-  G.per_al_bytes = AD_RCAP * 4 + 2 * G.seqbytes + 3 * G.tbytes;
+  G.per_al_bytes = AD_RCAP * 4 + 4 * G.seqwords + 3 * G.tbytes;
+  G.per_wave_bytes = 4 * G.seqwords + G.APW * G.per_al_bytes;
   return G;
 }
 
@@ -741,13 +795,14 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   // extra, always-out-of-band lane of the last group and is excluded from everything else.
   const bool ghost = lane / GL >= APW;
   const int al = ghost ? APW - 1 : lane / GL, g = ghost ? GL : lane % GL;
-  // per-alignment LDS: [run descriptors][centre bytes][raw bytes][factor offsets u16][quals]
-  uint8_t *abase = (uint8_t *)(s_dyn + nerr) + ((size_t)wib * APW + al) * G.per_al_bytes;
+  // per-wave LDS: [centre words]; per alignment: [run descriptors][raw words][factor offsets u16][quals]
+  uint8_t *wbase = (uint8_t *)(s_dyn + nerr) + (size_t)wib * G.per_wave_bytes;
+  uint32_t *cwd = (uint32_t *)wbase + (GL + 11);                        // centre base p as 9 << (8 * code)
+  uint8_t *abase = wbase + 4 * G.seqwords + (size_t)al * G.per_al_bytes;
   uint32_t *runs = (uint32_t *)abase;
-  uint8_t *cbytes = abase + AD_RCAP * 4 + (GL + 11);
-  uint8_t *rbytes = cbytes + G.seqbytes;
-  uint16_t *foff = (uint16_t *)(abase + AD_RCAP * 4 + 2 * G.seqbytes);   // byte offset into s_err of every raw position's factor
-  uint8_t *qlds = abase + AD_RCAP * 4 + 2 * G.seqbytes + 2 * G.tbytes;
+  uint32_t *rwd = (uint32_t *)(abase + AD_RCAP * 4) + (GL + 11);        // raw base p, same encoding
+  uint16_t *foff = (uint16_t *)(abase + AD_RCAP * 4 + 4 * G.seqwords);  // byte offset into s_err of every raw position's factor
+  uint8_t *qlds = abase + AD_RCAP * 4 + 4 * G.seqwords + 2 * G.tbytes;
   __syncthreads();
   const SampleDev &S = a.S;
   const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
@@ -770,9 +825,9 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     const int W = lband + rband + 1;                       // <= 2*NCOL
     const int T = (gapless || !active) ? -1 : L1 + L2;     // idle / gapless slots run no DP steps of their own
     // stage both sequences (one base per byte, guard bytes either side) and the raw's qualities
+    for (int p = lane; p < L1; p += 64) cwd[p] = 9u << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);   // (the wave's centre, by all its lanes)
     if (!ghost) {
-      for (int p = g; p < L1; p += GL) cbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)c * S.W2, p);
-      for (int p = g; p < L2; p += GL) rbytes[p] = (uint8_t)base_at(S.seq2 + (size_t)r * S.W2, p);
+      for (int p = g; p < L2; p += GL) rwd[p] = 9u << (base_at(S.seq2 + (size_t)r * S.W2, p) << 3);
       const uint32_t *qsrc = (const uint32_t *)(S.qual + (size_t)r * S.LQ);
       for (int w = g; w * 4 < L2; w += GL) ((uint32_t *)qlds)[w] = qsrc[w];
     }
@@ -790,10 +845,11 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       int d0 = SENT, d1 = SENT;
       uint32_t pw = 0;
       int i = (lbo >> 1) - g, j = -i;                        // the lane's even cell on step 0
-      uint32_t cb = cbytes[i - 1], rb = rbytes[j - 1];
+      uint32_t cb = cwd[i - 1], rb = rwd[j - 1];
       const bool g_first = g == 0, g_last = ghost || g == GL - 1;
       const bool kok0 = !ghost && 2 * g >= org && 2 * g < W + org, kok1 = !ghost && 2 * g + 1 >= org && 2 * g + 1 < W + org;
-      const int gs0 = kok0 ? (DEF ? -8 : GAP) : AD_OOB, gs1 = kok1 ? (DEF ? -8 : GAP) : AD_OOB;
+      const int gs0 = DEF ? (kok0 ? ADK_GAP : ADK_BIG) : (kok0 ? GAP : AD_OOB), gs1 = DEF ? (kok1 ? ADK_GAP : ADK_BIG) : (kok1 ? GAP : AD_OOB);
+      if (DEF) { d0 = ADK_BIG; d1 = ADK_BIG; }                 // (the default scores run in the cost domain: ad_step_k)
       // Steady state [tA, tB): every in-band cell of every alignment in the wave is interior and off the
       // last row / column (i >= 1, j >= 1, i < L1, j < L2 for all k in the band).
       int tA = (lband > rband ? lband : rband) + 2, tB = min(2 * L1 - lband, 2 * L2 - rband);
@@ -803,18 +859,21 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       tA = gcn_readfirstlane(tA);
       tB = gcn_readfirstlane(tB);
 #define AD_FLUSH(TT) { pg[(size_t)((TT) >> 4) * 64 + lane] = pw; pw = 0; }   /* every lane, unconditionally: one 256-byte store */
+#define AD_STEP(PARV, LEANV, VNEXT, FS, KOK, GS)                                                                                   \
+  {                                                                                                                             \
+    if (DEF) ad_step_k<GL, PARV, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2);    \
+    else ad_step<GL, PARV, DEF, LEANV, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2, SENT, MATCH, MISMATCH, GAP); \
+  }
 #define AD_FULL_STEP(TT)                                                                                                        \
   {                                                                                                                             \
-    if (((TT) & 1) == 0)                                                                                                        \
-      ad_step<GL, 0, DEF, false, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, rbytes[j], ((TT) & 15) << 1, g_first, g_last, kok0, gs0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
-    else                                                                                                                        \
-      ad_step<GL, 1, DEF, false, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, cbytes[i], ((TT) & 15) << 1, g_first, g_last, kok1, gs1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    if (((TT) & 1) == 0) AD_STEP(0, false, rwd[j], ((TT) & 15) << 1, kok0, gs0)                                                 \
+    else AD_STEP(1, false, cwd[i], ((TT) & 15) << 1, kok1, gs1)                                                                 \
     if (((TT) & 15) == 15) AD_FLUSH(TT)                                                                                         \
   }
 #define AD_LEAN_PAIR(TT)                                                                                                        \
   {                                                                                                                             \
-    ad_step<GL, 0, DEF, true, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, rbytes[j], ((TT) & 15) << 1, g_first, g_last, kok0, gs0, L1, L2, SENT, MATCH, MISMATCH, GAP); \
-    ad_step<GL, 1, DEF, true, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, cbytes[i], (((TT) + 1) & 15) << 1, g_first, g_last, kok1, gs1, L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    AD_STEP(0, true, rwd[j], ((TT) & 15) << 1, kok0, gs0)                                                                       \
+    AD_STEP(1, true, cwd[i], (((TT) + 1) & 15) << 1, kok1, gs1)                                                                 \
     if ((((TT) + 1) & 15) == 15) AD_FLUSH((TT) + 1)                                                                             \
   }
       int t = 0;
@@ -824,14 +883,14 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       for (; (t & 15) != 0 && t + 2 <= tB && t + 1 <= Tmax; t += 2) AD_LEAN_PAIR(t)
       // steady state in blocks of 16 steps = one pointer word per column: constant field shifts, one flush per block
       for (; t + 16 <= tB && t + 15 <= Tmax; t += 16) {
-        // the block consumes eight raw and eight centre bases: two 8-byte LDS reads (any byte address), bytes picked by index
-        uint64_t rw, cw;
-        __builtin_memcpy(&rw, rbytes + j, 8);
-        __builtin_memcpy(&cw, cbytes + i, 8);
+        // the block consumes eight raw and eight centre bases: two 32-byte LDS reads each
+        uint32_t rwv[8], cwv[8];
+        __builtin_memcpy(rwv, rwd + j, 32);
+        __builtin_memcpy(cwv, cwd + i, 32);
 #pragma unroll
-        for (int u = 0; u < 16; u += 2) {
-          ad_step<GL, 0, DEF, true, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, (uint32_t)(rw >> (4 * u)) & 0xFFu, 2 * u, g_first, g_last, kok0, gs0, L1, L2, SENT, MATCH, MISMATCH, GAP);
-          ad_step<GL, 1, DEF, true, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, (uint32_t)(cw >> (4 * u)) & 0xFFu, 2 * u + 2, g_first, g_last, kok1, gs1, L1, L2, SENT, MATCH, MISMATCH, GAP);
+        for (int u = 0; u < 8; u++) {
+          AD_STEP(0, true, rwv[u], 4 * u, kok0, gs0)
+          AD_STEP(1, true, cwv[u], 4 * u + 2, kok1, gs1)
         }
         AD_FLUSH(t)
       }
@@ -839,6 +898,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       for (; t <= Tmax; t++) AD_FULL_STEP(t)
 #undef AD_LEAN_PAIR
 #undef AD_FULL_STEP
+#undef AD_STEP
 #undef AD_FLUSH
       if (((t - 1) & 15) != 15) pg[(size_t)((t - 1) >> 4) * 64 + lane] = pw;
     }
@@ -926,10 +986,10 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
           const uint32_t dsc = runs[ri];
           const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
           for (int pj = lo + g; pj < lo + n; pj += GL) {
-            const uint32_t rb = rbytes[pj];
+            const uint32_t rb = (uint32_t)__builtin_ctz(rwd[pj]) >> 3;   // base code back from its word 9 << (8 * code)
             uint32_t tc = 5u * rb;
             if (dl != 255) {
-              const uint32_t cb = cbytes[pj + dl - 128];
+              const uint32_t cb = (uint32_t)__builtin_ctz(cwd[pj + dl - 128]) >> 3;
               tc = 4u * cb + rb;
               h += (cb != rb);
               if (a.view && active)
@@ -995,7 +1055,7 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev; a.stop_dev = d_stop_dev;
   { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
-  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.APW * G.per_al_bytes;
+  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_bytes;
   int waves = (std::max(maxwork, 1) + G.APW - 1) / G.APW;
   if (d_gl_work) waves = (S.N + G.APW - 1) / G.APW;
   int grid = std::max(1, std::min((waves + 3) / 4, std::min(256 * 8, S.ad_waves / 4)));   // one slot of the pointer ring per wave
@@ -1038,7 +1098,7 @@ size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 127) return 0;
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
-  return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.APW * G.per_al_bytes;
+  return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_bytes;
 }
 
 // ------------------------------------------------------------------------------------------------

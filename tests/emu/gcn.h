@@ -8,6 +8,15 @@
 namespace d2 {
 
 static inline int gcn_max3(int a, int b, int c) { return std::max(a, std::max(b, c)); }
+static inline int gcn_min3(int a, int b, int c) { return std::min(a, std::min(b, c)); }
+static inline int gcn_sad_u8(uint32_t a, uint32_t b, int acc) {
+  uint32_t s = (uint32_t)acc;
+  for (int k = 0; k < 4; k++) {
+    const int x = (int)((a >> (8 * k)) & 0xFFu), y = (int)((b >> (8 * k)) & 0xFFu);
+    s += (uint32_t)(x > y ? x - y : y - x);
+  }
+  return (int)s;
+}
 template <bool BOUND_CTRL> static inline int gcn_wave_shr1(int old, int src) {
   return (int)(uint32_t)emu::wave_op(emu::OP_DPP_SHR1, 64, (uint32_t)src, 0, (uint32_t)old, BOUND_CTRL, false);
 }
