@@ -699,13 +699,17 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
 constexpr int ADK_BIG = 1 << 22, ADK_MIS = 18, ADK_GAP = 21, ADK_FREE = 5;
 template <int GL, int PAR, bool LEAN, bool EDGE>
 static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
-                                                 uint32_t vnext, int fs, bool g_first, bool g_last, bool kok, int gsel, int L1, int L2) {
-  if (LEAN && !EDGE) {
+                                                 uint32_t vnext, int fs, bool g_first, bool g_last, bool kok, int gsel, int gsel_nb,
+                                                 int L1, int L2) {
+  if (LEAN) {
+    // gsel_nb is the addend of the neighbour LANE's cell: the gap cost, or BIG where that neighbour must not be seen (out of
+    // band, or - when the band fills the group's cells, EDGE - the last lane of the group before / the first of the next one;
+    // a lane without any source reads 0 there).  No select, no masking instruction: just a second per-lane constant.
     const int nb = PAR == 0 ? gcn_wave_shr1<true>(0, d1)     // lane-1's odd cell (wave_shr:1)
                             : gcn_wave_shl1<true>(0, d0);    // lane+1's even cell (wave_shl:1)
     const int own = PAR == 0 ? d0 : d1, other = PAR == 0 ? d1 : d0;
     const int diag = gcn_sad_u8(cb, rb, own);
-    const int left = (PAR == 0 ? nb : other) + gsel, up = (PAR == 0 ? other : nb) + gsel;
+    const int left = PAR == 0 ? nb + gsel_nb : other + gsel, up = PAR == 0 ? other + gsel : nb + gsel_nb;
     const int e = gcn_min3(left, diag, up);
     const bool t2 = up == e;                                  // up <= min(left, diag)  <=>  the minimum IS up
     const bool t1 = left <= diag;
@@ -723,17 +727,15 @@ static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &
     own = d1; left_src = d0; up_src = (EDGE && g_last) ? ADK_BIG : upn;
   }
   const int diag = own + (cb == rb ? 0 : ADK_MIS);
-  const int up = up_src + ((!LEAN && j == L2) ? ADK_FREE : ADK_GAP);      // free moves along the last column
-  const int left = left_src + ((!LEAN && i == L1) ? ADK_FREE : ADK_GAP);  // ... and the last row
+  const int up = up_src + (j == L2 ? ADK_FREE : ADK_GAP);      // free moves along the last column
+  const int left = left_src + (i == L1 ? ADK_FREE : ADK_GAP);  // ... and the last row
   const bool t1 = left <= diag;
   const int e1 = min(left, diag);
   const bool t2 = up <= e1;
   const int e = min(up, e1);
   int val;
   uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
-  if (LEAN) {
-    val = kok ? e : ADK_BIG;
-  } else {
+  {
     const bool interior = kok && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
     val = interior ? e : (kok ? ADK_FREE * (i + j) : ADK_BIG);  // axis cells: H = 0
     if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
@@ -754,13 +756,15 @@ struct AdGeom {
   int nwords;               // 16-step blocks of a sweep (pointer words per lane)
   int seqwords;             // words per staged sequence incl. guards (multiple of 4)
   int tbytes;               // bytes per quality row (multiple of 16); the factor-offset row has 2 * tbytes
-  int per_al_bytes, per_wave_bytes;
+  int per_al_bytes, per_wave_bytes;   // per_wave_bytes includes the wave's own centre words unless shared_c
+  int shared_c;             // the launch has one centre for all its work (no per-chunk centres): staged once per block
+  int block_bytes;          // LDS behind the err table
 };
 // Lane g of a group owns cells k' = 2g, 2g+1; an alignment's band cell k sits at k' = k + o.  The origin shift o makes
 // lband + o even, so every alignment of a wave is in phase (even cells live on even steps) whatever its length
 // difference.  When the group has room (W + 4 <= 2 GL) o is 2 or 3: the first two cells and the last cell of every
 // group are then never in band, always hold the sentinel, and the cross-group DPP reads need no masking.
-static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minlen) {
+static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minlen, int shared_c = 0) {
   AdGeom G;
   const int W = 2 * band + (maxlen - minlen) + 1;
   G.GL = W + 1 <= 42 ? 21 : (W + 1 <= 64 ? 32 : 64);   // 21 lanes x 2 cells cover the default band (W = 33): 3 alignments per wave
@@ -771,7 +775,9 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   G.seqwords = (maxlen + 2 * (G.GL + 11) + 3) & ~3;
   G.tbytes = (maxlen + 15) & ~15;
   G.per_al_bytes = AD_RCAP * 4 + 4 * G.seqwords + 3 * G.tbytes;
-  G.per_wave_bytes = 4 * G.seqwords + G.APW * G.per_al_bytes;
+  G.shared_c = shared_c;
+  G.per_wave_bytes = (shared_c ? 0 : 4 * G.seqwords) + G.APW * G.per_al_bytes;
+  G.block_bytes = (shared_c ? 4 * G.seqwords : 0) + 4 * G.per_wave_bytes;
   return G;
 }
 
@@ -795,16 +801,26 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   // extra, always-out-of-band lane of the last group and is excluded from everything else.
   const bool ghost = lane / GL >= APW;
   const int al = ghost ? APW - 1 : lane / GL, g = ghost ? GL : lane % GL;
-  // per-wave LDS: [centre words]; per alignment: [run descriptors][raw words][factor offsets u16][quals]
-  uint8_t *wbase = (uint8_t *)(s_dyn + nerr) + (size_t)wib * G.per_wave_bytes;
-  uint32_t *cwd = (uint32_t *)wbase + (GL + 11);                        // centre base p as 9 << (8 * code)
-  uint8_t *abase = wbase + 4 * G.seqwords + (size_t)al * G.per_al_bytes;
+  // LDS behind err: [centre words, once per block when the launch has ONE centre (a round) | once per wave (final pass,
+  // births: a centre per chunk)]; per alignment: [run descriptors][raw words][factor offsets u16][quals]
+  uint8_t *blk0 = (uint8_t *)(s_dyn + nerr);
+  const int cw_bytes = 4 * G.seqwords;
+  uint8_t *wbase = blk0 + (G.shared_c ? cw_bytes : 0) + (size_t)wib * G.per_wave_bytes;
+  uint32_t *cwd = (uint32_t *)(G.shared_c ? blk0 : wbase) + (GL + 11); // centre base p as 9 << (8 * code)
+  uint8_t *abase = wbase + (G.shared_c ? 0 : cw_bytes) + (size_t)al * G.per_al_bytes;
   uint32_t *runs = (uint32_t *)abase;
   uint32_t *rwd = (uint32_t *)(abase + AD_RCAP * 4) + (GL + 11);        // raw base p, same encoding
   uint16_t *foff = (uint16_t *)(abase + AD_RCAP * 4 + 4 * G.seqwords);  // byte offset into s_err of every raw position's factor
   uint8_t *qlds = abase + AD_RCAP * 4 + 4 * G.seqwords + 2 * G.tbytes;
-  __syncthreads();
   const SampleDev &S = a.S;
+  if (G.shared_c) {                                                    // the launch's one centre, staged by the whole block
+    const int cv = a.centre_dev ? *a.centre_dev : a.centre;
+    if (cv >= 0) {
+      const int Lc = S.len[cv];
+      for (int p = threadIdx.x; p < Lc; p += 256) cwd[p] = 9u << (base_at(S.seq2 + (size_t)cv * S.W2, p) << 3);
+    }
+  }
+  __syncthreads();
   const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
   uint32_t *pg = S.ad_ptr + (size_t)gwave * S.ad_wpw;      // this wave's slot of the pointer ring: [16-step block][lane]
   const int n_nw = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
@@ -825,7 +841,8 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     const int W = lband + rband + 1;                       // <= 2*NCOL
     const int T = (gapless || !active) ? -1 : L1 + L2;     // idle / gapless slots run no DP steps of their own
     // stage both sequences (one base per byte, guard bytes either side) and the raw's qualities
-    for (int p = lane; p < L1; p += 64) cwd[p] = 9u << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);   // (the wave's centre, by all its lanes)
+    if (!G.shared_c)                                       // the chunk's centre, by all lanes of the wave
+      for (int p = lane; p < L1; p += 64) cwd[p] = 9u << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);
     if (!ghost) {
       for (int p = g; p < L2; p += GL) rwd[p] = 9u << (base_at(S.seq2 + (size_t)r * S.W2, p) << 3);
       const uint32_t *qsrc = (const uint32_t *)(S.qual + (size_t)r * S.LQ);
@@ -849,6 +866,8 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       const bool g_first = g == 0, g_last = ghost || g == GL - 1;
       const bool kok0 = !ghost && 2 * g >= org && 2 * g < W + org, kok1 = !ghost && 2 * g + 1 >= org && 2 * g + 1 < W + org;
       const int gs0 = DEF ? (kok0 ? ADK_GAP : ADK_BIG) : (kok0 ? GAP : AD_OOB), gs1 = DEF ? (kok1 ? ADK_GAP : ADK_BIG) : (kok1 ? GAP : AD_OOB);
+      // ... and for the cell fetched from the neighbour lane: hidden across a group boundary when the band fills the group
+      const int gn0 = (EDGE && g_first) ? ADK_BIG : gs0, gn1 = (EDGE && g_last) ? ADK_BIG : gs1;
       if (DEF) { d0 = ADK_BIG; d1 = ADK_BIG; }                 // (the default scores run in the cost domain: ad_step_k)
       // Steady state [tA, tB): every in-band cell of every alignment in the wave is interior and off the
       // last row / column (i >= 1, j >= 1, i < L1, j < L2 for all k in the band).
@@ -861,7 +880,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 #define AD_FLUSH(TT) { pg[(size_t)((TT) >> 4) * 64 + lane] = pw; pw = 0; }   /* every lane, unconditionally: one 256-byte store */
 #define AD_STEP(PARV, LEANV, VNEXT, FS, KOK, GS)                                                                                   \
   {                                                                                                                             \
-    if (DEF) ad_step_k<GL, PARV, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2);    \
+    if (DEF) ad_step_k<GL, PARV, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), (PARV) ? gn1 : gn0, L1, L2); \
     else ad_step<GL, PARV, DEF, LEANV, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2, SENT, MATCH, MISMATCH, GAP); \
   }
 #define AD_FULL_STEP(TT)                                                                                                        \
@@ -1054,8 +1073,8 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
   a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev; a.stop_dev = d_stop_dev;
   { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
-  const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
-  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_bytes;
+  const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen, d_chunk_centre ? 0 : 1);
+  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)G.block_bytes;
   int waves = (std::max(maxwork, 1) + G.APW - 1) / G.APW;
   if (d_gl_work) waves = (S.N + G.APW - 1) / G.APW;
   int grid = std::max(1, std::min((waves + 3) / 4, std::min(256 * 8, S.ad_waves / 4)));   // one slot of the pointer ring per wave
@@ -1097,8 +1116,8 @@ size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || !S.ad_ptr) return 0;   // (factor offsets are u16: 16 * ncol * 8 < 65 536)
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 127) return 0;
-  const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);
-  return (size_t)16 * ap.ncol * 8 + (size_t)4 * G.per_wave_bytes;
+  const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);   // (a centre per wave: the larger of the two layouts)
+  return (size_t)16 * ap.ncol * 8 + (size_t)G.block_bytes;
 }
 
 // ------------------------------------------------------------------------------------------------

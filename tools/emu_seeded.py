@@ -23,7 +23,9 @@ CASES = [(1, {}), (2, dict(BAND_SIZE=4)), (3, dict(GREEDY=False, GAPLESS=False))
          (5, dict(MIN_FOLD=2, MIN_HAMMING=2, MIN_ABUNDANCE=2)), (6, dict(OMEGA_A=1e-4, OMEGA_C=1e-2)), (7, dict(SSE=0)),
          (8, dict(VECTORIZED_ALIGNMENT=False, KDIST_CUTOFF=0.3)), (9, dict(MAX_CLUST=3)), (10, dict(BAND_SIZE=0)),
          (11, dict(BAND_SIZE=-1)), (12, dict(BAND_SIZE=40)), (13, dict(MATCH=4, MISMATCH=-5, GAP_PENALTY=-7)),
-         (14, dict(BAND_SIZE=1)), (15, dict(BAND_SIZE=18))]
+         (14, dict(BAND_SIZE=1)), (15, dict(BAND_SIZE=18)),
+         # band fills the lane group (AdGeom::edge): 21 lanes with W = 39, 32 lanes with W = 61 (ragged), non-default scores there too
+         (17, dict(BAND_SIZE=19)), (18, dict(BAND_SIZE=20)), (19, dict(BAND_SIZE=19, MATCH=4, MISMATCH=-5, GAP_PENALTY=-7))]
 os.environ.setdefault("DADA2HIP_NW_KERNEL", "coop")
 only = [int(x) for x in sys.argv[1:]]
 for seed, kw in CASES:
