@@ -10,6 +10,8 @@ already on host, includes H2D, all kernels, D2H of results").  Workload by --con
                (--selfconsist runs configs[2]'s learnErrors-style loop on it: err from all-ones, noqual refit)
   2            100 000 unique 250-nt reads                                          (BASELINE.json configs[1])
   4            8 samples x 250 000 uniques, samples sharded round-robin over the ranks (strong scaling, configs[3])
+  --shard      (configs 2/3/5) ONE sample whose uniques are split over the ranks: every rank does the comparisons, shuffles and
+               p-values of its block, the moves / bud candidates / final sums are exchanged over RCCL (strong scaling)
   5            200 000 unique ~1 500-nt reads, BAND_SIZE 32, 94 quality columns     (configs[4])
 
 With --gpus N (configs 2/3/5) every rank denoises its own sample of the same size (weak scaling: the path shards
@@ -79,7 +81,7 @@ def make_inputs(cfg, args, rank):
         kw.update(q_hi=40.0, q_lo=34.0, q_sd=2.0)
     dereps = []
     if c["samples"] == 1:
-        dereps.append(make_sample(err, n, seed=20260925 + cfg + 1000 * rank, **kw))
+        dereps.append(make_sample(err, n, seed=20260925 + cfg + (0 if getattr(args, "shard", False) else 1000 * rank), **kw))
         mine = [0]
     else:
         # configs[3]: 8 samples, half of each sample's true variants shared across samples
@@ -113,6 +115,8 @@ def main():
     ap.add_argument("--cpu-repeats", type=int, default=3, help="timed repetitions of the all-core reference run (best is reported)")
     ap.add_argument("--no-extras", action="store_true", help="skip the selfconsist / secondary_workload sub-records of the default line")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--shard", action="store_true", help="ONE sample, the per-unique work of its uniques split over the ranks "
+                    "(dada2hip_sample_run_sharded, DESIGN.md 7): strong scaling of a single dada() call; resident samples")
     ap.add_argument("--deep", action="store_true", help="workload variant with >= 5 reads per unique (reads drawn at Q34-40)")
     args = ap.parse_args()
 
@@ -124,9 +128,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.shard:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     if world > 1 and "DADA2HIP_HOST_THREADS" not in os.environ:
         # one process per GPU on one host: the marshalling threads of the ranks share the host's cores and memory channels
@@ -139,8 +148,12 @@ def main():
     t_gen = time.time() - t0
     band = args.band or c["band"]
     opts = DadaOpts(BAND_SIZE=band)
-    strong = c["samples"] > 1
+    strong = c["samples"] > 1 or args.shard
     maxcol = err.shape[1]
+    shard_smp = None
+    if args.shard:   # one resident copy of THE sample per rank; each rank works on its block of the uniques
+        from dada2_amd import shard as shardmod
+        shard_smp = api.Sample(inputs[0], None, None, None, device=local)
 
     def barrier():
         if world > 1:
@@ -168,6 +181,8 @@ def main():
                                           host_input=inputs[0])
             sc_info = {"passes": len(tm) - 1, "ms_create": tm[0], "ms_per_pass": tm[1:], "partitions_last": res.nclust}
             results = [res]
+        elif args.shard:
+            return [shardmod.dada_sharded(shard_smp, err, opts, dist=dist, collective_device=torch.device("cuda", local))]
         else:
             results = [api.dada_uniques(hi, None, None, err, None, opts, device=local) for hi in inputs]
         allreduce_trans(results)
@@ -188,7 +203,7 @@ def main():
         dt = float(tt.item())
         nn = torch.tensor([n_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(nn)
-        total_uniques = int(nn.item())
+        total_uniques = n_local if args.shard else int(nn.item())   # --shard: every rank holds the SAME sample
     else:
         total_uniques = n_local
 
@@ -200,7 +215,7 @@ def main():
 
         # ---- secondary: the same pass on a resident sample + a fully event-timed pass for the roofline --------------
         resident, prof, saturated = None, None, None
-        if not args.selfconsist:
+        if not args.selfconsist and not args.shard:
             smp = api.Sample(inputs[0], None, None, None, device=local)
             smp.run(err, opts)
             tr0 = time.perf_counter()
@@ -227,13 +242,13 @@ def main():
                 r["timing"] = "not measured in this run (--no-profile-pass / --selfconsist): see the default run's record"
 
         cpu = None
-        if not args.no_cpu_baseline and world == 1 and not args.selfconsist:
+        if not args.no_cpu_baseline and world == 1 and not args.selfconsist and not args.shard:
             cpu = cpu_baseline(d, err, opts, args, res, gpu_cmp_per_s=st["ncompare"] * len(inputs) * world * args.steps / dt)
 
         # ---- sub-records of the default line: BASELINE configs[2]'s selfConsist loop on this very sample, and a workload
         #      whose comparisons are NOT 98 % shrouded (28 reads per unique) --------------------------------------------
         secondary = None
-        if args.config == 3 and world == 1 and not args.selfconsist and not args.no_extras and not args.deep:
+        if args.config == 3 and world == 1 and not args.selfconsist and not args.no_extras and not args.deep and not args.shard:
             tm = []
             t_sc = time.perf_counter()
             res_sc, err_sc, errs_sc = api.dada(dereps[0], None, self_consist=True, opts=opts, device=local, timings=tm,
@@ -259,7 +274,9 @@ def main():
                        "comparisons": st["ncompare"], "nw": st["nnw"], "gapless": st["ngapless"],
                        "shrouded": st["nshroud"], "greedy_skipped": st["nskipped"], "shuffles": st["nshuffle"],
                        "host_input_bytes": inputs[0].nbytes,
-                       "parallelism": (f"{c['samples']} samples round-robin over {world} rank(s)" if strong else f"sample-per-gpu x{world}")},
+                       "parallelism": ("one sample, its uniques in %d blocks (dada2hip_sample_run_sharded), host-driven rounds, sample resident" % world if args.shard
+                                       else (f"{c['samples']} samples round-robin over {world} rank(s)" if strong else f"sample-per-gpu x{world}")),
+                       "shard_collectives_per_step": res.stats.get("shard_collectives") if args.shard else None},
             "roofline": roofline, "roofline_secondary": other, "roofline_nw_saturated": saturated,
             "cpu_baseline": cpu,
             "resident": resident,
@@ -270,7 +287,9 @@ def main():
             "gen_s": t_gen,
         }
         print(json.dumps(out))
-    if world > 1:
+    if shard_smp is not None:
+        shard_smp.close()
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -38,10 +38,18 @@ class CStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+# dada2hip_shard (include/dada2hip.h): rank / world + the collective the library calls at its exchange points
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class CShard(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("exchange", EXCHANGE_FN), ("user", C.c_void_p)]
+
+
 # every symbol include/dada2hip.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = [
     "dada2hip_dada_uniques", "dada2hip_sample_create", "dada2hip_sample_set_priors", "dada2hip_sample_run",
-    "dada2hip_sample_free", "dada2hip_sample_nraw", "dada2hip_sample_maxlen", "dada2hip_result_nclust",
+    "dada2hip_sample_free", "dada2hip_sample_run_sharded", "dada2hip_sample_nraw", "dada2hip_sample_maxlen", "dada2hip_result_nclust",
     "dada2hip_result_nraw", "dada2hip_result_maxlen", "dada2hip_result_ncol", "dada2hip_result_nbirth_subs",
     "dada2hip_result_sequence", "dada2hip_result_abundance", "dada2hip_result_n0", "dada2hip_result_n1",
     "dada2hip_result_nunq", "dada2hip_result_clust_pval", "dada2hip_result_birth_from", "dada2hip_result_birth_pval",
@@ -78,6 +86,7 @@ def lib():
     L.dada2hip_sample_create.argtypes = [ip, vp, vp, vp, vp, ip, ip, C.POINTER(vp), cp, C.c_size_t]
     L.dada2hip_sample_set_priors.argtypes = [vp, vp, cp, C.c_size_t]
     L.dada2hip_sample_run.argtypes = [vp, vp, ip, C.POINTER(COpts), vp, C.POINTER(vp), cp, C.c_size_t]
+    L.dada2hip_sample_run_sharded.argtypes = [vp, vp, ip, C.POINTER(COpts), vp, C.POINTER(CShard), C.POINTER(vp), cp, C.c_size_t]
     L.dada2hip_sample_free.argtypes = [vp]
     L.dada2hip_sample_nraw.argtypes = [vp]
     L.dada2hip_sample_maxlen.argtypes = [vp]

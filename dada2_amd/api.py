@@ -263,6 +263,39 @@ class Sample:
         finally:
             L.dada2hip_result_free(h)
 
+    def run_sharded(self, err, opts: DadaOpts, rank: int, world: int, exchange, *, max_clust=None, copts: COpts = None) -> DadaResult:
+        """``dada2hip_sample_run_sharded``: this process does the per-unique work of block ``rank`` of ``world``.  ``exchange(kind,
+        send: bytes-like memoryview, recv: writable memoryview)`` is the collective of include/dada2hip.h's dada2hip_shard
+        (kind 0 = all-gather of equal-size payloads in rank order, kind 1 = in-place all-reduce(sum) of int64);
+        ``dada2_amd.shard`` provides it over torch.distributed.  Every rank gets the complete result."""
+        L = _lib.lib()
+        co = _copts(opts, max_clust, False, False, copts)
+        e, ncol = _err_colmajor(err)
+        failure = []
+
+        def _cb(user, kind, send, nbytes, recv):
+            try:
+                n = int(nbytes)
+                sv = (C.c_char * n).from_address(send) if n else (C.c_char * 0)()
+                rv = (C.c_char * (n * world if kind == 0 else n)).from_address(recv) if n else (C.c_char * 0)()
+                exchange(int(kind), memoryview(sv).cast("B"), memoryview(rv).cast("B"))
+                return 0
+            except BaseException as ex:   # never unwind through the C frames
+                failure.append(ex)
+                return 1
+        cb = _lib.EXCHANGE_FN(_cb)
+        sh = _lib.CShard(int(rank), int(world), cb, None)
+        eb = C.create_string_buffer(_EB)
+        h = C.c_void_p()
+        rc = L.dada2hip_sample_run_sharded(self._h, e.ctypes.data, ncol, C.byref(co), None, C.byref(sh), C.byref(h), eb, _EB)
+        if failure:
+            raise failure[0]
+        _lib.check(rc, eb)
+        try:
+            return _collect(L, h)
+        finally:
+            L.dada2hip_result_free(h)
+
     def compare(self, centre: int, err, opts: DadaOpts = None, kdist_cutoff=None, skip=None):
         """One b_compare round (cluster.cpp:90-149): (lambda[N], hamming[N], cls[N], stats)."""
         L = _lib.lib()

@@ -243,6 +243,7 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
   D2_HIP(hipEventCreate(&s->ev1));
   SampleDev &D = s->D;
   D.N = nraw; D.maxlen = maxlen; D.minlen = minlen;
+  D.r_lo = 0; D.r_hi = nraw;
   D.W2 = (((maxlen + 15) / 16) + 3) & ~3;
   D.LQ = (maxlen + 15) & ~15;
   D.LK = (std::max(maxlen - KMER_SIZE + 1, 1) + 7) & ~7;
@@ -526,6 +527,77 @@ struct Run {
     vsnprintf(buf, sizeof buf, fmt, a);
     va_end(a);
     hooks->log(buf, hooks->user);
+  }
+
+  // ---- one sample over several ranks (dada2hip_sample_run_sharded) ------------------------------------
+  const dada2hip_shard *shard = nullptr;
+  int lo = 0, hi = 0;                             // this rank's block of uniques
+  std::vector<uint8_t> h_upd;                     // host copy of Bi::update_e (the device only sees its own movers)
+  void sh_call(int kind, const void *send, int64_t nbytes, void *recv) {
+    if (shard->exchange(shard->user, kind, send, nbytes, recv) != 0)
+      throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: the shard exchange callback failed"};
+  }
+  // all-gather of payloads of different sizes: sizes first, then the payloads padded to the largest
+  std::vector<std::vector<uint8_t>> sh_gatherv(const void *p, size_t n) {
+    const int W = shard->world;
+    int64_t mine = (int64_t)n;
+    std::vector<int64_t> sizes(W);
+    sh_call(0, &mine, 8, sizes.data());
+    int64_t mx = 0;
+    for (int64_t x : sizes) mx = std::max(mx, x);
+    std::vector<std::vector<uint8_t>> out(W);
+    if (mx == 0) return out;
+    std::vector<uint8_t> sendb((size_t)mx, 0), recvb((size_t)mx * W);
+    if (n) memcpy(sendb.data(), p, n);
+    sh_call(0, sendb.data(), mx, recvb.data());
+    for (int w = 0; w < W; w++) out[w].assign(recvb.begin() + (size_t)w * mx, recvb.begin() + (size_t)w * mx + (size_t)sizes[w]);
+    return out;
+  }
+  void sh_allreduce(std::vector<int64_t> &v) { if (!v.empty()) sh_call(1, v.data(), (int64_t)v.size() * 8, v.data()); }
+  // the moves of one b_shuffle2 call on all ranks, in rank order (replay_moves sorts them into the reference's order)
+  std::vector<int32_t> sh_all_moves(const int32_t *mine, int nm) {
+    std::vector<int32_t> all;
+    for (auto &part : sh_gatherv(mine, (size_t)nm * 12)) {
+      const size_t k = part.size() / 4;
+      const size_t o = all.size();
+      all.resize(o + k);
+      if (k) memcpy(all.data() + o, part.data(), k * 4);
+    }
+    return all;
+  }
+  // after the global replay: partition reads from the mirror (the device applied only its own movers' deltas), and the
+  // update flags of every partition any rank's mover touched
+  void sh_push_partitions(const std::vector<int32_t> &moves) {
+    const int C = (int)bi.size();
+    if ((int)h_upd.size() < C) h_upd.resize(C, 0);
+    for (size_t k = 0; k + 2 < moves.size(); k += 3) { h_upd[moves[k + 1]] = 1; h_upd[moves[k + 2]] = 1; }
+    std::vector<uint32_t> rd(C);
+    for (int i = 0; i < C; i++) rd[i] = bi[i].reads;
+    D2_HIP(hipMemcpyAsync(P.creads, rd.data(), (size_t)C * 4, hipMemcpyHostToDevice, s->stream));
+    D2_HIP(hipMemcpyAsync(P.update_e, h_upd.data(), (size_t)C, hipMemcpyHostToDevice, s->stream));
+    D2_HIP(hipStreamSynchronize(s->stream));   // (sources are locals)
+  }
+  // this rank's movers of the call just fetched, complete
+  std::vector<int32_t> local_moves(int slot) {
+    const int nm = h_rout.p->cnt[slot];
+    std::vector<int32_t> mv((size_t)3 * std::max(nm, 0));
+    if (nm > MOVERS_INLINE) {
+      D2_HIP(hipMemcpyAsync(mv.data(), d_movers.p + (size_t)slot * 3 * N, (size_t)3 * nm * 4, hipMemcpyDeviceToHost, s->side));
+      D2_HIP(hipStreamSynchronize(s->side));
+    } else if (nm > 0) memcpy(mv.data(), h_rout.p->mov[slot], (size_t)3 * nm * 4);
+    return mv;
+  }
+  // one b_shuffle2 call in sharded mode: device arg-max on the own block, then every rank replays every rank's moves
+  bool sharded_shuffle() {
+    D2_HIP(hipMemsetAsync(ro()->cnt, 0, 8, s->stream));
+    enqueue_shuffle(0);
+    fetch_round_out();
+    const std::vector<int32_t> mine = local_moves(0);
+    const std::vector<int32_t> all = sh_all_moves(mine.data(), (int)(mine.size() / 3));
+    if (!all.empty()) replay_moves(all.data(), (int)(all.size() / 3));
+    sh_push_partitions(all);
+    snap_fresh = false;
+    return !all.empty();
   }
 
   // ---- device state -----------------------------------------------------------------------------
@@ -880,18 +952,30 @@ struct Run {
     auto t0 = clk::now();
     int nsh = 0;
     int32_t *guard = nullptr;
-    if (do_shuffle && plain) {                          // the reference's plain loop (test knob, and unsorted input)
+    if (do_shuffle && plain) {                          // the reference's plain loop (test knob, unsorted input, sharded runs)
       bool shuffled = true;
       while (shuffled && nsh < MAX_SHUFFLE) {
-        D2_HIP(hipMemsetAsync(ro()->cnt, 0, 8, s->stream));
-        enqueue_shuffle(0);
-        fetch_round_out();
-        shuffled = h_rout.p->cnt[0] > 0;
-        apply_shuffle_result(0);
+        if (shard) shuffled = sharded_shuffle();
+        else {
+          D2_HIP(hipMemsetAsync(ro()->cnt, 0, 8, s->stream));
+          enqueue_shuffle(0);
+          fetch_round_out();
+          shuffled = h_rout.p->cnt[0] > 0;
+          apply_shuffle_result(0);
+        }
         nsh++;
       }
       enqueue_pupdate_bud(nullptr);
       fetch_round_out();
+      if (shard) std::fill(h_upd.begin(), h_upd.end(), (uint8_t)0);   // b_p_update has consumed the flags (pval.cpp:24,37)
+      pending_slot = -1;
+      st.ms_bookkeep += ms_since(t0);
+      return;
+    }
+    if (shard && !do_shuffle) {                         // (after round 0: b_p_update + the first b_bud)
+      enqueue_pupdate_bud(nullptr);
+      fetch_round_out();
+      std::fill(h_upd.begin(), h_upd.end(), (uint8_t)0);
       pending_slot = -1;
       st.ms_bookkeep += ms_since(t0);
       return;
@@ -942,6 +1026,7 @@ struct Run {
     int nsh = 0;
     bool shuffled;
     do {
+      if (shard) { shuffled = sharded_shuffle(); continue; }
       D2_HIP(hipMemsetAsync(ro()->cnt, 0, 8, s->stream));
       enqueue_shuffle(0);
       fetch_round_out();
@@ -985,12 +1070,15 @@ struct Run {
     if (!use_v2 && (size_t)h.node_count + (size_t)N > (size_t)P.node_cap)
       grow_nodes(std::max((size_t)P.node_cap * 2, (size_t)h.node_count + 2 * (size_t)N));
     auto pick = [&](int track, BudTie &out, double &p_out) -> bool {
-      const int n = h.nties[track];
-      if (!h.found[track] || n <= 0) return false;
-      if (n == 1) { out = h.ties[track][0]; p_out = host_get_pA(out); return true; }
+      int n = h.nties[track];
+      if (!shard) {
+        if (!h.found[track] || n <= 0) return false;
+        if (n == 1) { out = h.ties[track][0]; p_out = host_get_pA(out); return true; }
+      } else if (!h.found[track] || n < 0) n = 0;         // (this rank has no candidate; others may)
       replay_pending();                                   // slot order and partition reads must be current
       std::vector<BudTie> cand;
-      if (n <= BUD_TIES) cand.assign(h.ties[track], h.ties[track] + n);
+      if (n == 0) { }
+      else if (n <= BUD_TIES) cand.assign(h.ties[track], h.ties[track] + n);
       else if (use_v2 && n <= TIES_FULL) {   // the device keeps the full records (it is halted: nothing rewrites them)
         cand.resize(n);
         D2_HIP(hipMemcpyAsync(cand.data(), v2_tiesrec.p + (size_t)track * TIES_FULL, (size_t)n * sizeof(BudTie), hipMemcpyDeviceToHost, s->side));
@@ -1011,6 +1099,19 @@ struct Run {
           c.raw = t[k]; c.from = clust_of[t[k]]; c.from_reads = bi[c.from].reads;
           c.comp_i = ci[t[k]]; c.comp_lam = lam[t[k]]; c.comp_ham = ham[t[k]]; c.p = 0; c.pad = 0;
         }
+      }
+      if (shard) {
+        // every rank lists the exact and near ties of ITS best key; the union holds the ties of the best key of all (a worse
+        // rank's window lies above the global one), and b_bud's rule below picks among them with the host's arithmetic
+        std::vector<BudTie> all;
+        for (auto &part : sh_gatherv(cand.data(), cand.size() * sizeof(BudTie))) {
+          const size_t k = part.size() / sizeof(BudTie), o = all.size();
+          all.resize(o + k);
+          if (k) memcpy((void *)(all.data() + o), part.data(), k * sizeof(BudTie));
+        }
+        cand.swap(all);
+        n = (int)cand.size();
+        if (n == 0) return false;
       }
       auto before = [&](int a, int b) { return clust_of[a] < clust_of[b] || (clust_of[a] == clust_of[b] && slot_of[a] < slot_of[b]); };
       int bk = -1;
@@ -1057,6 +1158,10 @@ struct Run {
     nclust_dev = b.newi + 1;
     snap_fresh = true;                                   // k_apply_bud rewrote the whole snapshot
     ri ^= 1;
+    if (shard) {
+      if ((int)h_upd.size() <= b.newi) h_upd.resize(b.newi + 1, 0);
+      h_upd[b.newi] = 1; h_upd[b.c.from] = 1;            // (cluster.cpp:341-346: both partitions' expected reads changed)
+    }
   }
 
   // the same, already done by k_auto_birth (and the next round already launched behind it): just book it
@@ -1485,16 +1590,25 @@ void init_run(Run &run, dada2hip_sample *s, const double *err, int err_ncol, con
 
 // ---- dada_uniques proper: run_dada (Rmain.cpp:297-336) + outputs (Rmain.cpp:172-294, error.cpp) --
 void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2hip_opts *opts,
-                const dada2hip_hooks *hooks, dada2hip_result *R) {
+                const dada2hip_hooks *hooks, dada2hip_result *R, const dada2hip_shard *shard = nullptr) {
   auto t_total = clk::now();
   select_device(s->device);
   if (!err || !opts) throw InputError{"Error matrix must have 16 rows."};
   check_opts(*opts, s->qmax, err_ncol);
   SampleDev &D = s->D;
   const int N = D.N;
+  if (shard && (shard->world < 1 || shard->rank < 0 || shard->rank >= shard->world || !shard->exchange))
+    throw InputError{"dada2hip: invalid shard descriptor."};
+  if (shard && shard->world == 1) shard = nullptr;      // one rank: the ordinary run
+  // this rank's block of uniques (restored on every exit: the resident sample serves unsharded runs too)
+  struct RangeGuard { SampleDev &D; ~RangeGuard() { D.r_lo = 0; D.r_hi = D.N; } } range_guard{D};
+  D.r_lo = shard ? (int32_t)((int64_t)N * shard->rank / shard->world) : 0;
+  D.r_hi = shard ? (int32_t)((int64_t)N * (shard->rank + 1) / shard->world) : N;
   if (!s->run_cache) s->run_cache = std::make_shared<Run>();
   Run &run = *static_cast<Run *>(s->run_cache.get());
   run.hooks = hooks;
+  run.shard = shard; run.lo = D.r_lo; run.hi = D.r_hi;
+  run.h_upd.assign(1, 1);
   init_run(run, s, err, err_ncol, opts, opts->kdist_cutoff);
   run.st.ms_upload = s->ms_upload;
   hipStream_t stq = s->stream;
@@ -1514,7 +1628,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       b0.reads += s->h_reads[i];
       if (s->h_reads[i] > mx) { b0.center = (uint32_t)i; mx = s->h_reads[i]; }
     }
-    run.plain = getenv("DADA2HIP_NO_SPECULATION") != nullptr || b0.raw[0] != b0.center;
+    run.plain = getenv("DADA2HIP_NO_SPECULATION") != nullptr || b0.raw[0] != b0.center || shard != nullptr;
     run.no_auto = run.plain || getenv("DADA2HIP_NO_AUTOBIRTH") != nullptr;
     const uint8_t one = 1;
     D2_HIP(hipMemcpy(run.P.slot0, &one, 1, hipMemcpyHostToDevice));   // unique 0 sits in slot 0 of partition 0
@@ -1525,7 +1639,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   run.nclust_dev = 1;
   int max_clust = opts->max_clust < 1 ? N : opts->max_clust;
   run.max_clust_run = max_clust;
-  run.use_v2 = max_clust > 1 && run.want_v2();
+  run.use_v2 = max_clust > 1 && !shard && run.want_v2();
   if (run.use_v2) run.v2_alloc(max_clust);
   run.compare_round(0, (int)run.bi[0].center, 1.0);   // Rmain.cpp:309-310: no k-mer screen in round 0
   // run_dada's loop (Rmain.cpp:312-331), rotated: every iteration ends with b_p_update + the b_bud that opens
@@ -1575,15 +1689,20 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   const size_t per = coop_fin ? (size_t)nw_ad_apw(D, run.ap) : (wide_fin ? (size_t)nw_adw_apw(D, run.ap) : 64);
   std::vector<int32_t> work, chunk_centre, centre_of_cluster(C);
   work.reserve((size_t)N + per * (size_t)C);
+  uint64_t n_final_local = 0;
   for (int i = 0; i < C; i++) {
     centre_of_cluster[i] = (int32_t)run.bi[i].center;
     const auto &m = run.bi[i].raw;
+    size_t kk = 0;
     for (size_t k = 0; k < m.size(); k++) {
-      if (k % per == 0) chunk_centre.push_back((int32_t)run.bi[i].center);
+      if ((int)m[k] < D.r_lo || (int)m[k] >= D.r_hi) continue;   // (sharded run: the members of this rank's block)
+      if (kk++ % per == 0) chunk_centre.push_back((int32_t)run.bi[i].center);
       work.push_back((int32_t)m[k]);
+      n_final_local++;
     }
     while (work.size() % per) work.push_back(-1);
   }
+  if (work.empty()) { work.assign(per, -1); chunk_centre.push_back((int32_t)run.bi[0].center); }
   s->d_work.alloc(work.size()); s->d_chunk_centre.alloc(chunk_centre.size());
   s->d_view.alloc((size_t)N * LV);
   s->d_correct.alloc(N);
@@ -1594,7 +1713,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   if (opts->band_size == 0) {
     launch_gapless(D, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), run.ap, s->d_err.p, s->d_lambda.p,
                    s->d_ham.p, s->d_view.p, LV, 0, stq);
-    run.st.ngapless += (uint64_t)N;
+    run.st.ngapless += n_final_local;
   } else {
     const int evn_i = run.ev_begin(Run::EV_NW, true, false, /*big=*/true);
     if (coop_fin)
@@ -1609,7 +1728,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
                 s->d_lambda.p, s->d_ham.p, s->d_view.p, LV, 0, nullptr, 0, nullptr, stq);
     }
     run.ev_end(evn_i);
-    run.st.nnw += (uint64_t)N;
+    run.st.nnw += n_final_local;
   }
   // final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252), on the device
   const int ev_fin = run.ev_begin(Run::EV_FINAL, run.profile_all);
@@ -1709,8 +1828,10 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     }
     D2_HIP(hipMemcpyAsync(&bview[(size_t)LV], s->d_view_b.p, (size_t)nb * LV * 2, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
-    run.st.ngapless += (uint64_t)n_gl;
-    run.st.nnw += (uint64_t)n_nw;
+    if (!shard || shard->rank == 0) {                       // (every rank aligns the few birth pairs; counted once)
+      run.st.ngapless += (uint64_t)n_gl;
+      run.st.nnw += (uint64_t)n_nw;
+    }
   }
   D2_HIP(hipStreamSynchronize(stq));
   D2_HIP(hipGetLastError());
@@ -1766,6 +1887,54 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
         run.st.batch_compares = run.v2_miss_launches;
         if (!run.profile_all) run.st.screen_kernel_launches = 1 + run.v2_miss_launches;
       } else run.st.screen_bytes = (run.st.ncompare - run.st.nskipped) * row + run.st.ncompare * 6;
+    }
+  }
+
+  if (shard) {
+    // ---- the blocks' results to every rank: per-unique values by block, sums by all-reduce -------------
+    const int W = shard->world;
+    auto gather_block = [&](void *base, size_t elem) {
+      auto parts = run.sh_gatherv((const char *)base + (size_t)D.r_lo * elem, (size_t)(D.r_hi - D.r_lo) * elem);
+      for (int w = 0; w < W; w++) {
+        const size_t lo_w = (size_t)((int64_t)N * w / W);
+        if (!parts[w].empty()) memcpy((char *)base + lo_w * elem, parts[w].data(), parts[w].size());
+      }
+    };
+    gather_block(R->pval.data(), 8);
+    gather_block(correct.data(), 1);
+    gather_block(nsubs.data(), 4);
+    {
+      std::vector<int64_t> v(R->subqual.size() + qsum.size() + qn.size());
+      size_t o = 0;
+      for (int32_t x : R->subqual) v[o++] = x;
+      for (unsigned long long x : qsum) v[o++] = (int64_t)x;
+      for (uint32_t x : qn) v[o++] = x;
+      run.sh_allreduce(v);
+      o = 0;
+      for (auto &x : R->subqual) x = (int32_t)v[o++];          // (int32 wrap-around as R's integer matrix, error.cpp:152-167)
+      for (auto &x : qsum) x = (unsigned long long)v[o++];
+      for (auto &x : qn) x = (uint32_t)v[o++];
+    }
+    {   // post-hoc comparisons (partition of a centre, partition compared, lambda) found in each block's store
+      struct Ph { int32_t j, i; double lam; };
+      std::vector<Ph> mine(ph_lam.size());
+      for (size_t k = 0; k < mine.size(); k++) mine[k] = Ph{ph_ji[2 * k], ph_ji[2 * k + 1], ph_lam[k]};
+      ph_ji.clear(); ph_lam.clear();
+      for (auto &part : run.sh_gatherv(mine.data(), mine.size() * sizeof(Ph)))
+        for (size_t k = 0; k + sizeof(Ph) <= part.size(); k += sizeof(Ph)) {
+          Ph e;
+          memcpy(&e, part.data() + k, sizeof(Ph));
+          ph_ji.push_back(e.j); ph_ji.push_back(e.i); ph_lam.push_back(e.lam);
+        }
+    }
+    {   // work counters: every rank counted its own block's comparisons
+      std::vector<int64_t> v = {(int64_t)run.st.nnw, (int64_t)run.st.ngapless, (int64_t)run.st.nshroud, (int64_t)run.st.nskipped,
+                                (int64_t)run.st.nstored};
+      run.sh_allreduce(v);
+      run.st.nnw = (uint64_t)v[0]; run.st.ngapless = (uint64_t)v[1]; run.st.nshroud = (uint64_t)v[2]; run.st.nskipped = (uint64_t)v[3];
+      run.st.nstored = (uint64_t)v[4];
+      run.st.nw_cells = run.st.nnw * run.nw_cells_per_alignment();
+      run.st.screen_bytes = (run.st.ncompare - run.st.nskipped) * 2 * (uint64_t)(D.maxlen - KMER_SIZE + 1) + run.st.ncompare * 6;
     }
   }
 
@@ -1869,6 +2038,20 @@ int dada2hip_sample_set_priors(dada2hip_sample *s, const uint8_t *priors, char *
     for (int i = 0; i < s->D.N; i++) s->h_prior[i] = priors && priors[i] ? 1 : 0;
     D2_HIP(hipMemcpy(s->D.prior, s->h_prior.data(), (size_t)s->D.N, hipMemcpyHostToDevice));
   });
+}
+
+int dada2hip_sample_run_sharded(dada2hip_sample *s, const double *err, int32_t err_ncol, const dada2hip_opts *opts,
+                                const dada2hip_hooks *hooks, const dada2hip_shard *shard, dada2hip_result **out,
+                                char *errbuf, size_t errlen) {
+  if (out) *out = nullptr;
+  dada2hip_result *R = new dada2hip_result();
+  int rc = guarded(errbuf, errlen, [&] {
+    if (!shard) throw InputError{"dada2hip: invalid shard descriptor."};
+    sample_run(s, err, err_ncol, opts, hooks, R, shard);
+  });
+  if (rc != DADA2HIP_OK) { delete R; return rc; }
+  *out = R;
+  return rc;
 }
 
 void dada2hip_sample_free(dada2hip_sample *s) {

@@ -39,6 +39,10 @@ struct DeviceError {
 // Uniques of one sample, resident in HBM (layout: DESIGN.md §3).
 struct SampleDev {
   int32_t N = 0, maxlen = 0, minlen = 0;
+  // the uniques this process works on: [r_lo, r_hi) = [0, N) normally; one contiguous block of them when the sample is
+  // sharded over several GPUs (dada2hip_sample_run_sharded: every rank holds all sequences, each does its block's
+  // comparisons, shuffles and p-values - the host-driven round loop)
+  int32_t r_lo = 0, r_hi = 0;
   int32_t W2 = 0;   // u32 words per 2-bit packed sequence row (multiple of 4 -> 16 B aligned rows)
   int32_t LQ = 0;   // bytes per quality row (multiple of 16)
   int32_t LK = 0;   // u16 entries per ordered-k-mer row (multiple of 8 -> 16 B)

@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256) void k_screen(SampleDev S, int centre, ScreenP
   const int sub = tid & 15, grp = tid >> 4;
   const int nchunk = (S.maxlen - KMER_SIZE + 1 + 7) >> 3;     // 16-byte chunks (8 k-mer records) per row; rows may be padded to 128 B
   const bool two = nchunk <= 32;                              // each lane owns <= 2 chunks: keep them in registers
-  for (int base = blockIdx.x * 16; base < S.N; base += gridDim.x * 16) {
+  for (int base = S.r_lo + blockIdx.x * 16; base < S.r_hi; base += gridDim.x * 16) {
     const int r = base + grp;
-    if (r >= S.N) continue;
+    if (r >= S.r_hi) continue;
     // issue the row's chunks and the per-unique scalars together (independent loads)
     const uint4 *row = (const uint4 *)(S.kord + (size_t)r * S.LK);
     const uint4 pad4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // rank 63: never counted
@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci,
   if (threadIdx.x < 2) s_cls[threadIdx.x] = 0;
   __syncthreads();
   int my_shroud = 0, my_skip = 0;
-  for (int base = blockIdx.x * 256; base < S.N; base += gridDim.x * 256) {
+  for (int base = S.r_lo + blockIdx.x * 256; base < S.r_hi; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(256) void k_store(PartState P, SampleDev S, int ci,
     double l = 0.0;
     uint32_t h = 0;
     int pos = 0;
-    if (r < S.N) {
+    if (r < S.r_hi) {
       const uint8_t cl = cls[r];
       my_shroud += (cl == CLS_SHROUD);
       my_skip += (cl == CLS_SKIP);
@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const
       atomicAdd((unsigned long long *)&P.totals[threadIdx.x], (unsigned long long)sa.round_counters[threadIdx.x]);
     if (threadIdx.x < 2) s_cls[threadIdx.x] = 0;
   }
-  for (int base = blockIdx.x * 256; base < S.N; base += gridDim.x * 256) {
+  for (int base = S.r_lo + blockIdx.x * 256; base < S.r_hi; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
     if (threadIdx.x == 0) { s_n = 0; s_sn = 0; }
     __syncthreads();
@@ -1665,13 +1665,13 @@ __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const
     int best_i = 0x7FFFFFFF;
     uint32_t best_h = 0;
     int head = -1;
-    if (r < S.N) head = P.head[r];
+    if (r < S.r_hi) head = P.head[r];
     // ---- store filter of this round's comparison ----
     bool keep = false;
     double l = 0.0;
     uint32_t h = 0;
     int spos = 0;
-    if (STORE && r < S.N) {
+    if (STORE && r < S.r_hi) {
       const uint8_t cl = sa.cls[r];
       my_shroud += (cl == CLS_SHROUD);
       my_skip += (cl == CLS_SKIP);
@@ -1703,7 +1703,7 @@ __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const
     // ---- arg-max over the stored comparisons and the move ----
     bool move = false;
     int from = 0, to = 0, pos = 0;
-    if (r < S.N) {
+    if (r < S.r_hi) {
       for (int n = head; n >= 0; n = P.node_next[n]) {
         const int i = P.node_i[n];
         const double nl = P.node_lam[n], e = nl * creads_snap[i];
@@ -1798,7 +1798,7 @@ __global__ __launch_bounds__(256) void k_pupdate_budmin(PartState P, SampleDev S
   __syncthreads();
   BudKey b0 = init, b1 = init;
   int would = 0;
-  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+  for (int r = S.r_lo + blockIdx.x * 256 + threadIdx.x; r < S.r_hi; r += gridDim.x * 256) {
     const int cl = P.clust_of[r];
     if (check_cnt) {
       double best_e = -1.0;
@@ -1903,7 +1903,7 @@ __global__ __launch_bounds__(256) void k_bud_ties(PartState P, SampleDev S, BudP
   // (no window when the best p-value is clearly not significant: b_bud then gives no birth whatever the order)
   const bool sig0 = b0.p * S.N < 2.0 * bp.omegaA, sig1 = b1.p < 2.0 * bp.omegaP;
   const double thr0 = sig0 ? b0.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0, thr1 = sig1 ? b1.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0;
-  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+  for (int r = S.r_lo + blockIdx.x * 256 + threadIdx.x; r < S.r_hi; r += gridDim.x * 256) {
     if (lock_tmp[r]) P.lock[r] = 1;                                    // b_p_update's greedy locks (pval.cpp:26-36)
     if (!bud_candidate(P, S, r, bp)) continue;
     const double p = P.p[r];
@@ -1999,7 +1999,7 @@ __global__ __launch_bounds__(256) void k_auto_birth(PartState P, SampleDev S, ui
 // final per-unique p and the OMEGA_C decision (Rmain.cpp:238-252)
 __global__ __launch_bounds__(256) void k_final_p(PartState P, SampleDev S, double omegaC, uint8_t *__restrict__ correct) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= S.N) return;
+  if (r < S.r_lo || r >= S.r_hi) return;
   const int cl = P.clust_of[r];
   double p = 1.0;
   uint8_t ok = 1;
@@ -2018,7 +2018,7 @@ __global__ __launch_bounds__(256) void k_posthoc(PartState P, SampleDev S, int n
                                                  double *__restrict__ out_lam, int32_t *__restrict__ nout, int cap) {
   (void)nnodes; (void)node_raw;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= S.N) return;
+  if (r < S.r_lo || r >= S.r_hi) return;
   const int j = cluster_of_centre[r];
   if (j < 0) return;
   for (int n = P.head[r]; n >= 0; n = P.node_next[n]) {
@@ -2124,7 +2124,7 @@ __global__ __launch_bounds__(256) void k_final_tables(SampleDev S, const uint16_
   __syncthreads();
   // one wave per unique, lanes stride over centre positions
   const int lane = threadIdx.x & 63, gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  for (int r = gwave; r < S.N; r += nwaves) {
+  for (int r = S.r_lo + gwave; r < S.r_hi; r += nwaves) {
     const int cl = cluster_of[r], c = centre_of_cluster[cl];
     const int Lc = S.len[c];
     const uint32_t *crow = S.seq2 + (size_t)c * S.W2;

@@ -135,6 +135,32 @@ int dada2hip_sample_set_priors(dada2hip_sample *s, const uint8_t *priors, char *
 int dada2hip_sample_run(dada2hip_sample *s, const double *err, int32_t err_ncol, const dada2hip_opts *opts,
                         const dada2hip_hooks *hooks, dada2hip_result **out, char *errbuf, size_t errlen);
 void dada2hip_sample_free(dada2hip_sample *s);
+
+/* ---- one sample over several GPUs (last row: "intra-sample sharding") --------------
+ * The reference has no counterpart: a sample is one serial dada_uniques call (R/dada.R:266).  Here every rank (one
+ * process per GPU) holds the whole sample's sequences, qualities and k-mer records, and does the per-unique work of
+ * run_dada - b_compare (src/cluster.cpp:90-204), b_shuffle2's arg-max (:229-239), b_p_update (src/pval.cpp:14-40), the
+ * first stage of b_bud (src/cluster.cpp:284-308), the final alignments (src/Rmain.cpp:172-236) - for ONE contiguous
+ * block of the uniques, [nraw * rank / world, nraw * (rank + 1) / world).  What the reference's serial bookkeeping
+ * shares between uniques is exchanged through `exchange` at fixed points, the same sequence on every rank:
+ *   per b_shuffle2 call   the (unique, from, to) triples that moved  (all ranks replay all of them in the reference's order:
+ *                         partition reads, member slots and the arg-max snapshot of the next call stay identical everywhere)
+ *   per b_bud             the candidate records of each rank's best key and its near ties (48 B each)
+ *   at the end            p-value / correction / substitution count of every unique, the transition and quality sums
+ * and every rank returns the complete, identical result.  The round loop runs host-driven (one centre per round, every
+ * decision on the host): the exchanges sit between its kernels.
+ *   kind 0  all-gather: every rank contributes send_bytes bytes (the same count on all ranks); recv receives
+ *           world * send_bytes bytes in rank order
+ *   kind 1  all-reduce(sum) of send_bytes / 8 int64 values; send == recv (in place)
+ * `exchange` returns 0 on success; anything else aborts the run with DADA2HIP_ERR_RUNTIME on that rank. */
+typedef struct dada2hip_shard {
+  int32_t rank, world;
+  int (*exchange)(void *user, int32_t kind, const void *send, int64_t send_bytes, void *recv);
+  void *user;
+} dada2hip_shard;
+int dada2hip_sample_run_sharded(dada2hip_sample *s, const double *err, int32_t err_ncol, const dada2hip_opts *opts,
+                                const dada2hip_hooks *hooks, const dada2hip_shard *shard, dada2hip_result **out,
+                                char *errbuf, size_t errlen);
 int32_t dada2hip_sample_nraw(const dada2hip_sample *s);
 int32_t dada2hip_sample_maxlen(const dada2hip_sample *s);
 

@@ -24,6 +24,8 @@ for s in $STEPS; do
     bench3q) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg3_quick.json 2> $OUT/bench_cfg3_quick.err; echo "bench3q rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg3_quick.json; python3 -c "import json;b=json.load(open('$OUT/bench_cfg3_quick.json'));print(b['resident']);print(b['phases_ms_last_step'])" ;;
     nwphases) timeout 600 python tools/nw_phases.py --sizes 4000,8700,18000,36000 > $OUT/nw_phases.jsonl 2> $OUT/nw_phases.err; echo "nwphases rc=$?" >> $OUT/steps.log; cat $OUT/nw_phases.jsonl ;;
     trace)   timeout 600 python tools/trace_round.py --seqs ${TRACE_SEQS:-60,300,600} > $OUT/round_trace.jsonl 2> $OUT/round_trace.err; echo "trace rc=$?" >> $OUT/steps.log; cat $OUT/round_trace.jsonl; tail -3 $OUT/round_trace.err ;;
+    bench3shard) timeout 900 python bench.py --shard --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass > $OUT/bench_cfg3_shard1.json 2> $OUT/bench_cfg3_shard1.err; echo "bench3shard rc=$?" >> $OUT/steps.log; cut -c1-500 $OUT/bench_cfg3_shard1.json; tail -3 $OUT/bench_cfg3_shard1.err ;;
+    tests_shard) timeout 900 python -m pytest tests/test_shard.py -m gpu -q -p no:cacheprovider > $OUT/gputests_shard.log 2>&1; echo "tests_shard rc=$?" >> $OUT/steps.log; tail -15 $OUT/gputests_shard.log ;;
     bench3full) timeout 1200 python bench.py --steps 5 --warmup 2 --cpu-full > $OUT/bench_cfg3_cpufull.json 2> $OUT/bench_cfg3_cpufull.err; echo "bench3full rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_cpufull.json ;;
     bench3sc) timeout 900 python bench.py --steps 2 --warmup 1 --selfconsist > $OUT/bench_cfg3_selfconsist.json 2> $OUT/bench_cfg3_selfconsist.err; echo "bench3sc rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_selfconsist.json ;;
     bench2)  timeout 600 python bench.py --config 2 --steps 10 --warmup 2 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; echo "bench2 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2.json ;;
