@@ -1568,9 +1568,6 @@ void alloc_round_buffers(dada2hip_sample *s) {
 }
 
 void check_opts(const dada2hip_opts &o, int qmax, int ncol) {
-  if (o.homo_gap != o.gap && !o.vectorized_alignment && o.homo_gap <= 0 && o.band_size != 0)
-    throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED,
-                     "dada2hip: HOMOPOLYMER_GAP_PENALTY != GAP_PENALTY (nwalign_endsfree_homo) is outside the implemented path."};
   if (ncol < 1) throw InputError{"Error matrix must have 16 rows."};
   // (checked whatever USE_QUALS says: the output tables index err's columns by quality, error.cpp:152-167)
   if (qmax > ncol - 1) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "Rounded quality exceeded range of err lookup table."};
@@ -1583,6 +1580,10 @@ void init_run(Run &run, dada2hip_sample *s, const double *err, int err_ncol, con
   alloc_round_buffers(s);
   run.wclass = nw_class(opts->band_size, s->D.maxlen, s->D.minlen);   // (the lane kernel's scratch ring is allocated on first use)
   run.ap = AlignParams{opts->match, opts->mismatch, opts->gap, opts->band_size, nw_sentinel(*opts), opts->use_quals, err_ncol};
+  // raw_align's choice (nwalign_endsfree.cpp:57-64): nwalign_endsfree_homo only with VECTORIZED_ALIGNMENT off and a homopolymer
+  // penalty that differs from the gap penalty (R/dada.R:229-231 switches the vectorized aligner off in that case)
+  run.ap.homo_gap = (!opts->vectorized_alignment && opts->homo_gap != opts->gap && opts->homo_gap <= 0) ? opts->homo_gap : opts->gap;
+  run.ap.endsfree = 1;
   run.sp = ScreenParams{opts->use_kmers, opts->gapless, opts->band_size, opts->SSE};
   run.thresh_round = make_thresh(s->D.maxlen, cutoff);
   run.thresh_one = make_thresh(s->D.maxlen, 1.0);
@@ -2221,12 +2222,10 @@ int dada2hip_calc_pA(int32_t n, const int32_t *reads, const double *E_reads, con
 }
 
 // ---- pairwise alignment exports (C_nwalign evaluate.cpp:18 / C_nwvec nwalign_vectorized.cpp:321) ---
-int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int32_t match, int32_t mismatch,
-                   int32_t gap_p, int32_t band, int32_t endsfree, int32_t device, char *const *out, char *errbuf,
-                   size_t errlen) {
+static int nwvec_any(int32_t n, const char *const *s1, const char *const *s2, int32_t match, int32_t mismatch,
+                     int32_t gap_p, int32_t homo_gap_p, int32_t band, int32_t endsfree, int32_t device, char *const *out, char *errbuf,
+                     size_t errlen) {
   return guarded(errbuf, errlen, [&] {
-    if (!endsfree)
-      throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: endsfree=FALSE (global nwalign) is outside the denoising path."};
     if (n <= 0) return;
     // a throw-away resident sample holding the 2n strings; pair i = (centre 2i, raw 2i+1), one pair per wave
     std::vector<const char *> seqs(2 * (size_t)n);
@@ -2252,6 +2251,11 @@ int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int3
     memset(&o, 0, sizeof o);
     o.match = match; o.mismatch = mismatch; o.gap = gap_p; o.vectorized_alignment = 1;
     AlignParams ap{match, mismatch, gap_p, band, nw_sentinel(o), 0, 1};
+    // C_nwalign (evaluate.cpp:36-48): nwalign_endsfree[_homo] when endsfree, the global nwalign (one gap penalty) otherwise;
+    // the scalar aligners mark the band edge with -9999 (nwalign_endsfree.cpp:113-119)
+    ap.endsfree = endsfree ? 1 : 0;
+    ap.homo_gap = endsfree ? homo_gap_p : gap_p;
+    if (!ap.plain()) ap.sentinel = -9999;
     std::vector<int32_t> work((size_t)n * 64, -1), cc(n);
     for (int i = 0; i < n; i++) { work[(size_t)i * 64] = 2 * i + 1; cc[i] = 2 * i; }
     const int stride = 2 * maxlen + 2;
@@ -2284,6 +2288,12 @@ int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int3
       o0[len] = 0; o1[len] = 0;
     }
   });
+}
+
+int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int32_t match, int32_t mismatch,
+                   int32_t gap_p, int32_t band, int32_t endsfree, int32_t device, char *const *out, char *errbuf,
+                   size_t errlen) {
+  return nwvec_any(n, s1, s2, match, mismatch, gap_p, gap_p, band, endsfree, device, out, errbuf, errlen);
 }
 
 // ---- bimera identification (chimera.cpp): the step after dada() ---------------------------------------------------
@@ -2463,13 +2473,9 @@ int dada2hip_is_bimera(const char *sq, int32_t npars, const char *const *pars, i
 
 int dada2hip_nwalign(const char *s1, const char *s2, int32_t match, int32_t mismatch, int32_t gap_p, int32_t homo_gap_p,
                      int32_t band, int32_t endsfree, int32_t device, char *out0, char *out1, char *errbuf, size_t errlen) {
-  if (gap_p != homo_gap_p) {
-    set_err(errbuf, errlen, "dada2hip: homo_gap_p != gap_p (nwalign_endsfree_homo) is outside the implemented path.");
-    return DADA2HIP_ERR_UNSUPPORTED;
-  }
   const char *a[1] = {s1}, *b[1] = {s2};
   char *o[2] = {out0, out1};
-  return dada2hip_nwvec(1, a, b, match, mismatch, gap_p, band, endsfree, device, o, errbuf, errlen);
+  return nwvec_any(1, a, b, match, mismatch, gap_p, homo_gap_p, band, endsfree, device, o, errbuf, errlen);
 }
 
 // ---- result getters ------------------------------------------------------------------------------

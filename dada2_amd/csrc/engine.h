@@ -66,6 +66,11 @@ struct SampleDev {
 struct AlignParams {
   int32_t match, mismatch, gap, band, sentinel;
   int32_t use_quals, ncol;
+  // the two aligners beside nwalign_endsfree / nwalign_vectorized2 (lane kernels k_nw / k_nw_gen only):
+  int32_t homo_gap = 0;   // gap opposite a base of a homopolymer run of >= 3 (nwalign_endsfree_homo, nwalign_endsfree.cpp:220-396);
+                          // equal to `gap` = no homopolymer gapping
+  int32_t endsfree = 1;   // 0: global nwalign (nwalign_endsfree.cpp:403-537): end gaps cost `gap`, no free moves on the last row / column
+  bool plain() const { return endsfree && homo_gap == gap; }
 };
 
 struct ScreenParams {

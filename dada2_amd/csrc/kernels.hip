@@ -22,6 +22,15 @@ static __device__ __forceinline__ uint32_t base_at(const uint32_t *__restrict__ 
   return (row[p >> 4] >> ((p & 15) << 1)) & 3u;
 }
 
+// position p of a 2-bit row of length len lies in a run of >= 3 equal bases (nwalign_endsfree.cpp:227-256)
+static __device__ __forceinline__ uint32_t homo_at(const uint32_t *__restrict__ row, int len, int p) {
+  if (p < 0 || p >= len) return 0u;
+  const uint32_t b = base_at(row, p);
+  const int l = (p >= 1 && base_at(row, p - 1) == b) ? ((p >= 2 && base_at(row, p - 2) == b) ? 2 : 1) : 0;
+  const int r = (p + 1 < len && base_at(row, p + 1) == b) ? ((p + 2 < len && base_at(row, p + 2) == b) ? 2 : 1) : 0;
+  return (l + r >= 2) ? 1u : 0u;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k-mer records, one thread per unique with a private 1024-entry u16 count table in LDS
 // (table[km][lane], 128 KiB per 64-thread block).  For every position i < len-4 it emits the
@@ -466,17 +475,21 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
     const int W = lband + rband + 1;          // <= WMAX (host picks the kernel class)
     const uint32_t *crow = S.seq2 + (size_t)c * S.W2, *rrow = S.seq2 + (size_t)r * S.W2;
 
+    // the other two scalar aligners of the reference ride on the same sweep (wave-uniform switches): EF = ends-free (first
+    // row / column 0, free moves along the last row / column), HOMO = a gap opposite a homopolymer base costs HG
+    const bool EF = a.ap.endsfree != 0, HOMO = EF && a.ap.homo_gap != GAP;
+    const int HG = a.ap.homo_gap;
     int d[WMAX];
-    // row 0: D[0][j] = 0 for 0 <= j <= min(rband, L2)
+    // row 0: D[0][j] = 0 (global: j * gap) for 0 <= j <= min(rband, L2)
 #pragma unroll
     for (int k = 0; k < WMAX; k++) {
       const int j = k - lband;
-      d[k] = (j >= 0 && j <= rband && j <= L2) ? 0 : SENT;
+      d[k] = (j >= 0 && j <= rband && j <= L2) ? (EF ? 0 : j * GAP) : SENT;
     }
     // raw window: code at k = base of raw position (0-based) i - lband + k - 1, for the row about to be computed
-    uint32_t win[NW32];
+    uint32_t win[NW32], hwin[NW32];            // hwin: homopolymer flag of the raw base of each column (same fields)
 #pragma unroll
-    for (int w = 0; w < NW32; w++) win[w] = 0;
+    for (int w = 0; w < NW32; w++) { win[w] = 0; hwin[w] = 0; }
     for (int k = 0; k < WMAX; k++) {          // prologue for row i = 1
       const int p = 1 - lband + k - 1;
       const uint32_t code = (p >= 0 && p < L2) ? base_at(rrow, p) : 0u;
@@ -484,6 +497,11 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
 #pragma unroll
       for (int w = 0; w < NW32 - 1; w++) win[w] = (win[w] >> 2) | (win[w + 1] << 30);
       win[NW32 - 1] = (win[NW32 - 1] >> 2) | (code << (((WMAX - 1) & 15) << 1));
+      if (HOMO) {
+#pragma unroll
+        for (int w = 0; w < NW32 - 1; w++) hwin[w] = (hwin[w] >> 2) | (hwin[w + 1] << 30);
+        hwin[NW32 - 1] = (hwin[NW32 - 1] >> 2) | (homo_at(rrow, L2, p) << (((WMAX - 1) & 15) << 1));
+      }
     }
     int kzero = lband - 1;                    // k of column j == 0 in row i (row 1 here)
     int kend = L2 - 1 + lband;                // k of column j == L2 in row i
@@ -498,7 +516,8 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
         const uint32_t x = win[w] ^ crep;
         m[w] = ~(x | (x >> 1)) & 0x55555555u;             // bit 2k' set where raw base == centre base
       }
-      const int gapL = (i == L1) ? 0 : GAP;               // free moves along the last row
+      const int gapL = (EF && i == L1) ? 0 : GAP;         // free moves along the last row
+      const int gapU = (HOMO && homo_at(crow, L1, i - 1)) ? HG : GAP;   // up move: a gap opposite centre base i - 1
       const int khi = kend < W - 1 ? kend : W - 1;
       uint32_t pw[NPW];
 #pragma unroll
@@ -509,8 +528,8 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
         const uint32_t mbit = (m[k >> 4] >> ((k & 15) << 1)) & 1u;
         const int diag = d[k] + (mbit ? MATCH : MISMATCH);
         const int upn = (k + 1 < WMAX) ? d[k + 1] : SENT;
-        const int up = upn + ((k == kend) ? 0 : GAP);       // free moves along the last column
-        const int left = leftv + gapL;
+        const int up = upn + ((EF && k == kend) ? 0 : gapU);   // free moves along the last column
+        const int left = leftv + ((HOMO && !(EF && i == L1) && ((hwin[k >> 4] >> ((k & 15) << 1)) & 1u)) ? HG : gapL);
         const bool t1 = left >= diag;
         const int e1 = t1 ? left : diag;
         const uint32_t p1 = t1 ? 2u : 1u;
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
         const int e = t2 ? up : e1;
         const uint32_t p = t2 ? 3u : p1;
         const bool valid = (k > kzero) && (k <= khi);
-        const int v = valid ? e : ((k == kzero) ? 0 : SENT);
+        const int v = valid ? e : ((k == kzero) ? (EF ? 0 : i * GAP) : SENT);
         d[k] = v;
         leftv = v;
         pw[k >> 4] |= p << ((k & 15) << 1);
@@ -532,6 +551,11 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
 #pragma unroll
         for (int w = 0; w < NW32 - 1; w++) win[w] = (win[w] >> 2) | (win[w + 1] << 30);
         win[NW32 - 1] = (win[NW32 - 1] >> 2) | (code << (((WMAX - 1) & 15) << 1));
+        if (HOMO) {
+#pragma unroll
+          for (int w = 0; w < NW32 - 1; w++) hwin[w] = (hwin[w] >> 2) | (hwin[w + 1] << 30);
+          hwin[NW32 - 1] = (hwin[NW32 - 1] >> 2) | (homo_at(rrow, L2, p) << (((WMAX - 1) & 15) << 1));
+        }
       }
       kzero--;
       kend--;
@@ -566,13 +590,16 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
     const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
     const int W = lband + rband + 1;
     const uint32_t *crow = S.seq2 + (size_t)c * S.W2, *rrow = S.seq2 + (size_t)r * S.W2;
+    const bool EF = a.ap.endsfree != 0, HOMO = EF && a.ap.homo_gap != GAP;   // (see k_nw)
+    const int HG = a.ap.homo_gap;
     for (int k = 0; k < Wgen; k++) {
       const int j = k - lband;
-      drow[(size_t)k * 64 + lane] = (j >= 0 && j <= rband && j <= L2) ? 0 : SENT;
+      drow[(size_t)k * 64 + lane] = (j >= 0 && j <= rband && j <= L2) ? (EF ? 0 : j * GAP) : SENT;
     }
     for (int i = 1; i <= L1; i++) {
       const uint32_t cb = base_at(crow, i - 1);
-      const int gapL = (i == L1) ? 0 : GAP;
+      const int gapL = (EF && i == L1) ? 0 : GAP;
+      const int gapU = (HOMO && homo_at(crow, L1, i - 1)) ? HG : GAP;
       const int kzero = lband - i, kend = L2 - i + lband;
       const int khi = kend < W - 1 ? kend : W - 1;
       int leftv = SENT;
@@ -582,13 +609,13 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
         const int upn = (k + 1 < Wgen) ? drow[(size_t)(k + 1) * 64 + lane] : SENT;
         const int j = i - lband + k;
         const bool valid = (k > kzero) && (k <= khi);
-        int v = (k == kzero) ? 0 : SENT;
+        int v = (k == kzero) ? (EF ? 0 : i * GAP) : SENT;
         uint32_t p = 0;
         if (valid) {
           const uint32_t rb = base_at(rrow, j - 1);
           const int diag = dk + (rb == cb ? MATCH : MISMATCH);
-          const int up = upn + ((k == kend) ? 0 : GAP);
-          const int left = leftv + gapL;
+          const int up = upn + ((EF && k == kend) ? 0 : gapU);
+          const int left = leftv + ((HOMO && !(EF && i == L1) && homo_at(rrow, L2, j - 1)) ? HG : gapL);
           const bool t1 = left >= diag;
           const int e1 = t1 ? left : diag;
           const bool t2 = up >= e1;
@@ -1113,7 +1140,7 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap) { return ad_geom(ap.band, S.maxlen, S.minlen).APW; }
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
-  if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || !S.ad_ptr) return 0;   // (factor offsets are u16: 16 * ncol * 8 < 65 536)
+  if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || !S.ad_ptr || !ap.plain()) return 0;   // (factor offsets are u16: 16 * ncol * 8 < 65 536)
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 127) return 0;
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);   // (a centre per wave: the larger of the two layouts)
@@ -1453,7 +1480,7 @@ __global__ __launch_bounds__(256, 3) void k_nw_adw(NwArgs a, AdwGeom G) {
 
 // Does the wide anti-diagonal kernel apply to this sample / band?  (run descriptors hold 12-bit positions)
 bool nw_adw_ok(const SampleDev &S, const AlignParams &ap) {
-  return ap.band > 0 && S.maxlen <= 4095 && 2 * ap.band + (S.maxlen - S.minlen) + 2 <= 512;
+  return ap.plain() && ap.band > 0 && S.maxlen <= 4095 && 2 * ap.band + (S.maxlen - S.minlen) + 2 <= 512;
 }
 size_t nw_adw_ptr_words_per_wave(const SampleDev &S, const AlignParams &ap) {
   return (size_t)adw_geom(ap.band, S.maxlen, S.minlen).nblk16 * 256;

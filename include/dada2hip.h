@@ -202,8 +202,10 @@ void dada2hip_result_free(dada2hip_result *r);
  * dada2hip_nwalign == C_nwalign(s1, s2, match, mismatch, gap_p, homo_gap_p, band, endsfree)
  * (src/evaluate.cpp:18): ACGT in, two gapped strings out (capacity >= len1+len2+1 each).
  * dada2hip_nwvec == C_nwvec (src/nwalign_vectorized.cpp:321): n pairs at once; out[2*i], out[2*i+1]
- * are caller buffers of capacity >= len1_i+len2_i+1.  Both run the device NW kernel.
- * Only endsfree=1 with homo_gap_p == gap_p is on the denoising path and implemented. */
+ * are caller buffers of capacity >= len1_i+len2_i+1.  Both run the device NW kernel, and all of C_nwalign's aligners
+ * are there: nwalign_endsfree (src/nwalign_endsfree.cpp:76-216), nwalign_endsfree_homo when homo_gap_p != gap_p
+ * (:220-396: a gap opposite a base of a homopolymer run of >= 3 costs homo_gap_p) and, with endsfree = 0, the global
+ * nwalign (:403-537; C_nwvec: nwalign_vectorized2 with end_gap_p = gap_p, src/nwalign_vectorized.cpp:333). */
 int dada2hip_nwalign(const char *s1, const char *s2, int32_t match, int32_t mismatch, int32_t gap_p,
                      int32_t homo_gap_p, int32_t band, int32_t endsfree, int32_t device, char *out0, char *out1,
                      char *errbuf, size_t errlen);

@@ -114,6 +114,17 @@ def nwalign(s1, s2, match=5, mismatch=-4, gap=-8, band=16, gapless=False):
     return o0.value.decode(), o1.value.decode()
 
 
+def C_nwalign(s1, s2, match=5, mismatch=-4, gap_p=-8, homo_gap_p=None, band=-1, endsfree=True):
+    """C_nwalign (evaluate.cpp:18-62): nwalign_endsfree / nwalign_endsfree_homo / global nwalign, by the restatement."""
+    L = lib()
+    L.oracle_nwalign2.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    n = len(s1) + len(s2) + 2
+    o0, o1 = C.create_string_buffer(n), C.create_string_buffer(n)
+    L.oracle_nwalign2(s1.encode(), s2.encode(), match, mismatch, gap_p, gap_p if homo_gap_p is None else homo_gap_p, band,
+                      int(endsfree), o0, o1)
+    return o0.value.decode(), o1.value.decode()
+
+
 def compare(cseq, cq, rseq, rq, err, opts: DadaOpts = None, kdist_cutoff=None):
     o = opts or DadaOpts()
     co = o.to_c()

@@ -14,8 +14,8 @@
  * Third-party arithmetic: ppois() lives in oracle/rmath_ppois.c ("parity unpinned"
  * against genuine libRmath — see that file's header).
  *
- * Not restated (outside the contract): nwalign_endsfree_homo
- * (homopolymer gap penalty != gap penalty) — oracle_run() refuses those options.
+ * nwalign_endsfree_homo (homopolymer gap penalty != gap penalty, reached with VECTORIZED_ALIGNMENT off,
+ * R/dada.R:229-231) and the global nwalign of C_nwalign(endsfree=FALSE) are restated in nw_general().
  */
 #include <math.h>
 #include <stdint.h>
@@ -92,20 +92,42 @@ static double kodist(const uint16_t *a, int la, const uint16_t *b, int lb, int s
 }
 
 /* --------------------------------------------------------------- alignment --- */
-/* Banded ends-free Needleman-Wunsch, semantics of nwalign_endsfree
-   (nwalign_endsfree.cpp:76-216) == nwalign_vectorized2 with end_gap_p=0
-   (nwalign_vectorized.cpp:71-318; identical output).  s1 = centre (rows),
-   s2 = raw (cols).  Tie-break up > left > diag (:146-156).  Out-of-band neighbours read a
-   large negative sentinel (-9999 at :113-119; INT16_MIN-min(..) at vectorized :106-112).
+/* Homopolymer flags of nwalign_endsfree_homo (nwalign_endsfree.cpp:227-256): position k is 1 when it lies in a run
+   of at least three equal bases. */
+static void homo_flags(const uint8_t *s, int len, uint8_t *h)
+{
+  int i = 0, j, k;
+  for (j = 0; j < len; j++)
+    if (j == len - 1 || s[j] != s[j + 1]) {
+      for (k = i; k <= j; k++) h[k] = (j - i >= 2) ? 1 : 0;
+      i = j + 1;
+    }
+}
+
+/* Banded Needleman-Wunsch of the three scalar aligners of nwalign_endsfree.cpp:
+     endsfree, homo_gap_p == gap_p   nwalign_endsfree       :76-216  (== nwalign_vectorized2 with end_gap_p = 0,
+                                                                       nwalign_vectorized.cpp:71-318; identical output)
+     endsfree, homo_gap_p != gap_p   nwalign_endsfree_homo  :220-396 (a gap opposite a base of a homopolymer run of >= 3 costs
+                                                                       homo_gap_p: left move -> the raw's base, up move -> the centre's)
+     !endsfree                       nwalign                :403-537 (global: the first row / column cost gap_p per step, no free
+                                                                       moves along the last row / column; homo_gap_p is ignored,
+                                                                       evaluate.cpp:44-48)
+   s1 = centre (rows), s2 = raw (cols).  Tie-break up > left > diag (:146-156).  Out-of-band neighbours read a large negative
+   sentinel (-9999 at :113-119; INT16_MIN-min(..) at vectorized :106-112).
    Returns alignment length; al0/al1 (capacity len1+len2+1) get the gapped strings, gap='-'. */
-static int nw_endsfree(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int match, int mismatch,
-                       int gap_p, int band, int sentinel, uint8_t *al0, uint8_t *al1)
+static int nw_general(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int match, int mismatch,
+                      int gap_p, int homo_gap_p, int endsfree, int band, int sentinel, uint8_t *al0, uint8_t *al1)
 {
   int i, j, ncol = len2 + 1, lband, rband, n = 0;
+  const int homo = endsfree && homo_gap_p != gap_p;
   int *d = (int *)malloc(sizeof(int) * (size_t)(len1 + 1) * ncol);
   uint8_t *p = (uint8_t *)malloc((size_t)(len1 + 1) * ncol);
-  for (i = 0; i <= len1; i++) { d[i * ncol] = 0; p[i * ncol] = 3; }
-  for (j = 0; j <= len2; j++) { d[j] = 0; p[j] = 2; }
+  uint8_t *h1 = (uint8_t *)calloc((size_t)len1 + 1, 1), *h2 = (uint8_t *)calloc((size_t)len2 + 1, 1);
+  if (homo) { homo_flags(s1, len1, h1); homo_flags(s2, len2, h2); }
+  d[0] = 0; p[0] = endsfree ? 3 : 0;
+  for (i = 1; i <= len1; i++) { d[i * ncol] = endsfree ? 0 : d[(i - 1) * ncol] + gap_p; p[i * ncol] = 3; }
+  for (j = 1; j <= len2; j++) { d[j] = endsfree ? 0 : d[j - 1] + gap_p; p[j] = 2; }
+  if (endsfree) p[0] = 2;                              /* (:88-98: the top-row loop runs last; never queried) */
   lband = band + (len1 > len2 ? len1 - len2 : 0);     /* :100-111 */
   rband = band + (len2 > len1 ? len2 - len1 : 0);
   if (band >= 0 && (band < len1 || band < len2)) {    /* :113-119 */
@@ -118,8 +140,8 @@ static int nw_endsfree(const uint8_t *s1, int len1, const uint8_t *s2, int len2,
     int l = 1, r = len2;
     if (band >= 0) { l = i - lband; if (l < 1) l = 1; r = i + rband; if (r > len2) r = len2; }
     for (j = l; j <= r; j++) {
-      int left = d[i * ncol + j - 1] + (i == len1 ? 0 : gap_p);
-      int up = d[(i - 1) * ncol + j] + (j == len2 ? 0 : gap_p);
+      int left = d[i * ncol + j - 1] + ((endsfree && i == len1) ? 0 : ((homo && h2[j - 1]) ? homo_gap_p : gap_p));
+      int up = d[(i - 1) * ncol + j] + ((endsfree && j == len2) ? 0 : ((homo && h1[i - 1]) ? homo_gap_p : gap_p));
       int diag = d[(i - 1) * ncol + j - 1] + (s1[i - 1] == s2[j - 1] ? match : mismatch);
       if (up >= diag && up >= left) { d[i * ncol + j] = up; p[i * ncol + j] = 3; }
       else if (left >= diag) { d[i * ncol + j] = left; p[i * ncol + j] = 2; }
@@ -139,8 +161,13 @@ static int nw_endsfree(const uint8_t *s1, int len1, const uint8_t *s2, int len2,
     uint8_t t = al0[i]; al0[i] = al0[n - 1 - i]; al0[n - 1 - i] = t;
     t = al1[i]; al1[i] = al1[n - 1 - i]; al1[n - 1 - i] = t;
   }
-  free(d); free(p);
+  free(d); free(p); free(h1); free(h2);
   return n;
+}
+static int nw_endsfree(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int match, int mismatch,
+                       int gap_p, int band, int sentinel, uint8_t *al0, uint8_t *al1)
+{
+  return nw_general(s1, len1, s2, len2, match, mismatch, gap_p, gap_p, 1, band, sentinel, al0, al1);
 }
 
 /* nwalign_endsfree.cpp:539-555 nwalign_gapless: shorter padded with '-' at the end. */
@@ -238,10 +265,10 @@ static void make_sub(S *s, unsigned c, unsigned r, int use_kmers, double cutoff,
   al1 = (uint8_t *)malloc(s->len[c] + s->len[r] + 2);
   if (o->band_size == 0 || (o->gapless && ko == kd))             /* :54-55 */
     n = nw_gapless(s->seq[c], s->len[c], s->seq[r], s->len[r], al0, al1);
-  else                                                           /* :57-64 (homo variant refused up front) */
-    n = nw_endsfree(s->seq[c], s->len[c], s->seq[r], s->len[r], o->match, o->mismatch, o->gap, o->band_size,
-                    nw_sentinel(o),
-                    al0, al1);
+  else                                                           /* :57-64: vectorized | endsfree_homo | endsfree */
+    n = nw_general(s->seq[c], s->len[c], s->seq[r], s->len[r], o->match, o->mismatch, o->gap,
+                   (!o->vectorized_alignment && o->homo_gap != o->gap && o->homo_gap <= 0) ? o->homo_gap : o->gap, 1, o->band_size,
+                   nw_sentinel(o), al0, al1);
   al2subs(al0, al1, n, sub);
   if (s->has_quals)
     for (i = 0; i < sub->nsubs; i++) { sub->q0[i] = s->qual[c][sub->pos[i]]; sub->q1[i] = s->qual[r][sub->map[sub->pos[i]]]; }
@@ -499,8 +526,6 @@ oracle_result *oracle_run(int nraw, const char *const *seqs, const int *abund, c
   if (maxlen >= SEQLEN) FAIL("Input sequences exceed the maximum allowed string length.");
   if (minlen <= KMER_SIZE) FAIL("Input sequences must all be longer than the kmer-size (5).");
   if (quals && quals_nrow != maxlen) FAIL("Sequence must have associated qualities for each nucleotide position.");
-  if (o->homo_gap != o->gap && !o->vectorized_alignment && o->homo_gap <= 0 && o->band_size != 0)
-    FAIL("oracle: homopolymer gap penalties (nwalign_endsfree_homo) are outside the restated path.");
   s->o = *o; s->nraw = nraw; s->maxlen = maxlen; s->ncol = err_ncol; s->has_quals = quals != NULL;
   e = (double *)malloc(sizeof(double) * 16 * err_ncol);          /* row-major copy, cluster.cpp:166-170 */
   for (i = 0; i < 16; i++) for (index = 0; index < err_ncol; index++) e[i * err_ncol + index] = err[index * 16 + i];
@@ -674,6 +699,20 @@ int oracle_nwalign(const char *s1, const char *s2, int match, int mismatch, int 
   uint8_t *al0 = (uint8_t *)malloc(l1 + l2 + 2), *al1 = (uint8_t *)malloc(l1 + l2 + 2);
   encode(s1, a, l1); encode(s2, b, l2);
   n = gapless ? nw_gapless(a, l1, b, l2, al0, al1) : nw_endsfree(a, l1, b, l2, match, mismatch, gap, band, -9999, al0, al1);
+  decode(al0, out0, n); decode(al1, out1, n);
+  free(a); free(b); free(al0); free(al1);
+  return n;
+}
+
+/* C_nwalign (evaluate.cpp:18-62): any of the three scalar aligners.  out0/out1 capacity len1+len2+1. */
+int oracle_nwalign2(const char *s1, const char *s2, int match, int mismatch, int gap, int homo_gap, int band, int endsfree,
+                    char *out0, char *out1)
+{
+  int l1 = (int)strlen(s1), l2 = (int)strlen(s2), n;
+  uint8_t *a = (uint8_t *)malloc(l1 + 1), *b = (uint8_t *)malloc(l2 + 1);
+  uint8_t *al0 = (uint8_t *)malloc(l1 + l2 + 2), *al1 = (uint8_t *)malloc(l1 + l2 + 2);
+  encode(s1, a, l1); encode(s2, b, l2);
+  n = nw_general(a, l1, b, l2, match, mismatch, gap, endsfree ? homo_gap : gap, endsfree, band, -9999, al0, al1);
   decode(al0, out0, n); decode(al1, out1, n);
   free(a); free(b); free(al0); free(al1);
   return n;

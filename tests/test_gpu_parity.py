@@ -258,9 +258,17 @@ def test_errors_keep_reference_messages(api):
         api.dada_uniques(d.seqs, d.abundances, None, tperr1()[:, :20], d.quals, DadaOpts())
     with pytest.raises(_lib.Dada2HipError, match="A/C/G/T"):
         api.dada_uniques(["ACGTNACGTA", "ACGTAACGTA"], [5, 1], None, tperr1(), np.full((2, 10), 30.0), DadaOpts())
-    with pytest.raises(_lib.Dada2HipError) as ei:
-        api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts(HOMOPOLYMER_GAP_PENALTY=-1))
-    assert ei.value.code == 4
+
+
+def test_nwalign_variants_match_reference(api):
+    """C_nwalign's three aligners on the device (src/evaluate.cpp:18-62): nwalign_endsfree, nwalign_endsfree_homo (a gap
+    opposite a homopolymer base has its own penalty) and the global nwalign of endsfree=FALSE, on 300 homopolymer-rich
+    pairs whose alignments the reference itself produced (tests/golden/make_homo_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, "nwalign_variants.npz"))
+    for i in range(len(z["s1"])):
+        got = api.nwalign(str(z["s1"][i]), str(z["s2"][i]), 5, -4, -8, homo_gap=int(z["homo_gap"][i]), band=int(z["band"][i]),
+                          endsfree=bool(z["endsfree"][i]))
+        assert got == (str(z["al0"][i]), str(z["al1"][i])), (i, int(z["band"][i]), int(z["homo_gap"][i]), int(z["endsfree"][i]))
 
 
 def test_work_counters_match_reference_counts(api, oracle_c):

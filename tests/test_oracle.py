@@ -153,3 +153,27 @@ def test_bimera_restatement_matches_reference_goldens(oracle_c):
             pars = [seqs[k] for k in range(len(seqs)) if tot[k] > 2 * tot[j] and tot[k] > 8]
             assert oracle_c.is_bimera(s, pars, allow_one_off=bool(oo)) == bool(z[f"isbim_oo{oo}"][j]), (j, oo)
     assert z["nflag_oo0_ms16"].max() == 2 and z["nflag_oo1_ms16"].sum() > z["nflag_oo0_ms16"].sum()
+
+
+def test_restated_aligner_variants_match_the_reference_goldens(oracle_c):
+    """nw_general() of the C restatement - nwalign_endsfree, nwalign_endsfree_homo, global nwalign - on the 300 pairs whose
+    alignments came out of the reference's own C_nwalign (tests/golden/make_homo_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, "nwalign_variants.npz"))
+    kinds = set()
+    for i in range(len(z["s1"])):
+        got = oracle_c.C_nwalign(str(z["s1"][i]), str(z["s2"][i]), 5, -4, -8, int(z["homo_gap"][i]), int(z["band"][i]), bool(z["endsfree"][i]))
+        assert got == (str(z["al0"][i]), str(z["al1"][i])), i
+        kinds.add((bool(z["endsfree"][i]), int(z["homo_gap"][i]) != -8))
+    assert kinds == {(True, False), (True, True), (False, False), (False, True)}
+
+
+def test_restated_homopolymer_path_matches_the_reference_live(oracle_c, oracle_ref):
+    """dada_uniques with HOMOPOLYMER_GAP_PENALTY (raw_align -> nwalign_endsfree_homo) : restatement vs the reference, live."""
+    from dada2_amd.opts import DadaOpts
+    from dada2_amd.synth import make_sample
+    d = make_sample(tperr1(), 700, L=110, G=8, seed=77, Lmin=90, indel_rate=3e-3, chunk=4000)
+    for kw in (dict(HOMOPOLYMER_GAP_PENALTY=-1), dict(HOMOPOLYMER_GAP_PENALTY=-2, BAND_SIZE=-1), dict(HOMOPOLYMER_GAP_PENALTY=0, BAND_SIZE=8)):
+        o = DadaOpts(**kw)
+        a = oracle_c.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)
+        b = oracle_ref.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, o)
+        assert_results_equal(a, b, exact_float=True)

@@ -25,6 +25,9 @@ CASES = [(1, {}), (2, dict(BAND_SIZE=4)), (3, dict(GREEDY=False, GAPLESS=False))
          (11, dict(BAND_SIZE=-1)), (12, dict(BAND_SIZE=40)), (13, dict(MATCH=4, MISMATCH=-5, GAP_PENALTY=-7)),
          (14, dict(BAND_SIZE=1)), (15, dict(BAND_SIZE=18)),
          # band fills the lane group (AdGeom::edge): 21 lanes with W = 39, 32 lanes with W = 61 (ragged), non-default scores there too
+         # homopolymer gapping (nwalign_endsfree_homo; 454 / Ion Torrent data): lane kernels, every band class
+         (20, dict(HOMOPOLYMER_GAP_PENALTY=-1)), (21, dict(HOMOPOLYMER_GAP_PENALTY=-1, BAND_SIZE=32)),
+         (22, dict(HOMOPOLYMER_GAP_PENALTY=-2, BAND_SIZE=-1)), (23, dict(HOMOPOLYMER_GAP_PENALTY=0, GAP_PENALTY=-6)),
          (17, dict(BAND_SIZE=19)), (18, dict(BAND_SIZE=20)), (19, dict(BAND_SIZE=19, MATCH=4, MISMATCH=-5, GAP_PENALTY=-7))]
 os.environ.setdefault("DADA2HIP_NW_KERNEL", "coop")
 only = [int(x) for x in sys.argv[1:]]
