@@ -39,7 +39,7 @@ extern "C" {
 #define DADA2HIP_ERR_INPUT     1   /* validation failure (messages of src/Rmain.cpp:52-78) */
 #define DADA2HIP_ERR_DEVICE    2   /* no usable GPU / HIP runtime error */
 #define DADA2HIP_ERR_RUNTIME   3   /* runtime error of the algorithm ("Lambda out-of-range error." ...) */
-#define DADA2HIP_ERR_UNSUPPORTED 4 /* option outside the implemented path (homopolymer gap penalty) */
+#define DADA2HIP_ERR_UNSUPPORTED 4 /* input outside what the device path represents (N / IUPAC codes in nwalign, band 0 in nwvec) */
 #define DADA2HIP_ERR_ABORTED   5   /* should_abort() returned non-zero (Rcpp::checkUserInterrupt analogue) */
 
 #define DADA2HIP_NA_INTEGER (-2147483647 - 1)   /* R's NA_integer_ */
