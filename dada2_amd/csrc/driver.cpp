@@ -2324,6 +2324,7 @@ void bimera_pairs(int ncol, const char *const *seqs, const std::vector<std::vect
   memset(&o, 0, sizeof o);
   o.match = match; o.mismatch = mismatch; o.gap = gap_p; o.vectorized_alignment = 1;   // nwalign_vectorized2 (chimera.cpp:26)
   AlignParams ap{match, mismatch, gap_p, max_shift, nw_sentinel(o), 0, 1};
+  ap.homo_gap = gap_p;   // (plain ends-free alignment: chimera.cpp:26,122 call nwalign_vectorized2 / nwalign_endsfree)
   const int stride = 2 * s->D.maxlen + 2;
   // batches of whole queries, each query's parents padded to the lane kernel's 64-alignment chunks
   const size_t budget_slots = std::max<size_t>(4096, ((size_t)256 << 20) / (size_t)stride);

@@ -70,7 +70,7 @@ struct AlignParams {
   int32_t homo_gap = 0;   // gap opposite a base of a homopolymer run of >= 3 (nwalign_endsfree_homo, nwalign_endsfree.cpp:220-396);
                           // equal to `gap` = no homopolymer gapping
   int32_t endsfree = 1;   // 0: global nwalign (nwalign_endsfree.cpp:403-537): end gaps cost `gap`, no free moves on the last row / column
-  bool plain() const { return endsfree && homo_gap == gap; }
+  bool plain() const { return endsfree && homo_gap == gap; }   // (whoever fills the struct sets homo_gap = gap for the plain aligner)
 };
 
 struct ScreenParams {

@@ -55,3 +55,12 @@ def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
 
 def test_emulated_long_read_band32_case(emu_lib):
     run_cases(emu_lib, ("samPB_band32",))
+
+
+def test_emulated_bimera_table_and_nwvec_goldens(emu_lib):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_bimera.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "bimera table goldens: ok" in out.stdout and "nwvec goldens: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_emulated_homopolymer_gap_goldens(emu_lib):
+    run_cases(emu_lib, ("sam1F_homogap",))
