@@ -647,6 +647,13 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
 static inline int ad_pad(int GL) { return GL + 8; }
 constexpr int AD_RCAP = 64;   // run descriptors buffered per alignment between traceback chunks
 
+// Traceback pointers of k_nw_ad: every step shifts TWO bits into the lane's pointer word, (A << 1) | B with
+//   A = 0 : the cell came from above (up; ties go to up first)      A = 1, B = 0 : from the left      A = 1, B = 1 : diagonal,
+// so after the 16 steps of a block step s sits at bits 31 - 2s (A) and 30 - 2s (B); the traceback reads the word bit-reversed
+// (step s at bits 2s, 2s + 1).  In the steady state A and B are the SIGN BITS of two differences, each shifted in by one
+// v_alignbit_b32 - no compare, no select, no wait states on VCC.
+static __device__ __forceinline__ uint32_t ad_ptr_code(bool from_up, bool left_ge_diag) { return from_up ? 0u : (left_ge_diag ? 2u : 3u); }
+
 // one anti-diagonal step of one lane's live cell.  PAR is the cell parity (k = 2g + PAR).
 // LEAN: steady-state step — every in-band cell of the wave is an interior cell away from the last
 // row/column, so the matrix-edge logic (axis cells, free end gaps) is compiled out.
@@ -683,9 +690,8 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
       e = max(up, e1);
     }
     const bool t1 = left >= diag;
-    const uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
     if (PAR == 0) { d0 = e; rb = vnext; j++; } else { d1 = e; cb = vnext; i++; }
-    pw |= p << fs;
+    pw = (pw << 2) | ad_ptr_code(t2, t1);
     return;
   }
   int left_src, up_src, own;
@@ -714,7 +720,7 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
     if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
   }
   if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
-  pw |= p << fs;
+  pw = (pw << 2) | (p == 3u ? 0u : (p == 2u ? 2u : 3u));   // (up / left / diagonal as ad_ptr_code)
 }
 
 // The same step for the reference's DEFAULT scores (match 5, mismatch -4, gap -8) in the COST domain K = 5 t - 2 H on
@@ -738,11 +744,9 @@ static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &
     const int diag = gcn_sad_u8(cb, rb, own);
     const int left = PAR == 0 ? nb + gsel_nb : other + gsel, up = PAR == 0 ? other + gsel : nb + gsel_nb;
     const int e = gcn_min3(left, diag, up);
-    const bool t2 = up == e;                                  // up <= min(left, diag)  <=>  the minimum IS up
-    const bool t1 = left <= diag;
-    const uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
+    pw = gcn_shift_in_sign(pw, e - up);                       // A: e < up  <=>  the minimum is NOT up (up wins its ties)
+    pw = gcn_shift_in_sign(pw, diag - left);                  // B: diag < left  <=>  NOT (left <= diag) (left wins its tie with diag)
     if (PAR == 0) { d0 = e; rb = vnext; j++; } else { d1 = e; cb = vnext; i++; }
-    pw |= p << fs;
     return;
   }
   int left_src, up_src, own;
@@ -768,7 +772,7 @@ static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &
     if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
   }
   if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
-  pw |= p << fs;
+  pw = (pw << 2) | (p == 3u ? 0u : (p == 2u ? 2u : 3u));   // (up / left / diagonal as ad_ptr_code)
 }
 
 // LDS geometry of k_nw_ad, shared by host and device.  Per WAVE: the staged centre (every alignment of a wave has the same
@@ -946,7 +950,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 #undef AD_FULL_STEP
 #undef AD_STEP
 #undef AD_FLUSH
-      if (((t - 1) & 15) != 15) pg[(size_t)((t - 1) >> 4) * 64 + lane] = pw;
+      if (((t - 1) & 15) != 15) pg[(size_t)((t - 1) >> 4) * 64 + lane] = pw << (2 * (15 - ((t - 1) & 15)));   // (the last, partial block: left-aligned)
     }
     // ---- traceback (first lane of each group) in chunks of <= AD_RCAP merged runs, expanded by all lanes into one
     //      transition code per raw position.  Run: pj_lo (12 b) | n (12 b) << 12 | (delta + 128) << 24, delta = pi - pj;
@@ -984,11 +988,12 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         const int gact = __shfl((int)act, gl0, 64);
         const int tt = __shfl(ti + tj, gl0, 64), col = __shfl((tj - ti + lbo) >> 1, gl0, 64);
         const int f0 = tt & 15, widx = (tt >> 4) - g;
-        uint32_t word = 0x55555555u;                       // (before the matrix: never reached, the axis cells stop the run)
+        uint32_t word = 0xFFFFFFFFu;                       // (before the matrix: never reached, the axis cells stop the run)
         if (gact && !ghost && widx >= 0) word = pg[(size_t)widx * 64 + gl0 + col];
         const int ftop = g == 0 ? f0 : 14 + (f0 & 1);
-        // fields of the path cell's parity at positions <= ftop that are NOT diagonal (01)
-        const uint32_t x = word ^ 0x55555555u;
+        // fields of the path cell's parity at positions <= ftop that are NOT diagonal (11)
+        word = __brev(word);                                // step s of the block at bits 2s (A), 2s + 1 (B); 3 = diagonal
+        const uint32_t x = ~word;
         uint32_t nz = (x | (x >> 1)) & 0x55555555u;
         nz &= (f0 & 1) ? 0x44444444u : 0x11111111u;
         nz &= (ftop == 15) ? 0xFFFFFFFFu : ((1u << ((ftop + 1) << 1)) - 1u);
@@ -1012,8 +1017,8 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
             ti -= n; tj -= n;
           }
           if (qs < GL && !clamped && (ti > 0 || tj > 0)) {  // (0,0) carries an axis pointer too: the path ends there
-            if (pq == 2u) { tj--; push(tj, 1, 255); }
-            else ti--;                                     // 3 (1 cannot be here)
+            if (pq == 1u) { tj--; push(tj, 1, 255); }      // A = 1, B = 0: from the left
+            else ti--;                                     // A = 0: from above (3 = diagonal cannot be here)
           }
         }
       }

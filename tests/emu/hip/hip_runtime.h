@@ -93,6 +93,12 @@ inline void __threadfence_block() {}
 inline void __threadfence_system() {}
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline unsigned __brev(unsigned x) {
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  return __builtin_bswap32(x);
+}
 // (__hip_atomic_load / __hip_atomic_store are clang builtins in every language mode; only the scope names are HIP's)
 #ifndef __HIP_MEMORY_SCOPE_SYSTEM
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
