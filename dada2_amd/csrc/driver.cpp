@@ -1218,7 +1218,8 @@ struct Run {
   DevBuf<double> v2_lam0, v2_lam1;
   DevBuf<uint32_t> v2_ham0, v2_ham1;
   DevBuf<int32_t> v2_i1;
-  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn, v2_sig;
+  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn, v2_sig, v2_n0d;
+  DevBuf<uint8_t> v2_moved;
   DevBuf<CompBlk> v2_blk;
   DevBuf<Ctl2> v2_ctl;
   DevBuf<BudTie> v2_tiesrec;
@@ -1258,6 +1259,7 @@ struct Run {
     E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
     E2.sp = sp; E2.thresh = d_thresh_round.p; E2.max_shuffle = MAX_SHUFFLE;
     E2.trace = v2_trace.p; E2.trace_seq = v2_trace_seq;
+    E2.moved = v2_moved.p; E2.n0d = v2_n0d.p;
     E2.sh_filter = 1; E2.grid_shuffle = 2048; E2.grid_pupdate = 1024;
     if (const char *e = getenv("DADA2HIP_V2_FILTER")) E2.sh_filter = atoi(e) != 0;
     if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::max(1, atoi(e));
@@ -1286,6 +1288,9 @@ struct Run {
     v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
     v2_listn.alloc(2); v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
+    v2_moved.alloc(n); v2_n0d.alloc(2 * SH_CHAIN);
+    D2_HIP(hipMemsetAsync(v2_moved.p, 0, n, stq));
+    D2_HIP(hipMemsetAsync(v2_n0d.p, 0, 2 * SH_CHAIN * 4, stq));
     D2_HIP(hipMemsetAsync(v2_sig.p, 0, 16, stq));
     D2_HIP(hipMemsetAsync(v2_blkcount.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));
@@ -1296,6 +1301,7 @@ struct Run {
     Ctl2 c;
     memset(&c, 0, sizeof c);
     c.nclust = 1; c.centre = (int32_t)bi[0].center; c.slot = 0; c.max_clust = max_clust;
+    c.n0 = N; c.low0 = N;
     for (int k = 0; k < KB_MAX; k++) c.bcentre[k] = -1;
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
     D2_HIP(hipStreamSynchronize(stq));   // `c` is a local
@@ -1456,7 +1462,7 @@ struct Run {
     v2_enqueue_chain(0, false, false);                        // b_p_update after round 0 + the first b_bud
     bool done = false;
     double t_decide = 0, t_halt = 0, t_top = 0;
-    long n_halt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_big = 0;
+    long n_halt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_big = 0, n_kind[5] = {0, 0, 0, 0, 0};
     while (!done) {
       const auto t_loop = clk::now();
       while (v2_enq - v2_cons < v2_depth) v2_enqueue_chain(v2_chain, true, true);
@@ -1471,6 +1477,18 @@ struct Run {
         fprintf(stderr, "[v2] blk %ld halt %d nclust %d nlev %d nsh %d cnt %d %d %d %d nbatch %d slot %d birth %d found %d nties %d p %.3e blk %d\n", seq,
                 b.halt, b.nclust, b.nlev, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],
                 b.bud.nties[0], b.bud.best_p[0], b.blk_count);
+      if (b.halt == H2_HOST_DECIDE && getenv("DADA2HIP_V2_SUMMARY")) {   // what kind of decision came back to the host
+        const int nt = b.bud.nties[0];
+        bool zero = b.bud.found[0] && nt > 1 && nt <= BUD_TIES, in0 = false, pristine = true;
+        int cmin = INT32_MAX, ncmin = 0;
+        for (int k = 0; zero && k < nt; k++) {
+          const BudTie &t = b.bud.ties[0][k];
+          if (t.p != 0.0) zero = false;
+          if (clust_of[t.raw] == 0) { in0 = true; if (slot_of[t.raw] != t.raw) pristine = false; }
+          if (clust_of[t.raw] < cmin) { cmin = clust_of[t.raw]; ncmin = 1; } else if (clust_of[t.raw] == cmin) ncmin++;
+        }
+        n_kind[!zero ? 0 : (in0 ? (pristine ? 1 : 2) : (ncmin == 1 ? 3 : 4))]++;
+      }
       v2_replay(b, seq);
       n_halt[b.halt & 7]++;
       if (b.cnt[0] + b.cnt[1] + b.cnt[2] + b.cnt[3] > MOV_INLINE2) n_big++;
@@ -1529,9 +1547,10 @@ struct Run {
     }
     if (getenv("DADA2HIP_V2_SUMMARY"))
       fprintf(stderr, "[v2] blocks %ld  halts none/nobirth/host/more/cap/max %ld %ld %ld %ld %ld %ld  big-mover blocks %ld  ms: wait %.1f replay %.1f "
-                      "enqueue %.1f decide %.1f halt-handling %.1f top-up %.1f total %.1f  moves %llu misses %llu\n", v2_cons, n_halt[0], n_halt[1],
+                      "enqueue %.1f decide %.1f halt-handling %.1f top-up %.1f total %.1f  moves %llu misses %llu  host decisions other/zero-ties in partition 0 at "
+                      "their first slots/... moved/elsewhere, one in the lowest partition/... several %ld %ld %ld %ld %ld\n", v2_cons, n_halt[0], n_halt[1],
               n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_big, st.ms_wait_device, st.ms_replay, st.ms_enqueue, t_decide, t_halt, t_top,
-              ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches);
+              ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches, n_kind[0], n_kind[1], n_kind[2], n_kind[3], n_kind[4]);
     sync_spin(s->stream);                                      // no-op launches queued behind the final halt
     if (v2_trace_seq >= 0 && v2_trace.p) {                     // dump the traced round's stamps (tools/trace_round.py reads them)
       const char *e = getenv("DADA2HIP_V2_TRACE");

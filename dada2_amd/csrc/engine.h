@@ -277,6 +277,7 @@ struct Ctl2 {
   int32_t nsh_base;     // shuffles of the round in flight executed by earlier chains
   int32_t max_clust;
   int32_t scan_hint;    // (reserved)
+  int32_t n0, low0;     // members of partition 0 now / a lower bound of the fewest it has ever had (tie rule of k2_birth)
   int32_t bcentre[KB_MAX];
   uint32_t breads[KB_MAX];
   int32_t blen[KB_MAX];
@@ -322,6 +323,15 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   Round2Out *dblk;                // [RING2] device-side result blocks
   Round2Out *hblk;                // [RING2] pinned host copies
   int32_t *dlt;                   // [SH_CHAIN][ccap] partition-read deltas of the chain's shuffles
+  // b_bud takes the FIRST of several equal keys in partition order, then in the order of the partition's member list
+  // (cluster.cpp:284-308).  The member lists live on the host (bi_pop_raw moves the LAST member into the hole,
+  // containers.cpp:177-194, so a list's order is the history of every move), but one case needs no list: a unique that has
+  // never moved still sits in partition 0 at the slot of its index as long as partition 0 has never been short enough to
+  // make it the last member.  moved[] and the two counters per shuffle call are what k2_birth needs to recognise that case
+  // and settle such a tie itself (they are most of the ties of a deep sample: p underflowed to 0, equal reads, neighbours
+  // in the abundance order) instead of halting for the host.
+  uint8_t *moved;                 // [N] the unique has been moved by a shuffle or a birth
+  int32_t *n0d;                   // [SH_CHAIN][2] members partition 0 lost / gained in each of the chain's shuffle calls
   int32_t *movers;                // [RING2][SH_CHAIN][3 N]
   // the round's comparisons (cluster.cpp:90-149): class per unique, work lists, then lambda / hamming from the aligner
   uint8_t *cls;

@@ -27,10 +27,10 @@ static __device__ __forceinline__ int gcn_sad_u8(uint32_t a, uint32_t b, int acc
   asm("v_sad_u8 %0, %1, %2, %3" : "=v"(e) : "v"(a), "v"(b), "v"(acc));
   return e;
 }
-// (acc << 1) | sign bit of x, in one instruction (v_alignbit_b32 takes bits 62..31 of {acc, x}): a comparison result is shifted
-// into a bit string without a compare / select pair (and without the VCC read-after-write wait states of gfx950)
-static __device__ __forceinline__ uint32_t gcn_shift_in_sign(uint32_t acc, int x) {
-  return __builtin_amdgcn_alignbit(acc, (uint32_t)x, 31);
+// (acc >> 2) | (x << 30) in one instruction (v_alignbit_b32 takes bits 33..2 of {x, acc}): the two LOW bits of x are pushed
+// into the top of a bit string - no mask, no shift, no or
+static __device__ __forceinline__ uint32_t gcn_push_low2(uint32_t acc, uint32_t x) {
+  return __builtin_amdgcn_alignbit(x, acc, 2);
 }
 // DPP wave shifts by one lane: lane L reads `src` of lane L-1 (shr) / L+1 (shl); a lane without a source keeps `old`
 // (bound_ctrl = false) or reads 0 (bound_ctrl = true)

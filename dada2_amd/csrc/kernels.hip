@@ -647,12 +647,13 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
 static inline int ad_pad(int GL) { return GL + 8; }
 constexpr int AD_RCAP = 64;   // run descriptors buffered per alignment between traceback chunks
 
-// Traceback pointers of k_nw_ad: every step shifts TWO bits into the lane's pointer word, (A << 1) | B with
-//   A = 0 : the cell came from above (up; ties go to up first)      A = 1, B = 0 : from the left      A = 1, B = 1 : diagonal,
-// so after the 16 steps of a block step s sits at bits 31 - 2s (A) and 30 - 2s (B); the traceback reads the word bit-reversed
-// (step s at bits 2s, 2s + 1).  In the steady state A and B are the SIGN BITS of two differences, each shifted in by one
-// v_alignbit_b32 - no compare, no select, no wait states on VCC.
-static __device__ __forceinline__ uint32_t ad_ptr_code(bool from_up, bool left_ge_diag) { return from_up ? 0u : (left_ge_diag ? 2u : 3u); }
+// Traceback pointers of k_nw_ad: every step shifts a TWO-bit move code into the TOP of the lane's pointer word,
+//   0 : the cell came from above (up; ties go to up first)      1 : from the left (it wins its tie with the diagonal)      2 : diagonal,
+// so after the 16 steps of a block step s sits at bits 2s, 2s + 1.  The codes are in the reference's tie order, which lets
+// the steady state of the default scores carry them as TAGS in the two low bits of the three candidates: the minimum of the
+// tagged candidates is the cell value AND the move (ad_step_k) - no compare, no select, no subtraction.
+constexpr uint32_t AD_UP = 0u, AD_LEFT = 1u, AD_DIAG = 2u;
+static __device__ __forceinline__ uint32_t ad_ptr_code(bool from_up, bool left_ge_diag) { return from_up ? AD_UP : (left_ge_diag ? AD_LEFT : AD_DIAG); }
 
 // one anti-diagonal step of one lane's live cell.  PAR is the cell parity (k = 2g + PAR).
 // LEAN: steady-state step — every in-band cell of the wave is an interior cell away from the last
@@ -691,7 +692,7 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
     }
     const bool t1 = left >= diag;
     if (PAR == 0) { d0 = e; rb = vnext; j++; } else { d1 = e; cb = vnext; i++; }
-    pw = (pw << 2) | ad_ptr_code(t2, t1);
+    pw = gcn_push_low2(pw, ad_ptr_code(t2, t1));
     return;
   }
   int left_src, up_src, own;
@@ -720,16 +721,21 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
     if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
   }
   if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
-  pw = (pw << 2) | (p == 3u ? 0u : (p == 2u ? 2u : 3u));   // (up / left / diagonal as ad_ptr_code)
+  pw = gcn_push_low2(pw, 3u - p);                           // (up / left / diagonal as ad_ptr_code)
 }
 
-// The same step for the reference's DEFAULT scores (match 5, mismatch -4, gap -8) in the COST domain K = 5 t - 2 H on
+// The same step for the reference's DEFAULT scores (match 5, mismatch -4, gap -8) in the COST domain K = 4 (5 t - 2 H) on
 // anti-diagonal t = i + j: every path into a cell has the same t, so arg-max and ties are exactly those of H, and
-//   a match costs 0, a mismatch 18, a gap 21, a free move along the last row / column 5, an axis cell is 5 t, out of band is BIG.
-// Bases are staged as one word each, 9 << (8 * code): the sum of absolute byte differences of two such words is 0 for equal
-// bases and 18 otherwise, so diag = own + substitution cost is ONE v_sad_u8 (it was compare + select + add), and the
+//   a match costs 0, a mismatch 72, a gap 84, a free move along the last row / column 20, an axis cell is 20 t, out of band is BIG.
+// Bases are staged as one word each, 36 << (8 * code): the sum of absolute byte differences of two such words is 0 for equal
+// bases and 72 otherwise, so diag = own + substitution cost is ONE v_sad_u8 (it was compare + select + add), and the
 // three-way minimum is one v_min3.  Out-of-band cells take BIG instead of the gap cost (additive mask, as above).
-constexpr int ADK_BIG = 1 << 22, ADK_MIS = 18, ADK_GAP = 21, ADK_FREE = 5;
+// All costs are multiples of 4, which leaves the two low bits of a candidate for its move code (AD_UP < AD_LEFT < AD_DIAG,
+// the reference's tie order): cells are kept as value + AD_DIAG, so the diagonal candidate is tagged by the v_sad_u8
+// itself and the two gap addends carry (code - AD_DIAG); v_min3 of the three tagged candidates then yields value and move
+// at once - equal values are separated by their tags exactly as the reference breaks the tie.  One v_alignbit_b32 moves
+// the tag into the pointer word, one v_and_or_b32 re-tags the cell: 6 vector instructions per cell (round 2: 11.25).
+constexpr int ADK_BIG = 1 << 24, ADK_MIS = 72, ADK_GAP = 84, ADK_FREE = 20, ADK_HOT = 36;
 template <int GL, int PAR, bool LEAN, bool EDGE>
 static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
                                                  uint32_t vnext, int fs, bool g_first, bool g_last, bool kok, int gsel, int gsel_nb,
@@ -743,15 +749,15 @@ static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &
     const int own = PAR == 0 ? d0 : d1, other = PAR == 0 ? d1 : d0;
     const int diag = gcn_sad_u8(cb, rb, own);
     const int left = PAR == 0 ? nb + gsel_nb : other + gsel, up = PAR == 0 ? other + gsel : nb + gsel_nb;
-    const int e = gcn_min3(left, diag, up);
-    pw = gcn_shift_in_sign(pw, e - up);                       // A: e < up  <=>  the minimum is NOT up (up wins its ties)
-    pw = gcn_shift_in_sign(pw, diag - left);                  // B: diag < left  <=>  NOT (left <= diag) (left wins its tie with diag)
+    const int et = gcn_min3(left, diag, up);                  // value | move code
+    pw = gcn_push_low2(pw, (uint32_t)et);
+    const int e = (et & ~3) | (int)AD_DIAG;
     if (PAR == 0) { d0 = e; rb = vnext; j++; } else { d1 = e; cb = vnext; i++; }
     return;
   }
   int left_src, up_src, own;
   if (PAR == 0) {
-    const int lft = gcn_wave_shr1<false>(ADK_BIG, d1);
+    const int lft = gcn_wave_shr1<false>(ADK_BIG, d1);        // (every source carries the same + AD_DIAG: the compares do not see it)
     own = d0; left_src = (EDGE && g_first) ? ADK_BIG : lft; up_src = d1;
   } else {
     const int upn = gcn_wave_shl1<false>(ADK_BIG, d0);
@@ -768,11 +774,11 @@ static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &
   uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
   {
     const bool interior = kok && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
-    val = interior ? e : (kok ? ADK_FREE * (i + j) : ADK_BIG);  // axis cells: H = 0
+    val = interior ? e : (kok ? ADK_FREE * (i + j) + (int)AD_DIAG : ADK_BIG);  // axis cells: H = 0
     if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
   }
   if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
-  pw = (pw << 2) | (p == 3u ? 0u : (p == 2u ? 2u : 3u));   // (up / left / diagonal as ad_ptr_code)
+  pw = gcn_push_low2(pw, 3u - p);                           // (up / left / diagonal as ad_ptr_code)
 }
 
 // LDS geometry of k_nw_ad, shared by host and device.  Per WAVE: the staged centre (every alignment of a wave has the same
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   uint8_t *blk0 = (uint8_t *)(s_dyn + nerr);
   const int cw_bytes = 4 * G.seqwords;
   uint8_t *wbase = blk0 + (G.shared_c ? cw_bytes : 0) + (size_t)wib * G.per_wave_bytes;
-  uint32_t *cwd = (uint32_t *)(G.shared_c ? blk0 : wbase) + (GL + 11); // centre base p as 9 << (8 * code)
+  uint32_t *cwd = (uint32_t *)(G.shared_c ? blk0 : wbase) + (GL + 11); // centre base p as ADK_HOT << (8 * code)
   uint8_t *abase = wbase + (G.shared_c ? 0 : cw_bytes) + (size_t)al * G.per_al_bytes;
   uint32_t *runs = (uint32_t *)abase;
   uint32_t *rwd = (uint32_t *)(abase + AD_RCAP * 4) + (GL + 11);        // raw base p, same encoding
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     const int cv = a.centre_dev ? *a.centre_dev : a.centre;
     if (cv >= 0) {
       const int Lc = S.len[cv];
-      for (int p = threadIdx.x; p < Lc; p += 256) cwd[p] = 9u << (base_at(S.seq2 + (size_t)cv * S.W2, p) << 3);
+      for (int p = threadIdx.x; p < Lc; p += 256) cwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)cv * S.W2, p) << 3);
     }
   }
   __syncthreads();
@@ -873,9 +879,9 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     const int T = (gapless || !active) ? -1 : L1 + L2;     // idle / gapless slots run no DP steps of their own
     // stage both sequences (one base per byte, guard bytes either side) and the raw's qualities
     if (!G.shared_c)                                       // the chunk's centre, by all lanes of the wave
-      for (int p = lane; p < L1; p += 64) cwd[p] = 9u << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);
+      for (int p = lane; p < L1; p += 64) cwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);
     if (!ghost) {
-      for (int p = g; p < L2; p += GL) rwd[p] = 9u << (base_at(S.seq2 + (size_t)r * S.W2, p) << 3);
+      for (int p = g; p < L2; p += GL) rwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)r * S.W2, p) << 3);
       const uint32_t *qsrc = (const uint32_t *)(S.qual + (size_t)r * S.LQ);
       for (int w = g; w * 4 < L2; w += GL) ((uint32_t *)qlds)[w] = qsrc[w];
     }
@@ -896,10 +902,13 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       uint32_t cb = cwd[i - 1], rb = rwd[j - 1];
       const bool g_first = g == 0, g_last = ghost || g == GL - 1;
       const bool kok0 = !ghost && 2 * g >= org && 2 * g < W + org, kok1 = !ghost && 2 * g + 1 >= org && 2 * g + 1 < W + org;
-      const int gs0 = DEF ? (kok0 ? ADK_GAP : ADK_BIG) : (kok0 ? GAP : AD_OOB), gs1 = DEF ? (kok1 ? ADK_GAP : ADK_BIG) : (kok1 ? GAP : AD_OOB);
+      // (cost domain: an even cell's own other cell is its UP source and the neighbour lane's its LEFT one, an odd cell's the
+      //  other way round; the addends carry the move code relative to the cells' + AD_DIAG)
+      constexpr int KUP = ADK_GAP + (int)AD_UP - (int)AD_DIAG, KLEFT = ADK_GAP + (int)AD_LEFT - (int)AD_DIAG;
+      const int gs0 = DEF ? (kok0 ? KUP : ADK_BIG) : (kok0 ? GAP : AD_OOB), gs1 = DEF ? (kok1 ? KLEFT : ADK_BIG) : (kok1 ? GAP : AD_OOB);
       // ... and for the cell fetched from the neighbour lane: hidden across a group boundary when the band fills the group
-      const int gn0 = (EDGE && g_first) ? ADK_BIG : gs0, gn1 = (EDGE && g_last) ? ADK_BIG : gs1;
-      if (DEF) { d0 = ADK_BIG; d1 = ADK_BIG; }                 // (the default scores run in the cost domain: ad_step_k)
+      const int gn0 = DEF ? ((EDGE && g_first) || !kok0 ? ADK_BIG : KLEFT) : gs0, gn1 = DEF ? ((EDGE && g_last) || !kok1 ? ADK_BIG : KUP) : gs1;
+      if (DEF) { d0 = ADK_BIG + (int)AD_DIAG; d1 = ADK_BIG + (int)AD_DIAG; }                 // (the default scores run in the cost domain: ad_step_k)
       // Steady state [tA, tB): every in-band cell of every alignment in the wave is interior and off the
       // last row / column (i >= 1, j >= 1, i < L1, j < L2 for all k in the band).
       int tA = (lband > rband ? lband : rband) + 2, tB = min(2 * L1 - lband, 2 * L2 - rband);
@@ -950,7 +959,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 #undef AD_FULL_STEP
 #undef AD_STEP
 #undef AD_FLUSH
-      if (((t - 1) & 15) != 15) pg[(size_t)((t - 1) >> 4) * 64 + lane] = pw << (2 * (15 - ((t - 1) & 15)));   // (the last, partial block: left-aligned)
+      if (((t - 1) & 15) != 15) pg[(size_t)((t - 1) >> 4) * 64 + lane] = pw >> (2 * (15 - ((t - 1) & 15)));   // (the last, partial block: step s at bits 2s too)
     }
     // ---- traceback (first lane of each group) in chunks of <= AD_RCAP merged runs, expanded by all lanes into one
     //      transition code per raw position.  Run: pj_lo (12 b) | n (12 b) << 12 | (delta + 128) << 24, delta = pi - pj;
@@ -988,12 +997,11 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         const int gact = __shfl((int)act, gl0, 64);
         const int tt = __shfl(ti + tj, gl0, 64), col = __shfl((tj - ti + lbo) >> 1, gl0, 64);
         const int f0 = tt & 15, widx = (tt >> 4) - g;
-        uint32_t word = 0xFFFFFFFFu;                       // (before the matrix: never reached, the axis cells stop the run)
+        uint32_t word = 0xAAAAAAAAu;                       // (before the matrix: never reached, the axis cells stop the run)
         if (gact && !ghost && widx >= 0) word = pg[(size_t)widx * 64 + gl0 + col];
         const int ftop = g == 0 ? f0 : 14 + (f0 & 1);
         // fields of the path cell's parity at positions <= ftop that are NOT diagonal (11)
-        word = __brev(word);                                // step s of the block at bits 2s (A), 2s + 1 (B); 3 = diagonal
-        const uint32_t x = ~word;
+        const uint32_t x = word ^ 0xAAAAAAAAu;              // step s of the block at bits 2s, 2s + 1; a zero field = diagonal
         uint32_t nz = (x | (x >> 1)) & 0x55555555u;
         nz &= (f0 & 1) ? 0x44444444u : 0x11111111u;
         nz &= (ftop == 15) ? 0xFFFFFFFFu : ((1u << ((ftop + 1) << 1)) - 1u);
@@ -1017,8 +1025,8 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
             ti -= n; tj -= n;
           }
           if (qs < GL && !clamped && (ti > 0 || tj > 0)) {  // (0,0) carries an axis pointer too: the path ends there
-            if (pq == 1u) { tj--; push(tj, 1, 255); }      // A = 1, B = 0: from the left
-            else ti--;                                     // A = 0: from above (3 = diagonal cannot be here)
+            if (pq == AD_LEFT) { tj--; push(tj, 1, 255); } // from the left
+            else ti--;                                     // from above (the diagonal code cannot be here)
           }
         }
       }

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   const uint32_t reads_ci = STORE ? rd_at(ci) : 0u;
   const uint32_t reads_0 = rd_at(0);
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
+  int my_n0 = 0;                                                         // members partition 0 lost (low half) / gained (high half)
   D2_TRACE(1 + level, 1);
   for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
     const int r = base + threadIdx.x;
@@ -211,6 +212,8 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
         else best_h = h;
         P.clust_of[r] = to;
         P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
+        E.moved[r] = 1;
+        my_n0 += (from == 0 ? 1 : 0) + (to == 0 ? 0x10000 : 0);
         const uint32_t rd = S.reads[r];
         if (to < ntab) atomicAdd(&s_delta[to], (int32_t)rd); else atomicAdd(&dl[to], (int32_t)rd);
         if (from < ntab) atomicSub(&s_delta[from], (int32_t)rd); else atomicSub(&dl[from], (int32_t)rd);
@@ -266,6 +269,14 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
     if (ki < MOV_INLINE2) { out->mov[3 * ki] = s_mov[3 * q]; out->mov[3 * ki + 1] = s_mov[3 * q + 1]; out->mov[3 * ki + 2] = s_mov[3 * q + 2]; }
   }
   __syncthreads();                                                       // every delta of the block is in the table
+  if (__any(my_n0 != 0)) {                                               // (a thread moves a handful of uniques at most: no carry)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) my_n0 += __shfl_xor(my_n0, o, 64);
+    if ((threadIdx.x & 63) == 0) {
+      if (my_n0 & 0xFFFF) atomicAdd(&E.n0d[2 * level], my_n0 & 0xFFFF);
+      if (my_n0 >> 16) atomicAdd(&E.n0d[2 * level + 1], my_n0 >> 16);
+    }
+  }
   if (STORE) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) my_keep += __shfl_xor(my_keep, o, 64);
@@ -528,6 +539,8 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
     P.clust_of[raw] = newi;
     P.lock[raw] = 0;                                                // bi_assign_center unlocks the members (cluster.cpp:377)
     P.slot0[raw] = 1;
+    E.moved[raw] = 1;
+    if (from == 0) { const int n0 = ctl->n0 - 1; ctl->n0 = n0; if (n0 < ctl->low0) ctl->low0 = n0; }
     P.creads[newi] = reads_new;
     P.creads[from] -= reads_new;
     P.centre_of[newi] = raw;
@@ -677,7 +690,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
   if (ctl->state != 0) return;
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
   __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
-  __shared__ int s_halt, s_raw, s_from, s_evalok, s_nt[2];
+  __shared__ int s_halt, s_raw, s_from, s_evalok, s_nt[2], s_nnear;
   __shared__ BudKey s_k[2][16];
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -695,6 +708,19 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
     if (d) P.creads[i] += (uint32_t)d;
   }
   if (threadIdx.x < 2) s_nt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    s_nnear = 0;
+    // partition 0's member count through the chain's shuffle calls: within one call only the number it lost is known, not
+    // the order of losses and gains, so the running minimum is taken as if all losses came first (a lower bound)
+    int n0 = ctl->n0, low0 = ctl->low0;
+    for (int l = 0; l < SH_CHAIN; l++) {
+      const int lost = E.n0d[2 * l], gained = E.n0d[2 * l + 1];
+      if (lost | gained) { E.n0d[2 * l] = 0; E.n0d[2 * l + 1] = 0; }
+      if (n0 - lost < low0) low0 = n0 - lost;
+      n0 += gained - lost;
+    }
+    ctl->n0 = n0; ctl->low0 = low0;
+  }
   __syncthreads();
   D2_TRB(1);
   // ---- second stage of b_bud's arg-min (cluster.cpp:284-308): the block minima of k2_pupdate, then the exact ties of the
@@ -738,6 +764,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
         const bool exact = p == bk.p && reads == bk.reads;
         const bool near = !exact && p != 0.0 && p <= (track ? thr1 : thr0);
         if (!exact && !near) continue;
+        if (near && track == 0) s_nnear = 1;
         const int k = atomicAdd(&s_nt[track], 1);
         if (k < TIES_FULL) {
           BudTie t;
@@ -772,7 +799,29 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
       // the unambiguous case of b_bud (cluster.cpp:300-330) is the device's; the margins keep every decision that depends
       // on the last ulp of a p-value on the host
       const double pA = b.best_p[0] * S.N;
-      const bool birthA = b.valid && b.found[0] && b.nties[0] == 1 && pA < E.omegaA * (1.0 - 1e-9);
+      // Several candidates with the same key: b_bud keeps the first one it meets, partitions in index order and each
+      // partition's members in list order (cluster.cpp:284-308).  Settled here when the key is p = 0 exactly (an underflow
+      // on any libm; nothing near it is listed) and the order follows without the member lists: the lowest partition holds
+      // one candidate, or it is partition 0 and its candidates have never moved and never been its last member - their
+      // slots are their indices (Eng2::moved).  Everything else stays the host's.
+      int win = b.nties[0] == 1 ? 0 : -1;
+      if (b.valid && b.found[0] && b.nties[0] > 1 && b.nties[0] <= BUD_TIES && !s_nnear && b.best_p[0] == 0.0) {
+        int cmin = 0x7FFFFFFF, ncmin = 0, kmin = -1, rmin = 0x7FFFFFFF;
+        bool ok = true;
+        const int low0 = ctl->low0;
+        for (int k = 0; k < b.nties[0]; k++) {
+          const int fr = b.ties[0][k].from, rw = b.ties[0][k].raw;
+          if (fr < cmin) { cmin = fr; ncmin = 0; rmin = 0x7FFFFFFF; }
+          if (fr == cmin) {
+            ncmin++;
+            if (fr == 0 && (E.moved[rw] || rw + 1 >= low0)) ok = false;
+            if (rw < rmin) { rmin = rw; kmin = k; }
+          }
+        }
+        if (ok && (ncmin == 1 || cmin == 0)) win = kmin;
+      }
+      if (win > 0) { const BudTie t = out->bud.ties[0][0]; out->bud.ties[0][0] = out->bud.ties[0][win]; out->bud.ties[0][win] = t; win = 0; }
+      const bool birthA = b.valid && b.found[0] && win == 0 && pA < E.omegaA * (1.0 - 1e-9);
       const bool noA = !b.found[0] || pA >= E.omegaA * (1.0 + 1e-9);
       const bool noP = !b.found[1] || b.best_p[1] >= E.omegaP * (1.0 + 1e-9);
       if (birthA) { raw = b.ties[0][0].raw; from = b.ties[0][0].from; }

@@ -64,3 +64,10 @@ def test_emulated_bimera_table_and_nwvec_goldens(emu_lib):
 
 def test_emulated_homopolymer_gap_goldens(emu_lib):
     run_cases(emu_lib, ("sam1F_homogap",))
+
+
+def test_emulated_exact_bud_ties_settled_on_the_device_or_the_host(emu_lib):
+    """tests/helpers.zero_tie_sample: ties of b_bud's best key that k2_birth settles itself (first-slot members of partition 0,
+    one candidate in the lowest partition) next to those it must leave to the host (moved members, several in one partition)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_ties.py"), "1", "2"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "zero ties: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

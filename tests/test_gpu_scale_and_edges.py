@@ -131,6 +131,20 @@ def test_near_tied_bud_candidates_follow_cpu_order(api, oracle_c):
         assert np.array_equal(got.clustering["birth_pval"][1:], want.clustering["birth_pval"][1:])
 
 
+# ---- exact ties of b_bud's best key: the first in partition order, then in member-list order (cluster.cpp:284-308) ---------
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_exact_bud_ties_follow_the_member_list_order(api, oracle_c, seed):
+    """Equal-read candidates with p = 0: the device settles the ties whose order needs no member list (never-moved members of
+    partition 0, a single candidate in the lowest partition), the host the others - all must be the reference's choice."""
+    from helpers import zero_tie_sample
+    seqs, ab, q = zero_tie_sample(seed)
+    for o in (DadaOpts(), DadaOpts(OMEGA_A=1e-4, DETECT_SINGLETONS=True)):
+        got = api.dada_uniques(seqs, ab, None, tperr1(), q, o)
+        want = oracle_c.dada_uniques(seqs, ab, None, tperr1(), q, o)
+        assert got.nclust == want.nclust >= 8
+        assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
 # ---- batch C entry point (dada2hip_run_multi): one host thread per device entry ------------------------------------------
 def test_run_multi_equals_per_sample_calls(api, oracle_c):
     from dada2_amd.synth import make_sample
