@@ -307,6 +307,10 @@ def phases(st, prof):
     out = {"host_wall_ms": {k: st[k] for k in ("ms_total", "ms_upload", "ms_screen", "ms_bookkeep", "ms_final", "ms_wait_device",
                                                 "ms_replay", "ms_enqueue")},
            "moves": st["nmoves"], "batch_compares": st["batch_compares"],
+           "alignments": {"committed_nw": st["nnw"], "committed_gapless": st["ngapless"], "run_for_rounds_nw": st["nnw_run"],
+                          "run_for_rounds_gapless": st["ngapless_run"],
+                          "note": "committed = the reference's counts (round 0 and the final pass included); run_for_rounds = pairs the aligner "
+                                  "processed for the batch compares of the rounds, incl. those a later greedy skip or an unused batch position wasted"},
            "host_wall_note": "upload = marshalling + H2D + k-mer build; screen = enqueue of the compare kernels; "
                              "bookkeep = round tails incl. waiting for the device; final = final pass + outputs"}
     if prof:

@@ -32,6 +32,7 @@ class CStats(C.Structure):
         ("dev_ms_pval", C.c_double), ("dev_ms_birth", C.c_double), ("dev_ms_final", C.c_double),
         ("ms_wait_device", C.c_double), ("ms_replay", C.c_double), ("ms_enqueue", C.c_double),
         ("nmoves", C.c_uint64), ("batch_compares", C.c_uint64),
+        ("nnw_run", C.c_uint64), ("ngapless_run", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -1218,7 +1218,9 @@ struct Run {
   DevBuf<double> v2_lam0, v2_lam1;
   DevBuf<uint32_t> v2_ham0, v2_ham1;
   DevBuf<int32_t> v2_i1;
-  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn, v2_sig, v2_n0d;
+  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn, v2_sig, v2_n0d, v2_blist, v2_blistn;
+  DevBuf<double> v2_lamB;
+  DevBuf<uint32_t> v2_hamB;
   DevBuf<uint8_t> v2_moved;
   DevBuf<CompBlk> v2_blk;
   DevBuf<Ctl2> v2_ctl;
@@ -1249,6 +1251,7 @@ struct Run {
     E2.T.blk_cap = (int32_t)std::min<size_t>(v2_blk.n, 0x7FFFFFF0u);
     E2.C.NBUF = v2_nbuf; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
     E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15;
+    E2.C.lamB = v2_lamB.p; E2.C.hamB = v2_hamB.p; E2.blist = v2_blist.p; E2.blist_n = v2_blistn.p;
     E2.cls = s->d_cls.p; E2.lam = s->d_lambda.p; E2.ham = s->d_ham.p;
     E2.nw_list = s->d_nw_list.p; E2.gl_list = s->d_gl_list.p; E2.list_n = v2_listn.p;
     E2.ctl = v2_ctl.p; E2.dblk = v2_dblk.p; E2.hblk = v2_hblk.p; E2.dlt = v2_dlt.p; E2.movers = v2_movers.p;
@@ -1269,6 +1272,16 @@ struct Run {
   void v2_alloc(int max_clust) {
     const size_t n = (size_t)N;
     v2_nbuf = 64;   // 512 cached centres, 2 bytes x N each (r02l sweep: 64 buffers beat 32 by 2.5 % at 1M uniques)
+    {   // a batch buffer holds class words and the aligner's results for KB_MAX centres: 98 bytes per unique.  At most an
+        // eighth of the device's memory goes to the cache (64 buffers take 6.3 GB at 10^6 uniques).  hipDeviceTotalMem, not
+        // hipMemGetInfo: the latter is refused while ANOTHER host thread captures its round graph (dada2hip_run_multi).
+      size_t total_b = 0;
+      int dev_ = 0;
+      (void)hipGetDevice(&dev_);
+      if (hipDeviceTotalMem(&total_b, dev_) != hipSuccess || !total_b) { (void)hipGetLastError(); total_b = (size_t)64 << 30; }
+      const size_t per_buf = (((size_t)N + 31) & ~(size_t)15) * (2 + (size_t)KB_MAX * 12);
+      v2_nbuf = (int)std::max<size_t>(2, std::min<size_t>(64, total_b / 8 / std::max<size_t>(per_buf, 1)));
+    }
     if (const char *e = getenv("DADA2HIP_V2_NBUF")) v2_nbuf = std::max(1, std::min(64, atoi(e)));   // (k2_birth keeps the slot table in LDS)
     if (const char *e = getenv("DADA2HIP_V2_DEPTH")) v2_depth = std::max(1, std::min(RING2 - 1, atoi(e)));
     v2_chain = SH_CHAIN;
@@ -1286,6 +1299,9 @@ struct Run {
     v2_movers.alloc((size_t)RING2 * SH_CHAIN * 3 * n);
     const size_t slots = (size_t)v2_nbuf * KB_MAX;
     v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
+    v2_lamB.alloc(slots * (((size_t)N + 31) & ~(size_t)15)); v2_hamB.alloc(slots * (((size_t)N + 31) & ~(size_t)15));
+    v2_blist.alloc((size_t)2 * KB_MAX * (((size_t)N + 31) & ~(size_t)15)); v2_blistn.alloc(2 * KB_MAX);
+    D2_HIP(hipMemsetAsync(v2_blistn.p, 0, 2 * KB_MAX * 4, stq));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
     v2_listn.alloc(2); v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
     v2_moved.alloc(n); v2_n0d.alloc(2 * SH_CHAIN);
@@ -1367,11 +1383,15 @@ struct Run {
       rec.ev_screen = ev_begin(EV_SCREEN, profile_all, /*spec=*/true);
       launch2_screen_multi(E2, stq);
       ev_end(rec.ev_screen);
-      launch2_lists(E2, stq);
-      rec.ev_nw = ev_begin(EV_NW, profile_all);
-      launch_nw_ad(s->D, -1, nullptr, s->d_nw_list.p, v2_listn.p, 0, s->d_gl_list.p, v2_listn.p + 1, ap, s->d_err.p, s->d_lambda.p,
-                   s->d_ham.p, nullptr, 0, 0, &v2_ctl.p->centre, stq, &v2_ctl.p->state);
+      // ... its survivors through the aligner, all batch positions in one launch (both no-ops on a cache hit) ...
+      launch2_batch_lists(E2, stq);
+      rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
+      const NwBatch nb{&v2_ctl.p->nbatch, v2_blistn.p, v2_blist.p, v2_ctl.p->bcentre, &v2_ctl.p->bbuf, E2.C.Npad};
+      launch_nw_ad(s->D, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, stq,
+                   &v2_ctl.p->state, &nb);
       ev_end(rec.ev_nw);
+      // ... and the round's own classes: the cached ones with the greedy skip as of now
+      launch2_lists(E2, stq);
     }
     int ev = ev_begin(EV_SHUFFLE, profile_all && nlev > 0);
     for (int l = 0; l < nlev; l++) launch2_shuffle(E2, l, store && l == 0, stq);
@@ -1497,6 +1517,8 @@ struct Run {
       if (rec.compare && b.nbatch > 0) {                       // (this chain's batch compare really ran: a cache miss)
         v2_miss_launches++;
         if (rec.ev_screen >= 0) evs[rec.ev_screen].ok = 1;
+        if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
+        st.nnw_run += (uint64_t)b.pad0[1]; st.ngapless_run += (uint64_t)b.pad0[2];
       }
       if (b.nlev > 0 && b.halt != H2_SHUFFLE_MORE) { }        // (a round's commit is complete)
       switch (b.halt) {

@@ -198,12 +198,22 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
                double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, uint8_t *d_moves,
                int moves_stride, int32_t *d_nmoves, hipStream_t st);
 
+// batch mode of k_nw_ad (round engine v2): the comparisons of a whole batch compare in one launch, everything read on the device
+struct NwBatch {
+  const int32_t *on;        // centres in the batch compare in flight (0: the launch has nothing to do)
+  const int32_t *n;         // [2 KB_MAX] lengths of the lists below
+  const int32_t *list;      // [2 KB_MAX][stride]: uniques to align with batch centre k (row k), its gapless ones (row KB_MAX + k)
+  const int32_t *centre;    // [KB_MAX]
+  const int32_t *bbuf;      // batch buffer: results go to row (*bbuf * KB_MAX + k) of d_lambda / d_ham, rows of `stride` entries
+  size_t stride;
+};
 // d_gl_work/d_gl_nwork (optional): the round's gapless comparisons, processed by the same kernel
 // d_view (optional): aligned views, row = unique (or chunk when view_by_chunk); chunks are nw_ad_apw() work slots
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,
-                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st, const int32_t *d_stop_dev = nullptr);
+                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st, const int32_t *d_stop_dev = nullptr,
+                  const NwBatch *batch = nullptr);
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap);
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap);
 
@@ -223,7 +233,9 @@ int nw_adw_apw(const SampleDev &S, const AlignParams &ap);
 //
 //  * A compare is no longer tied to its round: when the centre of the coming round has no comparisons yet, ONE pass
 //    over the k-mer records screens every unique against up to KB_MAX centres at once - the coming centre plus the
-//    candidates that the bud ordering makes likely to be born next - and one NW launch aligns all surviving pairs.
+//    candidates that the bud ordering makes likely to be born next - and ONE aligner launch aligns all surviving pairs
+//    (about eight rounds' worth: the launch runs in the aligner's saturated regime, where an alignment costs 0.6 of what it
+//    costs in a launch of one round's work).
 //    The results (class, lambda, hamming per unique) stay in a cache of NBUF batches; the round of a cached centre
 //    commits them without touching the k-mer records or the aligner again (HBM bytes per comparison / KB_MAX, aligner
 //    launches with KB_MAX rounds of work).  Exactness: a comparison depends only on the two uniques, err and the
@@ -283,9 +295,9 @@ struct Ctl2 {
   int32_t blen[KB_MAX];
 };
 
-// Screen results of the batch compares, kept until their centre's round comes (or the batch buffer is recycled): 2 bits
-// per (unique, batch position).  The aligner runs at commit time, on the round's centre only: a wrong guess costs its
-// share of one pass over the k-mer records, never an alignment.
+// Results of the batch compares, kept until their centre's round comes (or the batch buffer is recycled): the class, 2 bits
+// per (unique, batch position), and lambda / hamming of the pairs the aligner saw.  A wrong guess costs its share of one
+// pass over the k-mer records and its alignments (about one batch position in ten is never used; profiles/README.md).
 struct Cache2 {
   int32_t NBUF = 0;               // batch buffers
   uint16_t *bcls = nullptr;       // [NBUF][Npad]  2 bits per batch position: CLS_* as of the compare
@@ -293,6 +305,10 @@ struct Cache2 {
   uint2 *tab8 = nullptr;          // [1024]  byte k = min(count of the 5-mer in batch centre k, 63)
   uint16_t *full = nullptr;       // [KB_MAX][1024] full counts (heavy k-mer correction)
   uint16_t *ord = nullptr;        // [KB_MAX][LK] ordered 5-mers, 0xFFFF past the end
+  // lambda / hamming of the batch's alignments, row = cache slot (batch buffer * KB_MAX + position): written by the ONE
+  // aligner launch that follows a batch screen, read (sparsely: NW / gapless classes only) when the slot's round commits
+  double *lamB = nullptr;         // [NBUF * KB_MAX][Npad]
+  uint32_t *hamB = nullptr;       // [NBUF * KB_MAX][Npad]
   size_t Npad = 0;
 };
 
@@ -338,6 +354,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   double *lam;
   uint32_t *ham;
   int32_t *nw_list, *gl_list, *list_n;
+  int32_t *blist, *blist_n;       // [2 KB_MAX][Npad] / [2 KB_MAX]: work lists of the batch compare (NwBatch)
   void *partial;                  // block partials of the bud arg-min
   int32_t *ties0, *ties1;         // full tie lists
   BudTie *ties_rec;               // [2][TIES_FULL] full records of the first TIES_FULL listed candidates per track
@@ -360,7 +377,8 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
                     hipStream_t st);
 void launch2_screen_multi(const Eng2 &E, hipStream_t st);
-void launch2_lists(const Eng2 &E, hipStream_t st);                                    // cached classes + commit-time greedy skip -> work lists
+void launch2_batch_lists(const Eng2 &E, hipStream_t st);                              // classes of a batch screen -> the aligner's work lists
+void launch2_lists(const Eng2 &E, hipStream_t st);                                    // cached classes + commit-time greedy skip -> the round's classes
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
 // b_p_update + b_bud arg-min (grid) ; ties, decision, birth, plan of the coming round, publication (one block)
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);

@@ -250,8 +250,10 @@ class AllocCache {
   // cached device bytes are capped at a third of the device's memory (DADA2HIP_ALLOC_CACHE_GB overrides)
   size_t dev_cap() {
     if (cap_ == 0) {
-      size_t fr = 0, tot = 0;
-      cap_ = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? tot / 3 : ((size_t)32 << 30);
+      size_t tot = 0;   // (hipDeviceTotalMem: hipMemGetInfo is refused while another host thread captures a graph)
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      cap_ = (hipDeviceTotalMem(&tot, dev) == hipSuccess && tot) ? tot / 3 : ((size_t)32 << 30);
     }
     return cap_;
   }

@@ -394,6 +394,15 @@ struct NwArgs {
   int moves_stride;
   int32_t *nmoves;
   const int32_t *stop_dev;     // round engine v2: non-zero = the device has halted, nothing to do
+  // round engine v2, batch mode (k_nw_ad only): the alignments of a whole batch compare - up to KB_MAX centres - in ONE launch.
+  // List k (k < KB_MAX) holds the uniques to align with batch centre k, list KB_MAX + k its gapless ones; blocks work on
+  // one centre at a time (it is staged once per block), results go to row (bbuf * KB_MAX + k) of lam / ham.
+  const int32_t *batch_on;     // number of centres of the batch compare in flight (0: nothing to do), or nullptr: not batch mode
+  const int32_t *batch_n;      // [2 KB_MAX] list lengths
+  const int32_t *batch_list;   // [2 KB_MAX][batch_stride]
+  const int32_t *batch_centre; // [KB_MAX] centre of each batch position
+  const int32_t *batch_bbuf;   // batch buffer the results belong to
+  size_t batch_stride;         // row length of batch_list and of lam / ham
 };
 
 // shared tail: traceback + lambda.  NPW = pointer words per row.
@@ -825,12 +834,23 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double *s_err = s_dyn;
   const int nerr = 16 * a.ap.ncol;
+  const bool batch = a.batch_on != nullptr;
+  int bk[KB_MAX + 1];                                        // batch mode: first block-sized work slice of every batch position
   {   // the per-round grid is sized for the worst case (the batch size is only known on the device): blocks past the
       // work leave before touching anything, also when a speculative round turned out to have no centre
     if (a.stop_dev && *a.stop_dev != 0) return;
-    const int n_all = (a.nwork_dev ? *a.nwork_dev : a.nwork_host) + (gl_work ? *gl_nwork_dev : 0);
-    if ((int)blockIdx.x * 4 * APW >= n_all) return;
-    if (a.centre_dev && *a.centre_dev < 0) return;
+    bk[0] = 0;
+    if (batch) {
+      const int nb = *a.batch_on;
+      if (nb <= 0) return;
+#pragma unroll
+      for (int k = 0; k < KB_MAX; k++) bk[k + 1] = bk[k] + (k < nb ? (a.batch_n[k] + a.batch_n[KB_MAX + k] + 4 * APW - 1) / (4 * APW) : 0);
+      if ((int)blockIdx.x >= bk[KB_MAX]) return;
+    } else {
+      const int n_all = (a.nwork_dev ? *a.nwork_dev : a.nwork_host) + (gl_work ? *gl_nwork_dev : 0);
+      if ((int)blockIdx.x * 4 * APW >= n_all) return;
+      if (a.centre_dev && *a.centre_dev < 0) return;
+    }
   }
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = a.err[i];
   const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -850,7 +870,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   uint16_t *foff = (uint16_t *)(abase + AD_RCAP * 4 + 4 * G.seqwords);  // byte offset into s_err of every raw position's factor
   uint8_t *qlds = abase + AD_RCAP * 4 + 4 * G.seqwords + 2 * G.tbytes;
   const SampleDev &S = a.S;
-  if (G.shared_c) {                                                    // the launch's one centre, staged by the whole block
+  if (G.shared_c && !batch) {                                          // the launch's one centre, staged by the whole block
     const int cv = a.centre_dev ? *a.centre_dev : a.centre;
     if (cv >= 0) {
       const int Lc = S.len[cv];
@@ -858,18 +878,45 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     }
   }
   __syncthreads();
-  const int gwave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
+  const int gwave = blockIdx.x * 4 + wib;
   uint32_t *pg = S.ad_ptr + (size_t)gwave * S.ad_wpw;      // this wave's slot of the pointer ring: [16-step block][lane]
-  const int n_nw = a.nwork_dev ? *a.nwork_dev : a.nwork_host;
-  const int n_gl = gl_work ? *gl_nwork_dev : 0;            // gapless items ride along: same factors/product tail
-  const int nwork = n_nw + n_gl;
+  int n_nw = batch ? 0 : (a.nwork_dev ? *a.nwork_dev : a.nwork_host);
+  const int n_gl = batch ? 0 : (gl_work ? *gl_nwork_dev : 0);   // gapless items ride along: same factors/product tail
+  int nwork = n_nw + n_gl;
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
-  const int centre_v = a.centre_dev ? *a.centre_dev : a.centre;
+  const int centre_v = batch ? 0 : (a.centre_dev ? *a.centre_dev : a.centre);
   if (centre_v < 0 && !a.chunk_centre) return;
-  for (int chunk = gwave; chunk * APW < nwork; chunk += nwaves) {
+  const int32_t *wl = a.work, *gll = gl_work;
+  size_t out_off = 0;
+  int kcur = -1;
+  // one iteration = one work slice of the block (4 waves x APW alignments); it = blockIdx.x + j gridDim.x, so a wave's
+  // chunk index it * 4 + wib runs over gwave + j nwaves
+  for (int it = blockIdx.x;; it += gridDim.x) {
+    int chunk, c;
+    if (batch) {
+      if (it >= bk[KB_MAX]) break;                           // (block-uniform: the barriers below are safe)
+      int k = 0, b0 = 0;                                     // the last position whose first slice is <= it (bk is nondecreasing)
+#pragma unroll
+      for (int q = 1; q < KB_MAX; q++) if (it >= bk[q]) { k = q; b0 = bk[q]; }
+      c = a.batch_centre[k];
+      if (k != kcur) {                                       // next batch position: its centre replaces the staged one
+        __syncthreads();
+        const int Lc = S.len[c];
+        for (int p = threadIdx.x; p < Lc; p += 256) cwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);
+        __syncthreads();
+        kcur = k;
+        wl = a.batch_list + (size_t)k * a.batch_stride; gll = a.batch_list + (size_t)(KB_MAX + k) * a.batch_stride;
+        n_nw = a.batch_n[k]; nwork = n_nw + a.batch_n[KB_MAX + k];
+        out_off = ((size_t)*a.batch_bbuf * KB_MAX + k) * a.batch_stride;
+      }
+      chunk = (it - b0) * 4 + wib;
+    } else {
+      chunk = it * 4 + wib;
+      if (chunk * APW >= nwork) break;
+      c = a.chunk_centre ? a.chunk_centre[chunk] : centre_v;
+    }
     const int idx = chunk * APW + al;
-    const int c = a.chunk_centre ? a.chunk_centre[chunk] : centre_v;
-    int r = idx < n_nw ? a.work[idx] : (idx < nwork ? gl_work[idx - n_nw] : -1);
+    int r = idx < n_nw ? wl[idx] : (idx < nwork ? gll[idx - n_nw] : -1);
     const bool gapless = idx >= n_nw;
     const bool active = r >= 0;
     if (!active) r = c;
@@ -1095,8 +1142,8 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         for (int k = 0; k < 8; k++) l = l * f[k];
       }
       for (; pj < L2; pj++) l = l * *(const double *)(eb + foff[pj]);
-      a.lam[r] = l;
-      a.ham[r] = h;
+      a.lam[out_off + r] = l;
+      a.ham[out_off + r] = h;
     }
   }
 }
@@ -1104,8 +1151,9 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                   const int32_t *d_nwork, int nwork_host, const int32_t *d_gl_work, const int32_t *d_gl_nwork,
                   const AlignParams &ap, const double *d_err, double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV,
-                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st, const int32_t *d_stop_dev) {
+                  int view_by_chunk, const int32_t *d_centre_dev, hipStream_t st, const int32_t *d_stop_dev, const NwBatch *batch) {
   int maxwork = d_nwork ? S.N : nwork_host;
+  if (batch) maxwork = S.N;
   if (maxwork <= 0 && !d_gl_work) return;
   NwArgs a;
   memset(&a, 0, sizeof a);
@@ -1113,10 +1161,14 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
   a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev; a.stop_dev = d_stop_dev;
   { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
+  if (batch) {
+    a.batch_on = batch->on; a.batch_n = batch->n; a.batch_list = batch->list; a.batch_centre = batch->centre; a.batch_bbuf = batch->bbuf;
+    a.batch_stride = batch->stride;
+  }
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen, d_chunk_centre ? 0 : 1);
   const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)G.block_bytes;
   int waves = (std::max(maxwork, 1) + G.APW - 1) / G.APW;
-  if (d_gl_work) waves = (S.N + G.APW - 1) / G.APW;
+  if (d_gl_work || batch) waves = (S.N + G.APW - 1) / G.APW;
   int grid = std::max(1, std::min((waves + 3) / 4, std::min(256 * 8, S.ad_waves / 4)));   // one slot of the pointer ring per wave
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
 #define D2_LAUNCH_AD(GLV, DEFV, EDGEV, VARV)                                                                                 \

@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   int32_t *mv = E.movers + ((size_t)(ring * SH_CHAIN + level)) * 3 * (size_t)N;
   int32_t *dl = E.dlt + (size_t)level * E.ccap;
   const uint32_t creads_c = S.reads[centre];
+  const double *lam_row = E.C.lamB + (size_t)ctl->slot * E.C.Npad;       // the round's comparisons: its cache slot's rows
+  const uint32_t *ham_row = E.C.hamB + (size_t)ctl->slot * E.C.Npad;
   const uint32_t reads_ci = STORE ? rd_at(ci) : 0u;
   const uint32_t reads_0 = rd_at(0);
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
       if (need) {
       const double lam0_r = T.lam0[r], lam1_r = T.lam1[r];
       const uint8_t cl = STORE ? E.cls[r] : (uint8_t)0;
-      const double l_raw = STORE ? E.lam[r] : 0.0, em = STORE ? P.E_minmax[r] : 0.0;
-      const uint32_t h_raw = STORE ? E.ham[r] : 0u;
+      const double l_raw = STORE ? lam_row[r] : 0.0, em = STORE ? P.E_minmax[r] : 0.0;
+      const uint32_t h_raw = STORE ? ham_row[r] : 0u;
       head = i1 >= 0 ? head_raw : -1;                                    // (a chain only exists behind a used second entry)
       if (STORE) {
         if (cl >= CLS_GAPLESS) {
@@ -302,8 +304,6 @@ constexpr int LISTS_PER_THREAD = 8;
 __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
   const Ctl2 *ctl = E.ctl;
   if (ctl->state != 0) return;
-  __shared__ int32_t s_nw[256 * LISTS_PER_THREAD], s_gl[256 * LISTS_PER_THREAD];
-  __shared__ int s_cnt[8];
   __shared__ unsigned int s_stat[4];
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -311,7 +311,6 @@ __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
   const uint16_t *bcls = E.C.bcls + (size_t)(slot / KB_MAX) * E.C.Npad;
   const uint32_t creads_c = S.reads[centre];
   D2_TRACE(0, 0);
-  if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
   if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
   const int r0 = (blockIdx.x * 256 + threadIdx.x) * LISTS_PER_THREAD;
   uint4 cw = make_uint4(0, 0, 0, 0), rd0 = cw, rd1 = cw;
@@ -325,7 +324,7 @@ __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
   __syncthreads();
   const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w}, rds[8] = {rd0.x, rd0.y, rd0.z, rd0.w, rd1.x, rd1.y, rd1.z, rd1.w};
   uint32_t codes = 0;                                                  // 2 bits per unique
-  int my_stat[4] = {0, 0, 0, 0}, n_nw = 0, n_gl = 0;
+  int my_stat[4] = {0, 0, 0, 0};
   bool cache_hole = false;
 #pragma unroll
   for (int q = 0; q < LISTS_PER_THREAD; q++) {
@@ -337,8 +336,6 @@ __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
     else if (code == CLS_SKIP) cache_hole = true;                        // the cache lacks a comparison the round needs
     my_stat[code == CLS_NW ? 0 : (code == CLS_GAPLESS ? 1 : (code == CLS_SHROUD ? 2 : 3))]++;
     codes |= code << (2 * q);
-    n_nw += code == CLS_NW;
-    n_gl += code == CLS_GAPLESS;
   }
   if (cache_hole) atomicOr(P.err_flag, 8);
   if (r0 < S.N) {                                                       // the round's class bytes, eight at a time
@@ -348,15 +345,6 @@ __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
     if (r0 + LISTS_PER_THREAD <= S.N) *(uint2 *)(E.cls + r0) = make_uint2(lo, hi);
     else for (int q = 0; r0 + q < S.N; q++) E.cls[r0 + q] = (uint8_t)((codes >> (2 * q)) & 3u);
   }
-  // block-local lists: one LDS atomic per thread per list, one device atomic per block per list
-  int b_nw = n_nw ? atomicAdd(&s_cnt[0], n_nw) : 0, b_gl = n_gl ? atomicAdd(&s_cnt[1], n_gl) : 0;
-#pragma unroll
-  for (int q = 0; q < LISTS_PER_THREAD; q++) {
-    const uint32_t code = (codes >> (2 * q)) & 3u;
-    if (r0 + q >= S.N) break;
-    if (code == CLS_NW) s_nw[b_nw++] = r0 + q;
-    else if (code == CLS_GAPLESS) s_gl[b_gl++] = r0 + q;
-  }
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     int v = my_stat[q];
@@ -365,19 +353,72 @@ __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stat[q], (unsigned int)v);
   }
   __syncthreads();
-  if (threadIdx.x < 2) {
-    const int n = s_cnt[threadIdx.x];
-    s_cnt[4 + threadIdx.x] = n ? atomicAdd(&E.list_n[threadIdx.x], n) : 0;   // one global atomic per list per block
-  }
   if (threadIdx.x < 4 && s_stat[threadIdx.x]) {
     Round2Out *out = E.dblk + (ctl->pub_seq % RING2);
     atomicAdd(&out->stat[threadIdx.x], (unsigned long long)s_stat[threadIdx.x]);
   }
-  __syncthreads();
   D2_TRACE(0, 1);
-  for (int i = threadIdx.x; i < s_cnt[0]; i += 256) E.nw_list[s_cnt[4] + i] = s_nw[i];
-  for (int i = threadIdx.x; i < s_cnt[1]; i += 256) E.gl_list[s_cnt[5] + i] = s_gl[i];
   D2_TRACE(0, 2);
+}
+
+// ---- work lists of a batch compare: for every batch position the uniques whose pair goes to the aligner (class NW) and the
+// gapless ones, as of the screen (a pair the greedy rule skips at ITS commit is aligned in vain; locks only grow, so no pair
+// a commit needs is ever missing).  Same streaming shape as k2_lists; most class words have no such pair at all. ----
+__global__ __launch_bounds__(256) void k2_batch_lists(Eng2 E) {
+  const Ctl2 *ctl = E.ctl;
+  const int nb = ctl->nbatch;
+  if (ctl->state != 0 || nb == 0) return;
+  __shared__ int s_cnt[2 * KB_MAX], s_base[2 * KB_MAX];
+  const SampleDev &S = E.S;
+  const uint16_t *bcls = E.C.bcls + (size_t)ctl->bbuf * E.C.Npad;
+  if (threadIdx.x < 2 * KB_MAX) s_cnt[threadIdx.x] = 0;
+  const int r0 = (blockIdx.x * 256 + threadIdx.x) * LISTS_PER_THREAD;
+  uint4 cw = make_uint4(0, 0, 0, 0);
+  if (r0 < S.N) cw = *(const uint4 *)(bcls + r0);
+  __syncthreads();
+  const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+  // bit 2k+1 of a class word is set for NW and gapless (CLS_GAPLESS = 2, CLS_NW = 3); positions >= nb hold class 0
+  const bool any = ((cw.x | cw.y | cw.z | cw.w) & 0xAAAAAAAAu) != 0;
+  uint32_t n_lo = 0, n_hi = 0;                                          // per-list counts of this thread, 4 bits each (<= 8)
+  if (any) {
+#pragma unroll
+    for (int q = 0; q < LISTS_PER_THREAD; q++) {
+      if (r0 + q >= S.N) break;
+      const uint32_t w = (cws[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
+      for (uint32_t m = w & 0xAAAAu; m; m &= m - 1) {
+        const int k = __builtin_ctz(m) >> 1;
+        const int list = ((w >> (2 * k)) & 1u) ? k : KB_MAX + k;        // NW : gapless
+        if (list < 8) n_lo += 1u << (4 * list); else n_hi += 1u << (4 * (list - 8));
+      }
+    }
+  }
+  int mybase[2 * KB_MAX];                                               // ... and where they start in the block's share of each list
+#pragma unroll
+  for (int l = 0; l < 2 * KB_MAX; l++) {
+    const int n = (int)(((l < 8 ? n_lo : n_hi) >> (4 * (l & 7))) & 15u);
+    mybase[l] = n ? atomicAdd(&s_cnt[l], n) : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * KB_MAX) {
+    const int n = s_cnt[threadIdx.x];
+    s_base[threadIdx.x] = n ? atomicAdd(&E.blist_n[threadIdx.x], n) : 0;   // one device atomic per list per block
+  }
+  __syncthreads();
+  if (any) {
+#pragma unroll
+    for (int q = 0; q < LISTS_PER_THREAD; q++) {
+      if (r0 + q >= S.N) break;
+      const uint32_t w = (cws[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
+      for (uint32_t m = w & 0xAAAAu; m; m &= m - 1) {
+        const int k = __builtin_ctz(m) >> 1;
+        const int list = ((w >> (2 * k)) & 1u) ? k : KB_MAX + k;
+        int pos = 0;
+#pragma unroll
+        for (int l = 0; l < 2 * KB_MAX; l++) if (l == list) pos = s_base[l] + mybase[l]++;
+        E.blist[(size_t)list * E.C.Npad + pos] = r0 + q;
+      }
+    }
+  }
 }
 
 // ---- b_p_update + first stage of b_bud (no "would another shuffle move" pass: the chain's shuffles are real calls) -----
@@ -549,7 +590,6 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
     ctl->nclust = newi + 1;
     ctl->centre = raw;
     ctl->nsh_base = 0;
-    E.list_n[0] = 0; E.list_n[1] = 0;                               // the coming round's work lists
     *s_hit = -1;
   }
   __syncthreads();
@@ -568,6 +608,7 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
     s_bc[0] = raw;
     *s_nb = 1;
   }
+  if (tid < 2 * KB_MAX) E.blist_n[tid] = 0;                          // the batch compare's work lists (k2_batch_lists)
   for (int q = tid; q < PLAN_BITS / 32; q += blockDim.x) s_bits[q] = 0;
   __syncthreads();
   for (int q = tid; q < nslots; q += blockDim.x) {
@@ -789,6 +830,11 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
   D2_TRB(2);
   if (threadIdx.x == 0) {
     out->nlev = nlev; out->nsh = cs.nexec; out->slot = ctl->slot; out->nbatch = ctl->nbatch;
+    if (ctl->nbatch > 0) {                                       // alignments / gapless pairs this chain's batch compare ran
+      int nn = 0, ng = 0;
+      for (int k = 0; k < KB_MAX; k++) { nn += E.blist_n[k]; ng += E.blist_n[KB_MAX + k]; }
+      out->pad0[1] = nn; out->pad0[2] = ng;
+    }
     out->err_flag = *P.err_flag | (*S.nw_flag ? 4 : 0);
     out->blk_count = *E.T.blk_count;
     const BudOut &b = out->bud;
@@ -1042,6 +1088,10 @@ void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, c
                     hipStream_t st) {
   const int grid = std::min((E.S.N + 255) / 256, 2048);
   hipLaunchKernelGGL(k2_store0, dim3(grid), dim3(256), 0, st, E, d_lam, d_ham, d_cls, d_round_counters);
+}
+void launch2_batch_lists(const Eng2 &E, hipStream_t st) {
+  const int grid = (E.S.N + 256 * LISTS_PER_THREAD - 1) / (256 * LISTS_PER_THREAD);
+  hipLaunchKernelGGL(k2_batch_lists, dim3(grid), dim3(256), 0, st, E);
 }
 void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
   const size_t lds = (size_t)NKMER * 8 + (size_t)KB_MAX * E.S.LK * 2 + (size_t)(E.S.maxlen + 2) * 4 + 16;

@@ -90,6 +90,10 @@ typedef struct dada2hip_stats {
    * replaying moves / births on the host mirror, enqueuing launches; uniques moved by b_shuffle2 over the run */
   double ms_wait_device, ms_replay, ms_enqueue;
   uint64_t nmoves, batch_compares;
+  /* pairs the aligner processed for the rounds' batch compares (device-driven rounds align a whole batch - up to eight
+   * coming centres - in one launch, as of the screen: a pair the greedy rule skips when its round commits, or whose batch
+   * position is never used, is aligned in vain; nnw / ngapless above stay the reference's counts) */
+  uint64_t nnw_run, ngapless_run;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------

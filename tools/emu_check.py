@@ -29,4 +29,4 @@ for spec in specs:
     assert_results_equal(got, want)
     st = got.stats
     print(f"{spec}: ok, {got.nclust} partitions, emulated in {t1 - t0:.1f} s (oracle {time.time() - t1:.1f} s); nnw {st['nnw']} shuffles {st['nshuffle']} "
-          f"moves {st['nmoves']} batch compares {st['batch_compares']}", flush=True)
+          f"moves {st['nmoves']} batch compares {st['batch_compares']}; aligner ran {st['nnw_run']} + {st['ngapless_run']} gapless for the rounds", flush=True)
