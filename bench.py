@@ -307,6 +307,7 @@ def phases(st, prof):
     out = {"host_wall_ms": {k: st[k] for k in ("ms_total", "ms_upload", "ms_screen", "ms_bookkeep", "ms_final", "ms_wait_device",
                                                 "ms_replay", "ms_enqueue")},
            "moves": st["nmoves"], "batch_compares": st["batch_compares"],
+           "chains_without_compare": st["lite_chains"], "of_which_needed_one": st["lite_misses"],
            "alignments": {"committed_nw": st["nnw"], "committed_gapless": st["ngapless"], "run_for_rounds_nw": st["nnw_run"],
                           "run_for_rounds_gapless": st["ngapless_run"],
                           "note": "committed = the reference's counts (round 0 and the final pass included); run_for_rounds = pairs the aligner "

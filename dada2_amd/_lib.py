@@ -33,6 +33,7 @@ class CStats(C.Structure):
         ("ms_wait_device", C.c_double), ("ms_replay", C.c_double), ("ms_enqueue", C.c_double),
         ("nmoves", C.c_uint64), ("batch_compares", C.c_uint64),
         ("nnw_run", C.c_uint64), ("ngapless_run", C.c_uint64),
+        ("lite_chains", C.c_uint64), ("lite_misses", C.c_uint64),
     ]
 
     def as_dict(self):

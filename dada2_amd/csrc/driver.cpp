@@ -516,7 +516,7 @@ struct Run {
 
   ~Run() {
     for (auto &e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    if (v2_graph) (void)hipGraphExecDestroy(v2_graph);
+    for (auto g : v2_graph) if (g) (void)hipGraphExecDestroy(g);
   }
 
   void logf(const char *fmt, ...) {
@@ -1214,7 +1214,7 @@ struct Run {
   // Used when the rounds run on the cooperative NW kernel and nothing forces the plain loop; DADA2HIP_ENGINE=classic
   // keeps the round-1 loop (the parity tests run both).
   bool use_v2 = false;
-  Eng2 E2{};
+  Eng2 E2{}, E2L{};               // E2L: the argument block of chains WITHOUT the batch compare (Eng2::has_compare = 0)
   DevBuf<double> v2_lam0, v2_lam1;
   DevBuf<uint32_t> v2_ham0, v2_ham1;
   DevBuf<int32_t> v2_i1;
@@ -1267,6 +1267,8 @@ struct Run {
     if (const char *e = getenv("DADA2HIP_V2_FILTER")) E2.sh_filter = atoi(e) != 0;
     if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::max(1, atoi(e));
     if (const char *e = getenv("DADA2HIP_V2_GRID_PUPDATE")) E2.grid_pupdate = std::max(1, atoi(e));
+    E2.has_compare = 1;
+    E2L = E2; E2L.has_compare = 0;
     v2_drop_graph();                 // (captured launches hold the old argument block)
   }
   void v2_alloc(int max_clust) {
@@ -1317,7 +1319,7 @@ struct Run {
     Ctl2 c;
     memset(&c, 0, sizeof c);
     c.nclust = 1; c.centre = (int32_t)bi[0].center; c.slot = 0; c.max_clust = max_clust;
-    c.n0 = N; c.low0 = N;
+    c.n0 = N; c.low0 = N; c.need_compare = 0;
     for (int k = 0; k < KB_MAX; k++) c.bcentre[k] = -1;
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
     D2_HIP(hipStreamSynchronize(stq));   // `c` is a local
@@ -1328,6 +1330,9 @@ struct Run {
       D2_HIP(hipMemsetAsync(v2_trace.p, 0, (size_t)TRACE_KERNELS * TRACE_BLOCKS * 64, stq));
     }
     v2_enq = v2_cons = 0;
+    v2_next_full = 0;
+    v2_lite_on = true;
+    if (const char *e = getenv("DADA2HIP_V2_LITE")) v2_lite_on = atoi(e) != 0;
     v2_plain_rounds = 0;
     v2_miss_launches = 0;
     v2_enqrec.clear();
@@ -1339,45 +1344,54 @@ struct Run {
   // A full round is always the same launches with the same arguments (what differs lives in the control block), so it is
   // captured once into a hipGraph and replayed: one API call per round instead of nine, and back-to-back dispatch on the
   // device.  DADA2HIP_V2_GRAPH=0 keeps plain stream launches; profiling (events between launches) does too.
-  hipGraphExec_t v2_graph = nullptr;
+  // ... in both forms: [0] with the batch compare in front, [1] without (Eng2::has_compare)
+  hipGraphExec_t v2_graph[2] = {nullptr, nullptr};
   int v2_graph_state = 0;            // 0: not tried yet, 1: in use, -1: unavailable
   int v2_plain_rounds = 0;
+  long v2_next_full = 0;             // first chain (sequence number) that is expected to need a batch compare again
+  bool v2_lite_on = true;
   void v2_drop_graph() {
-    if (v2_graph) { (void)hipGraphExecDestroy(v2_graph); v2_graph = nullptr; }
+    for (auto &g : v2_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     if (v2_graph_state == 1) v2_graph_state = 0;
   }
   bool v2_try_graph() {
-    static const bool off = [] { const char *e = getenv("DADA2HIP_V2_GRAPH"); return e && atoi(e) == 0; }();
-    if (off || profile_all || v2_graph_state < 0) return false;
+    if (graph_off() || profile_all || v2_graph_state < 0) return false;
     if (v2_graph_state == 1) return true;
     if (v2_plain_rounds < 1) return false;   // the first round goes out plainly (one-time function attributes are set by its launches)
     hipStream_t stq = s->stream;
-    hipGraph_t g = nullptr;
-    if (hipStreamBeginCapture(stq, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); v2_graph_state = -1; return false; }
-    v2_round_launches(v2_chain, true, true, nullptr);
-    if (hipStreamEndCapture(stq, &g) != hipSuccess || !g) { (void)hipGetLastError(); v2_graph_state = -1; return false; }
-    const hipError_t e = hipGraphInstantiate(&v2_graph, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { (void)hipGetLastError(); v2_graph = nullptr; v2_graph_state = -1; return false; }
+    for (int lite = 0; lite < 2; lite++) {
+      hipGraph_t g = nullptr;
+      if (hipStreamBeginCapture(stq, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); v2_drop_graph(); v2_graph_state = -1; return false; }
+      v2_round_launches(v2_chain, true, true, nullptr, lite != 0);
+      if (hipStreamEndCapture(stq, &g) != hipSuccess || !g) { (void)hipGetLastError(); v2_drop_graph(); v2_graph_state = -1; return false; }
+      const hipError_t e = hipGraphInstantiate(&v2_graph[lite], g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e != hipSuccess) { (void)hipGetLastError(); v2_graph[lite] = nullptr; v2_drop_graph(); v2_graph_state = -1; return false; }
+    }
     v2_graph_state = 1;
     return true;
   }
+  static bool graph_off() { const char *e = getenv("DADA2HIP_V2_GRAPH"); return e && atoi(e) == 0; }
   void v2_enqueue_chain(int nlev, bool with_compare, bool store) {
     const auto t_enq = clk::now();
     EnqRec rec{-1, -1, with_compare};
-    if (nlev == v2_chain && with_compare && store && v2_try_graph()) D2_HIP(hipGraphLaunch(v2_graph, s->stream));
+    // a round that is expected to find its centre cached goes out without the batch compare's launches (engine.h, Eng2::has_compare)
+    const bool lite = with_compare && v2_lite_on && v2_plain_rounds >= 1 && v2_enq + 1 < v2_next_full;
+    if (nlev == v2_chain && with_compare && store && v2_try_graph()) D2_HIP(hipGraphLaunch(v2_graph[lite ? 1 : 0], s->stream));
     else {
-      v2_round_launches(nlev, with_compare, store, &rec);
+      v2_round_launches(nlev, with_compare, store, &rec, lite);
       if (with_compare) v2_plain_rounds++;
     }
+    if (lite) st.lite_chains++;
     v2_enqrec.push_back(rec);
     v2_enq++;
     st.ms_enqueue += ms_since(t_enq);
   }
-  void v2_round_launches(int nlev, bool with_compare, bool store, EnqRec *recp) {
+  void v2_round_launches(int nlev, bool with_compare, bool store, EnqRec *recp, bool lite = false) {
     hipStream_t stq = s->stream;
     EnqRec rec{-1, -1, with_compare};
-    if (with_compare) {
+    const Eng2 &E2 = lite ? this->E2L : this->E2;       // (chains without the compare say so to their kernels)
+    if (with_compare && !lite) {
       // the round's comparisons: a batch screen if its centre is not cached (no-op otherwise), the work lists of the centre
       // with the greedy skip as of now, the aligner on them (centre read from the control block)
       rec.ev_screen = ev_begin(EV_SCREEN, profile_all, /*spec=*/true);
@@ -1385,14 +1399,14 @@ struct Run {
       ev_end(rec.ev_screen);
       // ... its survivors through the aligner, all batch positions in one launch (both no-ops on a cache hit) ...
       launch2_batch_lists(E2, stq);
-      rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
       const NwBatch nb{&v2_ctl.p->nbatch, v2_blistn.p, v2_blist.p, v2_ctl.p->bcentre, &v2_ctl.p->bbuf, E2.C.Npad};
+      launch_gapless_batch(s->D, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &v2_ctl.p->state, stq);
+      rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
       launch_nw_ad(s->D, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, stq,
                    &v2_ctl.p->state, &nb);
       ev_end(rec.ev_nw);
-      // ... and the round's own classes: the cached ones with the greedy skip as of now
-      launch2_lists(E2, stq);
     }
+    if (with_compare) launch2_lists(E2, stq);             // the round's own classes: the cached ones with the greedy skip as of now
     int ev = ev_begin(EV_SHUFFLE, profile_all && nlev > 0);
     for (int l = 0; l < nlev; l++) launch2_shuffle(E2, l, store && l == 0, stq);
     ev_end(ev);
@@ -1519,6 +1533,7 @@ struct Run {
         if (rec.ev_screen >= 0) evs[rec.ev_screen].ok = 1;
         if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
         st.nnw_run += (uint64_t)b.pad0[1]; st.ngapless_run += (uint64_t)b.pad0[2];
+        v2_next_full = seq + b.nbatch;                         // the batch holds the centres of this round and, if the guesses hold, the next nbatch - 1
       }
       if (b.nlev > 0 && b.halt != H2_SHUFFLE_MORE) { }        // (a round's commit is complete)
       switch (b.halt) {
@@ -1551,9 +1566,18 @@ struct Run {
           if (bb.newi + 2 > ccap) v2_grow(b);
           logf("\nNew Cluster C%i:", bb.newi);
           launch2_host_birth(E2, bb.c.raw, bb.c.from, s->stream);
+          v2_next_full = 0;                                    // (whether the new centre is cached is not known here: send a full chain)
           nclust_dev = bb.newi + 1;
           record_birth(bb);
           st.ncompare += (uint64_t)N;
+          break;
+        }
+        case H2_NEED_COMPARE: {                                // a chain without the compare met a centre that is not cached
+          v2_enq = v2_cons;
+          v2_enqrec.resize((size_t)v2_cons);
+          v2_next_full = 0;
+          st.lite_misses++;
+          launch2_resume(E2, s->stream, /*keep_list=*/true);
           break;
         }
         case H2_SHUFFLE_MORE: {                                // more than SH_CHAIN moving shuffles: continue the same round
@@ -1568,10 +1592,10 @@ struct Run {
       if (b.halt == H2_NONE) t_decide += ms_since(t_dec); else t_halt += ms_since(t_dec);
     }
     if (getenv("DADA2HIP_V2_SUMMARY"))
-      fprintf(stderr, "[v2] blocks %ld  halts none/nobirth/host/more/cap/max %ld %ld %ld %ld %ld %ld  big-mover blocks %ld  ms: wait %.1f replay %.1f "
+      fprintf(stderr, "[v2] blocks %ld  halts none/nobirth/host/more/cap/max/need-compare %ld %ld %ld %ld %ld %ld %ld  chains without compare %llu  big-mover blocks %ld  ms: wait %.1f replay %.1f "
                       "enqueue %.1f decide %.1f halt-handling %.1f top-up %.1f total %.1f  moves %llu misses %llu  host decisions other/zero-ties in partition 0 at "
                       "their first slots/... moved/elsewhere, one in the lowest partition/... several %ld %ld %ld %ld %ld\n", v2_cons, n_halt[0], n_halt[1],
-              n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_big, st.ms_wait_device, st.ms_replay, st.ms_enqueue, t_decide, t_halt, t_top,
+              n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_halt[6], (unsigned long long)st.lite_chains, n_big, st.ms_wait_device, st.ms_replay, st.ms_enqueue, t_decide, t_halt, t_top,
               ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches, n_kind[0], n_kind[1], n_kind[2], n_kind[3], n_kind[4]);
     sync_spin(s->stream);                                      // no-op launches queued behind the final halt
     if (v2_trace_seq >= 0 && v2_trace.p) {                     // dump the traced round's stamps (tools/trace_round.py reads them)

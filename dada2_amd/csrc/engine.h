@@ -207,6 +207,8 @@ struct NwBatch {
   const int32_t *bbuf;      // batch buffer: results go to row (*bbuf * KB_MAX + k) of d_lambda / d_ham, rows of `stride` entries
   size_t stride;
 };
+void launch_gapless_batch(const SampleDev &S, const NwBatch &b, const AlignParams &ap, const double *d_err, double *d_lambda,
+                          uint32_t *d_ham, const int32_t *d_stop_dev, hipStream_t st);
 // d_gl_work/d_gl_nwork (optional): the round's gapless comparisons, processed by the same kernel
 // d_view (optional): aligned views, row = unique (or chunk when view_by_chunk); chunks are nw_ad_apw() work slots
 void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
@@ -274,7 +276,7 @@ struct Store2 {
   int32_t blk_cap = 0;
 };
 
-enum : int32_t { H2_NONE = 0, H2_NO_BIRTH, H2_HOST_DECIDE, H2_SHUFFLE_MORE, H2_CAPACITY, H2_MAXCLUST };
+enum : int32_t { H2_NONE = 0, H2_NO_BIRTH, H2_HOST_DECIDE, H2_SHUFFLE_MORE, H2_CAPACITY, H2_MAXCLUST, H2_NEED_COMPARE };
 
 struct Ctl2 {
   int32_t state;        // 0 = running, 1 = halted (every launch returns at once)
@@ -289,6 +291,7 @@ struct Ctl2 {
   int32_t nsh_base;     // shuffles of the round in flight executed by earlier chains
   int32_t max_clust;
   int32_t scan_hint;    // (reserved)
+  int32_t need_compare; // the coming round's centre is not cached: its chain must carry the batch compare (Eng2::has_compare)
   int32_t n0, low0;     // members of partition 0 now / a lower bound of the fewest it has ever had (tie rule of k2_birth)
   int32_t bcentre[KB_MAX];
   uint32_t breads[KB_MAX];
@@ -370,6 +373,12 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   // tail kernels stamps the shader clock at its phase boundaries into trace[(kernel * TRACE_BLOCKS + block) * 8 + phase]
   unsigned long long *trace;
   int32_t trace_seq;
+  // A chain comes in two forms: with the four launches of a batch compare in front (screen, work lists, gapless pairs,
+  // aligner) or without.  Seven rounds in eight find their centre cached, and each of those launches costs 4.6 us even when
+  // it has nothing to do, so the host leaves them out of the chains it expects to be cache hits (it knows how many centres the
+  // last batch held).  When it guessed wrong - the prediction of the coming centres failed early - the chain's kernels see
+  // need_compare without has_compare, do nothing, and k2_birth reports H2_NEED_COMPARE: the host sends a full chain.
+  int32_t has_compare;
   int32_t sh_filter;                                // later shuffle calls of a chain visit only the uniques the previous call can have unsettled
   int32_t grid_shuffle, grid_pupdate;               // host side: block caps of the per-round launches (tuning knobs)
 };
@@ -383,7 +392,7 @@ void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
 // b_p_update + b_bud arg-min (grid) ; ties, decision, birth, plan of the coming round, publication (one block)
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st);            // the host's decision applied + plan; resumes
-void launch2_resume(const Eng2 &E, hipStream_t st);
+void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list = false);   // keep_list: the candidates k2_pupdate listed stay valid
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st);
 

@@ -361,6 +361,59 @@ void launch_gapless(const SampleDev &S, int centre, const int32_t *d_chunk_centr
                      d_chunk_centre, d_work, d_nwork, nwork_host, ap, d_err, d_lambda, d_ham, d_view, LV, view_by_chunk);
 }
 
+// The gapless pairs of a batch compare (round engine v2, NwBatch): rows KB_MAX .. 2 KB_MAX - 1 of the batch lists, one thread per
+// pair as above, a wave works on one batch position (its centre is wave-uniform).  They used to ride along in the aligner's
+// launch, three to a wave; 64 to a wave they take a tenth of that time.
+__global__ __launch_bounds__(256) void k_gapless_batch(SampleDev S, NwBatch b, AlignParams ap, const double *__restrict__ err,
+                                                       double *__restrict__ lam, uint32_t *__restrict__ ham, const int32_t *__restrict__ stop_dev) {
+  if (stop_dev && *stop_dev != 0) return;
+  const int nb = *b.on;
+  if (nb <= 0) return;
+  int wk[KB_MAX + 1];                                        // first 64-pair slice of every batch position
+  wk[0] = 0;
+#pragma unroll
+  for (int k = 0; k < KB_MAX; k++) wk[k + 1] = wk[k] + (k < nb ? (b.n[KB_MAX + k] + 63) / 64 : 0);
+  if ((int)blockIdx.x * 4 >= wk[KB_MAX]) return;
+  extern __shared__ double s_err[];
+  for (int i = threadIdx.x; i < 16 * ap.ncol; i += blockDim.x) s_err[i] = err[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  for (int w = gwave; w < wk[KB_MAX]; w += nwaves) {
+    int k = 0, w0 = 0;
+#pragma unroll
+    for (int q = 1; q < KB_MAX; q++) if (w >= wk[q]) { k = q; w0 = wk[q]; }
+    const int idx = (w - w0) * 64 + lane;
+    if (idx >= b.n[KB_MAX + k]) continue;
+    const int r = b.list[(size_t)(KB_MAX + k) * b.stride + idx], c = b.centre[k];
+    const uint32_t *crow = S.seq2 + (size_t)c * S.W2, *rrow = S.seq2 + (size_t)r * S.W2;
+    const uint8_t *qrow = S.qual + (size_t)r * S.LQ;
+    const int L1 = S.len[c], L2 = S.len[r];
+    double l = 1.0;
+    uint32_t h = 0, cw = 0, rw = 0, qw = 0;
+    for (int p = 0; p < L2; p++) {                           // nwalign_gapless + compute_lambda_ts, exactly as k_gapless
+      if ((p & 15) == 0) { rw = rrow[p >> 4]; cw = p < L1 ? crow[p >> 4] : 0; }
+      if ((p & 3) == 0) qw = *(const uint32_t *)(qrow + p);
+      const uint32_t rb = (rw >> ((p & 15) << 1)) & 3u, q = ap.use_quals ? ((qw >> ((p & 3) << 3)) & 255u) : 0u;
+      uint32_t t = 5u * rb;
+      if (p < L1) {
+        const uint32_t cb = (cw >> ((p & 15) << 1)) & 3u;
+        t = 4u * cb + rb;
+        h += (cb != rb);
+      }
+      l = l * s_err[t * ap.ncol + q];
+    }
+    const size_t o = ((size_t)*b.bbuf * KB_MAX + k) * b.stride + r;
+    lam[o] = l;
+    ham[o] = h;
+  }
+}
+void launch_gapless_batch(const SampleDev &S, const NwBatch &b, const AlignParams &ap, const double *d_err, double *d_lambda,
+                          uint32_t *d_ham, const int32_t *d_stop_dev, hipStream_t st) {
+  const int grid = std::min((S.N + 255) / 256 + KB_MAX, 2048);
+  hipLaunchKernelGGL(k_gapless_batch, dim3(grid), dim3(256), (size_t)16 * ap.ncol * sizeof(double), st, S, b, ap, d_err, d_lambda, d_ham,
+                     d_stop_dev);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Banded ends-free Needleman-Wunsch, ONE ALIGNMENT PER LANE (64 per wave, the centre is
 // wave-uniform).  Band coordinates: cell (i, j) lives at k = j - i + lband, so in row i
@@ -395,8 +448,8 @@ struct NwArgs {
   int32_t *nmoves;
   const int32_t *stop_dev;     // round engine v2: non-zero = the device has halted, nothing to do
   // round engine v2, batch mode (k_nw_ad only): the alignments of a whole batch compare - up to KB_MAX centres - in ONE launch.
-  // List k (k < KB_MAX) holds the uniques to align with batch centre k, list KB_MAX + k its gapless ones; blocks work on
-  // one centre at a time (it is staged once per block), results go to row (bbuf * KB_MAX + k) of lam / ham.
+  // List k (k < KB_MAX) holds the uniques to align with batch centre k (list KB_MAX + k its gapless ones: k_gapless_batch);
+  // blocks work on one centre at a time (it is staged once per block), results go to row (bbuf * KB_MAX + k) of lam / ham.
   const int32_t *batch_on;     // number of centres of the batch compare in flight (0: nothing to do), or nullptr: not batch mode
   const int32_t *batch_n;      // [2 KB_MAX] list lengths
   const int32_t *batch_list;   // [2 KB_MAX][batch_stride]
@@ -844,7 +897,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       const int nb = *a.batch_on;
       if (nb <= 0) return;
 #pragma unroll
-      for (int k = 0; k < KB_MAX; k++) bk[k + 1] = bk[k] + (k < nb ? (a.batch_n[k] + a.batch_n[KB_MAX + k] + 4 * APW - 1) / (4 * APW) : 0);
+      for (int k = 0; k < KB_MAX; k++) bk[k + 1] = bk[k] + (k < nb ? (a.batch_n[k] + 4 * APW - 1) / (4 * APW) : 0);   // (the gapless rows: k_gapless_batch)
       if ((int)blockIdx.x >= bk[KB_MAX]) return;
     } else {
       const int n_all = (a.nwork_dev ? *a.nwork_dev : a.nwork_host) + (gl_work ? *gl_nwork_dev : 0);
@@ -906,7 +959,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         __syncthreads();
         kcur = k;
         wl = a.batch_list + (size_t)k * a.batch_stride; gll = a.batch_list + (size_t)(KB_MAX + k) * a.batch_stride;
-        n_nw = a.batch_n[k]; nwork = n_nw + a.batch_n[KB_MAX + k];
+        n_nw = a.batch_n[k]; nwork = n_nw;
         out_off = ((size_t)*a.batch_bbuf * KB_MAX + k) * a.batch_stride;
       }
       chunk = (it - b0) * 4 + wib;

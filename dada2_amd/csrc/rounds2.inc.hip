@@ -69,10 +69,15 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
 // k2_lists - greedy skip already applied with the lock state of the commit - lambda / hamming from the aligner).
 // Most uniques of a large sample never get a second stored comparison: for them the arg-max is partition 0 whatever the
 // reads are, and the pass touches 8 bytes of their state.
+// halted, or a chain without the batch compare its round needs (Eng2::has_compare): nothing to do
+static __device__ __forceinline__ bool v2_idle(const Eng2 &E) {
+  const Ctl2 *ctl = E.ctl;
+  return ctl->state != 0 || (!E.has_compare && ctl->need_compare != 0);
+}
 template <bool STORE>
 __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E, int level) {
   const Ctl2 *ctl = E.ctl;
-  if (ctl->state != 0) return;
+  if (v2_idle(E)) return;
   const int ring = ctl->pub_seq % RING2;
   Round2Out *out = E.dblk + ring;
   if (ctl->nsh_base + level >= E.max_shuffle) return;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
 constexpr int LISTS_PER_THREAD = 8;
 __global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
   const Ctl2 *ctl = E.ctl;
-  if (ctl->state != 0) return;
+  if (v2_idle(E)) return;
   __shared__ unsigned int s_stat[4];
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -439,7 +444,7 @@ constexpr int PUPD_TAB = 1024;    // partitions whose per-partition facts k2_pup
 constexpr int SIG_CAP = 1024;
 __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init, BudKey *__restrict__ partial) {
   const Ctl2 *ctl = E.ctl;
-  if (ctl->state != 0) return;
+  if (v2_idle(E)) return;
   Round2Out *out = E.dblk + (ctl->pub_seq % RING2);
   const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
   if (!cs.eval_ok) return;
@@ -596,7 +601,7 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
   for (int q = tid; q < nslots; q += blockDim.x) if (C.slot_centre[q] == raw) *s_hit = q;   // (at most one slot holds it)
   __syncthreads();
   if (*s_hit >= 0) {
-    if (tid == 0) { ctl->slot = *s_hit; ctl->nbatch = 0; }
+    if (tid == 0) { ctl->slot = *s_hit; ctl->nbatch = 0; ctl->need_compare = 0; }
     return;
   }
   if (tid == 0) {
@@ -688,7 +693,7 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
       C.slot_centre[ctl->bbuf * KB_MAX + k] = c;
     } else { ctl->bcentre[k] = -1; ctl->breads[k] = 0; ctl->blen[k] = 0; }
   }
-  if (tid == 0) ctl->nbatch = nb;
+  if (tid == 0) { ctl->nbatch = nb; ctl->need_compare = 1; }
 }
 
 static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
@@ -728,7 +733,25 @@ static __device__ void clear_block(Round2Out *nx) {
 
 __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, const BudKey *__restrict__ partial, int nblocks) {
   Ctl2 *ctl = E.ctl;
-  if (ctl->state != 0) return;
+  const bool halted = ctl->state != 0, starved = !E.has_compare && ctl->need_compare != 0;
+  __syncthreads();                                                       // every thread has read both before thread 0 changes either
+  if (halted) return;
+  if (starved) {
+    // the chain came without the batch compare its round needs: nothing has run, say so and halt (the block was cleared by
+    // the previous chain's k2_birth)
+    const int ring0 = ctl->pub_seq % RING2;
+    Round2Out *o = E.dblk + ring0;
+    if (threadIdx.x == 0) {
+      o->halt = H2_NEED_COMPARE; o->nclust = ctl->nclust; o->birth_applied = 0; o->nlev = 0; o->nsh = 0; o->nbatch = 0; o->slot = ctl->slot;
+      o->err_flag = *E.P.err_flag | (*E.S.nw_flag ? 4 : 0); o->blk_count = *E.T.blk_count;
+      ctl->state = 1; ctl->halt = H2_NEED_COMPARE;
+    }
+    __syncthreads();
+    clear_block(E.dblk + ((ring0 + 1) % RING2));
+    publish_block(E, o, ring0);
+    return;
+  }
+  if (threadIdx.x == 0) ctl->need_compare = 0;                           // the round's compare, if it needed one, has run
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
   __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
   __shared__ int s_halt, s_raw, s_from, s_evalok, s_nt[2], s_nnear;
@@ -908,7 +931,7 @@ __global__ __launch_bounds__(1024) void k2_host_birth(Eng2 E, int raw, int from)
   __syncthreads();
   if (threadIdx.x == 0) *E.sig_n = 0;
 }
-__global__ void k2_resume(Eng2 E) { E.ctl->state = 0; E.ctl->halt = H2_NONE; *E.sig_n = 0; }
+__global__ void k2_resume(Eng2 E, int keep_list) { E.ctl->state = 0; E.ctl->halt = H2_NONE; if (!keep_list) *E.sig_n = 0; }
 
 // ---- k-mer screen against the batch's centres ---------------------------------------------------------------------------
 // 16 lanes per unique as in k_screen, but one pass over the unique's k-mer record serves up to KB_MAX centres: the centre
@@ -1123,7 +1146,7 @@ void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st) 
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st) {
   hipLaunchKernelGGL(k2_host_birth, dim3(1), dim3(1024), 0, st, E, raw, from);
 }
-void launch2_resume(const Eng2 &E, hipStream_t st) { hipLaunchKernelGGL(k2_resume, dim3(1), dim3(1), 0, st, E); }
+void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list) { hipLaunchKernelGGL(k2_resume, dim3(1), dim3(1), 0, st, E, keep_list ? 1 : 0); }
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st) {
   hipLaunchKernelGGL(k2_posthoc, dim3((E.S.N + 255) / 256), dim3(256), 0, st, E, d_cluster_of_centre, d_out_ji, d_out_lam, d_nout, cap);

@@ -94,6 +94,9 @@ typedef struct dada2hip_stats {
    * coming centres - in one launch, as of the screen: a pair the greedy rule skips when its round commits, or whose batch
    * position is never used, is aligned in vain; nnw / ngapless above stay the reference's counts) */
   uint64_t nnw_run, ngapless_run;
+  /* rounds enqueued without the launches of a batch compare because their centre was expected to be cached, and how many
+   * of those guesses were wrong (the device then halts and the host sends the full chain) */
+  uint64_t lite_chains, lite_misses;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------

@@ -15,6 +15,9 @@
 #include <cstdio>
 #include <csignal>
 #include <execinfo.h>
+#include <dlfcn.h>
+#include <ucontext.h>
+#include <cstring>
 #include <unistd.h>
 #include <mutex>
 #include <sys/mman.h>
@@ -26,11 +29,32 @@ Cur cur;
 
 // a crash inside an emulated kernel: print the native frames before dying (fibers run on their own stacks, so the handler
 // gets an alternate one)
-static void on_segv(int sig) {
+static void put_hex(const char *label, unsigned long v) {
+  char buf[64];
+  int n = 0;
+  while (label[n]) { buf[n] = label[n]; n++; }
+  for (int k = 60; k >= 0; k -= 4) buf[n++] = "0123456789abcdef"[(v >> k) & 15];
+  buf[n++] = '\n';
+  (void)!write(2, buf, n);
+}
+static void on_segv(int sig, siginfo_t *si, void *uc) {
+  const char msg[] = "[emu] fatal signal inside the emulated library\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  // first what needs no unwinding (a fault inside a kernel runs on a fiber stack the unwinder may not get through):
+  // the address touched, the program counter, and where this library is loaded (pc - base goes to addr2line)
+  put_hex("[emu]   address 0x", (unsigned long)si->si_addr);
+  const unsigned long pc = (unsigned long)((ucontext_t *)uc)->uc_mcontext.gregs[REG_RIP];
+  put_hex("[emu]   pc      0x", pc);
+  Dl_info info;
+  if (dladdr((void *)pc, &info) && info.dli_fbase) {
+    put_hex("[emu]   pc - library base 0x", pc - (unsigned long)info.dli_fbase);
+    if (info.dli_sname) { (void)!write(2, "[emu]   in ", 11); (void)!write(2, info.dli_sname, strlen(info.dli_sname)); (void)!write(2, "\n", 1); }
+  }
+  put_hex("[emu]   block.x 0x", cur.bid.x);
+  put_hex("[emu]   thread.x 0x", cur.tid.x);
+  alarm(5);                                    // (should the unwinder loop on a fiber stack)
   void *frames[48];
   const int n = backtrace(frames, 48);
-  const char msg[] = "[emu] fatal signal inside the emulated library; native backtrace:\n";
-  (void)!write(2, msg, sizeof msg - 1);
   backtrace_symbols_fd(frames, n, 2);
   signal(sig, SIG_DFL);
   raise(sig);
@@ -41,12 +65,37 @@ static const int segv_installed = [] {
   ss.ss_sp = alt; ss.ss_size = sizeof alt;
   sigaltstack(&ss, nullptr);
   struct sigaction sa{};
-  sa.sa_handler = on_segv;
-  sa.sa_flags = SA_ONSTACK;
+  sa.sa_sigaction = on_segv;
+  sa.sa_flags = SA_ONSTACK | SA_SIGINFO;
   sigaction(SIGSEGV, &sa, nullptr);
   sigaction(SIGBUS, &sa, nullptr);
   return 1;
 }();
+
+// guarded allocations (EMU_GUARD=1): [pages ... | buffer, 16-byte aligned end at the page boundary][PROT_NONE page]
+static std::mutex guard_mu;
+static std::vector<std::pair<void *, std::pair<void *, size_t>>> guard_live;   // user pointer -> (mapping, length)
+void *guard_alloc(size_t n) {
+  const size_t page = 4096, body = (n + 15) & ~(size_t)15, len = ((body + page - 1) & ~(page - 1)) + page;
+  char *m = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (m == (char *)MAP_FAILED) return nullptr;
+  mprotect(m + len - page, page, PROT_NONE);
+  void *user = m + len - page - body;
+  std::lock_guard<std::mutex> g(guard_mu);
+  guard_live.push_back({user, {m, len}});
+  return user;
+}
+bool guard_free(void *p) {
+  std::lock_guard<std::mutex> g(guard_mu);
+  for (size_t i = 0; i < guard_live.size(); i++)
+    if (guard_live[i].first == p) {
+      munmap(guard_live[i].second.first, guard_live[i].second.second);
+      guard_live[i] = guard_live.back();
+      guard_live.pop_back();
+      return true;
+    }
+  return false;
+}
 
 namespace {
 

@@ -146,9 +146,16 @@ inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInv
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = *tot = (size_t)16 << 30; return hipSuccess; }
 inline hipError_t hipDeviceTotalMem(size_t *tot, int) { *tot = (size_t)16 << 30; return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// EMU_GUARD=1: every "device" allocation ends at an inaccessible page, so the first store past a buffer faults where it
+// happens (the fatal-signal handler of emu.cpp prints the frame) instead of corrupting the host heap
+namespace emu { void *guard_alloc(size_t n); bool guard_free(void *p); }
+inline hipError_t hipMalloc(void **p, size_t n) {
+  static const bool guard = getenv("EMU_GUARD") != nullptr;
+  *p = guard ? emu::guard_alloc(n) : std::aligned_alloc(256, (n + 255) & ~(size_t)255);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
-inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipFree(void *p) { if (!emu::guard_free(p)) std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
