@@ -305,7 +305,7 @@ struct Cache2 {
   int32_t NBUF = 0;               // batch buffers
   uint16_t *bcls = nullptr;       // [NBUF][Npad]  2 bits per batch position: CLS_* as of the compare
   int32_t *slot_centre = nullptr; // [NBUF * KB_MAX]  unique index or -1
-  uint2 *tab8 = nullptr;          // [1024]  byte k = min(count of the 5-mer in batch centre k, 63)
+  uint2 *tab8 = nullptr;          // [1024]  byte k = min(count of the 5-mer in batch centre k, 63) + 0x7F
   uint16_t *full = nullptr;       // [KB_MAX][1024] full counts (heavy k-mer correction)
   uint16_t *ord = nullptr;        // [KB_MAX][LK] ordered 5-mers, 0xFFFF past the end
   // lambda / hamming of the batch's alignments, row = cache slot (batch buffer * KB_MAX + position): written by the ONE

@@ -32,6 +32,9 @@ static __device__ __forceinline__ int gcn_sad_u8(uint32_t a, uint32_t b, int acc
 static __device__ __forceinline__ uint32_t gcn_push_low2(uint32_t acc, uint32_t x) {
   return __builtin_amdgcn_alignbit(x, acc, 2);
 }
+// the low byte of x in all four bytes, one full-rate instruction (v_perm_b32 with selector 0; x * 0x01010101 would be a
+// quarter-rate v_mul_lo_u32)
+static __device__ __forceinline__ uint32_t gcn_bcast_byte0(uint32_t x) { return __builtin_amdgcn_perm(x, x, 0u); }
 // DPP wave shifts by one lane: lane L reads `src` of lane L-1 (shr) / L+1 (shl); a lane without a source keeps `old`
 // (bound_ctrl = false) or reads 0 (bound_ctrl = true)
 template <bool BOUND_CTRL>

@@ -660,7 +660,8 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
   }
   __syncthreads();
   const int nb = *s_nb;
-  // ---- k-mer tables of the batch: byte k of tab8[id] = min(count of 5-mer id in centre k, 63) ----
+  // ---- k-mer tables of the batch: byte k of tab8[id] = min(count of 5-mer id in centre k, 63) + 0x7F (the screen's compare
+  //      then is one subtraction: bit 7 of byte - rank is set exactly when rank < count) ----
   for (int k = tid; k < KB_MAX * NKMER; k += blockDim.x) s_cnt[k] = 0;
   __syncthreads();
   for (int k = 0; k < nb; k++) {
@@ -679,7 +680,7 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
     uint32_t lo = 0, hi = 0;
     for (int k = 0; k < KB_MAX; k++) {
       const uint32_t c = k < nb ? s_cnt[k * NKMER + id] : 0u;
-      const uint32_t sat = c < RANK_SAT ? c : RANK_SAT;
+      const uint32_t sat = (c < RANK_SAT ? c : RANK_SAT) + 0x7Fu;
       if (k < 4) lo |= sat << (8 * k); else hi |= sat << (8 * (k - 4));
       C.full[(size_t)k * NKMER + id] = (uint16_t)c;
     }
@@ -935,7 +936,7 @@ __global__ void k2_resume(Eng2 E, int keep_list) { E.ctl->state = 0; E.ctl->halt
 
 // ---- k-mer screen against the batch's centres ---------------------------------------------------------------------------
 // 16 lanes per unique as in k_screen, but one pass over the unique's k-mer record serves up to KB_MAX centres: the centre
-// tables are interleaved (byte k of tab8[id] = min(count_k[id], 63)), so one 8-byte LDS read + two SWAR compares give
+// tables are interleaved (byte k of tab8[id] = min(count_k[id], 63) + 0x7F), so one 8-byte LDS read + two SWAR subtractions give
 // "rank < count" for all centres.  A wave owns 16 consecutive uniques per macro-iteration (lane group g takes uniques
 // 4g..4g+3 in turn): the four rows and their scalars are requested together before any of them is used, and the class
 // words of the 16 uniques (2 bits per centre) leave as one 32-byte store.  Only classes are produced: the aligner runs
@@ -1004,10 +1005,10 @@ __global__ __launch_bounds__(256, 4) void k2_screen_multi(Eng2 E) {
           for (int hlf = 0; hlf < 2; hlf++) {
             const uint32_t x = hlf ? (w[e] >> 16) : (w[e] & 0xFFFFu);
             const uint2 t = tab[x & 1023u];
-            const uint32_t rk = x >> 10;                               // rank 0..63; want rank < count  <=>  (count | 0x80) - rank - 1 >= 0x80
-            const uint32_t rr = (rk | (rk << 8) | (rk << 16) | (rk << 24)) + 0x01010101u;
-            ax += (((t.x | 0x80808080u) - rr) >> 7) & 0x01010101u;    // byte k: rank < min(count_k, 63)
-            ay += (((t.y | 0x80808080u) - rr) >> 7) & 0x01010101u;
+            const uint32_t rk = x >> 10;                               // rank 0..63; want rank < count  <=>  count + 0x7F - rank >= 0x80
+            const uint32_t rr = gcn_bcast_byte0(rk);                   // (bytes stay within 0x40 .. 0xBE: no borrow between them)
+            ax += ((t.x - rr) >> 7) & 0x01010101u;                     // byte k: rank < min(count_k, 63)
+            ay += ((t.y - rr) >> 7) & 0x01010101u;
           }
         }
         w0 += ax & 0x00FF00FFu; w1 += (ax >> 8) & 0x00FF00FFu;

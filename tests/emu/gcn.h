@@ -17,6 +17,7 @@ static inline int gcn_sad_u8(uint32_t a, uint32_t b, int acc) {
   }
   return (int)s;
 }
+static inline uint32_t gcn_bcast_byte0(uint32_t x) { return (x & 0xFFu) * 0x01010101u; }
 static inline uint32_t gcn_push_low2(uint32_t acc, uint32_t x) { return (acc >> 2) | (x << 30); }
 template <bool BOUND_CTRL> static inline int gcn_wave_shr1(int old, int src) {
   return (int)(uint32_t)emu::wave_op(emu::OP_DPP_SHR1, 64, (uint32_t)src, 0, (uint32_t)old, BOUND_CTRL, false);
