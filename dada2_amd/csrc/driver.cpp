@@ -1235,7 +1235,7 @@ struct Run {
   bool v2_debug = false;
   long v2_enq = 0, v2_cons = 0;
   uint64_t v2_miss_launches = 0;
-  struct EnqRec { int ev_screen, ev_nw; bool compare; bool guessed = false; };   // guessed: sent as the chain that refills the cache
+  struct EnqRec { int ev_screen, ev_nw; bool compare; };
   std::vector<EnqRec> v2_enqrec;      // per enqueued block (index = sequence number - 1)
 
   bool want_v2() const {
@@ -1382,10 +1382,8 @@ struct Run {
       v2_round_launches(nlev, with_compare, store, &rec, lite);
       if (with_compare) v2_plain_rounds++;
     }
-    if (lite) st.lite_chains++;
-    // a full chain sent because the cache was expected to run dry: its batch will hold KB_MAX centres if the guesses hold, so
-    // the chains behind it go out without a compare already (its result block, one chain later, corrects the estimate)
-    else if (with_compare && v2_lite_on && v2_next_full > 0 && v2_enq + 1 >= v2_next_full) { v2_next_full = v2_enq + 1 + KB_MAX; rec.guessed = true; }
+    if (lite) st.lite_chains++;   // (sending the chains behind an expected refill without a compare as well was tried: as many
+                                  //  more wrong guesses as it saved launches, profiles/README.md r03u)
     v2_enqrec.push_back(rec);
     v2_enq++;
     st.ms_enqueue += ms_since(t_enq);
@@ -1537,7 +1535,7 @@ struct Run {
         if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
         st.nnw_run += (uint64_t)b.pad0[1]; st.ngapless_run += (uint64_t)b.pad0[2];
         v2_next_full = seq + b.nbatch;                         // the batch holds the centres of this round and, if the guesses hold, the next nbatch - 1
-      } else if (rec.guessed) v2_next_full = 0;               // (it found its centre cached after all: full chains until the miss shows)
+      }
       if (b.nlev > 0 && b.halt != H2_SHUFFLE_MORE) { }        // (a round's commit is complete)
       switch (b.halt) {
         case H2_NONE: {                                        // birth applied on the device: book it
