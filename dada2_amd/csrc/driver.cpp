@@ -1407,7 +1407,6 @@ struct Run {
                    &v2_ctl.p->state, &nb);
       ev_end(rec.ev_nw);
     }
-    if (with_compare) launch2_lists(E2, stq);             // the round's own classes: the cached ones with the greedy skip as of now
     int ev = ev_begin(EV_SHUFFLE, profile_all && nlev > 0);
     for (int l = 0; l < nlev; l++) launch2_shuffle(E2, l, store && l == 0, stq);
     ev_end(ev);

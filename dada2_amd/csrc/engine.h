@@ -387,7 +387,6 @@ void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, c
                     hipStream_t st);
 void launch2_screen_multi(const Eng2 &E, hipStream_t st);
 void launch2_batch_lists(const Eng2 &E, hipStream_t st);                              // classes of a batch screen -> the aligner's work lists
-void launch2_lists(const Eng2 &E, hipStream_t st);                                    // cached classes + commit-time greedy skip -> the round's classes
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
 // b_p_update + b_bud arg-min (grid) ; ties, decision, birth, plan of the coming round, publication (one block)
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);

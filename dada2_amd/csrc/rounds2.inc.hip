@@ -2,7 +2,9 @@
 //   k2_screen_multi   kmer_dist_SSEi_8 / kord_dist_SSEi + raw_align's dispatch against up to KB_MAX centres per pass
 //                     (kmers.cpp:29-150, nwalign_endsfree.cpp:10-73)
 //   k2_store0         store filter of round 0 (cluster.cpp:179-201, every unique is kept: E_minmax starts at -999)
-//   k2_shuffle        store filter of a later round at commit time + b_shuffle2 (cluster.cpp:179-266)
+//   k2_batch_lists    the aligner's work lists of a batch compare (NwBatch)
+//   k2_shuffle        commit of a later round's cached comparisons (greedy skip of cluster.cpp:127-130 as of now, store filter
+//                     :179-201) + b_shuffle2 (:210-266)
 //   k2_pupdate/_ties  b_p_update + b_bud's arg-min (pval.cpp:14-40, cluster.cpp:274-310)
 //   k2_birth          the unambiguous birth (cluster.cpp:313-347), the plan of the coming round's compare, publication
 // Every launch reads what it has to do from the device control block (Ctl2): the host enqueues rounds ahead of the
@@ -65,8 +67,9 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
 }
 
 // ---- store filter of a round + b_shuffle2 ------------------------------------------------------------------------------
-// STORE (first shuffle of a round): the store filter of cluster.cpp:179-201 on the round's comparisons (classes from
-// k2_lists - greedy skip already applied with the lock state of the commit - lambda / hamming from the aligner).
+// STORE (first shuffle of a round): the commit of the round's cached comparisons - class from the batch's class word with
+// the greedy skip (cluster.cpp:127-130) applied with the lock state of the commit, lambda / hamming from the rows the
+// batch's aligner launch filled - and the store filter of cluster.cpp:179-201 on them.
 // Most uniques of a large sample never get a second stored comparison: for them the arg-max is partition 0 whatever the
 // reads are, and the pass touches 8 bytes of their state.
 // halted, or a chain without the batch compare its round needs (Eng2::has_compare): nothing to do
@@ -135,6 +138,11 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   const uint32_t creads_c = S.reads[centre];
   const double *lam_row = E.C.lamB + (size_t)ctl->slot * E.C.Npad;       // the round's comparisons: its cache slot's rows
   const uint32_t *ham_row = E.C.hamB + (size_t)ctl->slot * E.C.Npad;
+  // ... and their classes: the cached class word of the slot's batch, with the greedy skip of cluster.cpp:127-130 evaluated NOW
+  // (lock state of the commit, not of the compare).  This was a launch of its own (k2_lists, 10 us per round).
+  const uint16_t *cls_row = E.C.bcls + (size_t)(ctl->slot / KB_MAX) * E.C.Npad;
+  const int kpos2 = 2 * (ctl->slot % KB_MAX);
+  uint32_t st01 = 0, st23 = 0;                                           // this thread's NW | gapless and shrouded | skipped pairs (16 bits each)
   const uint32_t reads_ci = STORE ? rd_at(ci) : 0u;
   const uint32_t reads_0 = rd_at(0);
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
@@ -157,7 +165,14 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
         need = i1 >= 0 && (sgn_of(from) < 0 || (anyinc && ((from != 0 && sgn_of(0) > 0) || (i1 != from && sgn_of(i1) > 0) || head_raw >= 0)));
       if (need) {
       const double lam0_r = T.lam0[r], lam1_r = T.lam1[r];
-      const uint8_t cl = STORE ? E.cls[r] : (uint8_t)0;
+      uint32_t cl = 0;
+      if (STORE) {
+        cl = ((uint32_t)cls_row[r] >> kpos2) & 3u;
+        const bool skip = E.greedy && (S.reads[r] > creads_c || P.lock[r] != 0);
+        if (skip) cl = CLS_SKIP;
+        else if (cl == CLS_SKIP) atomicOr(P.err_flag, 8);              // the cache lacks a comparison the round needs
+        if (cl >= CLS_GAPLESS) st01 += cl == CLS_NW ? 1u : 0x10000u; else st23 += cl == CLS_SHROUD ? 1u : 0x10000u;
+      }
       const double l_raw = STORE ? lam_row[r] : 0.0, em = STORE ? P.E_minmax[r] : 0.0;
       const uint32_t h_raw = STORE ? ham_row[r] : 0u;
       head = i1 >= 0 ? head_raw : -1;                                    // (a chain only exists behind a used second entry)
@@ -290,6 +305,16 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
     if ((threadIdx.x & 63) == 0 && my_keep) atomicAdd(&s_keep, my_keep);
     __syncthreads();
     if (threadIdx.x == 0 && s_keep) atomicAdd(&out->pad0[0], s_keep);   // Comparisons kept this round (cluster.cpp:189-199)
+    // the round's class statistics (the reference's nalign / nshroud counters): a thread sees a handful of uniques, a wave
+    // at most 64 x that - no carry between the 16-bit halves
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { st01 += __shfl_xor(st01, o, 64); st23 += __shfl_xor(st23, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+      if (st01 & 0xFFFFu) atomicAdd(&out->stat[0], (unsigned long long)(st01 & 0xFFFFu));
+      if (st01 >> 16) atomicAdd(&out->stat[1], (unsigned long long)(st01 >> 16));
+      if (st23 & 0xFFFFu) atomicAdd(&out->stat[2], (unsigned long long)(st23 & 0xFFFFu));
+      if (st23 >> 16) atomicAdd(&out->stat[3], (unsigned long long)(st23 >> 16));
+    }
   }
   D2_TRACE(1 + level, 3);
   for (int k = threadIdx.x; k < ntab; k += 256) {
@@ -299,76 +324,12 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   D2_TRACE(1 + level, 4);
 }
 
-// ---- commit of a cached compare: classes of the round's centre from the batch buffer, the greedy skip of cluster.cpp:127-130
-// evaluated NOW (lock state of the commit, not of the compare), the aligner's work lists, and the round's class statistics ----
-// Streaming shape: one thread takes EIGHT consecutive uniques - one 16-byte load of their class words, one 8-byte load of
-// their locks, two 16-byte loads of their reads, all requested before any is used - and the whole sample is one wave of
-// blocks (489 blocks at 10^6 uniques): 7 bytes per unique, no loop, no dependent load.  (Arrays carry 64 bytes of slack, so
-// the last thread's vectors may reach past N; r < N guards every use.)
 constexpr int LISTS_PER_THREAD = 8;
-__global__ __launch_bounds__(256) void k2_lists(Eng2 E) {
-  const Ctl2 *ctl = E.ctl;
-  if (v2_idle(E)) return;
-  __shared__ unsigned int s_stat[4];
-  const PartState &P = E.P;
-  const SampleDev &S = E.S;
-  const int slot = ctl->slot, kpos = slot % KB_MAX, centre = ctl->centre;
-  const uint16_t *bcls = E.C.bcls + (size_t)(slot / KB_MAX) * E.C.Npad;
-  const uint32_t creads_c = S.reads[centre];
-  D2_TRACE(0, 0);
-  if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
-  const int r0 = (blockIdx.x * 256 + threadIdx.x) * LISTS_PER_THREAD;
-  uint4 cw = make_uint4(0, 0, 0, 0), rd0 = cw, rd1 = cw;
-  uint2 lk = make_uint2(0, 0);
-  if (r0 < S.N) {
-    cw = *(const uint4 *)(bcls + r0);
-    lk = *(const uint2 *)(P.lock + r0);
-    rd0 = *(const uint4 *)(S.reads + r0);
-    rd1 = *(const uint4 *)(S.reads + r0 + 4);
-  }
-  __syncthreads();
-  const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w}, rds[8] = {rd0.x, rd0.y, rd0.z, rd0.w, rd1.x, rd1.y, rd1.z, rd1.w};
-  uint32_t codes = 0;                                                  // 2 bits per unique
-  int my_stat[4] = {0, 0, 0, 0};
-  bool cache_hole = false;
-#pragma unroll
-  for (int q = 0; q < LISTS_PER_THREAD; q++) {
-    if (r0 + q >= S.N) break;
-    uint32_t code = ((cws[q >> 1] >> ((q & 1) * 16)) >> (2 * kpos)) & 3u;
-    const bool locked = ((q < 4 ? lk.x >> (8 * q) : lk.y >> (8 * (q - 4))) & 0xFFu) != 0;
-    const bool skip = E.greedy && (rds[q] > creads_c || locked);
-    if (skip) code = CLS_SKIP;
-    else if (code == CLS_SKIP) cache_hole = true;                        // the cache lacks a comparison the round needs
-    my_stat[code == CLS_NW ? 0 : (code == CLS_GAPLESS ? 1 : (code == CLS_SHROUD ? 2 : 3))]++;
-    codes |= code << (2 * q);
-  }
-  if (cache_hole) atomicOr(P.err_flag, 8);
-  if (r0 < S.N) {                                                       // the round's class bytes, eight at a time
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) { lo |= ((codes >> (2 * q)) & 3u) << (8 * q); hi |= ((codes >> (2 * (q + 4))) & 3u) << (8 * q); }
-    if (r0 + LISTS_PER_THREAD <= S.N) *(uint2 *)(E.cls + r0) = make_uint2(lo, hi);
-    else for (int q = 0; r0 + q < S.N; q++) E.cls[r0 + q] = (uint8_t)((codes >> (2 * q)) & 3u);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    int v = my_stat[q];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stat[q], (unsigned int)v);
-  }
-  __syncthreads();
-  if (threadIdx.x < 4 && s_stat[threadIdx.x]) {
-    Round2Out *out = E.dblk + (ctl->pub_seq % RING2);
-    atomicAdd(&out->stat[threadIdx.x], (unsigned long long)s_stat[threadIdx.x]);
-  }
-  D2_TRACE(0, 1);
-  D2_TRACE(0, 2);
-}
 
 // ---- work lists of a batch compare: for every batch position the uniques whose pair goes to the aligner (class NW) and the
 // gapless ones, as of the screen (a pair the greedy rule skips at ITS commit is aligned in vain; locks only grow, so no pair
-// a commit needs is ever missing).  Same streaming shape as k2_lists; most class words have no such pair at all. ----
+// a commit needs is ever missing).  Streaming shape: one thread takes EIGHT consecutive uniques with one 16-byte load of their
+// class words; most class words have no such pair at all. ----
 __global__ __launch_bounds__(256) void k2_batch_lists(Eng2 E) {
   const Ctl2 *ctl = E.ctl;
   const int nb = ctl->nbatch;
@@ -1128,10 +1089,6 @@ void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
   }
   const int grid = std::min((E.S.N + 63) / 64, 2048);
   hipLaunchKernelGGL(k2_screen_multi, dim3(grid), dim3(256), lds, st, E);
-}
-void launch2_lists(const Eng2 &E, hipStream_t st) {
-  const int grid = (E.S.N + 256 * LISTS_PER_THREAD - 1) / (256 * LISTS_PER_THREAD);
-  hipLaunchKernelGGL(k2_lists, dim3(grid), dim3(256), 0, st, E);
 }
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st) {
   const int grid = std::min((E.S.N + 255) / 256, (int)E.grid_shuffle);   // one device atomic per counter per block
