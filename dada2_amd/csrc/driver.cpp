@@ -1222,6 +1222,7 @@ struct Run {
   DevBuf<double> v2_lamB;
   DevBuf<uint32_t> v2_hamB;
   DevBuf<uint8_t> v2_moved;
+  DevBuf<uint32_t> v2_statpart;
   DevBuf<CompBlk> v2_blk;
   DevBuf<Ctl2> v2_ctl;
   DevBuf<BudTie> v2_tiesrec;
@@ -1262,10 +1263,10 @@ struct Run {
     E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
     E2.sp = sp; E2.thresh = d_thresh_round.p; E2.max_shuffle = MAX_SHUFFLE;
     E2.trace = v2_trace.p; E2.trace_seq = v2_trace_seq;
-    E2.moved = v2_moved.p; E2.n0d = v2_n0d.p;
+    E2.moved = v2_moved.p; E2.n0d = v2_n0d.p; E2.stat_part = v2_statpart.p; E2.stat_n = v2_n0d.p + 2 * SH_CHAIN;
     E2.sh_filter = 1; E2.grid_shuffle = 2048; E2.grid_pupdate = 1024;
     if (const char *e = getenv("DADA2HIP_V2_FILTER")) E2.sh_filter = atoi(e) != 0;
-    if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::max(1, atoi(e));
+    if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::min(8192, std::max(1, atoi(e)));
     if (const char *e = getenv("DADA2HIP_V2_GRID_PUPDATE")) E2.grid_pupdate = std::max(1, atoi(e));
     E2.has_compare = 1;
     E2L = E2; E2L.has_compare = 0;
@@ -1306,9 +1307,9 @@ struct Run {
     D2_HIP(hipMemsetAsync(v2_blistn.p, 0, 2 * KB_MAX * 4, stq));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
     v2_listn.alloc(2); v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
-    v2_moved.alloc(n); v2_n0d.alloc(2 * SH_CHAIN);
+    v2_moved.alloc(n); v2_n0d.alloc(2 * SH_CHAIN + 4); v2_statpart.alloc((size_t)4 * 8192);
     D2_HIP(hipMemsetAsync(v2_moved.p, 0, n, stq));
-    D2_HIP(hipMemsetAsync(v2_n0d.p, 0, 2 * SH_CHAIN * 4, stq));
+    D2_HIP(hipMemsetAsync(v2_n0d.p, 0, (2 * SH_CHAIN + 4) * 4, stq));
     D2_HIP(hipMemsetAsync(v2_sig.p, 0, 16, stq));
     D2_HIP(hipMemsetAsync(v2_blkcount.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));

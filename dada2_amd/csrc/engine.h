@@ -357,6 +357,8 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   double *lam;
   uint32_t *ham;
   int32_t *nw_list, *gl_list, *list_n;
+  uint32_t *stat_part;            // [grid of the store pass][4] per-block class counts of the round (NW, gapless, shrouded, skipped)
+  int32_t *stat_n;                // number of entries in stat_part (0: the chain had no store pass), consumed by k2_birth
   int32_t *blist, *blist_n;       // [2 KB_MAX][Npad] / [2 KB_MAX]: work lists of the batch compare (NwBatch)
   void *partial;                  // block partials of the bud arg-min
   int32_t *ties0, *ties1;         // full tie lists

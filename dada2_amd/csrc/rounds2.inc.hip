@@ -306,15 +306,19 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
     __syncthreads();
     if (threadIdx.x == 0 && s_keep) atomicAdd(&out->pad0[0], s_keep);   // Comparisons kept this round (cluster.cpp:189-199)
     // the round's class statistics (the reference's nalign / nshroud counters): a thread sees a handful of uniques, a wave
-    // at most 64 x that - no carry between the 16-bit halves
+    // at most 64 x that - no carry between the 16-bit halves.  Every block has some, so they leave as one plain 16-byte
+    // store per block and k2_birth adds them up (an atomic per wave on the four counters of the result block tripled this
+    // kernel's time: 32 000 atomics on one cache line)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { st01 += __shfl_xor(st01, o, 64); st23 += __shfl_xor(st23, o, 64); }
+    __shared__ uint32_t s_st[4][4];
     if ((threadIdx.x & 63) == 0) {
-      if (st01 & 0xFFFFu) atomicAdd(&out->stat[0], (unsigned long long)(st01 & 0xFFFFu));
-      if (st01 >> 16) atomicAdd(&out->stat[1], (unsigned long long)(st01 >> 16));
-      if (st23 & 0xFFFFu) atomicAdd(&out->stat[2], (unsigned long long)(st23 & 0xFFFFu));
-      if (st23 >> 16) atomicAdd(&out->stat[3], (unsigned long long)(st23 >> 16));
+      uint32_t *w = s_st[threadIdx.x >> 6];
+      w[0] = st01 & 0xFFFFu; w[1] = st01 >> 16; w[2] = st23 & 0xFFFFu; w[3] = st23 >> 16;
     }
+    __syncthreads();
+    if (threadIdx.x < 4) E.stat_part[(size_t)blockIdx.x * 4 + threadIdx.x] = s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *E.stat_n = (int32_t)gridDim.x;
   }
   D2_TRACE(1 + level, 3);
   for (int k = threadIdx.x; k < ntab; k += 256) {
@@ -734,7 +738,24 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
     if (d) P.creads[i] += (uint32_t)d;
   }
   if (threadIdx.x < 2) s_nt[threadIdx.x] = 0;
+  {   // class statistics of the chain's store pass, if it had one: the blocks' partial counts (k2_shuffle<true>)
+    const int np = *E.stat_n;
+    if (np > 0) {
+      uint32_t v[4] = {0, 0, 0, 0};
+      for (int b = threadIdx.x; b < np; b += blockDim.x) {
+        const uint4 q = ((const uint4 *)E.stat_part)[b];
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&out->stat[k], (unsigned long long)v[k]);
+      }
+    }
+  }
   if (threadIdx.x == 0) {
+    *E.stat_n = 0;
     s_nnear = 0;
     // partition 0's member count through the chain's shuffle calls: within one call only the number it lost is known, not
     // the order of losses and gains, so the running minimum is taken as if all losses came first (a lower bound)
