@@ -1342,9 +1342,8 @@ struct Run {
 
   // one chain: [shuffle x nlev][b_p_update + b_bud arg-min + ties][birth / plan / publish]; a full round is a chain with the
   // batch compare in front (no-ops on a cache hit) and the round's store filter in its first shuffle
-  // A full round is always the same launches with the same arguments (what differs lives in the control block), so it is
-  // captured once into a hipGraph and replayed: one API call per round instead of nine, and back-to-back dispatch on the
-  // device.  DADA2HIP_V2_GRAPH=0 keeps plain stream launches; profiling (events between launches) does too.
+  // A full round is always the same launches with the same arguments (what differs lives in the control block), so it can be
+  // captured once into a hipGraph and replayed: one API call per round (DADA2HIP_V2_GRAPH=1; off by default, see graph_off()),
   // ... in both forms: [0] with the batch compare in front, [1] without (Eng2::has_compare)
   hipGraphExec_t v2_graph[2] = {nullptr, nullptr};
   int v2_graph_state = 0;            // 0: not tried yet, 1: in use, -1: unavailable
@@ -1372,7 +1371,11 @@ struct Run {
     v2_graph_state = 1;
     return true;
   }
-  static bool graph_off() { const char *e = getenv("DADA2HIP_V2_GRAPH"); return e && atoi(e) == 0; }
+  // hipGraph replay is OFF by default: a graph launch leaves a 13 us bubble behind its last kernel (profiles/r03h, r03s), 10 ms
+  // per pass at 10^6 uniques, while the six or ten plain launches of a chain cost the host 25 us per round - a third of what
+  // it has (it trails the device anyway) - and run back to back: 173 against 183 ms per pass (profiles/r03x vs r03w).
+  // DADA2HIP_V2_GRAPH=1 brings the graphs back (a host that is short of cycles: 8 instead of 25 ms of enqueue per pass).
+  static bool graph_off() { const char *e = getenv("DADA2HIP_V2_GRAPH"); return !(e && atoi(e) != 0); }
   void v2_enqueue_chain(int nlev, bool with_compare, bool store) {
     const auto t_enq = clk::now();
     EnqRec rec{-1, -1, with_compare};
