@@ -75,6 +75,23 @@ class CSampleInput(C.Structure):
                 ("abundances", C.c_void_p), ("priors", C.c_void_p), ("quals", C.c_void_p)]
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  A ROCm build of torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): whichever
+    copy is mapped first serves both torch and this library, and torch does not see a device through the system copy.  So if
+    torch is INSTALLED (it is not imported here, and nothing of torch is used) its copy is mapped before libdada2hip.so asks
+    for the SONAME - `import dada2_amd` and `import torch` then work in either order.  DADA2HIP_SYSTEM_HIP=1 skips this."""
+    if os.environ.get("DADA2HIP_SYSTEM_HIP") or "emu" in os.path.basename(LIB_PATH):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+        if cand and os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:   # no torch, or its runtime does not load here: the system copy serves
+        pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -82,6 +99,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise Dada2HipError(2, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, ip, cp = C.c_void_p, C.c_int32, C.c_char_p
     L.dada2hip_version.restype = cp

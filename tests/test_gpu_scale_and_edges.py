@@ -377,3 +377,25 @@ def test_bimera_table_seeded_vs_oracle(api, oracle_c, seed, nseq, nsam, L):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (oo, mf, ma, ms)
     flagged = api.is_bimera_denovo_table(mat, seqs)
     assert flagged.dtype == bool and flagged.shape == (len(seqs),)
+
+
+def test_library_first_then_torch_share_one_hip_runtime():
+    """the library used to need `import torch` BEFORE it (two HIP runtimes otherwise, torch then sees no device).
+    dada2_amd._lib maps torch's bundled runtime first when torch is installed, so either order works: a fresh interpreter that
+    calls the library first and imports torch afterwards must still see the GPU through torch, and both must keep working."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from dada2_amd import api\n"
+        "assert 'torch' not in sys.modules\n"
+        "a = api.nwalign('ACGTTACGTAACGT', 'ACGTACGTAACGT', band=-1)\n"
+        "import torch\n"
+        "assert torch.cuda.is_available(), 'torch lost the device'\n"
+        "x = torch.arange(8, device='cuda').sum().item()\n"
+        "b = api.nwalign('ACGTTACGTAACGT', 'ACGTACGTAACGT', band=-1)\n"
+        "assert a == b and x == 28\n"
+        "print('ok')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
