@@ -274,7 +274,9 @@ def main():
                        "comparisons": st["ncompare"], "nw": st["nnw"], "gapless": st["ngapless"],
                        "shrouded": st["nshroud"], "greedy_skipped": st["nskipped"], "shuffles": st["nshuffle"],
                        "host_input_bytes": inputs[0].nbytes,
-                       "parallelism": ("one sample, its uniques in %d blocks (dada2hip_sample_run_sharded), host-driven rounds, sample resident" % world if args.shard
+                       "parallelism": ("one sample, its uniques in %d blocks (dada2hip_sample_run_sharded), %s, sample resident"
+                                       % (world, "host-driven rounds with the movers / bud candidates exchanged per round" if world > 1
+                                          else "world 1: the entry point runs the ordinary device-driven engine") if args.shard
                                        else (f"{c['samples']} samples round-robin over {world} rank(s)" if strong else f"sample-per-gpu x{world}")),
                        "shard_collectives_per_step": res.stats.get("shard_collectives") if args.shard else None},
             "roofline": roofline, "roofline_secondary": other, "roofline_nw_saturated": saturated,
@@ -493,7 +495,8 @@ def cpu_baseline(d, err, opts, args, gpu_res, gpu_cmp_per_s=None):
     tbest = int(max(sweep, key=lambda k: sweep[k]))
     out["sweep"] = {"uniques": nsw, "uniques_per_s_by_threads": sweep}
     out["threads_best"] = tbest
-    out["cores_used"] = tbest
+    out["cores"] = tbest                 # the threads the timed run used (the box has `host_cores`)
+    out["host_cores"] = ncores
 
     t_all, r = timed("O2", tbest, args.cpu_repeats)
     out.update(value=n / t_all, seconds=t_all, partitions=r.nclust, build="-O2 (R's default flags)", repeats=max(1, args.cpu_repeats),

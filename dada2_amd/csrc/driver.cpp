@@ -1269,6 +1269,7 @@ struct Run {
     if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::min(8192, std::max(1, atoi(e)));
     if (const char *e = getenv("DADA2HIP_V2_GRID_PUPDATE")) E2.grid_pupdate = std::max(1, atoi(e));
     E2.has_compare = 1;
+    E2.align_at_commit = v2_align_commit ? 1 : 0;
     E2L = E2; E2L.has_compare = 0;
     v2_drop_graph();                 // (captured launches hold the old argument block)
   }
@@ -1320,7 +1321,8 @@ struct Run {
     Ctl2 c;
     memset(&c, 0, sizeof c);
     c.nclust = 1; c.centre = (int32_t)bi[0].center; c.slot = 0; c.max_clust = max_clust;
-    c.n0 = N; c.low0 = N; c.need_compare = 0;
+    c.n0 = N; c.low0 = N; c.need_compare = 0; c.nalign = 0; c.abuf = 0;
+    for (int k = 0; k < KB_MAX; k++) c.acentre[k] = -1;
     for (int k = 0; k < KB_MAX; k++) c.bcentre[k] = -1;
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
     D2_HIP(hipStreamSynchronize(stq));   // `c` is a local
@@ -1334,6 +1336,11 @@ struct Run {
     v2_next_full = 0;
     v2_lite_on = true;
     if (const char *e = getenv("DADA2HIP_V2_LITE")) v2_lite_on = atoi(e) != 0;
+    // one alignment per wave (band windows > 65 cells: long reads): a round's own list fills the device, so its pairs are
+    // aligned when the round commits and nothing is aligned in vain (engine.h, Eng2::align_at_commit)
+    v2_align_commit = nw_ad_apw(s->D, ap) == 1;
+    if (const char *e = getenv("DADA2HIP_V2_ALIGN")) v2_align_commit = !strcmp(e, "commit");
+    if (v2_align_commit) v2_lite_on = false;                   // (every chain carries the aligner's launches)
     v2_plain_rounds = 0;
     v2_miss_launches = 0;
     v2_enqrec.clear();
@@ -1350,6 +1357,7 @@ struct Run {
   int v2_plain_rounds = 0;
   long v2_next_full = 0;             // first chain (sequence number) that is expected to need a batch compare again
   bool v2_lite_on = true;
+  bool v2_align_commit = false;       // Eng2::align_at_commit
   void v2_drop_graph() {
     for (auto &g : v2_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     if (v2_graph_state == 1) v2_graph_state = 0;
@@ -1404,7 +1412,7 @@ struct Run {
       ev_end(rec.ev_screen);
       // ... its survivors through the aligner, all batch positions in one launch (both no-ops on a cache hit) ...
       launch2_batch_lists(E2, stq);
-      const NwBatch nb{&v2_ctl.p->nbatch, v2_blistn.p, v2_blist.p, v2_ctl.p->bcentre, &v2_ctl.p->bbuf, E2.C.Npad};
+      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad};
       launch_gapless_batch(s->D, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &v2_ctl.p->state, stq);
       rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
       launch_nw_ad(s->D, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, stq,
@@ -1532,11 +1540,13 @@ struct Run {
       if (b.cnt[0] + b.cnt[1] + b.cnt[2] + b.cnt[3] > MOV_INLINE2) n_big++;
       const auto t_dec = clk::now();
       const EnqRec &rec = v2_enqrec[seq - 1];
+      if (rec.compare && b.pad0[1] + b.pad0[2] > 0) {          // (the aligner launches of this chain had work)
+        if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
+        st.nnw_run += (uint64_t)b.pad0[1]; st.ngapless_run += (uint64_t)b.pad0[2];
+      }
       if (rec.compare && b.nbatch > 0) {                       // (this chain's batch compare really ran: a cache miss)
         v2_miss_launches++;
         if (rec.ev_screen >= 0) evs[rec.ev_screen].ok = 1;
-        if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
-        st.nnw_run += (uint64_t)b.pad0[1]; st.ngapless_run += (uint64_t)b.pad0[2];
         v2_next_full = seq + b.nbatch;                         // the batch holds the centres of this round and, if the guesses hold, the next nbatch - 1
       }
       if (b.nlev > 0 && b.halt != H2_SHUFFLE_MORE) { }        // (a round's commit is complete)

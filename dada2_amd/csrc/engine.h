@@ -291,6 +291,11 @@ struct Ctl2 {
   int32_t nsh_base;     // shuffles of the round in flight executed by earlier chains
   int32_t max_clust;
   int32_t scan_hint;    // (reserved)
+  // what the aligner launches of the coming chain work on (NwBatch): positions [0, nalign) of batch buffer abuf, centre of
+  // position k = acentre[k] (-1: none).  Batch mode: the batch just planned (nalign = nbatch, 0 on a cache hit).  Commit mode
+  // (Eng2::align_at_commit): always the ONE position of the coming round's centre, whether it was screened just now or long ago.
+  int32_t nalign, abuf;
+  int32_t acentre[KB_MAX];
   int32_t need_compare; // the coming round's centre is not cached: its chain must carry the batch compare (Eng2::has_compare)
   int32_t n0, low0;     // members of partition 0 now / a lower bound of the fewest it has ever had (tie rule of k2_birth)
   int32_t bcentre[KB_MAX];
@@ -381,6 +386,12 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   // last batch held).  When it guessed wrong - the prediction of the coming centres failed early - the chain's kernels see
   // need_compare without has_compare, do nothing, and k2_birth reports H2_NEED_COMPARE: the host sends a full chain.
   int32_t has_compare;
+  // When are the pairs of a cached screen aligned?  0: all positions of a batch at once, right behind its screen - a launch
+  // of eight rounds' work runs in the aligner's saturated regime, at the price of the pairs a later greedy skip or an unused
+  // position wastes (10 % at 250 nt).  1: each centre's pairs when its round commits, with the greedy skip of that moment -
+  // nothing is wasted; chosen when one round's list fills the device on its own (one alignment per wave: long reads, where
+  // aligning ahead cost 20 % more alignments and saved nothing, profiles/r03z_bench_cfg5.json vs r04a).
+  int32_t align_at_commit;
   int32_t sh_filter;                                // later shuffle calls of a chain visit only the uniques the previous call can have unsettled
   int32_t grid_shuffle, grid_pupdate;               // host side: block caps of the per-round launches (tuning knobs)
 };

@@ -336,26 +336,48 @@ constexpr int LISTS_PER_THREAD = 8;
 // class words; most class words have no such pair at all. ----
 __global__ __launch_bounds__(256) void k2_batch_lists(Eng2 E) {
   const Ctl2 *ctl = E.ctl;
-  const int nb = ctl->nbatch;
+  const int nb = ctl->nalign;
   if (ctl->state != 0 || nb == 0) return;
   __shared__ int s_cnt[2 * KB_MAX], s_base[2 * KB_MAX];
   const SampleDev &S = E.S;
-  const uint16_t *bcls = E.C.bcls + (size_t)ctl->bbuf * E.C.Npad;
+  const uint16_t *bcls = E.C.bcls + (size_t)ctl->abuf * E.C.Npad;
+  // commit mode: only the position of the coming round's centre, and only the pairs the greedy rule (cluster.cpp:127-130) does
+  // not skip NOW - the lock state of the commit, which follows in the same chain
+  const bool commit = E.align_at_commit != 0;
+  const int kpos = ctl->slot % KB_MAX;
+  const uint32_t fmask = commit ? (2u << (2 * kpos)) : 0xAAAAu;        // bit 2k+1 of a class word: NW or gapless (CLS_GAPLESS = 2, CLS_NW = 3)
+  const uint32_t creads_c = commit ? S.reads[ctl->centre] : 0u;
   if (threadIdx.x < 2 * KB_MAX) s_cnt[threadIdx.x] = 0;
   const int r0 = (blockIdx.x * 256 + threadIdx.x) * LISTS_PER_THREAD;
-  uint4 cw = make_uint4(0, 0, 0, 0);
-  if (r0 < S.N) cw = *(const uint4 *)(bcls + r0);
+  uint4 cw = make_uint4(0, 0, 0, 0), rd0 = cw, rd1 = cw;
+  uint2 lk = make_uint2(0, 0);
+  if (r0 < S.N) {
+    cw = *(const uint4 *)(bcls + r0);
+    if (commit && E.greedy) {
+      lk = *(const uint2 *)(E.P.lock + r0);
+      rd0 = *(const uint4 *)(S.reads + r0);
+      rd1 = *(const uint4 *)(S.reads + r0 + 4);
+    }
+  }
   __syncthreads();
-  const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
-  // bit 2k+1 of a class word is set for NW and gapless (CLS_GAPLESS = 2, CLS_NW = 3); positions >= nb hold class 0
-  const bool any = ((cw.x | cw.y | cw.z | cw.w) & 0xAAAAAAAAu) != 0;
+  const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w}, rds[8] = {rd0.x, rd0.y, rd0.z, rd0.w, rd1.x, rd1.y, rd1.z, rd1.w};
+  const bool any = ((cw.x | cw.y | cw.z | cw.w) & (fmask | (fmask << 16))) != 0;   // (positions >= the batch's size hold class 0)
+  auto fields = [&](int q) __attribute__((always_inline)) -> uint32_t {   // class word of unique r0 + q, and which of its fields to list
+    const uint32_t w = (cws[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
+    uint32_t m = w & fmask;
+    if (commit && E.greedy) {
+      const bool locked = ((q < 4 ? lk.x >> (8 * q) : lk.y >> (8 * (q - 4))) & 0xFFu) != 0;
+      if (rds[q] > creads_c || locked) m = 0;
+    }
+    return w | (m << 16);
+  };
   uint32_t n_lo = 0, n_hi = 0;                                          // per-list counts of this thread, 4 bits each (<= 8)
   if (any) {
 #pragma unroll
     for (int q = 0; q < LISTS_PER_THREAD; q++) {
       if (r0 + q >= S.N) break;
-      const uint32_t w = (cws[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
-      for (uint32_t m = w & 0xAAAAu; m; m &= m - 1) {
+      const uint32_t wf = fields(q), w = wf & 0xFFFFu;
+      for (uint32_t m = wf >> 16; m; m &= m - 1) {
         const int k = __builtin_ctz(m) >> 1;
         const int list = ((w >> (2 * k)) & 1u) ? k : KB_MAX + k;        // NW : gapless
         if (list < 8) n_lo += 1u << (4 * list); else n_hi += 1u << (4 * (list - 8));
@@ -378,8 +400,8 @@ __global__ __launch_bounds__(256) void k2_batch_lists(Eng2 E) {
 #pragma unroll
     for (int q = 0; q < LISTS_PER_THREAD; q++) {
       if (r0 + q >= S.N) break;
-      const uint32_t w = (cws[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
-      for (uint32_t m = w & 0xAAAAu; m; m &= m - 1) {
+      const uint32_t wf = fields(q), w = wf & 0xFFFFu;
+      for (uint32_t m = wf >> 16; m; m &= m - 1) {
         const int k = __builtin_ctz(m) >> 1;
         const int list = ((w >> (2 * k)) & 1u) ? k : KB_MAX + k;
         int pos = 0;
@@ -530,6 +552,22 @@ static __device__ int block_best(double p, uint32_t reads, int r, double *s_p, u
 // candidates of the last evaluation (the significant ones k2_pupdate listed, in b_bud's own order: p ascending, reads
 // descending) that are not cached yet - they are the likely next centres, and a wrong guess only costs its share of one
 // pass over the k-mer records - and builds the batch's k-mer tables.
+// what the aligner launches of the coming chain work on (Ctl2::nalign / abuf / acentre); `slot` is the new centre's cache slot,
+// nb the size of the batch just planned (0: the centre was cached)
+static __device__ void plan_aligner(const Eng2 &E, int centre, int slot, int nb) {
+  Ctl2 *ctl = E.ctl;
+  const int tid = threadIdx.x;
+  __syncthreads();                                                      // (bcentre[] of a fresh batch is written)
+  if (E.align_at_commit) {
+    if (tid < KB_MAX) ctl->acentre[tid] = tid == slot % KB_MAX ? centre : -1;
+    if (tid == 0) { ctl->nalign = KB_MAX; ctl->abuf = slot / KB_MAX; }
+    if (tid < 2 * KB_MAX) E.blist_n[tid] = 0;
+  } else {
+    if (tid < KB_MAX) ctl->acentre[tid] = tid < nb ? ctl->bcentre[tid] : -1;
+    if (tid == 0) { ctl->nalign = nb; ctl->abuf = ctl->bbuf; }
+    if (nb > 0 && tid < 2 * KB_MAX) E.blist_n[tid] = 0;
+  }
+}
 static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -567,6 +605,7 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
   __syncthreads();
   if (*s_hit >= 0) {
     if (tid == 0) { ctl->slot = *s_hit; ctl->nbatch = 0; ctl->need_compare = 0; }
+    plan_aligner(E, raw, *s_hit, 0);
     return;
   }
   if (tid == 0) {
@@ -578,7 +617,6 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
     s_bc[0] = raw;
     *s_nb = 1;
   }
-  if (tid < 2 * KB_MAX) E.blist_n[tid] = 0;                          // the batch compare's work lists (k2_batch_lists)
   for (int q = tid; q < PLAN_BITS / 32; q += blockDim.x) s_bits[q] = 0;
   __syncthreads();
   for (int q = tid; q < nslots; q += blockDim.x) {
@@ -660,6 +698,7 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
     } else { ctl->bcentre[k] = -1; ctl->breads[k] = 0; ctl->blen[k] = 0; }
   }
   if (tid == 0) { ctl->nbatch = nb; ctl->need_compare = 1; }
+  plan_aligner(E, raw, ctl->bbuf * KB_MAX, nb);
 }
 
 static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
@@ -836,7 +875,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
   D2_TRB(2);
   if (threadIdx.x == 0) {
     out->nlev = nlev; out->nsh = cs.nexec; out->slot = ctl->slot; out->nbatch = ctl->nbatch;
-    if (ctl->nbatch > 0) {                                       // alignments / gapless pairs this chain's batch compare ran
+    if (ctl->nalign > 0 && nlev > 0) {                           // alignments / gapless pairs the aligner ran for this chain
       int nn = 0, ng = 0;
       for (int k = 0; k < KB_MAX; k++) { nn += E.blist_n[k]; ng += E.blist_n[KB_MAX + k]; }
       out->pad0[1] = nn; out->pad0[2] = ng;

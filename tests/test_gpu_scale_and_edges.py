@@ -222,7 +222,10 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V2_DEPTH": "3"},
     {"DADA2HIP_V2_CHAIN": "1"},                           # one shuffle per chain: rounds continue through the host (H2_SHUFFLE_MORE)
     {"DADA2HIP_V2_CHAIN": "2", "DADA2HIP_NODE_CAP": "1"}, # comparison store starts at N + 16 blocks: growth through H2_CAPACITY
-], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow"])
+    {"DADA2HIP_V2_ALIGN": "commit"},                      # each centre's pairs aligned when its round commits (the long-read mode)
+    {"DADA2HIP_V2_LITE": "0"},                            # every chain carries the batch compare's launches (no H2_NEED_COMPARE)
+    {"DADA2HIP_V2_GRAPH": "1", "DADA2HIP_V2_NBUF": "2"},  # hipGraph replay of both chain forms, frequent evictions
+], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
     20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""
