@@ -2306,7 +2306,9 @@ static int nwvec_any(int32_t n, const char *const *s1, const char *const *s2, in
                      size_t errlen) {
   return guarded(errbuf, errlen, [&] {
     if (n <= 0) return;
-    // a throw-away resident sample holding the 2n strings; pair i = (centre 2i, raw 2i+1), one pair per wave
+    // a throw-away resident sample holding the 2n strings; pair i = (centre 2i, raw 2i+1), one pair per LANE: the lane kernels
+    // take a centre per work item (NwArgs::pair_centre), so 64 unrelated pairs share a wave and the move strings take
+    // n x (2 maxlen + 2) bytes (round 2 gave every pair a whole 64-slot chunk: 64x the memory)
     std::vector<const char *> seqs(2 * (size_t)n);
     std::vector<int32_t> ab(2 * (size_t)n, 1);
     int maxlen = 0;
@@ -2335,16 +2337,16 @@ static int nwvec_any(int32_t n, const char *const *s1, const char *const *s2, in
     ap.endsfree = endsfree ? 1 : 0;
     ap.homo_gap = endsfree ? homo_gap_p : gap_p;
     if (!ap.plain()) ap.sentinel = -9999;
-    std::vector<int32_t> work((size_t)n * 64, -1), cc(n);
-    for (int i = 0; i < n; i++) { work[(size_t)i * 64] = 2 * i + 1; cc[i] = 2 * i; }
+    std::vector<int32_t> work((size_t)n), cc(n);
+    for (int i = 0; i < n; i++) { work[i] = 2 * i + 1; cc[i] = 2 * i; }
     const int stride = 2 * maxlen + 2;
     s->d_work.alloc(work.size()); s->d_chunk_centre.alloc(n); s->d_moves.alloc(work.size() * (size_t)stride);
     s->d_nmoves.alloc(work.size()); s->d_lambda.alloc(2 * (size_t)n); s->d_ham.alloc(2 * (size_t)n);
     D2_HIP(hipMemcpyAsync(s->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, s->stream));
     D2_HIP(hipMemcpyAsync(s->d_chunk_centre.p, cc.data(), (size_t)n * 4, hipMemcpyHostToDevice, s->stream));
     if (band == 0) throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: band == 0 is the gapless pairing, not an NW call."};
-    launch_nw(s->D, s->scr_class, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, (int)work.size(), ap, s->d_err.p, s->scr,
-              s->d_lambda.p, s->d_ham.p, nullptr, 0, 0, s->d_moves.p, stride, s->d_nmoves.p, s->stream);
+    launch_nw(s->D, s->scr_class, 0, nullptr, s->d_work.p, nullptr, (int)work.size(), ap, s->d_err.p, s->scr,
+              s->d_lambda.p, s->d_ham.p, nullptr, 0, 0, s->d_moves.p, stride, s->d_nmoves.p, s->stream, s->d_chunk_centre.p);
     std::vector<uint8_t> moves(work.size() * (size_t)stride);
     std::vector<int32_t> nm(work.size());
     D2_HIP(hipMemcpyAsync(moves.data(), s->d_moves.p, moves.size(), hipMemcpyDeviceToHost, s->stream));
@@ -2353,8 +2355,8 @@ static int nwvec_any(int32_t n, const char *const *s1, const char *const *s2, in
     D2_HIP(hipGetLastError());
     check_nw_flag(s);
     for (int i = 0; i < n; i++) {
-      const uint8_t *mv = &moves[(size_t)i * 64 * stride];
-      const int len = nm[(size_t)i * 64];
+      const uint8_t *mv = &moves[(size_t)i * stride];
+      const int len = nm[i];
       int a = (int)strlen(s1[i]), b = (int)strlen(s2[i]);
       char *o0 = out[2 * i], *o1 = out[2 * i + 1];
       for (int t = 0; t < len; t++) {   // moves were recorded from the end of the alignment backwards

@@ -196,7 +196,7 @@ size_t nw_ptr_words_per_wave(int wclass, int band, int maxlen, int minlen);
 void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err, const NwScratch &scr,
                double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, uint8_t *d_moves,
-               int moves_stride, int32_t *d_nmoves, hipStream_t st);
+               int moves_stride, int32_t *d_nmoves, hipStream_t st, const int32_t *d_pair_centre = nullptr);   // d_pair_centre: a centre per work item
 
 // batch mode of k_nw_ad (round engine v2): the comparisons of a whole batch compare in one launch, everything read on the device
 struct NwBatch {

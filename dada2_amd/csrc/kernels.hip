@@ -429,6 +429,8 @@ struct NwArgs {
   int centre;
   const int32_t *centre_dev;   // speculative round: centre read from the device descriptor (-1 = nothing to do)
   const int32_t *chunk_centre;
+  const int32_t *pair_centre;  // lane kernels (k_nw, k_nw_gen): the centre of EVERY work item (pairwise alignments: C_nwvec, mergePairs) -
+                               // 64 unrelated pairs to a wave instead of one; the row loops then run to each lane's own length
   const int32_t *work;
   const int32_t *nwork_dev;
   int nwork_host;
@@ -527,11 +529,13 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
   for (int chunk = gwave; chunk * 64 < nwork; chunk += nwaves) {
     const int idx = chunk * 64 + lane;
-    const int c = gcn_readfirstlane(a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
+    const bool pairs = a.pair_centre != nullptr;
+    const int c = pairs ? a.pair_centre[idx < nwork ? idx : nwork - 1]
+                        : gcn_readfirstlane(a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
     int r = idx < nwork ? a.work[idx] : -1;
     const bool active = r >= 0;
     if (!active) r = c;                       // idle lanes align the centre to itself, results dropped
-    const int L1 = gcn_readfirstlane(S.len[c]);
+    const int L1 = pairs ? S.len[c] : gcn_readfirstlane(S.len[c]);
     const int L2 = S.len[r];
     const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
     const int W = lband + rband + 1;          // <= WMAX (host picks the kernel class)
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
     int kend = L2 - 1 + lband;                // k of column j == L2 in row i
     uint32_t cw = 0;
     for (int i = 1; i <= L1; i++) {
-      if (((i - 1) & 15) == 0) cw = crow[(i - 1) >> 4];   // wave-uniform -> scalar load
+      if (((i - 1) & 15) == 0) cw = crow[(i - 1) >> 4];   // wave-uniform -> scalar load (per lane with pair_centre)
       const uint32_t cb = (cw >> (((i - 1) & 15) << 1)) & 3u;
       const uint32_t crep = cb * 0x55555555u;
       uint32_t m[NW32];
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap;
   for (int chunk = gwave; chunk * 64 < nwork; chunk += nwaves) {
     const int idx = chunk * 64 + lane;
-    const int c = a.chunk_centre ? a.chunk_centre[chunk] : a.centre;
+    const int c = a.pair_centre ? a.pair_centre[idx < nwork ? idx : nwork - 1] : (a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
     int r = idx < nwork ? a.work[idx] : -1;
     const bool active = r >= 0;
     if (!active) r = c;
@@ -1667,7 +1671,7 @@ size_t nw_ptr_words_per_wave(int wclass, int band, int maxlen, int minlen) {
 void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chunk_centre, const int32_t *d_work,
                const int32_t *d_nwork, int nwork_host, const AlignParams &ap, const double *d_err, const NwScratch &scr,
                double *d_lambda, uint32_t *d_ham, uint16_t *d_view, int LV, int view_by_chunk, uint8_t *d_moves,
-               int moves_stride, int32_t *d_nmoves, hipStream_t st) {
+               int moves_stride, int32_t *d_nmoves, hipStream_t st, const int32_t *d_pair_centre) {
   int maxwork = d_nwork ? S.N : nwork_host;
   if (maxwork <= 0) return;
   int waves = std::min((maxwork + 63) / 64, scr.nwaves);
@@ -1676,7 +1680,7 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
   if (grid < 1) grid = 1;
   NwArgs a;
   memset(&a, 0, sizeof a);
-  a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
+  a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.pair_centre = d_pair_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.ptr_scr = scr.ptr; a.t_scr = scr.tcode; a.row_scr = scr.rows;
   a.ptr_wpw = scr.ptr_words_per_wave; a.t_wpw = scr.t_words_per_wave; a.row_wpw = scr.row_words_per_wave;
   a.lam = d_lambda; a.ham = d_ham; a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.moves = d_moves; a.moves_stride = moves_stride;

@@ -127,8 +127,8 @@ static int merge_pairs_body(int64_t nreads, const int32_t *fwd, const int32_t *r
         bufs[2 * p].assign(cap, 0); bufs[2 * p + 1].assign(cap, 0);
         outs[2 * p] = bufs[2 * p].data(); outs[2 * p + 1] = bufs[2 * p + 1].data();
       }
-      // the device aligner takes a bounded batch per call (one pair per wave slot)
-      const size_t CH = 8192;
+      // the device aligner takes a bounded batch per call: 64 pairs to a wave, 65 536 pairs fill the 1 024 SIMDs once
+      const size_t CH = 65536;
       for (size_t p0 = 0; p0 < P; p0 += CH) {
         const int n = (int)std::min(CH, P - p0);
         const int rc = dada2hip_nwvec(n, s1.data() + p0, s2.data() + p0, match, mismatch, gap, /*band=*/-1, /*endsfree=*/1, device,

@@ -72,3 +72,10 @@ def test_emulated_exact_bud_ties_settled_on_the_device_or_the_host(emu_lib):
     one candidate in the lowest partition) next to those it must leave to the host (moved members, several in one partition)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_ties.py"), "1", "2"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "zero ties: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_emulated_merge_pairs_goldens_with_packed_pairs(emu_lib):
+    """dada2hip_merge_pairs on the emulated library: unbanded alignments on the lane kernel with a centre per work item (64
+    unrelated pairs to a wave), rows equal to the goldens made with the reference's C_nwalign / C_eval_pair / C_pair_consensus."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_merge.py"), "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "merge goldens: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
