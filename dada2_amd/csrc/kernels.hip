@@ -514,7 +514,7 @@ static __device__ __forceinline__ void nw_traceback_lambda(const NwArgs &a, cons
   if (active) { a.lam[r] = l; a.ham[r] = h; }
 }
 
-template <int WMAX>
+template <int WMAX, bool PAIRS>   // PAIRS: a centre per work item (NwArgs::pair_centre) instead of one per wave
 __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
   constexpr int NPW = (2 * WMAX + 31) / 32;   // pointer words per row
   constexpr int NW32 = (WMAX + 15) / 16;      // raw-window words (2-bit codes)
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
   for (int chunk = gwave; chunk * 64 < nwork; chunk += nwaves) {
     const int idx = chunk * 64 + lane;
-    const bool pairs = a.pair_centre != nullptr;
+    constexpr bool pairs = PAIRS;
     const int c = pairs ? a.pair_centre[idx < nwork ? idx : nwork - 1]
                         : gcn_readfirstlane(a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
     int r = idx < nwork ? a.work[idx] : -1;
@@ -633,6 +633,7 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
 // Generic variant for any band (incl. unbanded, band < 0) and any length difference: same recurrence,
 // DP row kept in an HBM/L2 scratch row [k][lane] instead of registers.  Used only when the band
 // window does not fit the register classes (default nwalign() calls, exotic BAND_SIZE).
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
   extern __shared__ double s_err[];
   for (int i = threadIdx.x; i < 16 * a.ap.ncol; i += blockDim.x) s_err[i] = a.err[i];
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
   const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap;
   for (int chunk = gwave; chunk * 64 < nwork; chunk += nwaves) {
     const int idx = chunk * 64 + lane;
-    const int c = a.pair_centre ? a.pair_centre[idx < nwork ? idx : nwork - 1] : (a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
+    const int c = PAIRS ? a.pair_centre[idx < nwork ? idx : nwork - 1] : (a.chunk_centre ? a.chunk_centre[chunk] : a.centre);
     int r = idx < nwork ? a.work[idx] : -1;
     const bool active = r >= 0;
     if (!active) r = c;
@@ -1686,17 +1687,20 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
   a.lam = d_lambda; a.ham = d_ham; a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.moves = d_moves; a.moves_stride = moves_stride;
   a.nmoves = d_nmoves;
   size_t lds = (size_t)16 * ap.ncol * sizeof(double);
+#define D2_NW_CLASS(W)                                                                                              \
+  case W:                                                                                                           \
+    if (d_pair_centre) hipLaunchKernelGGL((k_nw<W, true>), dim3(grid), dim3(256), lds, st, a);                      \
+    else hipLaunchKernelGGL((k_nw<W, false>), dim3(grid), dim3(256), lds, st, a);                                   \
+    break;
   switch (wclass) {
-    case 33: hipLaunchKernelGGL(k_nw<33>, dim3(grid), dim3(256), lds, st, a); break;
-    case 65: hipLaunchKernelGGL(k_nw<65>, dim3(grid), dim3(256), lds, st, a); break;
-    case 129: hipLaunchKernelGGL(k_nw<129>, dim3(grid), dim3(256), lds, st, a); break;
-    case 193: hipLaunchKernelGGL(k_nw<193>, dim3(grid), dim3(256), lds, st, a); break;
-    case 257: hipLaunchKernelGGL(k_nw<257>, dim3(grid), dim3(256), lds, st, a); break;
+    D2_NW_CLASS(33) D2_NW_CLASS(65) D2_NW_CLASS(129) D2_NW_CLASS(193) D2_NW_CLASS(257)
     default: {
       int Wgen = (ap.band < 0) ? (2 * S.maxlen + 1) : (2 * ap.band + (S.maxlen - S.minlen) + 1);
-      hipLaunchKernelGGL(k_nw_gen, dim3(grid), dim3(256), lds, st, a, Wgen);
+      if (d_pair_centre) hipLaunchKernelGGL(k_nw_gen<true>, dim3(grid), dim3(256), lds, st, a, Wgen);
+      else hipLaunchKernelGGL(k_nw_gen<false>, dim3(grid), dim3(256), lds, st, a, Wgen);
     }
   }
+#undef D2_NW_CLASS
 }
 
 // ================================================================================================
