@@ -514,7 +514,10 @@ static __device__ __forceinline__ void nw_traceback_lambda(const NwArgs &a, cons
   if (active) { a.lam[r] = l; a.ham[r] = h; }
 }
 
-template <int WMAX, bool PAIRS>   // PAIRS: a centre per work item (NwArgs::pair_centre) instead of one per wave
+// PAIRS: a centre per work item (NwArgs::pair_centre) instead of one per wave.  PLAIN: the default aligner (ends-free, one gap
+// penalty) with the switches of the other two compiled out - they cost the inner loop a quarter of its speed when they are
+// run-time flags (bimera table 3 000 x 8: 1.25 s against 0.99 s)
+template <int WMAX, bool PAIRS, bool PLAIN>
 __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
   constexpr int NPW = (2 * WMAX + 31) / 32;   // pointer words per row
   constexpr int NW32 = (WMAX + 15) / 16;      // raw-window words (2-bit codes)
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(256) void k_nw(NwArgs a) {
 
     // the other two scalar aligners of the reference ride on the same sweep (wave-uniform switches): EF = ends-free (first
     // row / column 0, free moves along the last row / column), HOMO = a gap opposite a homopolymer base costs HG
-    const bool EF = a.ap.endsfree != 0, HOMO = EF && a.ap.homo_gap != GAP;
+    const bool EF = PLAIN ? true : a.ap.endsfree != 0, HOMO = PLAIN ? false : (EF && a.ap.homo_gap != GAP);
     const int HG = a.ap.homo_gap;
     int d[WMAX];
     // row 0: D[0][j] = 0 (global: j * gap) for 0 <= j <= min(rband, L2)
@@ -1689,8 +1692,9 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
   size_t lds = (size_t)16 * ap.ncol * sizeof(double);
 #define D2_NW_CLASS(W)                                                                                              \
   case W:                                                                                                           \
-    if (d_pair_centre) hipLaunchKernelGGL((k_nw<W, true>), dim3(grid), dim3(256), lds, st, a);                      \
-    else hipLaunchKernelGGL((k_nw<W, false>), dim3(grid), dim3(256), lds, st, a);                                   \
+    if (d_pair_centre) hipLaunchKernelGGL((k_nw<W, true, false>), dim3(grid), dim3(256), lds, st, a);               \
+    else if (ap.plain()) hipLaunchKernelGGL((k_nw<W, false, true>), dim3(grid), dim3(256), lds, st, a);             \
+    else hipLaunchKernelGGL((k_nw<W, false, false>), dim3(grid), dim3(256), lds, st, a);                            \
     break;
   switch (wclass) {
     D2_NW_CLASS(33) D2_NW_CLASS(65) D2_NW_CLASS(129) D2_NW_CLASS(193) D2_NW_CLASS(257)
