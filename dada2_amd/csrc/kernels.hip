@@ -732,17 +732,16 @@ static __device__ __forceinline__ uint32_t ad_ptr_code(bool from_up, bool left_g
 // a per-lane register: GAP for an in-band cell, AD_OOB for the others), so they sit about 10^6 below the band and never
 // win a max in an in-band neighbour — one select less on every step.
 constexpr int AD_OOB = -(1 << 20);
-constexpr int AD_VAR_DEFAULT = 2;   // r02o A/B at 8 700 alignments: 69.7 (0) / 66.9 (1) / 63.3 us (2)
-// VAR selects the steady-state formulation (A/B knob DADA2HIP_AD_VARIANT): 0 = sentinel select, 1 = additive mask,
-// 2 = additive mask + v_max3.  vnext = the one base that changes for the next step (raw base after an even cell, centre
-// base after an odd one), loaded by the caller.
-template <int GL, int PAR, bool DEF, bool LEAN, bool EDGE, int VAR>
+// (round 2 kept three steady-state formulations behind a knob - sentinel select, additive mask, additive mask + v_max3:
+// 69.7 / 66.9 / 63.3 us at 8 700 alignments, profiles/r02o - only the last one is left.)  vnext = the one base that changes for the
+// next step (raw base after an even cell, centre base after an odd one), loaded by the caller.
+template <int GL, int PAR, bool DEF, bool LEAN, bool EDGE>
 static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
                                                uint32_t vnext, int fs, bool g_first, bool g_last,
                                                bool kok, int gsel, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
   // DEF: the reference's default scoring (MATCH 5, MISMATCH -4, GAP -8, vectorized sentinel) as literals
   const int SENT = DEF ? -32760 : SENT_, MATCH = DEF ? 5 : MATCH_, MISMATCH = DEF ? -4 : MISMATCH_, GAP = DEF ? -8 : GAP_;
-  if (LEAN && !EDGE && VAR >= 1) {
+  if (LEAN && !EDGE) {
     // steady state, band inside the lane group: the DPP neighbour needs no masking (lanes without a source read 0, they
     // are out of band), the fetch folds into the add, the two max into one v_max3
     const int nb = PAR == 0 ? gcn_wave_shr1<true>(0, d1)     // lane-1's odd cell (wave_shr:1)
@@ -750,16 +749,8 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
     const int own = PAR == 0 ? d0 : d1, other = PAR == 0 ? d1 : d0;
     const int diag = own + (cb == rb ? MATCH : MISMATCH);
     const int left = (PAR == 0 ? nb : other) + gsel, up = (PAR == 0 ? other : nb) + gsel;
-    int e;
-    bool t2;
-    if (VAR == 2) {                                          // (spelled out: the compiler would keep the inner max for t2)
-      e = gcn_max3(left, diag, up);
-      t2 = up == e;                                          // up >= max(left, diag)  <=>  the maximum IS up
-    } else {
-      const int e1 = max(left, diag);
-      t2 = up >= e1;
-      e = max(up, e1);
-    }
+    const int e = gcn_max3(left, diag, up);                  // (spelled out: the compiler would keep the inner max for t2)
+    const bool t2 = up == e;                                  // up >= max(left, diag)  <=>  the maximum IS up
     const bool t1 = left >= diag;
     if (PAR == 0) { d0 = e; rb = vnext; j++; } else { d1 = e; cb = vnext; i++; }
     pw = gcn_push_low2(pw, ad_ptr_code(t2, t1));
@@ -888,7 +879,7 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   return G;
 }
 
-template <int GL, bool DEF, bool EDGE, int VAR>
+template <int GL, bool DEF, bool EDGE>
 __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                AdGeom G) {
   constexpr int APW = 64 / GL;
@@ -1029,7 +1020,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 #define AD_STEP(PARV, LEANV, VNEXT, FS, KOK, GS)                                                                                   \
   {                                                                                                                             \
     if (DEF) ad_step_k<GL, PARV, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), (PARV) ? gn1 : gn0, L1, L2); \
-    else ad_step<GL, PARV, DEF, LEANV, EDGE, VAR>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    else ad_step<GL, PARV, DEF, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2, SENT, MATCH, MISMATCH, GAP); \
   }
 #define AD_FULL_STEP(TT)                                                                                                        \
   {                                                                                                                             \
@@ -1232,31 +1223,23 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   if (d_gl_work || batch) waves = (S.N + G.APW - 1) / G.APW;
   int grid = std::max(1, std::min((waves + 3) / 4, std::min(256 * 8, S.ad_waves / 4)));   // one slot of the pointer ring per wave
   const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
-#define D2_LAUNCH_AD(GLV, DEFV, EDGEV, VARV)                                                                                 \
+#define D2_LAUNCH_AD(GLV, DEFV, EDGEV)                                                                                       \
   do {                                                                                                                   \
     static size_t attr_set[64] = {0};   /* per device: the attribute belongs to the function ON a device */            \
     int dev_ = 0;                                                                                                        \
     (void)hipGetDevice(&dev_);                                                                                           \
     if (lds > attr_set[dev_ & 63]) {                                                                                     \
-      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV, VARV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_set[dev_ & 63] = lds;                                                                                         \
     }                                                                                                                    \
-    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV, VARV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);  \
+    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);  \
   } while (0)
 #define D2_LAUNCH_AD2(GLV)                                                                                               \
   do {                                                                                                                   \
-    if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true, AD_VAR_DEFAULT); else D2_LAUNCH_AD(GLV, true, false, AD_VAR_DEFAULT); } \
-    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true, AD_VAR_DEFAULT); else D2_LAUNCH_AD(GLV, false, false, AD_VAR_DEFAULT); }   \
+    if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true); else D2_LAUNCH_AD(GLV, true, false); } \
+    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true); else D2_LAUNCH_AD(GLV, false, false); }   \
   } while (0)
-  // the common shape (default band and scores) exists in all three steady-state formulations for A/B runs
-  const char *ve = getenv("DADA2HIP_AD_VARIANT");
-  const int var = ve ? atoi(ve) : AD_VAR_DEFAULT;
-  if (G.GL == 21 && def && !G.edge && var != AD_VAR_DEFAULT) {
-    if (var == 0) D2_LAUNCH_AD(21, true, false, 0);
-    else if (var == 1) D2_LAUNCH_AD(21, true, false, 1);
-    else D2_LAUNCH_AD(21, true, false, 2);
-  }
-  else if (G.GL == 21) D2_LAUNCH_AD2(21);
+  if (G.GL == 21) D2_LAUNCH_AD2(21);
   else if (G.GL == 32) D2_LAUNCH_AD2(32);
   else D2_LAUNCH_AD2(64);
 #undef D2_LAUNCH_AD2

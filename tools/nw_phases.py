@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--uniques", type=int, default=300000)
     ap.add_argument("--sizes", default="2000,4000,8700,18000,36000")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--variants", default="", help="comma list of DADA2HIP_AD_VARIANT values to compare (A/B of the DP step)")
     a = ap.parse_args()
     from dada2_amd import api
     from dada2_amd.opts import DadaOpts
@@ -41,12 +40,8 @@ def main():
         keep = rng.choice(nw_idx, size=size, replace=False)
         skip = np.ones(d.nraw, dtype=np.uint8)
         skip[keep] = 0
-        combos = [(v, None) for v in a.variants.split(",") if v] or [(None, None)]
-        for var, pk in combos:
+        for _once in (0,):
             row = {"batch": size}
-            if var is not None:
-                os.environ["DADA2HIP_AD_VARIANT"] = var
-                row["variant"] = int(var)
             for bits in (0, 2, 3, 4, 8, 15):   # (bit 1 alone would walk garbage pointers and trip the range flag)
                 os.environ["DADA2HIP_AD_DEBUG"] = str(bits)
                 t = []
