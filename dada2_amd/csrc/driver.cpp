@@ -1218,7 +1218,7 @@ struct Run {
   DevBuf<double> v2_lam0, v2_lam1;
   DevBuf<uint32_t> v2_ham0, v2_ham1;
   DevBuf<int32_t> v2_i1;
-  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_listn, v2_sig, v2_n0d, v2_blist, v2_blistn;
+  DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_sig, v2_n0d, v2_blist, v2_blistn;
   DevBuf<double> v2_lamB;
   DevBuf<uint32_t> v2_hamB;
   DevBuf<uint8_t> v2_moved;
@@ -1253,8 +1253,6 @@ struct Run {
     E2.C.NBUF = v2_nbuf; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
     E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15;
     E2.C.lamB = v2_lamB.p; E2.C.hamB = v2_hamB.p; E2.blist = v2_blist.p; E2.blist_n = v2_blistn.p;
-    E2.cls = s->d_cls.p; E2.lam = s->d_lambda.p; E2.ham = s->d_ham.p;
-    E2.nw_list = s->d_nw_list.p; E2.gl_list = s->d_gl_list.p; E2.list_n = v2_listn.p;
     E2.ctl = v2_ctl.p; E2.dblk = v2_dblk.p; E2.hblk = v2_hblk.p; E2.dlt = v2_dlt.p; E2.movers = v2_movers.p;
     E2.partial = d_partial.p; E2.ties0 = d_ties0.p; E2.ties1 = d_ties1.p; E2.ccap = ccap;
     E2.sig_list = v2_sig.p + 4; E2.sig_n = v2_sig.p; E2.ties_rec = v2_tiesrec.p;
@@ -1307,7 +1305,7 @@ struct Run {
     v2_blist.alloc((size_t)2 * KB_MAX * (((size_t)N + 31) & ~(size_t)15)); v2_blistn.alloc(2 * KB_MAX);
     D2_HIP(hipMemsetAsync(v2_blistn.p, 0, 2 * KB_MAX * 4, stq));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
-    v2_listn.alloc(2); v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
+    v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
     v2_moved.alloc(n); v2_n0d.alloc(2 * SH_CHAIN + 4); v2_statpart.alloc((size_t)4 * 8192);
     D2_HIP(hipMemsetAsync(v2_moved.p, 0, n, stq));
     D2_HIP(hipMemsetAsync(v2_n0d.p, 0, (2 * SH_CHAIN + 4) * 4, stq));
@@ -1316,7 +1314,6 @@ struct Run {
     D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));
     D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_CHAIN * ccap * 4, stq));
     D2_HIP(hipMemsetAsync(v2_slotc.p, 0xFF, slots * 4, stq));
-    D2_HIP(hipMemsetAsync(v2_listn.p, 0, 8, stq));
     for (int k = 0; k < RING2; k++) v2_hblk.p[k].seq = 0;
     Ctl2 c;
     memset(&c, 0, sizeof c);

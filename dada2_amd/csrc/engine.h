@@ -357,11 +357,6 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   uint8_t *moved;                 // [N] the unique has been moved by a shuffle or a birth
   int32_t *n0d;                   // [SH_CHAIN][2] members partition 0 lost / gained in each of the chain's shuffle calls
   int32_t *movers;                // [RING2][SH_CHAIN][3 N]
-  // the round's comparisons (cluster.cpp:90-149): class per unique, work lists, then lambda / hamming from the aligner
-  uint8_t *cls;
-  double *lam;
-  uint32_t *ham;
-  int32_t *nw_list, *gl_list, *list_n;
   uint32_t *stat_part;            // [grid of the store pass][4] per-block class counts of the round (NW, gapless, shrouded, skipped)
   int32_t *stat_n;                // number of entries in stat_part (0: the chain had no store pass), consumed by k2_birth
   int32_t *blist, *blist_n;       // [2 KB_MAX][Npad] / [2 KB_MAX]: work lists of the batch compare (NwBatch)
