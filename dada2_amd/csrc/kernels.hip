@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       if (nb <= 0) return;
 #pragma unroll
       for (int k = 0; k < KB_MAX; k++) bk[k + 1] = bk[k] + (k < nb ? (a.batch_n[k] + 4 * APW - 1) / (4 * APW) : 0);   // (the gapless rows: k_gapless_batch)
-      if (bk[KB_MAX] <= 0) return;
+      if ((int)blockIdx.x >= bk[KB_MAX]) return;
     } else {
       const int n_all = (a.nwork_dev ? *a.nwork_dev : a.nwork_host) + (gl_work ? *gl_nwork_dev : 0);
       if ((int)blockIdx.x * 4 * APW >= n_all) return;
@@ -943,39 +943,10 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   int kcur = -1;
   // one iteration = one work slice of the block (4 waves x APW alignments); it = blockIdx.x + j gridDim.x, so a wave's
   // chunk index it * 4 + wib runs over gwave + j nwaves
-  int it_begin = blockIdx.x, it_step = gridDim.x, it_end = batch ? bk[KB_MAX] : 0x7FFFFFFF;
-  if (batch) {
-    // The blocks of the launch are DEALT to the batch positions in proportion to their work, so a block works on one centre
-    // only: it stages that centre once and never meets the barrier of a restage again (walking the slices of all positions
-    // in turn, every block restaged eight times and its waves waited for each other each time: 372 us per launch of 74 k
-    // alignments against 300 for the same work in one-centre launches).  Share of position k: its slices x blocks / all
-    // slices, at least one block; if the grid is too small for that (tiny samples) the blocks walk all slices in turn.
-    const int G = (int)gridDim.x, tot = bk[KB_MAX];
-    int share[KB_MAX], sum = 0;
-#pragma unroll
-    for (int k = 0; k < KB_MAX; k++) {
-      const int sl = bk[k + 1] - bk[k];
-      share[k] = sl > 0 ? max(1, (int)(((long long)sl * G) / tot)) : 0;
-      if (share[k] > sl) share[k] = sl;                      // (more blocks than slices help nobody)
-      sum += share[k];
-    }
-    if (sum <= G) {
-      int b = blockIdx.x, kk = -1, lb = 0, sh = 0;
-#pragma unroll
-      for (int k = 0; k < KB_MAX; k++) {
-        if (kk < 0 && b < share[k]) { kk = k; lb = b; sh = share[k]; }
-        if (kk < 0) b -= share[k];
-      }
-      if (kk < 0) return;                                    // (a block left over by the rounding)
-#pragma unroll
-      for (int k = 0; k < KB_MAX; k++) if (k == kk) { it_begin = bk[k] + lb; it_end = bk[k + 1]; }
-      it_step = sh;
-    }
-  }
-  for (int it = it_begin;; it += it_step) {
+  for (int it = blockIdx.x;; it += gridDim.x) {
     int chunk, c;
     if (batch) {
-      if (it >= it_end) break;                               // (block-uniform: the barriers below are safe)
+      if (it >= bk[KB_MAX]) break;                           // (block-uniform: the barriers below are safe)
       int k = 0, b0 = 0;                                     // the last position whose first slice is <= it (bk is nondecreasing)
 #pragma unroll
       for (int q = 1; q < KB_MAX; q++) if (it >= bk[q]) { k = q; b0 = bk[q]; }
