@@ -80,7 +80,7 @@ def _share_torch_hip_runtime():
     copy is mapped first serves both torch and this library, and torch does not see a device through the system copy.  So if
     torch is INSTALLED (it is not imported here, and nothing of torch is used) its copy is mapped before libdada2hip.so asks
     for the SONAME - `import dada2_amd` and `import torch` then work in either order.  DADA2HIP_SYSTEM_HIP=1 skips this."""
-    if os.environ.get("DADA2HIP_SYSTEM_HIP") or "emu" in os.path.basename(LIB_PATH):
+    if os.environ.get("DADA2HIP_SYSTEM_HIP"):
         return
     try:
         import importlib.util

@@ -34,6 +34,7 @@ def stale(target, deps):
 
 
 def build(force=False):
+    os.environ.setdefault("DADA2HIP_SYSTEM_HIP", "1")   # (the emulated library links no HIP runtime: nothing to share with torch)
     os.makedirs(os.path.join(OUT, "csrc"), exist_ok=True)
     os.makedirs(os.path.join(OUT, "include"), exist_ok=True)
     srcs = sorted(f for f in os.listdir(SRC) if f.endswith((".hip", ".cpp", ".h")))
