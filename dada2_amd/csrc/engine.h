@@ -251,7 +251,7 @@ int nw_adw_apw(const SampleDev &S, const AlignParams &ap);
 constexpr int KB_MAX = 8;          // centres per batch compare (one byte lane each in the packed count table)
 constexpr int SH_CHAIN = 4;        // b_shuffle2 calls enqueued per chain (the first unconditional, the rest guarded)
 constexpr int RING2 = 4;           // result blocks / mover lists in flight
-constexpr int TRACE_BLOCKS = 4096, TRACE_KERNELS = 8;   // (lists, shuffle 0..3, p-update, birth, spare)
+constexpr int TRACE_BLOCKS = 4096, TRACE_KERNELS = 8;   // (slot 0 unused since k2_lists went into the store pass; shuffle 0..3, p-update, birth, spare)
 constexpr int MOV_INLINE2 = 8192;  // movers published inline per chain (all its shuffles, concatenated)
 
 // stored comparisons of one unique (Bi::comp entries that name it): the round-0 entry lives in lam0/ham0 (every

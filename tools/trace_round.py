@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/trace_round.py - phase timeline of the round-tail kernels of a few rounds of the headline run.
 
-Every block of k2_lists / k2_shuffle (levels 0..3) / k2_pupdate / k2_birth stamps the shader clock (s_memtime) at its
+Every block of k2_shuffle (levels 0..3) / k2_pupdate / k2_birth stamps the shader clock (s_memtime) at its
 phase boundaries when DADA2HIP_V2_TRACE=<block sequence number>:<file> is set (Eng2::trace, rounds2.inc.hip).  This
 script runs resident passes of bench.py's sample with the trace on for the requested rounds and prints, per kernel: the
 span from the first block's start to the last block's end, the skew of the block starts, and the time the blocks spend in
@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-KERNELS = ["k2_lists", "k2_shuffle L0 (store)", "k2_shuffle L1", "k2_shuffle L2", "k2_shuffle L3", "k2_pupdate", "k2_birth"]
+KERNELS = ["(k2_lists: folded into the store pass in round 3, no stamps)", "k2_shuffle L0 (commit + store)", "k2_shuffle L1", "k2_shuffle L2", "k2_shuffle L3", "k2_pupdate", "k2_birth"]
 PHASES = {0: ["entry->lists built", "lists written"], 1: ["prologue (tables)", "main loop", "buffers out", "stats", "deltas out"],
           5: ["prologue (tables)", "main loop", "reduce", "sig list out"],
           6: ["fold deltas", "arg-min + ties", "decision", "flags", "birth + plan", "publish"]}
