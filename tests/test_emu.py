@@ -47,8 +47,10 @@ def run_cases(emu_lib, names, env=None, timeout=900):
 
 
 @pytest.mark.parametrize("env", [{}, {"DADA2HIP_ENGINE": "classic"}, {"DADA2HIP_NW_KERNEL": "lane"}, {"DADA2HIP_NW_KERNEL": "wide"},
-                                 {"DADA2HIP_V2_ALIGN": "commit"}, {"DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_NBUF": "1"}],
-                         ids=["default", "classic-engine", "lane-kernel", "wide-kernel", "align-at-commit", "nolite-nbuf1"])
+                                 {"DADA2HIP_V2_ALIGN": "commit"}, {"DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_NBUF": "1"},
+                                 {"DADA2HIP_V2_ALIGN": "commit", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_CHAIN": "1", "DADA2HIP_NODE_CAP": "1"}],
+                         ids=["default", "classic-engine", "lane-kernel", "wide-kernel", "align-at-commit", "nolite-nbuf1",
+                              "commit-nbuf1-chain1-grow"])
 def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
     out = run_cases(emu_lib, ("sam1F_default", "sam1R_default"), env)
     assert "ok sam1F_default 10 " in out
