@@ -517,7 +517,6 @@ struct Run {
   ~Run() {
     for (auto &e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto g : v2_graph) if (g) (void)hipGraphExecDestroy(g);
-    for (auto ev : v2_pub_ev) if (ev) (void)hipEventDestroy(ev);
   }
 
   void logf(const char *fmt, ...) {
@@ -1269,7 +1268,6 @@ struct Run {
     if (const char *e = getenv("DADA2HIP_V2_GRID_PUPDATE")) E2.grid_pupdate = std::max(1, atoi(e));
     E2.has_compare = 1;
     E2.align_at_commit = v2_align_commit ? 1 : 0;
-    E2.side_publish = v2_side_pub ? 1 : 0;
     E2L = E2; E2L.has_compare = 0;
     v2_drop_graph();                 // (captured launches hold the old argument block)
   }
@@ -1340,10 +1338,6 @@ struct Run {
     v2_align_commit = nw_ad_apw(s->D, ap) == 1;
     if (const char *e = getenv("DADA2HIP_V2_ALIGN")) v2_align_commit = !strcmp(e, "commit");
     if (v2_align_commit) v2_lite_on = false;                   // (every chain carries the aligner's launches)
-    v2_side_pub = false;
-    if (const char *e = getenv("DADA2HIP_V2_SIDEPUB")) v2_side_pub = atoi(e) != 0 && graph_off() && !profile_all;
-    if (v2_side_pub)
-      for (auto &ev : v2_pub_ev) if (!ev) D2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     v2_plain_rounds = 0;
     v2_miss_launches = 0;
     v2_enqrec.clear();
@@ -1361,8 +1355,6 @@ struct Run {
   long v2_next_full = 0;             // first chain (sequence number) that is expected to need a batch compare again
   bool v2_lite_on = true;
   bool v2_align_commit = false;       // Eng2::align_at_commit
-  bool v2_side_pub = false;           // Eng2::side_publish
-  hipEvent_t v2_pub_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void v2_drop_graph() {
     for (auto &g : v2_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
     if (v2_graph_state == 1) v2_graph_state = 0;
@@ -1398,12 +1390,6 @@ struct Run {
     else {
       v2_round_launches(nlev, with_compare, store, &rec, lite);
       if (with_compare) v2_plain_rounds++;
-    }
-    if (v2_side_pub) {   // the result block goes to the host from the second stream, behind this chain
-      hipEvent_t ev = v2_pub_ev[v2_enq & 7];
-      D2_HIP(hipEventRecord(ev, s->stream));
-      D2_HIP(hipStreamWaitEvent(s->side, ev, 0));
-      launch2_publish(E2, (int)(v2_enq % RING2), (int)(v2_enq + 1), s->side);
     }
     if (lite) st.lite_chains++;   // (sending the chains behind an expected refill without a compare as well was tried: as many
                                   //  more wrong guesses as it saved launches, profiles/README.md r03u)
@@ -1450,7 +1436,6 @@ struct Run {
       if (polite && spins > 64) { struct timespec ts{0, 20000}; nanosleep(&ts, nullptr); }
       if ((spins & 0xFFFF) == 0xFFFF || (polite && (spins & 0xFF) == 0xFF)) {
         hipError_t e = hipStreamQuery(s->stream);
-        if (e == hipSuccess && v2_side_pub) e = hipStreamQuery(s->side);   // (the block comes from the second stream)
         if (e != hipSuccess && e != hipErrorNotReady)
           throw d2::DeviceError{DADA2HIP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e) + " (round result)"};
         if (e == hipSuccess && *seqp != want)
@@ -1624,7 +1609,6 @@ struct Run {
               n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_halt[6], (unsigned long long)st.lite_chains, n_big, st.ms_wait_device, st.ms_replay, st.ms_enqueue, t_decide, t_halt, t_top,
               ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches, n_kind[0], n_kind[1], n_kind[2], n_kind[3], n_kind[4]);
     sync_spin(s->stream);                                      // no-op launches queued behind the final halt
-    if (v2_side_pub) D2_HIP(hipStreamSynchronize(s->side));
     if (v2_trace_seq >= 0 && v2_trace.p) {                     // dump the traced round's stamps (tools/trace_round.py reads them)
       const char *e = getenv("DADA2HIP_V2_TRACE");
       const char *colon = e ? strchr(e, ':') : nullptr;

@@ -381,10 +381,6 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   // last batch held).  When it guessed wrong - the prediction of the coming centres failed early - the chain's kernels see
   // need_compare without has_compare, do nothing, and k2_birth reports H2_NEED_COMPARE: the host sends a full chain.
   int32_t has_compare;
-  // 1: k2_birth leaves the result block in device memory and a one-block kernel on a SECOND stream (k2_publish, behind an
-  // event) copies it to the host - the chain's own stream then never executes a system-scope release (experiment:
-  // DADA2HIP_V2_SIDEPUB=1; the idle behind k2_birth is what it is after)
-  int32_t side_publish;
   // When are the pairs of a cached screen aligned?  0: all positions of a batch at once, right behind its screen - a launch
   // of eight rounds' work runs in the aligner's saturated regime, at the price of the pairs a later greedy skip or an unused
   // position wastes (10 % at 250 nt).  1: each centre's pairs when its round commits, with the greedy skip of that moment -
@@ -403,7 +399,6 @@ void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
 // b_p_update + b_bud arg-min (grid) ; ties, decision, birth, plan of the coming round, publication (one block)
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st);            // the host's decision applied + plan; resumes
-void launch2_publish(const Eng2 &E, int ring, int seq, hipStream_t st);               // (Eng2::side_publish)
 void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list = false);   // keep_list: the candidates k2_pupdate listed stay valid
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st);

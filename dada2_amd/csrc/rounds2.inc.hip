@@ -701,15 +701,10 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
   plan_aligner(E, raw, ctl->bbuf * KB_MAX, nb);
 }
 
-// the copy of a result block to the pinned host mirror: plain stores, then the sequence number with a system-scope release
 static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
   // plain stores to pinned host memory, then the sequence number: the host polls it instead of copying and synchronising
   Ctl2 *ctl = E.ctl;
   __syncthreads();
-  if (E.side_publish) {   // (k2_publish on the second stream does the copy; the block says which chain completed it)
-    if (threadIdx.x == 0) { const int seq = ctl->pub_seq + 1; out->seq = seq; ctl->pub_seq = seq; }
-    return;
-  }
   int tot = 0;
   for (int l = 0; l < SH_CHAIN; l++) tot += out->cnt[l];
   if (tot > MOV_INLINE2) tot = MOV_INLINE2;
@@ -729,27 +724,6 @@ static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
     __threadfence_system();
     __hip_atomic_store(&E.hblk[ring].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     ctl->pub_seq = seq;
-  }
-}
-
-__global__ __launch_bounds__(1024) void k2_publish(Eng2 E, int ring, int seq) {
-  const Round2Out *out = E.dblk + ring;
-  if (out->seq != seq) return;                             // (the chain was a no-op behind a halt: nothing to publish)
-  int tot = 0;
-  for (int l = 0; l < SH_CHAIN; l++) tot += out->cnt[l];
-  if (tot > MOV_INLINE2) tot = MOV_INLINE2;
-  const int used16 = (int)((offsetof(Round2Out, mov) + (size_t)12 * tot + 15) / 16);
-  const uint4 *src = (const uint4 *)out;
-  uint4 *dst = (uint4 *)(E.hblk + ring);
-  for (int i = threadIdx.x; i < used16; i += blockDim.x) {
-    uint4 v = src[i];
-    if (i == 0) v.x = (uint32_t)(seq - 1);                 // (word 0 of the block is `seq`: not yet)
-    dst[i] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence_system();
-    __hip_atomic_store(&E.hblk[ring].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1190,7 +1164,6 @@ void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st) 
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st) {
   hipLaunchKernelGGL(k2_host_birth, dim3(1), dim3(1024), 0, st, E, raw, from);
 }
-void launch2_publish(const Eng2 &E, int ring, int seq, hipStream_t st) { hipLaunchKernelGGL(k2_publish, dim3(1), dim3(1024), 0, st, E, ring, seq); }
 void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list) { hipLaunchKernelGGL(k2_resume, dim3(1), dim3(1), 0, st, E, keep_list ? 1 : 0); }
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st) {
