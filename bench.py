@@ -64,6 +64,39 @@ def measured_peaks():
         return None
 
 
+def _cached(make_sample):
+    """Synthetic samples are seeded and deterministic but take minutes to draw at 10^6 uniques / 1.5 kb reads: keep them in a
+    scratch directory (DADA2HIP_BENCH_CACHE, default /tmp/dada2hip_bench_cache; empty string = off) so that the several
+    bench / profiler invocations of one GPU-box session draw each sample once.  Inputs only - nothing computed is cached."""
+    import hashlib
+    from dada2_amd.io import Derep
+    cdir = os.environ.get("DADA2HIP_BENCH_CACHE", "/tmp/dada2hip_bench_cache")
+
+    def wrapped(err, n, **kw):
+        if not cdir:
+            return make_sample(err, n, **kw)
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(err).tobytes())
+        h.update(repr((n, sorted((k, (v[0].tobytes(), v[1].tobytes()) if k == "variants" and v is not None else v) for k, v in kw.items()))).encode())
+        path = os.path.join(cdir, h.hexdigest()[:24] + ".npz")
+        try:
+            if os.path.exists(path):
+                z = np.load(path)
+                return Derep([x.decode() for x in z["seqs"]], z["abundances"], z["quals"], z["map"])
+        except Exception:
+            pass
+        d = make_sample(err, n, **kw)
+        try:
+            os.makedirs(cdir, exist_ok=True)
+            tmp = path + f".{os.getpid()}.tmp.npz"
+            np.savez(tmp, seqs=np.array([x.encode() for x in d.seqs]), abundances=d.abundances, quals=d.quals, map=d.map)
+            os.replace(tmp, path)
+        except Exception:
+            pass
+        return d
+    return wrapped
+
+
 def make_inputs(cfg, args, rank):
     """Synthetic samples of this rank (SURVEY.md §8d recipe) as HostInput objects + the error matrix."""
     from dada2_amd.api import HostInput
@@ -80,6 +113,7 @@ def make_inputs(cfg, args, rank):
         # reads at Q34-40, which gives ~14 reads per unique and several times the partitions for the same number of uniques
         kw.update(q_hi=40.0, q_lo=34.0, q_sd=2.0)
     dereps = []
+    make_sample = _cached(make_sample)
     if c["samples"] == 1:
         dereps.append(make_sample(err, n, seed=20260925 + cfg + (0 if getattr(args, "shard", False) else 1000 * rank), **kw))
         mine = [0]

@@ -1212,7 +1212,9 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   a.S = S; a.centre = centre; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_dev = d_nwork;
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
   a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev; a.stop_dev = d_stop_dev;
-  { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }   // profiling knob: skip phases
+#ifdef DADA2HIP_PROFILING   // `make prof` only (libdada2hip_prof.so, tools/nw_phases.py): skipping phases voids the results
+  { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }
+#endif
   if (batch) {
     a.batch_on = batch->on; a.batch_n = batch->n; a.batch_list = batch->list; a.batch_centre = batch->centre; a.batch_bbuf = batch->bbuf;
     a.batch_stride = batch->stride;

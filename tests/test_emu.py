@@ -81,3 +81,46 @@ def test_emulated_merge_pairs_goldens_with_packed_pairs(emu_lib):
     unrelated pairs to a wave), rows equal to the goldens made with the reference's C_nwalign / C_eval_pair / C_pair_consensus."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_merge.py"), "1"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "merge goldens: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def _seeded_through_emulator(emu_lib, cases, env=None, timeout=1500):
+    code = (
+        "import sys\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from dada2_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "from helpers import seeded_option_sample, assert_results_equal, tperr1\n"
+        "from dada2_amd import api\n"
+        "from dada2_amd.opts import DadaOpts\n"
+        "from oracle import cport\n"
+        "for seed, kw in %r:\n"
+        "    d, pri = seeded_option_sample(seed)\n"
+        "    o = DadaOpts(**kw)\n"
+        "    got = api.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)\n"
+        "    want = cport.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)\n"
+        "    assert_results_equal(got, want, check_birth_from=pri is None)\n"
+        "    print('ok', seed, got.nclust, got.stats['nnw'])\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib, list(cases))
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0 and out.stdout.count("ok ") == len(cases), out.stdout[-2000:] + out.stderr[-4000:]
+
+
+# the band / geometry cases tools/emu_seeded.py used to hold (VERDICT r3: the only non-default-score runs lived in a dev tool)
+EMU_GEOMETRY_CASES = [(10, dict(BAND_SIZE=0)), (11, dict(BAND_SIZE=-1)), (12, dict(BAND_SIZE=40)), (15, dict(BAND_SIZE=1)), (16, dict(BAND_SIZE=18)),
+                      (17, dict(BAND_SIZE=19)), (18, dict(BAND_SIZE=20)),
+                      (20, dict(HOMOPOLYMER_GAP_PENALTY=-1)), (21, dict(HOMOPOLYMER_GAP_PENALTY=-1, BAND_SIZE=32)),
+                      (22, dict(HOMOPOLYMER_GAP_PENALTY=-2, BAND_SIZE=-1)), (23, dict(HOMOPOLYMER_GAP_PENALTY=0, GAP_PENALTY=-6))]
+
+
+@pytest.mark.parametrize("nw_kernel", ["coop", "lane", "wide"])
+def test_emulated_option_sweep_with_user_scores_and_sse1(emu_lib, nw_kernel):
+    """tests/helpers.py's seeded option sweep through the emulated library on each aligner family - including MATCH / MISMATCH /
+    GAP_PENALTY away from 5 / -4 / -8 (the general-score instances of k_nw_ad) and SSE = 1."""
+    from helpers import BASE_OPTION_CASES, SCORE_OPTION_CASES
+    _seeded_through_emulator(emu_lib, BASE_OPTION_CASES + SCORE_OPTION_CASES, {"DADA2HIP_NW_KERNEL": nw_kernel})
+
+
+def test_emulated_band_geometries(emu_lib):
+    _seeded_through_emulator(emu_lib, EMU_GEOMETRY_CASES, {"DADA2HIP_NW_KERNEL": "coop"})

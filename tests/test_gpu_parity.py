@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, WHOLE_PATH_CASES, P_RTOL, assert_results_equal, case_inputs, load_input, tperr1
+from helpers import (BAND_OPTION_CASES, BASE_OPTION_CASES, GOLDEN, SCORE_OPTION_CASES, WHOLE_PATH_CASES, P_RTOL, assert_results_equal,
+                     case_inputs, load_input, long_read_sample, seeded_option_sample, tperr1)
 from dada2_amd.io import extend_err
 from dada2_amd.opts import DadaOpts
 
@@ -76,21 +77,62 @@ def _sample(seed, n, L=120, G=8, Lmin=None, indel=0.0):
     return make_sample(tperr1(), n, L=L, G=G, seed=seed, Lmin=Lmin, indel_rate=indel, chunk=4000)
 
 
-@pytest.mark.parametrize("seed,kw", [
-    (1, {}), (2, dict(BAND_SIZE=4)), (3, dict(GREEDY=False, GAPLESS=False)), (4, dict(USE_KMERS=False)),
-    (5, dict(MIN_FOLD=2, MIN_HAMMING=2, MIN_ABUNDANCE=2)), (6, dict(OMEGA_A=1e-4, OMEGA_C=1e-2)),
-    (7, dict(SSE=0)), (8, dict(VECTORIZED_ALIGNMENT=False, KDIST_CUTOFF=0.3)), (9, dict(MAX_CLUST=3)),
-    (10, dict(BAND_SIZE=0)), (11, dict(BAND_SIZE=-1)), (12, dict(BAND_SIZE=40)),
-])
+_ids = lambda v: str(v) if isinstance(v, int) else ("-".join(f"{k}={x}" for k, x in v.items()) or "default")
+
+
+@pytest.mark.parametrize("seed,kw", BASE_OPTION_CASES + BAND_OPTION_CASES, ids=_ids)
 def test_seeded_samples_match_oracle(api, oracle_c, seed, kw, monkeypatch):
     monkeypatch.setenv("DADA2HIP_NW_KERNEL", ("lane", "coop", "wide")[seed % 3])
-    ragged = seed % 2 == 0
-    d = _sample(seed, 800, Lmin=100 if ragged else None, indel=2e-3 if ragged else 0.0)
+    d, pri = seeded_option_sample(seed)
     o = DadaOpts(**kw)
-    pri = (np.arange(d.nraw) % 17 == 3).astype(np.uint8) if seed == 6 else None
     got = api.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)
     want = oracle_c.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)
     assert_results_equal(got, want, p_rtol=P_RTOL, check_birth_from=pri is None)
+
+
+@pytest.mark.parametrize("nw_kernel", ["coop", "lane", "wide"])
+@pytest.mark.parametrize("seed,kw", SCORE_OPTION_CASES, ids=_ids)
+def test_user_alignment_scores_and_sse1_on_every_aligner_family(api, oracle_c, oracle_ref, seed, kw, nw_kernel, monkeypatch):
+    """MATCH / MISMATCH / GAP_PENALTY are dada() options (/root/reference/R/dada.R:11-13, Rmain.cpp:33-35): they select the
+    non-default instances of k_nw_ad (general scores instead of the 5 / -4 / -8 cost domain), here also on the edge geometry,
+    through the non-vectorised aligner, with ties-prone small scores, and next to SSE = 1 (the 16-bit k-mer screen,
+    nwalign_endsfree.cpp:27-28).  Each case on all three aligner families, against the restatement AND the reference itself."""
+    monkeypatch.setenv("DADA2HIP_NW_KERNEL", nw_kernel)
+    d, pri = seeded_option_sample(seed)
+    o = DadaOpts(**kw)
+    got = api.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)
+    want = oracle_c.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+    assert_results_equal(got, oracle_ref.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o), p_rtol=P_RTOL)
+
+
+@pytest.mark.parametrize("nw_kernel", ["auto", "lane", "wide"])
+def test_reads_longer_than_2047_nt(api, oracle_ref, nw_kernel, monkeypatch):
+    """2.1-2.3 kb reads, band 32, PacBio qualities: longer than one block of k_nw_ad stages (nw_ad_lds_bytes returns 0), so
+    the rounds take k_nw_adw / the lane kernels.  Against the reference itself."""
+    if nw_kernel != "auto":
+        monkeypatch.setenv("DADA2HIP_NW_KERNEL", nw_kernel)
+    d, err = long_read_sample()
+    assert max(map(len, d.seqs)) > 2047
+    o = DadaOpts(BAND_SIZE=32)
+    got = api.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
+    want = oracle_ref.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
+    assert got.nclust == want.nclust > 8
+    assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+def test_full_operon_length_reads_4500_nt(api, oracle_ref):
+    """4.3-4.5 kb reads (PacBio rRNA-operon amplicons; the reference accepts up to 9 998 nt, dada.h:24)."""
+    d, err = long_read_sample(seed=43, n=200, L=4500, Lmin=4300, chunk=2500)
+    o = DadaOpts(BAND_SIZE=32)
+    got = api.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
+    oracle_ref.set_threads(os.cpu_count() or 1)
+    try:
+        want = oracle_ref.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o, multithread=True)
+    finally:
+        oracle_ref.set_threads(1)
+    assert got.nclust == want.nclust > 8
+    assert_results_equal(got, want, p_rtol=P_RTOL)
 
 
 @pytest.mark.parametrize("nw_kernel", ["auto", "lane"])

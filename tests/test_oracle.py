@@ -11,7 +11,8 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (GOLDEN, WHOLE_PATH_CASES, assert_results_equal, case_inputs, tperr1)
+from helpers import (BASE_OPTION_CASES, GOLDEN, SCORE_OPTION_CASES, WHOLE_PATH_CASES, assert_results_equal, case_inputs,
+                     long_read_sample, seeded_option_sample, tperr1)
 from dada2_amd.opts import DadaOpts
 
 
@@ -95,22 +96,26 @@ def _random_sample(seed, n=600, L=120, G=8, Lmin=None, indel=0.0):
     return make_sample(tperr1(), n, L=L, G=G, seed=seed, Lmin=Lmin, indel_rate=indel, chunk=2000)
 
 
-@pytest.mark.parametrize("seed,kw", [
-    (1, {}), (2, dict(BAND_SIZE=4)), (3, dict(GREEDY=False, GAPLESS=False)), (4, dict(USE_KMERS=False)),
-    (5, dict(MIN_FOLD=2, MIN_HAMMING=2, MIN_ABUNDANCE=2)), (6, dict(OMEGA_A=1e-4, OMEGA_C=1e-2)),
-    (7, dict(SSE=0)), (8, dict(VECTORIZED_ALIGNMENT=False, KDIST_CUTOFF=0.3)), (9, dict(MAX_CLUST=3)),
-])
+@pytest.mark.parametrize("seed,kw", BASE_OPTION_CASES + SCORE_OPTION_CASES, ids=lambda v: str(v) if isinstance(v, int) else "-".join(f"{k}={x}" for k, x in v.items()) or "default")
 def test_restatement_vs_reference_live(oracle_c, oracle_ref, seed, kw):
-    ragged = seed % 2 == 0
-    d = _random_sample(seed, Lmin=100 if ragged else None, indel=2e-3 if ragged else 0.0)
+    """The seeded option sweep (tests/helpers.py): restatement == reference, serial and multithreaded - among them the user
+    alignment scores and SSE = 1 that select code paths of their own on both sides."""
+    d, pri = seeded_option_sample(seed, n=600, chunk=2000)
     o = DadaOpts(**kw)
-    pri = None
-    if seed == 6:
-        pri = (np.arange(d.nraw) % 17 == 3).astype(np.uint8)
     for mt in (False, True):
         a = oracle_ref.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o, multithread=mt)
         b = oracle_c.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o, multithread=mt)
         assert_results_equal(a, b, exact_float=True, check_birth_from=pri is None)
+
+
+def test_restatement_vs_reference_reads_longer_than_2047(oracle_c, oracle_ref):
+    """2.1-2.3 kb reads (PacBio-style qualities, band 32): the checker of the -m gpu long-read case, pinned to the reference."""
+    d, err = long_read_sample()
+    o = DadaOpts(BAND_SIZE=32)
+    a = oracle_ref.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
+    b = oracle_c.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
+    assert a.nclust > 8 and max(map(len, d.seqs)) > 2047
+    assert_results_equal(a, b, exact_float=True)
 
 
 # NOTE: there is no "no quality matrix" case to pin: with a 0-row quals matrix the reference

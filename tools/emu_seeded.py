@@ -19,16 +19,10 @@ from dada2_amd.opts import DadaOpts  # noqa: E402
 from dada2_amd.synth import make_sample  # noqa: E402
 from oracle import cport  # noqa: E402
 
-CASES = [(1, {}), (2, dict(BAND_SIZE=4)), (3, dict(GREEDY=False, GAPLESS=False)), (4, dict(USE_KMERS=False)),
-         (5, dict(MIN_FOLD=2, MIN_HAMMING=2, MIN_ABUNDANCE=2)), (6, dict(OMEGA_A=1e-4, OMEGA_C=1e-2)), (7, dict(SSE=0)),
-         (8, dict(VECTORIZED_ALIGNMENT=False, KDIST_CUTOFF=0.3)), (9, dict(MAX_CLUST=3)), (10, dict(BAND_SIZE=0)),
-         (11, dict(BAND_SIZE=-1)), (12, dict(BAND_SIZE=40)), (13, dict(MATCH=4, MISMATCH=-5, GAP_PENALTY=-7)),
-         (14, dict(BAND_SIZE=1)), (15, dict(BAND_SIZE=18)),
-         # band fills the lane group (AdGeom::edge): 21 lanes with W = 39, 32 lanes with W = 61 (ragged), non-default scores there too
-         # homopolymer gapping (nwalign_endsfree_homo; 454 / Ion Torrent data): lane kernels, every band class
-         (20, dict(HOMOPOLYMER_GAP_PENALTY=-1)), (21, dict(HOMOPOLYMER_GAP_PENALTY=-1, BAND_SIZE=32)),
-         (22, dict(HOMOPOLYMER_GAP_PENALTY=-2, BAND_SIZE=-1)), (23, dict(HOMOPOLYMER_GAP_PENALTY=0, GAP_PENALTY=-6)),
-         (17, dict(BAND_SIZE=19)), (18, dict(BAND_SIZE=20)), (19, dict(BAND_SIZE=19, MATCH=4, MISMATCH=-5, GAP_PENALTY=-7))]
+from helpers import BAND_OPTION_CASES, BASE_OPTION_CASES, SCORE_OPTION_CASES  # noqa: E402
+from test_emu import EMU_GEOMETRY_CASES  # noqa: E402
+
+CASES = BASE_OPTION_CASES + BAND_OPTION_CASES + SCORE_OPTION_CASES + [c for c in EMU_GEOMETRY_CASES if c[0] > 12]   # (the tests run the same lists)
 os.environ.setdefault("DADA2HIP_NW_KERNEL", "coop")
 only = [int(x) for x in sys.argv[1:]]
 for seed, kw in CASES:

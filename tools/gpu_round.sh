@@ -16,6 +16,8 @@ for s in $STEPS; do
   case $s in
     tests)   timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=15 > $OUT/gputests.log 2>&1; echo "tests rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests.log ;;
     tests_fast) timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not 1M and not config5 and not config2" --durations=10 > $OUT/gputests_fast.log 2>&1; echo "tests_fast rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_fast.log ;;
+    tests_new) timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -k "${TESTS_K:-user_alignment or longer_than or 4500}" --durations=10 > $OUT/gputests_new.log 2>&1; echo "tests_new rc=$?" >> $OUT/steps.log; tail -15 $OUT/gputests_new.log ;;
+    nwphases5) timeout 900 python tools/nw_phases.py --config 5 --uniques ${NWP_UNIQUES:-60000} --sizes 2000,8000,20000,40000 --reps 3 > $OUT/nw_phases_cfg5.jsonl 2> $OUT/nw_phases_cfg5.err; echo "nwphases5 rc=$?" >> $OUT/steps.log; cat $OUT/nw_phases_cfg5.jsonl; tail -3 $OUT/nw_phases_cfg5.err ;;
     occ)     timeout 300 tools/microbench occ > $OUT/occ.json 2> $OUT/occ.err; echo "occ rc=$?" >> $OUT/steps.log; cat $OUT/occ.json ;;
     launch)  timeout 300 tools/microbench launch > $OUT/launch.json 2> $OUT/launch.err; echo "launch rc=$?" >> $OUT/steps.log; cat $OUT/launch.json ;;
     tests_iter) timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not at_size and not 1M" --durations=10 > $OUT/gputests_iter.log 2>&1; echo "tests_iter rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_iter.log ;;
@@ -31,15 +33,15 @@ for s in $STEPS; do
     bench2)  timeout 600 python bench.py --config 2 --steps 10 --warmup 2 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; echo "bench2 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2.json ;;
     bench2deep) timeout 1200 python bench.py --config 2 --deep --steps 3 --warmup 1 > $OUT/bench_cfg2_deep.json 2> $OUT/bench_cfg2_deep.err; echo "bench2deep rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2_deep.json ;;
     bench4)  timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; echo "bench4 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg4.json ;;
-    bench5)  timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; echo "bench5 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg5.json ;;
+    bench5)  timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 ${BENCH5_ARGS:-} > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; echo "bench5 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg5.json ;;
     prof3|prof2|prof5)
              CFG=${s#prof}; P=$OUT/prof$CFG; mkdir -p $P
-             CMD="python $ROOT/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras"
+             CMD="python $ROOT/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras ${PROF_ARGS:-}"
              ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $P/trace -o trace -- $CMD > $P/trace.log 2>&1 ); echo "$s rc=$?" >> $OUT/steps.log
              python3 profiles/summarize.py $P ${TAG}_cfg$CFG $OUT/summaries "python bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras" > $P/summarize.log 2>&1 ;;
-    pmc3|pmc2)
+    pmc3|pmc2|pmc5)
              CFG=${s#pmc}; P=$OUT/prof$CFG; mkdir -p $P
-             CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras"
+             CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass --no-extras ${PROF_ARGS:-}"
              ( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $P/pmc_fetch -o fetch -- $CMD > $P/pmc_fetch.log 2>&1 )
              ( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d $P/pmc_write -o write -- $CMD > $P/pmc_write.log 2>&1 )
              ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $P/pmc_valu -o valu -- $CMD > $P/pmc_valu.log 2>&1 )

@@ -2,7 +2,10 @@
 sample through dada2hip_sample_compare (event-timed NW launch), the batch thinned to a target size with the skip mask,
 timed with DADA2HIP_AD_DEBUG phase-skipping bits (1 DP, 2 traceback, 4 factors, 8 product; results are void then).
 
-    python tools/nw_phases.py [--uniques 300000] [--sizes 2000,4000,8700,18000,36000]"""
+Needs the profiling build of the library (`make -C dada2_amd/csrc prof`: the phase-skipping knob is compiled out of
+libdada2hip.so).
+
+    python tools/nw_phases.py [--config 3|5] [--uniques 300000] [--sizes 2000,4000,8700,18000,36000]"""
 import argparse
 import json
 import os
@@ -18,21 +21,24 @@ import bench  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=3, help="bench.py configuration whose geometry is profiled (5: long reads, band 32)")
     ap.add_argument("--uniques", type=int, default=300000)
     ap.add_argument("--sizes", default="2000,4000,8700,18000,36000")
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
+    from dada2_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "dada2_amd", "libdada2hip_prof.so")
     from dada2_amd import api
     from dada2_amd.opts import DadaOpts
     args = types.SimpleNamespace(uniques=a.uniques, length=0, variants=0, deep=False)
-    dereps, inputs, err, mine, c = bench.make_inputs(3, args, 0)
+    dereps, inputs, err, mine, c = bench.make_inputs(a.config, args, 0)
     d = dereps[0]
     opts = DadaOpts(BAND_SIZE=c["band"])
     s = api.Sample.from_derep(d, device=0)
     os.environ["DADA2HIP_NW_KERNEL"] = "coop"
     lam, ham, cls, st = s.compare(0, err, opts)
     nw_idx = np.flatnonzero(cls == 3)
-    print(json.dumps({"uniques": d.nraw, "nw_candidates_of_centre0": int(nw_idx.size)}), flush=True)
+    print(json.dumps({"config": a.config, "uniques": d.nraw, "maxlen": max(map(len, d.seqs)), "band": c["band"], "nw_candidates_of_centre0": int(nw_idx.size)}), flush=True)
     rng = np.random.default_rng(1)
     for size in [int(x) for x in a.sizes.split(",")]:
         if size > nw_idx.size:
