@@ -352,8 +352,19 @@ def phases(st, prof):
                              "bookkeep = round tails incl. waiting for the device; final = final pass + outputs"}
     if prof:
         out["device_ms_profiled_pass"] = {k[7:]: prof[k] for k in ("dev_ms_screen", "dev_ms_nw", "dev_ms_shuffle", "dev_ms_pval",
-                                                                   "dev_ms_birth", "dev_ms_final")}
-        out["device_ms_note"] = "HIP-event time of EVERY launch of a resident pass under DADA2HIP_PROFILE=1, summed per kernel class"
+                                                                   "dev_ms_birth", "dev_ms_final", "dev_ms_tail")}
+        out["device_ms_note"] = ("HIP-event time of EVERY launch of a resident pass under DADA2HIP_PROFILE=1, summed per kernel class; tail = the "
+                                 "persistent round-tail launches (k3_tail: shuffles, p-update, bud, birth of every round), which replace the "
+                                 "shuffle / pval / birth launch chains")
+        if prof.get("tail_launches"):
+            out["round_tail"] = {"launches": prof["tail_launches"], "blocks_per_launch": prof["tail_blocks"], "pauses": prof["tail_pauses"],
+                                 "shuffle_calls": prof["tail_levels"],
+                                 "block0_ms": {k[8:]: round(prof[k], 3) for k in ("tail_ms_entry", "tail_ms_shuffle0", "tail_ms_shuffle_more",
+                                                                                  "tail_ms_pupdate", "tail_ms_barriers", "tail_ms_birth",
+                                                                                  "tail_ms_publish")},
+                                 "note": "block 0's wall clock inside the persistent launches: entry = entry barrier, barriers = waiting for the "
+                                         "other blocks incl. the serial end of the round (birth) run by the last arriver; birth / publish = time "
+                                         "the deciding block spent in the serial section / copying the result block to the host"}
     return out
 
 

@@ -34,6 +34,11 @@ class CStats(C.Structure):
         ("nmoves", C.c_uint64), ("batch_compares", C.c_uint64),
         ("nnw_run", C.c_uint64), ("ngapless_run", C.c_uint64),
         ("lite_chains", C.c_uint64), ("lite_misses", C.c_uint64),
+        ("tail_launches", C.c_uint64), ("tail_pauses", C.c_uint64), ("tail_levels", C.c_uint64),
+        ("tail_blocks", C.c_uint32), ("tail_reserved", C.c_uint32),
+        ("dev_ms_tail", C.c_double), ("tail_ms_entry", C.c_double), ("tail_ms_shuffle0", C.c_double),
+        ("tail_ms_shuffle_more", C.c_double), ("tail_ms_pupdate", C.c_double), ("tail_ms_barriers", C.c_double),
+        ("tail_ms_birth", C.c_double), ("tail_ms_publish", C.c_double),
     ]
 
     def as_dict(self):

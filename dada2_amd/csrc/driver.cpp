@@ -121,6 +121,15 @@ struct dada2hip_result {
 
 namespace {
 
+// The persistent round tail (k3_tail) needs ALL its blocks co-resident, one per CU.  Two such launches dispatched to one device
+// at the same time (two samples of dada2hip_run_multi on the same GPU) could each get part of the CUs and wait for the rest
+// forever (their barriers would time out and the runs fail), so a device has ONE persistent slot per process: the run that
+// holds it uses k3_tail, any other run on that device meanwhile takes the launch chains.
+std::mutex &persistent_slot(int device) {
+  static std::mutex slots[64];
+  return slots[device & 63];
+}
+
 // Wait for the stream by polling: the per-round decision points (shuffle movers, bud result) sit on
 // the critical path, and a polled wait returns microseconds sooner than a blocking one.
 // DADA2HIP_WAIT=block (or more resident samples / ranks than host cores): sleep between polls instead of spinning.
@@ -491,7 +500,7 @@ struct Run {
   // ---- kernel timing with HIP events on the run's stream.  Default: sampled (round 0, every 8th round, the final pass)
   // and extrapolated, because an event pair per kernel per round costs four API calls on an enqueue-bound critical
   // path.  DADA2HIP_PROFILE=1: every launch of every kernel class is timed (stats.kernel_times_sampled = 0).
-  enum { EV_SCREEN = 0, EV_NW, EV_SHUFFLE, EV_PVAL, EV_BIRTH, EV_FINAL, EV_NCLS };
+  enum { EV_SCREEN = 0, EV_NW, EV_SHUFFLE, EV_PVAL, EV_BIRTH, EV_FINAL, EV_TAIL, EV_NCLS };
   struct EvRec { hipEvent_t a, b; int cls; uint8_t ok, big; };
   std::vector<EvRec> evs;
   size_t ev_used = 0;
@@ -1234,6 +1243,15 @@ struct Run {
   int v2_trace_seq = -1;
   int v2_nbuf = 64, v2_depth = 2, v2_chain = SH_CHAIN;
   bool v2_debug = false;
+  // persistent round tail (k3_tail, rounds3.inc.hip): rounds run back to back inside one launch
+  bool v3_on = false;                 // this run's rounds go through k3_tail (else: the launch chains)
+  int v3_grid = 1;                    // its blocks (co-resident: at most one per CU)
+  long v3_enq = 0;                    // k3_tail launches enqueued (their ordinals are 1, 2, ...)
+  long v3_ord_seen = 0;               // launch ordinal of the last consumed block
+  DevBuf<PSync> v3_psync;
+  DevBuf<unsigned long long> v3_ktime;
+  PinBuf<int32_t> v3_hflags;          // [0] result blocks the host has finished with, [16] ordinal of the last launch that ended
+  std::unique_lock<std::mutex> v3_slot;   // the device's persistent slot (held for the run)
   long v2_enq = 0, v2_cons = 0;
   uint64_t v2_miss_launches = 0;
   struct EnqRec { int ev_screen, ev_nw; bool compare; };
@@ -1261,11 +1279,15 @@ struct Run {
     E2.bp = BudParams{o.min_fold, o.omegaA, o.omegaP, o.min_hamming, o.min_abund};
     E2.sp = sp; E2.thresh = d_thresh_round.p; E2.max_shuffle = MAX_SHUFFLE;
     E2.trace = v2_trace.p; E2.trace_seq = v2_trace_seq;
-    E2.moved = v2_moved.p; E2.n0d = v2_n0d.p; E2.stat_part = v2_statpart.p; E2.stat_n = v2_n0d.p + 2 * SH_CHAIN;
+    E2.moved = v2_moved.p; E2.n0d = v2_n0d.p; E2.stat_part = v2_statpart.p; E2.stat_n = v2_n0d.p + 2 * SH_LEVELS;
+    E2.psync = v3_psync.p; E2.hcons = v3_hflags.p; E2.hexit = v3_hflags.p ? v3_hflags.p + 16 : nullptr; E2.ktime = v3_ktime.p;
     E2.sh_filter = 1; E2.grid_shuffle = 2048; E2.grid_pupdate = 1024;
     if (const char *e = getenv("DADA2HIP_V2_FILTER")) E2.sh_filter = atoi(e) != 0;
     if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::min(8192, std::max(1, atoi(e)));
     if (const char *e = getenv("DADA2HIP_V2_GRID_PUPDATE")) E2.grid_pupdate = std::max(1, atoi(e));
+    E2.mov_inline = MOV_INLINE2; E2.ring_limit = RING2;
+    if (const char *e = getenv("DADA2HIP_V2_MOV_INLINE")) E2.mov_inline = std::max(1, std::min(MOV_INLINE2, atoi(e)));   // test knob: long mover lists
+    if (const char *e = getenv("DADA2HIP_V3_RING")) E2.ring_limit = std::max(1, std::min(RING2, atoi(e)));               // test knob: a host that lags
     E2.has_compare = 1;
     E2.align_at_commit = v2_align_commit ? 1 : 0;
     E2L = E2; E2L.has_compare = 0;
@@ -1285,7 +1307,7 @@ struct Run {
       v2_nbuf = (int)std::max<size_t>(2, std::min<size_t>(64, total_b / 8 / std::max<size_t>(per_buf, 1)));
     }
     if (const char *e = getenv("DADA2HIP_V2_NBUF")) v2_nbuf = std::max(1, std::min(64, atoi(e)));   // (k2_birth keeps the slot table in LDS)
-    if (const char *e = getenv("DADA2HIP_V2_DEPTH")) v2_depth = std::max(1, std::min(RING2 - 1, atoi(e)));
+    if (const char *e = getenv("DADA2HIP_V2_DEPTH")) v2_depth = std::max(1, std::min(MOV_RING - 1, atoi(e)));
     v2_chain = SH_CHAIN;
     if (const char *e = getenv("DADA2HIP_V2_CHAIN")) v2_chain = std::max(1, std::min(SH_CHAIN, atoi(e)));   // test knob: shorter shuffle chains
     v2_debug = getenv("DADA2HIP_V2_DEBUG") != nullptr;
@@ -1297,8 +1319,8 @@ struct Run {
       if (v2_blk.n < cap0) v2_blk.alloc(cap0);
     }
     v2_ctl.alloc(1); v2_dblk.alloc(RING2); v2_hblk.alloc(RING2);
-    v2_dlt.alloc((size_t)SH_CHAIN * ccap);
-    v2_movers.alloc((size_t)RING2 * SH_CHAIN * 3 * n);
+    v2_dlt.alloc((size_t)SH_LEVELS * ccap);
+    v2_movers.alloc((size_t)std::max(MOV_RING * SH_CHAIN, SH_LEVELS) * 3 * n);
     const size_t slots = (size_t)v2_nbuf * KB_MAX;
     v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
     v2_lamB.alloc(slots * (((size_t)N + 31) & ~(size_t)15)); v2_hamB.alloc(slots * (((size_t)N + 31) & ~(size_t)15));
@@ -1306,14 +1328,15 @@ struct Run {
     D2_HIP(hipMemsetAsync(v2_blistn.p, 0, 2 * KB_MAX * 4, stq));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
     v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
-    v2_moved.alloc(n); v2_n0d.alloc(2 * SH_CHAIN + 4); v2_statpart.alloc((size_t)4 * 8192);
+    v2_moved.alloc(n); v2_n0d.alloc(2 * SH_LEVELS + 4); v2_statpart.alloc((size_t)4 * 8192);
     D2_HIP(hipMemsetAsync(v2_moved.p, 0, n, stq));
-    D2_HIP(hipMemsetAsync(v2_n0d.p, 0, (2 * SH_CHAIN + 4) * 4, stq));
+    D2_HIP(hipMemsetAsync(v2_n0d.p, 0, (2 * SH_LEVELS + 4) * 4, stq));
     D2_HIP(hipMemsetAsync(v2_sig.p, 0, 16, stq));
     D2_HIP(hipMemsetAsync(v2_blkcount.p, 0, 4, stq));
     D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));
-    D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_CHAIN * ccap * 4, stq));
+    D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_LEVELS * ccap * 4, stq));
     D2_HIP(hipMemsetAsync(v2_slotc.p, 0xFF, slots * 4, stq));
+    v3_setup(stq);
     for (int k = 0; k < RING2; k++) v2_hblk.p[k].seq = 0;
     Ctl2 c;
     memset(&c, 0, sizeof c);
@@ -1342,6 +1365,154 @@ struct Run {
     v2_miss_launches = 0;
     v2_enqrec.clear();
     v2_bind();
+  }
+
+  // ---- persistent round tail -----------------------------------------------------------------------------------------------
+  // DADA2HIP_V2_TAIL=chain keeps the launch chains; DADA2HIP_V3_GRID=n forces the number of blocks (tests: several blocks on a
+  // small sample)
+  void v3_setup(hipStream_t stq) {
+    v3_on = true;
+    if (const char *e = getenv("DADA2HIP_V2_TAIL")) v3_on = strcmp(e, "chain") != 0;
+    if (getenv("DADA2HIP_V2_GRAPH") && !graph_off()) v3_on = false;     // (hipGraph replay is a property of the chains)
+    if (v2_trace_seq >= 0 || getenv("DADA2HIP_V2_TRACE")) v3_on = false; // (the phase trace stamps the chains' kernels)
+    if (v3_on && !v3_slot.owns_lock()) {
+      v3_slot = std::unique_lock<std::mutex>(persistent_slot(s->device), std::try_to_lock);
+      if (!v3_slot.owns_lock()) v3_on = false;                           // another run on this device holds the slot
+    }
+    v3_grid = tail_grid(N, s->device);
+    if (const char *e = getenv("DADA2HIP_V3_GRID")) v3_grid = std::max(1, std::min(atoi(e), tail_grid(1 << 30, s->device)));
+    v3_psync.alloc(1); v3_hflags.alloc(32); v3_ktime.alloc(KT_N);
+    D2_HIP(hipMemsetAsync(v3_psync.p, 0, sizeof(PSync), stq));
+    D2_HIP(hipMemsetAsync(v3_ktime.p, 0, KT_N * 8, stq));
+    for (int k = 0; k < 32; k++) v3_hflags.p[k] = 0;
+    v3_enq = 0; v3_ord_seen = 0;
+  }
+  void v3_release() { if (v3_slot.owns_lock()) v3_slot.unlock(); }
+  bool v3_block_ready() const { return *(volatile int32_t *)&v2_hblk.p[v2_cons % RING2].seq == (int32_t)(v2_cons + 1); }
+  long v3_ended() const { return (long)*(volatile int32_t *)(v3_hflags.p + 16); }
+  // one super-chain: the launches of a batch compare (they find nothing to do unless the round in front of the device needs
+  // one: Ctl2::nbatch / nalign), then the persistent tail, which runs rounds until the next compare is due
+  std::vector<EnqRec> v3_rec;          // per k3_tail launch (index = ordinal - 1): its compare's profile events
+  void v3_enqueue(bool first) {
+    const auto t_enq = clk::now();
+    hipStream_t stq = s->stream;
+    EnqRec rec{-1, -1, !first};
+    if (!first) {
+      rec.ev_screen = ev_begin(EV_SCREEN, profile_all, /*spec=*/true);
+      launch2_screen_multi(E2, stq);
+      ev_end(rec.ev_screen);
+      launch2_batch_lists(E2, stq);
+      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad};
+      launch_gapless_batch(s->D, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &v2_ctl.p->state, stq);
+      rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
+      launch_nw_ad(s->D, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, stq,
+                   &v2_ctl.p->state, &nb);
+      ev_end(rec.ev_nw);
+    }
+    const int ev = ev_begin(EV_TAIL, profile_all);
+    Eng2 Ek = E2;
+    if (!profile_all) Ek.ktime = nullptr;
+    launch3_tail(Ek, v3_grid, first, (int)(v3_enq + 1), s->h_reads[bi[0].center], stq);
+    ev_end(ev);
+    v3_rec.push_back(rec);
+    v3_enq++;
+    st.ms_enqueue += ms_since(t_enq);
+  }
+
+  // run_dada's loop (Rmain.cpp:312-331) with the rounds inside persistent launches: the host keeps v2_depth super-chains queued,
+  // trails the device through the published result blocks exactly as with the launch chains, and answers the same halts
+  void run_v3(int max_clust) {
+    auto t0 = clk::now();
+    st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
+    v3_rec.clear();
+    v3_enqueue(true);                                          // b_p_update after round 0 + the first b_bud (+ the rounds that follow)
+    bool done = false;
+    long n_halt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_pause = 0, n_blocks = 0;
+    while (!done) {
+      // keep the device fed: super-chains in flight = enqueued - ended (the device reports the ordinal of every launch that
+      // ends, whether it ran rounds or found the device halted); none is added while a result block waits to be consumed
+      while (v3_enq - v3_ended() < v2_depth && !v3_block_ready()) v3_enqueue(false);
+      const long seq = v2_cons + 1;
+      const Round2Out &b = v2_wait_block();
+      n_blocks++;
+      if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
+        throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
+      if (v2_debug)
+        fprintf(stderr, "[v3] blk %ld launch %d halt %d paused %d nclust %d nsh %d cnt %d %d %d %d nbatch %d slot %d birth %d found %d nties %d p %.3e blk %d\n", seq,
+                b.kord, b.halt, b.paused, b.nclust, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],
+                b.bud.nties[0], b.bud.best_p[0], b.blk_count);
+      v2_replay(b, seq);
+      n_halt[b.halt & 7]++;
+      if (b.kord > v3_ord_seen) {                              // first block of its launch: the compare in front of that launch served it
+        v3_ord_seen = b.kord;
+        const EnqRec &rec = v3_rec[(size_t)b.kord - 1];
+        if (rec.compare && b.pad0[1] + b.pad0[2] > 0) {        // (the aligner launches had work)
+          if (rec.ev_nw >= 0) evs[rec.ev_nw].ok = 1;
+          st.nnw_run += (uint64_t)b.pad0[1]; st.ngapless_run += (uint64_t)b.pad0[2];
+        }
+        if (rec.compare && b.nbatch > 0) {                     // (a batch screen ran: a cache miss)
+          v2_miss_launches++;
+          if (rec.ev_screen >= 0) evs[rec.ev_screen].ok = 1;
+        }
+      }
+      switch (b.halt) {
+        case H2_NONE: {                                        // birth applied on the device: book it
+          Birth bb = decide_bud(b.bud);
+          if (!bb.yes || bb.type != 'A' || bb.c.raw != b.bud.ties[0][0].raw)
+            throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: device and host bud decisions differ"};
+          logf("\nNew Cluster C%i:", bb.newi);
+          nclust_dev = bb.newi + 1;
+          record_birth(bb);
+          st.ncompare += (uint64_t)N;
+          if (b.paused) {                                      // its mover lists did not fit the block: fetched (v2_replay), go on
+            n_pause++;
+            launch2_resume(E2, s->stream, /*keep_list=*/true);
+          }
+          break;
+        }
+        case H2_NO_BIRTH: {
+          Birth bb = decide_bud(b.bud);
+          if (bb.yes) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: device and host bud decisions differ"};
+          done = true;
+          break;
+        }
+        case H2_MAXCLUST: done = true; break;
+        case H2_HOST_DECIDE:
+        case H2_CAPACITY: {
+          // the launches already queued behind the halt end at once (they neither touch state nor publish): the host's birth
+          // is simply queued behind them, no drain needed unless buffers have to grow
+          if (b.halt == H2_CAPACITY) v2_grow(b);
+          Birth bb = decide_bud(b.bud);
+          if (!bb.yes) { done = true; break; }
+          if (bb.newi + 2 > ccap) v2_grow(b);
+          logf("\nNew Cluster C%i:", bb.newi);
+          launch2_host_birth(E2, bb.c.raw, bb.c.from, s->stream);
+          nclust_dev = bb.newi + 1;
+          record_birth(bb);
+          st.ncompare += (uint64_t)N;
+          break;
+        }
+        case H2_FAIL: throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: a grid barrier of the persistent round tail timed out (blocks not co-resident?)"};
+        default: throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: unexpected halt code from the persistent round tail"};
+      }
+      *(volatile int32_t *)v3_hflags.p = (int32_t)v2_cons;     // the device may reuse the ring slots of everything consumed
+    }
+    sync_spin(s->stream);                                      // launches queued behind the final halt
+    if (profile_all && v3_ktime.p) {                           // phase clocks of block 0 (100 MHz): what the tail's time went into
+      unsigned long long kt[KT_N];
+      D2_HIP(hipMemcpy(kt, v3_ktime.p, sizeof kt, hipMemcpyDeviceToHost));
+      const double ms = 1e3 / 1e8;
+      st.tail_ms_shuffle0 = kt[KT_S0] * ms; st.tail_ms_shuffle_more = kt[KT_SL] * ms; st.tail_ms_pupdate = kt[KT_P] * ms;
+      st.tail_ms_barriers = (kt[KT_S0_BAR] + kt[KT_SL_BAR] + kt[KT_P_BAR]) * ms; st.tail_ms_birth = kt[KT_BIRTH] * ms;
+      st.tail_ms_publish = kt[KT_PUBLISH] * ms; st.tail_ms_entry = kt[KT_LAUNCH] * ms;
+      st.tail_levels = kt[KT_LEVELS];
+    }
+    st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid;
+    if (getenv("DADA2HIP_V2_SUMMARY"))
+      fprintf(stderr, "[v3] blocks %ld  launches %ld  grid %d  halts none/nobirth/host/more/cap/max %ld %ld %ld %ld %ld %ld  pauses %ld  ms: wait %.1f replay %.1f enqueue %.1f total %.1f  moves %llu misses %llu\n",
+              n_blocks, v3_enq, v3_grid, n_halt[0], n_halt[1], n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_pause, st.ms_wait_device, st.ms_replay,
+              st.ms_enqueue, ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches);
+    st.ms_bookkeep += ms_since(t0);
   }
 
   // one chain: [shuffle x nlev][b_p_update + b_bud arg-min + ties][birth / plan / publish]; a full round is a chain with the
@@ -1456,16 +1627,18 @@ struct Run {
     int tot = 0;
     for (int l = 0; l < b.nsh; l++) tot += b.cnt[l];
     st.nmoves += (uint64_t)tot;
-    if (tot <= MOV_INLINE2) {
+    if (tot <= E2.mov_inline) {
       int off = 0;
       for (int l = 0; l < b.nsh; l++) { replay_moves(b.mov + 3 * off, b.cnt[l]); off += b.cnt[l]; }
     } else {
-      const int ring = (int)((seq - 1) % RING2);
+      // (launch chains keep MOV_RING sets of lists; the persistent tail one set, and it stays halted until resumed)
+      const int ring = (int)((seq - 1) % MOV_RING);
       for (int l = 0; l < b.nsh; l++) {
         const int nm = b.cnt[l];
         if (!nm) continue;
         h_big.alloc((size_t)3 * nm);
-        D2_HIP(hipMemcpyAsync(h_big.p, v2_movers.p + ((size_t)(ring * SH_CHAIN + l)) * 3 * N, (size_t)3 * nm * 4, hipMemcpyDeviceToHost,
+        const size_t slot = b.kord ? (size_t)l : (size_t)(ring * SH_CHAIN + l);
+        D2_HIP(hipMemcpyAsync(h_big.p, v2_movers.p + slot * 3 * N, (size_t)3 * nm * 4, hipMemcpyDeviceToHost,
                               s->side));
         D2_HIP(hipStreamSynchronize(s->side));
         replay_moves(h_big.p, nm);
@@ -1484,8 +1657,8 @@ struct Run {
     sync_spin(s->stream);
     if (nclust_dev + 2 > ccap) {
       grow_clusters(std::max(ccap * 2, nclust_dev + 2));
-      v2_dlt.alloc((size_t)SH_CHAIN * ccap);                       // (deltas are all zero between chains)
-      D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_CHAIN * ccap * 4, s->stream));
+      v2_dlt.alloc((size_t)SH_LEVELS * ccap);                      // (deltas are all zero between chains)
+      D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_LEVELS * ccap * 4, s->stream));
     }
     if ((size_t)b.blk_count + (size_t)N > v2_blk.n) {
       const size_t cap = std::max(v2_blk.n * 2, (size_t)b.blk_count + 2 * (size_t)N);
@@ -1722,7 +1895,8 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   // run_dada's loop (Rmain.cpp:312-331), rotated: every iteration ends with b_p_update + the b_bud that opens
   // the reference's next iteration, so one device round trip serves both.  After a decision the next round's
   // kernels are launched first; the host mirror (moves replay, birth record) is updated while the GPU works.
-  if (run.use_v2) run.run_v2(max_clust);
+  if (run.use_v2 && run.v3_on) run.run_v3(max_clust);
+  else if (run.use_v2) run.run_v2(max_clust);
   else if (run.nclust_dev < max_clust) {
     run.round_tail(false);                            // b_p_update after round 0, then the first b_bud
     for (;;) {
@@ -1928,7 +2102,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     // kernel times: event-timed launches, summed per kernel class.  Sampled mode: the per-round NW and screen launches
     // are extrapolated from the sampled ones; DADA2HIP_PROFILE=1: every launch was timed, the sums are exact.
     float ems;
-    double cls_ms[Run::EV_NCLS] = {0, 0, 0, 0, 0, 0};
+    double cls_ms[Run::EV_NCLS] = {0, 0, 0, 0, 0, 0, 0};
     double nw_big = 0, nw_small = 0, sc_sum = 0;
     int n_small = 0, n_sc = 0, n_big = 0;
     for (size_t k = 0; k < run.ev_used; k++) {
@@ -1949,6 +2123,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       run.st.dev_ms_screen = cls_ms[Run::EV_SCREEN]; run.st.dev_ms_nw = cls_ms[Run::EV_NW];
       run.st.dev_ms_shuffle = cls_ms[Run::EV_SHUFFLE]; run.st.dev_ms_pval = cls_ms[Run::EV_PVAL];
       run.st.dev_ms_birth = cls_ms[Run::EV_BIRTH]; run.st.dev_ms_final = cls_ms[Run::EV_FINAL];
+      run.st.dev_ms_tail = cls_ms[Run::EV_TAIL];
     } else {
       run.st.nw_kernel_ms = nw_big + (n_small ? nw_small / n_small * (rounds - 1) : 0.0);
       run.st.nw_kernel_launches = (uint64_t)rounds + 1;

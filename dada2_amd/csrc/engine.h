@@ -250,7 +250,9 @@ int nw_adw_apw(const SampleDev &S, const AlignParams &ap);
 //    halts - every later launch becomes a no-op - and the host takes over as in the classic loop.
 constexpr int KB_MAX = 8;          // centres per batch compare (one byte lane each in the packed count table)
 constexpr int SH_CHAIN = 4;        // b_shuffle2 calls enqueued per chain (the first unconditional, the rest guarded)
-constexpr int RING2 = 4;           // result blocks / mover lists in flight
+constexpr int SH_LEVELS = MAX_SHUFFLE;   // b_shuffle2 calls of one round (Rmain.cpp:321): what the persistent tail kernel runs in one go
+constexpr int RING2 = 16;          // result blocks in flight (device copies + pinned host copies)
+constexpr int MOV_RING = 4;        // full mover lists in flight (launch chains; the persistent tail keeps one set and pauses on overflow)
 constexpr int TRACE_BLOCKS = 4096, TRACE_KERNELS = 8;   // (slot 0 unused since k2_lists went into the store pass; shuffle 0..3, p-update, birth, spare)
 constexpr int MOV_INLINE2 = 8192;  // movers published inline per chain (all its shuffles, concatenated)
 
@@ -276,7 +278,7 @@ struct Store2 {
   int32_t blk_cap = 0;
 };
 
-enum : int32_t { H2_NONE = 0, H2_NO_BIRTH, H2_HOST_DECIDE, H2_SHUFFLE_MORE, H2_CAPACITY, H2_MAXCLUST, H2_NEED_COMPARE };
+enum : int32_t { H2_NONE = 0, H2_NO_BIRTH, H2_HOST_DECIDE, H2_SHUFFLE_MORE, H2_CAPACITY, H2_MAXCLUST, H2_NEED_COMPARE, H2_FAIL };
 
 struct Ctl2 {
   int32_t state;        // 0 = running, 1 = halted (every launch returns at once)
@@ -301,6 +303,9 @@ struct Ctl2 {
   int32_t bcentre[KB_MAX];
   uint32_t breads[KB_MAX];
   int32_t blen[KB_MAX];
+  // persistent tail (k3_tail): leave the launch after the round in flight (a compare is due, the host's ring is nearly full, a
+  // pause); what the host has consumed as far as the device knows
+  int32_t kexit, hcons_seen;
 };
 
 // Results of the batch compares, kept until their centre's round comes (or the batch buffer is recycled): the class, 2 bits
@@ -327,11 +332,14 @@ struct Round2Out {
   int32_t birth_applied;          // 1: bud.ties[0][0] became partition nclust - 1 on the device
   int32_t nlev;                   // shuffle launches of the chain
   int32_t nsh;                    // ... of which executed
-  int32_t cnt[SH_CHAIN];          // movers of each
+  int32_t cnt[SH_LEVELS];         // movers of each
   int32_t nbatch;                 // centres compared by this round's batch launch (0 = hit)
   int32_t slot;
   int32_t err_flag, blk_count;
   int32_t pad0[4];
+  int32_t kord;                   // persistent tail: ordinal of the k3_tail launch that ran this round (0: a launch chain)
+  int32_t paused;                 // persistent tail: the device halted BEHIND this block's decision because its mover lists did not fit
+                                  // the block (they stay in Eng2::movers until the host has fetched them and resumes)
   unsigned long long stat[4];     // commit-time classes of the round's comparisons: NW, gapless, shrouded, greedy-skipped
   BudOut bud;
   int32_t mov[3 * MOV_INLINE2];   // (unique, from, to) of the chain's movers, shuffles concatenated
@@ -346,7 +354,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   Ctl2 *ctl;
   Round2Out *dblk;                // [RING2] device-side result blocks
   Round2Out *hblk;                // [RING2] pinned host copies
-  int32_t *dlt;                   // [SH_CHAIN][ccap] partition-read deltas of the chain's shuffles
+  int32_t *dlt;                   // [SH_LEVELS][ccap] partition-read deltas of the chain's shuffles
   // b_bud takes the FIRST of several equal keys in partition order, then in the order of the partition's member list
   // (cluster.cpp:284-308).  The member lists live on the host (bi_pop_raw moves the LAST member into the hole,
   // containers.cpp:177-194, so a list's order is the history of every move), but one case needs no list: a unique that has
@@ -355,8 +363,8 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   // and settle such a tie itself (they are most of the ties of a deep sample: p underflowed to 0, equal reads, neighbours
   // in the abundance order) instead of halting for the host.
   uint8_t *moved;                 // [N] the unique has been moved by a shuffle or a birth
-  int32_t *n0d;                   // [SH_CHAIN][2] members partition 0 lost / gained in each of the chain's shuffle calls
-  int32_t *movers;                // [RING2][SH_CHAIN][3 N]
+  int32_t *n0d;                   // [SH_LEVELS][2] members partition 0 lost / gained in each of the chain's shuffle calls
+  int32_t *movers;                // [MOV_RING][SH_CHAIN][3 N] (launch chains) / [SH_LEVELS][3 N] (persistent tail)
   uint32_t *stat_part;            // [grid of the store pass][4] per-block class counts of the round (NW, gapless, shrouded, skipped)
   int32_t *stat_n;                // number of entries in stat_part (0: the chain had no store pass), consumed by k2_birth
   int32_t *blist, *blist_n;       // [2 KB_MAX][Npad] / [2 KB_MAX]: work lists of the batch compare (NwBatch)
@@ -389,7 +397,23 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   int32_t align_at_commit;
   int32_t sh_filter;                                // later shuffle calls of a chain visit only the uniques the previous call can have unsettled
   int32_t grid_shuffle, grid_pupdate;               // host side: block caps of the per-round launches (tuning knobs)
+  int32_t mov_inline;                               // movers published inline with a round's result block (<= MOV_INLINE2; test knob)
+  int32_t ring_limit;                               // result blocks the device may be ahead of the host (<= RING2; test knob)
+  // ---- persistent round tail (k3_tail, rounds3.inc.hip) ----
+  struct PSync *psync;                              // grid barrier of the launch
+  volatile int32_t *hcons;                          // pinned host word: result blocks the host has finished with
+  volatile int32_t *hexit;                          // pinned host word: ordinal of the last k3_tail launch that has ended
+  unsigned long long *ktime;                        // [KT_N] phase clocks of block 0 (DADA2HIP_PROFILE=1), else nullptr
 };
+
+// Grid barrier of the persistent tail kernel: one monotonic arrival counter and one generation word, each on a cache line of
+// its own (rounds3.inc.hip).  Zeroed when a run starts; a launch continues where the previous one left them.
+struct PSync {
+  uint32_t arrive, pad0[31];
+  uint32_t gen, pad1[31];
+  uint32_t fail, pad2[31];
+};
+enum { KT_S0 = 0, KT_S0_BAR, KT_SL, KT_SL_BAR, KT_P, KT_P_BAR, KT_BIRTH, KT_PUBLISH, KT_ROUNDS, KT_LEVELS, KT_LAUNCH, KT_N = 16 };
 
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
                     hipStream_t st);
@@ -402,6 +426,10 @@ void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st);      
 void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list = false);   // keep_list: the candidates k2_pupdate listed stay valid
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st);
+// the persistent round tail: rounds run back to back inside ONE launch of `grid` co-resident blocks until a compare is due, the
+// device halts or the host's ring fills up.  first: the evaluation behind round 0 (no shuffle).  ordinal: this launch's number.
+int tail_grid(int N, int device);
+void launch3_tail(const Eng2 &E, int grid, bool first, int ordinal, uint32_t init_reads, hipStream_t st);
 
 // get_lr + get_ham_endsfree (chimera.cpp:211-293) on the move strings k_nw left behind: out[slot] = {left, right, left_oo, right_oo, ham}
 void launch_bimera_lr(const SampleDev &S, const int32_t *d_chunk_centre, const int32_t *d_work, int nwork, const uint8_t *d_moves,

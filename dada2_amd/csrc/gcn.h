@@ -51,6 +51,32 @@ static __device__ __forceinline__ int gcn_readfirstlane(int v) { return __builti
 // operations across the point (and gives the lane-by-lane emulator its rendezvous).
 // shader-clock timestamp (s_memtime) for the in-kernel phase traces of tools/trace_round.py
 static __device__ __forceinline__ unsigned long long gcn_clock() { return __builtin_amdgcn_s_memtime(); }
-static __device__ __forceinline__ void gcn_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// (the bare wave barrier is IntrNoMem - it pins the machine schedule, not LLVM's IR passes; the wavefront-scope
+// fences either side emit no instruction beyond waitcnts but keep the optimiser from moving LDS accesses across the hand-off)
+static __device__ __forceinline__ void gcn_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- inter-workgroup hand-offs inside one launch (the persistent round-tail kernel; MI355X: 8 XCDs with private L2s, a CU's
+// L1 is never refreshed by other CUs' stores).  Producer: its own stores drained, block barrier, ONE lane releases at agent
+// scope (writes the XCD's dirty L2 lines back) and then touches the flag; consumer: ONE lane polls relaxed, acquires at agent
+// scope once (drops its CU's stale L1 lines), block barrier, plain loads.
+static __device__ __forceinline__ void gcn_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+static __device__ __forceinline__ void gcn_release_agent() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (restated where the compiler cannot drop it behind the write-back)
+}
+static __device__ __forceinline__ void gcn_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+static __device__ __forceinline__ uint32_t gcn_load_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void gcn_store_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ uint32_t gcn_add_agent(uint32_t *p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ int32_t gcn_load_system(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// what a polling lane does between two looks at a word another workgroup (or the host) will write
+static __device__ __forceinline__ void gcn_poll_pause() { __builtin_amdgcn_s_sleep(2); }
+// constant-rate clock (100 MHz) for the bounds of those spins
+static __device__ __forceinline__ unsigned long long gcn_wall_clock() { return wall_clock64(); }
+constexpr unsigned long long GCN_WALL_HZ = 100000000ull;
 
 }  // namespace d2

@@ -715,6 +715,8 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
 // multiplies them in raw-position order (pval.cpp:188-192) — bit-identical to k_nw.
 // guard entries either side of the staged sequences (cell indices run about -GL .. len+GL)
 static inline int ad_pad(int GL) { return GL + 8; }
+// guard words in front of a staged sequence in k_nw_ad (>= GL + 11, a multiple of 4: position 0 is 16-byte aligned)
+static __host__ __device__ constexpr int ad_guard(int GL) { return (GL + 11 + 3) & ~3; }
 constexpr int AD_RCAP = 64;   // run descriptors buffered per alignment between traceback chunks
 
 // Traceback pointers of k_nw_ad: every step shifts a TWO-bit move code into the TOP of the lane's pointer word,
@@ -843,8 +845,12 @@ static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &
 }
 
 // LDS geometry of k_nw_ad, shared by host and device.  Per WAVE: the staged centre (every alignment of a wave has the same
-// centre), one word per base with guard words either side.  Per alignment: run descriptors, the staged raw (one word per
-// base), one u16 per raw position (byte offset of its error-model factor in the LDS copy of err) and the raw's qualities.
+// centre), one word per base with guard words either side.  Per alignment: run descriptors and the staged raw (one word per
+// base).  The expansion of the traceback overwrites each raw base IN PLACE with the byte offset of that position's error-model
+// factor in the LDS copy of err (a position belongs to exactly one run, and nothing reads the bases after the DP), and reads
+// the qualities from global memory where it needs them: round 3 kept a u16 offset row and a staged quality row per alignment
+// besides the words - 40 % of the per-alignment LDS, which at 1 500 nt held the kernel at ONE block per CU (one wave per SIMD:
+// 6.85 cycles per dependent VALU instruction instead of ~4.2 at four; profiles/r05a_cfg5_summary.md).
 // The 2-bit traceback pointers are NOT here: they go to the HBM ring SampleDev::ad_ptr, one coalesced 256-byte store per wave
 // per 16 steps (they took 2.3 of the 4.1 KB per alignment of round 2's kernel and, with the fp64 factor array that aliased
 // them, held the kernel at three blocks per CU).
@@ -853,7 +859,6 @@ struct AdGeom {
   int edge;                 // 1: group-boundary lanes must mask their DPP neighbour (band fills the group's cells)
   int nwords;               // 16-step blocks of a sweep (pointer words per lane)
   int seqwords;             // words per staged sequence incl. guards (multiple of 4)
-  int tbytes;               // bytes per quality row (multiple of 16); the factor-offset row has 2 * tbytes
   int per_al_bytes, per_wave_bytes;   // per_wave_bytes includes the wave's own centre words unless shared_c
   int shared_c;             // the launch has one centre for all its work (no per-chunk centres): staged once per block
   int block_bytes;          // LDS behind the err table
@@ -870,9 +875,8 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   G.edge = (W + 4 > 2 * G.GL) ? 1 : 0;
   G.NCOL = (W + (G.edge ? 1 : 3) + 1) / 2;
   G.nwords = (2 * maxlen + 1 + 15) / 16;
-  G.seqwords = (maxlen + 2 * (G.GL + 11) + 3) & ~3;
-  G.tbytes = (maxlen + 15) & ~15;
-  G.per_al_bytes = AD_RCAP * 4 + 4 * G.seqwords + 3 * G.tbytes;
+  G.seqwords = (maxlen + 2 * ad_guard(G.GL) + 3) & ~3;
+  G.per_al_bytes = AD_RCAP * 4 + 4 * G.seqwords;
   G.shared_c = shared_c;
   G.per_wave_bytes = (shared_c ? 0 : 4 * G.seqwords) + G.APW * G.per_al_bytes;
   G.block_bytes = (shared_c ? 4 * G.seqwords : 0) + 4 * G.per_wave_bytes;
@@ -915,12 +919,11 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   uint8_t *blk0 = (uint8_t *)(s_dyn + nerr);
   const int cw_bytes = 4 * G.seqwords;
   uint8_t *wbase = blk0 + (G.shared_c ? cw_bytes : 0) + (size_t)wib * G.per_wave_bytes;
-  uint32_t *cwd = (uint32_t *)(G.shared_c ? blk0 : wbase) + (GL + 11); // centre base p as ADK_HOT << (8 * code)
+  uint32_t *cwd = (uint32_t *)(G.shared_c ? blk0 : wbase) + ad_guard(GL); // centre base p as ADK_HOT << (8 * code)
   uint8_t *abase = wbase + (G.shared_c ? 0 : cw_bytes) + (size_t)al * G.per_al_bytes;
   uint32_t *runs = (uint32_t *)abase;
-  uint32_t *rwd = (uint32_t *)(abase + AD_RCAP * 4) + (GL + 11);        // raw base p, same encoding
-  uint16_t *foff = (uint16_t *)(abase + AD_RCAP * 4 + 4 * G.seqwords);  // byte offset into s_err of every raw position's factor
-  uint8_t *qlds = abase + AD_RCAP * 4 + 4 * G.seqwords + 2 * G.tbytes;
+  uint32_t *rwd = (uint32_t *)(abase + AD_RCAP * 4) + ad_guard(GL);      // raw base p, same encoding; after the expansion: byte offset
+                                                                        // into s_err of the position's error-model factor
   const SampleDev &S = a.S;
   if (G.shared_c && !batch) {                                          // the launch's one centre, staged by the whole block
     const int cv = a.centre_dev ? *a.centre_dev : a.centre;
@@ -979,11 +982,9 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     // stage both sequences (one base per byte, guard bytes either side) and the raw's qualities
     if (!G.shared_c)                                       // the chunk's centre, by all lanes of the wave
       for (int p = lane; p < L1; p += 64) cwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);
-    if (!ghost) {
+    if (!ghost)
       for (int p = g; p < L2; p += GL) rwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)r * S.W2, p) << 3);
-      const uint32_t *qsrc = (const uint32_t *)(S.qual + (size_t)r * S.LQ);
-      for (int w = g; w * 4 < L2; w += GL) ((uint32_t *)qlds)[w] = qsrc[w];
-    }
+    const uint8_t *qrow = S.qual + (size_t)r * S.LQ;        // the raw's qualities (read where the expansion needs them)
     // aligned view of the unique on its centre (final pass / birth substitutions): centre positions facing a gap stay 0
     const size_t vr = a.view_by_chunk ? (size_t)chunk : (size_t)r;
     if (a.view && active && !ghost)
@@ -1145,15 +1146,16 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
           const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
           for (int pj = lo + g; pj < lo + n; pj += GL) {
             const uint32_t rb = (uint32_t)__builtin_ctz(rwd[pj]) >> 3;   // base code back from its word 9 << (8 * code)
+            const uint32_t q = a.ap.use_quals ? qrow[pj] : 0u;
             uint32_t tc = 5u * rb;
             if (dl != 255) {
               const uint32_t cb = (uint32_t)__builtin_ctz(cwd[pj + dl - 128]) >> 3;
               tc = 4u * cb + rb;
               h += (cb != rb);
               if (a.view && active)
-                a.view[vr * a.LV + pj + dl - 128] = (uint16_t)(0x8000u | (rb << 8) | (a.ap.use_quals ? qlds[pj] : 0));
+                a.view[vr * a.LV + pj + dl - 128] = (uint16_t)(0x8000u | (rb << 8) | q);
             }
-            foff[pj] = (uint16_t)((tc * (uint32_t)a.ap.ncol + (a.ap.use_quals ? qlds[pj] : 0u)) << 3);   // &err[t(pj)][q(pj)] - err, in bytes
+            rwd[pj] = (tc * (uint32_t)a.ap.ncol + q) << 3;   // &err[t(pj)][q(pj)] - err, in bytes: replaces the base (each position is in ONE run)
           }
         }
       }
@@ -1166,17 +1168,16 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     gcn_wave_sync();                                       // (also: every lane's factors are in LDS before one lane multiplies them)
     h = runs[0];
     // ---- lambda: sequential product in raw-position order (pval.cpp:188-192), one lane per alignment.  The factors are
-    //      fetched straight from the LDS copy of err through the offsets the expansion left: eight offsets per 16-byte read,
+    //      fetched straight from the LDS copy of err through the offsets the expansion left: eight offsets per two 16-byte reads,
     //      the next eight factors on their way while the current eight are multiplied (the product itself stays strictly
     //      sequential) ---------
     if (g == 0 && active && !(dbg & 8)) {
       const char *eb = (const char *)s_err;
       auto fetch8 = [&](int pj, double (&f)[8]) __attribute__((always_inline)) {
-        const uint4 o = *(const uint4 *)(foff + pj);
-        f[0] = *(const double *)(eb + (o.x & 0xFFFFu)); f[1] = *(const double *)(eb + (o.x >> 16));
-        f[2] = *(const double *)(eb + (o.y & 0xFFFFu)); f[3] = *(const double *)(eb + (o.y >> 16));
-        f[4] = *(const double *)(eb + (o.z & 0xFFFFu)); f[5] = *(const double *)(eb + (o.z >> 16));
-        f[6] = *(const double *)(eb + (o.w & 0xFFFFu)); f[7] = *(const double *)(eb + (o.w >> 16));
+        uint32_t o[8];
+        __builtin_memcpy(o, (const uint32_t *)__builtin_assume_aligned(rwd + pj, 16), 32);   // (pj is a multiple of 8, the guard a multiple of 4 words)
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] = *(const double *)(eb + o[k]);
       };
       double l = 1.0;
       int pj = 0;
@@ -1193,7 +1194,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 #pragma unroll
         for (int k = 0; k < 8; k++) l = l * f[k];
       }
-      for (; pj < L2; pj++) l = l * *(const double *)(eb + foff[pj]);
+      for (; pj < L2; pj++) l = l * *(const double *)(eb + rwd[pj]);
       a.lam[out_off + r] = l;
       a.ham[out_off + r] = h;
     }
@@ -2460,5 +2461,6 @@ void launch_bimera_lr(const SampleDev &S, const int32_t *d_chunk_centre, const i
 }
 
 #include "rounds2.inc.hip"
+#include "rounds3.inc.hip"
 
 }  // namespace d2

@@ -10,6 +10,12 @@
 // Every launch reads what it has to do from the device control block (Ctl2): the host enqueues rounds ahead of the
 // results it has seen.
 
+#ifndef D2_PUPD_INLINE
+#define D2_PUPD_INLINE __forceinline__
+#endif
+#ifndef D2_SHUF_INLINE
+#define D2_SHUF_INLINE __forceinline__
+#endif
 // phase stamps of the traced round (Eng2::trace; nullptr in every normal run)
 #define D2_TRACE(KID, PHASE)                                                                                       \
   do {                                                                                                             \
@@ -77,30 +83,34 @@ static __device__ __forceinline__ bool v2_idle(const Eng2 &E) {
   const Ctl2 *ctl = E.ctl;
   return ctl->state != 0 || (!E.has_compare && ctl->need_compare != 0);
 }
-template <bool STORE>
-__global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E, int level) {
+// LDS of one block of the shuffle pass (BS threads): movers and new store blocks are buffered per block and written out once
+// at the end - ONE device atomic per block for each of the two counters (thousands of same-address atomics per launch were
+// most of this kernel's time)
+template <int BS>
+struct ShufLds {
+  static constexpr int MOVCAP = BS, NEWCAP = BS / 2;
+  int s_n, s_base, s_an, s_abase, s_keep, s_anyinc;
+  int32_t s_mov[3 * MOVCAP];
+  int32_t s_newr[NEWCAP], s_newhead[NEWCAP];
+  uint32_t s_newh[NEWCAP];
+  double s_newl[NEWCAP];
+  int32_t s_delta[DELTA_TAB];
+  uint32_t s_reads[DELTA_TAB];                                           // partition reads as of the start of this call
+  int8_t s_sgn[DELTA_TAB];
+  uint32_t s_st[BS / 64][4];
+};
+// One b_shuffle2 call (STORE: preceded by the commit of the round's comparisons) by a grid of BS-thread blocks: the body of
+// k2_shuffle (a launch of its own, BS = 256) and of the shuffle phases of the persistent tail k3_tail (BS = 1024).
+// out: the round's result block; mv: where the call's full mover list goes; moved_before: movers of the round's earlier calls.
+template <bool STORE, int BS>
+static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L, int level, int moved_before, int32_t *mv, Round2Out *out) {
   const Ctl2 *ctl = E.ctl;
-  if (v2_idle(E)) return;
-  const int ring = ctl->pub_seq % RING2;
-  Round2Out *out = E.dblk + ring;
-  if (ctl->nsh_base + level >= E.max_shuffle) return;
-  int moved_before = 0;
-  for (int l = 0; l < level; l++) {
-    const int c = out->cnt[l];
-    if (c == 0) return;                                                // an earlier call moved nothing: the loop has ended
-    moved_before += c;
-  }
-  // movers and new store blocks are buffered per block in LDS and written out once at the end: ONE device atomic per block
-  // for each of the two counters (thousands of same-address atomics per launch were most of this kernel's time)
-  constexpr int MOVCAP = 256, NEWCAP = 128;
-  __shared__ int s_n, s_base, s_an, s_abase;
-  __shared__ int32_t s_mov[3 * MOVCAP];
-  __shared__ int32_t s_newr[NEWCAP], s_newhead[NEWCAP];
-  __shared__ uint32_t s_newh[NEWCAP];
-  __shared__ double s_newl[NEWCAP];
-  __shared__ int32_t s_delta[DELTA_TAB];
-  __shared__ uint32_t s_reads[DELTA_TAB];                                // partition reads as of the start of this call
-  __shared__ int s_keep;
+  constexpr int MOVCAP = ShufLds<BS>::MOVCAP, NEWCAP = ShufLds<BS>::NEWCAP;
+  int &s_n = L.s_n, &s_base = L.s_base, &s_an = L.s_an, &s_abase = L.s_abase, &s_keep = L.s_keep, &s_anyinc = L.s_anyinc;
+  int32_t *s_mov = L.s_mov, *s_newr = L.s_newr, *s_newhead = L.s_newhead, *s_delta = L.s_delta;
+  uint32_t *s_newh = L.s_newh, *s_reads = L.s_reads;
+  double *s_newl = L.s_newl;
+  int8_t *s_sgn = L.s_sgn;
   D2_TRACE(1 + level, 0);
   if (threadIdx.x == 0) { s_n = 0; s_an = 0; s_keep = 0; }
   const PartState &P = E.P;
@@ -116,12 +126,10 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   // a falling rival or a rising home cannot change the winner).  s_sgn[k] = sign of partition k's net reads delta of the
   // previous call; everybody else leaves after reading 12 bytes.
   const bool filt = !STORE && level >= 1 && E.sh_filter;
-  __shared__ int8_t s_sgn[DELTA_TAB];
-  __shared__ int s_anyinc;
   const int32_t *dlp = E.dlt + (size_t)(level >= 1 ? level - 1 : 0) * E.ccap;
   if (filt && threadIdx.x == 0) s_anyinc = 0;
   __syncthreads();
-  for (int k = threadIdx.x; k < ntab; k += 256) {
+  for (int k = threadIdx.x; k < ntab; k += BS) {
     s_delta[k] = 0; s_reads[k] = reads_at(E, k, level);
     if (filt) {
       const int32_t d = dlp[k];
@@ -133,7 +141,6 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   const bool anyinc = filt ? (s_anyinc != 0 || nclust > ntab) : true;
   auto sgn_of = [&](int i) __attribute__((always_inline)) -> int { if (i < ntab) return s_sgn[i]; const int32_t d = dlp[i]; return d < 0 ? -1 : (d > 0 ? 1 : 0); };
   auto rd_at = [&](int i) __attribute__((always_inline)) -> uint32_t { return i < ntab ? s_reads[i] : reads_at(E, i, level); };
-  int32_t *mv = E.movers + ((size_t)(ring * SH_CHAIN + level)) * 3 * (size_t)N;
   int32_t *dl = E.dlt + (size_t)level * E.ccap;
   const uint32_t creads_c = S.reads[centre];
   const double *lam_row = E.C.lamB + (size_t)ctl->slot * E.C.Npad;       // the round's comparisons: its cache slot's rows
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
   int my_n0 = 0;                                                         // members partition 0 lost (low half) / gained (high half)
   D2_TRACE(1 + level, 1);
-  for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
+  for (int base = blockIdx.x * BS; base < N; base += gridDim.x * BS) {
     const int r = base + threadIdx.x;
     bool keep = false, need_new = false, move = false;
     double l = 0.0, best_l = 0.0;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
         int32_t *m = mv + 3 * (size_t)k;
         m[0] = r; m[1] = from; m[2] = to;
         const int ki = moved_before + k;
-        if (ki < MOV_INLINE2) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
+        if (ki < E.mov_inline) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
       }
     }
   }
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
     s_abase = nnew ? atomicAdd(T.blk_count, nnew) : 0;
   }
   __syncthreads();
-  for (int q = threadIdx.x; q < nnew; q += 256) {
+  for (int q = threadIdx.x; q < nnew; q += BS) {
     const int nb = s_abase + q;
     if (nb < T.blk_cap) {
       CompBlk *cb = T.blk + nb;
@@ -283,12 +290,12 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
       T.head[s_newr[q]] = nb;
     } else atomicOr(P.err_flag, 2);
   }
-  for (int q = threadIdx.x; q < nmov; q += 256) {
+  for (int q = threadIdx.x; q < nmov; q += BS) {
     const int k = s_base + q;
     int32_t *m = mv + 3 * (size_t)k;
     m[0] = s_mov[3 * q]; m[1] = s_mov[3 * q + 1]; m[2] = s_mov[3 * q + 2];
     const int ki = moved_before + k;
-    if (ki < MOV_INLINE2) { out->mov[3 * ki] = s_mov[3 * q]; out->mov[3 * ki + 1] = s_mov[3 * q + 1]; out->mov[3 * ki + 2] = s_mov[3 * q + 2]; }
+    if (ki < E.mov_inline) { out->mov[3 * ki] = s_mov[3 * q]; out->mov[3 * ki + 1] = s_mov[3 * q + 1]; out->mov[3 * ki + 2] = s_mov[3 * q + 2]; }
   }
   __syncthreads();                                                       // every delta of the block is in the table
   if (__any(my_n0 != 0)) {                                               // (a thread moves a handful of uniques at most: no carry)
@@ -311,21 +318,41 @@ __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E,
     // kernel's time: 32 000 atomics on one cache line)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { st01 += __shfl_xor(st01, o, 64); st23 += __shfl_xor(st23, o, 64); }
-    __shared__ uint32_t s_st[4][4];
     if ((threadIdx.x & 63) == 0) {
-      uint32_t *w = s_st[threadIdx.x >> 6];
+      uint32_t *w = L.s_st[threadIdx.x >> 6];
       w[0] = st01 & 0xFFFFu; w[1] = st01 >> 16; w[2] = st23 & 0xFFFFu; w[3] = st23 >> 16;
     }
     __syncthreads();
-    if (threadIdx.x < 4) E.stat_part[(size_t)blockIdx.x * 4 + threadIdx.x] = s_st[0][threadIdx.x] + s_st[1][threadIdx.x] + s_st[2][threadIdx.x] + s_st[3][threadIdx.x];
+    if (threadIdx.x < 4) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int w = 0; w < BS / 64; w++) v += L.s_st[w][threadIdx.x];
+      E.stat_part[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) *E.stat_n = (int32_t)gridDim.x;
   }
   D2_TRACE(1 + level, 3);
-  for (int k = threadIdx.x; k < ntab; k += 256) {
+  for (int k = threadIdx.x; k < ntab; k += BS) {
     const int32_t d = s_delta[k];
     if (d) atomicAdd(&dl[k], d);
   }
   D2_TRACE(1 + level, 4);
+}
+
+template <bool STORE>
+__global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E, int level) {
+  const Ctl2 *ctl = E.ctl;
+  if (v2_idle(E)) return;
+  Round2Out *out = E.dblk + (ctl->pub_seq % RING2);
+  if (ctl->nsh_base + level >= E.max_shuffle) return;
+  int moved_before = 0;
+  for (int l = 0; l < level; l++) {
+    const int c = out->cnt[l];
+    if (c == 0) return;                                                // an earlier call moved nothing: the loop has ended
+    moved_before += c;
+  }
+  __shared__ ShufLds<256> L;
+  shuffle_body<STORE, 256>(E, L, level, moved_before, E.movers + ((size_t)((ctl->pub_seq % MOV_RING) * SH_CHAIN + level)) * 3 * (size_t)E.S.N, out);
 }
 
 constexpr int LISTS_PER_THREAD = 8;
@@ -429,27 +456,36 @@ static __device__ __forceinline__ bool bud_candidate2(const Eng2 &E, int r, int 
 // uniques.
 constexpr int PUPD_TAB = 1024;    // partitions whose per-partition facts k2_pupdate keeps in LDS
 constexpr int SIG_CAP = 1024;
-__global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init, BudKey *__restrict__ partial) {
-  const Ctl2 *ctl = E.ctl;
-  if (v2_idle(E)) return;
-  Round2Out *out = E.dblk + (ctl->pub_seq % RING2);
-  const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
-  if (!cs.eval_ok) return;
-  __shared__ BudKey s_k[2][4];
-  __shared__ int32_t s_sig[SIG_CAP];
-  __shared__ int s_nsig, s_sbase;
+template <int BS>
+struct PupdLds {
+  BudKey s_k[2][BS / 64];
+  int32_t s_sig[SIG_CAP];
+  int s_nsig, s_sbase;
   // what a unique needs from ITS PARTITION (reads, update / lock flags, the centre and its reads) sits in LDS: the loads
   // behind clust_of[r] were a chain of three global round trips per unique in a latency-bound kernel
-  __shared__ uint32_t s_prd[PUPD_TAB], s_cread[PUPD_TAB];
-  __shared__ int32_t s_cen[PUPD_TAB];
-  __shared__ uint8_t s_upd[PUPD_TAB], s_chk[PUPD_TAB];
+  uint32_t s_prd[PUPD_TAB], s_cread[PUPD_TAB];
+  int32_t s_cen[PUPD_TAB];
+  uint8_t s_upd[PUPD_TAB], s_chk[PUPD_TAB];
+};
+// b_p_update + the first stage of b_bud's arg-min by a grid of BS-thread blocks, after `nexec` shuffle calls of the round: the
+// body of k2_pupdate (BS = 256) and of the evaluation phase of the persistent tail (BS = 1024).  partial[2 b], [2 b + 1]: block
+// b's best keys.
+template <int BS>
+static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L, int nexec, BudKey init, BudKey *__restrict__ partial) {
+  const Ctl2 *ctl = E.ctl;
+  BudKey (&s_k)[2][BS / 64] = L.s_k;
+  int32_t *s_sig = L.s_sig;
+  int &s_nsig = L.s_nsig, &s_sbase = L.s_sbase;
+  uint32_t *s_prd = L.s_prd, *s_cread = L.s_cread;
+  int32_t *s_cen = L.s_cen;
+  uint8_t *s_upd = L.s_upd, *s_chk = L.s_chk;
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   const int ntab = min(ctl->nclust, PUPD_TAB);
   D2_TRACE(5, 0);
-  for (int k = threadIdx.x; k < ntab; k += 256) {
+  for (int k = threadIdx.x; k < ntab; k += BS) {
     const int c = P.centre_of[k];
-    s_prd[k] = reads_at(E, k, cs.nexec);
+    s_prd[k] = reads_at(E, k, nexec);
     s_cen[k] = c;
     s_cread[k] = S.reads[c];
     s_upd[k] = P.update_e[k];
@@ -459,7 +495,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   __syncthreads();
   BudKey b0 = init, b1 = init;
   D2_TRACE(5, 1);
-  for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
+  for (int r = blockIdx.x * BS + threadIdx.x; r < S.N; r += gridDim.x * BS) {
     const int cl = P.clust_of[r];
     const double l = P.comp_lam[r];
     const uint32_t reads = S.reads[r];
@@ -468,7 +504,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
     const bool s0 = P.slot0[r] != 0;
     double p = P.p[r];
     const bool intab = cl < ntab;
-    const uint32_t prd = intab ? s_prd[cl] : reads_at(E, cl, cs.nexec);
+    const uint32_t prd = intab ? s_prd[cl] : reads_at(E, cl, nexec);
     if (intab ? s_upd[cl] : P.update_e[cl]) {
       p = dev_get_pA(reads, pr, E.detect_singletons != 0, l, ham, prd);
       P.p[r] = p;
@@ -503,7 +539,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   if ((threadIdx.x & 63) == 0) { s_k[0][w] = b0; s_k[1][w] = b1; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; k++) {
+    for (int k = 1; k < BS / 64; k++) {
       if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
       if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
     }
@@ -513,8 +549,17 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
     s_sbase = n ? atomicAdd(E.sig_n, n) : 0;                           // one global atomic per block
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < min(s_nsig, SIG_CAP); i += 256) E.sig_list[s_sbase + i] = s_sig[i];
+  for (int i = threadIdx.x; i < min(s_nsig, SIG_CAP); i += BS) E.sig_list[s_sbase + i] = s_sig[i];
   D2_TRACE(5, 3);
+}
+__global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init, BudKey *__restrict__ partial) {
+  const Ctl2 *ctl = E.ctl;
+  if (v2_idle(E)) return;
+  Round2Out *out = E.dblk + (ctl->pub_seq % RING2);
+  const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
+  if (!cs.eval_ok) return;
+  __shared__ PupdLds<256> L;
+  pupdate_body<256>(E, L, cs.nexec, init, partial);
 }
 
 // ---- the birth, the plan of the coming round's compare, and the publication of the round's result block -----------------
@@ -523,7 +568,7 @@ constexpr int PLAN_PER = 8;       // significant candidates each thread of k2_bi
 constexpr int PLAN_BITS = 65536;  // uniques below this index are looked up in a bitmap of the cached centres
 
 // block-wide arg-min of (p, reads, r) keys over the 1024 threads; returns the winning unique (or -1) to every thread
-static __device__ int block_best(double p, uint32_t reads, int r, double *s_p, uint32_t *s_rd, int *s_r) {
+static __device__ __forceinline__ int block_best(double p, uint32_t reads, int r, double *s_p, uint32_t *s_rd, int *s_r) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const double p2 = __shfl_xor(p, o, 64);
@@ -554,7 +599,7 @@ static __device__ int block_best(double p, uint32_t reads, int r, double *s_p, u
 // pass over the k-mer records - and builds the batch's k-mer tables.
 // what the aligner launches of the coming chain work on (Ctl2::nalign / abuf / acentre); `slot` is the new centre's cache slot,
 // nb the size of the batch just planned (0: the centre was cached)
-static __device__ void plan_aligner(const Eng2 &E, int centre, int slot, int nb) {
+static __device__ __forceinline__ void plan_aligner(const Eng2 &E, int centre, int slot, int nb) {
   Ctl2 *ctl = E.ctl;
   const int tid = threadIdx.x;
   __syncthreads();                                                      // (bcentre[] of a fresh batch is written)
@@ -568,7 +613,7 @@ static __device__ void plan_aligner(const Eng2 &E, int centre, int slot, int nb)
     if (nb > 0 && tid < 2 * KB_MAX) E.blist_n[tid] = 0;
   }
 }
-static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc) {
+static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   Ctl2 *ctl = E.ctl;
@@ -701,15 +746,13 @@ static __device__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, ui
   plan_aligner(E, raw, ctl->bbuf * KB_MAX, nb);
 }
 
-static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
+static __device__ __forceinline__ void publish_copy(const Eng2 &E, Round2Out *out, int ring, int seq) {
   // plain stores to pinned host memory, then the sequence number: the host polls it instead of copying and synchronising
-  Ctl2 *ctl = E.ctl;
   __syncthreads();
   int tot = 0;
-  for (int l = 0; l < SH_CHAIN; l++) tot += out->cnt[l];
-  if (tot > MOV_INLINE2) tot = MOV_INLINE2;
+  for (int l = 0; l < SH_LEVELS; l++) tot += out->cnt[l];
+  if (tot > E.mov_inline) tot = E.mov_inline;
   const int used16 = (int)((offsetof(Round2Out, mov) + (size_t)12 * tot + 15) / 16);
-  const int seq = ctl->pub_seq + 1;
   const uint4 *src = (const uint4 *)out;
   uint4 *dst = (uint4 *)(E.hblk + ring);
   for (int i = threadIdx.x; i < used16; i += blockDim.x) {
@@ -723,40 +766,32 @@ static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
   if (threadIdx.x == 0) {
     __threadfence_system();
     __hip_atomic_store(&E.hblk[ring].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    ctl->pub_seq = seq;
   }
 }
+static __device__ void publish_block(const Eng2 &E, Round2Out *out, int ring) {
+  const int seq = E.ctl->pub_seq + 1;
+  publish_copy(E, out, ring, seq);
+  if (threadIdx.x == 0) E.ctl->pub_seq = seq;
+}
 
-static __device__ void clear_block(Round2Out *nx) {
-  if (threadIdx.x < SH_CHAIN) nx->cnt[threadIdx.x] = 0;
+static __device__ __forceinline__ void clear_block(Round2Out *nx) {
+  if (threadIdx.x < SH_LEVELS) nx->cnt[threadIdx.x] = 0;
   if (threadIdx.x < 4) { nx->stat[threadIdx.x] = 0; nx->pad0[threadIdx.x] = 0; }
   if (threadIdx.x == 0) {
     nx->bud.nties[0] = 0; nx->bud.nties[1] = 0; nx->bud.valid = 0; nx->bud.found[0] = 0; nx->bud.found[1] = 0;
     nx->bud.auto_applied = 0; nx->halt = H2_NONE; nx->birth_applied = 0; nx->nsh = 0; nx->nlev = 0; nx->nbatch = 0;
+    nx->kord = 0; nx->paused = 0;
   }
 }
 
-__global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, const BudKey *__restrict__ partial, int nblocks) {
+// The serial end of a round (ONE block of 1024 threads): folds the reads deltas and class counts of the round's shuffle calls,
+// finishes b_bud's arg-min over the block minima, lists ties / near ties, takes the decision that is the device's to take,
+// applies the birth and plans the coming round's compare (apply_birth_and_plan), clears the next result block.  The caller
+// publishes.  cs: which of the chain's `nlev` shuffle calls ran and whether the evaluation behind them stands.
+// kord: 0 in a launch chain (k2_birth); the launch ordinal in the persistent tail (k3_tail), which also wants to know whether to
+// leave the launch after this round (Ctl2::kexit) and pauses when the round's movers do not fit the block.
+static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const Chain2 cs, BudKey init, const BudKey *__restrict__ partial, int nblocks, int kord) {
   Ctl2 *ctl = E.ctl;
-  const bool halted = ctl->state != 0, starved = !E.has_compare && ctl->need_compare != 0;
-  __syncthreads();                                                       // every thread has read both before thread 0 changes either
-  if (halted) return;
-  if (starved) {
-    // the chain came without the batch compare its round needs: nothing has run, say so and halt (the block was cleared by
-    // the previous chain's k2_birth)
-    const int ring0 = ctl->pub_seq % RING2;
-    Round2Out *o = E.dblk + ring0;
-    if (threadIdx.x == 0) {
-      o->halt = H2_NEED_COMPARE; o->nclust = ctl->nclust; o->birth_applied = 0; o->nlev = 0; o->nsh = 0; o->nbatch = 0; o->slot = ctl->slot;
-      o->err_flag = *E.P.err_flag | (*E.S.nw_flag ? 4 : 0); o->blk_count = *E.T.blk_count;
-      ctl->state = 1; ctl->halt = H2_NEED_COMPARE;
-    }
-    __syncthreads();
-    clear_block(E.dblk + ((ring0 + 1) % RING2));
-    publish_block(E, o, ring0);
-    return;
-  }
-  if (threadIdx.x == 0) ctl->need_compare = 0;                           // the round's compare, if it needed one, has run
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
   __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
   __shared__ int s_halt, s_raw, s_from, s_evalok, s_nt[2], s_nnear;
@@ -765,7 +800,6 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
   const SampleDev &S = E.S;
   const int ring = ctl->pub_seq % RING2;
   Round2Out *out = E.dblk + ring;
-  const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
   const int nclust = ctl->nclust;
   const bool tr = E.trace && ctl->pub_seq == E.trace_seq && threadIdx.x == 0;
 #define D2_TRB(PHASE) do { if (tr) E.trace[((size_t)6 * TRACE_BLOCKS) * 8 + (PHASE)] = gcn_clock(); } while (0)
@@ -773,7 +807,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
   // fold the chain's partition-read deltas into the reads
   for (int i = threadIdx.x; i < nclust; i += blockDim.x) {
     int32_t d = 0;
-    for (int l = 0; l < SH_CHAIN; l++) { d += E.dlt[(size_t)l * E.ccap + i]; E.dlt[(size_t)l * E.ccap + i] = 0; }
+    for (int l = 0; l < SH_LEVELS; l++) { d += E.dlt[(size_t)l * E.ccap + i]; E.dlt[(size_t)l * E.ccap + i] = 0; }
     if (d) P.creads[i] += (uint32_t)d;
   }
   if (threadIdx.x < 2) s_nt[threadIdx.x] = 0;
@@ -799,7 +833,7 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
     // partition 0's member count through the chain's shuffle calls: within one call only the number it lost is known, not
     // the order of losses and gains, so the running minimum is taken as if all losses came first (a lower bound)
     int n0 = ctl->n0, low0 = ctl->low0;
-    for (int l = 0; l < SH_CHAIN; l++) {
+    for (int l = 0; l < SH_LEVELS; l++) {
       const int lost = E.n0d[2 * l], gained = E.n0d[2 * l + 1];
       if (lost | gained) { E.n0d[2 * l] = 0; E.n0d[2 * l + 1] = 0; }
       if (n0 - lost < low0) low0 = n0 - lost;
@@ -937,10 +971,53 @@ __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, 
     if (threadIdx.x == 0) *E.sig_n = 0;                      // consumed: the next evaluation lists afresh
   }
   D2_TRB(4);
+  if (kord && threadIdx.x == 0) {
+    int tot = 0;
+    for (int l = 0; l < SH_LEVELS; l++) tot += out->cnt[l];
+    const bool pause = s_halt == H2_NONE && tot > E.mov_inline;      // the full lists stay in Eng2::movers until the host has them
+    if (pause) { out->paused = 1; ctl->state = 1; ctl->halt = H2_NONE; }
+    out->kord = kord;
+    // leave the launch after this round?  a halt, a pause, a compare (or, aligning at commit time, the aligner) is due, or the
+    // host's ring of result blocks would not take the NEXT block: publishing sequence number q reuses the slot of q - RING2
+    const int seq = ctl->pub_seq + 1;
+    int ex = (s_halt != H2_NONE || pause || ctl->need_compare != 0 || E.align_at_commit != 0) ? 1 : 0;
+    if (!ex && seq + 1 - ctl->hcons_seen > E.ring_limit) {
+      const int hc = gcn_load_system((const int32_t *)E.hcons);
+      ctl->hcons_seen = hc;
+      if (seq + 1 - hc > E.ring_limit) ex = 1;
+    }
+    ctl->kexit = ex;
+  }
   clear_block(E.dblk + ((ring + 1) % RING2));
-  publish_block(E, out, ring);
-  D2_TRB(5);
 #undef D2_TRB
+}
+
+__global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, const BudKey *__restrict__ partial, int nblocks) {
+  Ctl2 *ctl = E.ctl;
+  const bool halted = ctl->state != 0, starved = !E.has_compare && ctl->need_compare != 0;
+  __syncthreads();                                                       // every thread has read both before thread 0 changes either
+  if (halted) return;
+  if (starved) {
+    // the chain came without the batch compare its round needs: nothing has run, say so and halt (the block was cleared by
+    // the previous chain's k2_birth)
+    const int ring0 = ctl->pub_seq % RING2;
+    Round2Out *o = E.dblk + ring0;
+    if (threadIdx.x == 0) {
+      o->halt = H2_NEED_COMPARE; o->nclust = ctl->nclust; o->birth_applied = 0; o->nlev = 0; o->nsh = 0; o->nbatch = 0; o->slot = ctl->slot;
+      o->err_flag = *E.P.err_flag | (*E.S.nw_flag ? 4 : 0); o->blk_count = *E.T.blk_count;
+      ctl->state = 1; ctl->halt = H2_NEED_COMPARE;
+    }
+    __syncthreads();
+    clear_block(E.dblk + ((ring0 + 1) % RING2));
+    publish_block(E, o, ring0);
+    return;
+  }
+  if (threadIdx.x == 0) ctl->need_compare = 0;                           // the round's compare, if it needed one, has run
+  const int ring = ctl->pub_seq % RING2;
+  Round2Out *out = E.dblk + ring;
+  const Chain2 cs = chain_state(ctl, out, nlev, E.max_shuffle);
+  birth_body(E, nlev, cs, init, partial, nblocks, 0);
+  publish_block(E, out, ring);
 }
 
 // the host's own b_bud decision (ties, near ties, prior births, capacity) applied, the coming round planned, the device resumed

@@ -1,0 +1,188 @@
+// rounds3.inc.hip — the persistent round tail of engine v2 (engine.h); included by kernels.hip inside namespace d2
+// behind rounds2.inc.hip, whose phase bodies it runs.
+//
+// A round of run_dada (Rmain.cpp:316-331) behind its compare is  b_shuffle2 x (1..MAX_SHUFFLE)  ->  b_p_update  ->  b_bud  ->
+// birth.  As a chain of launches that is 4-8 kernels of 13-20 us each whose work is worth 2-4 us of HBM traffic: they are bound
+// by grid ramp-up, control-block loads, dependent gathers and the guarded launches that find nothing to do.  k3_tail runs the
+// same phase bodies inside ONE launch of G co-resident blocks (1024 threads, at most one per CU):
+//
+//   round:  commit + shuffle call 0 | barrier | shuffle call 1 | barrier | ... until a call moves nothing | evaluation |
+//           barrier, whose LAST ARRIVER runs the serial end of the round (birth_body: arg-min, ties, decision, birth, plan)
+//           before it releases the others | the same block then publishes the round's result block to the host
+//
+// and goes on to the next round for as long as the new centre's comparisons are cached.  It leaves the launch when a compare
+// is due (the launches of the batch compare follow in the stream, then the next k3_tail), when the device halts (the same
+// halts as the launch chains, minus SHUFFLE_MORE and NEED_COMPARE which cannot occur), when the round's movers did not fit the
+// result block (pause) or when the host's ring of result blocks would not take another one.
+//
+// Inter-block visibility (MI355X: eight XCDs with private L2s, per-CU L1s never refreshed by other CUs' stores) follows
+// /opt/skills/guides: every block drains its stores, one lane releases at agent scope and arrives on a monotonic counter; the
+// last arriver acquires, works, releases and bumps the generation word; the others poll it relaxed, acquire once, and only
+// then read.  Every spin is bounded (GRID_WAIT_S): a launch that cannot become co-resident fails loudly instead of hanging.
+// Nothing here depends on which XCD or in which order blocks run.
+
+constexpr double GRID_WAIT_S = 2.0;     // bound of a barrier wait (the slowest phase is tens of microseconds)
+
+template <int BS>
+struct TailLds {
+  union {
+    ShufLds<BS> sh;
+    PupdLds<BS> pu;
+  };
+  int last, ok;
+};
+
+static __device__ __forceinline__ void tail_fail(const Eng2 &E) {
+  // a barrier gave up: halt the device-side progression so that the launches queued behind this one do nothing
+  gcn_store_agent(&E.psync->fail, 1u);
+  E.ctl->state = 1; E.ctl->halt = H2_FAIL;
+}
+
+// Grid barrier with a serial section: every block arrives; the last one runs `serial` (the whole block, block barriers allowed)
+// between its acquire and the release of the others.  Returns false when the wait ran into its bound (every block then leaves).
+template <int BS, typename F>
+static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, uint32_t &epoch, int G, F &&serial) {
+  PSync *ps = E.psync;
+  gcn_drain_stores();                                   // every wave: its own stores have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int last = 1, ok = 1;
+    if (G > 1) {
+      gcn_release_agent();
+      const uint32_t t = gcn_add_agent(&ps->arrive, 1u);
+      last = t == (epoch + 1u) * (uint32_t)G - 1u;
+      if (!last) {
+        const unsigned long long t0 = gcn_wall_clock();
+        for (unsigned n = 1;; n++) {
+          if ((int32_t)(gcn_load_agent(&ps->gen) - (epoch + 1u)) >= 0) break;
+          gcn_poll_pause();
+          if ((n & 63u) == 0u && (gcn_load_agent(&ps->fail) != 0u || gcn_wall_clock() - t0 > (unsigned long long)(GRID_WAIT_S * GCN_WALL_HZ))) { ok = 0; break; }
+        }
+        if (!ok) tail_fail(E);
+      }
+      gcn_acquire_agent();
+    }
+    L.last = last; L.ok = ok;
+  }
+  __syncthreads();
+  if (!L.ok) return false;
+  if (L.last) {
+    serial();
+    if (G > 1) {
+      gcn_drain_stores();
+      __syncthreads();
+      if (threadIdx.x == 0) { gcn_release_agent(); gcn_store_agent(&ps->gen, epoch + 1u); }
+    }
+  }
+  epoch++;
+  return true;
+}
+
+__global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, int ordinal) {
+  constexpr int BS = 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn3[];
+  TailLds<BS> &L = *(TailLds<BS> *)s_dyn3;
+  Ctl2 *ctl = E.ctl;
+  const int G = (int)gridDim.x;
+  const bool timer = E.ktime != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long tk = timer ? gcn_wall_clock() : 0ull;
+#define KT_LAP(SLOT) do { if (timer) { const unsigned long long now_ = gcn_wall_clock(); E.ktime[SLOT] += now_ - tk; tk = now_; } } while (0)
+  if (ctl->state != 0) {                                 // halted before the launch (written by an earlier kernel: every block sees it)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *E.hexit = ordinal;
+    return;
+  }
+  uint32_t epoch = E.psync->gen;                         // barriers completed by earlier launches (arrive == gen * G between launches)
+  // entry: every block is resident before any state changes, and ONE block decides whether the host's ring takes the first
+  // result block of this launch (the host may still be reading the slot it goes to)
+  if (!grid_sync<BS>(E, L, epoch, G, [&]() {
+        if (threadIdx.x == 0) {
+          const int seq = ctl->pub_seq + 1;
+          int ex = 0;
+          if (seq - ctl->hcons_seen > E.ring_limit) {
+            const int hc = gcn_load_system((const int32_t *)E.hcons);
+            ctl->hcons_seen = hc;
+            if (seq - hc > E.ring_limit) ex = 1;
+          }
+          ctl->kexit = ex;
+          ctl->need_compare = 0;                          // the compare of the coming round, if it needed one, ran in front of this launch
+        }
+      }))
+    return;
+  if (ctl->kexit) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *E.hexit = ordinal;
+    return;
+  }
+  KT_LAP(KT_LAUNCH);
+  for (int rnd = 0;; rnd++) {
+    const int ring = ctl->pub_seq % RING2;
+    Round2Out *out = E.dblk + ring;
+    int level = 0;
+    if (!(first && rnd == 0)) {
+      // ---- commit of the round's cached comparisons + b_shuffle2 until a call moves nothing (Rmain.cpp:320-325) ----
+      shuffle_body<true, BS>(E, L.sh, 0, 0, E.movers, out);
+      KT_LAP(KT_S0);
+      if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
+      KT_LAP(KT_S0_BAR);
+      int moved = out->cnt[0];
+      level = 1;
+      while (level < E.max_shuffle && out->cnt[level - 1] > 0) {
+        shuffle_body<false, BS>(E, L.sh, level, moved, E.movers + (size_t)level * 3 * (size_t)E.S.N, out);
+        KT_LAP(KT_SL);
+        if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
+        KT_LAP(KT_SL_BAR);
+        moved += out->cnt[level];
+        level++;
+      }
+    }
+    // ---- b_p_update + the block minima of b_bud; the last block to arrive takes the round's decision ----
+    pupdate_body<BS>(E, L.pu, level, init, (BudKey *)E.partial);
+    KT_LAP(KT_P);
+    const int nlev = level;
+    if (!grid_sync<BS>(E, L, epoch, G, [&]() {
+          const unsigned long long tb = E.ktime ? gcn_wall_clock() : 0ull;
+          birth_body(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal);
+          if (threadIdx.x == 0) {
+            ctl->pub_seq = ctl->pub_seq + 1;              // (the others find the NEXT round's block through it)
+            if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
+          }
+        }))
+      return;
+    KT_LAP(KT_P_BAR);
+    const bool leave = ctl->kexit != 0;
+    if (L.last) {
+      // the block that took the decision publishes it while the others are already in the next round's first phase
+      const unsigned long long tp = E.ktime ? gcn_wall_clock() : 0ull;
+      publish_copy(E, out, ring, ctl->pub_seq);
+      if (threadIdx.x == 0) {
+        if (leave) *E.hexit = ordinal;
+        if (E.ktime) atomicAdd(&E.ktime[KT_PUBLISH], gcn_wall_clock() - tp);
+      }
+    }
+    if (leave) return;
+  }
+#undef KT_LAP
+}
+
+int tail_grid(int N, int device) {
+  static int ncu[64] = {0};
+  const int d = device & 63;
+  if (!ncu[d]) {
+    hipDeviceProp_t prop;
+    ncu[d] = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
+  }
+  // one block of 1024 threads per CU at most (they have to be co-resident); about four uniques per thread at 10^6 uniques
+  const int want = (N + 4095) / 4096;
+  return std::max(1, std::min(want, ncu[d]));
+}
+void launch3_tail(const Eng2 &E, int grid, bool first, int ordinal, uint32_t init_reads, hipStream_t st) {
+  BudKey init{1.0, init_reads};
+  const size_t lds = sizeof(TailLds<1024>);
+  static bool attr_set[64] = {false};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (!attr_set[dev_ & 63]) {
+    (void)hipFuncSetAttribute((const void *)k3_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev_ & 63] = true;
+  }
+  hipLaunchKernelGGL(k3_tail, dim3(grid), dim3(1024), lds, st, E, init, first ? 1 : 0, ordinal);
+}

@@ -97,6 +97,14 @@ typedef struct dada2hip_stats {
   /* rounds enqueued without the launches of a batch compare because their centre was expected to be cached, and how many
    * of those guesses were wrong (the device then halts and the host sends the full chain) */
   uint64_t lite_chains, lite_misses;
+  /* persistent round tail (one launch runs rounds back to back until the next batch compare is due): launches, blocks of the
+   * launch, pauses (a round whose mover lists did not fit its result block), shuffle calls; under DADA2HIP_PROFILE=1 also the
+   * device time of those launches and what block 0 of them spent in each phase (barriers = waiting for the other blocks,
+   * which includes the serial end of the round run by the last arriver) */
+  uint64_t tail_launches, tail_pauses, tail_levels;
+  uint32_t tail_blocks, tail_reserved;
+  double dev_ms_tail, tail_ms_entry, tail_ms_shuffle0, tail_ms_shuffle_more, tail_ms_pupdate, tail_ms_barriers, tail_ms_birth,
+      tail_ms_publish;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------

@@ -37,7 +37,7 @@ def build(force=False):
     os.environ.setdefault("DADA2HIP_SYSTEM_HIP", "1")   # (the emulated library links no HIP runtime: nothing to share with torch)
     os.makedirs(os.path.join(OUT, "csrc"), exist_ok=True)
     os.makedirs(os.path.join(OUT, "include"), exist_ok=True)
-    srcs = sorted(f for f in os.listdir(SRC) if f.endswith((".hip", ".cpp", ".h")))
+    srcs = sorted(f for f in os.listdir(SRC) if f.endswith((".hip", ".cpp", ".h")))   # (the .inc.hip files are copied too)
     deps = [os.path.join(SRC, f) for f in srcs] + [os.path.join(HERE, f) for f in ("emu.cpp", "gcn.h", "build.py", "hip/hip_runtime.h")]
     deps.append(os.path.join(ROOT, "include", "dada2hip.h"))
     lib = os.path.join(OUT, "libdada2hip_emu.so")

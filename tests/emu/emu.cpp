@@ -1,7 +1,11 @@
 // tests/emu/emu.cpp — TEST INFRASTRUCTURE ONLY (see tests/emu/hip/hip_runtime.h).
 //
 // Executes a "kernel launch" on the host: the blocks of the grid one after the other, the threads of a block as fibers
-// on one host thread.  A fiber runs until it finishes or reaches a rendezvous:
+// on one host thread.  A block that waits for OTHER blocks (the grid barrier of the persistent round-tail kernel: its
+// polling lane calls emu::grid_yield() where the GPU code sleeps) is parked with its fibers, stacks and dynamic LDS intact,
+// the remaining blocks are started, and the parked ones are resumed in turn until every block has finished - so a kernel
+// whose blocks synchronise through global memory runs here with as many co-resident blocks as its grid has.
+// A fiber runs until it finishes or reaches a rendezvous:
 //   * a cross-lane operation of its wave (shuffle / DPP shift / ballot / readfirstlane) over the lanes
 //     [base, base + width) - released when every LIVE lane of that group waits in an operation of the same width, and
 //     the scheduler computes each lane's result at that moment (lanes that have left the kernel count as inactive:
@@ -126,7 +130,7 @@ emu_switch:
 .size emu_switch,.-emu_switch
 )");
 
-enum State : uint8_t { RUN, WAIT_WAVE, WAIT_BLOCK, DONE };
+enum State : uint8_t { RUN, WAIT_WAVE, WAIT_BLOCK, WAIT_GRID, DONE };
 
 struct Lane {
   void *sp = nullptr;
@@ -146,6 +150,8 @@ struct Block {
   int running = -1;
   const std::function<void()> *body = nullptr;
   char *stacks = nullptr;
+  void *lds = nullptr;     // dynamic LDS of this block (a parked block keeps its own)
+  Idx bid{0, 0, 0};
 };
 
 Block *B = nullptr;
@@ -246,8 +252,14 @@ bool release_waves(Block *b) {
   return any;
 }
 
-void run_block(Block *b) {
-  for (int t = 0; t < b->n; t++) init_fiber(b, t);
+// Runs block b until it has finished (true) or until nothing in it can move before another block does: some lane polls
+// global memory in emu::grid_yield() and every other live lane waits for it (false: the caller parks the block).
+bool run_block(Block *b, bool fresh) {
+  B = b;
+  cur.bid = b->bid;
+  cur.dyn_lds = b->lds;
+  if (fresh) for (int t = 0; t < b->n; t++) init_fiber(b, t);
+  else for (int t = 0; t < b->n; t++) if (b->lanes[t].st == WAIT_GRID) b->lanes[t].st = RUN;   // poll again
   for (;;) {
     bool progressed = false;
     int ndone = 0;
@@ -261,7 +273,7 @@ void run_block(Block *b) {
       progressed = true;
       if (x.st == DONE) ndone++;
     }
-    if (ndone == b->n) break;
+    if (ndone == b->n) return true;
     if (release_waves(b)) progressed = true;
     {   // __syncthreads: every live thread waits in it
       int nlive = 0, nbar = 0;
@@ -276,6 +288,7 @@ void run_block(Block *b) {
       }
     }
     if (!progressed) {
+      for (int t = 0; t < b->n; t++) if (b->lanes[t].st == WAIT_GRID) return false;   // waits for another block
       fprintf(stderr, "[emu] DEADLOCK in block (%u,%u,%u): lanes wait for rendezvous that can never complete\n", cur.bid.x, cur.bid.y, cur.bid.z);
       for (int t = 0; t < b->n; t++) {
         const Lane &x = b->lanes[t];
@@ -286,6 +299,17 @@ void run_block(Block *b) {
       abort();
     }
   }
+}
+
+// block contexts: one is enough for an ordinary launch; every parked block holds one until it finishes
+std::vector<Block *> pool;
+Block *acquire_block() {
+  if (!pool.empty()) { Block *b = pool.back(); pool.pop_back(); return b; }
+  Block *b = new Block();
+  b->stacks = (char *)mmap(nullptr, STACK_BYTES * MAX_THREADS, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (b->stacks == (char *)MAP_FAILED) { perror("[emu] mmap"); abort(); }
+  b->lds = std::aligned_alloc(64, 160 * 1024);
+  return b;
 }
 
 }  // namespace
@@ -308,33 +332,42 @@ void block_barrier() {
   yield_to_scheduler();
 }
 
+// the polling lane of a grid-level wait: let the other blocks run (the GPU code sleeps here)
+void grid_yield() {
+  Block *b = B;
+  Lane &me = b->lanes[b->running];
+  me.st = WAIT_GRID;
+  yield_to_scheduler();
+}
+
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body) {
   static std::mutex mu;   // host threads of dada2hip_run_multi: one emulated launch at a time
   std::lock_guard<std::mutex> guard(mu);
-  static Block *blk = nullptr;
-  static void *lds = nullptr;
-  if (!blk) {
-    blk = new Block();
-    blk->stacks = (char *)mmap(nullptr, STACK_BYTES * MAX_THREADS, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (blk->stacks == (char *)MAP_FAILED) { perror("[emu] mmap"); abort(); }
-    lds = std::aligned_alloc(64, 160 * 1024);
-  }
   if (B) { fprintf(stderr, "[emu] nested launch\n"); abort(); }
   const unsigned nthreads = block.x * block.y * block.z;
   if (nthreads == 0 || nthreads > (unsigned)MAX_THREADS || lds_bytes > 160 * 1024) { fprintf(stderr, "[emu] bad launch geometry\n"); abort(); }
-  B = blk;
-  blk->n = (int)nthreads;
-  blk->body = &body;
   cur.bdim = Idx{block.x, block.y, block.z};
   cur.gdim = Idx{grid.x, grid.y, grid.z};
-  cur.dyn_lds = lds;
-  for (unsigned t = 0; t < nthreads; t++) blk->lanes[t].tid = Idx{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+  std::vector<Block *> parked;
   for (unsigned bz = 0; bz < grid.z; bz++)
     for (unsigned by = 0; by < grid.y; by++)
       for (unsigned bx = 0; bx < grid.x; bx++) {
-        cur.bid = Idx{bx, by, bz};
-        run_block(blk);
+        Block *blk = acquire_block();
+        blk->n = (int)nthreads;
+        blk->body = &body;
+        blk->bid = Idx{bx, by, bz};
+        for (unsigned t = 0; t < nthreads; t++) blk->lanes[t].tid = Idx{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+        if (run_block(blk, true)) pool.push_back(blk);
+        else {
+          parked.push_back(blk);
+          if (parked.size() > 64) { fprintf(stderr, "[emu] more than 64 blocks wait for one another: not a grid this emulator holds\n"); abort(); }
+        }
       }
+  while (!parked.empty())
+    for (size_t k = 0; k < parked.size();) {
+      if (run_block(parked[k], false)) { pool.push_back(parked[k]); parked[k] = parked.back(); parked.pop_back(); }
+      else k++;
+    }
   B = nullptr;
 }
 

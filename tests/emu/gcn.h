@@ -27,6 +27,17 @@ template <bool BOUND_CTRL> static inline int gcn_wave_shl1(int old, int src) {
 }
 static inline unsigned long long gcn_clock() { return 0; }
 static inline void gcn_wave_sync() { (void)emu::wave_op(emu::OP_BALLOT, 64, 0, 0, 0, false, false); }
+static inline void gcn_drain_stores() {}
+static inline void gcn_release_agent() {}
+static inline void gcn_acquire_agent() {}
+static inline uint32_t gcn_load_agent(const uint32_t *p) { return *(const volatile uint32_t *)p; }
+static inline void gcn_store_agent(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
+static inline uint32_t gcn_add_agent(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+static inline int32_t gcn_load_system(const int32_t *p) { return *(const volatile int32_t *)p; }
+static inline void gcn_poll_pause() { emu::grid_yield(); }   // the other blocks of the launch run while this lane waits
+// a counter instead of a clock: every look at it is one "tick", so a wait that can never end still runs into its bound
+static inline unsigned long long gcn_wall_clock() { static unsigned long long t = 0; return t += 64; }
+constexpr unsigned long long GCN_WALL_HZ = 100000000ull;
 static inline int gcn_readfirstlane(int v) { return (int)(uint32_t)emu::wave_op(emu::OP_READFIRST, 64, (uint32_t)v, 0, 0, false, false); }
 
 }  // namespace d2

@@ -55,6 +55,7 @@ enum Op { OP_SHFL, OP_SHFL_XOR, OP_DPP_SHR1, OP_DPP_SHL1, OP_BALLOT, OP_READFIRS
 // rendezvous of the lanes [base, base + width) of the calling lane's wave; returns this lane's result
 uint64_t wave_op(Op op, int width, uint64_t value, int param, uint64_t old, bool bound_ctrl, bool pred);
 void block_barrier();
+void grid_yield();   // the polling lane of a grid-level wait (the persistent round-tail kernel's barrier): run the other blocks
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body);
 inline void *dyn_lds() { return cur.dyn_lds; }
 
@@ -144,6 +145,7 @@ inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::memset(p, 0, sizeof *p); p->multiProcessorCount = 8; p->clockRate = 1000000; return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = *tot = (size_t)16 << 30; return hipSuccess; }
 inline hipError_t hipDeviceTotalMem(size_t *tot, int) { *tot = (size_t)16 << 30; return hipSuccess; }
 // EMU_GUARD=1: every "device" allocation ends at an inaccessible page, so the first store past a buffer faults where it

@@ -47,10 +47,19 @@ def run_cases(emu_lib, names, env=None, timeout=900):
 
 
 @pytest.mark.parametrize("env", [{}, {"DADA2HIP_ENGINE": "classic"}, {"DADA2HIP_NW_KERNEL": "lane"}, {"DADA2HIP_NW_KERNEL": "wide"},
-                                 {"DADA2HIP_V2_ALIGN": "commit"}, {"DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_NBUF": "1"},
-                                 {"DADA2HIP_V2_ALIGN": "commit", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_CHAIN": "1", "DADA2HIP_NODE_CAP": "1"}],
-                         ids=["default", "classic-engine", "lane-kernel", "wide-kernel", "align-at-commit", "nolite-nbuf1",
-                              "commit-nbuf1-chain1-grow"])
+                                 {"DADA2HIP_V2_ALIGN": "commit", "DADA2HIP_V3_GRID": "2"},
+                                 # the persistent round tail (k3_tail) with several co-resident blocks, with mover lists that do not
+                                 # fit the result block (pause), with a host that lags (ring limit), growing its buffers
+                                 {"DADA2HIP_V3_GRID": "3"}, {"DADA2HIP_V3_GRID": "5", "DADA2HIP_V2_MOV_INLINE": "8"},
+                                 {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V3_RING": "1", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_NODE_CAP": "1"},
+                                 # the launch chains (DADA2HIP_V2_TAIL=chain: what a second sample on the same device runs on)
+                                 {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_ALIGN": "commit"},
+                                 {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_MOV_INLINE": "8"},
+                                 {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_ALIGN": "commit", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_CHAIN": "1",
+                                  "DADA2HIP_NODE_CAP": "1"}],
+                         ids=["default", "classic-engine", "lane-kernel", "wide-kernel", "align-at-commit-grid2", "tail-grid3", "tail-grid5-pauses",
+                              "tail-grid2-ring1-nbuf1-grow", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
+                              "chains-commit-nbuf1-chain1-grow"])
 def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
     out = run_cases(emu_lib, ("sam1F_default", "sam1R_default"), env)
     assert "ok sam1F_default 10 " in out

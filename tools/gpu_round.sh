@@ -18,6 +18,9 @@ for s in $STEPS; do
     tests_fast) timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not 1M and not config5 and not config2" --durations=10 > $OUT/gputests_fast.log 2>&1; echo "tests_fast rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_fast.log ;;
     tests_new) timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -k "${TESTS_K:-user_alignment or longer_than or 4500}" --durations=10 > $OUT/gputests_new.log 2>&1; echo "tests_new rc=$?" >> $OUT/steps.log; tail -15 $OUT/gputests_new.log ;;
     nwphases5) timeout 900 python tools/nw_phases.py --config 5 --uniques ${NWP_UNIQUES:-60000} --sizes 2000,8000,20000,40000 --reps 3 > $OUT/nw_phases_cfg5.jsonl 2> $OUT/nw_phases_cfg5.err; echo "nwphases5 rc=$?" >> $OUT/steps.log; cat $OUT/nw_phases_cfg5.jsonl; tail -3 $OUT/nw_phases_cfg5.err ;;
+    smoke)   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/steps.log; tail -3 $OUT/smoke.log ;;
+    bench3qchain) DADA2HIP_V2_TAIL=chain timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg3_quick_chain.json 2> $OUT/bench_cfg3_quick_chain.err; echo "bench3qchain rc=$?" >> $OUT/steps.log; python3 -c "import json;b=json.load(open('$OUT/bench_cfg3_quick_chain.json'));print(b['ms_per_step'], b['resident']);print(b['phases_ms_last_step'])" ;;
+    bench2q) timeout 600 python bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg2_quick.json 2> $OUT/bench_cfg2_quick.err; echo "bench2q rc=$?" >> $OUT/steps.log; python3 -c "import json;b=json.load(open('$OUT/bench_cfg2_quick.json'));print(b['ms_per_step'], b['resident']);print(b['phases_ms_last_step'])" ;;
     occ)     timeout 300 tools/microbench occ > $OUT/occ.json 2> $OUT/occ.err; echo "occ rc=$?" >> $OUT/steps.log; cat $OUT/occ.json ;;
     launch)  timeout 300 tools/microbench launch > $OUT/launch.json 2> $OUT/launch.err; echo "launch rc=$?" >> $OUT/steps.log; cat $OUT/launch.json ;;
     tests_iter) timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not at_size and not 1M" --durations=10 > $OUT/gputests_iter.log 2>&1; echo "tests_iter rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_iter.log ;;
