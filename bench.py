@@ -361,9 +361,9 @@ def phases(st, prof):
                                  "shuffle_calls": prof["tail_levels"],
                                  "block0_ms": {k[8:]: round(prof[k], 3) for k in ("tail_ms_entry", "tail_ms_shuffle0", "tail_ms_shuffle_more",
                                                                                   "tail_ms_pupdate", "tail_ms_barriers", "tail_ms_birth",
-                                                                                  "tail_ms_publish")},
+                                                                                  "tail_ms_publish", "tail_ms_release")},
                                  "note": "block 0's wall clock inside the persistent launches: entry = entry barrier, barriers = waiting for the "
-                                         "other blocks incl. the serial end of the round (birth) run by the last arriver; birth / publish = time "
+                                         "other blocks incl. the serial end of the round (birth) run by the last arriver and block 0's own agent-scope release (release); birth / publish = time "
                                          "the deciding block spent in the serial section / copying the result block to the host"}
     return out
 

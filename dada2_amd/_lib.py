@@ -38,7 +38,7 @@ class CStats(C.Structure):
         ("tail_blocks", C.c_uint32), ("tail_reserved", C.c_uint32),
         ("dev_ms_tail", C.c_double), ("tail_ms_entry", C.c_double), ("tail_ms_shuffle0", C.c_double),
         ("tail_ms_shuffle_more", C.c_double), ("tail_ms_pupdate", C.c_double), ("tail_ms_barriers", C.c_double),
-        ("tail_ms_birth", C.c_double), ("tail_ms_publish", C.c_double),
+        ("tail_ms_birth", C.c_double), ("tail_ms_publish", C.c_double), ("tail_ms_release", C.c_double),
     ]
 
     def as_dict(self):

@@ -1422,6 +1422,7 @@ struct Run {
   // run_dada's loop (Rmain.cpp:312-331) with the rounds inside persistent launches: the host keeps v2_depth super-chains queued,
   // trails the device through the published result blocks exactly as with the launch chains, and answers the same halts
   void run_v3(int max_clust) {
+    struct SlotGuard { Run *r; ~SlotGuard() { r->v3_release(); } } slot_guard{this};   // the device's persistent slot is held for the rounds only
     auto t0 = clk::now();
     st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
     v3_rec.clear();
@@ -1505,7 +1506,7 @@ struct Run {
       st.tail_ms_shuffle0 = kt[KT_S0] * ms; st.tail_ms_shuffle_more = kt[KT_SL] * ms; st.tail_ms_pupdate = kt[KT_P] * ms;
       st.tail_ms_barriers = (kt[KT_S0_BAR] + kt[KT_SL_BAR] + kt[KT_P_BAR]) * ms; st.tail_ms_birth = kt[KT_BIRTH] * ms;
       st.tail_ms_publish = kt[KT_PUBLISH] * ms; st.tail_ms_entry = kt[KT_LAUNCH] * ms;
-      st.tail_levels = kt[KT_LEVELS];
+      st.tail_levels = kt[KT_LEVELS]; st.tail_ms_release = kt[KT_RELEASE] * ms;
     }
     st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid;
     if (getenv("DADA2HIP_V2_SUMMARY"))

@@ -155,33 +155,39 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
   int my_n0 = 0;                                                         // members partition 0 lost (low half) / gained (high half)
   D2_TRACE(1 + level, 1);
-  for (int base = blockIdx.x * BS; base < N; base += gridDim.x * BS) {
-    const int r = base + threadIdx.x;
+  // The sweep is bound by memory latency, not bytes: a thread's uniques are taken U at a time - FIRST every unique's few bytes
+  // that decide whether it has anything to do (second stored comparison? class of this round's comparison, reads, lock), THEN,
+  // for the ones that do, what the decision needs (the stored lambdas, this round's lambda / hamming / E_minmax), then the work.
+  // Two dependent round trips per U uniques; round 3 went through them one unique at a time (a chain of two to three per
+  // unique, 14-20 us per sweep of 10^6 uniques for 12-50 MB), and loaded every field of every unique.
+  constexpr int U = BS >= 1024 ? 4 : 2;
+  struct Pre {
+    int r, i1, from, head_raw;
+    uint32_t cl;
+    bool on, want2, maykeep;
+    double lam0, lam1, l_raw, em;
+    uint32_t h_raw;
+  };
+  auto process = [&](const Pre &q) __attribute__((always_inline)) {
+    const int r = q.r;
     bool keep = false, need_new = false, move = false;
     double l = 0.0, best_l = 0.0;
     uint32_t h = 0, best_h = 0;
-    int head = -1, hcnt = 3, apos = 0, pos = 0, from = 0, to = 0;
-    if (r < N) {
-      // everything the common cases need is requested up front, independent of one another: ONE memory round trip instead
-      // of a chain of three (the kernel is latency-bound; by the later rounds most uniques hold a second comparison)
-      const int i1 = T.i1[r];
-      const int head_raw = T.head[r];
-      from = P.clust_of[r];
+    int head = -1, hcnt = 3, apos = 0, pos = 0, from = q.from, to = 0;
+    if (q.on) {
+      const int i1 = q.i1;
+      const int head_raw = q.head_raw;
       bool need = true;
       if (filt)   // (a unique with one stored comparison never moves; chains are not walked for the test: any rise counts)
         need = i1 >= 0 && (sgn_of(from) < 0 || (anyinc && ((from != 0 && sgn_of(0) > 0) || (i1 != from && sgn_of(i1) > 0) || head_raw >= 0)));
       if (need) {
-      const double lam0_r = T.lam0[r], lam1_r = T.lam1[r];
-      uint32_t cl = 0;
+      const double lam0_r = q.lam0, lam1_r = q.lam1;
+      const uint32_t cl = q.cl;
       if (STORE) {
-        cl = ((uint32_t)cls_row[r] >> kpos2) & 3u;
-        const bool skip = E.greedy && (S.reads[r] > creads_c || P.lock[r] != 0);
-        if (skip) cl = CLS_SKIP;
-        else if (cl == CLS_SKIP) atomicOr(P.err_flag, 8);              // the cache lacks a comparison the round needs
         if (cl >= CLS_GAPLESS) st01 += cl == CLS_NW ? 1u : 0x10000u; else st23 += cl == CLS_SHROUD ? 1u : 0x10000u;
       }
-      const double l_raw = STORE ? lam_row[r] : 0.0, em = STORE ? P.E_minmax[r] : 0.0;
-      const uint32_t h_raw = STORE ? ham_row[r] : 0u;
+      const double l_raw = q.l_raw, em = q.em;
+      const uint32_t h_raw = q.h_raw;
       head = i1 >= 0 ? head_raw : -1;                                    // (a chain only exists behind a used second entry)
       if (STORE) {
         if (cl >= CLS_GAPLESS) {
@@ -273,6 +279,46 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
         if (ki < E.mov_inline) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
       }
     }
+  };
+  for (int base = blockIdx.x * BS * U; base < N; base += gridDim.x * BS * U) {
+    Pre q[U];
+    // ---- first round trip: what decides whether the unique has anything to do ----
+    uint32_t clw[U], rds[U];
+    uint8_t lks[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = base + u * BS + threadIdx.x;
+      q[u].r = r; q[u].on = r < N;
+      q[u].i1 = -1; q[u].from = 0; clw[u] = 0; rds[u] = 0; lks[u] = 0;
+      if (q[u].on) {
+        q[u].i1 = T.i1[r];
+        q[u].from = P.clust_of[r];
+        if (STORE) { clw[u] = cls_row[r]; rds[u] = S.reads[r]; lks[u] = P.lock[r]; }
+      }
+    }
+    // ---- second round trip: only for the uniques that hold a second stored comparison or get one now ----
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = q[u].r;
+      uint32_t cl = 0;
+      if (STORE && q[u].on) {
+        cl = (clw[u] >> kpos2) & 3u;
+        const bool skip = E.greedy && (rds[u] > creads_c || lks[u] != 0);
+        if (skip) cl = CLS_SKIP;
+        else if (cl == CLS_SKIP) atomicOr(P.err_flag, 8);              // the cache lacks a comparison the round needs
+      }
+      q[u].cl = cl;
+      q[u].maykeep = STORE && cl >= CLS_GAPLESS;
+      q[u].want2 = q[u].on && (q[u].i1 >= 0 || q[u].maykeep);
+      q[u].head_raw = -1; q[u].lam0 = 0.0; q[u].lam1 = 0.0; q[u].l_raw = 0.0; q[u].em = 0.0; q[u].h_raw = 0u;
+      if (q[u].want2) {
+        q[u].lam0 = T.lam0[r];
+        if (q[u].i1 >= 0) { q[u].head_raw = T.head[r]; q[u].lam1 = T.lam1[r]; }
+        if (q[u].maykeep) { q[u].l_raw = lam_row[r]; q[u].h_raw = ham_row[r]; q[u].em = P.E_minmax[r]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) process(q[u]);
   }
   __syncthreads();                                                       // the block's movers / new blocks are all buffered
   D2_TRACE(1 + level, 2);
@@ -495,14 +541,33 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
   __syncthreads();
   BudKey b0 = init, b1 = init;
   D2_TRACE(5, 1);
-  for (int r = blockIdx.x * BS + threadIdx.x; r < S.N; r += gridDim.x * BS) {
-    const int cl = P.clust_of[r];
-    const double l = P.comp_lam[r];
-    const uint32_t reads = S.reads[r];
-    const uint32_t ham = P.comp_ham[r];
-    const bool pr = S.prior[r] != 0;
-    const bool s0 = P.slot0[r] != 0;
-    double p = P.p[r];
+  // (latency-bound like the shuffle sweep: the seven loads of U uniques are requested together, then the uniques are worked on)
+  constexpr int U = BS >= 1024 ? 4 : 2;
+  for (int base = blockIdx.x * BS * U; base < S.N; base += gridDim.x * BS * U) {
+    int cls_[U];
+    double ls_[U], ps_[U];
+    uint32_t rds_[U], hams_[U];
+    uint8_t prs_[U], s0s_[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = base + u * BS + threadIdx.x;
+      cls_[u] = -1; ls_[u] = 0.0; ps_[u] = 0.0; rds_[u] = 0; hams_[u] = 0; prs_[u] = 0; s0s_[u] = 0;
+      if (r < S.N) {
+        cls_[u] = P.clust_of[r]; ls_[u] = P.comp_lam[r]; rds_[u] = S.reads[r]; hams_[u] = P.comp_ham[r];
+        prs_[u] = S.prior[r]; s0s_[u] = P.slot0[r]; ps_[u] = P.p[r];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+    const int r = base + u * BS + threadIdx.x;
+    if (cls_[u] < 0) continue;
+    const int cl = cls_[u];
+    const double l = ls_[u];
+    const uint32_t reads = rds_[u];
+    const uint32_t ham = hams_[u];
+    const bool pr = prs_[u] != 0;
+    const bool s0 = s0s_[u] != 0;
+    double p = ps_[u];
     const bool intab = cl < ntab;
     const uint32_t prd = intab ? s_prd[cl] : reads_at(E, cl, nexec);
     if (intab ? s_upd[cl] : P.update_e[cl]) {
@@ -524,6 +589,7 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
     if (p * S.N < 2.0 * E.bp.omegaA || (pr && p < 2.0 * E.bp.omegaP)) {
       const int q = atomicAdd(&s_nsig, 1);
       if (q < SIG_CAP) s_sig[q] = r; else E.sig_list[atomicAdd(E.sig_n, 1)] = r;
+    }
     }
   }
   D2_TRACE(5, 2);
@@ -807,7 +873,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
   // fold the chain's partition-read deltas into the reads
   for (int i = threadIdx.x; i < nclust; i += blockDim.x) {
     int32_t d = 0;
-    for (int l = 0; l < SH_LEVELS; l++) { d += E.dlt[(size_t)l * E.ccap + i]; E.dlt[(size_t)l * E.ccap + i] = 0; }
+    for (int l = 0; l < cs.nexec; l++) { d += E.dlt[(size_t)l * E.ccap + i]; E.dlt[(size_t)l * E.ccap + i] = 0; }   // (the rows of calls that did not run hold zeros)
     if (d) P.creads[i] += (uint32_t)d;
   }
   if (threadIdx.x < 2) s_nt[threadIdx.x] = 0;
@@ -833,7 +899,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
     // partition 0's member count through the chain's shuffle calls: within one call only the number it lost is known, not
     // the order of losses and gains, so the running minimum is taken as if all losses came first (a lower bound)
     int n0 = ctl->n0, low0 = ctl->low0;
-    for (int l = 0; l < SH_LEVELS; l++) {
+    for (int l = 0; l < cs.nexec; l++) {
       const int lost = E.n0d[2 * l], gained = E.n0d[2 * l + 1];
       if (lost | gained) { E.n0d[2 * l] = 0; E.n0d[2 * l + 1] = 0; }
       if (n0 - lost < low0) low0 = n0 - lost;

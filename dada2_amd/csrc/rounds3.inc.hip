@@ -48,7 +48,10 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
   if (threadIdx.x == 0) {
     int last = 1, ok = 1;
     if (G > 1) {
+      const bool tm = E.ktime != nullptr && blockIdx.x == 0;
+      const unsigned long long tr0 = tm ? gcn_wall_clock() : 0ull;
       gcn_release_agent();
+      if (tm) E.ktime[KT_RELEASE] += gcn_wall_clock() - tr0;
       const uint32_t t = gcn_add_agent(&ps->arrive, 1u);
       last = t == (epoch + 1u) * (uint32_t)G - 1u;
       if (!last) {
@@ -60,6 +63,11 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
         }
         if (!ok) tail_fail(E);
       }
+      gcn_acquire_agent();
+    } else {
+      // one block: no other block to wait for, but the phase that follows reads through this CU's L1 what device-scope atomics
+      // of the phase before left in L2 (reads deltas, counters): the L1 lines have to go, as at a kernel boundary
+      gcn_release_agent();
       gcn_acquire_agent();
     }
     L.last = last; L.ok = ok;

@@ -104,7 +104,7 @@ typedef struct dada2hip_stats {
   uint64_t tail_launches, tail_pauses, tail_levels;
   uint32_t tail_blocks, tail_reserved;
   double dev_ms_tail, tail_ms_entry, tail_ms_shuffle0, tail_ms_shuffle_more, tail_ms_pupdate, tail_ms_barriers, tail_ms_birth,
-      tail_ms_publish;
+      tail_ms_publish, tail_ms_release;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------
