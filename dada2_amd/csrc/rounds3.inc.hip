@@ -76,10 +76,14 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
   if (!L.ok) return false;
   if (L.last) {
     serial();
+    gcn_drain_stores();
+    __syncthreads();                                    // the whole block is through the serial section
     if (G > 1) {
-      gcn_drain_stores();
-      __syncthreads();
       if (threadIdx.x == 0) { gcn_release_agent(); gcn_store_agent(&ps->gen, epoch + 1u); }
+    } else {
+      // one block: its own waves read next what the serial section just wrote (the control block, the new centre's state)
+      if (threadIdx.x == 0) { gcn_release_agent(); gcn_acquire_agent(); }
+      __syncthreads();
     }
   }
   epoch++;

@@ -23,7 +23,7 @@ for s in $STEPS; do
     bench2q) timeout 600 python bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg2_quick.json 2> $OUT/bench_cfg2_quick.err; echo "bench2q rc=$?" >> $OUT/steps.log; python3 -c "import json;b=json.load(open('$OUT/bench_cfg2_quick.json'));print(b['ms_per_step'], b['resident']);print(b['phases_ms_last_step'])" ;;
     occ)     timeout 300 tools/microbench occ > $OUT/occ.json 2> $OUT/occ.err; echo "occ rc=$?" >> $OUT/steps.log; cat $OUT/occ.json ;;
     launch)  timeout 300 tools/microbench launch > $OUT/launch.json 2> $OUT/launch.err; echo "launch rc=$?" >> $OUT/steps.log; cat $OUT/launch.json ;;
-    tests_iter) timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not at_size and not 1M" --durations=10 > $OUT/gputests_iter.log 2>&1; echo "tests_iter rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_iter.log ;;
+    tests_iter) timeout 1200 python -X faulthandler -m pytest tests -m gpu -q -rf -p no:cacheprovider -k "not at_size and not 1M" --durations=10 > $OUT/gputests_iter.log 2>&1; echo "tests_iter rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_iter.log ;;
     peaks)   timeout 300 tools/microbench peaks > $OUT/peaks.json 2> $OUT/peaks.err; echo "peaks rc=$?" >> $OUT/steps.log; cat $OUT/peaks.json ;;
     bench3)  timeout 1200 python bench.py --steps 5 --warmup 2 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; echo "bench3 rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3.json ;;
     bench3q) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg3_quick.json 2> $OUT/bench_cfg3_quick.err; echo "bench3q rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg3_quick.json; python3 -c "import json;b=json.load(open('$OUT/bench_cfg3_quick.json'));print(b['resident']);print(b['phases_ms_last_step'])" ;;
