@@ -1419,6 +1419,39 @@ struct Run {
     st.ms_enqueue += ms_since(t_enq);
   }
 
+  // Wait for the next result block, keeping v2_depth super-chains queued meanwhile.  The device reports the end of every launch
+  // through a word of its own (v3_ended), which can reach the host a moment after the last block of that launch: a stream that
+  // has gone idle without a block in sight is therefore no error as long as a further launch can still be sent.
+  const Round2Out &v3_wait_block() {
+    const int ring = (int)(v2_cons % RING2);
+    const int32_t want = (int32_t)(v2_cons + 1);
+    volatile int32_t *seqp = &v2_hblk.p[ring].seq;
+    const auto tw = clk::now();
+    const bool polite = wait_blocks();
+    for (unsigned spins = 0; *seqp != want; spins++) {
+      if (v3_enq - v3_ended() < v2_depth) { v3_enqueue(false); continue; }
+      cpu_relax();
+      if (polite && spins > 64) { struct timespec ts{0, 20000}; nanosleep(&ts, nullptr); }
+      if ((spins & 0xFFFF) == 0xFFFF || (polite && (spins & 0xFF) == 0xFF)) {
+        hipError_t e = hipStreamQuery(s->stream);
+        if (e != hipSuccess && e != hipErrorNotReady)
+          throw d2::DeviceError{DADA2HIP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e) + " (round result)"};
+        if (e == hipSuccess && *seqp != want) {
+          // everything queued has run (its writes are visible now) and the block is not there: every launch found the device
+          // halted or the ring full and said so - send another one - or a launch ended without saying so (a barrier timed out)
+          if (v3_ended() >= v3_enq) { v3_enqueue(false); continue; }
+          throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: the persistent round tail ended without publishing its result (a grid barrier timed out?)"};
+        }
+        if (ms_since(tw) > wait_timeout_s() * 1e3)
+          throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: timed out waiting for the round result"};
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    v2_cons++;
+    st.ms_wait_device += ms_since(tw);
+    return v2_hblk.p[ring];
+  }
+
   // run_dada's loop (Rmain.cpp:312-331) with the rounds inside persistent launches: the host keeps v2_depth super-chains queued,
   // trails the device through the published result blocks exactly as with the launch chains, and answers the same halts
   void run_v3(int max_clust) {
@@ -1432,9 +1465,8 @@ struct Run {
     while (!done) {
       // keep the device fed: super-chains in flight = enqueued - ended (the device reports the ordinal of every launch that
       // ends, whether it ran rounds or found the device halted); none is added while a result block waits to be consumed
-      while (v3_enq - v3_ended() < v2_depth && !v3_block_ready()) v3_enqueue(false);
       const long seq = v2_cons + 1;
-      const Round2Out &b = v2_wait_block();
+      const Round2Out &b = v3_wait_block();
       n_blocks++;
       if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
         throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};

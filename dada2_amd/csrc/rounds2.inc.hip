@@ -89,7 +89,9 @@ static __device__ __forceinline__ bool v2_idle(const Eng2 &E) {
 template <int BS>
 struct ShufLds {
   static constexpr int MOVCAP = BS, NEWCAP = BS / 2;
-  int s_n, s_base, s_an, s_abase, s_keep, s_anyinc;
+  static constexpr int U = BS >= 1024 ? 4 : 2;                           // uniques per thread per group of the sweep
+  int s_n, s_base, s_an, s_abase, s_keep, s_anyinc, s_nwork;
+  int32_t s_work[U * BS];                                                // the group's uniques that have work to do: index | class << 30
   int32_t s_mov[3 * MOVCAP];
   int32_t s_newr[NEWCAP], s_newhead[NEWCAP];
   uint32_t s_newh[NEWCAP];
@@ -155,39 +157,70 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
   int my_n0 = 0;                                                         // members partition 0 lost (low half) / gained (high half)
   D2_TRACE(1 + level, 1);
-  // The sweep is bound by memory latency, not bytes: a thread's uniques are taken U at a time - FIRST every unique's few bytes
-  // that decide whether it has anything to do (second stored comparison? class of this round's comparison, reads, lock), THEN,
-  // for the ones that do, what the decision needs (the stored lambdas, this round's lambda / hamming / E_minmax), then the work.
-  // Two dependent round trips per U uniques; round 3 went through them one unique at a time (a chain of two to three per
-  // unique, 14-20 us per sweep of 10^6 uniques for 12-50 MB), and loaded every field of every unique.
-  constexpr int U = BS >= 1024 ? 4 : 2;
-  struct Pre {
-    int r, i1, from, head_raw;
-    uint32_t cl;
-    bool on, want2, maykeep;
-    double lam0, lam1, l_raw, em;
-    uint32_t h_raw;
-  };
-  auto process = [&](const Pre &q) __attribute__((always_inline)) {
-    const int r = q.r;
-    bool keep = false, need_new = false, move = false;
-    double l = 0.0, best_l = 0.0;
-    uint32_t h = 0, best_h = 0;
-    int head = -1, hcnt = 3, apos = 0, pos = 0, from = q.from, to = 0;
-    if (q.on) {
-      const int i1 = q.i1;
-      const int head_raw = q.head_raw;
+  // The sweep in two passes per U * BS uniques of the block.  PASS A, a few instructions per unique with the U uniques of a
+  // thread requested together: does the unique hold a second stored comparison (only such a unique can ever move), and - the
+  // commit of the round - the class of its comparison with the new centre after the greedy skip, counted.  The rest (most
+  // uniques of a large sample: one stored comparison, shrouded or skipped now) is done with after 4 / 11 bytes.  The others go
+  // to a work list in LDS.  PASS B takes the list one unique per thread: everything the decision needs in ONE round trip, then
+  // the store filter, the arg-max, the move.  The long code exists once and runs on full waves (round 3 ran it in whatever
+  // lanes happened to need it, one unique after the other, with a chain of two to three round trips each: 14-20 us per sweep
+  // of 10^6 uniques for 12-50 MB of traffic).
+  constexpr int U = ShufLds<BS>::U;
+  int32_t *s_work = L.s_work;
+  int &s_nwork = L.s_nwork;
+  for (int base = blockIdx.x * BS * U; base < N; base += gridDim.x * BS * U) {
+    if (threadIdx.x == 0) s_nwork = 0;
+    __syncthreads();
+    {
+      int i1s[U];
+      uint32_t clw[U], rds[U];
+      uint8_t lks[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int r = base + u * BS + threadIdx.x;
+        i1s[u] = -1; clw[u] = 0; rds[u] = 0; lks[u] = 0;
+        if (r < N) {
+          i1s[u] = T.i1[r];
+          if (STORE) { clw[u] = cls_row[r]; rds[u] = S.reads[r]; lks[u] = P.lock[r]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int r = base + u * BS + threadIdx.x;
+        if (r >= N) continue;
+        uint32_t cl = 0;
+        if (STORE) {
+          cl = (clw[u] >> kpos2) & 3u;
+          const bool skip = E.greedy && (rds[u] > creads_c || lks[u] != 0);
+          if (skip) cl = CLS_SKIP;
+          else if (cl == CLS_SKIP) atomicOr(P.err_flag, 8);            // the cache lacks a comparison the round needs
+          if (cl >= CLS_GAPLESS) st01 += cl == CLS_NW ? 1u : 0x10000u; else st23 += cl == CLS_SHROUD ? 1u : 0x10000u;
+        }
+        // a unique with ONE stored comparison (partition 0's) that gets no second one now sits in partition 0 or is a centre
+        if (i1s[u] >= 0 || cl >= CLS_GAPLESS) s_work[atomicAdd(&s_nwork, 1)] = (int32_t)((uint32_t)r | (cl << 30));
+      }
+    }
+    __syncthreads();
+    const int nwork = s_nwork;
+    for (int w = threadIdx.x; w < nwork; w += BS) {
+      const uint32_t item = (uint32_t)s_work[w];
+      const int r = (int)(item & 0x3FFFFFFFu);
+      const uint32_t cl = item >> 30;
+      // one round trip: everything the decision can need (a unique on this list is one in five to ten)
+      const int i1 = T.i1[r];
+      const int from = P.clust_of[r];
+      const int head_raw = T.head[r];
+      const double lam0_r = T.lam0[r], lam1_r = T.lam1[r];
+      const double l_raw = (STORE && cl >= CLS_GAPLESS) ? lam_row[r] : 0.0, em = (STORE && cl >= CLS_GAPLESS) ? P.E_minmax[r] : 0.0;
+      const uint32_t h_raw = (STORE && cl >= CLS_GAPLESS) ? ham_row[r] : 0u;
+      bool keep = false, need_new = false, move = false;
+      double l = 0.0, best_l = 0.0;
+      uint32_t h = 0, best_h = 0;
+      int head = -1, hcnt = 3, apos = 0, pos = 0, to = 0;
       bool need = true;
       if (filt)   // (a unique with one stored comparison never moves; chains are not walked for the test: any rise counts)
         need = i1 >= 0 && (sgn_of(from) < 0 || (anyinc && ((from != 0 && sgn_of(0) > 0) || (i1 != from && sgn_of(i1) > 0) || head_raw >= 0)));
       if (need) {
-      const double lam0_r = q.lam0, lam1_r = q.lam1;
-      const uint32_t cl = q.cl;
-      if (STORE) {
-        if (cl >= CLS_GAPLESS) st01 += cl == CLS_NW ? 1u : 0x10000u; else st23 += cl == CLS_SHROUD ? 1u : 0x10000u;
-      }
-      const double l_raw = q.l_raw, em = q.em;
-      const uint32_t h_raw = q.h_raw;
       head = i1 >= 0 ? head_raw : -1;                                    // (a chain only exists behind a used second entry)
       if (STORE) {
         if (cl >= CLS_GAPLESS) {
@@ -255,70 +288,31 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
         P.update_e[to] = 1; P.update_e[from] = 1;
       }
       }   // need
-    }
-    if (need_new) {
-      apos = atomicAdd(&s_an, 1);
-      if (apos < NEWCAP) { s_newr[apos] = r; s_newhead[apos] = head; s_newh[apos] = h; s_newl[apos] = l; }
-      else {   // (more new blocks in one thread block than the buffer holds: straight to the device counter)
-        const int nb = atomicAdd(T.blk_count, 1);
-        if (nb < T.blk_cap) {
-          CompBlk *cb = T.blk + nb;
-          cb->next = head; cb->cnt = 1; cb->i[0] = ci; cb->ham[0] = h; cb->lam[0] = l;
-          T.head[r] = nb;
-        } else atomicOr(P.err_flag, 2);
+      if (need_new) {
+        apos = atomicAdd(&s_an, 1);
+        if (apos < NEWCAP) { s_newr[apos] = r; s_newhead[apos] = head; s_newh[apos] = h; s_newl[apos] = l; }
+        else {   // (more new blocks in one thread block than the buffer holds: straight to the device counter)
+          const int nb = atomicAdd(T.blk_count, 1);
+          if (nb < T.blk_cap) {
+            CompBlk *cb = T.blk + nb;
+            cb->next = head; cb->cnt = 1; cb->i[0] = ci; cb->ham[0] = h; cb->lam[0] = l;
+            T.head[r] = nb;
+          } else atomicOr(P.err_flag, 2);
+        }
+      }
+      if (move) {
+        pos = atomicAdd(&s_n, 1);
+        if (pos < MOVCAP) { s_mov[3 * pos] = r; s_mov[3 * pos + 1] = from; s_mov[3 * pos + 2] = to; }
+        else {
+          const int k = atomicAdd(&out->cnt[level], 1);
+          int32_t *m = mv + 3 * (size_t)k;
+          m[0] = r; m[1] = from; m[2] = to;
+          const int ki = moved_before + k;
+          if (ki < E.mov_inline) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
+        }
       }
     }
-    if (move) {
-      pos = atomicAdd(&s_n, 1);
-      if (pos < MOVCAP) { s_mov[3 * pos] = r; s_mov[3 * pos + 1] = from; s_mov[3 * pos + 2] = to; }
-      else {
-        const int k = atomicAdd(&out->cnt[level], 1);
-        int32_t *m = mv + 3 * (size_t)k;
-        m[0] = r; m[1] = from; m[2] = to;
-        const int ki = moved_before + k;
-        if (ki < E.mov_inline) { out->mov[3 * ki] = r; out->mov[3 * ki + 1] = from; out->mov[3 * ki + 2] = to; }
-      }
-    }
-  };
-  for (int base = blockIdx.x * BS * U; base < N; base += gridDim.x * BS * U) {
-    Pre q[U];
-    // ---- first round trip: what decides whether the unique has anything to do ----
-    uint32_t clw[U], rds[U];
-    uint8_t lks[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int r = base + u * BS + threadIdx.x;
-      q[u].r = r; q[u].on = r < N;
-      q[u].i1 = -1; q[u].from = 0; clw[u] = 0; rds[u] = 0; lks[u] = 0;
-      if (q[u].on) {
-        q[u].i1 = T.i1[r];
-        q[u].from = P.clust_of[r];
-        if (STORE) { clw[u] = cls_row[r]; rds[u] = S.reads[r]; lks[u] = P.lock[r]; }
-      }
-    }
-    // ---- second round trip: only for the uniques that hold a second stored comparison or get one now ----
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int r = q[u].r;
-      uint32_t cl = 0;
-      if (STORE && q[u].on) {
-        cl = (clw[u] >> kpos2) & 3u;
-        const bool skip = E.greedy && (rds[u] > creads_c || lks[u] != 0);
-        if (skip) cl = CLS_SKIP;
-        else if (cl == CLS_SKIP) atomicOr(P.err_flag, 8);              // the cache lacks a comparison the round needs
-      }
-      q[u].cl = cl;
-      q[u].maykeep = STORE && cl >= CLS_GAPLESS;
-      q[u].want2 = q[u].on && (q[u].i1 >= 0 || q[u].maykeep);
-      q[u].head_raw = -1; q[u].lam0 = 0.0; q[u].lam1 = 0.0; q[u].l_raw = 0.0; q[u].em = 0.0; q[u].h_raw = 0u;
-      if (q[u].want2) {
-        q[u].lam0 = T.lam0[r];
-        if (q[u].i1 >= 0) { q[u].head_raw = T.head[r]; q[u].lam1 = T.lam1[r]; }
-        if (q[u].maykeep) { q[u].l_raw = lam_row[r]; q[u].h_raw = ham_row[r]; q[u].em = P.E_minmax[r]; }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) process(q[u]);
+    __syncthreads();                                                     // (the list is rewritten by the next group)
   }
   __syncthreads();                                                       // the block's movers / new blocks are all buffered
   D2_TRACE(1 + level, 2);
@@ -504,6 +498,9 @@ constexpr int PUPD_TAB = 1024;    // partitions whose per-partition facts k2_pup
 constexpr int SIG_CAP = 1024;
 template <int BS>
 struct PupdLds {
+  static constexpr int U = BS >= 1024 ? 4 : 2;                           // uniques per thread per group of the sweep
+  int s_nwork;
+  int32_t s_work[U * BS];                                                // the group's uniques whose p-value / candidacy has to be looked at
   BudKey s_k[2][BS / 64];
   int32_t s_sig[SIG_CAP];
   int s_nsig, s_sbase;
@@ -541,33 +538,48 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
   __syncthreads();
   BudKey b0 = init, b1 = init;
   D2_TRACE(5, 1);
-  // (latency-bound like the shuffle sweep: the seven loads of U uniques are requested together, then the uniques are worked on)
-  constexpr int U = BS >= 1024 ? 4 : 2;
+  // Two passes per U * BS uniques, as in the shuffle sweep.  PASS A reads a unique's partition and p-value: a unique whose
+  // partition has not changed and whose p is exactly 1 (nine in ten of a large sample: singletons, pval.cpp:69) can neither be
+  // re-evaluated nor be a bud candidate - init is (p = 1, reads of the most abundant unique), and 1 is never below a threshold
+  // (omegaA < 1 <= N / 2; omegaP <= 1 / 2 is checked) - and is done with after 12 bytes.  The others go to a work list in LDS.
+  // PASS B, one listed unique per thread: the reference's b_p_update / lock / candidate code, the special functions of the
+  // p-value on full waves instead of in the odd lane.
+  constexpr int U = PupdLds<BS>::U;
+  const bool p1_skip = 2.0 * E.bp.omegaP <= 1.0 && 2.0 * E.bp.omegaA <= (double)S.N;
+  int32_t *s_work = L.s_work;
+  int &s_nwork = L.s_nwork;
   for (int base = blockIdx.x * BS * U; base < S.N; base += gridDim.x * BS * U) {
-    int cls_[U];
-    double ls_[U], ps_[U];
-    uint32_t rds_[U], hams_[U];
-    uint8_t prs_[U], s0s_[U];
+    if (threadIdx.x == 0) s_nwork = 0;
+    __syncthreads();
+    {
+      int cls_[U];
+      double ps_[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int r = base + u * BS + threadIdx.x;
-      cls_[u] = -1; ls_[u] = 0.0; ps_[u] = 0.0; rds_[u] = 0; hams_[u] = 0; prs_[u] = 0; s0s_[u] = 0;
-      if (r < S.N) {
-        cls_[u] = P.clust_of[r]; ls_[u] = P.comp_lam[r]; rds_[u] = S.reads[r]; hams_[u] = P.comp_ham[r];
-        prs_[u] = S.prior[r]; s0s_[u] = P.slot0[r]; ps_[u] = P.p[r];
+      for (int u = 0; u < U; u++) {
+        const int r = base + u * BS + threadIdx.x;
+        cls_[u] = -1; ps_[u] = 1.0;
+        if (r < S.N) { cls_[u] = P.clust_of[r]; ps_[u] = P.p[r]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int r = base + u * BS + threadIdx.x, cl = cls_[u];
+        if (cl < 0) continue;
+        const bool intab = cl < ntab;
+        const bool touched = (intab ? s_upd[cl] : P.update_e[cl]) || (E.greedy && (intab ? s_chk[cl] : P.check_locks[cl]));
+        if (touched || !(p1_skip && ps_[u] == 1.0)) s_work[atomicAdd(&s_nwork, 1)] = r;
       }
     }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-    const int r = base + u * BS + threadIdx.x;
-    if (cls_[u] < 0) continue;
-    const int cl = cls_[u];
-    const double l = ls_[u];
-    const uint32_t reads = rds_[u];
-    const uint32_t ham = hams_[u];
-    const bool pr = prs_[u] != 0;
-    const bool s0 = s0s_[u] != 0;
-    double p = ps_[u];
+    __syncthreads();
+    const int nwork = s_nwork;
+    for (int w = threadIdx.x; w < nwork; w += BS) {
+    const int r = s_work[w];
+    const int cl = P.clust_of[r];
+    const double l = P.comp_lam[r];
+    const uint32_t reads = S.reads[r];
+    const uint32_t ham = P.comp_ham[r];
+    const bool pr = S.prior[r] != 0;
+    const bool s0 = P.slot0[r] != 0;
+    double p = P.p[r];
     const bool intab = cl < ntab;
     const uint32_t prd = intab ? s_prd[cl] : reads_at(E, cl, nexec);
     if (intab ? s_upd[cl] : P.update_e[cl]) {
@@ -591,6 +603,7 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
       if (q < SIG_CAP) s_sig[q] = r; else E.sig_list[atomicAdd(E.sig_n, 1)] = r;
     }
     }
+    __syncthreads();                                                     // (the list is rewritten by the next group)
   }
   D2_TRACE(5, 2);
 #pragma unroll
