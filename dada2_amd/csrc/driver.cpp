@@ -1539,6 +1539,11 @@ struct Run {
       st.tail_ms_barriers = (kt[KT_S0_BAR] + kt[KT_SL_BAR] + kt[KT_P_BAR]) * ms; st.tail_ms_birth = kt[KT_BIRTH] * ms;
       st.tail_ms_publish = kt[KT_PUBLISH] * ms; st.tail_ms_entry = kt[KT_LAUNCH] * ms;
       st.tail_levels = kt[KT_LEVELS]; st.tail_ms_release = kt[KT_RELEASE] * ms;
+      if (getenv("DADA2HIP_V2_SUMMARY")) {
+        fprintf(stderr, "[v3] block-0 sub-phase ms (kid: 1 commit+shuffle0, 2 later shuffles, 5 p-update, 6 serial end):");
+        for (int kid : {1, 2, 5, 6}) { fprintf(stderr, "  kid%d:", kid); for (int ph = 1; ph < 8; ph++) fprintf(stderr, " %.2f", kt[KT_SUB + 8 * kid + ph] * ms); }
+        fprintf(stderr, "\n");
+      }
     }
     st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid;
     if (getenv("DADA2HIP_V2_SUMMARY"))

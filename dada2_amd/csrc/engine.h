@@ -413,7 +413,7 @@ struct PSync {
   uint32_t gen, pad1[31];
   uint32_t fail, pad2[31];
 };
-enum { KT_S0 = 0, KT_S0_BAR, KT_SL, KT_SL_BAR, KT_P, KT_P_BAR, KT_BIRTH, KT_PUBLISH, KT_ROUNDS, KT_LEVELS, KT_LAUNCH, KT_RELEASE, KT_N = 16 };
+enum { KT_S0 = 0, KT_S0_BAR, KT_SL, KT_SL_BAR, KT_P, KT_P_BAR, KT_BIRTH, KT_PUBLISH, KT_ROUNDS, KT_LEVELS, KT_LAUNCH, KT_RELEASE, KT_SUB_LAST = 14, KT_SUB = 16, KT_N = 80 };
 
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
                     hipStream_t st);

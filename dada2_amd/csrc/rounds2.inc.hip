@@ -21,7 +21,31 @@
   do {                                                                                                             \
     if (E.trace && threadIdx.x == 0 && (int)blockIdx.x < TRACE_BLOCKS && E.ctl->pub_seq == E.trace_seq)           \
       E.trace[((size_t)(KID) * TRACE_BLOCKS + blockIdx.x) * 8 + (PHASE)] = gcn_clock();                            \
+    D2_KSUB((KID) > 2 ? (KID) : ((KID) == 1 ? 1 : 2), PHASE, blockIdx.x == 0);                                     \
   } while (0)
+// persistent tail under DADA2HIP_PROFILE=1: what block 0 (the deciding block for the serial section) spends between the stamps
+// of a phase body, summed over the run: ktime[KT_SUB + 8 kid + phase] (kid 1 = commit + first shuffle call, 2 = later calls,
+// 5 = p-update, 6 = serial end of the round)
+#define D2_KSUB(KID, PHASE, WHO)                                                                                   \
+  do {                                                                                                             \
+    if (E.ktime && threadIdx.x == 0 && (WHO)) {                                                                    \
+      const unsigned long long now_ = gcn_wall_clock();                                                            \
+      unsigned long long *last_ = E.ktime + KT_SUB_LAST + ((KID) == 6 ? 1 : 0);                                    \
+      if ((PHASE) > 0) E.ktime[KT_SUB + 8 * (KID) + (PHASE)] += now_ - *last_;                                      \
+      *last_ = now_;                                                                                               \
+    }                                                                                                              \
+  } while (0)
+
+// Which unique thread t of block b looks at in slice u of its group grp of a sweep: waves of 64 consecutive uniques are dealt
+// round-robin over the blocks.  The input is sorted by abundance, and the abundant uniques are the expensive ones (long chains
+// of stored comparisons, p-values below 1, bud candidates): dealt in contiguous runs they all landed in the first blocks, and in
+// the persistent tail every other block waited for those at the barrier.
+template <int BS, int U>
+static __device__ __forceinline__ int sweep_unique(int grp, int u) {
+  const long long chunk = ((long long)(grp * U + u) * (BS / 64) + (threadIdx.x >> 6)) * gridDim.x + blockIdx.x;
+  const long long r = chunk * 64 + (threadIdx.x & 63);
+  return r > 0x7FFFFFF0ll ? 0x7FFFFFF0 : (int)r;
+}
 
 // ---- chain bookkeeping: which shuffle launches of the chain ran, and whether the evaluation after them stands -------
 struct Chain2 { int nexec; bool eval_ok; };
@@ -168,7 +192,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   constexpr int U = ShufLds<BS>::U;
   int32_t *s_work = L.s_work;
   int &s_nwork = L.s_nwork;
-  for (int base = blockIdx.x * BS * U; base < N; base += gridDim.x * BS * U) {
+  for (int grp = 0; (long long)grp * U * BS * gridDim.x < N; grp++) {
     if (threadIdx.x == 0) s_nwork = 0;
     __syncthreads();
     {
@@ -177,7 +201,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
       uint8_t lks[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = base + u * BS + threadIdx.x;
+        const int r = sweep_unique<BS, U>(grp, u);
         i1s[u] = -1; clw[u] = 0; rds[u] = 0; lks[u] = 0;
         if (r < N) {
           i1s[u] = T.i1[r];
@@ -186,7 +210,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = base + u * BS + threadIdx.x;
+        const int r = sweep_unique<BS, U>(grp, u);
         if (r >= N) continue;
         uint32_t cl = 0;
         if (STORE) {
@@ -201,6 +225,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
       }
     }
     __syncthreads();
+    D2_TRACE(1 + level, 5);
     const int nwork = s_nwork;
     for (int w = threadIdx.x; w < nwork; w += BS) {
       const uint32_t item = (uint32_t)s_work[w];
@@ -313,6 +338,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
       }
     }
     __syncthreads();                                                     // (the list is rewritten by the next group)
+    D2_TRACE(1 + level, 6);
   }
   __syncthreads();                                                       // the block's movers / new blocks are all buffered
   D2_TRACE(1 + level, 2);
@@ -548,7 +574,7 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
   const bool p1_skip = 2.0 * E.bp.omegaP <= 1.0 && 2.0 * E.bp.omegaA <= (double)S.N;
   int32_t *s_work = L.s_work;
   int &s_nwork = L.s_nwork;
-  for (int base = blockIdx.x * BS * U; base < S.N; base += gridDim.x * BS * U) {
+  for (int grp = 0; (long long)grp * U * BS * gridDim.x < S.N; grp++) {
     if (threadIdx.x == 0) s_nwork = 0;
     __syncthreads();
     {
@@ -556,13 +582,13 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
       double ps_[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = base + u * BS + threadIdx.x;
+        const int r = sweep_unique<BS, U>(grp, u);
         cls_[u] = -1; ps_[u] = 1.0;
         if (r < S.N) { cls_[u] = P.clust_of[r]; ps_[u] = P.p[r]; }
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = base + u * BS + threadIdx.x, cl = cls_[u];
+        const int r = sweep_unique<BS, U>(grp, u), cl = cls_[u];
         if (cl < 0) continue;
         const bool intab = cl < ntab;
         const bool touched = (intab ? s_upd[cl] : P.update_e[cl]) || (E.greedy && (intab ? s_chk[cl] : P.check_locks[cl]));
@@ -570,6 +596,7 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
       }
     }
     __syncthreads();
+    D2_TRACE(5, 4);
     const int nwork = s_nwork;
     for (int w = threadIdx.x; w < nwork; w += BS) {
     const int r = s_work[w];
@@ -604,6 +631,7 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
     }
     }
     __syncthreads();                                                     // (the list is rewritten by the next group)
+    D2_TRACE(5, 5);
   }
   D2_TRACE(5, 2);
 #pragma unroll
@@ -881,7 +909,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
   Round2Out *out = E.dblk + ring;
   const int nclust = ctl->nclust;
   const bool tr = E.trace && ctl->pub_seq == E.trace_seq && threadIdx.x == 0;
-#define D2_TRB(PHASE) do { if (tr) E.trace[((size_t)6 * TRACE_BLOCKS) * 8 + (PHASE)] = gcn_clock(); } while (0)
+#define D2_TRB(PHASE) do { if (tr) E.trace[((size_t)6 * TRACE_BLOCKS) * 8 + (PHASE)] = gcn_clock(); D2_KSUB(6, PHASE, true); } while (0)
   D2_TRB(0);
   // fold the chain's partition-read deltas into the reads
   for (int i = threadIdx.x; i < nclust; i += blockDim.x) {

@@ -21,6 +21,7 @@ for s in $STEPS; do
     smoke)   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/steps.log; tail -3 $OUT/smoke.log ;;
     bench3qchain) DADA2HIP_V2_TAIL=chain timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg3_quick_chain.json 2> $OUT/bench_cfg3_quick_chain.err; echo "bench3qchain rc=$?" >> $OUT/steps.log; python3 -c "import json;b=json.load(open('$OUT/bench_cfg3_quick_chain.json'));print(b['ms_per_step'], b['resident']);print(b['phases_ms_last_step'])" ;;
     bench2q) timeout 600 python bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg2_quick.json 2> $OUT/bench_cfg2_quick.err; echo "bench2q rc=$?" >> $OUT/steps.log; python3 -c "import json;b=json.load(open('$OUT/bench_cfg2_quick.json'));print(b['ms_per_step'], b['resident']);print(b['phases_ms_last_step'])" ;;
+    subphases) for c in 2 3; do DADA2HIP_V2_SUMMARY=1 timeout 600 python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-extras 2> $OUT/subphases_cfg$c.err > $OUT/subphases_cfg$c.json; grep "sub-phase\|\[v3\] blocks" $OUT/subphases_cfg$c.err | tail -2; done; echo "subphases rc=$?" >> $OUT/steps.log ;;
     occ)     timeout 300 tools/microbench occ > $OUT/occ.json 2> $OUT/occ.err; echo "occ rc=$?" >> $OUT/steps.log; cat $OUT/occ.json ;;
     launch)  timeout 300 tools/microbench launch > $OUT/launch.json 2> $OUT/launch.err; echo "launch rc=$?" >> $OUT/steps.log; cat $OUT/launch.json ;;
     tests_iter) timeout 1200 python -X faulthandler -m pytest tests -m gpu -q -rf -p no:cacheprovider -k "not at_size and not 1M" --durations=10 > $OUT/gputests_iter.log 2>&1; echo "tests_iter rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_iter.log ;;
