@@ -1227,6 +1227,7 @@ struct Run {
   DevBuf<double> v2_lam0, v2_lam1;
   DevBuf<uint32_t> v2_ham0, v2_ham1;
   DevBuf<int32_t> v2_i1;
+  DevBuf<unsigned long long> v2_smask;
   DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_sig, v2_n0d, v2_blist, v2_blistn;
   DevBuf<double> v2_lamB;
   DevBuf<uint32_t> v2_hamB;
@@ -1266,7 +1267,7 @@ struct Run {
   }
   void v2_bind() {   // (re)build the by-value kernel argument block after any (re)allocation
     E2.P = P; E2.S = s->D;
-    E2.T.lam0 = v2_lam0.p; E2.T.ham0 = v2_ham0.p; E2.T.lam1 = v2_lam1.p; E2.T.ham1 = v2_ham1.p; E2.T.i1 = v2_i1.p; E2.T.head = v2_head.p; E2.T.blk = v2_blk.p; E2.T.blk_count = v2_blkcount.p;
+    E2.T.lam0 = v2_lam0.p; E2.T.ham0 = v2_ham0.p; E2.T.lam1 = v2_lam1.p; E2.T.ham1 = v2_ham1.p; E2.T.i1 = v2_i1.p; E2.T.smask = v2_smask.p; E2.T.head = v2_head.p; E2.T.blk = v2_blk.p; E2.T.blk_count = v2_blkcount.p;
     E2.T.blk_cap = (int32_t)std::min<size_t>(v2_blk.n, 0x7FFFFFF0u);
     E2.C.NBUF = v2_nbuf; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
     E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15;
@@ -1312,7 +1313,7 @@ struct Run {
     if (const char *e = getenv("DADA2HIP_V2_CHAIN")) v2_chain = std::max(1, std::min(SH_CHAIN, atoi(e)));   // test knob: shorter shuffle chains
     v2_debug = getenv("DADA2HIP_V2_DEBUG") != nullptr;
     hipStream_t stq = s->stream;
-    v2_lam0.alloc(n); v2_ham0.alloc(n); v2_lam1.alloc(n); v2_ham1.alloc(n); v2_i1.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
+    v2_lam0.alloc(n); v2_ham0.alloc(n); v2_lam1.alloc(n); v2_ham1.alloc(n); v2_i1.alloc(n); v2_smask.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
     {
       size_t cap0 = std::max<size_t>(2 * n, (size_t)1 << 16);
       if (const char *e = getenv("DADA2HIP_NODE_CAP")) cap0 = std::max<size_t>((size_t)atoll(e), n + 16);   // test knob: forces growth
@@ -1341,7 +1342,7 @@ struct Run {
     Ctl2 c;
     memset(&c, 0, sizeof c);
     c.nclust = 1; c.centre = (int32_t)bi[0].center; c.slot = 0; c.max_clust = max_clust;
-    c.n0 = N; c.low0 = N; c.need_compare = 0; c.nalign = 0; c.abuf = 0;
+    c.n0 = N; c.low0 = N; c.need_compare = 0; c.nalign = 0; c.abuf = 0; c.stable = 1; c.bfrom = 0;
     for (int k = 0; k < KB_MAX; k++) c.acentre[k] = -1;
     for (int k = 0; k < KB_MAX; k++) c.bcentre[k] = -1;
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));

@@ -272,6 +272,9 @@ struct Store2 {
   double *lam0 = nullptr, *lam1 = nullptr;
   uint32_t *ham0 = nullptr, *ham1 = nullptr;
   int32_t *i1 = nullptr;          // partition of the second entry, -1 = none
+  // bit (k & 63) is set for every partition k the unique holds a stored comparison with: lets a shuffle call tell "none of this
+  // unique's partitions gained reads" without walking its chain (false positives only cost a look)
+  unsigned long long *smask = nullptr;
   int32_t *head = nullptr;
   CompBlk *blk = nullptr;
   int32_t *blk_count = nullptr;
@@ -306,6 +309,9 @@ struct Ctl2 {
   // persistent tail (k3_tail): leave the launch after the round in flight (a compare is due, the host's ring is nearly full, a
   // pause); what the host has consumed as far as the device knows
   int32_t kexit, hcons_seen;
+  // what the first shuffle call of a round may assume: the previous round's calls ended with one that moved nothing (every
+  // unique sits in its arg-max), and since then only the birth has changed reads - partition bfrom lost its new centre's
+  int32_t stable, bfrom;
 };
 
 // Results of the batch compares, kept until their centre's round comes (or the batch buffer is recycled): the class, 2 bits

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
       P.comp_i[r] = 0; P.comp_lam[r] = l; P.comp_ham[r] = h;           // i == 0: Raw::comp is refreshed (cluster.cpp:197)
     }
     E.T.lam0[r] = l; E.T.ham0[r] = h;
+    E.T.smask[r] = 1ull;                                               // (one stored comparison: partition 0's)
     E.T.i1[r] = -1;
     E.T.head[r] = -1;
   }
@@ -115,6 +116,7 @@ struct ShufLds {
   static constexpr int MOVCAP = BS, NEWCAP = BS / 2;
   static constexpr int U = BS >= 1024 ? 4 : 2;                           // uniques per thread per group of the sweep
   int s_n, s_base, s_an, s_abase, s_keep, s_anyinc, s_nwork;
+  unsigned long long s_incmask;                                          // bit (k & 63) of every partition k whose reads rose in the previous call
   int32_t s_work[U * BS];                                                // the group's uniques that have work to do: index | class << 30
   int32_t s_mov[3 * MOVCAP];
   int32_t s_newr[NEWCAP], s_newhead[NEWCAP];
@@ -153,18 +155,24 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   // previous call; everybody else leaves after reading 12 bytes.
   const bool filt = !STORE && level >= 1 && E.sh_filter;
   const int32_t *dlp = E.dlt + (size_t)(level >= 1 ? level - 1 : 0) * E.ccap;
-  if (filt && threadIdx.x == 0) s_anyinc = 0;
+  if (filt && threadIdx.x == 0) { s_anyinc = 0; L.s_incmask = nclust > ntab ? ~0ull : 0ull; }
   __syncthreads();
   for (int k = threadIdx.x; k < ntab; k += BS) {
     s_delta[k] = 0; s_reads[k] = reads_at(E, k, level);
     if (filt) {
       const int32_t d = dlp[k];
       s_sgn[k] = d < 0 ? -1 : (d > 0 ? 1 : 0);
-      if (d > 0) s_anyinc = 1;
+      if (d > 0) { s_anyinc = 1; atomicOr(&L.s_incmask, 1ull << (k & 63)); }
     }
   }
   __syncthreads();
   const bool anyinc = filt ? (s_anyinc != 0 || nclust > ntab) : true;
+  const unsigned long long incmask = filt ? L.s_incmask : ~0ull;
+  // the commit of a round: who can move in the round's FIRST call?  Whoever stores a comparison with the new centre now; and,
+  // if the previous round ended stable, only the members of the partition the birth took the centre from (its reads fell) -
+  // nobody else's home lost reads, and the only partition that gained is the new one
+  const bool stable = STORE && ctl->stable != 0;
+  const int bfrom = ctl->bfrom;
   auto sgn_of = [&](int i) __attribute__((always_inline)) -> int { if (i < ntab) return s_sgn[i]; const int32_t d = dlp[i]; return d < 0 ? -1 : (d > 0 ? 1 : 0); };
   auto rd_at = [&](int i) __attribute__((always_inline)) -> uint32_t { return i < ntab ? s_reads[i] : reads_at(E, i, level); };
   int32_t *dl = E.dlt + (size_t)level * E.ccap;
@@ -196,16 +204,19 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
     if (threadIdx.x == 0) s_nwork = 0;
     __syncthreads();
     {
-      int i1s[U];
+      int i1s[U], froms[U];
       uint32_t clw[U], rds[U];
       uint8_t lks[U];
+      unsigned long long sms[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = sweep_unique<BS, U>(grp, u);
-        i1s[u] = -1; clw[u] = 0; rds[u] = 0; lks[u] = 0;
+        i1s[u] = -1; froms[u] = 0; clw[u] = 0; rds[u] = 0; lks[u] = 0; sms[u] = 0;
         if (r < N) {
           i1s[u] = T.i1[r];
+          if (STORE || filt) froms[u] = P.clust_of[r];
           if (STORE) { clw[u] = cls_row[r]; rds[u] = S.reads[r]; lks[u] = P.lock[r]; }
+          if (filt) sms[u] = T.smask[r];
         }
       }
 #pragma unroll
@@ -220,8 +231,15 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
           else if (cl == CLS_SKIP) atomicOr(P.err_flag, 8);            // the cache lacks a comparison the round needs
           if (cl >= CLS_GAPLESS) st01 += cl == CLS_NW ? 1u : 0x10000u; else st23 += cl == CLS_SHROUD ? 1u : 0x10000u;
         }
-        // a unique with ONE stored comparison (partition 0's) that gets no second one now sits in partition 0 or is a centre
-        if (i1s[u] >= 0 || cl >= CLS_GAPLESS) s_work[atomicAdd(&s_nwork, 1)] = (int32_t)((uint32_t)r | (cl << 30));
+        // a unique with ONE stored comparison (partition 0's) that gets no second one now sits in partition 0 or is a centre;
+        // one with several can only want to move if its home lost reads or a partition it holds a comparison with gained
+        bool work = cl >= CLS_GAPLESS;
+        if (i1s[u] >= 0) {
+          if (STORE) work = work || !stable || froms[u] == bfrom;
+          else if (filt) work = sgn_of(froms[u]) < 0 || (anyinc && (sms[u] & incmask) != 0ull);
+          else work = true;
+        }
+        if (work) s_work[atomicAdd(&s_nwork, 1)] = (int32_t)((uint32_t)r | (cl << 30));
       }
     }
     __syncthreads();
@@ -242,10 +260,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
       double l = 0.0, best_l = 0.0;
       uint32_t h = 0, best_h = 0;
       int head = -1, hcnt = 3, apos = 0, pos = 0, to = 0;
-      bool need = true;
-      if (filt)   // (a unique with one stored comparison never moves; chains are not walked for the test: any rise counts)
-        need = i1 >= 0 && (sgn_of(from) < 0 || (anyinc && ((from != 0 && sgn_of(0) > 0) || (i1 != from && sgn_of(i1) > 0) || head_raw >= 0)));
-      if (need) {
+      {
       head = i1 >= 0 ? head_raw : -1;                                    // (a chain only exists behind a used second entry)
       if (STORE) {
         if (cl >= CLS_GAPLESS) {
@@ -256,14 +271,18 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
             my_keep++;
             if (l * creads_c > em) P.E_minmax[r] = l * creads_c;
             if (r == centre) { P.comp_i[r] = ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
+            T.smask[r] |= 1ull << (ci & 63);
           }
         }
       }
+      // (the commit of a stable round: a unique that stores nothing now and whose home did not lose reads stays where it is)
+      const bool reeval = !STORE || keep || !stable || from == bfrom;
       // arg-max of lambda * reads over the stored comparisons; ties go to the lowest partition (cluster.cpp:229-239)
-      int best_i = 0, best_src = 0;                                      // 0: round-0 entry, 1: second entry, 2: chain block, 3: this round's
       const CompBlk *best_cb = nullptr;
       int best_k = 0;
-      if (i1 >= 0 || keep) {
+      int best_i = from, best_src = 0;                                   // 0: round-0 entry, 1: second entry, 2: chain block, 3: this round's
+      if (reeval && (i1 >= 0 || keep)) {
+        best_i = 0;
         best_l = lam0_r;
         double best_e = best_l * reads_0;
         if (i1 >= 0) {
@@ -312,7 +331,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
         if (from < ntab) atomicSub(&s_delta[from], (int32_t)rd); else atomicSub(&dl[from], (int32_t)rd);
         P.update_e[to] = 1; P.update_e[from] = 1;
       }
-      }   // need
+      }
       if (need_new) {
         apos = atomicAdd(&s_an, 1);
         if (apos < NEWCAP) { s_newr[apos] = r; s_newhead[apos] = head; s_newh[apos] = h; s_newl[apos] = l; }
@@ -749,6 +768,7 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
     P.update_e[from] = 1;
     ctl->nclust = newi + 1;
     ctl->centre = raw;
+    ctl->bfrom = from;
     ctl->nsh_base = 0;
     *s_hit = -1;
   }
@@ -1061,6 +1081,9 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
       else halt = H2_HOST_DECIDE;
       if (halt == H2_NONE && (nclust + 2 > E.ccap || out->blk_count + S.N > E.T.blk_cap)) halt = H2_CAPACITY;
     }
+    // did the round's shuffles end with a call that moved nothing?  (not when MAX_SHUFFLE cut them short, Rmain.cpp:321: the
+    // next round's first call then looks at everybody)
+    if (cs.eval_ok) ctl->stable = (nlev == 0 || (cs.nexec > 0 && out->cnt[cs.nexec - 1] == 0)) ? 1 : 0;
     out->halt = halt;
     out->birth_applied = halt == H2_NONE ? 1 : 0;
     out->nclust = nclust + (halt == H2_NONE ? 1 : 0);
