@@ -1475,7 +1475,7 @@ struct Run {
         fprintf(stderr, "[v3] blk %ld launch %d halt %d paused %d nclust %d nsh %d cnt %d %d %d %d nbatch %d slot %d birth %d found %d nties %d p %.3e blk %d\n", seq,
                 b.kord, b.halt, b.paused, b.nclust, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],
                 b.bud.nties[0], b.bud.best_p[0], b.blk_count);
-      v2_replay(b, seq);
+      v2_replay(b, seq, /*resume_after_fetch=*/b.paused != 0 && b.halt == H2_NONE);
       n_halt[b.halt & 7]++;
       if (b.kord > v3_ord_seen) {                              // first block of its launch: the compare in front of that launch served it
         v3_ord_seen = b.kord;
@@ -1498,10 +1498,7 @@ struct Run {
           nclust_dev = bb.newi + 1;
           record_birth(bb);
           st.ncompare += (uint64_t)N;
-          if (b.paused) {                                      // its mover lists did not fit the block: fetched (v2_replay), go on
-            n_pause++;
-            launch2_resume(E2, s->stream, /*keep_list=*/true);
-          }
+          if (b.paused) n_pause++;                             // (its mover lists did not fit the block: v2_replay fetched them and resumed the device)
           break;
         }
         case H2_NO_BIRTH: {
@@ -1661,7 +1658,9 @@ struct Run {
   }
 
   // bring the host mirror up to date with one published block: the chain's moves in call order, then the counters
-  void v2_replay(const Round2Out &b, long seq) {
+  // resume_after_fetch (persistent tail, a paused block): the device waits halted until the host has the full mover lists - it is
+  // resumed as soon as they have been COPIED, the replay of (possibly 10^5) moves then runs beside it
+  void v2_replay(const Round2Out &b, long seq, bool resume_after_fetch = false) {
     const auto t_rep = clk::now();
     int tot = 0;
     for (int l = 0; l < b.nsh; l++) tot += b.cnt[l];
@@ -1672,16 +1671,22 @@ struct Run {
     } else {
       // (launch chains keep MOV_RING sets of lists; the persistent tail one set, and it stays halted until resumed)
       const int ring = (int)((seq - 1) % MOV_RING);
+      h_big.alloc((size_t)3 * tot);
+      size_t off = 0;
       for (int l = 0; l < b.nsh; l++) {
         const int nm = b.cnt[l];
         if (!nm) continue;
-        h_big.alloc((size_t)3 * nm);
         const size_t slot = b.kord ? (size_t)l : (size_t)(ring * SH_CHAIN + l);
-        D2_HIP(hipMemcpyAsync(h_big.p, v2_movers.p + slot * 3 * N, (size_t)3 * nm * 4, hipMemcpyDeviceToHost,
-                              s->side));
-        D2_HIP(hipStreamSynchronize(s->side));
-        replay_moves(h_big.p, nm);
+        D2_HIP(hipMemcpyAsync(h_big.p + 3 * off, v2_movers.p + slot * 3 * N, (size_t)3 * nm * 4, hipMemcpyDeviceToHost, s->side));
+        off += (size_t)nm;
       }
+      D2_HIP(hipStreamSynchronize(s->side));
+      if (resume_after_fetch) {
+        launch2_resume(E2, s->stream, /*keep_list=*/true);
+        v3_enqueue(false);                                     // (what was queued behind the pause found the device halted)
+      }
+      off = 0;
+      for (int l = 0; l < b.nsh; l++) { replay_moves(h_big.p + 3 * off, b.cnt[l]); off += (size_t)b.cnt[l]; }
     }
     st.nshuffle += (uint64_t)b.nsh;
     st.nnw += b.stat[0]; st.ngapless += b.stat[1]; st.nshroud += b.stat[2]; st.nskipped += b.stat[3];

@@ -254,7 +254,7 @@ constexpr int SH_LEVELS = MAX_SHUFFLE;   // b_shuffle2 calls of one round (Rmain
 constexpr int RING2 = 16;          // result blocks in flight (device copies + pinned host copies)
 constexpr int MOV_RING = 4;        // full mover lists in flight (launch chains; the persistent tail keeps one set and pauses on overflow)
 constexpr int TRACE_BLOCKS = 4096, TRACE_KERNELS = 8;   // (slot 0 unused since k2_lists went into the store pass; shuffle 0..3, p-update, birth, spare)
-constexpr int MOV_INLINE2 = 8192;  // movers published inline per chain (all its shuffles, concatenated)
+constexpr int MOV_INLINE2 = 32768; // movers published inline per chain (all its shuffles, concatenated); only the used part is copied
 
 // stored comparisons of one unique (Bi::comp entries that name it): the round-0 entry lives in lam0/ham0 (every
 // unique has one, containers.cpp:39 + cluster.cpp:189), the next one - for most uniques of a large sample the only other

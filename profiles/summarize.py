@@ -69,6 +69,18 @@ if dbs:
     tot_busy = sum(sum(v) for v in dur.values()) / 1e3
     tot_gap = sum(sum(v) for v in gap.values()) / 1e3
     L += [f"GPU busy {tot_busy:.1f} ms, idle gaps between consecutive kernels (< 200 us each) {tot_gap:.1f} ms.", ""]
+    # the long gaps (200 us .. 20 ms: the device waits for the host inside a pass; longer ones are between passes / steps)
+    big = collections.defaultdict(list)
+    for i, (n, st, en) in enumerate(ks[:-1]):
+        g = (ks[i + 1][1] - en) / 1e3
+        if 200.0 <= g < 20000.0:
+            big[(short(n), short(ks[i + 1][0]))].append(g)
+    if big:
+        L += ["## Long idle gaps (200 us - 20 ms): the device waiting for the host", "", "| kernel before | kernel after | gaps | total ms | median us |", "|---|---|---|---|---|"]
+        for (a, b2), v in sorted(big.items(), key=lambda kv: -sum(kv[1]))[:12]:
+            sv = sorted(v)
+            L.append(f"| `{a}` | `{b2}` | {len(v)} | {sum(v) / 1e3:.2f} | {sv[len(sv) // 2]:.0f} |")
+        L += ["", f"Total {sum(sum(v) for v in big.values()) / 1e3:.1f} ms in {sum(len(v) for v in big.values())} gaps.", ""]
     res = list(db.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
                           "max(workgroup_x), avg(grid_x) from kernels where name like 'd2::%' or name like 'void d2::%' group by name"))
     L += ["## Dispatch resources", "", "| kernel | VGPR | AGPR | SGPR | LDS B | scratch B | wg | avg grid threads |", "|---|---|---|---|---|---|---|---|"]
