@@ -823,7 +823,11 @@ struct Run {
   // ---- b_shuffle2: device arg-max + move, host replay of the moves in the reference's order -------
   // replay a batch of device moves in the reference's order: partitions ascending, slots descending
   // (cluster.cpp:242-259), keeping bi_pop_raw's swap-with-last / bi_add_raw's append (containers.cpp:150-197)
+  // (persistent tail) the replay of a long mover list takes milliseconds in which the device can run out of queued launches:
+  // it looks at the device's launch counter every few thousand moves
+  bool v3_running = false;
   void replay_moves(const int32_t *mv, int nm) {
+    if (v3_running && nm > 2048) v3_topup();
     std::vector<int32_t> order(nm);
     for (int k = 0; k < nm; k++) order[k] = k;
     std::sort(order.begin(), order.end(), [&](int a, int b) {
@@ -832,7 +836,9 @@ struct Run {
       return slot_of[mv[3 * a]] > slot_of[mv[3 * b]];
     });
     bool slot0_changed = false;
+    int tick = 0;
     for (int k : order) {
+      if (v3_running && (++tick & 4095) == 0) v3_topup();
       const uint32_t r = (uint32_t)mv[3 * k];
       const int from = mv[3 * k + 1], to = mv[3 * k + 2];
       Bi &bf = bi[from];
@@ -1420,6 +1426,7 @@ struct Run {
     st.ms_enqueue += ms_since(t_enq);
   }
 
+  void v3_topup() { while (v3_enq - v3_ended() < v2_depth) v3_enqueue(false); }
   // Wait for the next result block, keeping v2_depth super-chains queued meanwhile.  The device reports the end of every launch
   // through a word of its own (v3_ended), which can reach the host a moment after the last block of that launch: a stream that
   // has gone idle without a block in sight is therefore no error as long as a further launch can still be sent.
@@ -1456,7 +1463,8 @@ struct Run {
   // run_dada's loop (Rmain.cpp:312-331) with the rounds inside persistent launches: the host keeps v2_depth super-chains queued,
   // trails the device through the published result blocks exactly as with the launch chains, and answers the same halts
   void run_v3(int max_clust) {
-    struct SlotGuard { Run *r; ~SlotGuard() { r->v3_release(); } } slot_guard{this};   // the device's persistent slot is held for the rounds only
+    struct SlotGuard { Run *r; ~SlotGuard() { r->v3_release(); r->v3_running = false; } } slot_guard{this};   // the device's persistent slot is held for the rounds only
+    v3_running = true;
     auto t0 = clk::now();
     st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
     v3_rec.clear();
@@ -1528,6 +1536,7 @@ struct Run {
       }
       *(volatile int32_t *)v3_hflags.p = (int32_t)v2_cons;     // the device may reuse the ring slots of everything consumed
     }
+    v3_running = false;
     sync_spin(s->stream);                                      // launches queued behind the final halt
     if (profile_all && v3_ktime.p) {                           // phase clocks of block 0 (100 MHz): what the tail's time went into
       unsigned long long kt[KT_N];

@@ -14,7 +14,10 @@ from dada2_amd.opts import COpts, DadaOpts, DadaResult, CLUSTERING_COLS, BIRTH_S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # two builds of the same sources: -O2 (R's default flags; the parity target) and -O3 -march=x86-64-v3 (bench baseline)
-_PATHS = {"O2": os.path.join(_HERE, "_ref", "libdada2ref.so"), "O3": os.path.join(_HERE, "_ref", "libdada2ref_o3.so")}
+_PATHS = {"O2": os.path.join(_HERE, "_ref", "libdada2ref.so"), "O3": os.path.join(_HERE, "_ref", "libdada2ref_o3.so"),
+          # NOT the reference: the Rcpp glue TU of INTEGRATION.md over libdada2hip.so (tests/glue), which hands back the same
+          # Rcpp::List through the same flat entry points - read here so that both sides go through one marshalling
+          "glue": os.path.join(os.path.dirname(_HERE), "tests", "glue", "libdada2glue.so")}
 _PATH = _PATHS["O2"]
 _libs = {}
 
@@ -37,21 +40,22 @@ def lib(flavour: str = "O2"):
                                      C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
         L.ref_result_str.restype = C.c_char_p
         L.ref_result_str.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_long]
-        L.ref_nwalign.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
-                                  C.c_char_p, C.c_char_p, C.c_int]
-        L.ref_compare.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int,
-                                  C.POINTER(COpts), C.c_double, C.c_void_p, C.c_char_p, C.c_int]
-        L.ref_calc_pA.restype = C.c_double
-        L.ref_calc_pA.argtypes = [C.c_int, C.c_double, C.c_int]
-        L.dada2_oracle_ppois.restype = C.c_double
-        L.dada2_oracle_ppois.argtypes = [C.c_double, C.c_double, C.c_int]
-        L.dada2_shim_set_threads.argtypes = [C.c_int]
+        if flavour != "glue":
+            L.ref_nwalign.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                      C.c_char_p, C.c_char_p, C.c_int]
+            L.ref_compare.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.POINTER(COpts), C.c_double, C.c_void_p, C.c_char_p, C.c_int]
+            L.ref_calc_pA.restype = C.c_double
+            L.ref_calc_pA.argtypes = [C.c_int, C.c_double, C.c_int]
+            L.dada2_oracle_ppois.restype = C.c_double
+            L.dada2_oracle_ppois.argtypes = [C.c_double, C.c_double, C.c_int]
+            L.dada2_shim_set_threads.argtypes = [C.c_int]
         _libs[flavour] = L
     return _libs[flavour]
 
 
 def set_threads(n: int):
-    for f in _PATHS:
+    for f in ("O2", "O3"):
         if available(f):
             lib(f).dada2_shim_set_threads(int(n))
 

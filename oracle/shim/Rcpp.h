@@ -65,6 +65,9 @@ public:
   std::shared_ptr<std::vector<T>> p;
   Vec() : p(std::make_shared<std::vector<T>>()) {}
   explicit Vec(size_t n) : p(std::make_shared<std::vector<T>>(n, T())) {}
+  template <typename It> Vec(It first, It last) : p(std::make_shared<std::vector<T>>(first, last)) {}   // (tests/glue: Rcpp's range constructor)
+  typename std::vector<T>::iterator begin() { return p->begin(); }
+  typename std::vector<T>::iterator end() { return p->end(); }
   std::vector<T> &v() { return *p; }
   const std::vector<T> &v() const { return *p; }
   size_t size() const { return p->size(); }
@@ -84,6 +87,7 @@ public:
   explicit IntegerVector(size_t n) : Vec<int>(n) {}
   IntegerVector(size_t n, int fill) : Vec<int>(n) { for (auto &x : v()) x = fill; }   // chimera.cpp:195-196
   IntegerVector(NilType) : is_null(true) {}
+  IntegerVector(const int *first, const int *last) : Vec<int>(first, last) {}
   template <typename... A> static IntegerVector create(const A &...a) {                // evaluate.cpp:112 (named integer(3))
     IntegerVector r;
     NamedInt arr[] = {NamedInt{a.name, a.val->iv.at(0)}...};
@@ -96,6 +100,7 @@ class NumericVector : public Vec<double> {
 public:
   NumericVector() {}
   explicit NumericVector(size_t n) : Vec<double>(n) {}
+  NumericVector(const double *first, const double *last) : Vec<double>(first, last) {}
   static double get_na() { return NA_REAL; }
 };
 class CharacterVector : public Vec<std::string> {
@@ -105,6 +110,7 @@ public:
   explicit CharacterVector(size_t n) : Vec<std::string>(n) {}
   CharacterVector(const std::string &x) { push_back(x); }   // evaluate.cpp:172 returns a std::string as character(1)
   CharacterVector(NilType) : is_null(true) {}
+  static CharacterVector create(const std::string &a, const std::string &b) { CharacterVector r; r.push_back(a); r.push_back(b); return r; }
 };
 
 // (matrices are reference objects too: chimera.cpp:76 keeps a view of a by-value IntegerMatrix parameter after it is gone)
@@ -118,6 +124,9 @@ public:
   const std::vector<T> &v() const { return *p; }
   int nrow() const { return nr; }
   int ncol() const { return nc; }
+  T &operator[](size_t i) { return (*p)[i]; }                              // (column-major storage, as R's)
+  const T &operator[](size_t i) const { return (*p)[i]; }
+  typename std::vector<T>::iterator begin() { return p->begin(); }
   T &operator()(size_t r, size_t c) { return (*p)[c * (size_t)nr + r]; }  // column-major, as R
   const T &operator()(size_t r, size_t c) const { return (*p)[c * (size_t)nr + r]; }
 };
