@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-uniques", type=int, default=0, help="prefix of the sample timed on the CPU (0 = auto, bounded)")
     ap.add_argument("--cpu-full", action="store_true", help="time the reference on the WHOLE sample and check every output against the GPU's")
+    ap.add_argument("--no-cpu-whole", action="store_true", help="skip the one reference run on the WHOLE sample (about a minute at 10^6 uniques)")
     ap.add_argument("--cpu-repeats", type=int, default=3, help="timed repetitions of the all-core reference run (best is reported)")
     ap.add_argument("--no-extras", action="store_true", help="skip the selfconsist / secondary_workload sub-records of the default line")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -560,6 +561,25 @@ def cpu_baseline(d, err, opts, args, gpu_res, gpu_cmp_per_s=None):
     t1 = cs[-1]
     out["single_thread"] = {"value": n1 / t1, "seconds": t1, "sample_uniques": n1, "partitions": r1.nclust,
                             "comparisons_per_s": n1 * r1.nclust / t1}
+    # ... and ONCE the whole sample (no extrapolated baseline): one run at the best thread count of the sweep, every
+    # output compared with the GPU's.  About a minute at 10^6 uniques x 250 nt; long reads keep the prefix (--cpu-full there).
+    if n < d.nraw and L <= 500 and not getattr(args, "no_cpu_whole", False):
+        ref.set_threads(tbest)
+        cs = []
+        rw = ref.dada_uniques(d.seqs, d.abundances, None, err, d.quals, opts, multithread=True, call_seconds=cs)
+        whole = {"uniques": d.nraw, "value": d.nraw / cs[-1], "seconds": cs[-1], "threads": tbest, "partitions": rw.nclust,
+                 "comparisons_per_s": d.nraw * rw.nclust / cs[-1], "repeats": 1, "build": "-O2 (R's default flags)"}
+        if gpu_cmp_per_s:
+            whole["comparisons_per_s_ratio_gpu_over_cpu"] = gpu_cmp_per_s / whole["comparisons_per_s"]
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import assert_results_equal
+        try:
+            assert_results_equal(gpu_res, rw)
+            whole["parity_vs_gpu"] = True
+        except AssertionError as e:
+            whole["parity_vs_gpu"] = False
+            whole["parity_error"] = str(e)[:300]
+        out["whole_sample"] = whole
     if n == d.nraw:   # same input as the GPU run: EVERY output compared (tests/helpers.assert_results_equal)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import assert_results_equal

@@ -80,21 +80,60 @@ class CSampleInput(C.Structure):
                 ("abundances", C.c_void_p), ("priors", C.c_void_p), ("quals", C.c_void_p)]
 
 
+HIP_RUNTIME = {"chosen": "system", "path": None, "note": "no torch runtime looked for yet"}   # which libamdhip64 serves this process
+
+
+def _soname_major(path):
+    """Major version in the DT_SONAME of a libamdhip64 file (``libamdhip64.so.7`` -> 7), read from the file's string table
+    without loading it; None if it cannot be told."""
+    import mmap
+    import re
+    try:
+        with open(path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as m:
+            hit = re.search(rb"libamdhip64\.so\.(\d+)\x00", m)
+            return int(hit.group(1)) if hit else None
+    except Exception:
+        return None
+
+
 def _share_torch_hip_runtime():
     """One HIP runtime per process.  A ROCm build of torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): whichever
     copy is mapped first serves both torch and this library, and torch does not see a device through the system copy.  So if
     torch is INSTALLED (it is not imported here, and nothing of torch is used) its copy is mapped before libdada2hip.so asks
-    for the SONAME - `import dada2_amd` and `import torch` then work in either order.  DADA2HIP_SYSTEM_HIP=1 skips this."""
+    for the SONAME - `import dada2_amd` and `import torch` then work in either order.  Only a copy of the SAME SONAME major as
+    the runtime the library was built against is taken (a wheel from another ROCm generation must not silently serve
+    the library's HIP calls); the choice is recorded in ``HIP_RUNTIME`` and reported by ``runtime_info()``.
+    DADA2HIP_SYSTEM_HIP=1 skips this."""
     if os.environ.get("DADA2HIP_SYSTEM_HIP"):
+        HIP_RUNTIME.update(chosen="system", note="DADA2HIP_SYSTEM_HIP is set")
         return
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
         cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
-        if cand and os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-    except Exception:   # no torch, or its runtime does not load here: the system copy serves
-        pass
+        if not (cand and os.path.exists(cand)):
+            HIP_RUNTIME.update(chosen="system", note="no torch-bundled libamdhip64 found")
+            return
+        built = None
+        for sysdir in ("/opt/rocm/lib", "/opt/rocm/lib64"):
+            if os.path.exists(os.path.join(sysdir, "libamdhip64.so")):
+                built = _soname_major(os.path.realpath(os.path.join(sysdir, "libamdhip64.so")))
+                break
+        theirs = _soname_major(cand)
+        if built is not None and theirs is not None and built != theirs:
+            HIP_RUNTIME.update(chosen="system", path=None,
+                               note=f"torch bundles libamdhip64.so.{theirs}, the library was built against .so.{built}: not shared")
+            return
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        HIP_RUNTIME.update(chosen="torch", path=cand, note=f"SONAME major {theirs} (system: {built})")
+    except Exception as ex:   # no torch, or its runtime does not load here: the system copy serves
+        HIP_RUNTIME.update(chosen="system", note=f"torch runtime not mapped: {type(ex).__name__}")
+
+
+def runtime_info():
+    """Version string of the library and which HIP runtime serves it in this process."""
+    L = lib()
+    return {"library": L.dada2hip_version().decode(), "hip_runtime": dict(HIP_RUNTIME)}
 
 
 def lib():

@@ -36,6 +36,7 @@ static double na_real() {
 }
 
 struct InputError { std::string msg; };
+struct PeerFailed {};   // sharded run: another rank reported a failure at an exchange point
 struct RuntimeErr { int code; std::string msg; };
 
 // device / pinned buffers; the memory comes from (and returns to) the per-process allocation cache (hostpar.h)
@@ -55,6 +56,7 @@ template <typename T> struct DevBuf {
     D2_HIP(AllocCache::get().dev_alloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T) + 64));
   }
   void zero(hipStream_t st) { D2_HIP(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
+  void free() { if (p) AllocCache::get().dev_release(p); p = nullptr; n = 0; }
 };
 
 template <typename T> struct PinBuf {
@@ -297,12 +299,13 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
   s->seq2.alloc((size_t)nraw * D.W2);
   s->nwflag.alloc(1);
   D.nw_flag = s->nwflag.p;
-  {   // pointer ring of k_nw_ad (kernels.hip): 8 192 wave slots of 8 KB at 250 nt; fewer, never below 1 024, for long reads
+  {   // pointer ring of k_nw_ad (kernels.hip): 8 192 wave slots of 8 KB at 250 nt; fewer, never below 1 024, for long reads.
+      // Only its geometry here: the 64-256 MB are taken for the duration of a run (ensure_ad_ring) - the throw-away
+      // samples of nwvec / merge / bimera never need them, and hundreds of resident samples would each have held one
     D.ad_wpw = 64 * ((2 * maxlen + 1 + 15) / 16);
     int waves = 8192;
     while (waves > 1024 && (size_t)waves * D.ad_wpw * 4 > ((size_t)256 << 20)) waves /= 2;
-    s->scr_ad.alloc((size_t)waves * D.ad_wpw);
-    D.ad_ptr = s->scr_ad.p;
+    D.ad_ptr = nullptr;
     D.ad_waves = waves;
   }
   D2_HIP(hipMemsetAsync(D.nw_flag, 0, 4, s->stream));
@@ -372,6 +375,22 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
 }
 
 // a traceback that left its bounds (cannot happen with valid pointers; nwalign_endsfree.cpp:185 raises the same way)
+// the traceback-pointer ring of k_nw_ad for the time of one run (it comes from and goes back to the allocation cache)
+void ensure_ad_ring(dada2hip_sample *s) {
+  if (s->D.ad_ptr) return;
+  s->scr_ad.alloc((size_t)s->D.ad_waves * s->D.ad_wpw);
+  s->D.ad_ptr = s->scr_ad.p;
+}
+struct AdRingGuard {
+  dada2hip_sample *s;
+  ~AdRingGuard() {
+    if (!s->D.ad_ptr) return;
+    if (std::uncaught_exceptions() == 0) (void)hipStreamSynchronize(s->stream);   // (no launch that uses it is left in the stream)
+    s->scr_ad.free();
+    s->D.ad_ptr = nullptr;
+  }
+};
+
 void check_nw_flag(dada2hip_sample *s) {
   int32_t f = 0;
   D2_HIP(hipMemcpy(&f, s->D.nw_flag, 4, hipMemcpyDeviceToHost));
@@ -553,7 +572,12 @@ struct Run {
     std::vector<int64_t> sizes(W);
     sh_call(0, &mine, 8, sizes.data());
     int64_t mx = 0;
-    for (int64_t x : sizes) mx = std::max(mx, x);
+    for (int64_t x : sizes) {
+      // a rank that failed says so in place of its size (dada2hip_sample_run_sharded): every rank leaves here, together,
+      // instead of waiting for it in the next collective for ever
+      if (x < 0) throw PeerFailed{};
+      mx = std::max(mx, x);
+    }
     std::vector<std::vector<uint8_t>> out(W);
     if (mx == 0) return out;
     std::vector<uint8_t> sendb((size_t)mx, 0), recvb((size_t)mx * W);
@@ -562,7 +586,11 @@ struct Run {
     for (int w = 0; w < W; w++) out[w].assign(recvb.begin() + (size_t)w * mx, recvb.begin() + (size_t)w * mx + (size_t)sizes[w]);
     return out;
   }
-  void sh_allreduce(std::vector<int64_t> &v) { if (!v.empty()) sh_call(1, v.data(), (int64_t)v.size() * 8, v.data()); }
+  void sh_allreduce(std::vector<int64_t> &v) {
+    if (v.empty()) return;
+    (void)sh_gatherv(nullptr, 0);                  // (every exchange point opens with the 8-byte size / status gather)
+    sh_call(1, v.data(), (int64_t)v.size() * 8, v.data());
+  }
   // the moves of one b_shuffle2 call on all ranks, in rank order (replay_moves sorts them into the reference's order)
   std::vector<int32_t> sh_all_moves(const int32_t *mine, int nm) {
     std::vector<int32_t> all;
@@ -1291,6 +1319,8 @@ struct Run {
     E2.sh_filter = 1; E2.grid_shuffle = 2048; E2.grid_pupdate = 1024;
     if (const char *e = getenv("DADA2HIP_V2_FILTER")) E2.sh_filter = atoi(e) != 0;
     if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::min(8192, std::max(1, atoi(e)));
+    // (a wave of the shuffle pass adds up per-thread counts in 16-bit halves: fewer than 1000 uniques per thread)
+    E2.grid_shuffle = std::max<int>(E2.grid_shuffle, (int)std::min<long long>(8192, (long long)N / (256ll * 1000) + 1));
     if (const char *e = getenv("DADA2HIP_V2_GRID_PUPDATE")) E2.grid_pupdate = std::max(1, atoi(e));
     E2.mov_inline = MOV_INLINE2; E2.ring_limit = RING2;
     if (const char *e = getenv("DADA2HIP_V2_MOV_INLINE")) E2.mov_inline = std::max(1, std::min(MOV_INLINE2, atoi(e)));   // test knob: long mover lists
@@ -1907,6 +1937,8 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   struct RangeGuard { SampleDev &D; ~RangeGuard() { D.r_lo = 0; D.r_hi = D.N; } } range_guard{D};
   D.r_lo = shard ? (int32_t)((int64_t)N * shard->rank / shard->world) : 0;
   D.r_hi = shard ? (int32_t)((int64_t)N * (shard->rank + 1) / shard->world) : N;
+  ensure_ad_ring(s);
+  AdRingGuard ring_guard{s};
   if (!s->run_cache) s->run_cache = std::make_shared<Run>();
   Run &run = *static_cast<Run *>(s->run_cache.get());
   run.hooks = hooks;
@@ -2352,7 +2384,20 @@ int dada2hip_sample_run_sharded(dada2hip_sample *s, const double *err, int32_t e
   dada2hip_result *R = new dada2hip_result();
   int rc = guarded(errbuf, errlen, [&] {
     if (!shard) throw InputError{"dada2hip: invalid shard descriptor."};
-    sample_run(s, err, err_ncol, opts, hooks, R, shard);
+    try {
+      sample_run(s, err, err_ncol, opts, hooks, R, shard);
+    } catch (const PeerFailed &) {
+      throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: another rank of the sharded run failed"};
+    } catch (...) {
+      // tell the other ranks at their next exchange point (each opens with an 8-byte all-gather of a size: -1 = failed), so
+      // that they return an error too instead of blocking in a collective this rank will never join
+      if (shard->world > 1 && shard->exchange) {
+        const int64_t failed = -1;
+        std::vector<int64_t> all((size_t)shard->world);
+        (void)shard->exchange(shard->user, 0, &failed, 8, all.data());
+      }
+      throw;
+    }
   });
   if (rc != DADA2HIP_OK) { delete R; return rc; }
   *out = R;
@@ -2447,6 +2492,8 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
     select_device(s->device);
     if (centre < 0 || centre >= s->D.N) throw InputError{"dada2hip: centre out of range"};
     check_opts(*opts, s->qmax, err_ncol);
+    ensure_ad_ring(s);
+    AdRingGuard ring_guard{s};
     Run run;
     run.hooks = nullptr;
     init_run(run, s, err, err_ncol, opts, kdist_cutoff);

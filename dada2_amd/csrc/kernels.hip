@@ -1252,7 +1252,7 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap) { return ad_geom(ap.band, S.maxlen, S.minlen).APW; }
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
-  if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || !S.ad_ptr || !ap.plain()) return 0;   // (factor offsets are u16: 16 * ncol * 8 < 65 536)
+  if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || S.ad_waves <= 0 || !ap.plain()) return 0;   // (factor offsets are u16: 16 * ncol * 8 < 65 536)
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 127) return 0;
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);   // (a centre per wave: the larger of the two layouts)

@@ -2,8 +2,8 @@
 
 The path shards naturally at sample granularity: each ``dada_uniques`` call
 depends only on its own sample and the shared error matrix (R/dada.R:266-366).  One process per
-GPU (``torch.distributed``, backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests); rank r owns
-samples r, r+W, r+2W, ... resident on its own GPU for the whole selfConsist loop.  The only
+GPU (``torch.distributed``, backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests); the samples are dealt longest-first
+(``shard``: r, r+W, r+2W, ... when they are of one size) and stay resident on their rank's GPU for the whole selfConsist loop.  The only
 cross-rank exchange is ``accumulateTrans`` (R/errorModels.R:462-471): one all-reduce(sum) of the
 16 x Q int64 transition-count matrix per pass (<= 12 KB, latency-bound; xGMI bandwidth is
 irrelevant at this size).  Every rank then refits ``err`` from the identical reduced counts, so no
@@ -17,9 +17,22 @@ from .io import extend_err
 from .opts import DadaOpts
 
 
-def shard(n_samples: int, rank: int, world: int):
-    """Indices of the samples rank ``rank`` owns (round-robin)."""
-    return list(range(rank, n_samples, world))
+def shard(n_samples: int, rank: int, world: int, sizes=None):
+    """Indices of the samples rank ``rank`` owns.  With ``sizes`` (uniques per sample) the deal is longest-first:
+    samples in decreasing cost - a sample costs about N x partitions, and partitions grow roughly as sqrt(N) on these data -
+    each to the rank with the least work so far; every rank computes the same deal from the same sizes.  Equal sizes (or no
+    sizes) give the round-robin r, r + W, r + 2 W, ..."""
+    if sizes is None or len(set(int(x) for x in sizes)) <= 1:
+        return list(range(rank, n_samples, world))
+    cost = [float(n) ** 1.5 for n in sizes]
+    order = sorted(range(n_samples), key=lambda i: (-cost[i], i))
+    load = [0.0] * world
+    owner = [0] * n_samples
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += cost[i]
+    return [i for i in range(n_samples) if owner[i] == rank]
 
 
 def allreduce_trans(local_trans: np.ndarray, maxcol: int, dist=None, device=None) -> np.ndarray:
@@ -50,7 +63,7 @@ def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts 
     err_fun = err_fun or noqual_errfun
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    mine = shard(len(dereps), rank, world)
+    mine = shard(len(dereps), rank, world, sizes=[d.nraw for d in dereps])
     if make_runner is None:
         from .api import Sample
         dev_index = device.index if device is not None and getattr(device, "index", None) is not None else 0

@@ -34,6 +34,27 @@ try:
     else:
         d, err, pri, o, exp, meta = case_inputs(case)
     smp = api.Sample.from_derep(d, pri, device=0)
+    if os.environ.get("SHARD_TEST_FAIL"):
+        # one rank fails in the middle of the run (here: at the opening of its 6th exchange point): EVERY rank must come back
+        # with an error instead of waiting for it in a collective for ever
+        from dada2_amd.shard import make_exchange
+        ex0 = make_exchange(dist, None)
+        state = {"n": 0, "fired": False}
+
+        def ex(kind, send, recv):
+            if rank == 1 and not state["fired"] and kind == 0 and len(send) == 8:
+                state["n"] += 1
+                if state["n"] == 6:
+                    state["fired"] = True
+                    raise RuntimeError("injected failure on rank 1")
+            return ex0(kind, send, recv)
+        try:
+            smp.run_sharded(err, o, rank, world, ex)
+            print(f"rank {rank}/{world} UNEXPECTEDLY finished", flush=True)
+        except Exception as e:   # noqa: BLE001
+            print(f"rank {rank}/{world} ok: failed as it should: {e}", flush=True)
+        smp.close()
+        sys.exit(0)
     want = smp.run(err, o)
     got = dada_sharded(smp, err, o, dist=dist, collective_device=torch.device("cuda", 0) if backend == "nccl" else None)
     smp.close()

@@ -85,3 +85,8 @@ def test_shard_round_robin():
     from dada2_amd.multi import shard
     assert shard(8, 0, 8) == [0] and shard(8, 3, 4) == [3, 7] and shard(5, 1, 2) == [1, 3]
     assert sorted(sum((shard(11, r, 4) for r in range(4)), [])) == list(range(11))
+    # unequal samples: longest first, each to the least loaded rank; every rank derives the same deal
+    sizes = [100, 900, 300, 300, 50, 800, 20, 10]
+    deal = [shard(8, r, 3, sizes) for r in range(3)]
+    assert sorted(sum(deal, [])) == list(range(8)) and deal[0] == [1] and deal[1] == [5]
+    assert shard(8, 2, 4, [7] * 8) == [2, 6]

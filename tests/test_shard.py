@@ -51,6 +51,17 @@ def test_sharded_run_under_gloo_equals_the_single_process_result(world, case):
     run_group("emu", "gloo", case, world)
 
 
+@needs_emu
+def test_a_failing_rank_takes_the_others_down_with_an_error_not_a_hang():
+    """A rank that fails between exchange points says so at the next one (the 8-byte size gather every exchange opens with
+    carries -1): its peers return DADA2HIP_ERR_RUNTIME there instead of blocking in a collective."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build as emu_build
+    emu_build.build()
+    outs = run_group("emu", "gloo", "sam1F_default", 2, timeout=300, env_extra={"SHARD_TEST_FAIL": "1"})
+    assert "injected failure on rank 1" in outs[1] and "another rank of the sharded run failed" in outs[0], outs
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,case", [(2, "sam1F_default"), (2, "synth:20000:250:96"), (3, "synth3000_default")])
 def test_gpu_two_ranks_share_one_gpu_under_gloo(world, case):
