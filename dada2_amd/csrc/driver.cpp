@@ -1456,7 +1456,14 @@ struct Run {
     st.ms_enqueue += ms_since(t_enq);
   }
 
-  void v3_topup() { while (v3_enq - v3_ended() < v2_depth) v3_enqueue(false); }
+  // (a fixed number per call: while the device is halted every launch ends at once, and "fewer than depth in flight" stays true
+  //  however many are sent)
+  bool v3_dev_halted = false;          // the block in the host's hands halted the device: nothing to keep fed until it is answered
+  void v3_topup() {
+    if (v3_dev_halted) return;
+    const long need = (long)v2_depth - (v3_enq - v3_ended());
+    for (long k = 0; k < need; k++) v3_enqueue(false);
+  }
   // Wait for the next result block, keeping v2_depth super-chains queued meanwhile.  The device reports the end of every launch
   // through a word of its own (v3_ended), which can reach the host a moment after the last block of that launch: a stream that
   // has gone idle without a block in sight is therefore no error as long as a further launch can still be sent.
@@ -1466,8 +1473,9 @@ struct Run {
     volatile int32_t *seqp = &v2_hblk.p[ring].seq;
     const auto tw = clk::now();
     const bool polite = wait_blocks();
+    int burst = 0;
     for (unsigned spins = 0; *seqp != want; spins++) {
-      if (v3_enq - v3_ended() < v2_depth) { v3_enqueue(false); continue; }
+      if (v3_enq - v3_ended() < v2_depth && burst < 256) { v3_enqueue(false); burst++; continue; }   // (bounded: a device that ends every launch at once without a block is an error)
       cpu_relax();
       if (polite && spins > 64) { struct timespec ts{0, 20000}; nanosleep(&ts, nullptr); }
       if ((spins & 0xFFFF) == 0xFFFF || (polite && (spins & 0xFF) == 0xFF)) {
@@ -1477,7 +1485,7 @@ struct Run {
         if (e == hipSuccess && *seqp != want) {
           // everything queued has run (its writes are visible now) and the block is not there: every launch found the device
           // halted or the ring full and said so - send another one - or a launch ended without saying so (a barrier timed out)
-          if (v3_ended() >= v3_enq) { v3_enqueue(false); continue; }
+          if (v3_ended() >= v3_enq && burst < 512) { v3_enqueue(false); burst++; continue; }
           throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: the persistent round tail ended without publishing its result (a grid barrier timed out?)"};
         }
         if (ms_since(tw) > wait_timeout_s() * 1e3)
@@ -1513,6 +1521,7 @@ struct Run {
         fprintf(stderr, "[v3] blk %ld launch %d halt %d paused %d nclust %d nsh %d cnt %d %d %d %d nbatch %d slot %d birth %d found %d nties %d p %.3e blk %d\n", seq,
                 b.kord, b.halt, b.paused, b.nclust, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],
                 b.bud.nties[0], b.bud.best_p[0], b.blk_count);
+      v3_dev_halted = b.halt != H2_NONE;                       // (a paused block is resumed inside v2_replay, before its moves are replayed)
       v2_replay(b, seq, /*resume_after_fetch=*/b.paused != 0 && b.halt == H2_NONE);
       n_halt[b.halt & 7]++;
       if (b.kord > v3_ord_seen) {                              // first block of its launch: the compare in front of that launch served it
@@ -1564,6 +1573,7 @@ struct Run {
         case H2_FAIL: throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: a grid barrier of the persistent round tail timed out (blocks not co-resident?)"};
         default: throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: unexpected halt code from the persistent round tail"};
       }
+      v3_dev_halted = false;                                   // (answered: host birth / resume are in the stream)
       *(volatile int32_t *)v3_hflags.p = (int32_t)v2_cons;     // the device may reuse the ring slots of everything consumed
     }
     v3_running = false;
