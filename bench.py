@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--shard", action="store_true", help="ONE sample, the per-unique work of its uniques split over the ranks "
                     "(dada2hip_sample_run_sharded, DESIGN.md 7): strong scaling of a single dada() call; resident samples")
+    ap.add_argument("--inflight", type=int, default=2, help="samples of one rank in flight on its GPU (configs with several samples per rank: "
+                    "dada2hip_run_multi with the device listed that many times; their rounds take turns, everything else overlaps)")
     ap.add_argument("--deep", action="store_true", help="workload variant with >= 5 reads per unique (reads drawn at Q34-40)")
     args = ap.parse_args()
 
@@ -219,7 +221,10 @@ def main():
         elif args.shard:
             return [shardmod.dada_sharded(shard_smp, err, opts, dist=dist, collective_device=torch.device("cuda", local))]
         else:
-            results = [api.dada_uniques(hi, None, None, err, None, opts, device=local) for hi in inputs]
+            if len(inputs) > 1 and args.inflight > 1:   # several samples on this rank's GPU: `inflight` boundary calls at a time
+                results = api.dada_uniques_multi(inputs, err, opts, devices=(local,) * min(args.inflight, len(inputs)))
+            else:
+                results = [api.dada_uniques(hi, None, None, err, None, opts, device=local) for hi in inputs]
         allreduce_trans(results)
         return results
 
@@ -312,7 +317,7 @@ def main():
                        "parallelism": ("one sample, its uniques in %d blocks (dada2hip_sample_run_sharded), %s, sample resident"
                                        % (world, "host-driven rounds with the movers / bud candidates exchanged per round" if world > 1
                                           else "world 1: the entry point runs the ordinary device-driven engine") if args.shard
-                                       else (f"{c['samples']} samples round-robin over {world} rank(s)" if strong else f"sample-per-gpu x{world}")),
+                                       else (f"{c['samples']} samples round-robin over {world} rank(s), {min(args.inflight, len(inputs))} in flight per GPU" if strong else f"sample-per-gpu x{world}")),
                        "shard_collectives_per_step": res.stats.get("shard_collectives") if args.shard else None},
             "roofline": roofline, "roofline_secondary": other, "roofline_nw_saturated": saturated,
             "cpu_baseline": cpu,

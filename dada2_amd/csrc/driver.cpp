@@ -8,6 +8,10 @@
 // per unique per round (cluster.cpp:179-201 store filter, b_shuffle2, b_bud, b_p_update) is
 // ordered, pointer-chasing integer/fp64-compare work and runs on the host from the dense device
 // output.  There is no CPU implementation of any kernel: without a GPU every entry point fails.
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -130,6 +134,30 @@ namespace {
 std::mutex &persistent_slot(int device) {
   static std::mutex slots[64];
   return slots[device & 63];
+}
+// ... and across processes that share a GPU (several ranks on one device): an advisory lock on a file named after the
+// device's PCI address, taken without waiting - a process that does not get it runs its rounds on the launch chains.
+struct PersistFile {
+  int fd = -1;
+  bool held = false;
+  bool try_acquire(int device) {
+    if (fd < 0) {
+      char bus[64] = "unknown";
+      if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", device); }
+      for (char *c = bus; *c; c++) if (*c == ':' || *c == '/') *c = '_';
+      char path[160];
+      snprintf(path, sizeof path, "/tmp/dada2hip_persistent_%s.lock", bus);
+      fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+      if (fd < 0) return true;                      // (no lock file possible: trust the in-process slot)
+    }
+    held = flock(fd, LOCK_EX | LOCK_NB) == 0;
+    return held;
+  }
+  void release() { if (held && fd >= 0) (void)flock(fd, LOCK_UN); held = false; }
+};
+PersistFile &persistent_file(int device) {
+  static PersistFile files[64];
+  return files[device & 63];
 }
 
 // Wait for the stream by polling: the per-round decision points (shuffle movers, bud result) sit on
@@ -1412,10 +1440,7 @@ struct Run {
     if (const char *e = getenv("DADA2HIP_V2_TAIL")) v3_on = strcmp(e, "chain") != 0;
     if (getenv("DADA2HIP_V2_GRAPH") && !graph_off()) v3_on = false;     // (hipGraph replay is a property of the chains)
     if (v2_trace_seq >= 0 || getenv("DADA2HIP_V2_TRACE")) v3_on = false; // (the phase trace stamps the chains' kernels)
-    if (v3_on && !v3_slot.owns_lock()) {
-      v3_slot = std::unique_lock<std::mutex>(persistent_slot(s->device), std::try_to_lock);
-      if (!v3_slot.owns_lock()) v3_on = false;                           // another run on this device holds the slot
-    }
+
     v3_grid = tail_grid(N, s->device);
     if (const char *e = getenv("DADA2HIP_V3_GRID")) v3_grid = std::max(1, std::min(atoi(e), tail_grid(1 << 30, s->device)));
     v3_psync.alloc(1); v3_hflags.alloc(32); v3_ktime.alloc(KT_N);
@@ -1424,7 +1449,18 @@ struct Run {
     for (int k = 0; k < 32; k++) v3_hflags.p[k] = 0;
     v3_enq = 0; v3_ord_seen = 0;
   }
-  void v3_release() { if (v3_slot.owns_lock()) v3_slot.unlock(); }
+  // The device's persistent slot, taken for the rounds only (run_v3 releases it).  Threads of this process take turns - the
+  // rounds of one sample fill the device, the uploads, round 0 and final passes of the others overlap them; another PROCESS on
+  // the same GPU that holds the slot sends this run to the launch chains.
+  bool v3_acquire() {
+    if (v3_slot.owns_lock()) return true;
+    v3_slot = std::unique_lock<std::mutex>(persistent_slot(s->device));
+    if (!persistent_file(s->device).try_acquire(s->device)) { v3_slot.unlock(); return false; }
+    return true;
+  }
+  void v3_release() {
+    if (v3_slot.owns_lock()) { persistent_file(s->device).release(); v3_slot.unlock(); }
+  }
   bool v3_block_ready() const { return *(volatile int32_t *)&v2_hblk.p[v2_cons % RING2].seq == (int32_t)(v2_cons + 1); }
   long v3_ended() const { return (long)*(volatile int32_t *)(v3_hflags.p + 16); }
   // one super-chain: the launches of a batch compare (they find nothing to do unless the round in front of the device needs
@@ -1990,7 +2026,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   // run_dada's loop (Rmain.cpp:312-331), rotated: every iteration ends with b_p_update + the b_bud that opens
   // the reference's next iteration, so one device round trip serves both.  After a decision the next round's
   // kernels are launched first; the host mirror (moves replay, birth record) is updated while the GPU works.
-  if (run.use_v2 && run.v3_on) run.run_v3(max_clust);
+  if (run.use_v2 && run.v3_on && run.v3_acquire()) run.run_v3(max_clust);
   else if (run.use_v2) run.run_v2(max_clust);
   else if (run.nclust_dev < max_clust) {
     run.round_tail(false);                            // b_p_update after round 0, then the first b_bud

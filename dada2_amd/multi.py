@@ -50,12 +50,13 @@ def allreduce_trans(local_trans: np.ndarray, maxcol: int, dist=None, device=None
 
 
 def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts = None, make_runner=None, dist=None,
-               device=None, max_col: int = None, on_pass=None):
+               device=None, max_col: int = None, on_pass=None, inflight: int = 2):
     """dada() over many samples, sharded across the ranks of ``dist``.
 
     ``dereps``       all samples (every rank sees the list; only its shard is touched)
     ``make_runner``  derep -> object with .run(err, opts, max_clust=...) -> DadaResult and .close();
                      default = GPU-resident dada2_amd.api.Sample on this rank's device
+    ``inflight``     samples of this rank running at a time (1 = the serial loop of R/dada.R:266)
     Returns (dict sample_index -> DadaResult for the local shard, err_out, list of err tried).
     Mirrors the loop of R/dada.R:256-405 (see dada2_amd.api.dada for the single-process form)."""
     from .api import accumulate_trans, noqual_errfun
@@ -80,13 +81,23 @@ def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts 
                 errs.append(np.array(err, copy=True))
             local = np.zeros((16, maxcol), dtype=np.int64)
             used = {}
-            for i in mine:
+            def one(i):
                 d = dereps[i]
                 qmax = int(np.ceil(np.nanmax(d.quals)))
                 erri = np.ones((16, max(41, qmax + 1))) if initialize else extend_err(err, qmax)
-                results[i] = runners[i].run(erri, o, max_clust=1 if initialize else None)
+                return i, erri, runners[i].run(erri, o, max_clust=1 if initialize else None)
+            # a rank's samples `inflight` at a time (threads; the library call releases the GIL): the rounds of one sample fill the
+            # GPU and take turns, the round 0, final passes and result marshalling of the others run beside them
+            if inflight > 1 and len(mine) > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=min(inflight, len(mine))) as pool:
+                    done = list(pool.map(one, mine))
+            else:
+                done = [one(i) for i in mine]
+            for i, erri, res in done:
+                results[i] = res
                 used[i] = erri
-                t = results[i].subqual
+                t = res.subqual
                 local[:, : t.shape[1]] += t
             if on_pass is not None:   # (tests: every pass of the loop is checked, not just the last)
                 on_pass(0 if initialize else len(errs), used, 1 if initialize else None, dict(results))

@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <cstdio>
+#include <unistd.h>
 
 // ---- qualifiers ------------------------------------------------------------------------------------------------------
 #define __global__
@@ -145,6 +147,7 @@ inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipDeviceGetPCIBusId(char *b, int n, int d) { snprintf(b, n, "emu%d_%d", d, (int)getpid()); return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::memset(p, 0, sizeof *p); p->multiProcessorCount = 8; p->clockRate = 1000000; return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = *tot = (size_t)16 << 30; return hipSuccess; }
 inline hipError_t hipDeviceTotalMem(size_t *tot, int) { *tot = (size_t)16 << 30; return hipSuccess; }
