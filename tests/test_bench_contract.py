@@ -1,4 +1,4 @@
-"""bench.py's one-line JSON contract, checked on the committed records of the last GPU runs (profiles/r02z / r03b bench_*.json):
+"""bench.py's one-line JSON contract, checked on the committed records of the last GPU runs (profiles/r05z_bench_*.json):
 the driver and the judge parse these keys, so a refactor of bench.py must keep them."""
 import json
 import os
@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORDS = ["r02z_bench_cfg3.json", "r03b_bench_cfg2.json", "r03b_bench_cfg4.json", "r03b_bench_cfg5.json"]   # [0] = the default run
+RECORDS = ["r05z_bench_cfg3.json", "r05z_bench_cfg2.json", "r05z_bench_cfg4_inflight2.json", "r05z_bench_cfg5.json"]   # [0] = the default run
 
 
 @pytest.mark.parametrize("name", RECORDS)

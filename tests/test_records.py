@@ -23,7 +23,7 @@ def test_every_profile_record_the_documents_cite_exists():
 
 
 def test_committed_default_bench_line_has_the_contract_keys():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03y_bench_cfg3.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05z_bench_cfg3.json")))
     assert files
     d = json.loads(open(files[-1]).read().split("\n")[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -39,3 +39,5 @@ def test_committed_default_bench_line_has_the_contract_keys():
     assert d["cpu_baseline"]["kind"] == "reference"
     assert abs(d["value"] - d["config"]["uniques_per_sample"] / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
     assert d["selfconsist"] and d["secondary_workload"]          # the sub-records VERDICT r2 asked for
+    whole = d["cpu_baseline"]["whole_sample"]                     # the reference ONCE on the whole 1 M sample, outputs compared
+    assert whole["uniques"] == d["config"]["uniques_per_sample"] and whole["parity_vs_gpu"] is True

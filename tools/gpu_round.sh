@@ -22,6 +22,7 @@ for s in $STEPS; do
     bench3qchain) DADA2HIP_V2_TAIL=chain timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg3_quick_chain.json 2> $OUT/bench_cfg3_quick_chain.err; echo "bench3qchain rc=$?" >> $OUT/steps.log; python3 -c "import json;b=json.load(open('$OUT/bench_cfg3_quick_chain.json'));print(b['ms_per_step'], b['resident']);print(b['phases_ms_last_step'])" ;;
     bench2q) timeout 600 python bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg2_quick.json 2> $OUT/bench_cfg2_quick.err; echo "bench2q rc=$?" >> $OUT/steps.log; python3 -c "import json;b=json.load(open('$OUT/bench_cfg2_quick.json'));print(b['ms_per_step'], b['resident']);print(b['phases_ms_last_step'])" ;;
     subphases) for c in 2 3; do DADA2HIP_V2_SUMMARY=1 timeout 600 python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-extras 2> $OUT/subphases_cfg$c.err > $OUT/subphases_cfg$c.json; grep "sub-phase\|\[v3\] blocks" $OUT/subphases_cfg$c.err | tail -2; done; echo "subphases rc=$?" >> $OUT/steps.log ;;
+    bench4sweep) for k in 1 2 3 4; do timeout 600 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass --inflight $k > $OUT/bench_cfg4_inflight$k.json 2> $OUT/bench_cfg4_inflight$k.err; python3 -c "import json;b=json.load(open('$OUT/bench_cfg4_inflight$k.json'));print('inflight $k', round(b['ms_per_step'],1), round(b['value']))"; done; echo "bench4sweep rc=$?" >> $OUT/steps.log ;;
     occ)     timeout 300 tools/microbench occ > $OUT/occ.json 2> $OUT/occ.err; echo "occ rc=$?" >> $OUT/steps.log; cat $OUT/occ.json ;;
     launch)  timeout 300 tools/microbench launch > $OUT/launch.json 2> $OUT/launch.err; echo "launch rc=$?" >> $OUT/steps.log; cat $OUT/launch.json ;;
     tests_iter) timeout 1200 python -X faulthandler -m pytest tests -m gpu -q -rf -p no:cacheprovider -k "not at_size and not 1M" --durations=10 > $OUT/gputests_iter.log 2>&1; echo "tests_iter rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_iter.log ;;
@@ -36,7 +37,7 @@ for s in $STEPS; do
     bench3sc) timeout 900 python bench.py --steps 2 --warmup 1 --selfconsist > $OUT/bench_cfg3_selfconsist.json 2> $OUT/bench_cfg3_selfconsist.err; echo "bench3sc rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/bench_cfg3_selfconsist.json ;;
     bench2)  timeout 600 python bench.py --config 2 --steps 10 --warmup 2 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err; echo "bench2 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2.json ;;
     bench2deep) timeout 1200 python bench.py --config 2 --deep --steps 3 --warmup 1 > $OUT/bench_cfg2_deep.json 2> $OUT/bench_cfg2_deep.err; echo "bench2deep rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg2_deep.json ;;
-    bench4)  timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; echo "bench4 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg4.json ;;
+    bench4)  timeout 900 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline ${BENCH4_ARGS:-} > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err; echo "bench4 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg4.json ;;
     bench5)  timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 ${BENCH5_ARGS:-} > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; echo "bench5 rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/bench_cfg5.json ;;
     prof3|prof2|prof5)
              CFG=${s#prof}; P=$OUT/prof$CFG; mkdir -p $P
