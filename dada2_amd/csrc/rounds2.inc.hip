@@ -739,7 +739,10 @@ static __device__ __forceinline__ void plan_aligner(const Eng2 &E, int centre, i
     if (nb > 0 && tid < 2 * KB_MAX) E.blist_n[tid] = 0;
   }
 }
-static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc) {
+// hint (optional, the serial end of a round has them at hand; nullptr: read from memory): hint[0] = reads of `raw`,
+// hint[1], hint[2] = Ctl2::n0 / low0 as of now, hint[3] != 0: s_misc + 32 already holds a copy of Cache2::slot_centre
+static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc,
+                                                            const int32_t *hint = nullptr) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   Ctl2 *ctl = E.ctl;
@@ -755,12 +758,12 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
   uint32_t *s_rd = (uint32_t *)(s_p + 16);                          // [16]
   if (tid == 0) {
     const int newi = ctl->nclust;
-    const uint32_t reads_new = S.reads[raw];
+    const uint32_t reads_new = hint ? (uint32_t)hint[0] : S.reads[raw];
     P.clust_of[raw] = newi;
     P.lock[raw] = 0;                                                // bi_assign_center unlocks the members (cluster.cpp:377)
     P.slot0[raw] = 1;
     E.moved[raw] = 1;
-    if (from == 0) { const int n0 = ctl->n0 - 1; ctl->n0 = n0; if (n0 < ctl->low0) ctl->low0 = n0; }
+    if (from == 0) { const int n0 = (hint ? hint[1] : ctl->n0) - 1; ctl->n0 = n0; if (n0 < (hint ? hint[2] : ctl->low0)) ctl->low0 = n0; }
     P.creads[newi] = reads_new;
     P.creads[from] -= reads_new;
     P.centre_of[newi] = raw;
@@ -773,7 +776,8 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
     *s_hit = -1;
   }
   __syncthreads();
-  for (int q = tid; q < nslots; q += blockDim.x) if (C.slot_centre[q] == raw) *s_hit = q;   // (at most one slot holds it)
+  if (hint && hint[3]) { for (int q = tid; q < nslots; q += blockDim.x) if (s_tab[q] == raw) *s_hit = q; }
+  else for (int q = tid; q < nslots; q += blockDim.x) if (C.slot_centre[q] == raw) *s_hit = q;   // (at most one slot holds it)
   __syncthreads();
   if (*s_hit >= 0) {
     if (tid == 0) { ctl->slot = *s_hit; ctl->nbatch = 0; ctl->need_compare = 0; }
@@ -918,31 +922,80 @@ static __device__ __forceinline__ void clear_block(Round2Out *nx) {
 // kord: 0 in a launch chain (k2_birth); the launch ordinal in the persistent tail (k3_tail), which also wants to know whether to
 // leave the launch after this round (Ctl2::kexit) and pauses when the round's movers do not fit the block.
 static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const Chain2 cs, BudKey init, const BudKey *__restrict__ partial, int nblocks, int kord) {
+  // The section is one block's work while (in the persistent tail) every other block waits: it is written as few dependent
+  // memory round trips as the logic allows.  STAGE 1 requests everything that depends on nothing computed here - the scalars
+  // thread 0 will want (one lane each, into LDS), the reads deltas, the blocks' statistics and minima, the head of the
+  // candidate list, the cache's slot table - in one go; STAGE 2 the p-values of the listed candidates; the ties then sit in
+  // LDS for the decision.  (Round 3's form took about fifteen trips, 24 us a round at 10^6 uniques.)
   Ctl2 *ctl = E.ctl;
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
   __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
   __shared__ int s_halt, s_raw, s_from, s_evalok, s_nt[2], s_nnear;
   __shared__ BudKey s_k[2][16];
+  __shared__ int32_t s_pre[64];
+  __shared__ int32_t s_hint[4];
+  __shared__ BudTie s_tie[BUD_TIES];                     // the first ties of track 0, where the decision reads them
+  enum { PRE_N0 = 0, PRE_LOW0, PRE_NALIGN, PRE_SLOT, PRE_NBATCH, PRE_MAXCLUST, PRE_ERR, PRE_NWFLAG, PRE_BLKCNT, PRE_STATN, PRE_SIGN,
+         PRE_NEEDCMP, PRE_HCONS, PRE_N0D = 14 /* 2 SH_LEVELS */, PRE_BLIST = 34 /* 2 KB_MAX */, PRE_CNT = 50 /* SH_LEVELS */ };
+  static_assert(PRE_N0D + 2 * SH_LEVELS <= PRE_BLIST && PRE_BLIST + 2 * KB_MAX <= PRE_CNT && PRE_CNT + SH_LEVELS <= 64, "scalar slots");
   const PartState &P = E.P;
   const SampleDev &S = E.S;
+  const int tid = threadIdx.x;
   const int ring = ctl->pub_seq % RING2;
   Round2Out *out = E.dblk + ring;
   const int nclust = ctl->nclust;
   const bool tr = E.trace && ctl->pub_seq == E.trace_seq && threadIdx.x == 0;
 #define D2_TRB(PHASE) do { if (tr) E.trace[((size_t)6 * TRACE_BLOCKS) * 8 + (PHASE)] = gcn_clock(); D2_KSUB(6, PHASE, true); } while (0)
   D2_TRB(0);
+  // ---- stage 1: requests ----
+  const int32_t *pa = nullptr;
+  switch (tid) {
+    case PRE_N0: pa = &ctl->n0; break;
+    case PRE_LOW0: pa = &ctl->low0; break;
+    case PRE_NALIGN: pa = &ctl->nalign; break;
+    case PRE_SLOT: pa = &ctl->slot; break;
+    case PRE_NBATCH: pa = &ctl->nbatch; break;
+    case PRE_MAXCLUST: pa = &ctl->max_clust; break;
+    case PRE_ERR: pa = P.err_flag; break;
+    case PRE_NWFLAG: pa = S.nw_flag; break;
+    case PRE_BLKCNT: pa = E.T.blk_count; break;
+    case PRE_STATN: pa = E.stat_n; break;
+    case PRE_SIGN: pa = E.sig_n; break;
+    case PRE_NEEDCMP: pa = &ctl->need_compare; break;
+    case PRE_HCONS: pa = &ctl->hcons_seen; break;
+    default:
+      if (tid >= PRE_N0D && tid < PRE_N0D + 2 * cs.nexec) pa = E.n0d + (tid - PRE_N0D);
+      else if (tid >= PRE_BLIST && tid < PRE_BLIST + 2 * KB_MAX) pa = E.blist_n + (tid - PRE_BLIST);
+      else if (tid >= PRE_CNT && tid < PRE_CNT + SH_LEVELS) pa = &out->cnt[tid - PRE_CNT];
+  }
+  const int32_t pv = pa ? *pa : 0;
+  uint4 sp = make_uint4(0, 0, 0, 0);                      // this thread's share of the store pass's class counts (masked below)
+  if (tid < 8192) sp = ((const uint4 *)E.stat_part)[tid];   // (the buffer holds 8192 entries; what lies past the pass's grid is dropped below)
+  BudKey pk0 = init, pk1 = init;                          // ... of the blocks' minima
+  if (cs.eval_ok && tid < nblocks) { pk0 = partial[2 * tid]; pk1 = partial[2 * tid + 1]; }
+  int sq[2] = {-1, -1};                                   // ... of the candidate list (entries past its end are dropped below)
+  if (cs.eval_ok) {
+    if (tid < S.N) sq[0] = E.sig_list[tid];
+    if (tid + (int)blockDim.x < S.N) sq[1] = E.sig_list[tid + blockDim.x];
+  }
+  const int nslots = E.C.NBUF * KB_MAX;
+  int *s_tab = s_misc + 32;
+  for (int q = tid; q < nslots; q += blockDim.x) s_tab[q] = E.C.slot_centre[q];
   // fold the chain's partition-read deltas into the reads
-  for (int i = threadIdx.x; i < nclust; i += blockDim.x) {
+  for (int i = tid; i < nclust; i += blockDim.x) {
     int32_t d = 0;
     for (int l = 0; l < cs.nexec; l++) { d += E.dlt[(size_t)l * E.ccap + i]; E.dlt[(size_t)l * E.ccap + i] = 0; }   // (the rows of calls that did not run hold zeros)
     if (d) P.creads[i] += (uint32_t)d;
   }
-  if (threadIdx.x < 2) s_nt[threadIdx.x] = 0;
+  if (tid < 64) s_pre[tid] = pv;
+  if (tid < 2) s_nt[tid] = 0;
+  __syncthreads();
   {   // class statistics of the chain's store pass, if it had one: the blocks' partial counts (k2_shuffle<true>)
-    const int np = *E.stat_n;
+    const int np = s_pre[PRE_STATN];
     if (np > 0) {
       uint32_t v[4] = {0, 0, 0, 0};
-      for (int b = threadIdx.x; b < np; b += blockDim.x) {
+      if (tid < np) { v[0] = sp.x; v[1] = sp.y; v[2] = sp.z; v[3] = sp.w; }
+      for (int b = tid + blockDim.x; b < np; b += blockDim.x) {
         const uint4 q = ((const uint4 *)E.stat_part)[b];
         v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
       }
@@ -950,31 +1003,32 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
       for (int k = 0; k < 4; k++) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
-        if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&out->stat[k], (unsigned long long)v[k]);
+        if ((tid & 63) == 0 && v[k]) atomicAdd(&out->stat[k], (unsigned long long)v[k]);
       }
     }
   }
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     *E.stat_n = 0;
     s_nnear = 0;
     // partition 0's member count through the chain's shuffle calls: within one call only the number it lost is known, not
     // the order of losses and gains, so the running minimum is taken as if all losses came first (a lower bound)
-    int n0 = ctl->n0, low0 = ctl->low0;
+    int n0 = s_pre[PRE_N0], low0 = s_pre[PRE_LOW0];
     for (int l = 0; l < cs.nexec; l++) {
-      const int lost = E.n0d[2 * l], gained = E.n0d[2 * l + 1];
+      const int lost = s_pre[PRE_N0D + 2 * l], gained = s_pre[PRE_N0D + 2 * l + 1];
       if (lost | gained) { E.n0d[2 * l] = 0; E.n0d[2 * l + 1] = 0; }
       if (n0 - lost < low0) low0 = n0 - lost;
       n0 += gained - lost;
     }
     ctl->n0 = n0; ctl->low0 = low0;
+    s_hint[1] = n0; s_hint[2] = low0; s_hint[3] = 1;
   }
-  __syncthreads();
   D2_TRB(1);
   // ---- second stage of b_bud's arg-min (cluster.cpp:284-308): the block minima of k2_pupdate, then the exact ties of the
   //      best key and every other listed candidate whose non-zero p is within BUD_NEAR of it (engine.h) ----
   if (cs.eval_ok) {
     BudKey b0 = init, b1 = init;
-    for (int k = threadIdx.x; k < nblocks; k += blockDim.x) {
+    if (tid < nblocks) { if (bud_better(pk0.p, pk0.reads, b0)) b0 = pk0; if (bud_better(pk1.p, pk1.reads, b1)) b1 = pk1; }
+    for (int k = tid + blockDim.x; k < nblocks; k += blockDim.x) {
       if (bud_better(partial[2 * k].p, partial[2 * k].reads, b0)) b0 = partial[2 * k];
       if (bud_better(partial[2 * k + 1].p, partial[2 * k + 1].reads, b1)) b1 = partial[2 * k + 1];
     }
@@ -986,7 +1040,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
       t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
       if (bud_better(t.p, t.reads, b1)) b1 = t;
     }
-    if ((threadIdx.x & 63) == 0) { s_k[0][threadIdx.x >> 6] = b0; s_k[1][threadIdx.x >> 6] = b1; }
+    if ((tid & 63) == 0) { s_k[0][tid >> 6] = b0; s_k[1][tid >> 6] = b1; }
     __syncthreads();
     b0 = s_k[0][0]; b1 = s_k[1][0];
     for (int k = 1; k < 16; k++) {
@@ -998,14 +1052,21 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
     //  that are not significant were not listed, and an exact tie of a significant key is significant itself)
     const bool sig0 = b0.p * S.N < 2.0 * E.bp.omegaA, sig1 = b1.p < 2.0 * E.bp.omegaP;
     const double thr0 = sig0 ? b0.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0, thr1 = sig1 ? b1.p * (1.0 + BUD_NEAR) + 2e-323 : -1.0;
-    const int M = *E.sig_n;
+    const int M = s_pre[PRE_SIGN];
     BudOut *bo = &out->bud;
-    for (int q = threadIdx.x; q < M; q += blockDim.x) {
-      const int r = E.sig_list[q];
-      const double p = P.p[r];
-      const uint32_t reads = S.reads[r];
+    // ---- stage 2: the listed candidates' keys, the first two per thread requested together ----
+    double ps_[2] = {0.0, 0.0};
+    uint32_t rds_[2] = {0, 0};
+    uint8_t prs_[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int q = tid + j * (int)blockDim.x;
+      if (q >= M) sq[j] = -1;
+      if (sq[j] >= 0) { ps_[j] = P.p[sq[j]]; rds_[j] = S.reads[sq[j]]; prs_[j] = S.prior[sq[j]]; }
+    }
+    auto consider = [&](int r, double p, uint32_t reads, bool prior) __attribute__((always_inline)) {
       for (int track = 0; track < 2; track++) {
-        if (track == 1 && !S.prior[r]) continue;
+        if (track == 1 && !prior) continue;
         const BudKey &bk = track ? b1 : b0;
         if (!(track ? (found1 && sig1) : (found0 && sig0))) continue;
         const bool exact = p == bk.p && reads == bk.reads;
@@ -1017,52 +1078,64 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
           BudTie t;
           t.raw = r; t.comp_i = P.comp_i[r]; t.comp_ham = P.comp_ham[r]; t.comp_lam = P.comp_lam[r];
           t.from = P.clust_of[r]; t.from_reads = P.creads[t.from]; t.p = p; t.pad = 0;
-          if (k < BUD_TIES) bo->ties[track][k] = t;
+          if (k < BUD_TIES) { bo->ties[track][k] = t; if (track == 0) s_tie[k] = t; }
           E.ties_rec[(size_t)track * TIES_FULL + k] = t;
         }
         (track ? E.ties1 : E.ties0)[k] = r;
       }
+    };
+#pragma unroll
+    for (int j = 0; j < 2; j++) if (sq[j] >= 0) consider(sq[j], ps_[j], rds_[j], prs_[j] != 0);
+    for (int q = tid + 2 * (int)blockDim.x; q < M; q += blockDim.x) {
+      const int r = E.sig_list[q];
+      consider(r, P.p[r], S.reads[r], S.prior[r] != 0);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       bo->best_p[0] = b0.p; bo->best_p[1] = b1.p;
       bo->best_reads[0] = b0.reads; bo->best_reads[1] = b1.reads;
       bo->found[0] = found0; bo->found[1] = found1;
       bo->nties[0] = s_nt[0]; bo->nties[1] = s_nt[1];
       bo->valid = 1;
+      // ---- the decision (thread 0; everything it reads is in registers or LDS) ----
+      s_k[0][0] = b0; s_k[1][0] = b1;                     // (kept for the decision block below)
+      s_misc[2] = found0 ? 1 : 0; s_misc[3] = found1 ? 1 : 0;
     }
   }
   __syncthreads();
   D2_TRB(2);
-  if (threadIdx.x == 0) {
-    out->nlev = nlev; out->nsh = cs.nexec; out->slot = ctl->slot; out->nbatch = ctl->nbatch;
-    if (ctl->nalign > 0 && nlev > 0) {                           // alignments / gapless pairs the aligner ran for this chain
+  if (tid == 0) {
+    out->nlev = nlev; out->nsh = cs.nexec; out->slot = s_pre[PRE_SLOT]; out->nbatch = s_pre[PRE_NBATCH];
+    if (s_pre[PRE_NALIGN] > 0 && nlev > 0) {                     // alignments / gapless pairs the aligner ran for this chain
       int nn = 0, ng = 0;
-      for (int k = 0; k < KB_MAX; k++) { nn += E.blist_n[k]; ng += E.blist_n[KB_MAX + k]; }
+      for (int k = 0; k < KB_MAX; k++) { nn += s_pre[PRE_BLIST + k]; ng += s_pre[PRE_BLIST + KB_MAX + k]; }
       out->pad0[1] = nn; out->pad0[2] = ng;
     }
-    out->err_flag = *P.err_flag | (*S.nw_flag ? 4 : 0);
-    out->blk_count = *E.T.blk_count;
-    const BudOut &b = out->bud;
+    const int errf = s_pre[PRE_ERR] | (s_pre[PRE_NWFLAG] ? 4 : 0), blkc = s_pre[PRE_BLKCNT];
+    out->err_flag = errf;
+    out->blk_count = blkc;
     int halt = H2_NONE, raw = -1, from = 0;
     if (!cs.eval_ok) { halt = H2_SHUFFLE_MORE; ctl->nsh_base += cs.nexec; }
-    else if (nclust >= ctl->max_clust) halt = H2_MAXCLUST;
+    else if (nclust >= s_pre[PRE_MAXCLUST]) halt = H2_MAXCLUST;
     else {
+      const BudKey b0 = s_k[0][0], b1 = s_k[1][0];
+      const bool found0 = s_misc[2] != 0, found1 = s_misc[3] != 0;
+      const int nt0 = s_nt[0];
       // the unambiguous case of b_bud (cluster.cpp:300-330) is the device's; the margins keep every decision that depends
       // on the last ulp of a p-value on the host
-      const double pA = b.best_p[0] * S.N;
+      const double pA = b0.p * S.N;
       // Several candidates with the same key: b_bud keeps the first one it meets, partitions in index order and each
       // partition's members in list order (cluster.cpp:284-308).  Settled here when the key is p = 0 exactly (an underflow
       // on any libm; nothing near it is listed) and the order follows without the member lists: the lowest partition holds
       // one candidate, or it is partition 0 and its candidates have never moved and never been its last member - their
       // slots are their indices (Eng2::moved).  Everything else stays the host's.
-      int win = b.nties[0] == 1 ? 0 : -1;
-      if (b.valid && b.found[0] && b.nties[0] > 1 && b.nties[0] <= BUD_TIES && !s_nnear && b.best_p[0] == 0.0) {
+      int win = nt0 == 1 ? 0 : -1;
+      if (found0 && nt0 > 1 && nt0 <= BUD_TIES && !s_nnear && b0.p == 0.0) {
         int cmin = 0x7FFFFFFF, ncmin = 0, kmin = -1, rmin = 0x7FFFFFFF;
         bool ok = true;
-        const int low0 = ctl->low0;
-        for (int k = 0; k < b.nties[0]; k++) {
-          const int fr = b.ties[0][k].from, rw = b.ties[0][k].raw;
+        const int low0 = s_hint[2];
+        for (int k = 0; k < nt0; k++) {
+          const int fr = s_tie[k].from, rw = s_tie[k].raw;
           if (fr < cmin) { cmin = fr; ncmin = 0; rmin = 0x7FFFFFFF; }
           if (fr == cmin) {
             ncmin++;
@@ -1072,18 +1145,22 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
         }
         if (ok && (ncmin == 1 || cmin == 0)) win = kmin;
       }
-      if (win > 0) { const BudTie t = out->bud.ties[0][0]; out->bud.ties[0][0] = out->bud.ties[0][win]; out->bud.ties[0][win] = t; win = 0; }
-      const bool birthA = b.valid && b.found[0] && win == 0 && pA < E.omegaA * (1.0 - 1e-9);
-      const bool noA = !b.found[0] || pA >= E.omegaA * (1.0 + 1e-9);
-      const bool noP = !b.found[1] || b.best_p[1] >= E.omegaP * (1.0 + 1e-9);
-      if (birthA) { raw = b.ties[0][0].raw; from = b.ties[0][0].from; }
-      else if (b.valid && noA && noP) halt = H2_NO_BIRTH;
+      if (win > 0) {
+        const BudTie t = s_tie[0]; s_tie[0] = s_tie[win]; s_tie[win] = t;
+        out->bud.ties[0][0] = s_tie[0]; out->bud.ties[0][win] = s_tie[win];
+        win = 0;
+      }
+      const bool birthA = found0 && win == 0 && pA < E.omegaA * (1.0 - 1e-9);
+      const bool noA = !found0 || pA >= E.omegaA * (1.0 + 1e-9);
+      const bool noP = !found1 || b1.p >= E.omegaP * (1.0 + 1e-9);
+      if (birthA) { raw = s_tie[0].raw; from = s_tie[0].from; s_hint[0] = (int32_t)b0.reads; }
+      else if (noA && noP) halt = H2_NO_BIRTH;
       else halt = H2_HOST_DECIDE;
-      if (halt == H2_NONE && (nclust + 2 > E.ccap || out->blk_count + S.N > E.T.blk_cap)) halt = H2_CAPACITY;
+      if (halt == H2_NONE && (nclust + 2 > E.ccap || blkc + S.N > E.T.blk_cap)) halt = H2_CAPACITY;
     }
     // did the round's shuffles end with a call that moved nothing?  (not when MAX_SHUFFLE cut them short, Rmain.cpp:321: the
     // next round's first call then looks at everybody)
-    if (cs.eval_ok) ctl->stable = (nlev == 0 || (cs.nexec > 0 && out->cnt[cs.nexec - 1] == 0)) ? 1 : 0;
+    if (cs.eval_ok) ctl->stable = (nlev == 0 || (cs.nexec > 0 && s_pre[PRE_CNT + cs.nexec - 1] == 0)) ? 1 : 0;
     out->halt = halt;
     out->birth_applied = halt == H2_NONE ? 1 : 0;
     out->nclust = nclust + (halt == H2_NONE ? 1 : 0);
@@ -1093,17 +1170,17 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
   __syncthreads();
   D2_TRB(3);
   if (s_evalok)   // b_p_update has consumed the flags (pval.cpp:24,37)
-    for (int k = threadIdx.x; k < nclust; k += blockDim.x) { P.update_e[k] = 0; P.check_locks[k] = 0; }
+    for (int k = tid; k < nclust; k += blockDim.x) { P.update_e[k] = 0; P.check_locks[k] = 0; }
   __syncthreads();
   if (s_halt == H2_NONE) {
-    apply_birth_and_plan(E, s_raw, s_from, s_cnt, s_misc);
+    apply_birth_and_plan(E, s_raw, s_from, s_cnt, s_misc, s_hint);
     __syncthreads();
-    if (threadIdx.x == 0) *E.sig_n = 0;                      // consumed: the next evaluation lists afresh
+    if (tid == 0) *E.sig_n = 0;                              // consumed: the next evaluation lists afresh
   }
   D2_TRB(4);
-  if (kord && threadIdx.x == 0) {
+  if (kord && tid == 0) {
     int tot = 0;
-    for (int l = 0; l < SH_LEVELS; l++) tot += out->cnt[l];
+    for (int l = 0; l < SH_LEVELS; l++) tot += s_pre[PRE_CNT + l];
     const bool pause = s_halt == H2_NONE && tot > E.mov_inline;      // the full lists stay in Eng2::movers until the host has them
     if (pause) { out->paused = 1; ctl->state = 1; ctl->halt = H2_NONE; }
     out->kord = kord;
@@ -1111,7 +1188,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
     // host's ring of result blocks would not take the NEXT block: publishing sequence number q reuses the slot of q - RING2
     const int seq = ctl->pub_seq + 1;
     int ex = (s_halt != H2_NONE || pause || ctl->need_compare != 0 || E.align_at_commit != 0) ? 1 : 0;
-    if (!ex && seq + 1 - ctl->hcons_seen > E.ring_limit) {
+    if (!ex && seq + 1 - s_pre[PRE_HCONS] > E.ring_limit) {
       const int hc = gcn_load_system((const int32_t *)E.hcons);
       ctl->hcons_seen = hc;
       if (seq + 1 - hc > E.ring_limit) ex = 1;
