@@ -1094,6 +1094,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       for (;;) {
         const bool act = lead && !done && (ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard > 0;
         if (!__any(act)) break;
+        bool gapmove = false;
         const int gact = __shfl((int)act, gl0, 64);
         const int tt = __shfl(ti + tj, gl0, 64), col = __shfl((tj - ti + lbo) >> 1, gl0, 64);
         const int f0 = tt & 15, widx = (tt >> 4) - g;
@@ -1124,10 +1125,30 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
             push(tj - n, n, ti - tj + 128);
             ti -= n; tj -= n;
           }
-          if (qs < GL && !clamped && (ti > 0 || tj > 0)) {  // (0,0) carries an axis pointer too: the path ends there
-            if (pq == AD_LEFT) { tj--; push(tj, 1, 255); } // from the left
-            else ti--;                                     // from above (the diagonal code cannot be here)
+          gapmove = qs < GL && !clamped && (ti > 0 || tj > 0);   // (0,0) carries an axis pointer too: the path ends there
+        }
+        // The stretch ended at a gap move.  A RUN of gap moves in one direction - the free end gaps of a pair of unequal
+        // lengths are 20-60 of them at 1.5 kb - is measured by the whole group in one round trip: lane s looks at the pointer
+        // of the cell s moves further along the row (from the left) or the column (from above).  Taking them one per round
+        // was three quarters of the long reads' traceback time (profiles/r05v_nw_phases_cfg5.jsonl).
+        const int gdir = __shfl(gapmove ? (int)pq : -1, gl0, 64);
+        const int gi = __shfl(ti, gl0, 64), gj = __shfl(tj, gl0, 64);
+        bool cont = false;
+        if (gdir >= 0 && !ghost) {
+          const int ci = gdir == (int)AD_LEFT ? gi : gi - g, cj = gdir == (int)AD_LEFT ? gj - g : gj;
+          if (gdir == (int)AD_LEFT ? (cj >= 1 && ci >= 0) : (ci >= 1 && cj >= 0)) {
+            const int t2 = ci + cj, k2 = cj - ci + lbo;
+            if (k2 >= org && k2 < W + org)                 // (in band: the path never leaves it)
+              cont = ((pg[(size_t)(t2 >> 4) * 64 + gl0 + (k2 >> 1)] >> ((t2 & 15) << 1)) & 3u) == (uint32_t)gdir;
           }
+        }
+        const unsigned long long runmask = (__ballot(cont) >> gl0) & (GL == 64 ? ~0ull : ((1ull << (GL & 63)) - 1ull));
+        if (gapmove) {
+          int m = runmask == ~0ull ? 64 : __builtin_ctzll(~runmask);   // leading lanes whose cell goes on in the same direction
+          if (m > GL) m = GL;
+          if (m < 1) m = 1;                                // (lane 0 looks at the cell the stretch ended on: never 0)
+          if (pq == AD_LEFT) { tj -= m; push(tj, m, 255); }   // from the left: m raw positions facing gaps
+          else ti -= m;                                    // from above (the diagonal code cannot be here)
         }
       }
       if (lead && !gapless && active) {
@@ -1141,7 +1162,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) nrmax = max(nrmax, __shfl_xor(nrmax, o, 64));
       for (int ri = 0; ri < nrmax; ri++) {
-        if (ri < nruns && !ghost) {
+        if (ri < nruns && !ghost && !(dbg & 4)) {
           const uint32_t dsc = runs[ri];
           const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
           for (int pj = lo + g; pj < lo + n; pj += GL) {
