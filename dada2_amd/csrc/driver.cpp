@@ -103,6 +103,8 @@ struct dada2hip_sample {
   DevBuf<uint8_t> d_skip, d_cls, d_correct, d_moves;
   DevBuf<double> d_lambda, d_err;
   DevBuf<uint32_t> d_ham, scr_ptr, scr_t, d_qn, d_ctab, scr_adw, scr_ad;
+  DevBuf<uint16_t> scr_foff;          // k_nw_ad -> k_ad_product: factor offsets of the launch's alignments (engine.h, SampleDev::ad_foff)
+  DevBuf<AdDesc> scr_fdesc;
   int scr_adw_waves = 0, scr_adw_band = -999;
   size_t scr_adw_wpw = 0;
   DevBuf<int32_t> d_nw_list, d_gl_list, d_counters, d_thresh, scr_rows, d_work, d_chunk_centre, d_cluster_of,
@@ -408,14 +410,23 @@ void ensure_ad_ring(dada2hip_sample *s) {
   if (s->D.ad_ptr) return;
   s->scr_ad.alloc((size_t)s->D.ad_waves * s->D.ad_wpw);
   s->D.ad_ptr = s->scr_ad.p;
+  // the factor-offset rows of k_ad_product: one per work slot of a launch - at most all pairs of a batch compare (8 N), at
+  // most 2^20, at most 1 GB; what does not fit is multiplied up inside k_nw_ad as before
+  const int stride = (s->D.maxlen + 7) & ~7;
+  long long cap = std::min<long long>(1ll << 20, ((long long)1 << 30) / (2ll * stride));
+  cap = std::min<long long>(cap, 8ll * s->D.N + 512);
+  s->scr_foff.alloc((size_t)cap * stride);
+  s->scr_fdesc.alloc((size_t)cap);
+  D2_HIP(hipMemsetAsync(s->scr_fdesc.p, 0xFF, (size_t)cap * sizeof(AdDesc), s->stream));   // dest = -1: nothing to do
+  s->D.ad_foff = s->scr_foff.p; s->D.ad_desc = s->scr_fdesc.p; s->D.ad_fcap = (int32_t)cap; s->D.ad_fstride = stride;
 }
 struct AdRingGuard {
   dada2hip_sample *s;
   ~AdRingGuard() {
     if (!s->D.ad_ptr) return;
     if (std::uncaught_exceptions() == 0) (void)hipStreamSynchronize(s->stream);   // (no launch that uses it is left in the stream)
-    s->scr_ad.free();
-    s->D.ad_ptr = nullptr;
+    s->scr_ad.free(); s->scr_foff.free(); s->scr_fdesc.free();
+    s->D.ad_ptr = nullptr; s->D.ad_foff = nullptr; s->D.ad_desc = nullptr; s->D.ad_fcap = 0;
   }
 };
 

@@ -61,7 +61,15 @@ struct SampleDev {
   uint32_t *ad_ptr = nullptr;
   int32_t ad_waves = 0;       // wave slots (a multiple of 4)
   int32_t ad_wpw = 0;         // words per wave slot = 64 * ceil((2 * maxlen + 1) / 16)
+  // lambda of k_nw_ad's alignments is multiplied up by a kernel of its own, one LANE per alignment (k_ad_product): the aligner
+  // leaves each alignment's per-position factor offsets (u16 byte offsets into err) in row `id` of ad_foff and a descriptor
+  // (where lambda goes, how many positions) in ad_desc[id]; id = the alignment's work slot in the launch, < ad_fcap
+  uint16_t *ad_foff = nullptr;
+  struct AdDesc *ad_desc = nullptr;
+  int32_t ad_fcap = 0, ad_fstride = 0;
 };
+
+struct AdDesc { long long dest; int32_t L2, pad; };   // dest < 0: nothing to do (consumed / never written)
 
 struct AlignParams {
   int32_t match, mismatch, gap, band, sentinel;

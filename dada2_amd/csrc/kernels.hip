@@ -1192,6 +1192,24 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     //      fetched straight from the LDS copy of err through the offsets the expansion left: eight offsets per two 16-byte reads,
     //      the next eight factors on their way while the current eight are multiplied (the product itself stays strictly
     //      sequential) ---------
+    // Since round 4 the product normally runs in k_ad_product, 64 alignments to a wave: here it kept ONE lane of a wave busy
+    // for 2.5 instructions per position - a sixth of the launch's issued wave-instructions on an issue-bound kernel.  The
+    // group copies its offsets out (u16, coalesced) and leaves a descriptor; alignments past the buffer's capacity are still
+    // multiplied up here.
+    const long long fid = ((long long)it * 4 + wib) * APW + al;
+    const bool offload = S.ad_foff != nullptr && fid < (long long)S.ad_fcap && !(dbg & 8);
+    if (offload) {
+      if (active && !ghost) {
+        uint16_t *fo = S.ad_foff + (size_t)fid * S.ad_fstride;
+        for (int pj = g; pj < L2; pj += GL) fo[pj] = (uint16_t)rwd[pj];
+        if (g == 0) {
+          AdDesc d;
+          d.dest = (long long)(out_off + r); d.L2 = L2; d.pad = 0;
+          S.ad_desc[fid] = d;
+          a.ham[out_off + r] = h;
+        }
+      }
+    } else
     if (g == 0 && active && !(dbg & 8)) {
       const char *eb = (const char *)s_err;
       auto fetch8 = [&](int pj, double (&f)[8]) __attribute__((always_inline)) {
@@ -1219,6 +1237,41 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       a.lam[out_off + r] = l;
       a.ham[out_off + r] = h;
     }
+  }
+}
+
+// lambda = the sequential product of the per-position error-model factors in raw-position order (pval.cpp:188-192) for the
+// alignments k_nw_ad left offsets and a descriptor for: ONE LANE per alignment (the product of one alignment cannot be split -
+// fp64 multiplication is not associative and the reference's order is part of the result - but 64 alignments multiply side by
+// side), eight offsets per 16-byte load, the factors from the LDS copy of err.  A descriptor is consumed (dest = -1) so that
+// the slots a later, smaller launch does not write are not multiplied again.
+__global__ __launch_bounds__(256) void k_ad_product(const uint16_t *__restrict__ foff, int stride, AdDesc *__restrict__ desc, int nscan,
+                                                    const double *__restrict__ err, int nerr, double *__restrict__ lam,
+                                                    const int32_t *__restrict__ stop_dev, const int32_t *__restrict__ batch_on) {
+  extern __shared__ double s_err[];
+  if (stop_dev && *stop_dev != 0) return;
+  if (batch_on && *batch_on <= 0) return;
+  for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = err[i];
+  __syncthreads();
+  const char *eb = (const char *)s_err;
+  for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < nscan; id += gridDim.x * blockDim.x) {
+    const AdDesc d = desc[id];
+    if (d.dest < 0) continue;
+    desc[id].dest = -1;
+    const uint16_t *row = foff + (size_t)id * stride;
+    double l = 1.0;
+    int pj = 0;
+    for (; pj + 8 <= d.L2; pj += 8) {
+      const uint4 o = *(const uint4 *)(row + pj);
+      const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+      double f[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { f[2 * k] = *(const double *)(eb + (w[k] & 0xFFFFu)); f[2 * k + 1] = *(const double *)(eb + (w[k] >> 16)); }
+#pragma unroll
+      for (int k = 0; k < 8; k++) l = l * f[k];
+    }
+    for (; pj < d.L2; pj++) l = l * *(const double *)(eb + row[pj]);
+    lam[d.dest] = l;
   }
 }
 
@@ -1268,6 +1321,14 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   else D2_LAUNCH_AD2(64);
 #undef D2_LAUNCH_AD2
 #undef D2_LAUNCH_AD
+  if (S.ad_foff && a.moves_stride == 0) {   // the products of what the launch aligned (its work slots: ids below the bound)
+    const int nerr = 16 * ap.ncol;
+    long long bound = batch ? (long long)S.ad_fcap : (long long)((maxwork + (d_gl_work ? S.N : 0) + 4 * G.APW - 1) / (4 * G.APW) + 1) * 4 * G.APW;
+    const int nscan = (int)std::min<long long>(bound, S.ad_fcap);
+    const int pgrid = std::max(1, std::min((nscan + 255) / 256, 2048));
+    hipLaunchKernelGGL(k_ad_product, dim3(pgrid), dim3(256), (size_t)nerr * 8, st, (const uint16_t *)S.ad_foff, (int)S.ad_fstride, S.ad_desc, nscan, d_err, nerr,
+                       d_lambda, d_stop_dev, batch ? batch->on : nullptr);
+  }
 }
 
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
