@@ -1247,10 +1247,18 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 // the slots a later, smaller launch does not write are not multiplied again.
 __global__ __launch_bounds__(256) void k_ad_product(const uint16_t *__restrict__ foff, int stride, AdDesc *__restrict__ desc, int nscan,
                                                     const double *__restrict__ err, int nerr, double *__restrict__ lam,
-                                                    const int32_t *__restrict__ stop_dev, const int32_t *__restrict__ batch_on) {
+                                                    const int32_t *__restrict__ stop_dev, const int32_t *__restrict__ batch_on,
+                                                    const int32_t *__restrict__ batch_n, int slots_per_slice) {
   extern __shared__ double s_err[];
   if (stop_dev && *stop_dev != 0) return;
-  if (batch_on && *batch_on <= 0) return;
+  if (batch_on) {   // batch mode: the launch's work slots are known on the device only (the lists' lengths, as k_nw_ad counts them)
+    const int nb = *batch_on;
+    if (nb <= 0) return;
+    int slices = 0;
+    for (int k = 0; k < KB_MAX; k++) slices += k < nb ? (batch_n[k] + slots_per_slice - 1) / slots_per_slice : 0;
+    nscan = min(nscan, slices * slots_per_slice);
+  }
+  if ((int)(blockIdx.x * blockDim.x) >= nscan) return;
   for (int i = threadIdx.x; i < nerr; i += blockDim.x) s_err[i] = err[i];
   __syncthreads();
   const char *eb = (const char *)s_err;
@@ -1327,7 +1335,7 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
     const int nscan = (int)std::min<long long>(bound, S.ad_fcap);
     const int pgrid = std::max(1, std::min((nscan + 255) / 256, 2048));
     hipLaunchKernelGGL(k_ad_product, dim3(pgrid), dim3(256), (size_t)nerr * 8, st, (const uint16_t *)S.ad_foff, (int)S.ad_fstride, S.ad_desc, nscan, d_err, nerr,
-                       d_lambda, d_stop_dev, batch ? batch->on : nullptr);
+                       d_lambda, d_stop_dev, batch ? batch->on : nullptr, batch ? batch->n : nullptr, 4 * G.APW);
   }
 }
 
