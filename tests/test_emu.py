@@ -61,7 +61,7 @@ def run_cases(emu_lib, names, env=None, timeout=900):
                               "tail-grid2-ring1-nbuf1-grow", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
                               "chains-commit-nbuf1-chain1-grow"])
 def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
-    out = run_cases(emu_lib, ("sam1F_default", "sam1R_default"), env)
+    out = run_cases(emu_lib, ("sam1F_default", "sam1R_default") if not env else ("sam1F_default",), env)   # (CPU suite budget: both only once)
     assert "ok sam1F_default 10 " in out
 
 
@@ -128,7 +128,8 @@ def test_emulated_option_sweep_with_user_scores_and_sse1(emu_lib, nw_kernel):
     """tests/helpers.py's seeded option sweep through the emulated library on each aligner family - including MATCH / MISMATCH /
     GAP_PENALTY away from 5 / -4 / -8 (the general-score instances of k_nw_ad) and SSE = 1."""
     from helpers import BASE_OPTION_CASES, SCORE_OPTION_CASES
-    _seeded_through_emulator(emu_lib, BASE_OPTION_CASES + SCORE_OPTION_CASES, {"DADA2HIP_NW_KERNEL": nw_kernel})
+    cases = (BASE_OPTION_CASES if nw_kernel == "coop" else []) + SCORE_OPTION_CASES   # (the base sweep once; the -m gpu tests run it on every family)
+    _seeded_through_emulator(emu_lib, cases, {"DADA2HIP_NW_KERNEL": nw_kernel})
 
 
 def test_emulated_band_geometries(emu_lib):
