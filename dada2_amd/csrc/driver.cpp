@@ -415,6 +415,7 @@ void ensure_ad_ring(dada2hip_sample *s) {
   const int stride = (s->D.maxlen + 7) & ~7;
   long long cap = std::min<long long>(1ll << 20, ((long long)1 << 30) / (2ll * stride));
   cap = std::min<long long>(cap, 8ll * s->D.N + 512);
+  if (const char *e = getenv("DADA2HIP_AD_FCAP")) cap = std::max<long long>(1, std::min<long long>(cap, atoll(e)));   // test knob: the in-kernel product for what does not fit
   s->scr_foff.alloc((size_t)cap * stride);
   s->scr_fdesc.alloc((size_t)cap);
   D2_HIP(hipMemsetAsync(s->scr_fdesc.p, 0xFF, (size_t)cap * sizeof(AdDesc), s->stream));   // dest = -1: nothing to do

@@ -51,7 +51,8 @@ def run_cases(emu_lib, names, env=None, timeout=900):
                                  # the persistent round tail (k3_tail) with several co-resident blocks, with mover lists that do not
                                  # fit the result block (pause), with a host that lags (ring limit), growing its buffers
                                  {"DADA2HIP_V3_GRID": "3"}, {"DADA2HIP_V3_GRID": "5", "DADA2HIP_V2_MOV_INLINE": "8"},
-                                 {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V3_RING": "1", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_NODE_CAP": "1"},
+                                 {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V3_RING": "1", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_NODE_CAP": "1",
+                                  "DADA2HIP_AD_FCAP": "40"},   # (+ a product buffer of 40 rows: the rest is multiplied up inside k_nw_ad)
                                  # the launch chains (DADA2HIP_V2_TAIL=chain: what a second sample on the same device runs on)
                                  {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_ALIGN": "commit"},
                                  {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_MOV_INLINE": "8"},

@@ -225,7 +225,15 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V2_ALIGN": "commit"},                      # each centre's pairs aligned when its round commits (the long-read mode)
     {"DADA2HIP_V2_LITE": "0"},                            # every chain carries the batch compare's launches (no H2_NEED_COMPARE)
     {"DADA2HIP_V2_GRAPH": "1", "DADA2HIP_V2_NBUF": "2"},  # hipGraph replay of both chain forms, frequent evictions
-], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph"])
+    # round 4: the persistent tail is the default above; here with several blocks on small samples, with pauses (movers that
+    # do not fit the result block), a lagging host (ring limit), a tiny product buffer (in-kernel lambda for the overflow) -
+    # and the launch chains, which the settings above that name chain knobs no longer reach by themselves
+    {"DADA2HIP_V3_GRID": "7", "DADA2HIP_V2_MOV_INLINE": "64", "DADA2HIP_V3_RING": "2", "DADA2HIP_AD_FCAP": "1000"},
+    {"DADA2HIP_V2_TAIL": "chain"},
+    {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_CHAIN": "1", "DADA2HIP_V2_MOV_INLINE": "64"},
+    {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_ALIGN": "commit"},
+], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph",
+        "tail-grid7-pauses-ring2-fcap", "chains", "chains-chain1-biglists", "chains-nolite-commit"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
     20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""
