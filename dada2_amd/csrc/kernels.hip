@@ -1064,11 +1064,6 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     // ---- traceback (first lane of each group) in chunks of <= AD_RCAP merged runs, expanded by all lanes into one
     //      transition code per raw position.  Run: pj_lo (12 b) | n (12 b) << 12 | (delta + 128) << 24, delta = pi - pj;
     //      255 << 24 = gap in the centre (self transition).
-    // lambda's product normally runs in k_ad_product (below): the expansion then writes a position's factor offset straight into
-    // the alignment's row of the global buffer instead of over its staged base
-    const long long fid = ((long long)it * 4 + wib) * APW + al;
-    const bool offload = S.ad_foff != nullptr && fid < (long long)S.ad_fcap && !(dbg & 8);
-    uint16_t *fo = offload ? S.ad_foff + (size_t)fid * S.ad_fstride : nullptr;
     int ti = L1, tj = L2;
     bool done = !active || (dbg & 2);
     uint32_t h = 0;
@@ -1170,12 +1165,9 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         if (ri < nruns && !ghost && !(dbg & 4)) {
           const uint32_t dsc = runs[ri];
           const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
-          int pj = lo + g;
-          uint32_t qnext = (a.ap.use_quals && pj < lo + n) ? qrow[pj] : 0u;     // (the next position's quality is on its way while this one is worked on)
-          for (; pj < lo + n; pj += GL) {
+          for (int pj = lo + g; pj < lo + n; pj += GL) {
             const uint32_t rb = (uint32_t)__builtin_ctz(rwd[pj]) >> 3;   // base code back from its word 9 << (8 * code)
-            const uint32_t q = qnext;
-            if (a.ap.use_quals && pj + GL < lo + n) qnext = qrow[pj + GL];
+            const uint32_t q = a.ap.use_quals ? qrow[pj] : 0u;
             uint32_t tc = 5u * rb;
             if (dl != 255) {
               const uint32_t cb = (uint32_t)__builtin_ctz(cwd[pj + dl - 128]) >> 3;
@@ -1184,9 +1176,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
               if (a.view && active)
                 a.view[vr * a.LV + pj + dl - 128] = (uint16_t)(0x8000u | (rb << 8) | q);
             }
-            const uint32_t off = (tc * (uint32_t)a.ap.ncol + q) << 3;   // &err[t(pj)][q(pj)] - err, in bytes
-            if (offload) fo[pj] = (uint16_t)off;               // ... for k_ad_product
-            else rwd[pj] = off;                                // ... or in place of the base (each position is in ONE run): the product below
+            rwd[pj] = (tc * (uint32_t)a.ap.ncol + q) << 3;   // &err[t(pj)][q(pj)] - err, in bytes: replaces the base (each position is in ONE run)
           }
         }
       }
@@ -1204,10 +1194,14 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     //      sequential) ---------
     // Since round 4 the product normally runs in k_ad_product, 64 alignments to a wave: here it kept ONE lane of a wave busy
     // for 2.5 instructions per position - a sixth of the launch's issued wave-instructions on an issue-bound kernel.  The
-    // expansion wrote the offsets into the alignment's row (u16, coalesced); here only the descriptor.  Alignments past the
-    // buffer's capacity are still multiplied up here.
+    // group copies its offsets out (u16, coalesced) and leaves a descriptor; alignments past the buffer's capacity are still
+    // multiplied up here.
+    const long long fid = ((long long)it * 4 + wib) * APW + al;
+    const bool offload = S.ad_foff != nullptr && fid < (long long)S.ad_fcap && !(dbg & 8);
     if (offload) {
       if (active && !ghost) {
+        uint16_t *fo = S.ad_foff + (size_t)fid * S.ad_fstride;
+        for (int pj = g; pj < L2; pj += GL) fo[pj] = (uint16_t)rwd[pj];
         if (g == 0) {
           AdDesc d;
           d.dest = (long long)(out_off + r); d.L2 = L2; d.pad = 0;
