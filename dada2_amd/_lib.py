@@ -65,7 +65,7 @@ EXPORTS = [
     "dada2hip_result_bs_clust", "dada2hip_result_subqual", "dada2hip_result_clusterquals", "dada2hip_result_map",
     "dada2hip_result_pval", "dada2hip_result_stats", "dada2hip_result_free", "dada2hip_nwalign", "dada2hip_nwvec",
     "dada2hip_sample_compare", "dada2hip_calc_pA", "dada2hip_version", "dada2hip_run_multi", "dada2hip_trim_cache",
-    "dada2hip_table_bimera2", "dada2hip_is_bimera", "dada2hip_derep_fastq", "dada2hip_derep_nuniques",
+    "dada2hip_table_bimera2", "dada2hip_is_bimera", "dada2hip_bimera_pairs", "dada2hip_derep_fastq", "dada2hip_derep_nuniques",
     "dada2hip_derep_nreads", "dada2hip_derep_maxlen", "dada2hip_derep_seqs", "dada2hip_derep_abundances",
     "dada2hip_derep_quals", "dada2hip_derep_map", "dada2hip_derep_free", "dada2hip_sample_from_derep",
     "dada2hip_merge_pairs", "dada2hip_mergers_nrow", "dada2hip_mergers_sequence", "dada2hip_mergers_abundance",
@@ -185,6 +185,7 @@ def lib():
                                      C.c_size_t]
     L.dada2hip_table_bimera2.argtypes = [ip, ip, vp, C.POINTER(cp), C.c_double, ip, ip, ip, ip, ip, ip, ip, ip, vp, vp, cp, C.c_size_t]
     L.dada2hip_is_bimera.argtypes = [cp, ip, C.POINTER(cp), ip, ip, ip, ip, ip, ip, ip, C.POINTER(ip), cp, C.c_size_t]
+    L.dada2hip_bimera_pairs.argtypes = [ip, C.POINTER(cp), C.POINTER(cp), ip, ip, ip, ip, ip, ip, C.c_void_p, cp, C.c_size_t]
     L.dada2hip_derep_fastq.argtypes = [cp, C.c_int64, ip, C.POINTER(vp), cp, C.c_size_t]
     for name, rt in (("nuniques", ip), ("nreads", C.c_int64), ("maxlen", ip), ("seqs", C.POINTER(cp)),
                      ("abundances", C.POINTER(C.c_int32)), ("quals", C.POINTER(C.c_double)), ("map", C.POINTER(C.c_int32))):

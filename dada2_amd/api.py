@@ -383,6 +383,22 @@ def is_bimera(sq, parents, allow_one_off=False, min_one_off_par_dist=4, match=5,
     return bool(out.value)
 
 
+def bimera_pairs(queries, parents, allow_one_off=False, match=5, mismatch=-4, gap_p=-8, max_shift=16, device: int = 0):
+    """get_lr / get_ham_endsfree (src/chimera.cpp:211-293) of each (query, parent) alignment: int32 [n, 5] =
+    left, right, left_oo, right_oo, hamming - what C_is_bimera / C_table_bimera2 reduce to a flag."""
+    L = _lib.lib()
+    n = len(queries)
+    if n != len(parents):
+        raise ValueError("queries and parents must have the same length")
+    qa = (C.c_char_p * max(n, 1))(*[s.encode("ascii") for s in queries])
+    pa = (C.c_char_p * max(n, 1))(*[s.encode("ascii") for s in parents])
+    out = np.zeros((n, 5), dtype=np.int32)
+    eb = C.create_string_buffer(_EB)
+    _lib.check(L.dada2hip_bimera_pairs(n, qa, pa, int(allow_one_off), match, mismatch, gap_p, int(max_shift), device,
+                                       out.ctypes.data, eb, _EB), eb)
+    return out
+
+
 def is_bimera_denovo_table(mat, seqs, min_sample_fraction=0.9, ignore_n_negatives=1, **kw):
     """isBimeraDenovoTable (R/chimeras.R:220-247): the consensus decision over samples on top of C_table_bimera2."""
     nflag, nsam = table_bimera2(mat, seqs, **kw)

@@ -2715,6 +2715,9 @@ struct BimPair { int32_t left, right, left_oo, right_oo, ham; };
 // get_lr / get_ham_endsfree results.  parents[j] lists the k's (ascending); res[j][t] belongs to parents[j][t].
 void bimera_pairs(int ncol, const char *const *seqs, const std::vector<std::vector<int32_t>> &parents, int match, int mismatch,
                   int gap_p, int max_shift, int allow_one_off, int device, std::vector<std::vector<BimPair>> &res) {
+  static const bool times = [] { const char *e = getenv("DADA2HIP_BIMERA_TIMES"); return e && !strcmp(e, "1"); }();
+  auto t0 = clk::now();
+  double ms_dev = 0, ms_unpack = 0, ms_pack = 0;
   res.assign(ncol, {});
   size_t npairs = 0;
   for (int j = 0; j < ncol; j++) { res[j].resize(parents[j].size()); npairs += parents[j].size(); }
@@ -2728,7 +2731,6 @@ void bimera_pairs(int ncol, const char *const *seqs, const std::vector<std::vect
   std::unique_ptr<dada2hip_sample, void (*)(dada2hip_sample *)> guard(s, dada2hip_sample_free);
   sample_create(s, ncol, seqs, ab.data(), nullptr, nullptr, 0, device, /*lite=*/true);
   if (max_shift == 0) throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: maxShift 0 is outside the implemented path."};
-  ensure_scratch(s, max_shift);
   std::vector<double> errm(16, 1.0), rowm;
   upload_err(s, errm.data(), 1, rowm);
   dada2hip_opts o;
@@ -2737,50 +2739,88 @@ void bimera_pairs(int ncol, const char *const *seqs, const std::vector<std::vect
   AlignParams ap{match, mismatch, gap_p, max_shift, nw_sentinel(o), 0, 1};
   ap.homo_gap = gap_p;   // (plain ends-free alignment: chimera.cpp:26,122 call nwalign_vectorized2 / nwalign_endsfree)
   const int stride = 2 * s->D.maxlen + 2;
-  // batches of whole queries, each query's parents padded to the lane kernel's 64-alignment chunks
-  const size_t budget_slots = std::max<size_t>(4096, ((size_t)256 << 20) / (size_t)stride);
+  // The aligner: the anti-diagonal kernel of the denoising path in its bimera mode (k_nw_ad<.., LR>: the alignment is reduced
+  // to get_lr / get_ham_endsfree inside the kernel, nothing but five words per pair leaves it) wherever its geometry applies
+  // (reads <= 2 047 nt, band window <= 127 cells); otherwise - and under DADA2HIP_NW_KERNEL=lane|wide, the tests' way of
+  // running both - the lane kernel with its move strings kept and k_bimera_lr behind it.
+  const bool coop = [&] {
+    const char *f = getenv("DADA2HIP_NW_KERNEL");
+    if (f && (!strcmp(f, "lane") || !strcmp(f, "wide"))) return false;
+    const size_t b = nw_ad_lr_lds_bytes(s->D, ap);
+    return b > 0 && b <= 150 * 1024;
+  }();
+  AdRingGuard ring{s};
+  if (coop) ensure_ad_ring(s);
+  else ensure_scratch(s, max_shift);
+  // batches of whole queries, each query's parents padded to the kernel's chunks (alignments that share their query)
+  const size_t per = coop ? (size_t)nw_ad_apw(s->D, ap) : 64;
+  const size_t budget_slots = coop ? ((size_t)1 << 23) : std::max<size_t>(4096, ((size_t)256 << 20) / (size_t)stride);
   s->d_lambda.alloc(ncol); s->d_ham.alloc(ncol);
   DevBuf<int32_t> d_out;
-  std::vector<int32_t> work, cc, h_out;
+  PinBuf<int32_t> h_out;
+  std::vector<int32_t> work, cc;
   std::vector<std::pair<int, size_t>> where;   // (query, first slot) of the batch
   hipStream_t stq = s->stream;
-  int j = 0;
+  const double ms_setup = ms_since(t0);
+  int j = 0, nbatch = 0;
   while (j < ncol) {
-    work.clear(); cc.clear(); where.clear();
-    while (j < ncol && (work.empty() || work.size() + parents[j].size() + 64 <= budget_slots)) {
+    auto tb = clk::now();
+    // the batch's queries and their first slots, then the lists filled by the host pool (4.4 M slots at 3 000 sequences)
+    where.clear();
+    size_t nslots = 0;
+    while (j < ncol && (nslots == 0 || nslots + parents[j].size() + per <= budget_slots)) {
       if (!parents[j].empty()) {
-        where.push_back({j, work.size()});
-        for (size_t t = 0; t < parents[j].size(); t++) {
-          if (t % 64 == 0) cc.push_back(j);
-          work.push_back(parents[j][t]);
-        }
-        while (work.size() % 64) work.push_back(-1);
+        where.push_back({j, nslots});
+        nslots += (parents[j].size() + per - 1) / per * per;
       }
       j++;
     }
+    work.resize(nslots); cc.resize(nslots / per);
+    parallel_for(where.size(), 16, [&](size_t lo, size_t hi) {
+      for (size_t w = lo; w < hi; w++) {
+        const int q = where[w].first;
+        const size_t first = where[w].second, np = parents[q].size(), padded = (np + per - 1) / per * per;
+        memcpy(&work[first], parents[q].data(), np * sizeof(int32_t));
+        for (size_t t = np; t < padded; t++) work[first + t] = -1;
+        for (size_t c = 0; c < padded / per; c++) cc[first / per + c] = q;
+      }
+    });
     if (work.empty()) continue;
     const int nwork = (int)work.size();
-    s->d_work.alloc(work.size()); s->d_chunk_centre.alloc(cc.size()); s->d_moves.alloc(work.size() * (size_t)stride);
-    s->d_nmoves.alloc(work.size()); d_out.alloc(work.size() * 5);
+    nbatch++;
+    ms_pack += ms_since(tb); tb = clk::now();
+    s->d_work.alloc(work.size()); s->d_chunk_centre.alloc(cc.size()); d_out.alloc(work.size() * 5);
+    h_out.alloc(work.size() * 5);
     D2_HIP(hipMemcpyAsync(s->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, stq));
     D2_HIP(hipMemcpyAsync(s->d_chunk_centre.p, cc.data(), cc.size() * 4, hipMemcpyHostToDevice, stq));
-    launch_nw(s->D, s->scr_class, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, nwork, ap, s->d_err.p, s->scr, s->d_lambda.p, s->d_ham.p,
-              nullptr, 0, 0, s->d_moves.p, stride, s->d_nmoves.p, stq);
-    launch_bimera_lr(s->D, s->d_chunk_centre.p, s->d_work.p, nwork, s->d_moves.p, stride, s->d_nmoves.p, allow_one_off, max_shift,
-                     d_out.p, stq);
-    h_out.resize(work.size() * 5);
-    D2_HIP(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * 4, hipMemcpyDeviceToHost, stq));
+    if (coop)
+      launch_nw_ad_lr(s->D, s->d_chunk_centre.p, s->d_work.p, nwork, ap, s->d_err.p, allow_one_off, max_shift, d_out.p, stq);
+    else {
+      s->d_moves.alloc(work.size() * (size_t)stride); s->d_nmoves.alloc(work.size());
+      launch_nw(s->D, s->scr_class, 0, s->d_chunk_centre.p, s->d_work.p, nullptr, nwork, ap, s->d_err.p, s->scr, s->d_lambda.p, s->d_ham.p,
+                nullptr, 0, 0, s->d_moves.p, stride, s->d_nmoves.p, stq);
+      launch_bimera_lr(s->D, s->d_chunk_centre.p, s->d_work.p, nwork, s->d_moves.p, stride, s->d_nmoves.p, allow_one_off, max_shift,
+                       d_out.p, stq);
+    }
+    D2_HIP(hipMemcpyAsync(h_out.p, d_out.p, work.size() * 5 * 4, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
     D2_HIP(hipGetLastError());
     check_nw_flag(s);
-    for (auto &w : where) {
-      const int q = w.first;
-      for (size_t t = 0; t < parents[q].size(); t++) {
-        const int32_t *o5 = &h_out[(w.second + t) * 5];
-        res[q][t] = BimPair{o5[0], o5[1], o5[2], o5[3], o5[4]};
+    ms_dev += ms_since(tb); tb = clk::now();
+    parallel_for(where.size(), 16, [&](size_t lo, size_t hi) {
+      for (size_t w = lo; w < hi; w++) {
+        const int q = where[w].first;
+        for (size_t t = 0; t < parents[q].size(); t++) {
+          const int32_t *o5 = h_out.p + (where[w].second + t) * 5;
+          res[q][t] = BimPair{o5[0], o5[1], o5[2], o5[3], o5[4]};
+        }
       }
-    }
+    });
+    ms_unpack += ms_since(tb);
   }
+  if (times)
+    fprintf(stderr, "[bimera] pairs %zu in %d batches (%s): setup %.1f ms, work lists %.1f ms, device (alloc + H2D + kernels + D2H) %.1f ms, unpack %.1f ms\n",
+            npairs, nbatch, coop ? "k_nw_ad, bimera mode" : "k_nw + k_bimera_lr", ms_setup, ms_pack, ms_dev, ms_unpack);
 }
 }  // namespace
 
@@ -2794,6 +2834,8 @@ int dada2hip_table_bimera2(int32_t nrow, int32_t ncol, const int32_t *mat, const
     select_device(device);
     // which (query, parent) pairs does the table ask for?  (chimera.cpp:117-118: a parent is more abundant than the query
     // by min_fold and at least min_abund in some sample where the query is present)
+    static const bool times = [] { const char *e = getenv("DADA2HIP_BIMERA_TIMES"); return e && !strcmp(e, "1"); }();
+    auto t0 = clk::now();
     std::vector<std::vector<int32_t>> parents(ncol);
     parallel_for((size_t)ncol, 8, [&](size_t lo, size_t hi) {
       std::vector<uint8_t> need(ncol);
@@ -2810,8 +2852,12 @@ int dada2hip_table_bimera2(int32_t nrow, int32_t ncol, const int32_t *mat, const
         for (int k = 0; k < ncol; k++) if (need[k]) parents[j].push_back(k);
       }
     });
+    const double ms_parents = ms_since(t0);
+    auto t1 = clk::now();
     std::vector<std::vector<BimPair>> res;
     bimera_pairs(ncol, seqs, parents, match, mismatch, gap_p, max_shift, allow_one_off, device, res);
+    const double ms_pairs = ms_since(t1);
+    t1 = clk::now();
     // per sequence and sample: is there a two-parent model?  (chimera.cpp:103-161)
     parallel_for((size_t)ncol, 8, [&](size_t lo, size_t hi) {
       std::vector<int32_t> lefts(ncol), rights(ncol), lefts_oo(ncol), rights_oo(ncol);
@@ -2848,6 +2894,7 @@ int dada2hip_table_bimera2(int32_t nrow, int32_t ncol, const int32_t *mat, const
         nflag[j] = nf; nsam[j] = ns;
       }
     });
+    if (times) fprintf(stderr, "[bimera] table %d x %d: parent lists %.1f ms, pairs %.1f ms, flags %.1f ms\n", nrow, ncol, ms_parents, ms_pairs, ms_since(t1));
   });
 }
 
@@ -2880,6 +2927,31 @@ int dada2hip_is_bimera(const char *sq, int32_t npars, const char *const *pars, i
     }
     if (max_right + max_left >= sqlen) *out = 1;
     if (allow_one_off && (oml + omro >= sqlen || omlo + omr >= sqlen)) *out = 1;
+  });
+}
+
+// get_lr / get_ham_endsfree (chimera.cpp:211-293) of n (query, parent) alignments: what C_is_bimera / C_table_bimera2 look at
+int dada2hip_bimera_pairs(int32_t n, const char *const *queries, const char *const *parents, int32_t allow_one_off, int32_t match,
+                          int32_t mismatch, int32_t gap_p, int32_t max_shift, int32_t device, int32_t *out, char *errbuf,
+                          size_t errlen) {
+  return guarded(errbuf, errlen, [&] {
+    if (n < 0 || (n > 0 && (!queries || !parents || !out))) throw InputError{"dada2hip: bad arguments"};
+    if (n == 0) return;
+    select_device(device);
+    std::vector<const char *> seqs(2 * (size_t)n);
+    std::vector<std::vector<int32_t>> par(2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+      if (!queries[i] || !parents[i]) throw InputError{"dada2hip: bad arguments"};
+      seqs[2 * i] = queries[i]; seqs[2 * i + 1] = parents[i];
+      par[2 * i].push_back(2 * i + 1);
+    }
+    std::vector<std::vector<BimPair>> res;
+    bimera_pairs(2 * n, seqs.data(), par, match, mismatch, gap_p, max_shift, allow_one_off, device, res);
+    for (int i = 0; i < n; i++) {
+      const BimPair &b = res[2 * i][0];
+      int32_t *o = out + 5 * (size_t)i;
+      o[0] = b.left; o[1] = b.right; o[2] = b.left_oo; o[3] = b.right_oo; o[4] = b.ham;
+    }
   });
 }
 

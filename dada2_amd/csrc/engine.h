@@ -226,6 +226,10 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
                   const NwBatch *batch = nullptr);
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap);
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap);
+// bimera mode (chimera.cpp): pairs (query = chunk centre, parent = work item) reduced in the kernel to get_lr / get_ham_endsfree
+void launch_nw_ad_lr(const SampleDev &S, const int32_t *d_chunk_centre, const int32_t *d_work, int nwork, const AlignParams &ap,
+                     const double *d_err, int allow_one_off, int max_shift, int32_t *d_out, hipStream_t st);
+size_t nw_ad_lr_lds_bytes(const SampleDev &S, const AlignParams &ap);
 
 // wide-band / long-read anti-diagonal kernel (8 band cells per lane, pointers in an HBM ring of `scr_waves` wave slots)
 bool nw_adw_ok(const SampleDev &S, const AlignParams &ap);

@@ -449,6 +449,8 @@ struct NwArgs {
   int moves_stride;
   int32_t *nmoves;
   const int32_t *stop_dev;     // round engine v2: non-zero = the device has halted, nothing to do
+  int32_t *lr_out;             // bimera mode of k_nw_ad: five words per work slot (left, right, left_oo, right_oo, hamming)
+  int lr_one_off, lr_max_shift;
   // round engine v2, batch mode (k_nw_ad only): the alignments of a whole batch compare - up to KB_MAX centres - in ONE launch.
   // List k (k < KB_MAX) holds the uniques to align with batch centre k (list KB_MAX + k its gapless ones: k_gapless_batch);
   // blocks work on one centre at a time (it is staged once per block), results go to row (bbuf * KB_MAX + k) of lam / ham.
@@ -862,12 +864,13 @@ struct AdGeom {
   int per_al_bytes, per_wave_bytes;   // per_wave_bytes includes the wave's own centre words unless shared_c
   int shared_c;             // the launch has one centre for all its work (no per-chunk centres): staged once per block
   int block_bytes;          // LDS behind the err table
+  int bmw;                  // bimera mode (k_nw_ad<.., LR>): words per column bitmap (three of them behind the raw words), else 0
 };
 // Lane g of a group owns cells k' = 2g, 2g+1; an alignment's band cell k sits at k' = k + o.  The origin shift o makes
 // lband + o even, so every alignment of a wave is in phase (even cells live on even steps) whatever its length
 // difference.  When the group has room (W + 4 <= 2 GL) o is 2 or 3: the first two cells and the last cell of every
 // group are then never in band, always hold the sentinel, and the cross-group DPP reads need no masking.
-static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minlen, int shared_c = 0) {
+static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minlen, int shared_c = 0, int lr = 0) {
   AdGeom G;
   const int W = 2 * band + (maxlen - minlen) + 1;
   G.GL = W + 1 <= 42 ? 21 : (W + 1 <= 64 ? 32 : 64);   // 21 lanes x 2 cells cover the default band (W = 33): 3 alignments per wave
@@ -876,14 +879,95 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   G.NCOL = (W + (G.edge ? 1 : 3) + 1) / 2;
   G.nwords = (2 * maxlen + 1 + 15) / 16;
   G.seqwords = (maxlen + 2 * ad_guard(G.GL) + 3) & ~3;
-  G.per_al_bytes = AD_RCAP * 4 + 4 * G.seqwords;
+  G.bmw = lr ? (((2 * maxlen + 2 + 31) / 32 + 3) & ~3) : 0;   // one bit per alignment column (at most 2 maxlen of them)
+  G.per_al_bytes = AD_RCAP * 4 + 4 * G.seqwords + 12 * G.bmw;
   G.shared_c = shared_c;
   G.per_wave_bytes = (shared_c ? 0 : 4 * G.seqwords) + G.APW * G.per_al_bytes;
   G.block_bytes = (shared_c ? 4 * G.seqwords : 0) + 4 * G.per_wave_bytes;
   return G;
 }
 
-template <int GL, bool DEF, bool EDGE>
+// ---- bimera mode of k_nw_ad (chimera.cpp:211-293): the alignment as three bitmaps over its columns, bit t = column t counted
+//      from the END of the alignment (the order the traceback finds them in) ----
+static __device__ __forceinline__ bool bm_bit(const uint32_t *bm, int t) { return ((bm[t >> 5] >> (t & 31)) & 1u) != 0u; }
+// smallest t' in [t, len) whose bit equals `want`, or len
+static __device__ __forceinline__ int bm_next(const uint32_t *bm, int t, int len, bool want) {
+  while (t < len) {
+    uint32_t w = bm[t >> 5];
+    if (!want) w = ~w;
+    w >>= (t & 31);
+    if (w) { const int r = t + __builtin_ctz(w); return r < len ? r : len; }
+    t = (t | 31) + 1;
+  }
+  return len;
+}
+// largest t' in [0, t] whose bit equals `want`, or -1
+static __device__ __forceinline__ int bm_prev(const uint32_t *bm, int t, bool want) {
+  while (t >= 0) {
+    uint32_t w = bm[t >> 5];
+    if (!want) w = ~w;
+    w <<= 31 - (t & 31);
+    if (w) return t - __builtin_clz(w);
+    t = (t & ~31) - 1;
+  }
+  return -1;
+}
+// set bits at lo..hi (inclusive)
+static __device__ __forceinline__ int bm_count(const uint32_t *bm, int lo, int hi) {
+  int n = 0;
+  for (int t = lo; t <= hi;) {
+    uint32_t w = bm[t >> 5] >> (t & 31);
+    const int span = min(32 - (t & 31), hi - t + 1);
+    if (span < 32) w &= (1u << span) - 1u;
+    n += __builtin_popcount(w);
+    t += span;
+  }
+  return n;
+}
+// get_lr (chimera.cpp:243-293) and get_ham_endsfree (:211-239) of one alignment from its bitmaps: NE = the column is not a pair
+// of equal bases, B2 = gap in the query (the chunk's centre), B3 = gap in the parent; len columns.  Forward column c is bit
+// len - 1 - c.  The statement-by-statement form of the same rules is k_bimera_lr below (on move strings).
+static __device__ __forceinline__ void bimera_lr_bits(const uint32_t *NE, const uint32_t *B2, const uint32_t *B3, int len, int one_off,
+                                                      int ms, int32_t *__restrict__ o) {
+  // left: scan in over the columns before the query starts, ends-free until the parent starts, covered until a mismatch
+  int pos = len - 1 - bm_prev(B2, len - 1, false), left = 0;
+  if (pos < ms) {
+    const int p3 = min(len - 1 - bm_prev(B3, len - 1 - pos, false), ms);
+    left = p3 - pos; pos = p3;
+  }
+  { const int pn = len - 1 - bm_prev(NE, len - 1 - pos, true); left += pn - pos; pos = pn; }
+  int left_oo = 0;
+  if (one_off) {
+    left_oo = left;
+    pos++;
+    if (pos < len && !bm_bit(B2, len - 1 - pos)) left_oo++;
+    if (pos < len) left_oo += (len - 1 - bm_prev(NE, len - 1 - pos, true)) - pos;
+  }
+  // right: the same from the end (the reference compares `pos > len - max_shift` in size_t: never true when len < max_shift)
+  int t = bm_next(B2, 0, len, false), right = 0;
+  if (len >= ms && t < ms - 1) {
+    const int t3 = min(bm_next(B3, t, len, false), ms - 1);
+    right = t3 - t; t = t3;
+  }
+  { const int tn = bm_next(NE, t, len, true); right += tn - t; t = tn; }
+  int right_oo = 0;
+  if (one_off) {
+    right_oo = right;
+    t++;
+    if (t < len && !bm_bit(B2, t)) right_oo++;
+    if (t < len) right_oo += bm_next(NE, t, len, true) - t;
+  }
+  // hamming distance between the two end-gap runs
+  int is = 0, ntrail = 0;
+  if (bm_bit(B2, len - 1)) is = len - 1 - bm_prev(B2, len - 1, false);
+  else if (bm_bit(B3, len - 1)) is = len - 1 - bm_prev(B3, len - 1, false);
+  if (bm_bit(B2, 0)) ntrail = bm_next(B2, 0, len, false);
+  else if (bm_bit(B3, 0)) ntrail = bm_next(B3, 0, len, false);
+  o[0] = left; o[1] = right; o[2] = left_oo; o[3] = right_oo;
+  o[4] = len - 1 - is >= ntrail ? bm_count(NE, ntrail, len - 1 - is) : 0;
+}
+
+template <int GL, bool DEF, bool EDGE, bool LR = false>
 __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                AdGeom G) {
   constexpr int APW = 64 / GL;
@@ -924,6 +1008,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   uint32_t *runs = (uint32_t *)abase;
   uint32_t *rwd = (uint32_t *)(abase + AD_RCAP * 4) + ad_guard(GL);      // raw base p, same encoding; after the expansion: byte offset
                                                                         // into s_err of the position's error-model factor
+  uint32_t *bm = (uint32_t *)(abase + AD_RCAP * 4 + 4 * G.seqwords);     // bimera mode: the column bitmaps NE | B2 | B3
   const SampleDev &S = a.S;
   if (G.shared_c && !batch) {                                          // the launch's one centre, staged by the whole block
     const int cv = a.centre_dev ? *a.centre_dev : a.centre;
@@ -984,6 +1069,9 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       for (int p = lane; p < L1; p += 64) cwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);
     if (!ghost)
       for (int p = g; p < L2; p += GL) rwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)r * S.W2, p) << 3);
+    if (LR && !ghost)
+      for (int w = g; w < 3 * G.bmw; w += GL) bm[w] = 0;
+    int ecol = 0;                                          // bimera mode: alignment columns found so far (from the end)
     const uint8_t *qrow = S.qual + (size_t)r * S.LQ;        // the raw's qualities (read where the expansion needs them)
     // aligned view of the unique on its centre (final pass / birth substitutions): centre positions facing a gap stay 0
     const size_t vr = a.view_by_chunk ? (size_t)chunk : (size_t)r;
@@ -1148,7 +1236,10 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
           if (m > GL) m = GL;
           if (m < 1) m = 1;                                // (lane 0 looks at the cell the stretch ended on: never 0)
           if (pq == AD_LEFT) { tj -= m; push(tj, m, 255); }   // from the left: m raw positions facing gaps
-          else ti -= m;                                    // from above (the diagonal code cannot be here)
+          else {                                           // from above (the diagonal code cannot be here)
+            ti -= m;
+            if (LR) push(ti, m, 254);                      // bimera mode: centre positions facing gaps are columns too
+          }
         }
       }
       if (lead && !gapless && active) {
@@ -1165,6 +1256,18 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         if (ri < nruns && !ghost && !(dbg & 4)) {
           const uint32_t dsc = runs[ri];
           const int lo = dsc & 4095, n = (dsc >> 12) & 4095, dl = (int)(dsc >> 24);
+          if (LR) {
+            // bimera mode: one bit per column instead of a factor per raw position.  254 / 255 = gap in the parent / the query
+            for (int p = lo + g; p < lo + n; p += GL) {
+              const int tc = ecol + (lo + n - 1 - p);
+              const uint32_t bit = 1u << (tc & 31);
+              bool ne = true;
+              if (dl < 254) ne = __builtin_ctz(rwd[p]) != __builtin_ctz(cwd[p + dl - 128]);
+              else atomicOr(&bm[(dl == 255 ? 1 : 2) * G.bmw + (tc >> 5)], bit);
+              if (ne) atomicOr(&bm[tc >> 5], bit);
+            }
+            ecol += n;
+          } else
           for (int pj = lo + g; pj < lo + n; pj += GL) {
             const uint32_t rb = (uint32_t)__builtin_ctz(rwd[pj]) >> 3;   // base code back from its word 9 << (8 * code)
             const uint32_t q = a.ap.use_quals ? qrow[pj] : 0u;
@@ -1181,6 +1284,12 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         }
       }
       if (__all(done)) break;
+    }
+    if (LR) {
+      gcn_wave_sync();                                     // every lane's bits are in LDS before one lane reads them
+      if (g == 0 && !ghost && active)
+        bimera_lr_bits(bm, bm + G.bmw, bm + 2 * G.bmw, ecol, a.lr_one_off, a.lr_max_shift, a.lr_out + (size_t)idx * 5);
+      continue;
     }
     // hamming: group sum through LDS (group sizes are not powers of two); the run buffer is free by now
     if (g == 0 && !ghost) runs[0] = 0;
@@ -1337,6 +1446,49 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
     hipLaunchKernelGGL(k_ad_product, dim3(pgrid), dim3(256), (size_t)nerr * 8, st, (const uint16_t *)S.ad_foff, (int)S.ad_fstride, S.ad_desc, nscan, d_err, nerr,
                        d_lambda, d_stop_dev, batch ? batch->on : nullptr, batch ? batch->n : nullptr, 4 * G.APW);
   }
+}
+
+// Bimera mode: the pairs (query = chunk centre, parent = work item; chunks of nw_ad_apw() slots, -1 = empty slot) aligned by
+// k_nw_ad<.., LR> with band = max_shift (chimera.cpp:26,122), each reduced in the kernel to get_lr / get_ham_endsfree:
+// d_out[5 slot .. 5 slot + 4] = left, right, left_oo, right_oo, hamming.  Needs the pointer ring (SampleDev::ad_ptr).
+void launch_nw_ad_lr(const SampleDev &S, const int32_t *d_chunk_centre, const int32_t *d_work, int nwork, const AlignParams &ap,
+                     const double *d_err, int allow_one_off, int max_shift, int32_t *d_out, hipStream_t st) {
+  if (nwork <= 0) return;
+  NwArgs a;
+  memset(&a, 0, sizeof a);
+  a.S = S; a.chunk_centre = d_chunk_centre; a.work = d_work; a.nwork_host = nwork; a.ap = ap; a.err = d_err;
+  a.lr_out = d_out; a.lr_one_off = allow_one_off; a.lr_max_shift = max_shift;
+  const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen, 0, 1);
+  const size_t lds = (size_t)16 * ap.ncol * 8 + (size_t)G.block_bytes;
+  const int waves = (nwork + G.APW - 1) / G.APW;
+  const int grid = std::max(1, std::min((waves + 3) / 4, std::min(256 * 8, S.ad_waves / 4)));   // one slot of the pointer ring per wave
+  const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
+#define D2_LAUNCH_LR(GLV, DEFV, EDGEV)                                                                                   \
+  do {                                                                                                                   \
+    static size_t attr_set[64] = {0};                                                                                    \
+    int dev_ = 0;                                                                                                        \
+    (void)hipGetDevice(&dev_);                                                                                           \
+    if (lds > attr_set[dev_ & 63]) {                                                                                     \
+      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set[dev_ & 63] = lds;                                                                                         \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV, true>), dim3(grid), dim3(256), lds, st, a, (const int32_t *)nullptr,   \
+                       (const int32_t *)nullptr, G);                                                                     \
+  } while (0)
+#define D2_LAUNCH_LR2(GLV)                                                                                               \
+  do {                                                                                                                   \
+    if (def) { if (G.edge) D2_LAUNCH_LR(GLV, true, true); else D2_LAUNCH_LR(GLV, true, false); }                         \
+    else { if (G.edge) D2_LAUNCH_LR(GLV, false, true); else D2_LAUNCH_LR(GLV, false, false); }                           \
+  } while (0)
+  if (G.GL == 21) D2_LAUNCH_LR2(21);
+  else if (G.GL == 32) D2_LAUNCH_LR2(32);
+  else D2_LAUNCH_LR2(64);
+#undef D2_LAUNCH_LR2
+#undef D2_LAUNCH_LR
+}
+size_t nw_ad_lr_lds_bytes(const SampleDev &S, const AlignParams &ap) {
+  if (nw_ad_lds_bytes(S, ap) == 0) return 0;
+  return (size_t)16 * ap.ncol * 8 + (size_t)ad_geom(ap.band, S.maxlen, S.minlen, 0, 1).block_bytes;
 }
 
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.

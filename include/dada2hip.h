@@ -242,6 +242,14 @@ int dada2hip_table_bimera2(int32_t nrow, int32_t ncol, const int32_t *mat, const
 int dada2hip_is_bimera(const char *sq, int32_t npars, const char *const *pars, int32_t allow_one_off,
                        int32_t min_one_off_par_dist, int32_t match, int32_t mismatch, int32_t gap_p, int32_t max_shift,
                        int32_t device, int32_t *out, char *errbuf, size_t errlen);
+/* dada2hip_bimera_pairs: the quantities the two entry points above reduce to a decision, for n (query, parent) pairs:
+ * out[5 i .. 5 i + 4] = left, right, left_oo, right_oo of get_lr (src/chimera.cpp:243-293) and get_ham_endsfree (:211-239) on the
+ * alignment nwalign_vectorized2(query, parent, match, mismatch, gap_p, 0, max_shift) (chimera.cpp:26,122).  The reference keeps
+ * them inside C_is_bimera / BimeraTableParallel; this entry exists so that parity can be checked per alignment and not only
+ * per flagged sequence (tests/, oracle_bimera_pairs). */
+int dada2hip_bimera_pairs(int32_t n, const char *const *queries, const char *const *parents, int32_t allow_one_off,
+                          int32_t match, int32_t mismatch, int32_t gap_p, int32_t max_shift, int32_t device, int32_t *out,
+                          char *errbuf, size_t errlen);
 
 /* ---- dereplication front-end: the step before dada() ----------------------------------------
  * dada2hip_derep_fastq == derepFastq(fl, n = chunk_reads, qualityType = "Auto" | offset) (R/sequenceIO.R:45-124 on top of

@@ -167,6 +167,19 @@ def table_bimera2(mat, seqs, min_fold=1.5, min_abund=2, allow_one_off=False, min
     return nflag, nsam
 
 
+def bimera_pairs(queries, parents, allow_one_off=False, match=5, mismatch=-4, gap_p=-8, max_shift=16):
+    """get_lr / get_ham_endsfree (chimera.cpp:211-293) per (query, parent) pair: int32 [n, 5]."""
+    L = lib()
+    n = len(queries)
+    qa = (C.c_char_p * max(n, 1))(*[s.encode() for s in queries])
+    pa = (C.c_char_p * max(n, 1))(*[s.encode() for s in parents])
+    out = np.zeros((n, 5), dtype=np.int32)
+    L.oracle_bimera_pairs.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.oracle_bimera_pairs.restype = None
+    L.oracle_bimera_pairs(n, qa, pa, int(allow_one_off), match, mismatch, gap_p, int(max_shift), out.ctypes.data)
+    return out
+
+
 def is_bimera(sq, pars, allow_one_off=False, min_one_off_par_dist=4, match=5, mismatch=-4, gap_p=-8, max_shift=16):
     L = lib()
     _bim_args(L)

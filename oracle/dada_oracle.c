@@ -808,6 +808,18 @@ static void bim_pair(const char *q, const char *p, int match, int mismatch, int 
   free(a); free(b); free(al0); free(al1);
 }
 
+/* the per-pair quantities of the two entry points below, for n pairs: out[5 i ..] = left, right, left_oo, right_oo, ham */
+void oracle_bimera_pairs(int n, const char *const *queries, const char *const *parents, int allow_one_off, int match, int mismatch,
+                         int gap_p, int max_shift, int *out)
+{
+  int i;
+  for (i = 0; i < n; i++) {
+    BimPair b;
+    bim_pair(queries[i], parents[i], match, mismatch, gap_p, max_shift, allow_one_off, &b);
+    out[5 * i] = b.left; out[5 * i + 1] = b.right; out[5 * i + 2] = b.left_oo; out[5 * i + 3] = b.right_oo; out[5 * i + 4] = b.ham;
+  }
+}
+
 /* C_is_bimera (chimera.cpp:18-59) */
 int oracle_is_bimera(const char *sq, int npars, const char *const *pars, int allow_one_off, int min_one_off_par_dist, int match,
                      int mismatch, int gap_p, int max_shift)

@@ -199,6 +199,19 @@ def table_bimera2(mat, seqs, min_fold=1.5, min_abund=2, allow_one_off=False, min
     return nflag, nsam
 
 
+def bimera_pairs(queries, parents, allow_one_off=False, match=5, mismatch=-4, gap_p=-8, max_shift=16):
+    """The reference's get_lr / get_ham_endsfree on its own nwalign_vectorized2 alignment (chimera.cpp:26-36): int32 [n, 5]."""
+    L = lib()
+    n = len(queries)
+    qa = (C.c_char_p * max(n, 1))(*[s.encode() for s in queries])
+    pa = (C.c_char_p * max(n, 1))(*[s.encode() for s in parents])
+    out = np.zeros((n, 5), dtype=np.int32)
+    L.ref_bimera_pairs.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    if L.ref_bimera_pairs(n, qa, pa, int(allow_one_off), match, mismatch, gap_p, int(max_shift), out.ctypes.data) != 0:
+        raise RuntimeError("get_lr failed")
+    return out
+
+
 def is_bimera(sq, pars, allow_one_off=False, min_one_off_par_dist=4, match=5, mismatch=-4, gap_p=-8, max_shift=16):
     L = lib()
     L.ref_is_bimera.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -23,6 +23,9 @@ Rcpp::List dada_uniques(std::vector<std::string> seqs, std::vector<int> abundanc
                         int homo_gap, bool multithread, bool verbose, int SSE, bool gapless, bool greedy);
 
 // chimera.cpp:18,192 (the step after dada(): bimera identification on the sequence table)
+// chimera.cpp:7-8 (external linkage): what C_is_bimera reduces an alignment to
+int get_ham_endsfree(const char *seq1, const char *seq2);
+void get_lr(char **al, int &left, int &right, int &left_oo, int &right_oo, bool allow_one_off, int max_shift);
 bool C_is_bimera(std::string sq, std::vector<std::string> pars, bool allow_one_off, int min_one_off_par_dist, int match,
                  int mismatch, int gap_p, int max_shift);
 Rcpp::DataFrame C_table_bimera2(Rcpp::IntegerMatrix mat, std::vector<std::string> seqs, double min_fold, int min_abund,
@@ -282,6 +285,26 @@ int ref_table_bimera2(int nrow, int ncol, const int *mat, const char *const *seq
   } catch (std::exception &e) {
     if (errbuf && errlen > 0) snprintf(errbuf, errlen, "%s", e.what());
     return 1;
+  }
+}
+
+// the reference's own get_lr / get_ham_endsfree (chimera.cpp:243-293, :196-239; external linkage) on its own alignment, as
+// C_is_bimera calls them (chimera.cpp:26-36): out[5 i ..] = left, right, left_oo, right_oo, ham
+int ref_bimera_pairs(int n, const char *const *queries, const char *const *parents, int allow_one_off, int match, int mismatch,
+                     int gap_p, int max_shift, int *out) {
+  try {
+    for (int i = 0; i < n; i++) {
+      char **al = nwalign_vectorized2(queries[i], strlen(queries[i]), parents[i], strlen(parents[i]), (int16_t)match,
+                                      (int16_t)mismatch, (int16_t)gap_p, 0, max_shift);
+      int left = 0, right = 0, left_oo = 0, right_oo = 0;
+      get_lr(al, left, right, left_oo, right_oo, allow_one_off != 0, max_shift);
+      out[5 * i] = left; out[5 * i + 1] = right; out[5 * i + 2] = left_oo; out[5 * i + 3] = right_oo;
+      out[5 * i + 4] = get_ham_endsfree(al[0], al[1]);
+      free(al[0]); free(al[1]); free(al);
+    }
+    return 0;
+  } catch (std::exception &) {
+    return -1;
   }
 }
 

@@ -70,6 +70,32 @@ def test_emulated_long_read_band32_case(emu_lib):
     run_cases(emu_lib, ("samPB_band32",))
 
 
+def test_emulated_bimera_pair_quantities_both_kernels(emu_lib):
+    """The bimera mode of k_nw_ad (alignment reduced to get_lr / get_ham_endsfree inside the kernel, from column bitmaps) and the
+    lane kernel + k_bimera_lr behind DADA2HIP_NW_KERNEL=lane, per alignment against the oracle."""
+    code = (
+        "import os, sys\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from dada2_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "import numpy as np\n"
+        "from dada2_amd import api\n"
+        "from oracle import cport\n"
+        "from helpers import BIMERA_PAIR_OPTIONS, bimera_pair_cases\n"
+        "for seed, n, L in ((1, 90, 60), (2, 60, 130), (3, 45, 251)):\n"
+        "    qs, ps = bimera_pair_cases(seed, n, L)\n"
+        "    for oo, ms, sc in BIMERA_PAIR_OPTIONS:\n"
+        "        want = cport.bimera_pairs(qs, ps, oo, *sc, ms)\n"
+        "        for kern in ('', 'lane'):\n"
+        "            os.environ['DADA2HIP_NW_KERNEL'] = kern\n"
+        "            got = api.bimera_pairs(qs, ps, oo, *sc, ms)\n"
+        "            assert np.array_equal(got, want), (seed, oo, ms, sc, kern, np.nonzero((got != want).any(axis=1))[0][:5])\n"
+        "print('bimera pairs: ok')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "bimera pairs: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_emulated_bimera_table_and_nwvec_goldens(emu_lib):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_bimera.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "bimera table goldens: ok" in out.stdout and "nwvec goldens: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

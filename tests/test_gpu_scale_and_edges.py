@@ -390,6 +390,34 @@ def test_bimera_table_seeded_vs_oracle(api, oracle_c, seed, nseq, nsam, L):
     assert flagged.dtype == bool and flagged.shape == (len(seqs),)
 
 
+@pytest.mark.parametrize("nw_kernel", ["coop", "lane"])
+def test_bimera_pair_quantities_match_the_reference(api, oracle_c, nw_kernel, monkeypatch):
+    """What C_is_bimera / C_table_bimera2 look at, per alignment (get_lr / get_ham_endsfree, chimera.cpp:211-293): k_nw_ad in its
+    bimera mode (coop: the default wherever its geometry applies) and the lane kernel + k_bimera_lr, against the oracle - and the
+    reference's own functions where `_ref` is present (test_oracle.py pins the one to the other)."""
+    from helpers import BIMERA_PAIR_OPTIONS, bimera_pair_cases
+    from oracle import ref
+    monkeypatch.setenv("DADA2HIP_NW_KERNEL", nw_kernel)
+    for seed, n, L in ((1, 400, 60), (2, 400, 130), (3, 300, 251), (4, 120, 600)):
+        qs, ps = bimera_pair_cases(seed, n, L)
+        for oo, ms, sc in BIMERA_PAIR_OPTIONS:
+            want = oracle_c.bimera_pairs(qs, ps, oo, *sc, ms)
+            got = api.bimera_pairs(qs, ps, oo, *sc, ms)
+            assert np.array_equal(got, want), (seed, oo, ms, sc, np.nonzero((got != want).any(axis=1))[0][:5])
+        if ref.available():
+            assert np.array_equal(api.bimera_pairs(qs, ps, True), ref.bimera_pairs(qs, ps, True))
+
+
+def test_bimera_pair_quantities_many_pairs_one_launch(api, oracle_c):
+    """60 000 pairs of 250 nt in one call: more chunks than the launch has waves (every block walks several work slices and
+    reuses its slot of the pointer ring), every pair against the oracle."""
+    from helpers import bimera_pair_cases
+    qs, ps = bimera_pair_cases(11, 60000, 250)
+    got = api.bimera_pairs(qs, ps, True)
+    want = oracle_c.bimera_pairs(qs, ps, True)
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0][:5]
+
+
 def test_library_first_then_torch_share_one_hip_runtime():
     """the library used to need `import torch` BEFORE it (two HIP runtimes otherwise, torch then sees no device).
     dada2_amd._lib maps torch's bundled runtime first when torch is installed, so either order works: a fresh interpreter that

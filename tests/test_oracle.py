@@ -144,6 +144,19 @@ def test_nwalign_vs_both_reference_aligners(oracle_c, oracle_ref):
         assert oracle_c.nwalign(s1, s2, 5, -4, g, band) == want
 
 
+def test_bimera_pair_quantities_restatement_matches_the_reference(oracle_c, oracle_ref):
+    """get_lr / get_ham_endsfree per alignment (chimera.cpp:211-293): the restatement against the reference's own functions on
+    its own alignments - shared halves, shifts, truncations, indels, unrelated pairs; one-off on and off, four bands, two score sets."""
+    from helpers import BIMERA_PAIR_OPTIONS, bimera_pair_cases
+    for seed, n, L in ((1, 150, 60), (2, 150, 130), (3, 120, 251)):
+        qs, ps = bimera_pair_cases(seed, n, L)
+        for oo, ms, sc in BIMERA_PAIR_OPTIONS:
+            want = oracle_ref.bimera_pairs(qs, ps, oo, *sc, ms)
+            got = oracle_c.bimera_pairs(qs, ps, oo, *sc, ms)
+            assert np.array_equal(got, want), (seed, oo, ms, sc, np.nonzero((got != want).any(axis=1))[0][:5])
+        assert (want[:, 0] + want[:, 1] > 0).any() and (want[:, 4] > 0).any()
+
+
 def test_bimera_restatement_matches_reference_goldens(oracle_c):
     """Bimera identification (src/chimera.cpp): the C restatement against the vectors the reference itself produced
     (tests/golden/make_bimera_golden.py) - the checker of the GPU path's dada2hip_table_bimera2 / dada2hip_is_bimera."""

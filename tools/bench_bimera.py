@@ -41,7 +41,7 @@ got = api.table_bimera2(mat, seqs)
 t_gpu = time.perf_counter() - t0
 out = {"nseq": len(seqs), "nsam": nsam, "L": L, "gpu_s": t_gpu, "flagged": int((got[0] > 0).sum())}
 from oracle import ref
-if ref.available():
+if ref.available() and not os.environ.get("BIMERA_NO_REF"):
     ref.set_threads(os.cpu_count() or 1)
     t0 = time.perf_counter()
     want = ref.table_bimera2(mat, seqs)

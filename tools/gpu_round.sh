@@ -23,6 +23,14 @@ for s in $STEPS; do
     bench2q) timeout 600 python bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg2_quick.json 2> $OUT/bench_cfg2_quick.err; echo "bench2q rc=$?" >> $OUT/steps.log; python3 -c "import json;b=json.load(open('$OUT/bench_cfg2_quick.json'));print(b['ms_per_step'], b['resident']);print(b['phases_ms_last_step'])" ;;
     subphases) for c in 2 3; do DADA2HIP_V2_SUMMARY=1 timeout 600 python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-extras 2> $OUT/subphases_cfg$c.err > $OUT/subphases_cfg$c.json; grep "sub-phase\|\[v3\] blocks" $OUT/subphases_cfg$c.err | tail -2; done; echo "subphases rc=$?" >> $OUT/steps.log ;;
     bench4sweep) for k in 1 2 3 4; do timeout 600 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass --inflight $k > $OUT/bench_cfg4_inflight$k.json 2> $OUT/bench_cfg4_inflight$k.err; python3 -c "import json;b=json.load(open('$OUT/bench_cfg4_inflight$k.json'));print('inflight $k', round(b['ms_per_step'],1), round(b['value']))"; done; echo "bench4sweep rc=$?" >> $OUT/steps.log ;;
+    bimera)  P=$OUT/prof_bimera; mkdir -p $P
+             DADA2HIP_BIMERA_TIMES=1 timeout 300 python tools/bench_bimera.py > $OUT/bench_bimera.json 2> $OUT/bench_bimera.err; echo "bimera rc=$?" >> $OUT/steps.log; cat $OUT/bench_bimera.json; grep "bimera" $OUT/bench_bimera.err
+             ( cd /tmp && BIMERA_NO_REF=1 timeout 300 rocprofv3 --kernel-trace --stats -d $P/trace -o trace -- python $ROOT/tools/bench_bimera.py > $P/trace.log 2>&1 )
+             python3 -c "
+import sqlite3,glob
+c=sqlite3.connect(glob.glob('$P/trace/**/*.db', recursive=True)[0])
+for r in c.execute('select name,total_calls,total_duration,average,percentage from top_kernels limit 8'): print(r[0][:80], r[1], 'total_us', r[2], 'avg_us', r[3], 'pct', round(r[4],2))
+" | tee $OUT/bimera_kernels.txt ;;
     occ)     timeout 300 tools/microbench occ > $OUT/occ.json 2> $OUT/occ.err; echo "occ rc=$?" >> $OUT/steps.log; cat $OUT/occ.json ;;
     launch)  timeout 300 tools/microbench launch > $OUT/launch.json 2> $OUT/launch.err; echo "launch rc=$?" >> $OUT/steps.log; cat $OUT/launch.json ;;
     tests_iter) timeout 1200 python -X faulthandler -m pytest tests -m gpu -q -rf -p no:cacheprovider -k "not at_size and not 1M" --durations=10 > $OUT/gputests_iter.log 2>&1; echo "tests_iter rc=$?" >> $OUT/steps.log; tail -5 $OUT/gputests_iter.log ;;
