@@ -90,6 +90,12 @@ def test_emulated_bimera_pair_quantities_both_kernels(emu_lib):
         "            os.environ['DADA2HIP_NW_KERNEL'] = kern\n"
         "            got = api.bimera_pairs(qs, ps, oo, *sc, ms)\n"
         "            assert np.array_equal(got, want), (seed, oo, ms, sc, kern, np.nonzero((got != want).any(axis=1))[0][:5])\n"
+        "from helpers import bimera_short_pair_cases\n"
+        "qs, ps = bimera_short_pair_cases(5, 150)\n"
+        "for oo, ms in ((True, 16), (False, 4), (True, 1), (True, 40)):\n"
+        "    for kern in ('', 'lane'):\n"
+        "        os.environ['DADA2HIP_NW_KERNEL'] = kern\n"
+        "        assert np.array_equal(api.bimera_pairs(qs, ps, oo, max_shift=ms), cport.bimera_pairs(qs, ps, oo, max_shift=ms)), (oo, ms, kern)\n"
         "print('bimera pairs: ok')\n"
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)

@@ -406,6 +406,10 @@ def test_bimera_pair_quantities_match_the_reference(api, oracle_c, nw_kernel, mo
             assert np.array_equal(got, want), (seed, oo, ms, sc, np.nonzero((got != want).any(axis=1))[0][:5])
         if ref.available():
             assert np.array_equal(api.bimera_pairs(qs, ps, True), ref.bimera_pairs(qs, ps, True))
+    from helpers import bimera_short_pair_cases
+    qs, ps = bimera_short_pair_cases(5, 600)            # shorter than the band, all-gap alignments, maxShift 1 .. 40
+    for oo, ms in ((True, 16), (False, 16), (True, 4), (True, 1), (True, 40)):
+        assert np.array_equal(api.bimera_pairs(qs, ps, oo, max_shift=ms), oracle_c.bimera_pairs(qs, ps, oo, max_shift=ms)), (oo, ms)
 
 
 def test_bimera_pair_quantities_many_pairs_one_launch(api, oracle_c):

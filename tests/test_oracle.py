@@ -155,6 +155,10 @@ def test_bimera_pair_quantities_restatement_matches_the_reference(oracle_c, orac
             got = oracle_c.bimera_pairs(qs, ps, oo, *sc, ms)
             assert np.array_equal(got, want), (seed, oo, ms, sc, np.nonzero((got != want).any(axis=1))[0][:5])
         assert (want[:, 0] + want[:, 1] > 0).any() and (want[:, 4] > 0).any()
+    from helpers import bimera_short_pair_cases
+    qs, ps = bimera_short_pair_cases(5, 400)
+    for oo, ms in ((True, 16), (False, 16), (True, 4), (True, 1), (True, 40)):
+        assert np.array_equal(oracle_c.bimera_pairs(qs, ps, oo, max_shift=ms), oracle_ref.bimera_pairs(qs, ps, oo, max_shift=ms)), (oo, ms)
 
 
 def test_bimera_restatement_matches_reference_goldens(oracle_c):
