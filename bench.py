@@ -288,6 +288,7 @@ def main():
         # ---- sub-records of the default line: BASELINE configs[2]'s selfConsist loop on this very sample, and a workload
         #      whose comparisons are NOT 98 % shrouded (28 reads per unique) --------------------------------------------
         secondary = None
+        bimera = None
         if args.config == 3 and world == 1 and not args.selfconsist and not args.no_extras and not args.deep and not args.shard:
             tm = []
             t_sc = time.perf_counter()
@@ -299,6 +300,7 @@ def main():
                        "partitions_last": res_sc.nclust, "converged": bool(any(np.array_equal(e, err_sc) for e in errs_sc)),
                        "uniques_per_s_whole_loop": d.nraw / (time.perf_counter() - t_sc)}
             secondary = secondary_workload(api, opts, local, args)
+            bimera = bimera_table_record(api, local, reference=cpu is not None)
 
         out = {
             "metric": "unique reads denoised/sec (dada() wall-clock)", "value": value, "unit": "uniques/s",
@@ -324,6 +326,7 @@ def main():
             "resident": resident,
             "selfconsist": sc_info,
             "secondary_workload": secondary,
+            "bimera_table": bimera,
             "phases_ms_last_step": phases(st, pst if prof else None),
             "comparisons_per_s": st["ncompare"] * len(inputs) * world * args.steps / dt,
             "gen_s": t_gen,
@@ -492,6 +495,18 @@ def secondary_workload(api, opts, local, args):
             "partitions": r.nclust, "comparisons": ncmp, "comparisons_per_s": ncmp / dt,
             "shrouded_frac": st["nshroud"] / max(1, ncmp), "nw": st["nnw"], "gapless": st["ngapless"],
             "greedy_skipped": st["nskipped"], "roofline_nw": roof, "gen_s": gen_s}
+
+
+def bimera_table_record(api, device, reference=True):
+    """The row after the path (removeBimeraDenovo's C_table_bimera2): 3 000 sequences x 8 samples, one call.
+    With `reference` (part of the cpu_baseline leg: off under --no-cpu-baseline) the reference on all host cores beside it, tables
+    compared.  Never lets the main line down."""
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_bimera
+        return bench_bimera.record(api, device=device, reference=reference)
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def cpu_baseline(d, err, opts, args, gpu_res, gpu_cmp_per_s=None):
