@@ -114,6 +114,7 @@ struct dada2hip_sample {
   PinBuf<int32_t> h_counters;
   NwScratch scr;
   int scr_class = -1, scr_band = 0;
+  size_t scr_items = 0;          // alignments per launch the lane-kernel scratch was sized for
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::shared_ptr<void> run_cache;   // Run object: partition-state buffers reused by every dada2hip_sample_run
 };
@@ -449,12 +450,16 @@ std::string seq_string(const dada2hip_sample *s, int i) {
   return out;
 }
 
-void ensure_scratch(dada2hip_sample *s, int band) {
+// items: alignments a launch will hold when that is more than one per unique (the bimera table's pairs: a few thousand
+// sequences, millions of pairs - sized by N the launch would run on a dozen blocks)
+void ensure_scratch(dada2hip_sample *s, int band, size_t items = 0) {
   SampleDev &D = s->D;
   int wc = nw_class(band, D.maxlen, D.minlen);
-  if (s->scr_class == wc && s->scr_band == band && s->scr.ptr) return;
+  const size_t want = std::max<size_t>((size_t)D.N, items);
+  if (s->scr_class == wc && s->scr_band == band && s->scr.ptr && s->scr_items >= want) return;
+  s->scr_items = want;
   size_t ppw = nw_ptr_words_per_wave(wc, band, D.maxlen, D.minlen);
-  int nwaves = std::min(4096, ((D.N + 63) / 64 + 3) & ~3);
+  int nwaves = (int)std::min<size_t>(4096, ((want + 63) / 64 + 3) & ~(size_t)3);
   const size_t budget_words = (size_t)6 << 28;  // 6 GiB of pointer scratch at most
   while (nwaves > 64 && (size_t)nwaves * ppw > budget_words) nwaves /= 2;
   nwaves = std::max(4, nwaves & ~3);
@@ -2751,7 +2756,7 @@ void bimera_pairs(int ncol, const char *const *seqs, const std::vector<std::vect
   }();
   AdRingGuard ring{s};
   if (coop) ensure_ad_ring(s);
-  else ensure_scratch(s, max_shift);
+  else ensure_scratch(s, max_shift, npairs);
   // batches of whole queries, each query's parents padded to the kernel's chunks (alignments that share their query)
   const size_t per = coop ? (size_t)nw_ad_apw(s->D, ap) : 64;
   const size_t budget_slots = coop ? ((size_t)1 << 23) : std::max<size_t>(4096, ((size_t)256 << 20) / (size_t)stride);
