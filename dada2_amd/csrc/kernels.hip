@@ -739,12 +739,48 @@ constexpr int AD_OOB = -(1 << 20);
 // (round 2 kept three steady-state formulations behind a knob - sentinel select, additive mask, additive mask + v_max3:
 // 69.7 / 66.9 / 63.3 us at 8 700 alignments, profiles/r02o - only the last one is left.)  vnext = the one base that changes for the
 // next step (raw base after an even cell, centre base after an odd one), loaded by the caller.
-template <int GL, int PAR, bool DEF, bool LEAN, bool EDGE>
+// HOMO (nwalign_endsfree_homo, nwalign_endsfree.cpp:220-396): a gap opposite a base of a homopolymer run of >= 3 costs HG
+// instead of GAP.  The staged base words carry that flag in bit 31 (ad_base_word): the up move consumes centre base i - 1 (cb),
+// the left move raw base j - 1 (rb).
+template <int GL, int PAR, bool DEF, bool LEAN, bool EDGE, bool HOMO = false>
 static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
                                                uint32_t vnext, int fs, bool g_first, bool g_last,
-                                               bool kok, int gsel, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_) {
+                                               bool kok, int gsel, int L1, int L2, int SENT_, int MATCH_, int MISMATCH_, int GAP_,
+                                               int HG_ = 0) {
   // DEF: the reference's default scoring (MATCH 5, MISMATCH -4, GAP -8, vectorized sentinel) as literals
   const int SENT = DEF ? -32760 : SENT_, MATCH = DEF ? 5 : MATCH_, MISMATCH = DEF ? -4 : MISMATCH_, GAP = DEF ? -8 : GAP_;
+  if (HOMO) {
+    // the same cell with the two gap addends chosen per base; equality looks past the flag bit
+    const bool same = ((cb ^ rb) << 1) == 0u;
+    const bool hu = (cb >> 31) != 0u, hl = (rb >> 31) != 0u;
+    int left_src, up_src, own;
+    if (PAR == 0) {
+      const int lft = gcn_wave_shr1<false>(SENT, d1);
+      own = d0; left_src = (EDGE && g_first) ? SENT : lft; up_src = d1;
+    } else {
+      const int upn = gcn_wave_shl1<false>(SENT, d0);
+      own = d1; left_src = d0; up_src = (EDGE && g_last) ? SENT : upn;
+    }
+    const int diag = own + (same ? MATCH : MISMATCH);
+    const int up = up_src + ((!LEAN && j == L2) ? 0 : (hu ? HG_ : GAP));      // free moves along the last column
+    const int left = left_src + ((!LEAN && i == L1) ? 0 : (hl ? HG_ : GAP));  // ... and the last row
+    const bool t1 = left >= diag;
+    const int e1 = max(left, diag);
+    const bool t2 = up >= e1;
+    const int e = max(up, e1);
+    int val;
+    uint32_t p = t2 ? 3u : (t1 ? 2u : 1u);
+    if (LEAN) {
+      val = kok ? e : SENT;
+    } else {
+      const bool interior = kok && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
+      val = interior ? e : (kok ? 0 : SENT);
+      if (!interior) p = (i <= 0 ? 2u : 3u);
+    }
+    if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
+    pw = gcn_push_low2(pw, 3u - p);
+    return;
+  }
   if (LEAN && !EDGE) {
     // steady state, band inside the lane group: the DPP neighbour needs no masking (lanes without a source read 0, they
     // are out of band), the fetch folds into the add, the two max into one v_max3
@@ -887,6 +923,13 @@ static __host__ __device__ inline AdGeom ad_geom(int band, int maxlen, int minle
   return G;
 }
 
+// a staged base: ADK_HOT << (8 * code); HOMO: bit 31 = the position lies in a homopolymer run of >= 3 (homo_at)
+template <bool HOMO>
+static __device__ __forceinline__ uint32_t ad_base_word(const uint32_t *__restrict__ row, int len, int p) {
+  const uint32_t w = (uint32_t)ADK_HOT << (base_at(row, p) << 3);
+  return HOMO ? (w | (homo_at(row, len, p) << 31)) : w;
+}
+
 // ---- bimera mode of k_nw_ad (chimera.cpp:211-293): the alignment as three bitmaps over its columns, bit t = column t counted
 //      from the END of the alignment (the order the traceback finds them in) ----
 static __device__ __forceinline__ bool bm_bit(const uint32_t *bm, int t) { return ((bm[t >> 5] >> (t & 31)) & 1u) != 0u; }
@@ -967,7 +1010,7 @@ static __device__ __forceinline__ void bimera_lr_bits(const uint32_t *NE, const 
   o[4] = len - 1 - is >= ntrail ? bm_count(NE, ntrail, len - 1 - is) : 0;
 }
 
-template <int GL, bool DEF, bool EDGE, bool LR = false>
+template <int GL, bool DEF, bool EDGE, bool LR = false, bool HOMO = false>
 __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                AdGeom G) {
   constexpr int APW = 64 / GL;
@@ -1014,7 +1057,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     const int cv = a.centre_dev ? *a.centre_dev : a.centre;
     if (cv >= 0) {
       const int Lc = S.len[cv];
-      for (int p = threadIdx.x; p < Lc; p += 256) cwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)cv * S.W2, p) << 3);
+      for (int p = threadIdx.x; p < Lc; p += 256) cwd[p] = ad_base_word<HOMO>(S.seq2 + (size_t)cv * S.W2, Lc, p);
     }
   }
   __syncthreads();
@@ -1023,7 +1066,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
   int n_nw = batch ? 0 : (a.nwork_dev ? *a.nwork_dev : a.nwork_host);
   const int n_gl = batch ? 0 : (gl_work ? *gl_nwork_dev : 0);   // gapless items ride along: same factors/product tail
   int nwork = n_nw + n_gl;
-  const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band;
+  const int SENT = a.ap.sentinel, MATCH = a.ap.match, MISMATCH = a.ap.mismatch, GAP = a.ap.gap, B = a.ap.band, HGAP = a.ap.homo_gap;
   const int centre_v = batch ? 0 : (a.centre_dev ? *a.centre_dev : a.centre);
   if (centre_v < 0 && !a.chunk_centre) return;
   const int32_t *wl = a.work, *gll = gl_work;
@@ -1042,7 +1085,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       if (k != kcur) {                                       // next batch position: its centre replaces the staged one
         __syncthreads();
         const int Lc = S.len[c];
-        for (int p = threadIdx.x; p < Lc; p += 256) cwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);
+        for (int p = threadIdx.x; p < Lc; p += 256) cwd[p] = ad_base_word<HOMO>(S.seq2 + (size_t)c * S.W2, Lc, p);
         __syncthreads();
         kcur = k;
         wl = a.batch_list + (size_t)k * a.batch_stride; gll = a.batch_list + (size_t)(KB_MAX + k) * a.batch_stride;
@@ -1066,9 +1109,9 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     const int T = (gapless || !active) ? -1 : L1 + L2;     // idle / gapless slots run no DP steps of their own
     // stage both sequences (one base per byte, guard bytes either side) and the raw's qualities
     if (!G.shared_c)                                       // the chunk's centre, by all lanes of the wave
-      for (int p = lane; p < L1; p += 64) cwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)c * S.W2, p) << 3);
+      for (int p = lane; p < L1; p += 64) cwd[p] = ad_base_word<HOMO>(S.seq2 + (size_t)c * S.W2, L1, p);
     if (!ghost)
-      for (int p = g; p < L2; p += GL) rwd[p] = (uint32_t)ADK_HOT << (base_at(S.seq2 + (size_t)r * S.W2, p) << 3);
+      for (int p = g; p < L2; p += GL) rwd[p] = ad_base_word<HOMO>(S.seq2 + (size_t)r * S.W2, L2, p);
     if (LR && !ghost)
       for (int w = g; w < 3 * G.bmw; w += GL) bm[w] = 0;
     int ecol = 0;                                          // bimera mode: alignment columns found so far (from the end)
@@ -1109,7 +1152,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 #define AD_STEP(PARV, LEANV, VNEXT, FS, KOK, GS)                                                                                   \
   {                                                                                                                             \
     if (DEF) ad_step_k<GL, PARV, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), (PARV) ? gn1 : gn0, L1, L2); \
-    else ad_step<GL, PARV, DEF, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2, SENT, MATCH, MISMATCH, GAP); \
+    else ad_step<GL, PARV, DEF, LEANV, EDGE, HOMO>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2, SENT, MATCH, MISMATCH, GAP, HGAP); \
   }
 #define AD_FULL_STEP(TT)                                                                                                        \
   {                                                                                                                             \
@@ -1416,22 +1459,24 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   int waves = (std::max(maxwork, 1) + G.APW - 1) / G.APW;
   if (d_gl_work || batch) waves = (S.N + G.APW - 1) / G.APW;
   int grid = std::max(1, std::min((waves + 3) / 4, std::min(256 * 8, S.ad_waves / 4)));   // one slot of the pointer ring per wave
-  const bool def = ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
-#define D2_LAUNCH_AD(GLV, DEFV, EDGEV)                                                                                       \
+  const bool homo = ap.endsfree && ap.homo_gap != ap.gap;   // nwalign_endsfree_homo: the generic-score step with per-base gap costs
+  const bool def = !homo && ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
+#define D2_LAUNCH_AD(GLV, DEFV, EDGEV, HOMOV)                                                                                      \
   do {                                                                                                                   \
     static size_t attr_set[64] = {0};   /* per device: the attribute belongs to the function ON a device */            \
     int dev_ = 0;                                                                                                        \
     (void)hipGetDevice(&dev_);                                                                                           \
     if (lds > attr_set[dev_ & 63]) {                                                                                     \
-      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV, false, HOMOV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_set[dev_ & 63] = lds;                                                                                         \
     }                                                                                                                    \
-    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);  \
+    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV, false, HOMOV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);  \
   } while (0)
 #define D2_LAUNCH_AD2(GLV)                                                                                               \
   do {                                                                                                                   \
-    if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true); else D2_LAUNCH_AD(GLV, true, false); } \
-    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true); else D2_LAUNCH_AD(GLV, false, false); }   \
+    if (homo) { if (G.edge) D2_LAUNCH_AD(GLV, false, true, true); else D2_LAUNCH_AD(GLV, false, false, true); } \
+    else if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true, false); else D2_LAUNCH_AD(GLV, true, false, false); } \
+    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true, false); else D2_LAUNCH_AD(GLV, false, false, false); }   \
   } while (0)
   if (G.GL == 21) D2_LAUNCH_AD2(21);
   else if (G.GL == 32) D2_LAUNCH_AD2(32);
@@ -1494,7 +1539,10 @@ size_t nw_ad_lr_lds_bytes(const SampleDev &S, const AlignParams &ap) {
 // LDS needed by k_nw_ad for this sample/band, or 0 when the cooperative kernel does not apply.
 int nw_ad_apw(const SampleDev &S, const AlignParams &ap) { return ad_geom(ap.band, S.maxlen, S.minlen).APW; }
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
-  if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || S.ad_waves <= 0 || !ap.plain()) return 0;   // (factor offsets are u16: 16 * ncol * 8 < 65 536)
+  // (factor offsets are u16: 16 * ncol * 8 < 65 536.)  The global aligner (endsfree = 0: C_nwalign only) stays on the lane
+  // kernels; the homopolymer-gap aligner of dada() runs here unless DADA2HIP_AD_HOMO=0 sends it back to them.
+  const bool homo_ok = [] { const char *e = getenv("DADA2HIP_AD_HOMO"); return !(e && !strcmp(e, "0")); }();   // (read per call: the tests flip it)
+  if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || S.ad_waves <= 0 || !ap.endsfree || (!ap.plain() && !homo_ok)) return 0;
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 127) return 0;
   const AdGeom G = ad_geom(ap.band, S.maxlen, S.minlen);   // (a centre per wave: the larger of the two layouts)

@@ -107,8 +107,36 @@ def test_emulated_bimera_table_and_nwvec_goldens(emu_lib):
     assert out.returncode == 0 and "bimera table goldens: ok" in out.stdout and "nwvec goldens: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_emulated_homopolymer_gap_goldens(emu_lib):
-    run_cases(emu_lib, ("sam1F_homogap",))
+@pytest.mark.parametrize("env", [{}, {"DADA2HIP_AD_HOMO": "0"}], ids=["anti-diagonal-kernel", "lane-kernel"])
+def test_emulated_homopolymer_gap_goldens(emu_lib, env):
+    """HOMOPOLYMER_GAP_PENALTY: since round 4 on k_nw_ad<.., HOMO> (engine v2 and the persistent tail with it); DADA2HIP_AD_HOMO=0
+    = the lane kernels and the classic engine as before."""
+    run_cases(emu_lib, ("sam1F_homogap",), env)
+
+
+def test_emulated_homopolymer_rich_samples_on_the_anti_diagonal_kernel(emu_lib):
+    """helpers.homopolymer_sample (run-length errors: the option changes the result) on the edge geometry and at band 32 with a
+    free homopolymer gap, against the oracle."""
+    code = (
+        "import sys\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from dada2_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "from helpers import HOMO_OPTION_CASES, homopolymer_sample, assert_results_equal, tperr1\n"
+        "from dada2_amd import api\n"
+        "from dada2_amd.io import extend_err\n"
+        "from dada2_amd.opts import DadaOpts\n"
+        "from oracle import cport\n"
+        "for seed, kw in (HOMO_OPTION_CASES[1], HOMO_OPTION_CASES[3]):\n"
+        "    d = homopolymer_sample(seed, nreads=3000)\n"
+        "    err = extend_err(tperr1(), 40)\n"
+        "    got = api.dada_uniques(d.seqs, d.abundances, None, err, d.quals, DadaOpts(**kw))\n"
+        "    assert_results_equal(got, cport.dada_uniques(d.seqs, d.abundances, None, err, d.quals, DadaOpts(**kw)))\n"
+        "    assert got.stats['tail_launches'] > 0\n"
+        "print('homopolymer samples: ok')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "homopolymer samples: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_emulated_exact_bud_ties_settled_on_the_device_or_the_host(emu_lib):

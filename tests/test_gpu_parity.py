@@ -7,8 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (BAND_OPTION_CASES, BASE_OPTION_CASES, GOLDEN, SCORE_OPTION_CASES, WHOLE_PATH_CASES, P_RTOL, assert_results_equal,
-                     case_inputs, load_input, long_read_sample, seeded_option_sample, tperr1)
+from helpers import (BAND_OPTION_CASES, BASE_OPTION_CASES, GOLDEN, HOMO_OPTION_CASES, SCORE_OPTION_CASES, WHOLE_PATH_CASES, P_RTOL,
+                     assert_results_equal, case_inputs, homopolymer_sample, load_input, long_read_sample, seeded_option_sample, tperr1)
 from dada2_amd.io import extend_err
 from dada2_amd.opts import DadaOpts
 
@@ -104,6 +104,23 @@ def test_user_alignment_scores_and_sse1_on_every_aligner_family(api, oracle_c, o
     want = oracle_c.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o)
     assert_results_equal(got, want, p_rtol=P_RTOL)
     assert_results_equal(got, oracle_ref.dada_uniques(d.seqs, d.abundances, pri, tperr1(), d.quals, o), p_rtol=P_RTOL)
+
+
+@pytest.mark.parametrize("route", ["anti-diagonal", "lane"])
+@pytest.mark.parametrize("seed,kw", HOMO_OPTION_CASES, ids=_ids)
+def test_homopolymer_gap_penalty_on_homopolymer_rich_reads(api, oracle_c, seed, kw, route, monkeypatch):
+    """HOMOPOLYMER_GAP_PENALTY (R/dada.R:14, nwalign_endsfree_homo nwalign_endsfree.cpp:220-396; the 454 / Ion Torrent setting) on
+    reads whose errors are run-length changes of homopolymers - a sample on which the option changes the result
+    (test_oracle.py pins the oracle to the reference on the same cases).  Since round 4 these runs take k_nw_ad<.., HOMO>, engine
+    v2 and the persistent tail; DADA2HIP_AD_HOMO=0 = the lane kernels with the classic engine."""
+    if route == "lane":
+        monkeypatch.setenv("DADA2HIP_AD_HOMO", "0")
+    d = homopolymer_sample(seed)
+    err = extend_err(tperr1(), 40)
+    o = DadaOpts(**kw)
+    got = api.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
+    assert_results_equal(got, oracle_c.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o), p_rtol=P_RTOL)
+    assert (got.stats["tail_launches"] > 0) == (route == "anti-diagonal")
 
 
 @pytest.mark.parametrize("nw_kernel", ["auto", "lane", "wide"])

@@ -144,6 +144,24 @@ def test_nwalign_vs_both_reference_aligners(oracle_c, oracle_ref):
         assert oracle_c.nwalign(s1, s2, 5, -4, g, band) == want
 
 
+def test_homopolymer_gap_restatement_matches_the_reference_on_homopolymer_rich_reads(oracle_c, oracle_ref):
+    """nwalign_endsfree_homo inside the whole path (HOMOPOLYMER_GAP_PENALTY, the 454 / Ion Torrent setting): reads whose errors are
+    run-length changes of homopolymers, where the option changes the result - restatement vs the reference itself."""
+    from helpers import HOMO_OPTION_CASES, homopolymer_sample
+    from dada2_amd.io import extend_err
+    changed = 0
+    for seed, kw in HOMO_OPTION_CASES:
+        d = homopolymer_sample(seed)
+        err = extend_err(tperr1(), 40)
+        want = oracle_ref.dada_uniques(d.seqs, d.abundances, None, err, d.quals, DadaOpts(**kw))
+        got = oracle_c.dada_uniques(d.seqs, d.abundances, None, err, d.quals, DadaOpts(**kw))
+        assert_results_equal(got, want)
+        plain = dict(kw); plain.pop("HOMOPOLYMER_GAP_PENALTY")
+        other = oracle_c.dada_uniques(d.seqs, d.abundances, None, err, d.quals, DadaOpts(**plain))
+        changed += not np.array_equal(other.subqual, got.subqual)
+    assert changed == len(HOMO_OPTION_CASES)          # (the sample is one on which the homopolymer penalty matters)
+
+
 def test_bimera_pair_quantities_restatement_matches_the_reference(oracle_c, oracle_ref):
     """get_lr / get_ham_endsfree per alignment (chimera.cpp:211-293): the restatement against the reference's own functions on
     its own alignments - shared halves, shifts, truncations, indels, unrelated pairs; one-off on and off, four bands, two score sets."""
