@@ -35,10 +35,13 @@ class CStats(C.Structure):
         ("nnw_run", C.c_uint64), ("ngapless_run", C.c_uint64),
         ("lite_chains", C.c_uint64), ("lite_misses", C.c_uint64),
         ("tail_launches", C.c_uint64), ("tail_pauses", C.c_uint64), ("tail_levels", C.c_uint64),
-        ("tail_blocks", C.c_uint32), ("tail_reserved", C.c_uint32),
+        ("tail_blocks", C.c_uint32), ("tail_fallbacks", C.c_uint32),
         ("dev_ms_tail", C.c_double), ("tail_ms_entry", C.c_double), ("tail_ms_shuffle0", C.c_double),
         ("tail_ms_shuffle_more", C.c_double), ("tail_ms_pupdate", C.c_double), ("tail_ms_barriers", C.c_double),
         ("tail_ms_birth", C.c_double), ("tail_ms_publish", C.c_double), ("tail_ms_release", C.c_double),
+        ("pf_compares", C.c_uint64), ("pf_hits", C.c_uint64), ("pf_waits", C.c_uint64), ("pf_exits", C.c_uint64),
+        ("pf_centres", C.c_uint64), ("tail_threads", C.c_uint32), ("overlap_on", C.c_uint32),
+        ("dev_ms_pf_screen", C.c_double), ("dev_ms_pf_nw", C.c_double),
     ]
 
     def as_dict(self):
@@ -47,6 +50,43 @@ class CStats(C.Structure):
 
 # dada2hip_shard (include/dada2hip.h): rank / world + the collective the library calls at its exchange points
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+# dada2hip_hooks (include/dada2hip.h): the verbose log lines (Rprintf, src/Rmain.cpp:317-333) and the abort poll
+# (Rcpp::checkUserInterrupt, src/Rmain.cpp:330)
+LOG_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+ABORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class CHooks(C.Structure):
+    _fields_ = [("log", LOG_FN), ("should_abort", ABORT_FN), ("user", C.c_void_p)]
+
+
+def make_hooks(log=None, should_abort=None):
+    """(CHooks, keepalive) for ``log(str)`` / ``should_abort() -> bool`` callables, or (None, None) when both are None.
+    An exception raised by a callback cannot cross the C frame: it is recorded in ``keepalive['error']`` (and aborts the run
+    when it comes from ``should_abort``); the caller re-raises it after the library call."""
+    if log is None and should_abort is None:
+        return None, None
+    keep = {"error": None}
+
+    def _log(msg, _user):
+        try:
+            if log is not None:
+                log(msg.decode(errors="replace"))
+        except BaseException as ex:   # noqa: BLE001
+            keep["error"] = keep["error"] or ex
+
+    def _abort(_user):
+        try:
+            return 1 if (should_abort is not None and should_abort()) else 0
+        except BaseException as ex:   # noqa: BLE001
+            keep["error"] = keep["error"] or ex
+            return 1
+
+    h = CHooks(LOG_FN(_log), ABORT_FN(_abort), None)
+    keep["cb"] = (h.log, h.should_abort)
+    return h, keep
 
 
 class CShard(C.Structure):

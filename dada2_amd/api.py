@@ -116,18 +116,25 @@ def _copts(opts, max_clust, multithread, verbose, copts):
 
 
 def dada_uniques(seqs, abundances, priors, err, quals, opts: DadaOpts = None, *, max_clust=None, multithread=False,
-                 verbose=False, copts: COpts = None, device: int = 0) -> DadaResult:
+                 verbose=False, copts: COpts = None, device: int = 0, log=None, should_abort=None) -> DadaResult:
     """One ``dada_uniques`` call (src/Rmain.cpp:30) on the GPU.  ``quals`` is the derep-side
-    [N, maxlen] matrix (NaN past a short read's end); ``err`` is 16 x Q."""
+    [N, maxlen] matrix (NaN past a short read's end); ``err`` is 16 x Q.  ``log(str)`` receives the ``verbose`` lines
+    (Rprintf, src/Rmain.cpp:317-333), ``should_abort()`` is polled once per divisive round (Rcpp::checkUserInterrupt,
+    src/Rmain.cpp:330): a true value ends the call with ``Dada2HipError(code=5)``."""
     L = _lib.lib()
     co = _copts(opts, max_clust, multithread, verbose, copts)
+    hooks, keep = _lib.make_hooks(log, should_abort)
     hi = _pack(seqs, abundances, priors, quals)
     e, ncol = _err_colmajor(err)
     eb = C.create_string_buffer(_EB)
     h = C.c_void_p()
     rc = L.dada2hip_dada_uniques(hi.n, hi.seqs_p, hi.ab.ctypes.data, hi.pr.ctypes.data if hi.pr is not None else None,
                                  e.ctypes.data, ncol, hi.q.ctypes.data if hi.q is not None else None, hi.qn, C.byref(co),
-                                 device, None, C.byref(h), eb, _EB)
+                                 device, C.byref(hooks) if hooks is not None else None, C.byref(h), eb, _EB)
+    if keep and keep["error"] is not None:
+        if rc == 0:
+            L.dada2hip_result_free(h)
+        raise keep["error"]
     _lib.check(rc, eb)
     try:
         return _collect(L, h)
@@ -251,13 +258,20 @@ class Sample:
         _lib.check(_lib.lib().dada2hip_sample_set_priors(self._h, pr.ctypes.data, eb, _EB), eb)
 
     def run(self, err, opts: DadaOpts = None, *, max_clust=None, multithread=False, verbose=False,
-            copts: COpts = None) -> DadaResult:
+            copts: COpts = None, log=None, should_abort=None) -> DadaResult:
         L = _lib.lib()
         co = _copts(opts, max_clust, multithread, verbose, copts)
         e, ncol = _err_colmajor(err)
         eb = C.create_string_buffer(_EB)
         h = C.c_void_p()
-        _lib.check(L.dada2hip_sample_run(self._h, e.ctypes.data, ncol, C.byref(co), None, C.byref(h), eb, _EB), eb)
+        hooks, keep = _lib.make_hooks(log, should_abort)
+        rc = L.dada2hip_sample_run(self._h, e.ctypes.data, ncol, C.byref(co), C.byref(hooks) if hooks is not None else None,
+                                   C.byref(h), eb, _EB)
+        if keep and keep["error"] is not None:
+            if rc == 0:
+                L.dada2hip_result_free(h)
+            raise keep["error"]
+        _lib.check(rc, eb)
         try:
             return _collect(L, h)
         finally:

@@ -26,6 +26,7 @@
 
 #include "engine.h"
 #include "hostpar.h"
+#include "knobs.h"
 #include "ppois.h"
 
 namespace d2 {
@@ -42,6 +43,7 @@ static double na_real() {
 struct InputError { std::string msg; };
 struct PeerFailed {};   // sharded run: another rank reported a failure at an exchange point
 struct RuntimeErr { int code; std::string msg; };
+struct TailEntryFailed {};   // the persistent round tail could not become co-resident (nothing changed): the launch chains take over
 
 // device / pinned buffers; the memory comes from (and returns to) the per-process allocation cache (hostpar.h)
 template <typename T> struct DevBuf {
@@ -150,8 +152,12 @@ struct PersistFile {
       for (char *c = bus; *c; c++) if (*c == ':' || *c == '/') *c = '_';
       char path[160];
       snprintf(path, sizeof path, "/tmp/dada2hip_persistent_%s.lock", bus);
-      fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-      if (fd < 0) return true;                      // (no lock file possible: trust the in-process slot)
+      // O_NOFOLLOW: never through a symlink somebody planted in /tmp.  A file another user created under umask 022 cannot be
+      // opened for writing: flock works on a read-only descriptor too.  No descriptor at all = no way to know whether another
+      // process holds the device's slot: the run then takes the launch chains, it does not assume it is alone.
+      fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+      if (fd < 0) fd = open(path, O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
+      if (fd < 0) return false;
     }
     held = flock(fd, LOCK_EX | LOCK_NB) == 0;
     return held;
@@ -166,14 +172,8 @@ PersistFile &persistent_file(int device) {
 // Wait for the stream by polling: the per-round decision points (shuffle movers, bud result) sit on
 // the critical path, and a polled wait returns microseconds sooner than a blocking one.
 // DADA2HIP_WAIT=block (or more resident samples / ranks than host cores): sleep between polls instead of spinning.
-static bool wait_blocks() {
-  static const bool b = [] { const char *e = getenv("DADA2HIP_WAIT"); return e && !strcmp(e, "block"); }();
-  return b;
-}
-static double wait_timeout_s() {
-  static const double t = [] { const char *e = getenv("DADA2HIP_WAIT_TIMEOUT_S"); return e ? atof(e) : 600.0; }();
-  return t;
-}
+static bool wait_blocks() { return knobs().wait_block; }
+static double wait_timeout_s() { return knobs().wait_timeout_s; }
 static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_pause();
@@ -198,6 +198,7 @@ void set_err(char *errbuf, size_t errlen, const std::string &m) {
 
 template <typename F> int guarded(char *errbuf, size_t errlen, F &&f) {
   try {
+    knobs_reload();   // the environment is read HERE, once per boundary call (knobs.h)
     f();
     return DADA2HIP_OK;
   } catch (const InputError &e) {
@@ -291,7 +292,7 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
   D.LK = (std::max(maxlen - KMER_SIZE + 1, 1) + 7) & ~7;
   {   // DADA2HIP_KORD_ALIGN=1: rows of k-mer records padded to 128-B cache lines (the screen's two 256-B reads per row then
       // touch 2 lines each instead of 3).  Measured 2 % on the screen at 1e6 uniques for 3 % more memory: off by default.
-    static const bool aligned = [] { const char *e = getenv("DADA2HIP_KORD_ALIGN"); return e && !strcmp(e, "1"); }();
+    const bool aligned = knobs().kord_align;
     if (aligned) D.LK = (D.LK + 63) & ~63;
   }
   D.HMAX = std::max(0, (maxlen - KMER_SIZE + 1) / (RANK_SAT + 1));
@@ -416,7 +417,7 @@ void ensure_ad_ring(dada2hip_sample *s) {
   const int stride = (s->D.maxlen + 7) & ~7;
   long long cap = std::min<long long>(1ll << 20, ((long long)1 << 30) / (2ll * stride));
   cap = std::min<long long>(cap, 8ll * s->D.N + 512);
-  if (const char *e = getenv("DADA2HIP_AD_FCAP")) cap = std::max<long long>(1, std::min<long long>(cap, atoll(e)));   // test knob: the in-kernel product for what does not fit
+  if (knobs().ad_fcap > 0) cap = std::max<long long>(1, std::min<long long>(cap, knobs().ad_fcap));   // test knob: the in-kernel product for what does not fit
   s->scr_foff.alloc((size_t)cap * stride);
   s->scr_fdesc.alloc((size_t)cap);
   D2_HIP(hipMemsetAsync(s->scr_fdesc.p, 0xFF, (size_t)cap * sizeof(AdDesc), s->stream));   // dest = -1: nothing to do
@@ -525,7 +526,7 @@ struct BudKeyH { double p; uint32_t reads; uint32_t pad; };
 
 // below this many alignments in one launch the cooperative (anti-diagonal) kernel beats one-alignment-per-lane
 // (measured up to 1e6 alignments: 1M-unique pass 358 -> 349 ms; beyond 4e6 untested, the lane kernel takes over)
-static const int COOP_MAX_BATCH = [] { const char *e = getenv("DADA2HIP_COOP_MAX"); return e ? atoi(e) : 4000000; }();
+#define COOP_MAX_BATCH (knobs().coop_max)
 
 struct Run {
   dada2hip_sample *s;
@@ -695,7 +696,7 @@ struct Run {
     P.totals = d_totals.p;
     {   // comparison store: grows by doubling (decide_bud); DADA2HIP_NODE_CAP shrinks the first allocation (test knob)
       size_t cap0 = std::max<size_t>(4 * n, 1u << 20);
-      if (const char *e = getenv("DADA2HIP_NODE_CAP")) cap0 = std::max<size_t>((size_t)atoll(e), n + 16);
+      if (knobs().node_cap > 0) cap0 = std::max<size_t>((size_t)knobs().node_cap, n + 16);
       grow_nodes(cap0);
     }
     grow_clusters(256);
@@ -709,7 +710,7 @@ struct Run {
     bi.clear();
     ev_used = 0;
     ev_round = 0; n_round_launches = 0;
-    profile_all = [] { const char *e = getenv("DADA2HIP_PROFILE"); return e && atoi(e) != 0; }();
+    profile_all = knobs().profile;
     D2_HIP(hipMemsetAsync(d_rout.p, 0, 2 * sizeof(RoundOut), stq));
     D2_HIP(hipMemsetAsync(d_next.p, 0xFF, 16, stq));
     ri = 0;
@@ -820,8 +821,8 @@ struct Run {
   bool spec_launched = false;
   int32_t *spec_ctr = nullptr;
   bool rounds_use_coop() const {
-    const char *f = getenv("DADA2HIP_NW_KERNEL");
-    if (f && (!strcmp(f, "lane") || !strcmp(f, "wide"))) return false;
+    const int f = knobs().nw_kernel;
+    if (f == NWK_LANE || f == NWK_WIDE) return false;
     return nw_ad_lds_bytes(s->D, ap) > 0 && nw_ad_lds_bytes(s->D, ap) <= 150 * 1024;
   }
   void confirm_spec(int ci, int centre) {
@@ -850,16 +851,16 @@ struct Run {
     // thousand (cooperative kernel).
     const int evn_i = ev_begin(EV_NW, timed, spec, /*big=*/ci == 0);
     spec_ev_nw = spec ? evn_i : -1;
-    const char *f = getenv("DADA2HIP_NW_KERNEL");
+    const int f = knobs().nw_kernel;
     const bool coop_ok = nw_ad_lds_bytes(D, ap) > 0 && nw_ad_lds_bytes(D, ap) <= 150 * 1024;
     bool coop = coop_ok && (ci != 0 || N < COOP_MAX_BATCH);
-    if (f && !strcmp(f, "lane")) coop = false;
-    if (f && !strcmp(f, "coop") && coop_ok) coop = true;
+    if (f == NWK_LANE) coop = false;
+    if (f == NWK_COOP && coop_ok) coop = true;
     // band windows too wide for the LDS-pointer kernel (ragged long reads): eight cells per lane, pointers in HBM
     bool wide = !coop && nw_adw_ok(D, ap) && nw_adw_lds_bytes(D, ap) <= 150 * 1024 && wclass != 33 && wclass != 65 &&
                 N < (1 << 20);
-    if (f && !strcmp(f, "lane")) wide = false;
-    if (f && !strcmp(f, "wide")) wide = nw_adw_ok(D, ap) && nw_adw_lds_bytes(D, ap) <= 150 * 1024;
+    if (f == NWK_LANE) wide = false;
+    if (f == NWK_WIDE) wide = nw_adw_ok(D, ap) && nw_adw_lds_bytes(D, ap) <= 150 * 1024;
     if (coop && !wide)   // the gapless pairings of the round share the kernel's factor/product tail
       launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, ctr, 0, s->d_gl_list.p, ctr + 1, ap, s->d_err.p, s->d_lambda.p,
                    s->d_ham.p, nullptr, 0, 0, spec ? d_next.p : nullptr, stq);
@@ -1338,8 +1339,7 @@ struct Run {
   std::vector<EnqRec> v2_enqrec;      // per enqueued block (index = sequence number - 1)
 
   bool want_v2() const {
-    const char *e = getenv("DADA2HIP_ENGINE");
-    if (e && !strcmp(e, "classic")) return false;
+    if (knobs().engine_classic) return false;
     if (plain || no_auto || !rounds_use_coop()) return false;
     if (s->D.N < 2) return false;
     return true;
@@ -1362,14 +1362,16 @@ struct Run {
     E2.moved = v2_moved.p; E2.n0d = v2_n0d.p; E2.stat_part = v2_statpart.p; E2.stat_n = v2_n0d.p + 2 * SH_LEVELS;
     E2.psync = v3_psync.p; E2.hcons = v3_hflags.p; E2.hexit = v3_hflags.p ? v3_hflags.p + 16 : nullptr; E2.ktime = v3_ktime.p;
     E2.sh_filter = 1; E2.grid_shuffle = 2048; E2.grid_pupdate = 1024;
-    if (const char *e = getenv("DADA2HIP_V2_FILTER")) E2.sh_filter = atoi(e) != 0;
-    if (const char *e = getenv("DADA2HIP_V2_GRID_SHUFFLE")) E2.grid_shuffle = std::min(8192, std::max(1, atoi(e)));
+    const Knobs &K = knobs();
+    if (K.v2_filter >= 0) E2.sh_filter = K.v2_filter;
+    if (K.v2_grid_shuffle > 0) E2.grid_shuffle = std::min(8192, K.v2_grid_shuffle);
     // (a wave of the shuffle pass adds up per-thread counts in 16-bit halves: fewer than 1000 uniques per thread)
     E2.grid_shuffle = std::max<int>(E2.grid_shuffle, (int)std::min<long long>(8192, (long long)N / (256ll * 1000) + 1));
-    if (const char *e = getenv("DADA2HIP_V2_GRID_PUPDATE")) E2.grid_pupdate = std::max(1, atoi(e));
+    if (K.v2_grid_pupdate > 0) E2.grid_pupdate = K.v2_grid_pupdate;
     E2.mov_inline = MOV_INLINE2; E2.ring_limit = RING2;
-    if (const char *e = getenv("DADA2HIP_V2_MOV_INLINE")) E2.mov_inline = std::max(1, std::min(MOV_INLINE2, atoi(e)));   // test knob: long mover lists
-    if (const char *e = getenv("DADA2HIP_V3_RING")) E2.ring_limit = std::max(1, std::min(RING2, atoi(e)));               // test knob: a host that lags
+    if (K.v2_mov_inline > 0) E2.mov_inline = std::min(MOV_INLINE2, K.v2_mov_inline);   // test knob: long mover lists
+    if (K.v3_ring > 0) E2.ring_limit = std::min(RING2, K.v3_ring);                     // test knob: a host that lags
+    E2.fail_ordinal = K.v3_fail_entry > 0 ? K.v3_fail_entry : 0;
     E2.has_compare = 1;
     E2.align_at_commit = v2_align_commit ? 1 : 0;
     E2L = E2; E2L.has_compare = 0;
@@ -1388,16 +1390,16 @@ struct Run {
       const size_t per_buf = (((size_t)N + 31) & ~(size_t)15) * (2 + (size_t)KB_MAX * 12);
       v2_nbuf = (int)std::max<size_t>(2, std::min<size_t>(64, total_b / 8 / std::max<size_t>(per_buf, 1)));
     }
-    if (const char *e = getenv("DADA2HIP_V2_NBUF")) v2_nbuf = std::max(1, std::min(64, atoi(e)));   // (k2_birth keeps the slot table in LDS)
-    if (const char *e = getenv("DADA2HIP_V2_DEPTH")) v2_depth = std::max(1, std::min(MOV_RING - 1, atoi(e)));
-    v2_chain = SH_CHAIN;
-    if (const char *e = getenv("DADA2HIP_V2_CHAIN")) v2_chain = std::max(1, std::min(SH_CHAIN, atoi(e)));   // test knob: shorter shuffle chains
-    v2_debug = getenv("DADA2HIP_V2_DEBUG") != nullptr;
+    const Knobs &K = knobs();
+    if (K.v2_nbuf > 0) v2_nbuf = std::min(64, K.v2_nbuf);   // (k2_birth keeps the slot table in LDS)
+    v2_depth = K.v2_depth > 0 ? std::min(MOV_RING - 1, K.v2_depth) : 2;
+    v2_chain = K.v2_chain > 0 ? std::min(SH_CHAIN, K.v2_chain) : SH_CHAIN;   // test knob: shorter shuffle chains
+    v2_debug = K.v2_debug;
     hipStream_t stq = s->stream;
     v2_lam0.alloc(n); v2_ham0.alloc(n); v2_lam1.alloc(n); v2_ham1.alloc(n); v2_i1.alloc(n); v2_smask.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
     {
       size_t cap0 = std::max<size_t>(2 * n, (size_t)1 << 16);
-      if (const char *e = getenv("DADA2HIP_NODE_CAP")) cap0 = std::max<size_t>((size_t)atoll(e), n + 16);   // test knob: forces growth
+      if (K.node_cap > 0) cap0 = std::max<size_t>((size_t)K.node_cap, n + 16);   // test knob: forces growth
       if (v2_blk.n < cap0) v2_blk.alloc(cap0);
     }
     v2_ctl.alloc(1); v2_dblk.alloc(RING2); v2_hblk.alloc(RING2);
@@ -1429,19 +1431,19 @@ struct Run {
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
     D2_HIP(hipStreamSynchronize(stq));   // `c` is a local
     v2_trace_seq = -1;
-    if (const char *e = getenv("DADA2HIP_V2_TRACE")) {
-      v2_trace_seq = atoi(e);
+    if (K.v2_trace_on) {
+      v2_trace_seq = K.v2_trace_seq;
       v2_trace.alloc((size_t)TRACE_KERNELS * TRACE_BLOCKS * 8);
       D2_HIP(hipMemsetAsync(v2_trace.p, 0, (size_t)TRACE_KERNELS * TRACE_BLOCKS * 64, stq));
     }
     v2_enq = v2_cons = 0;
     v2_next_full = 0;
     v2_lite_on = true;
-    if (const char *e = getenv("DADA2HIP_V2_LITE")) v2_lite_on = atoi(e) != 0;
+    if (K.v2_lite >= 0) v2_lite_on = K.v2_lite != 0;
     // one alignment per wave (band windows > 65 cells: long reads): a round's own list fills the device, so its pairs are
     // aligned when the round commits and nothing is aligned in vain (engine.h, Eng2::align_at_commit)
     v2_align_commit = nw_ad_apw(s->D, ap) == 1;
-    if (const char *e = getenv("DADA2HIP_V2_ALIGN")) v2_align_commit = !strcmp(e, "commit");
+    if (K.v2_align >= 0) v2_align_commit = K.v2_align == 1;
     if (v2_align_commit) v2_lite_on = false;                   // (every chain carries the aligner's launches)
     v2_plain_rounds = 0;
     v2_miss_launches = 0;
@@ -1453,13 +1455,15 @@ struct Run {
   // DADA2HIP_V2_TAIL=chain keeps the launch chains; DADA2HIP_V3_GRID=n forces the number of blocks (tests: several blocks on a
   // small sample)
   void v3_setup(hipStream_t stq) {
-    v3_on = true;
-    if (const char *e = getenv("DADA2HIP_V2_TAIL")) v3_on = strcmp(e, "chain") != 0;
-    if (getenv("DADA2HIP_V2_GRAPH") && !graph_off()) v3_on = false;     // (hipGraph replay is a property of the chains)
-    if (v2_trace_seq >= 0 || getenv("DADA2HIP_V2_TRACE")) v3_on = false; // (the phase trace stamps the chains' kernels)
+    const Knobs &K = knobs();
+    v3_on = !K.v2_tail_chain;
+    if (K.v2_graph) v3_on = false;                                      // (hipGraph replay is a property of the chains)
+    if (v2_trace_seq >= 0 || K.v2_trace_on) v3_on = false;              // (the phase trace stamps the chains' kernels)
 
     v3_grid = tail_grid(N, s->device);
-    if (const char *e = getenv("DADA2HIP_V3_GRID")) v3_grid = std::max(1, std::min(atoi(e), tail_grid(1 << 30, s->device)));
+    if (K.v3_grid > 0) v3_grid = std::min(K.v3_grid, tail_grid(1 << 30, s->device));
+    // refuse up front a grid the device cannot hold at once (the entry barrier would time out): the launch chains serve the run
+    if (v3_on) { const int cap = tail_resident_max(s->device); if (cap > 0 && v3_grid > cap) v3_on = false; }
     v3_psync.alloc(1); v3_hflags.alloc(32); v3_ktime.alloc(KT_N);
     D2_HIP(hipMemsetAsync(v3_psync.p, 0, sizeof(PSync), stq));
     D2_HIP(hipMemsetAsync(v3_ktime.p, 0, KT_N * 8, stq));
@@ -1477,6 +1481,30 @@ struct Run {
   }
   void v3_release() {
     if (v3_slot.owns_lock()) { persistent_file(s->device).release(); v3_slot.unlock(); }
+  }
+  // halt whatever this run still has queued or running on the device and wait for it (errors ignored: this runs while another
+  // error unwinds).  A running k3_tail sees the halt at its next round boundary at the latest when the host stops consuming
+  // (ring limit); queued launches return at their first instruction.
+  void v3_quiesce() {
+    if (!v2_ctl.p || !s) return;
+    v3_hflags.p[24] = 1;
+    (void)hipMemcpyAsync(&v2_ctl.p->state, v3_hflags.p + 24, 4, hipMemcpyHostToDevice, s->side);
+    (void)hipStreamSynchronize(s->side);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipGetLastError();
+  }
+  // the entry barrier of a persistent launch failed: clear the failure, give the slot back, continue on the launch chains
+  void v3_fallback() {
+    sync_spin(s->stream);
+    D2_HIP(hipMemsetAsync(v3_psync.p, 0, sizeof(PSync), s->stream));
+    launch2_resume(E2, s->stream, /*keep_list=*/true, /*compare_done=*/true);   // (every launch but the first has its compare in front of it)
+    v3_release();
+    v3_on = false;
+    st.tail_fallbacks++;
+    v2_enq = v2_cons;
+    v2_enqrec.assign((size_t)v2_cons, EnqRec{-1, -1, false});
+    v2_next_full = 0;                                          // (whether the coming centre is cached is not known here: full chains)
+    if (knobs().v2_summary) fprintf(stderr, "[v3] entry barrier failed after %ld blocks: continuing on the launch chains\n", v2_cons);
   }
   bool v3_block_ready() const { return *(volatile int32_t *)&v2_hblk.p[v2_cons % RING2].seq == (int32_t)(v2_cons + 1); }
   long v3_ended() const { return (long)*(volatile int32_t *)(v3_hflags.p + 16); }
@@ -1538,8 +1566,16 @@ struct Run {
         if (e == hipSuccess && *seqp != want) {
           // everything queued has run (its writes are visible now) and the block is not there: every launch found the device
           // halted or the ring full and said so - send another one - or a launch ended without saying so (a barrier timed out)
-          if (v3_ended() >= v3_enq && burst < 512) { v3_enqueue(false); burst++; continue; }
-          throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: the persistent round tail ended without publishing its result (a grid barrier timed out?)"};
+          // ... in which case a barrier gave up.  The ENTRY barrier (not all blocks of the launch became resident: another tenant
+          // holds CUs) has changed nothing - the run goes on on the launch chains (run_v3 catches this)
+          if (v3_ended() < v3_enq || burst >= 2) {
+            PSync ps;
+            D2_HIP(hipMemcpy(&ps, v3_psync.p, sizeof ps, hipMemcpyDeviceToHost));
+            if (ps.fail == 1u) throw TailEntryFailed{};
+            if (ps.fail != 0u || v3_ended() < v3_enq || burst >= 512)
+              throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: the persistent round tail ended without publishing its result (a grid barrier timed out?)"};
+          }
+          v3_enqueue(false); burst++; continue;
         }
         if (ms_since(tw) > wait_timeout_s() * 1e3)
           throw d2::DeviceError{DADA2HIP_ERR_DEVICE, "dada2hip: timed out waiting for the round result"};
@@ -1554,7 +1590,10 @@ struct Run {
   // run_dada's loop (Rmain.cpp:312-331) with the rounds inside persistent launches: the host keeps v2_depth super-chains queued,
   // trails the device through the published result blocks exactly as with the launch chains, and answers the same halts
   void run_v3(int max_clust) {
-    struct SlotGuard { Run *r; ~SlotGuard() { r->v3_release(); r->v3_running = false; } } slot_guard{this};   // the device's persistent slot is held for the rounds only
+    // the device's persistent slot is held for the rounds only.  An exception (abort hook, time-out, internal error) can leave
+    // launches of this run queued or running: they are halted and waited for BEFORE the slot goes to the next run, which would
+    // otherwise put its own persistent kernel beside a dying one
+    struct SlotGuard { Run *r; ~SlotGuard() { if (r->v3_running) r->v3_quiesce(); r->v3_release(); r->v3_running = false; } } slot_guard{this};
     v3_running = true;
     auto t0 = clk::now();
     st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
@@ -1566,7 +1605,18 @@ struct Run {
       // keep the device fed: super-chains in flight = enqueued - ended (the device reports the ordinal of every launch that
       // ends, whether it ran rounds or found the device halted); none is added while a result block waits to be consumed
       const long seq = v2_cons + 1;
-      const Round2Out &b = v3_wait_block();
+      const Round2Out *bp = nullptr;
+      try { bp = &v3_wait_block(); }
+      catch (const TailEntryFailed &) {
+        // every queued launch has ended and none of them has touched the state since the last consumed block: hand the rounds
+        // to the launch chains from exactly here
+        v3_running = false;
+        v3_fallback();
+        st.ms_bookkeep += ms_since(t0);
+        run_v2(max_clust, /*resume=*/true, /*first=*/v2_cons == 0);
+        return;
+      }
+      const Round2Out &b = *bp;
       n_blocks++;
       if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
         throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
@@ -1639,14 +1689,14 @@ struct Run {
       st.tail_ms_barriers = (kt[KT_S0_BAR] + kt[KT_SL_BAR] + kt[KT_P_BAR]) * ms; st.tail_ms_birth = kt[KT_BIRTH] * ms;
       st.tail_ms_publish = kt[KT_PUBLISH] * ms; st.tail_ms_entry = kt[KT_LAUNCH] * ms;
       st.tail_levels = kt[KT_LEVELS]; st.tail_ms_release = kt[KT_RELEASE] * ms;
-      if (getenv("DADA2HIP_V2_SUMMARY")) {
+      if (knobs().v2_summary) {
         fprintf(stderr, "[v3] block-0 sub-phase ms (kid: 1 commit+shuffle0, 2 later shuffles, 5 p-update, 6 serial end):");
         for (int kid : {1, 2, 5, 6}) { fprintf(stderr, "  kid%d:", kid); for (int ph = 1; ph < 8; ph++) fprintf(stderr, " %.2f", kt[KT_SUB + 8 * kid + ph] * ms); }
         fprintf(stderr, "\n");
       }
     }
     st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid;
-    if (getenv("DADA2HIP_V2_SUMMARY"))
+    if (knobs().v2_summary)
       fprintf(stderr, "[v3] blocks %ld  launches %ld  grid %d  halts none/nobirth/host/more/cap/max %ld %ld %ld %ld %ld %ld  pauses %ld  ms: wait %.1f replay %.1f enqueue %.1f total %.1f  moves %llu misses %llu\n",
               n_blocks, v3_enq, v3_grid, n_halt[0], n_halt[1], n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_pause, st.ms_wait_device, st.ms_replay,
               st.ms_enqueue, ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches);
@@ -1689,7 +1739,7 @@ struct Run {
   // per pass at 10^6 uniques, while the six or ten plain launches of a chain cost the host 25 us per round - a third of what
   // it has (it trails the device anyway) - and run back to back: 173 against 183 ms per pass (profiles/r03x vs r03w).
   // DADA2HIP_V2_GRAPH=1 brings the graphs back (a host that is short of cycles: 8 instead of 25 ms of enqueue per pass).
-  static bool graph_off() { const char *e = getenv("DADA2HIP_V2_GRAPH"); return !(e && atoi(e) != 0); }
+  static bool graph_off() { return !knobs().v2_graph; }
   void v2_enqueue_chain(int nlev, bool with_compare, bool store) {
     const auto t_enq = clk::now();
     EnqRec rec{-1, -1, with_compare};
@@ -1818,10 +1868,11 @@ struct Run {
   }
 
   // run_dada's loop (Rmain.cpp:312-331) with the device in charge of the rounds
-  void run_v2(int max_clust) {
+  // resume: taking over from the persistent tail in mid-run (its entry barrier failed); first: nothing has been evaluated yet
+  void run_v2(int max_clust, bool resume = false, bool first = true) {
     auto t0 = clk::now();
-    st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
-    v2_enqueue_chain(0, false, false);                        // b_p_update after round 0 + the first b_bud
+    if (!resume) st.nstored = (uint64_t)N;                     // round 0 keeps every comparison (E_minmax starts at -999)
+    if (first) v2_enqueue_chain(0, false, false);             // b_p_update after round 0 + the first b_bud
     bool done = false;
     double t_decide = 0, t_halt = 0, t_top = 0;
     long n_halt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_big = 0, n_kind[5] = {0, 0, 0, 0, 0};
@@ -1839,7 +1890,7 @@ struct Run {
         fprintf(stderr, "[v2] blk %ld halt %d nclust %d nlev %d nsh %d cnt %d %d %d %d nbatch %d slot %d birth %d found %d nties %d p %.3e blk %d\n", seq,
                 b.halt, b.nclust, b.nlev, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],
                 b.bud.nties[0], b.bud.best_p[0], b.blk_count);
-      if (b.halt == H2_HOST_DECIDE && getenv("DADA2HIP_V2_SUMMARY")) {   // what kind of decision came back to the host
+      if (b.halt == H2_HOST_DECIDE && knobs().v2_summary) {   // what kind of decision came back to the host
         const int nt = b.bud.nties[0];
         bool zero = b.bud.found[0] && nt > 1 && nt <= BUD_TIES, in0 = false, pristine = true;
         int cmin = INT32_MAX, ncmin = 0;
@@ -1921,7 +1972,7 @@ struct Run {
       }
       if (b.halt == H2_NONE) t_decide += ms_since(t_dec); else t_halt += ms_since(t_dec);
     }
-    if (getenv("DADA2HIP_V2_SUMMARY"))
+    if (knobs().v2_summary)
       fprintf(stderr, "[v2] blocks %ld  halts none/nobirth/host/more/cap/max/need-compare %ld %ld %ld %ld %ld %ld %ld  chains without compare %llu  big-mover blocks %ld  ms: wait %.1f replay %.1f "
                       "enqueue %.1f decide %.1f halt-handling %.1f top-up %.1f total %.1f  moves %llu misses %llu  host decisions other/zero-ties in partition 0 at "
                       "their first slots/... moved/elsewhere, one in the lowest partition/... several %ld %ld %ld %ld %ld\n", v2_cons, n_halt[0], n_halt[1],
@@ -1929,11 +1980,9 @@ struct Run {
               ms_since(t0), (unsigned long long)st.nmoves, (unsigned long long)v2_miss_launches, n_kind[0], n_kind[1], n_kind[2], n_kind[3], n_kind[4]);
     sync_spin(s->stream);                                      // no-op launches queued behind the final halt
     if (v2_trace_seq >= 0 && v2_trace.p) {                     // dump the traced round's stamps (tools/trace_round.py reads them)
-      const char *e = getenv("DADA2HIP_V2_TRACE");
-      const char *colon = e ? strchr(e, ':') : nullptr;
       std::vector<unsigned long long> h((size_t)TRACE_KERNELS * TRACE_BLOCKS * 8);
       D2_HIP(hipMemcpy(h.data(), v2_trace.p, h.size() * 8, hipMemcpyDeviceToHost));
-      if (FILE *f = fopen(colon ? colon + 1 : "dada2hip_trace.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      if (FILE *f = fopen(knobs().v2_trace_file.c_str(), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
     st.ms_bookkeep += ms_since(t0);
   }
@@ -2026,8 +2075,8 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       b0.reads += s->h_reads[i];
       if (s->h_reads[i] > mx) { b0.center = (uint32_t)i; mx = s->h_reads[i]; }
     }
-    run.plain = getenv("DADA2HIP_NO_SPECULATION") != nullptr || b0.raw[0] != b0.center || shard != nullptr;
-    run.no_auto = run.plain || getenv("DADA2HIP_NO_AUTOBIRTH") != nullptr;
+    run.plain = knobs().no_speculation || b0.raw[0] != b0.center || shard != nullptr;
+    run.no_auto = run.plain || knobs().no_autobirth;
     const uint8_t one = 1;
     D2_HIP(hipMemcpy(run.P.slot0, &one, 1, hipMemcpyHostToDevice));   // unique 0 sits in slot 0 of partition 0
     run.push_cluster(0, true, true);
@@ -2074,16 +2123,16 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   const int LV = D.maxlen;
   // work slots grouped in chunks that share a centre: 64 (one wave of the lane kernel) or the cooperative kernel's
   // alignments per wave
-  const char *fk = getenv("DADA2HIP_NW_KERNEL");
+  const int fk = knobs().nw_kernel;
   const bool coop_fin_ok = opts->band_size != 0 && nw_ad_lds_bytes(D, run.ap) > 0 && nw_ad_lds_bytes(D, run.ap) <= 150 * 1024;
   bool coop_fin = coop_fin_ok && N < COOP_MAX_BATCH;
-  if (fk && !strcmp(fk, "lane")) coop_fin = false;
-  if (fk && !strcmp(fk, "coop") && coop_fin_ok) coop_fin = true;
+  if (fk == NWK_LANE) coop_fin = false;
+  if (fk == NWK_COOP && coop_fin_ok) coop_fin = true;
   // band windows too wide for the LDS-pointer kernel: the wide anti-diagonal kernel (same rule as compare_round)
   bool wide_fin = !coop_fin_ok && opts->band_size > 0 && nw_adw_ok(D, run.ap) && nw_adw_lds_bytes(D, run.ap) <= 150 * 1024 &&
                   run.wclass != 33 && run.wclass != 65 && N < (1 << 20);
-  if (fk && !strcmp(fk, "lane")) wide_fin = false;
-  if (fk && !strcmp(fk, "wide")) wide_fin = opts->band_size > 0 && nw_adw_ok(D, run.ap) && nw_adw_lds_bytes(D, run.ap) <= 150 * 1024;
+  if (fk == NWK_LANE) wide_fin = false;
+  if (fk == NWK_WIDE) wide_fin = opts->band_size > 0 && nw_adw_ok(D, run.ap) && nw_adw_lds_bytes(D, run.ap) <= 150 * 1024;
   if (wide_fin) { coop_fin = false; ensure_adw_scratch(s, run.ap); }
   const size_t per = coop_fin ? (size_t)nw_ad_apw(D, run.ap) : (wide_fin ? (size_t)nw_adw_apw(D, run.ap) : 64);
   std::vector<int32_t> work, chunk_centre, centre_of_cluster(C);
@@ -2199,7 +2248,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     D2_HIP(hipMemcpyAsync(pair_cls.data(), d_bcls.p, (size_t)nb, hipMemcpyDeviceToHost, stq));
     D2_HIP(hipStreamSynchronize(stq));
     bool coop_b = coop_fin_ok && !wide_fin;          // one pair per chunk: the cooperative kernels need no 64-wide batch
-    if (fk && !strcmp(fk, "lane")) coop_b = false;
+    if (fk == NWK_LANE) coop_b = false;
     const size_t pern = coop_b ? (size_t)nw_ad_apw(D, run.ap) : (wide_fin ? (size_t)nw_adw_apw(D, run.ap) : 64);
     std::vector<int32_t> w_gl((size_t)nb * 64, -1), w_nw((size_t)nb * pern, -1);
     int n_gl = 0, n_nw = 0;
@@ -2586,11 +2635,11 @@ int dada2hip_sample_compare(dada2hip_sample *s, int32_t centre, const double *er
       for (int i = 0; i < N; i++) { run.st.nshroud += hc[i] == CLS_SHROUD; run.st.nskipped += hc[i] == CLS_SKIP; }
     }
     if (n_nw > 0) {
-      const char *f = getenv("DADA2HIP_NW_KERNEL");
+      const int f = knobs().nw_kernel;
       const bool coop_ok = nw_ad_lds_bytes(D, run.ap) > 0 && nw_ad_lds_bytes(D, run.ap) <= 150 * 1024;
       bool coop = coop_ok && n_nw < 65536;
-      if (f && !strcmp(f, "lane")) coop = false;
-      if (f && !strcmp(f, "coop") && coop_ok) coop = true;
+      if (f == NWK_LANE) coop = false;
+      if (f == NWK_COOP && coop_ok) coop = true;
       D2_HIP(hipEventRecord(s->ev0, stq));
       if (coop)
         launch_nw_ad(D, centre, nullptr, s->d_nw_list.p, nullptr, n_nw, nullptr, nullptr, run.ap, s->d_err.p, s->d_lambda.p,
@@ -2720,7 +2769,7 @@ struct BimPair { int32_t left, right, left_oo, right_oo, ham; };
 // get_lr / get_ham_endsfree results.  parents[j] lists the k's (ascending); res[j][t] belongs to parents[j][t].
 void bimera_pairs(int ncol, const char *const *seqs, const std::vector<std::vector<int32_t>> &parents, int match, int mismatch,
                   int gap_p, int max_shift, int allow_one_off, int device, std::vector<std::vector<BimPair>> &res) {
-  static const bool times = [] { const char *e = getenv("DADA2HIP_BIMERA_TIMES"); return e && !strcmp(e, "1"); }();
+  const bool times = knobs().bimera_times;
   auto t0 = clk::now();
   double ms_dev = 0, ms_unpack = 0, ms_pack = 0;
   res.assign(ncol, {});
@@ -2749,8 +2798,8 @@ void bimera_pairs(int ncol, const char *const *seqs, const std::vector<std::vect
   // (reads <= 2 047 nt, band window <= 127 cells); otherwise - and under DADA2HIP_NW_KERNEL=lane|wide, the tests' way of
   // running both - the lane kernel with its move strings kept and k_bimera_lr behind it.
   const bool coop = [&] {
-    const char *f = getenv("DADA2HIP_NW_KERNEL");
-    if (f && (!strcmp(f, "lane") || !strcmp(f, "wide"))) return false;
+    const int f = knobs().nw_kernel;
+    if (f == NWK_LANE || f == NWK_WIDE) return false;
     const size_t b = nw_ad_lr_lds_bytes(s->D, ap);
     return b > 0 && b <= 150 * 1024;
   }();
@@ -2839,7 +2888,7 @@ int dada2hip_table_bimera2(int32_t nrow, int32_t ncol, const int32_t *mat, const
     select_device(device);
     // which (query, parent) pairs does the table ask for?  (chimera.cpp:117-118: a parent is more abundant than the query
     // by min_fold and at least min_abund in some sample where the query is present)
-    static const bool times = [] { const char *e = getenv("DADA2HIP_BIMERA_TIMES"); return e && !strcmp(e, "1"); }();
+    const bool times = knobs().bimera_times;
     auto t0 = clk::now();
     std::vector<std::vector<int32_t>> parents(ncol);
     parallel_for((size_t)ncol, 8, [&](size_t lo, size_t hi) {

@@ -422,6 +422,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   volatile int32_t *hcons;                          // pinned host word: result blocks the host has finished with
   volatile int32_t *hexit;                          // pinned host word: ordinal of the last k3_tail launch that has ended
   unsigned long long *ktime;                        // [KT_N] phase clocks of block 0 (DADA2HIP_PROFILE=1), else nullptr
+  int32_t fail_ordinal;                             // test knob (DADA2HIP_V3_FAIL_ENTRY): the k3_tail launch of this ordinal fails its entry barrier (0: none)
 };
 
 // Grid barrier of the persistent tail kernel: one monotonic arrival counter and one generation word, each on a cache line of
@@ -441,12 +442,13 @@ void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
 // b_p_update + b_bud arg-min (grid) ; ties, decision, birth, plan of the coming round, publication (one block)
 void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st);
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st);            // the host's decision applied + plan; resumes
-void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list = false);   // keep_list: the candidates k2_pupdate listed stay valid
+void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list = false, bool compare_done = false);   // keep_list: the candidates k2_pupdate listed stay valid
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st);
 // the persistent round tail: rounds run back to back inside ONE launch of `grid` co-resident blocks until a compare is due, the
 // device halts or the host's ring fills up.  first: the evaluation behind round 0 (no shuffle).  ordinal: this launch's number.
 int tail_grid(int N, int device);
+int tail_resident_max(int device);                  // blocks of k3_tail the device can hold at once (occupancy query; 0 = unknown)
 void launch3_tail(const Eng2 &E, int grid, bool first, int ordinal, uint32_t init_reads, hipStream_t st);
 
 // get_lr + get_ham_endsfree (chimera.cpp:211-293) on the move strings k_nw left behind: out[slot] = {left, right, left_oo, right_oo, ham}

@@ -14,6 +14,8 @@
 #include <thread>
 #include <vector>
 
+#include "knobs.h"
+
 #include <unistd.h>
 
 #include <hip/hip_runtime.h>
@@ -65,7 +67,7 @@ class HostPool {
     int n = (int)std::thread::hardware_concurrency();
     if (n <= 0) n = 1;
     if (n > 64) n = 64;                                  // memory-bound copies: 16 / 32 / 64 threads = 55 / 34 / 25 ms for the 1M-unique upload (profiles/r02q_bench_cfg3_threads*.json)
-    if (const char *e = getenv("DADA2HIP_HOST_THREADS")) n = std::max(1, atoi(e));
+    if (knobs().host_threads > 0) n = knobs().host_threads;
     nthreads_ = n;
     spawn();
   }
@@ -243,8 +245,8 @@ class AllocCache {
 
  private:
   AllocCache() {
-    if (const char *e = getenv("DADA2HIP_ALLOC_CACHE")) enabled_ = atoi(e) != 0;
-    if (const char *e = getenv("DADA2HIP_ALLOC_CACHE_GB")) cap_ = (size_t)atoll(e) << 30;
+    if (knobs().alloc_cache >= 0) enabled_ = knobs().alloc_cache != 0;
+    if (knobs().alloc_cache_gb >= 0) cap_ = (size_t)knobs().alloc_cache_gb << 30;
   }
   struct Blk { int dev; size_t cls; };
   // cached device bytes are capped at a third of the device's memory (DADA2HIP_ALLOC_CACHE_GB overrides)

@@ -14,6 +14,7 @@
 
 #include "engine.h"
 #include "gcn.h"
+#include "knobs.h"
 #include "ppois.h"
 
 namespace d2 {
@@ -239,7 +240,7 @@ void launch_screen(const SampleDev &S, int centre, const ScreenParams &sp, const
                    int32_t *d_gl_list, int32_t *d_counters, uint32_t *d_ctab, bool build_table, const int32_t *d_centre_dev,
                    hipStream_t st) {
   if (build_table) hipLaunchKernelGGL(k_centre_table, dim3(1), dim3(256), 0, st, S, centre, d_ctab);
-  static const int grid_cap = [] { const char *e = getenv("DADA2HIP_SCREEN_GRID"); return e ? atoi(e) : 2048; }();
+  const int grid_cap = std::max(1, knobs().screen_grid);
   int grid = std::min((S.N + 15) / 16, grid_cap);
   int iters = ((S.N + 15) / 16 + grid - 1) / grid;
   int cap = iters * 16;
@@ -1448,7 +1449,7 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   a.nwork_host = nwork_host; a.ap = ap; a.err = d_err; a.lam = d_lambda; a.ham = d_ham;
   a.view = d_view; a.LV = LV; a.view_by_chunk = view_by_chunk; a.centre_dev = d_centre_dev; a.stop_dev = d_stop_dev;
 #ifdef DADA2HIP_PROFILING   // `make prof` only (libdada2hip_prof.so, tools/nw_phases.py): skipping phases voids the results
-  { const char *e = getenv("DADA2HIP_AD_DEBUG"); a.moves_stride = e ? atoi(e) : 0; }
+  a.moves_stride = knobs().ad_debug;
 #endif
   if (batch) {
     a.batch_on = batch->on; a.batch_n = batch->n; a.batch_list = batch->list; a.batch_centre = batch->centre; a.batch_bbuf = batch->bbuf;
@@ -1541,7 +1542,7 @@ int nw_ad_apw(const SampleDev &S, const AlignParams &ap) { return ad_geom(ap.ban
 size_t nw_ad_lds_bytes(const SampleDev &S, const AlignParams &ap) {
   // (factor offsets are u16: 16 * ncol * 8 < 65 536.)  The global aligner (endsfree = 0: C_nwalign only) stays on the lane
   // kernels; the homopolymer-gap aligner of dada() runs here unless DADA2HIP_AD_HOMO=0 sends it back to them.
-  const bool homo_ok = [] { const char *e = getenv("DADA2HIP_AD_HOMO"); return !(e && !strcmp(e, "0")); }();   // (read per call: the tests flip it)
+  const bool homo_ok = knobs().ad_homo;
   if (ap.band <= 0 || S.maxlen > 2047 || ap.ncol > 500 || S.ad_waves <= 0 || !ap.endsfree || (!ap.plain() && !homo_ok)) return 0;
   const int W = 2 * ap.band + (S.maxlen - S.minlen) + 1;
   if (W > 127) return 0;

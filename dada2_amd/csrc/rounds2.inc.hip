@@ -1237,7 +1237,14 @@ __global__ __launch_bounds__(1024) void k2_host_birth(Eng2 E, int raw, int from)
   __syncthreads();
   if (threadIdx.x == 0) *E.sig_n = 0;
 }
-__global__ void k2_resume(Eng2 E, int keep_list) { E.ctl->state = 0; E.ctl->halt = H2_NONE; if (!keep_list) *E.sig_n = 0; }
+// compare_done: the batch compare the control block still announces has run already (it stood in front of a persistent launch
+// that gave up at its entry barrier): the launch chains that take over must not run it again - k2_batch_lists would append every
+// pair to the work lists a second time
+__global__ void k2_resume(Eng2 E, int keep_list, int compare_done) {
+  E.ctl->state = 0; E.ctl->halt = H2_NONE;
+  if (!keep_list) *E.sig_n = 0;
+  if (compare_done) { E.ctl->nbatch = 0; E.ctl->need_compare = 0; if (!E.align_at_commit) E.ctl->nalign = 0; }
+}
 
 // ---- k-mer screen against the batch's centres ---------------------------------------------------------------------------
 // 16 lanes per unique as in k_screen, but one pass over the unique's k-mer record serves up to KB_MAX centres: the centre
@@ -1448,7 +1455,9 @@ void launch2_eval(const Eng2 &E, int nlev, uint32_t init_reads, hipStream_t st) 
 void launch2_host_birth(const Eng2 &E, int raw, int from, hipStream_t st) {
   hipLaunchKernelGGL(k2_host_birth, dim3(1), dim3(1024), 0, st, E, raw, from);
 }
-void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list) { hipLaunchKernelGGL(k2_resume, dim3(1), dim3(1), 0, st, E, keep_list ? 1 : 0); }
+void launch2_resume(const Eng2 &E, hipStream_t st, bool keep_list, bool compare_done) {
+  hipLaunchKernelGGL(k2_resume, dim3(1), dim3(1), 0, st, E, keep_list ? 1 : 0, compare_done ? 1 : 0);
+}
 void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t *d_out_ji, double *d_out_lam, int32_t *d_nout,
                      int cap, hipStream_t st) {
   hipLaunchKernelGGL(k2_posthoc, dim3((E.S.N + 255) / 256), dim3(256), 0, st, E, d_cluster_of_centre, d_out_ji, d_out_lam, d_nout, cap);

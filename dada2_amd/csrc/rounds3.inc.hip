@@ -32,16 +32,19 @@ struct TailLds {
   int last, ok;
 };
 
-static __device__ __forceinline__ void tail_fail(const Eng2 &E) {
+// code: TAIL_FAIL_ENTRY = the launch's entry barrier (not every block became resident: nothing has changed yet, the host sends the
+// run to the launch chains), TAIL_FAIL_LATE = a barrier inside a round (the run is lost)
+enum : uint32_t { TAIL_FAIL_ENTRY = 1u, TAIL_FAIL_LATE = 2u };
+static __device__ __forceinline__ void tail_fail(const Eng2 &E, uint32_t code) {
   // a barrier gave up: halt the device-side progression so that the launches queued behind this one do nothing
-  gcn_store_agent(&E.psync->fail, 1u);
+  gcn_store_agent(&E.psync->fail, code);
   E.ctl->state = 1; E.ctl->halt = H2_FAIL;
 }
 
 // Grid barrier with a serial section: every block arrives; the last one runs `serial` (the whole block, block barriers allowed)
 // between its acquire and the release of the others.  Returns false when the wait ran into its bound (every block then leaves).
 template <int BS, typename F>
-static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, uint32_t &epoch, int G, F &&serial) {
+static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, uint32_t &epoch, int G, F &&serial, uint32_t fail_code = TAIL_FAIL_LATE) {
   PSync *ps = E.psync;
   gcn_drain_stores();                                   // every wave: its own stores have left the CU
   __syncthreads();
@@ -61,8 +64,8 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
           gcn_poll_pause();
           if ((n & 63u) == 0u && (gcn_load_agent(&ps->fail) != 0u || gcn_wall_clock() - t0 > (unsigned long long)(GRID_WAIT_S * GCN_WALL_HZ))) { ok = 0; break; }
         }
-        if (!ok) tail_fail(E);
-      }
+        if (!ok) tail_fail(E, fail_code);
+      } else if (fail_code == TAIL_FAIL_ENTRY && gcn_load_agent(&ps->fail) != 0u) ok = 0;   // (the others gave up waiting for this block: leave with them)
       gcn_acquire_agent();
     } else {
       // one block: no other block to wait for, but the phase that follows reads through this CU's L1 what device-scope atomics
@@ -103,6 +106,10 @@ __global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *E.hexit = ordinal;
     return;
   }
+  if (ordinal == E.fail_ordinal) {                       // test knob (DADA2HIP_V3_FAIL_ENTRY): what a launch that cannot become co-resident leaves behind
+    if (blockIdx.x == 0 && threadIdx.x == 0) tail_fail(E, TAIL_FAIL_ENTRY);
+    return;
+  }
   uint32_t epoch = E.psync->gen;                         // barriers completed by earlier launches (arrive == gen * G between launches)
   // entry: every block is resident before any state changes, and ONE block decides whether the host's ring takes the first
   // result block of this launch (the host may still be reading the slot it goes to)
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, 
           ctl->kexit = ex;
           ctl->need_compare = 0;                          // the compare of the coming round, if it needed one, ran in front of this launch
         }
-      }))
+      }, TAIL_FAIL_ENTRY))
     return;
   if (ctl->kexit) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *E.hexit = ordinal;
@@ -175,6 +182,21 @@ __global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, 
 #undef KT_LAP
 }
 
+// How many blocks of the persistent tail can be resident on the device at once (0: the query failed).  The launch is an ordinary
+// one - nothing but this check and the bounded entry barrier stands between a grid that cannot be co-resident and a hang.
+int tail_resident_max(int device) {
+  static int cap[64] = {0};
+  const int d = device & 63;
+  if (!cap[d]) {
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k3_tail, 1024, sizeof(TailLds<1024>)) != hipSuccess ||
+        hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    cap[d] = std::max(0, per_cu) * std::max(1, prop.multiProcessorCount);
+    if (!cap[d]) cap[d] = -1;
+  }
+  return std::max(0, cap[d]);
+}
 int tail_grid(int N, int device) {
   static int ncu[64] = {0};
   const int d = device & 63;

@@ -24,6 +24,18 @@
  * kept where one exists).  Inputs are borrowed for the duration of the call only.  A result is
  * owned by the library until dada2hip_result_free().  There is NO CPU fallback: every entry point
  * that computes fails with DADA2HIP_ERR_DEVICE when no gfx950 device is usable.
+ *
+ * Environment.  The library reads its DADA2HIP_* variables in ONE place (dada2_amd/csrc/knobs.h), once per boundary call,
+ * into an immutable snapshot; none of them changes a result.  Supported (the parity tests sweep them):
+ *   DADA2HIP_ENGINE=classic            one centre per round, a host round trip per decision (round 1's engine)
+ *   DADA2HIP_V2_TAIL=chain             the round tail as launch chains instead of the persistent kernel
+ *   DADA2HIP_V3_OVERLAP=0|1            the next batch's compare under the persistent tail on a second stream (default: on)
+ *   DADA2HIP_NW_KERNEL=lane|coop|wide  force one aligner family;  DADA2HIP_AD_HOMO=0  homopolymer gaps on the lane kernels
+ *   DADA2HIP_WAIT=block, DADA2HIP_WAIT_TIMEOUT_S=<s>   sleep instead of spin while waiting; bound of every device wait
+ *   DADA2HIP_HOST_THREADS=<n>, DADA2HIP_ALLOC_CACHE=0, DADA2HIP_ALLOC_CACHE_GB=<n>   marshalling pool, allocation cache
+ *   DADA2HIP_PROFILE=1, DADA2HIP_V2_SUMMARY, DADA2HIP_V2_DEBUG   per-launch device times in the stats; traces on stderr
+ * Test / tuning knobs (sizes of rings and grids, forced growth paths, injected failures) are listed with their meaning in
+ * knobs.h and DESIGN.md §10b; they are not part of the interface.
  */
 #ifndef DADA2HIP_H
 #define DADA2HIP_H
@@ -102,9 +114,17 @@ typedef struct dada2hip_stats {
    * device time of those launches and what block 0 of them spent in each phase (barriers = waiting for the other blocks,
    * which includes the serial end of the round run by the last arriver) */
   uint64_t tail_launches, tail_pauses, tail_levels;
-  uint32_t tail_blocks, tail_reserved;
+  uint32_t tail_blocks;
+  uint32_t tail_fallbacks;   /* persistent launches whose entry barrier failed (blocks not co-resident): the run went on on the launch chains */
   double dev_ms_tail, tail_ms_entry, tail_ms_shuffle0, tail_ms_shuffle_more, tail_ms_pupdate, tail_ms_barriers, tail_ms_birth,
       tail_ms_publish, tail_ms_release;
+  /* the NEXT batch's compare under the persistent tail (second stream): prefetch compares launched; rounds whose centre came out
+   * of a prefetched batch; how often the tail had to spin for a prefetch still in flight / left its launch for one; centres
+   * prefetched; threads per block of the tail; 1 if the overlap was on.  Under DADA2HIP_PROFILE=1: device time of the
+   * prefetch compares' screen and aligner launches (they run INSIDE the interval of dev_ms_tail) */
+  uint64_t pf_compares, pf_hits, pf_waits, pf_exits, pf_centres;
+  uint32_t tail_threads, overlap_on;
+  double dev_ms_pf_screen, dev_ms_pf_nw;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------

@@ -150,6 +150,7 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipDeviceGetPCIBusId(char *b, int n, int d) { snprintf(b, n, "emu%d_%d", d, (int)getpid()); return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::memset(p, 0, sizeof *p); p->multiProcessorCount = 8; p->clockRate = 1000000; return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = *tot = (size_t)16 << 30; return hipSuccess; }
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 1; return hipSuccess; }
 inline hipError_t hipDeviceTotalMem(size_t *tot, int) { *tot = (size_t)16 << 30; return hipSuccess; }
 // EMU_GUARD=1: every "device" allocation ends at an inaccessible page, so the first store past a buffer faults where it
 // happens (the fatal-signal handler of emu.cpp prints the frame) instead of corrupting the host heap

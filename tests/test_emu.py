@@ -195,3 +195,81 @@ def test_emulated_option_sweep_with_user_scores_and_sse1(emu_lib, nw_kernel):
 
 def test_emulated_band_geometries(emu_lib):
     _seeded_through_emulator(emu_lib, EMU_GEOMETRY_CASES, {"DADA2HIP_NW_KERNEL": "coop"})
+
+
+HOOKS_CODE = (
+    "import sys\n"
+    "sys.path[:0] = [%r, %r]\n"
+    "from dada2_amd import _lib\n"
+    "if %r: _lib.LIB_PATH = %r\n"
+    "from helpers import case_inputs, assert_results_equal\n"
+    "from dada2_amd import api\n"
+    "d, err, pri, o, exp, meta = case_inputs('sam1F_default')\n"
+    "for k in %r:\n"
+    "    polls = []\n"
+    "    def stop():\n"
+    "        polls.append(1)\n"
+    "        return len(polls) >= k\n"
+    "    try:\n"
+    "        api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o, should_abort=stop)\n"
+    "        raise SystemExit('not aborted')\n"
+    "    except _lib.Dada2HipError as ex:\n"
+    "        assert ex.code == 5 and 'aborted' in str(ex), (ex.code, str(ex))\n"
+    "    assert len(polls) == k, (len(polls), k)\n"
+    "    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"          # the same process, right behind the abort
+    "    assert_results_equal(got, exp)\n"
+    "lines = []\n"
+    "got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o, verbose=True, log=lines.append, should_abort=lambda: False)\n"
+    "assert_results_equal(got, exp)\n"
+    "text = ''.join(lines)\n"
+    "assert text.count('New Cluster C') == got.nclust - 1, text\n"                      # Rmain.cpp:317, once per birth
+    "assert 'ALIGN: 8655 aligns, 3032 shrouded (%%d raw).' %% len(d.seqs) in text, text\n"   # Rmain.cpp:333 with the reference's counters
+    "class Boom(Exception): pass\n"
+    "def bad(): raise Boom('from the callback')\n"
+    "try:\n"
+    "    api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o, should_abort=bad)\n"
+    "    raise SystemExit('callback exception lost')\n"
+    "except Boom: pass\n"
+    "assert_results_equal(api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o), exp)\n"
+    "print('hooks: ok')\n"
+)
+
+ENGINE_ENVS = [{}, {"DADA2HIP_V3_GRID": "3"}, {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_ENGINE": "classic"}]
+ENGINE_IDS = ["persistent-tail", "persistent-tail-grid3", "chains", "classic-engine"]
+
+
+@pytest.mark.parametrize("env", ENGINE_ENVS, ids=ENGINE_IDS)
+def test_emulated_abort_hook_and_verbose_log_on_every_engine(emu_lib, env):
+    """dada2hip_hooks (Rcpp::checkUserInterrupt / the verbose Rprintfs, src/Rmain.cpp:317-333): a run aborted at its first, third and
+    eighth round returns DADA2HIP_ERR_ABORTED with launches still queued, the next run in the same process equals the golden; the
+    log carries one line per birth and the reference's nalign / nshroud."""
+    code = HOOKS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib, (1, 3, 8))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "hooks: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("env", [{"DADA2HIP_V3_FAIL_ENTRY": "1"}, {"DADA2HIP_V3_FAIL_ENTRY": "2", "DADA2HIP_V3_GRID": "3"},
+                                 {"DADA2HIP_V3_FAIL_ENTRY": "4", "DADA2HIP_V2_NBUF": "1"}],
+                         ids=["first-launch", "second-launch-grid3", "fourth-launch-nbuf1"])
+def test_emulated_entry_barrier_failure_continues_on_the_launch_chains(emu_lib, env):
+    """A persistent launch whose blocks do not all become resident gives up at its entry barrier, before anything has changed
+    (DADA2HIP_V3_FAIL_ENTRY=n makes the n-th launch do exactly that): the run goes on on the launch chains and equals the golden."""
+    code = (
+        "import sys\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from dada2_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "from helpers import case_inputs, assert_results_equal\n"
+        "from dada2_amd import api\n"
+        "d, err, pri, o, exp, meta = case_inputs('sam1F_default')\n"
+        "got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"
+        "assert_results_equal(got, exp)\n"
+        "assert got.stats['tail_fallbacks'] == 1, got.stats['tail_fallbacks']\n"
+        "print('fallback: ok', got.stats['tail_launches'])\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "fallback: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

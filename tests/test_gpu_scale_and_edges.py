@@ -442,3 +442,76 @@ def test_library_first_then_torch_share_one_hip_runtime():
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
+
+
+# ---- the boundary's callbacks and the default engine's way out ------------------------------------------------
+ENGINE_ENVS = [{}, {"DADA2HIP_V3_GRID": "3"}, {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_ENGINE": "classic"}]
+ENGINE_IDS = ["persistent-tail", "persistent-tail-grid3", "chains", "classic-engine"]
+
+
+@pytest.mark.parametrize("env", ENGINE_ENVS, ids=ENGINE_IDS)
+def test_abort_hook_then_clean_run_and_verbose_log(api, env, monkeypatch):
+    """dada2hip_hooks: should_abort (= Rcpp::checkUserInterrupt, src/Rmain.cpp:330) ends a run at its 1st / 3rd / 8th round with
+    DADA2HIP_ERR_ABORTED while launches of that run are still queued (the persistent slot held); the NEXT run in the same process
+    equals the golden.  log (= the verbose Rprintfs, Rmain.cpp:317,333) carries one line per birth and the reference's counters."""
+    from helpers import case_inputs
+    from dada2_amd import _lib
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d, err, pri, o, exp, meta = case_inputs("sam1F_default")
+    for k in (1, 3, 8):
+        polls = []
+
+        def stop():
+            polls.append(1)
+            return len(polls) >= k
+        with pytest.raises(_lib.Dada2HipError) as ei:
+            api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o, should_abort=stop)
+        assert ei.value.code == 5 and "aborted" in str(ei.value)
+        assert len(polls) == k
+        assert_results_equal(api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o), exp)
+    lines = []
+    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o, verbose=True, log=lines.append, should_abort=lambda: False)
+    assert_results_equal(got, exp)
+    text = "".join(lines)
+    assert text.count("New Cluster C") == got.nclust - 1
+    assert "ALIGN: 8655 aligns, 3032 shrouded (%d raw)." % len(d.seqs) in text
+
+
+@pytest.mark.parametrize("nth", [1, 2, 5])
+def test_injected_entry_barrier_failure_continues_on_the_launch_chains(api, nth, monkeypatch):
+    from helpers import case_inputs
+    monkeypatch.setenv("DADA2HIP_V3_FAIL_ENTRY", str(nth))
+    monkeypatch.setenv("DADA2HIP_V3_GRID", "7")
+    d, err, pri, o, exp, meta = case_inputs("sam1F_default")
+    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)
+    assert_results_equal(got, exp)
+    assert got.stats["tail_fallbacks"] == 1
+
+
+def test_another_tenant_on_the_gpu_sends_the_run_to_the_launch_chains(api, monkeypatch):
+    """k3_tail needs all its blocks resident at once.  With another tenant holding half of the CUs (tests/glue/occupy.hip: 128
+    blocks on a stream of their own that each claim a CU's whole LDS for a few seconds) a 250-block launch cannot be: its entry
+    barrier gives up after its 2-second bound with nothing changed, and the run continues on the launch chains - the result is
+    the golden, not DADA2HIP_ERR_DEVICE."""
+    import ctypes
+    import time
+    from helpers import case_inputs
+    so = os.path.join(ROOT, "tests", "glue", "liboccupy.so")
+    if not os.path.exists(so):
+        pytest.skip("tests/glue/liboccupy.so not built")
+    occ = ctypes.CDLL(so)
+    occ.occupy_start.argtypes = [ctypes.c_int, ctypes.c_double]
+    d, err, pri, o, exp, meta = case_inputs("sam1F_default")
+    assert_results_equal(api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o), exp)   # (warm: allocations cached)
+    monkeypatch.setenv("DADA2HIP_V3_GRID", "250")
+    assert occ.occupy_start(128, 6000.0) == 0
+    try:
+        time.sleep(0.3)                                                    # (its blocks are resident)
+        t0 = time.time()
+        got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)
+        dt = time.time() - t0
+    finally:
+        assert occ.occupy_wait() == 0
+    assert_results_equal(got, exp)
+    assert got.stats["tail_fallbacks"] == 1, (got.stats["tail_fallbacks"], dt)
