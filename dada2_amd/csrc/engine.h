@@ -448,8 +448,8 @@ void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t 
 // the persistent round tail: rounds run back to back inside ONE launch of `grid` co-resident blocks until a compare is due, the
 // device halts or the host's ring fills up.  first: the evaluation behind round 0 (no shuffle).  ordinal: this launch's number.
 int tail_grid(int N, int device);
-int tail_resident_max(int device);                  // blocks of k3_tail the device can hold at once (occupancy query; 0 = unknown)
-void launch3_tail(const Eng2 &E, int grid, bool first, int ordinal, uint32_t init_reads, hipStream_t st);
+int tail_resident_max(int device, int bs);                  // blocks of k3_tail the device can hold at once (occupancy query; 0 = unknown)
+void launch3_tail(const Eng2 *d_E, int grid, int bs, bool first, int ordinal, uint32_t init_reads, hipStream_t st);   // d_E: device copy of the argument block; bs: 1024 or 512 threads per block
 
 // get_lr + get_ham_endsfree (chimera.cpp:211-293) on the move strings k_nw left behind: out[slot] = {left, right, left_oo, right_oo, ham}
 void launch_bimera_lr(const SampleDev &S, const int32_t *d_chunk_centre, const int32_t *d_work, int nwork, const uint8_t *d_moves,

@@ -46,6 +46,11 @@ static __device__ __forceinline__ int gcn_wave_shl1(int old, int src) {
   return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xF, 0xF, BOUND_CTRL);
 }
 static __device__ __forceinline__ int gcn_readfirstlane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Values the optimiser must not see through (no instruction): a uniform pointer / a per-lane integer that come out of an empty
+// volatile asm are not invariants of an enclosing loop any more, so nothing derived from them is hoisted out of it and kept
+// alive (spilled) across it - the persistent round-tail kernel's outer loop spans every phase of a round
+template <typename T> static __device__ __forceinline__ const T *gcn_opaque_uniform(const T *p) { asm volatile("" : "+s"(p)); return p; }
+static __device__ __forceinline__ int gcn_opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
 // The lanes of a wave execute in lockstep, so data one lane leaves in LDS is there for the others at the next instruction;
 // this marks the places where a kernel relies on that.  No instruction: it only stops the compiler from moving memory
 // operations across the point (and gives the lane-by-lane emulator its rendezvous).

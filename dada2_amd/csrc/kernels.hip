@@ -15,6 +15,7 @@
 #include "engine.h"
 #include "gcn.h"
 #include "knobs.h"
+#include "rounds_common.h"
 #include "ppois.h"
 
 namespace d2 {
@@ -2071,10 +2072,9 @@ struct StoreArgs {
 // XCD's L2 on this part - measured 1.7x slower at 1e6 uniques - so the snapshot stays a copy between launches.)
 // check_only: count the uniques that WOULD move, apply nothing (then the live partition reads can stand in for the
 // snapshot: nothing changes them during the kernel).  The speculative second shuffle of a round is such a check.
-// Reads deltas of the movers are accumulated per block in LDS (partitions < DELTA_TAB) and flushed with one global
-// atomic per touched partition: thousands of movers join the same new partition in a round, and same-address
+// Reads deltas of the movers are accumulated per block in LDS (partitions < DELTA_TAB, rounds_common.h) and flushed with one
+// global atomic per touched partition: thousands of movers join the same new partition in a round, and same-address
 // device atomics serialise.
-constexpr int DELTA_TAB = 1024;
 template <bool STORE>
 __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const uint32_t *__restrict__ creads_snap,
                                                  int32_t *__restrict__ movers, int32_t *__restrict__ nmovers,
@@ -2185,21 +2185,7 @@ __global__ __launch_bounds__(256) void k_shuffle(PartState P, SampleDev S, const
   }
 }
 
-// get_pA (pval.cpp:67-89)
-static __device__ __forceinline__ double dev_get_pA(uint32_t reads, bool prior, bool detect_singletons, double lambda,
-                                                    uint32_t hamming, uint32_t bi_reads) {
-  if (reads == 1 && !prior && !detect_singletons) return 1.;
-  if (hamming == 0) return 1.;
-  if (lambda == 0) return 0.;
-  return pp::calc_pA((int)reads, lambda * bi_reads, prior || detect_singletons);
-}
-
-// b_bud (cluster.cpp:274-350), arg-min part.  Key order: p ascending, then reads descending; exact
-// ties are resolved by the host in (partition, slot) scan order.  track 0 = all candidates, 1 = priors.
-struct BudKey { double p; uint32_t reads; };
-static __device__ __forceinline__ bool bud_better(double p, uint32_t reads, const BudKey &b) {
-  return p < b.p || (p == b.p && reads > b.reads);
-}
+// (dev_get_pA, BudKey, bud_better: rounds_common.h)
 static __device__ __forceinline__ bool bud_candidate(const PartState &P, const SampleDev &S, int r, BudParams bp) {
   if (P.slot0[r]) return false;                                          // r = 0 is skipped as "the centre" (:285)
   const uint32_t reads = S.reads[r];
@@ -2751,7 +2737,6 @@ void launch_bimera_lr(const SampleDev &S, const int32_t *d_chunk_centre, const i
                      d_nmoves, allow_one_off, max_shift, d_out);
 }
 
-#include "rounds2.inc.hip"
-#include "rounds3.inc.hip"
+#include "rounds2.inc.hip"   // (the persistent round tail, rounds3.inc.hip, is the translation unit tail.hip)
 
 }  // namespace d2

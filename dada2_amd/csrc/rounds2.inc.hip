@@ -42,8 +42,11 @@
 // the persistent tail every other block waited for those at the barrier.
 template <int BS, int U>
 static __device__ __forceinline__ int sweep_unique(int grp, int u) {
-  const long long chunk = ((long long)(grp * U + u) * (BS / 64) + (threadIdx.x >> 6)) * gridDim.x + blockIdx.x;
-  const long long r = chunk * 64 + (threadIdx.x & 63);
+  // (the thread index goes through an opaque move: inside the persistent kernel the indices - and every address derived from
+  //  them - are invariants of the round loop, and hoisted out of it they were a hundred spilled registers)
+  const int t = gcn_opaque_lane((int)threadIdx.x);
+  const long long chunk = ((long long)(grp * U + u) * (BS / 64) + (t >> 6)) * gridDim.x + blockIdx.x;
+  const long long r = chunk * 64 + (t & 63);
   return r > 0x7FFFFFF0ll ? 0x7FFFFFF0 : (int)r;
 }
 
@@ -68,6 +71,7 @@ static __device__ __forceinline__ uint32_t reads_at(const Eng2 &E, int i, int nl
   return v;
 }
 
+#ifndef D2_TAIL_TU
 // ---- round 0: every unique keeps its comparison with the first centre -----------------------------------------------
 __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restrict__ lam, const uint32_t *__restrict__ ham,
                                                  const uint8_t *__restrict__ cls, const int32_t *__restrict__ round_counters) {
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
   }
 }
 
+#endif  // D2_TAIL_TU
 // ---- store filter of a round + b_shuffle2 ------------------------------------------------------------------------------
 // STORE (first shuffle of a round): the commit of the round's cached comparisons - class from the batch's class word with
 // the greedy skip (cluster.cpp:127-130) applied with the lock state of the commit, lambda / hamming from the rows the
@@ -114,7 +119,7 @@ static __device__ __forceinline__ bool v2_idle(const Eng2 &E) {
 template <int BS>
 struct ShufLds {
   static constexpr int MOVCAP = BS, NEWCAP = BS / 2;
-  static constexpr int U = BS >= 1024 ? 4 : 2;                           // uniques per thread per group of the sweep
+  static constexpr int U = BS >= 512 ? 4096 / BS : 2;                        // uniques per thread per group of the sweep (4096 per block in the persistent tail)
   int s_n, s_base, s_an, s_abase, s_keep, s_anyinc, s_nwork;
   unsigned long long s_incmask;                                          // bit (k & 63) of every partition k whose reads rose in the previous call
   int32_t s_work[U * BS];                                                // the group's uniques that have work to do: index | class << 30
@@ -424,6 +429,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   D2_TRACE(1 + level, 4);
 }
 
+#ifndef D2_TAIL_TU
 template <bool STORE>
 __global__ __launch_bounds__(256, 8) GCN_SGPR_BUDGET(80) void k2_shuffle(Eng2 E, int level) {
   const Ctl2 *ctl = E.ctl;
@@ -525,6 +531,7 @@ __global__ __launch_bounds__(256) void k2_batch_lists(Eng2 E) {
   }
 }
 
+#endif  // D2_TAIL_TU
 // ---- b_p_update + first stage of b_bud (no "would another shuffle move" pass: the chain's shuffles are real calls) -----
 static __device__ __forceinline__ bool bud_candidate2(const Eng2 &E, int r, int nlv) {
   const PartState &P = E.P;
@@ -543,7 +550,7 @@ constexpr int PUPD_TAB = 1024;    // partitions whose per-partition facts k2_pup
 constexpr int SIG_CAP = 1024;
 template <int BS>
 struct PupdLds {
-  static constexpr int U = BS >= 1024 ? 4 : 2;                           // uniques per thread per group of the sweep
+  static constexpr int U = BS >= 512 ? 4096 / BS : 2;                        // uniques per thread per group of the sweep
   int s_nwork;
   int32_t s_work[U * BS];                                                // the group's uniques whose p-value / candidacy has to be looked at
   BudKey s_k[2][BS / 64];
@@ -678,6 +685,7 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
   for (int i = threadIdx.x; i < min(s_nsig, SIG_CAP); i += BS) E.sig_list[s_sbase + i] = s_sig[i];
   D2_TRACE(5, 3);
 }
+#ifndef D2_TAIL_TU
 __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init, BudKey *__restrict__ partial) {
   const Ctl2 *ctl = E.ctl;
   if (v2_idle(E)) return;
@@ -688,6 +696,7 @@ __global__ __launch_bounds__(256) void k2_pupdate(Eng2 E, int nlev, BudKey init,
   pupdate_body<256>(E, L, cs.nexec, init, partial);
 }
 
+#endif  // D2_TAIL_TU
 // ---- the birth, the plan of the coming round's compare, and the publication of the round's result block -----------------
 constexpr int NBUF_MAX = 64;      // batch buffers (NBUF_MAX x KB_MAX cached centres at most)
 constexpr int PLAN_PER = 8;       // significant candidates each thread of k2_birth looks at when it predicts (8192 in all)
@@ -703,12 +712,12 @@ static __device__ __forceinline__ int block_best(double p, uint32_t reads, int r
     const bool take = r2 >= 0 && (r < 0 || p2 < p || (p2 == p && (rd2 > reads || (rd2 == reads && r2 < r))));
     if (take) { p = p2; reads = rd2; r = r2; }
   }
-  const int w = threadIdx.x >> 6;
+  const int w = threadIdx.x >> 6, nwv = (int)blockDim.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) { s_p[w] = p; s_rd[w] = reads; s_r[w] = r; }
   __syncthreads();
   p = s_p[0]; reads = s_rd[0]; r = s_r[0];
-  for (int k = 1; k < 16; k++) {
+  for (int k = 1; k < nwv; k++) {
     const double p2 = s_p[k];
     const uint32_t rd2 = s_rd[k];
     const int r2 = s_r[k];
@@ -803,13 +812,13 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
   __syncthreads();
   // ---- prediction: the best keys among the listed candidates ----
   {
-    const int M = min(*E.sig_n, PLAN_PER * 1024);
+    const int M = min(*E.sig_n, PLAN_PER * (int)blockDim.x);
     double kp[PLAN_PER];
     uint32_t krd[PLAN_PER];
     int kr[PLAN_PER];
 #pragma unroll
     for (int j = 0; j < PLAN_PER; j++) {
-      const int q = tid + j * 1024;
+      const int q = tid + j * (int)blockDim.x;
       kr[j] = -1; kp[j] = 0.0; krd[j] = 0;
       if (q < M) {
         const int r = E.sig_list[q];
@@ -1043,7 +1052,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
     if ((tid & 63) == 0) { s_k[0][tid >> 6] = b0; s_k[1][tid >> 6] = b1; }
     __syncthreads();
     b0 = s_k[0][0]; b1 = s_k[1][0];
-    for (int k = 1; k < 16; k++) {
+    for (int k = 1; k < ((int)blockDim.x >> 6); k++) {
       if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
       if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
     }
@@ -1199,6 +1208,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
 #undef D2_TRB
 }
 
+#ifndef D2_TAIL_TU
 __global__ __launch_bounds__(1024) void k2_birth(Eng2 E, int nlev, BudKey init, const BudKey *__restrict__ partial, int nblocks) {
   Ctl2 *ctl = E.ctl;
   const bool halted = ctl->state != 0, starved = !E.has_compare && ctl->need_compare != 0;
@@ -1462,3 +1472,4 @@ void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t 
                      int cap, hipStream_t st) {
   hipLaunchKernelGGL(k2_posthoc, dim3((E.S.N + 255) / 256), dim3(256), 0, st, E, d_cluster_of_centre, d_out_ji, d_out_lam, d_nout, cap);
 }
+#endif  // D2_TAIL_TU

@@ -93,8 +93,13 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
   return true;
 }
 
-__global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, int ordinal) {
-  constexpr int BS = 1024;
+// The argument block of the persistent kernel lives in device memory and is read through a pointer the optimiser cannot see
+// through, afresh for every phase: its hundred-odd fields are invariants of the round loop, and hoisted out of it (which is what
+// happens to a by-value kernel argument) they were 330 spilled SGPRs of this 128-register kernel.
+static __device__ __forceinline__ const Eng2 &tail_args(const Eng2 *p) { return *gcn_opaque_uniform(p); }
+template <int BS>
+__global__ __launch_bounds__(BS, 4) void k3_tail(const Eng2 *__restrict__ Ep, BudKey init, int first, int ordinal) {
+  const Eng2 &E = *Ep;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn3[];
   TailLds<BS> &L = *(TailLds<BS> *)s_dyn3;
   Ctl2 *ctl = E.ctl;
@@ -133,19 +138,23 @@ __global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, 
   }
   KT_LAP(KT_LAUNCH);
   for (int rnd = 0;; rnd++) {
+    // (the argument block is read through a pointer the optimiser cannot see through, once per round: its hundred-odd fields are
+    //  loop invariants, and hoisted out of this loop they were 330 spilled SGPRs + 100 spilled VGPRs of a 128-register kernel)
+    const Eng2 &E = tail_args(Ep);
+    Ctl2 *ctl = E.ctl;
     const int ring = ctl->pub_seq % RING2;
     Round2Out *out = E.dblk + ring;
     int level = 0;
     if (!(first && rnd == 0)) {
       // ---- commit of the round's cached comparisons + b_shuffle2 until a call moves nothing (Rmain.cpp:320-325) ----
-      shuffle_body<true, BS>(E, L.sh, 0, 0, E.movers, out);
+      shuffle_body<true, BS>(tail_args(Ep), L.sh, 0, 0, E.movers, out);
       KT_LAP(KT_S0);
       if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
       KT_LAP(KT_S0_BAR);
       int moved = out->cnt[0];
       level = 1;
       while (level < E.max_shuffle && out->cnt[level - 1] > 0) {
-        shuffle_body<false, BS>(E, L.sh, level, moved, E.movers + (size_t)level * 3 * (size_t)E.S.N, out);
+        shuffle_body<false, BS>(tail_args(Ep), L.sh, level, moved, E.movers + (size_t)level * 3 * (size_t)E.S.N, out);
         KT_LAP(KT_SL);
         if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
         KT_LAP(KT_SL_BAR);
@@ -154,12 +163,12 @@ __global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, 
       }
     }
     // ---- b_p_update + the block minima of b_bud; the last block to arrive takes the round's decision ----
-    pupdate_body<BS>(E, L.pu, level, init, (BudKey *)E.partial);
+    pupdate_body<BS>(tail_args(Ep), L.pu, level, init, (BudKey *)E.partial);
     KT_LAP(KT_P);
     const int nlev = level;
     if (!grid_sync<BS>(E, L, epoch, G, [&]() {
           const unsigned long long tb = E.ktime ? gcn_wall_clock() : 0ull;
-          birth_body(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal);
+          birth_body(tail_args(Ep), nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal);
           if (threadIdx.x == 0) {
             ctl->pub_seq = ctl->pub_seq + 1;              // (the others find the NEXT round's block through it)
             if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, 
     if (L.last) {
       // the block that took the decision publishes it while the others are already in the next round's first phase
       const unsigned long long tp = E.ktime ? gcn_wall_clock() : 0ull;
-      publish_copy(E, out, ring, ctl->pub_seq);
+      publish_copy(tail_args(Ep), out, ring, ctl->pub_seq);
       if (threadIdx.x == 0) {
         if (leave) *E.hexit = ordinal;
         if (E.ktime) atomicAdd(&E.ktime[KT_PUBLISH], gcn_wall_clock() - tp);
@@ -184,18 +193,19 @@ __global__ __launch_bounds__(1024) void k3_tail(Eng2 E, BudKey init, int first, 
 
 // How many blocks of the persistent tail can be resident on the device at once (0: the query failed).  The launch is an ordinary
 // one - nothing but this check and the bounded entry barrier stands between a grid that cannot be co-resident and a hang.
-int tail_resident_max(int device) {
-  static int cap[64] = {0};
-  const int d = device & 63;
-  if (!cap[d]) {
+int tail_resident_max(int device, int bs) {
+  static int cap[2][64] = {{0}, {0}};
+  const int d = device & 63, w = bs == 512 ? 1 : 0;
+  if (!cap[w][d]) {
     int per_cu = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k3_tail, 1024, sizeof(TailLds<1024>)) != hipSuccess ||
-        hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    cap[d] = std::max(0, per_cu) * std::max(1, prop.multiProcessorCount);
-    if (!cap[d]) cap[d] = -1;
+    const hipError_t e = w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k3_tail<512>, 512, sizeof(TailLds<512>))
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k3_tail<1024>, 1024, sizeof(TailLds<1024>));
+    if (e != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    cap[w][d] = std::max(0, per_cu) * std::max(1, prop.multiProcessorCount);
+    if (!cap[w][d]) cap[w][d] = -1;
   }
-  return std::max(0, cap[d]);
+  return std::max(0, cap[w][d]);
 }
 int tail_grid(int N, int device) {
   static int ncu[64] = {0};
@@ -204,19 +214,21 @@ int tail_grid(int N, int device) {
     hipDeviceProp_t prop;
     ncu[d] = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
   }
-  // one block of 1024 threads per CU at most (they have to be co-resident); about four uniques per thread at 10^6 uniques
+  // one block (of 1024 or 512 threads) per CU at most (they have to be co-resident); 4096 uniques per block at 10^6 uniques
   const int want = (N + 4095) / 4096;
   return std::max(1, std::min(want, ncu[d]));
 }
-void launch3_tail(const Eng2 &E, int grid, bool first, int ordinal, uint32_t init_reads, hipStream_t st) {
+// d_E: the run's argument block in DEVICE memory (the kernel reads it through a pointer, see tail.hip)
+void launch3_tail(const Eng2 *d_E, int grid, int bs, bool first, int ordinal, uint32_t init_reads, hipStream_t st) {
   BudKey init{1.0, init_reads};
-  const size_t lds = sizeof(TailLds<1024>);
   static bool attr_set[64] = {false};
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
   if (!attr_set[dev_ & 63]) {
-    (void)hipFuncSetAttribute((const void *)k3_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k3_tail<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailLds<1024>));
+    (void)hipFuncSetAttribute((const void *)k3_tail<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailLds<512>));
     attr_set[dev_ & 63] = true;
   }
-  hipLaunchKernelGGL(k3_tail, dim3(grid), dim3(1024), lds, st, E, init, first ? 1 : 0, ordinal);
+  if (bs == 512) hipLaunchKernelGGL(k3_tail<512>, dim3(grid), dim3(512), sizeof(TailLds<512>), st, d_E, init, first ? 1 : 0, ordinal);
+  else hipLaunchKernelGGL(k3_tail<1024>, dim3(grid), dim3(1024), sizeof(TailLds<1024>), st, d_E, init, first ? 1 : 0, ordinal);
 }

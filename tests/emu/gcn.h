@@ -25,6 +25,8 @@ template <bool BOUND_CTRL> static inline int gcn_wave_shr1(int old, int src) {
 template <bool BOUND_CTRL> static inline int gcn_wave_shl1(int old, int src) {
   return (int)(uint32_t)emu::wave_op(emu::OP_DPP_SHL1, 64, (uint32_t)src, 0, (uint32_t)old, BOUND_CTRL, false);
 }
+template <typename T> static inline const T *gcn_opaque_uniform(const T *p) { return p; }
+static inline int gcn_opaque_lane(int v) { return v; }
 static inline unsigned long long gcn_clock() { return 0; }
 static inline void gcn_wave_sync() { (void)emu::wave_op(emu::OP_BALLOT, 64, 0, 0, 0, false, false); }
 static inline void gcn_drain_stores() {}
