@@ -1331,7 +1331,6 @@ struct Run {
   long v3_enq = 0;                    // k3_tail launches enqueued (their ordinals are 1, 2, ...)
   long v3_ord_seen = 0;               // launch ordinal of the last consumed block
   DevBuf<PSync> v3_psync;
-  DevBuf<Eng2> v3_eng;                // the argument block of k3_tail (device copy of E2, rewritten by v2_bind)
   DevBuf<unsigned long long> v3_ktime;
   PinBuf<int32_t> v3_hflags;          // [0] result blocks the host has finished with, [16] ordinal of the last launch that ended
   std::unique_lock<std::mutex> v3_slot;   // the device's persistent slot (held for the run)
@@ -1377,13 +1376,6 @@ struct Run {
     E2.has_compare = 1;
     E2.align_at_commit = v2_align_commit ? 1 : 0;
     E2L = E2; E2L.has_compare = 0;
-    // the persistent tail reads its argument block from device memory (tail.hip); without DADA2HIP_PROFILE it keeps no phase clocks
-    {
-      Eng2 Ek = E2;
-      if (!profile_all) Ek.ktime = nullptr;
-      v3_eng.alloc(1);
-      D2_HIP(hipMemcpy(v3_eng.p, &Ek, sizeof Ek, hipMemcpyHostToDevice));   // (bind is rare and nothing of this run is in flight: v2_alloc / v2_grow)
-    }
     v2_drop_graph();                 // (captured launches hold the old argument block)
   }
   void v2_alloc(int max_clust) {
@@ -1538,7 +1530,9 @@ struct Run {
       ev_end(rec.ev_nw);
     }
     const int ev = ev_begin(EV_TAIL, profile_all);
-    launch3_tail(v3_eng.p, v3_grid, v3_bs, first, (int)(v3_enq + 1), s->h_reads[bi[0].center], stq);
+    Eng2 Ek = E2;
+    if (!profile_all) Ek.ktime = nullptr;
+    launch3_tail(Ek, v3_grid, v3_bs, first, (int)(v3_enq + 1), s->h_reads[bi[0].center], stq);
     ev_end(ev);
     v3_rec.push_back(rec);
     v3_enq++;

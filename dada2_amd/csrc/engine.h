@@ -324,6 +324,17 @@ struct Ctl2 {
   // what the first shuffle call of a round may assume: the previous round's calls ended with one that moved nothing (every
   // unique sits in its arg-max), and since then only the birth has changed reads - partition bfrom lost its new centre's
   int32_t stable, bfrom;
+  // ---- the NEXT batch's compare under the persistent tail (Eng2::pf_on) ----
+  // pf_seq: prefetch compares planned so far (the host launches number k on the second stream when it sees pf_seq >= k in a
+  // published block; PfSync::done follows when the compare has run).  pf_bbuf: the batch buffer the latest one fills.
+  // last_bbuf: the batch buffer planned last, by a miss or by a prefetch - the round whose centre is found in it plans the next
+  // prefetch.  pf_wait: the coming round's centre sits in prefetch number pf_wait whose compare had not finished when the round
+  // was decided: no round may start before PfSync::done >= pf_wait (0: nothing to wait for).
+  int32_t pf_seq, pf_bbuf, last_bbuf, pf_wait;
+  // statistics of the run so far: rounds whose centre came out of a prefetched batch; spins for a prefetch in flight that
+  // ended in time / that ended with the launch left; centres prefetched
+  int32_t pf_hits, pf_spins, pf_exits, pf_centres;
+  unsigned long long pf_mask;   // bit b: batch buffer b was filled by a prefetch
 };
 
 // Results of the batch compares, kept until their centre's round comes (or the batch buffer is recycled): the class, 2 bits
@@ -355,6 +366,10 @@ struct Round2Out {
   int32_t slot;
   int32_t err_flag, blk_count;
   int32_t pad0[4];
+  int32_t pf_seq;                 // persistent tail with overlap: prefetch compares planned so far (Ctl2::pf_seq as of this block)
+  int32_t pf_wait;                // ... and the prefetch this block's NEXT round has to wait for (Ctl2::pf_wait; 0: none)
+  int32_t pf_stat[4];             // Ctl2::pf_hits / pf_spins / pf_exits / pf_centres as of this block
+  int32_t pad1[2];
   int32_t kord;                   // persistent tail: ordinal of the k3_tail launch that ran this round (0: a launch chain)
   int32_t paused;                 // persistent tail: the device halted BEHIND this block's decision because its mover lists did not fit
                                   // the block (they stay in Eng2::movers until the host has fetched them and resumes)
@@ -423,6 +438,21 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   volatile int32_t *hexit;                          // pinned host word: ordinal of the last k3_tail launch that has ended
   unsigned long long *ktime;                        // [KT_N] phase clocks of block 0 (DADA2HIP_PROFILE=1), else nullptr
   int32_t fail_ordinal;                             // test knob (DADA2HIP_V3_FAIL_ENTRY): the k3_tail launch of this ordinal fails its entry barrier (0: none)
+  // ---- the next batch's compare under the persistent tail: what a prefetch compare works with.  The compare
+  //      kernels of the second stream get a copy of this block whose `ctl`, `C.tab8 / full / ord`, `blist / blist_n` and aligner
+  //      scratch ARE these (so they run unchanged); the tail's planner fills pf_ctl and clears pf_blist_n ----
+  int32_t pf_on;                                    // 1: the tail plans prefetch compares
+  int32_t pf_min;                                   // fewest uncached candidates worth a prefetch pass
+  Ctl2 *pf_ctl;                                     // descriptor of the prefetch compare (nbatch, bbuf, bcentre / breads / blen, nalign, abuf, acentre; state stays 0)
+  int32_t *pf_blist_n;                              // [2 KB_MAX] lengths of its work lists
+  struct PfSync *pfsync;                            // PfSync::done = prefetch compares that have run
+  unsigned long long pf_wait_ticks;                 // how long (100 MHz ticks) a round waits inside the launch for a prefetch in flight
+};
+
+// Written by the last kernel of a prefetch compare (k2_pf_done, second stream), polled by the persistent tail.
+struct PfSync {
+  uint32_t done, pad0[31];
+  unsigned long long nnw, ngapless;                 // pairs the prefetch compares' aligner launches worked through (run totals)
 };
 
 // Grid barrier of the persistent tail kernel: one monotonic arrival counter and one generation word, each on a cache line of
@@ -437,6 +467,10 @@ enum { KT_S0 = 0, KT_S0_BAR, KT_SL, KT_SL_BAR, KT_P, KT_P_BAR, KT_BIRTH, KT_PUBL
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
                     hipStream_t st);
 void launch2_screen_multi(const Eng2 &E, hipStream_t st);
+// prefetch compare (second stream): the k-mer tables of the batch pf_ctl describes (the planner only chose its centres) in front
+// of the screen, the completion word behind the aligner.  E = the prefetch's argument block (see Eng2::pf_on)
+void launch2_pf_tables(const Eng2 &E, hipStream_t st);
+void launch2_pf_done(const Eng2 &E, hipStream_t st);
 void launch2_batch_lists(const Eng2 &E, hipStream_t st);                              // classes of a batch screen -> the aligner's work lists
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st);
 // b_p_update + b_bud arg-min (grid) ; ties, decision, birth, plan of the coming round, publication (one block)
@@ -449,7 +483,7 @@ void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t 
 // device halts or the host's ring fills up.  first: the evaluation behind round 0 (no shuffle).  ordinal: this launch's number.
 int tail_grid(int N, int device);
 int tail_resident_max(int device, int bs);                  // blocks of k3_tail the device can hold at once (occupancy query; 0 = unknown)
-void launch3_tail(const Eng2 *d_E, int grid, int bs, bool first, int ordinal, uint32_t init_reads, hipStream_t st);   // d_E: device copy of the argument block; bs: 1024 or 512 threads per block
+void launch3_tail(const Eng2 &E, int grid, int bs, bool first, int ordinal, uint32_t init_reads, hipStream_t st);   // bs: 1024 or 512 threads per block
 
 // get_lr + get_ham_endsfree (chimera.cpp:211-293) on the move strings k_nw left behind: out[slot] = {left, right, left_oo, right_oo, ham}
 void launch_bimera_lr(const SampleDev &S, const int32_t *d_chunk_centre, const int32_t *d_work, int nwork, const uint8_t *d_moves,

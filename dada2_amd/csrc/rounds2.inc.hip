@@ -748,6 +748,134 @@ static __device__ __forceinline__ void plan_aligner(const Eng2 &E, int centre, i
     if (nb > 0 && tid < 2 * KB_MAX) E.blist_n[tid] = 0;
   }
 }
+// The best listed candidates of the last evaluation (the significant ones k2_pupdate listed, in b_bud's own order: p ascending,
+// reads descending) that are neither cached (s_tab / s_bits: the slot table and a bitmap of its low indices) nor `raw`:
+// positions [first, KB_MAX) of s_bc, *s_nb = number of positions filled.  They are the likely next centres.
+static __device__ __forceinline__ void plan_select(const Eng2 &E, int raw, int first, int *s_bc, int *s_nb, const int *s_tab, const uint32_t *s_bits,
+                                                   double *s_p, uint32_t *s_rd, int *s_r, int nslots) {
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  const int tid = threadIdx.x;
+  const int M = min(*E.sig_n, PLAN_PER * (int)blockDim.x);
+  double kp[PLAN_PER];
+  uint32_t krd[PLAN_PER];
+  int kr[PLAN_PER];
+#pragma unroll
+  for (int j = 0; j < PLAN_PER; j++) {
+    const int q = tid + j * (int)blockDim.x;
+    kr[j] = -1; kp[j] = 0.0; krd[j] = 0;
+    if (q < M) {
+      const int r = E.sig_list[q];
+      bool ok = r != raw && !P.slot0[r];
+      if (ok) {
+        if (r < PLAN_BITS) ok = !((s_bits[r >> 5] >> (r & 31)) & 1u);
+        else for (int t = 0; ok && t < nslots; t++) if (s_tab[t] == r) ok = false;
+      }
+      if (ok) { kr[j] = r; kp[j] = P.p[r]; krd[j] = S.reads[r]; }
+    }
+  }
+  for (int sel = first; sel < KB_MAX; sel++) {
+    double bp = 0.0;
+    uint32_t brd = 0;
+    int br = -1;
+#pragma unroll
+    for (int j = 0; j < PLAN_PER; j++)
+      if (kr[j] >= 0 && (br < 0 || kp[j] < bp || (kp[j] == bp && (krd[j] > brd || (krd[j] == brd && kr[j] < br))))) {
+        bp = kp[j]; brd = krd[j]; br = kr[j];
+      }
+    const int win = block_best(bp, brd, br, s_p, s_rd, s_r);
+    if (win < 0) break;
+#pragma unroll
+    for (int j = 0; j < PLAN_PER; j++) if (kr[j] == win) kr[j] = -1;
+    if (tid == 0) { s_bc[sel] = win; *s_nb = sel + 1; }
+  }
+  __syncthreads();
+}
+
+// k-mer tables of a batch of nb centres (bc[], in LDS or global memory): byte k of tab8[id] = min(count of 5-mer id in centre k, 63) + 0x7F
+// (the screen's compare then is one subtraction: bit 7 of byte - rank is set exactly when rank < count), the full counts and
+// the ordered 5-mers.  s_cnt: [KB_MAX][1024] words of LDS.
+static __device__ __forceinline__ void build_batch_tables(const SampleDev &S, const Cache2 &C, int nb, const int *bc, uint32_t *s_cnt) {
+  const int tid = threadIdx.x;
+  for (int k = tid; k < KB_MAX * NKMER; k += blockDim.x) s_cnt[k] = 0;
+  __syncthreads();
+  for (int k = 0; k < nb; k++) {
+    const int c = bc[k];
+    const int nkc = S.len[c] - KMER_SIZE + 1;
+    const uint16_t *crow = S.kord + (size_t)c * S.LK;
+    uint16_t *ko = C.ord + (size_t)k * S.LK;
+    for (int i = tid; i < S.LK; i += blockDim.x) {
+      const uint32_t km = crow[i] & 1023u;
+      if (i < nkc) atomicAdd(&s_cnt[k * NKMER + km], 1u);
+      ko[i] = i < nkc ? (uint16_t)km : (uint16_t)0xFFFF;
+    }
+  }
+  __syncthreads();
+  for (int id = tid; id < NKMER; id += blockDim.x) {
+    uint32_t lo = 0, hi = 0;
+    for (int k = 0; k < KB_MAX; k++) {
+      const uint32_t c = k < nb ? s_cnt[k * NKMER + id] : 0u;
+      const uint32_t sat = (c < RANK_SAT ? c : RANK_SAT) + 0x7Fu;
+      if (k < 4) lo |= sat << (8 * k); else hi |= sat << (8 * (k - 4));
+      C.full[(size_t)k * NKMER + id] = (uint16_t)c;
+    }
+    C.tab8[id] = make_uint2(lo, hi);
+  }
+}
+
+// The next batch's compare under the persistent tail (Eng2::pf_on): choose up to KB_MAX of the best candidates
+// that are not cached, give them the next batch buffer (never `keepbuf`, whose rows the coming round's commit reads) and describe
+// the compare in E.pf_ctl.  The host sees Ctl2::pf_seq move in the round's result block and launches the compare on its second
+// stream; the rounds go on meanwhile.  s_tab / s_bits as for plan_select, current as of now.
+static __device__ __forceinline__ void plan_prefetch(const Eng2 &E, int raw, int keepbuf, int *s_misc, int *s_tab, uint32_t *s_bits, double *s_p, uint32_t *s_rd) {
+  const SampleDev &S = E.S;
+  Ctl2 *ctl = E.ctl;
+  const Cache2 &C = E.C;
+  const int tid = threadIdx.x;
+  const int nslots = C.NBUF * KB_MAX;
+  int *s_nb = s_misc, *s_bc = s_misc + 4, *s_r = s_misc + 12, *s_pb = s_misc + 2;
+  if (tid == 0) {
+    int bbuf = ctl->next_bbuf;
+    if (bbuf == keepbuf) bbuf = (bbuf + 1) % C.NBUF;
+    *s_pb = bbuf;
+    *s_nb = 0;
+  }
+  __syncthreads();
+  const int bbuf = *s_pb;
+  // what the buffer held is gone (whether or not the plan goes through: a batch buffer is a cache)
+  if (tid < KB_MAX) {
+    const int c = s_tab[bbuf * KB_MAX + tid];
+    if (c >= 0 && c < PLAN_BITS) atomicAnd(&s_bits[c >> 5], ~(1u << (c & 31)));
+    s_tab[bbuf * KB_MAX + tid] = -1;
+  }
+  __syncthreads();
+  plan_select(E, raw, 0, s_bc, s_nb, s_tab, s_bits, s_p, s_rd, s_r, nslots);
+  const int nb = *s_nb;
+  if (nb < E.pf_min) {
+    // too few candidates left for a pass over the k-mer records to be worth it: no further attempt until something is planned
+    if (tid == 0) ctl->last_bbuf = -2;
+    return;
+  }
+  Ctl2 *pc = E.pf_ctl;
+  if (tid < KB_MAX) {
+    const int k = tid;
+    const int c = k < nb ? s_bc[k] : -1;
+    pc->bcentre[k] = c; pc->acentre[k] = c;
+    pc->breads[k] = c >= 0 ? S.reads[c] : 0u;
+    pc->blen[k] = c >= 0 ? S.len[c] : 0;
+    C.slot_centre[bbuf * KB_MAX + k] = c;
+  }
+  if (tid < 2 * KB_MAX) E.pf_blist_n[tid] = 0;
+  if (tid == 0) {
+    const int seq = ctl->pf_seq + 1;
+    pc->nbatch = nb; pc->bbuf = bbuf; pc->nalign = nb; pc->abuf = bbuf; pc->pf_seq = seq; pc->state = 0;
+    ctl->next_bbuf = (bbuf + 1) % C.NBUF;
+    ctl->pf_seq = seq; ctl->pf_bbuf = bbuf; ctl->last_bbuf = bbuf;
+    ctl->pf_mask |= 1ull << (bbuf & 63);
+    ctl->pf_centres += nb;
+  }
+}
+
 // hint (optional, the serial end of a round has them at hand; nullptr: read from memory): hint[0] = reads of `raw`,
 // hint[1], hint[2] = Ctl2::n0 / low0 as of now, hint[3] != 0: s_misc + 32 already holds a copy of Cache2::slot_centre
 static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc,
@@ -758,7 +886,7 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
   const Cache2 &C = E.C;
   const int tid = threadIdx.x;
   const int nslots = C.NBUF * KB_MAX;
-  int *s_nb = s_misc, *s_hit = s_misc + 1;
+  int *s_nb = s_misc, *s_hit = s_misc + 1, *s_trig = s_misc + 3;
   int *s_bc = s_misc + 4;                                           // [KB_MAX]
   int *s_r = s_misc + 12;                                           // [16]
   int *s_tab = s_misc + 32;                                         // [nslots] copy of slot_centre
@@ -782,15 +910,48 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
     ctl->centre = raw;
     ctl->bfrom = from;
     ctl->nsh_base = 0;
-    *s_hit = -1;
+    *s_hit = -1; *s_trig = 0;
   }
   __syncthreads();
-  if (hint && hint[3]) { for (int q = tid; q < nslots; q += blockDim.x) if (s_tab[q] == raw) *s_hit = q; }
+  const bool have_tab = hint && hint[3];
+  if (have_tab) { for (int q = tid; q < nslots; q += blockDim.x) if (s_tab[q] == raw) *s_hit = q; }
   else for (int q = tid; q < nslots; q += blockDim.x) if (C.slot_centre[q] == raw) *s_hit = q;   // (at most one slot holds it)
   __syncthreads();
-  if (*s_hit >= 0) {
-    if (tid == 0) { ctl->slot = *s_hit; ctl->nbatch = 0; ctl->need_compare = 0; }
-    plan_aligner(E, raw, *s_hit, 0);
+  const int hit = *s_hit;
+  if (hit >= 0) {
+    if (tid == 0) {
+      ctl->slot = hit; ctl->nbatch = 0; ctl->need_compare = 0;
+      if (E.pf_on) {
+        // a centre out of a prefetched batch whose compare is still running: give it a moment inside the launch, else leave the
+        // launch - no round may read the batch's rows before PfSync::done says they are there (Ctl2::pf_wait)
+        const int hb = hit / KB_MAX;
+        int wait = 0;
+        if ((ctl->pf_mask >> (hb & 63)) & 1ull) ctl->pf_hits += 1;
+        uint32_t done = gcn_load_agent(&E.pfsync->done);
+        const uint32_t seq = (uint32_t)ctl->pf_seq;
+        if (hb == ctl->pf_bbuf && (int32_t)(done - seq) < 0) {
+          const unsigned long long t0 = gcn_wall_clock();
+          while ((int32_t)(done - seq) < 0 && gcn_wall_clock() - t0 < E.pf_wait_ticks) { gcn_poll_pause(); done = gcn_load_agent(&E.pfsync->done); }
+          if ((int32_t)(done - seq) < 0) { wait = (int)seq; ctl->pf_exits += 1; } else ctl->pf_spins += 1;
+        }
+        ctl->pf_wait = wait;
+        // the first round out of the batch planned last: time to plan the one after it, if the second stream is free
+        *s_trig = (hb == ctl->last_bbuf && (int32_t)(done - seq) >= 0) ? 1 : 0;
+      }
+    }
+    plan_aligner(E, raw, hit, 0);
+    if (!E.pf_on) return;
+    __syncthreads();
+    if (!*s_trig) return;
+    for (int q = tid; q < PLAN_BITS / 32; q += blockDim.x) s_bits[q] = 0;
+    __syncthreads();
+    for (int q = tid; q < nslots; q += blockDim.x) {
+      const int c = have_tab ? s_tab[q] : C.slot_centre[q];
+      s_tab[q] = c;
+      if (c >= 0 && c < PLAN_BITS) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
+    }
+    __syncthreads();
+    plan_prefetch(E, raw, hit / KB_MAX, s_misc, s_tab, s_bits, s_p, s_rd);
     return;
   }
   if (tid == 0) {
@@ -799,8 +960,12 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
     for (int k = 0; k < KB_MAX; k++) C.slot_centre[bbuf * KB_MAX + k] = -1;
     ctl->bbuf = bbuf;
     ctl->slot = bbuf * KB_MAX;
+    ctl->last_bbuf = bbuf;
+    ctl->pf_mask &= ~(1ull << (bbuf & 63));
+    ctl->pf_wait = 0;
     s_bc[0] = raw;
     *s_nb = 1;
+    if (E.pf_on) *s_trig = (int32_t)(gcn_load_agent(&E.pfsync->done) - (uint32_t)ctl->pf_seq) >= 0 ? 1 : 0;
   }
   for (int q = tid; q < PLAN_BITS / 32; q += blockDim.x) s_bits[q] = 0;
   __syncthreads();
@@ -811,79 +976,34 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
   }
   __syncthreads();
   // ---- prediction: the best keys among the listed candidates ----
-  {
-    const int M = min(*E.sig_n, PLAN_PER * (int)blockDim.x);
-    double kp[PLAN_PER];
-    uint32_t krd[PLAN_PER];
-    int kr[PLAN_PER];
-#pragma unroll
-    for (int j = 0; j < PLAN_PER; j++) {
-      const int q = tid + j * (int)blockDim.x;
-      kr[j] = -1; kp[j] = 0.0; krd[j] = 0;
-      if (q < M) {
-        const int r = E.sig_list[q];
-        bool ok = r != raw && !P.slot0[r];
-        if (ok) {
-          if (r < PLAN_BITS) ok = !((s_bits[r >> 5] >> (r & 31)) & 1u);
-          else for (int t = 0; ok && t < nslots; t++) if (s_tab[t] == r) ok = false;
-        }
-        if (ok) { kr[j] = r; kp[j] = P.p[r]; krd[j] = S.reads[r]; }
-      }
-    }
-    for (int sel = 1; sel < KB_MAX; sel++) {
-      double bp = 0.0;
-      uint32_t brd = 0;
-      int br = -1;
-#pragma unroll
-      for (int j = 0; j < PLAN_PER; j++)
-        if (kr[j] >= 0 && (br < 0 || kp[j] < bp || (kp[j] == bp && (krd[j] > brd || (krd[j] == brd && kr[j] < br))))) {
-          bp = kp[j]; brd = krd[j]; br = kr[j];
-        }
-      const int win = block_best(bp, brd, br, s_p, s_rd, s_r);
-      if (win < 0) break;
-#pragma unroll
-      for (int j = 0; j < PLAN_PER; j++) if (kr[j] == win) kr[j] = -1;
-      if (tid == 0) { s_bc[sel] = win; *s_nb = sel + 1; }
-    }
-  }
-  __syncthreads();
+  plan_select(E, raw, 1, s_bc, s_nb, s_tab, s_bits, s_p, s_rd, s_r, nslots);
   const int nb = *s_nb;
-  // ---- k-mer tables of the batch: byte k of tab8[id] = min(count of 5-mer id in centre k, 63) + 0x7F (the screen's compare
-  //      then is one subtraction: bit 7 of byte - rank is set exactly when rank < count) ----
-  for (int k = tid; k < KB_MAX * NKMER; k += blockDim.x) s_cnt[k] = 0;
-  __syncthreads();
-  for (int k = 0; k < nb; k++) {
-    const int c = s_bc[k];
-    const int nkc = S.len[c] - KMER_SIZE + 1;
-    const uint16_t *crow = S.kord + (size_t)c * S.LK;
-    uint16_t *ko = C.ord + (size_t)k * S.LK;
-    for (int i = tid; i < S.LK; i += blockDim.x) {
-      const uint32_t km = crow[i] & 1023u;
-      if (i < nkc) atomicAdd(&s_cnt[k * NKMER + km], 1u);
-      ko[i] = i < nkc ? (uint16_t)km : (uint16_t)0xFFFF;
-    }
-  }
-  __syncthreads();
-  for (int id = tid; id < NKMER; id += blockDim.x) {
-    uint32_t lo = 0, hi = 0;
-    for (int k = 0; k < KB_MAX; k++) {
-      const uint32_t c = k < nb ? s_cnt[k * NKMER + id] : 0u;
-      const uint32_t sat = (c < RANK_SAT ? c : RANK_SAT) + 0x7Fu;
-      if (k < 4) lo |= sat << (8 * k); else hi |= sat << (8 * (k - 4));
-      C.full[(size_t)k * NKMER + id] = (uint16_t)c;
-    }
-    C.tab8[id] = make_uint2(lo, hi);
-  }
+  const int bbuf_now = ctl->bbuf;
+  // (with a prefetch to plan behind this batch, the selection needs the LDS that the tables are built in: remember the batch first)
+  int mine = -1;
   if (tid < KB_MAX) {
     const int k = tid;
     if (k < nb) {
       const int c = s_bc[k];
+      mine = c;
       ctl->bcentre[k] = c; ctl->breads[k] = S.reads[c]; ctl->blen[k] = S.len[c];
-      C.slot_centre[ctl->bbuf * KB_MAX + k] = c;
+      C.slot_centre[bbuf_now * KB_MAX + k] = c;
     } else { ctl->bcentre[k] = -1; ctl->breads[k] = 0; ctl->blen[k] = 0; }
   }
+  if (E.pf_on && *s_trig) {
+    if (tid < KB_MAX && mine >= 0) {                                  // the batch just planned counts as cached
+      s_tab[bbuf_now * KB_MAX + tid] = mine;
+      if (mine < PLAN_BITS) atomicOr(&s_bits[mine >> 5], 1u << (mine & 31));
+    }
+    __syncthreads();
+    plan_prefetch(E, raw, bbuf_now, s_misc, s_tab, s_bits, s_p, s_rd);
+    __syncthreads();
+  }
+  // ---- k-mer tables of the batch (the centres are re-read from the control block: the prefetch plan reused the LDS list) ----
+  __syncthreads();
+  build_batch_tables(S, C, nb, ctl->bcentre, s_cnt);
   if (tid == 0) { ctl->nbatch = nb; ctl->need_compare = 1; }
-  plan_aligner(E, raw, ctl->bbuf * KB_MAX, nb);
+  plan_aligner(E, raw, bbuf_now * KB_MAX, nb);
 }
 
 static __device__ __forceinline__ void publish_copy(const Eng2 &E, Round2Out *out, int ring, int seq) {
@@ -1196,13 +1316,18 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
     // leave the launch after this round?  a halt, a pause, a compare (or, aligning at commit time, the aligner) is due, or the
     // host's ring of result blocks would not take the NEXT block: publishing sequence number q reuses the slot of q - RING2
     const int seq = ctl->pub_seq + 1;
-    int ex = (s_halt != H2_NONE || pause || ctl->need_compare != 0 || E.align_at_commit != 0) ? 1 : 0;
+    // (... or the coming round's centre sits in a prefetched batch whose compare is still running)
+    int ex = (s_halt != H2_NONE || pause || ctl->need_compare != 0 || E.align_at_commit != 0 || ctl->pf_wait != 0) ? 1 : 0;
     if (!ex && seq + 1 - s_pre[PRE_HCONS] > E.ring_limit) {
       const int hc = gcn_load_system((const int32_t *)E.hcons);
       ctl->hcons_seen = hc;
       if (seq + 1 - hc > E.ring_limit) ex = 1;
     }
     ctl->kexit = ex;
+  }
+  if (tid == 0) {
+    out->pf_seq = ctl->pf_seq; out->pf_wait = ctl->pf_wait;
+    out->pf_stat[0] = ctl->pf_hits; out->pf_stat[1] = ctl->pf_spins; out->pf_stat[2] = ctl->pf_exits; out->pf_stat[3] = ctl->pf_centres;
   }
   clear_block(E.dblk + ((ring + 1) % RING2));
 #undef D2_TRB
@@ -1254,6 +1379,25 @@ __global__ void k2_resume(Eng2 E, int keep_list, int compare_done) {
   E.ctl->state = 0; E.ctl->halt = H2_NONE;
   if (!keep_list) *E.sig_n = 0;
   if (compare_done) { E.ctl->nbatch = 0; E.ctl->need_compare = 0; if (!E.align_at_commit) E.ctl->nalign = 0; }
+}
+
+// ---- a prefetch compare on the second stream (Eng2::pf_on): E is ITS argument block - ctl = the prefetch descriptor, C.tab8 /
+//      full / ord and blist / blist_n its own copies.  The tables of the batch in front of the screen (the planner, inside the
+//      persistent tail's serial section, only chose the centres); the completion word behind the aligner. ----
+__global__ __launch_bounds__(1024) void k2_pf_tables(Eng2 E) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
+  const int nb = E.ctl->nbatch;
+  if (nb <= 0) return;
+  build_batch_tables(E.S, E.C, nb, E.ctl->bcentre, s_cnt);
+}
+__global__ void k2_pf_done(Eng2 E) {
+  if (threadIdx.x != 0) return;
+  unsigned long long nn = 0, ng = 0;
+  for (int k = 0; k < KB_MAX; k++) { nn += (unsigned long long)E.blist_n[k]; ng += (unsigned long long)E.blist_n[KB_MAX + k]; }
+  E.pfsync->nnw += nn; E.pfsync->ngapless += ng;
+  // everything the compare's kernels wrote is in memory (they ended); the word the persistent tail polls follows it
+  gcn_release_agent();
+  gcn_store_agent(&E.pfsync->done, (uint32_t)E.ctl->pf_seq);
 }
 
 // ---- k-mer screen against the batch's centres ---------------------------------------------------------------------------
@@ -1439,6 +1583,8 @@ void launch2_batch_lists(const Eng2 &E, hipStream_t st) {
   const int grid = (E.S.N + 256 * LISTS_PER_THREAD - 1) / (256 * LISTS_PER_THREAD);
   hipLaunchKernelGGL(k2_batch_lists, dim3(grid), dim3(256), 0, st, E);
 }
+void launch2_pf_tables(const Eng2 &E, hipStream_t st) { hipLaunchKernelGGL(k2_pf_tables, dim3(1), dim3(1024), 0, st, E); }
+void launch2_pf_done(const Eng2 &E, hipStream_t st) { hipLaunchKernelGGL(k2_pf_done, dim3(1), dim3(64), 0, st, E); }
 void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
   const size_t lds = (size_t)NKMER * 8 + (size_t)KB_MAX * E.S.LK * 2 + (size_t)(E.S.maxlen + 2) * 4 + 16;
   static size_t attr_set[64] = {0};

@@ -93,15 +93,11 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
   return true;
 }
 
-// The argument block of the persistent kernel lives in device memory and is read through a pointer the optimiser cannot see
-// through, afresh for every phase: its hundred-odd fields are invariants of the round loop, and hoisted out of it (which is what
-// happens to a by-value kernel argument) they were 330 spilled SGPRs of this 128-register kernel.
-static __device__ __forceinline__ const Eng2 &tail_args(const Eng2 *p) { return *gcn_opaque_uniform(p); }
 template <int BS>
-__global__ __launch_bounds__(BS, 4) void k3_tail(const Eng2 *__restrict__ Ep, BudKey init, int first, int ordinal) {
-  const Eng2 &E = *Ep;
+__global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first, int ordinal) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn3[];
   TailLds<BS> &L = *(TailLds<BS> *)s_dyn3;
+  gcn_raise_priority();                                  // (its waves are few and wait most of the time: when they can issue, they go first)
   Ctl2 *ctl = E.ctl;
   const int G = (int)gridDim.x;
   const bool timer = E.ktime != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
@@ -127,6 +123,15 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(const Eng2 *__restrict__ Ep, Bu
             ctl->hcons_seen = hc;
             if (seq - hc > E.ring_limit) ex = 1;
           }
+          if (ctl->pf_wait) {
+            // the coming round's centre sits in a prefetched batch whose compare was still running when the last launch left:
+            // it has to be there before any block reads the batch's rows (the host orders the launch behind it when it can)
+            const uint32_t seq = (uint32_t)ctl->pf_wait;
+            uint32_t done = gcn_load_agent(&E.pfsync->done);
+            const unsigned long long t0 = gcn_wall_clock();
+            while ((int32_t)(done - seq) < 0 && gcn_wall_clock() - t0 < E.pf_wait_ticks) { gcn_poll_pause(); done = gcn_load_agent(&E.pfsync->done); }
+            if ((int32_t)(done - seq) < 0) ex = 1; else ctl->pf_wait = 0;
+          }
           ctl->kexit = ex;
           ctl->need_compare = 0;                          // the compare of the coming round, if it needed one, ran in front of this launch
         }
@@ -138,23 +143,19 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(const Eng2 *__restrict__ Ep, Bu
   }
   KT_LAP(KT_LAUNCH);
   for (int rnd = 0;; rnd++) {
-    // (the argument block is read through a pointer the optimiser cannot see through, once per round: its hundred-odd fields are
-    //  loop invariants, and hoisted out of this loop they were 330 spilled SGPRs + 100 spilled VGPRs of a 128-register kernel)
-    const Eng2 &E = tail_args(Ep);
-    Ctl2 *ctl = E.ctl;
     const int ring = ctl->pub_seq % RING2;
     Round2Out *out = E.dblk + ring;
     int level = 0;
     if (!(first && rnd == 0)) {
       // ---- commit of the round's cached comparisons + b_shuffle2 until a call moves nothing (Rmain.cpp:320-325) ----
-      shuffle_body<true, BS>(tail_args(Ep), L.sh, 0, 0, E.movers, out);
+      shuffle_body<true, BS>(E, L.sh, 0, 0, E.movers, out);
       KT_LAP(KT_S0);
       if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
       KT_LAP(KT_S0_BAR);
       int moved = out->cnt[0];
       level = 1;
       while (level < E.max_shuffle && out->cnt[level - 1] > 0) {
-        shuffle_body<false, BS>(tail_args(Ep), L.sh, level, moved, E.movers + (size_t)level * 3 * (size_t)E.S.N, out);
+        shuffle_body<false, BS>(E, L.sh, level, moved, E.movers + (size_t)level * 3 * (size_t)E.S.N, out);
         KT_LAP(KT_SL);
         if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
         KT_LAP(KT_SL_BAR);
@@ -163,12 +164,12 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(const Eng2 *__restrict__ Ep, Bu
       }
     }
     // ---- b_p_update + the block minima of b_bud; the last block to arrive takes the round's decision ----
-    pupdate_body<BS>(tail_args(Ep), L.pu, level, init, (BudKey *)E.partial);
+    pupdate_body<BS>(E, L.pu, level, init, (BudKey *)E.partial);
     KT_LAP(KT_P);
     const int nlev = level;
     if (!grid_sync<BS>(E, L, epoch, G, [&]() {
           const unsigned long long tb = E.ktime ? gcn_wall_clock() : 0ull;
-          birth_body(tail_args(Ep), nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal);
+          birth_body(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal);
           if (threadIdx.x == 0) {
             ctl->pub_seq = ctl->pub_seq + 1;              // (the others find the NEXT round's block through it)
             if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(const Eng2 *__restrict__ Ep, Bu
     if (L.last) {
       // the block that took the decision publishes it while the others are already in the next round's first phase
       const unsigned long long tp = E.ktime ? gcn_wall_clock() : 0ull;
-      publish_copy(tail_args(Ep), out, ring, ctl->pub_seq);
+      publish_copy(E, out, ring, ctl->pub_seq);
       if (threadIdx.x == 0) {
         if (leave) *E.hexit = ordinal;
         if (E.ktime) atomicAdd(&E.ktime[KT_PUBLISH], gcn_wall_clock() - tp);
@@ -218,8 +219,7 @@ int tail_grid(int N, int device) {
   const int want = (N + 4095) / 4096;
   return std::max(1, std::min(want, ncu[d]));
 }
-// d_E: the run's argument block in DEVICE memory (the kernel reads it through a pointer, see tail.hip)
-void launch3_tail(const Eng2 *d_E, int grid, int bs, bool first, int ordinal, uint32_t init_reads, hipStream_t st) {
+void launch3_tail(const Eng2 &E, int grid, int bs, bool first, int ordinal, uint32_t init_reads, hipStream_t st) {
   BudKey init{1.0, init_reads};
   static bool attr_set[64] = {false};
   int dev_ = 0;
@@ -229,6 +229,6 @@ void launch3_tail(const Eng2 *d_E, int grid, int bs, bool first, int ordinal, ui
     (void)hipFuncSetAttribute((const void *)k3_tail<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailLds<512>));
     attr_set[dev_ & 63] = true;
   }
-  if (bs == 512) hipLaunchKernelGGL(k3_tail<512>, dim3(grid), dim3(512), sizeof(TailLds<512>), st, d_E, init, first ? 1 : 0, ordinal);
-  else hipLaunchKernelGGL(k3_tail<1024>, dim3(grid), dim3(1024), sizeof(TailLds<1024>), st, d_E, init, first ? 1 : 0, ordinal);
+  if (bs == 512) hipLaunchKernelGGL(k3_tail<512>, dim3(grid), dim3(512), sizeof(TailLds<512>), st, E, init, first ? 1 : 0, ordinal);
+  else hipLaunchKernelGGL(k3_tail<1024>, dim3(grid), dim3(1024), sizeof(TailLds<1024>), st, E, init, first ? 1 : 0, ordinal);
 }

@@ -478,8 +478,10 @@ def test_abort_hook_then_clean_run_and_verbose_log(api, env, monkeypatch):
     assert "ALIGN: 8655 aligns, 3032 shrouded (%d raw)." % len(d.seqs) in text
 
 
-@pytest.mark.parametrize("nth", [1, 2, 5])
+@pytest.mark.parametrize("nth", [1, 2])
 def test_injected_entry_barrier_failure_continues_on_the_launch_chains(api, nth, monkeypatch):
+    """(DADA2HIP_V3_FAIL_ENTRY=n: the n-th persistent launch gives up at its entry barrier, as one whose blocks cannot all be
+    resident does; a run has at least two launches - the one behind round 0 and the one behind the first batch compare.)"""
     from helpers import case_inputs
     monkeypatch.setenv("DADA2HIP_V3_FAIL_ENTRY", str(nth))
     monkeypatch.setenv("DADA2HIP_V3_GRID", "7")

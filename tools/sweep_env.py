@@ -26,6 +26,9 @@ def main():
     ap.add_argument("settings", nargs="*")
     ap.add_argument("--list", default="", help="settings separated by ';'")
     a = ap.parse_args()
+    if os.environ.get("DADA2HIP_LIB"):   # (a build variant of the library: code-generation experiments)
+        from dada2_amd import _lib
+        _lib.LIB_PATH = os.environ["DADA2HIP_LIB"]
     from dada2_amd import api
     from dada2_amd.opts import DadaOpts
     args = types.SimpleNamespace(uniques=a.uniques, length=0, variants=0, deep=False)
