@@ -97,7 +97,7 @@ def _cached(make_sample):
     return wrapped
 
 
-def make_inputs(cfg, args, rank):
+def make_inputs(cfg, args, rank, host_inputs=True):
     """Synthetic samples of this rank (SURVEY.md §8d recipe) as HostInput objects + the error matrix."""
     from dada2_amd.api import HostInput
     from dada2_amd.io import extend_err
@@ -129,7 +129,74 @@ def make_inputs(cfg, args, rank):
             tl = np.concatenate([shared[1], own[1]])
             perm = np.random.default_rng(99 + i).permutation(tv.shape[0])   # abundance ranks differ per sample
             dereps.append(make_sample(err, n, seed=20260925 + cfg + 1000 * (i + 1), variants=(tv[perm], tl[perm]), **kw))
-    return dereps, [HostInput.from_derep(d) for d in dereps], err, mine, c
+    return dereps, ([HostInput.from_derep(d) for d in dereps] if host_inputs else None), err, mine, c
+
+
+def start_generators(jobs):
+    """Draw the sub-records' synthetic samples in child processes (numpy only, one core each) while the headline is measured: they
+    land in the input cache, and the sub-records then load them.  jobs: argument lists for `bench.py --gen-only`."""
+    import subprocess
+    if not os.environ.get("DADA2HIP_BENCH_CACHE", "/tmp/dada2hip_bench_cache"):
+        return []
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = ""          # (they never touch a device)
+    return [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gen-only"] + j, env=env, stdout=subprocess.DEVNULL,
+                             stderr=subprocess.DEVNULL) for j in jobs]
+
+
+def sub_config5(api, local, args):
+    """BASELINE.json configs[4] inside the default line (so that the driver times it): 200 000 unique ~1.5 kb reads, BAND_SIZE 32."""
+    from types import SimpleNamespace
+    from dada2_amd.opts import DadaOpts
+    a5 = SimpleNamespace(uniques=0, length=0, variants=0, deep=False)
+    t0 = time.time()
+    dereps, inputs, err, _, c = make_inputs(5, a5, 0)
+    gen_s = time.time() - t0
+    d = dereps[0]
+    o5 = DadaOpts(BAND_SIZE=c["band"])
+    api.dada_uniques(inputs[0], None, None, err, None, o5, device=local)   # warm-up
+    nst = 2
+    t0 = time.perf_counter()
+    for _ in range(nst):
+        r = api.dada_uniques(inputs[0], None, None, err, None, o5, device=local)
+    dt = (time.perf_counter() - t0) / nst
+    roof = None
+    if not args.no_profile_pass:
+        smp = api.Sample(inputs[0], None, None, None, device=local)
+        smp.run(err, o5)
+        os.environ["DADA2HIP_PROFILE"] = "1"
+        pst = smp.run(err, o5).stats
+        del os.environ["DADA2HIP_PROFILE"]
+        smp.close()
+        roof = rooflines(pst, 1510, c["band"], 5, d.nraw)[0]
+    st = r.stats
+    return {"workload": workload_name(5, d.nraw, max(len(x) for x in d.seqs[:256]), c["band"], c, False), "value": d.nraw / dt, "unit": "uniques/s",
+            "ms_per_step": dt * 1e3, "steps": nst, "partitions": r.nclust, "comparisons": st["ncompare"], "comparisons_per_s": st["ncompare"] / dt,
+            "nw": st["nnw"], "shrouded_frac": st["nshroud"] / max(1, st["ncompare"]), "roofline": roof, "gen_s": gen_s}
+
+
+def sub_config4(api, local, args):
+    """BASELINE.json configs[3] on ONE GPU inside the default line: 8 samples x 250 000 uniques, two samples in flight."""
+    from types import SimpleNamespace
+    from dada2_amd.opts import DadaOpts
+    a4 = SimpleNamespace(uniques=0, length=0, variants=0, deep=False)
+    t0 = time.time()
+    dereps, inputs, err, _, c = make_inputs(4, a4, 0)
+    gen_s = time.time() - t0
+    o4 = DadaOpts(BAND_SIZE=c["band"])
+    inflight = max(1, min(args.inflight, len(inputs)))
+    api.dada_uniques_multi(inputs, err, o4, devices=(local,) * inflight)   # warm-up
+    nst = 2
+    t0 = time.perf_counter()
+    for _ in range(nst):
+        res = api.dada_uniques_multi(inputs, err, o4, devices=(local,) * inflight)
+    dt = (time.perf_counter() - t0) / nst
+    n = sum(d.nraw for d in dereps)
+    return {"workload": workload_name(4, dereps[0].nraw, 250, c["band"], c, False) + f"; all 8 samples on this ONE GPU, {inflight} in flight",
+            "value": n / dt, "unit": "uniques/s", "ms_per_step": dt * 1e3, "steps": nst, "samples": len(inputs),
+            "partitions_per_sample": [r.nclust for r in res], "comparisons": int(sum(r.stats["ncompare"] for r in res)), "gen_s": gen_s}
 
 
 def main():
@@ -155,7 +222,17 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="samples of one rank in flight on its GPU (configs with several samples per rank: "
                     "dada2hip_run_multi with the device listed that many times; their rounds take turns, everything else overlaps)")
     ap.add_argument("--deep", action="store_true", help="workload variant with >= 5 reads per unique (reads drawn at Q34-40)")
+    ap.add_argument("--gen-only", action="store_true", help="draw this configuration's synthetic samples into the input cache and exit "
+                    "(no GPU touched: the default line starts these for its sub-records while it measures the headline)")
+    ap.add_argument("--gen-sample", type=int, default=-1, help="with --gen-only --config 4: only this sample of the eight")
     args = ap.parse_args()
+    if args.gen_only:
+        if args.gen_sample >= 0:   # one sample of configs[3]'s eight = what rank `gen_sample` of 8 draws
+            os.environ["WORLD_SIZE"] = "8"
+            make_inputs(args.config, args, args.gen_sample, host_inputs=False)
+        else:
+            make_inputs(args.config, args, 0, host_inputs=False)
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +257,11 @@ def main():
     from dada2_amd import api
     from dada2_amd.opts import DadaOpts
 
+    extras = (args.config == 3 and world == 1 and not args.selfconsist and not args.no_extras and not args.deep and not args.shard
+              and not args.uniques)
+    gens = []
+    if extras and rank == 0:   # the sub-records' samples are drawn by child processes while the headline runs
+        gens = start_generators([["--config", "2", "--deep"], ["--config", "5"]] + [["--config", "4", "--gen-sample", str(i)] for i in range(8)])
     t0 = time.time()
     dereps, inputs, err, mine, c = make_inputs(args.config, args, rank)
     t_gen = time.time() - t0
@@ -272,10 +354,11 @@ def main():
                 saturated = nw_saturated(smp, err, opts) if args.config != 5 else None   # (long reads run k_nw_adw)
             smp.close()
         pst = prof or st
-        roofline, other = rooflines(pst, L, band, args.config)
+        ranked = rooflines(pst, L, band, args.config, d.nraw if prof else 0)
+        roofline, other = ranked[0], ranked[1:]
         if prof is None:
             # without the event-timed pass the library only times a sample of the launches: no per-launch figure is claimed
-            for r in (roofline, other):
+            for r in ranked:
                 for k in ("achieved", "frac", "frac_of_measured_peak", "avg_launch_ms", "kernel_ms"):
                     if k in r:
                         r[k] = None
@@ -289,6 +372,7 @@ def main():
         #      whose comparisons are NOT 98 % shrouded (28 reads per unique) --------------------------------------------
         secondary = None
         bimera = None
+        sub5 = sub4 = None
         if args.config == 3 and world == 1 and not args.selfconsist and not args.no_extras and not args.deep and not args.shard:
             tm = []
             t_sc = time.perf_counter()
@@ -299,8 +383,21 @@ def main():
                        "passes": len(tm) - 1, "ms_create": tm[0], "ms_per_pass": tm[1:], "ms_total": (time.perf_counter() - t_sc) * 1e3,
                        "partitions_last": res_sc.nclust, "converged": bool(any(np.array_equal(e, err_sc) for e in errs_sc)),
                        "uniques_per_s_whole_loop": d.nraw / (time.perf_counter() - t_sc)}
+            for g in gens:
+                try:
+                    g.wait(timeout=600)
+                except Exception:   # noqa: BLE001
+                    g.kill()
             secondary = secondary_workload(api, opts, local, args)
             bimera = bimera_table_record(api, local, reference=cpu is not None)
+            try:
+                sub5 = sub_config5(api, local, args)
+            except Exception as e:   # noqa: BLE001  (a sub-record never lets the main line down)
+                sub5 = {"error": repr(e)}
+            try:
+                sub4 = sub_config4(api, local, args)
+            except Exception as e:   # noqa: BLE001
+                sub4 = {"error": repr(e)}
 
         out = {
             "metric": "unique reads denoised/sec (dada() wall-clock)", "value": value, "unit": "uniques/s",
@@ -321,12 +418,16 @@ def main():
                                           else "world 1: the entry point runs the ordinary device-driven engine") if args.shard
                                        else (f"{c['samples']} samples round-robin over {world} rank(s), {min(args.inflight, len(inputs))} in flight per GPU" if strong else f"sample-per-gpu x{world}")),
                        "shard_collectives_per_step": res.stats.get("shard_collectives") if args.shard else None},
-            "roofline": roofline, "roofline_secondary": other, "roofline_nw_saturated": saturated,
+            "roofline": roofline, "roofline_others": other, "roofline_nw_saturated": saturated,
+            "roofline_note": "roofline = the kernel class with the largest summed device time of the event-timed pass (phases_ms_last_step."
+                             "device_ms_profiled_pass); roofline_others = the remaining classes in that order",
             "cpu_baseline": cpu,
             "resident": resident,
             "selfconsist": sc_info,
             "secondary_workload": secondary,
             "bimera_table": bimera,
+            "config5_long_reads": sub5,
+            "config4_eight_samples_one_gpu": sub4,
             "phases_ms_last_step": phases(st, pst if prof else None),
             "comparisons_per_s": st["ncompare"] * len(inputs) * world * args.steps / dt,
             "gen_s": t_gen,
@@ -361,7 +462,13 @@ def phases(st, prof):
                              "bookkeep = round tails incl. waiting for the device; final = final pass + outputs"}
     if prof:
         out["device_ms_profiled_pass"] = {k[7:]: prof[k] for k in ("dev_ms_screen", "dev_ms_nw", "dev_ms_shuffle", "dev_ms_pval",
-                                                                   "dev_ms_birth", "dev_ms_final", "dev_ms_tail")}
+                                                                   "dev_ms_birth", "dev_ms_final", "dev_ms_tail", "dev_ms_pf_screen", "dev_ms_pf_nw")}
+        if prof.get("overlap_on"):
+            out["overlap"] = {"prefetch_compares": prof["pf_compares"], "centres_prefetched": prof["pf_centres"],
+                              "rounds_served_from_a_prefetched_batch": prof["pf_hits"], "waits_inside_the_launch": prof["pf_waits"],
+                              "launches_left_for_a_prefetch": prof["pf_exits"], "tail_threads_per_block": prof["tail_threads"],
+                              "note": "the next batch's compare runs on a second stream UNDER the persistent tail (pf_screen / pf_nw above "
+                                      "lie inside the interval of `tail`): DESIGN.md 5c"}
         out["device_ms_note"] = ("HIP-event time of EVERY launch of a resident pass under DADA2HIP_PROFILE=1, summed per kernel class; tail = the "
                                  "persistent round-tail launches (k3_tail: shuffles, p-update, bud, birth of every round), which replace the "
                                  "shuffle / pval / birth launch chains")
@@ -377,8 +484,46 @@ def phases(st, prof):
     return out
 
 
-def rooflines(st, L, band, cfg):
-    """Per-launch rooflines of the two hot kernels from HIP-event times (exact sums under DADA2HIP_PROFILE=1)."""
+def roofline_tail(st, n_uniques, cfg):
+    """The persistent round tail (k3_tail: every b_shuffle2 call, b_p_update, b_bud and the birth of every round inside a few launches;
+    /root/reference/src/Rmain.cpp:316-331 behind the compare).  Its ALGORITHMIC bytes are what its scans must read - 15 B per unique in
+    a round's commit + first shuffle call, 16 B in every later call, 12 B in the p-update - against the HBM peak; the
+    model it is actually bound by is printed beside it: a round is a chain of dependent global round trips and grid barriers, so
+    `us_per_round` and `dependent_phases_per_round` are the figures to watch, not the bandwidth."""
+    ms = st.get("dev_ms_tail", 0.0)
+    if not ms or not st.get("tail_launches"):
+        return None
+    rounds = max(1, int(st["rounds"]) - 1)                      # rounds behind round 0 (each: commit + shuffles + p-update + bud)
+    calls = int(st["nshuffle"])                                 # b_shuffle2 calls of the run (the first of each round is the commit)
+    later = max(0, calls - rounds)
+    evals = rounds + 1                                          # (+ the evaluation behind round 0)
+    alg = float(n_uniques) * (15.0 * rounds + 16.0 * later + 12.0 * evals)
+    nl = max(1, int(st["tail_launches"]))
+    phases = calls + evals                                      # grid-wide phases, each closed by a grid barrier
+    r = {"kernel": "k3_tail (persistent round tail: b_shuffle2 x n, b_p_update, b_bud, birth of every round)", "bound": "hbm",
+         "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None,
+         "kernel_ms": ms, "launches": int(st["tail_launches"]), "avg_launch_ms": ms / nl, "algorithmic_bytes_per_launch": alg / nl,
+         "timing": "every launch event-timed (DADA2HIP_PROFILE=1)",
+         "latency_model": {"rounds": rounds, "shuffle_calls": calls, "grid_phases": phases, "us_per_round": ms * 1e3 / rounds,
+                           "us_per_phase": ms * 1e3 / max(1, phases), "blocks": int(st.get("tail_blocks", 0)),
+                           "threads_per_block": int(st.get("tail_threads", 0) or 1024),
+                           "note": "a phase = one scan over the uniques + a work-list pass + a grid barrier; each is a chain of ~4-10 dependent "
+                                   "global round trips of ~2 us (block 0's clock per phase: round_tail.block0_ms)"}}
+    r["frac"] = r["achieved"] / r["peak"]
+    peaks = measured_peaks()
+    if peaks and "hbm_read_gbs" in peaks:
+        r["peak_measured"] = peaks["hbm_read_gbs"]
+        r["frac_of_measured_peak"] = r["achieved"] / peaks["hbm_read_gbs"]
+    tr = load_traffic(cfg)
+    if tr and tr.get("tail"):
+        r["traffic"] = tr["tail"].get("hbm_bytes_per_launch")
+        r["traffic_source"] = "committed rocprofv3 PMC pass of this command: " + tr["_file"]
+    return r
+
+
+def rooflines(st, L, band, cfg, n_uniques=0):
+    """Per-launch rooflines of the hot kernel classes from HIP-event times (exact sums under DADA2HIP_PROFILE=1), the one with the
+    largest summed device time FIRST - the persistent round tail included (it is half of a pass)."""
     peaks = measured_peaks()
     nw_ms, nw_n = st["nw_kernel_ms"], max(1, st["nw_kernel_launches"])
     sc_ms, sc_n = st["screen_kernel_ms"], max(1, st["screen_kernel_launches"])
@@ -407,7 +552,12 @@ def rooflines(st, L, band, cfg):
         roof_nw["traffic"] = tr.get("nw", {}).get("hbm_bytes_per_launch")
         roof_sc["traffic"] = tr.get("screen", {}).get("hbm_bytes_per_launch")
         roof_nw["traffic_source"] = roof_sc["traffic_source"] = "committed rocprofv3 PMC pass of this command: " + tr["_file"]
-    return (roof_nw, roof_sc) if nw_ms >= sc_ms else (roof_sc, roof_nw)
+    ranked = [roof_nw, roof_sc]
+    rt = roofline_tail(st, n_uniques, cfg) if n_uniques else None
+    if rt:
+        ranked.append(rt)
+    ranked.sort(key=lambda r: -(r.get("kernel_ms") or 0.0))
+    return ranked
 
 
 def nw_saturated(smp, err, opts, target=60000, reps=3):
@@ -484,7 +634,7 @@ def secondary_workload(api, opts, local, args):
         os.environ["DADA2HIP_PROFILE"] = "1"
         pst = smp.run(err, opts).stats
         del os.environ["DADA2HIP_PROFILE"]
-        roof, _ = rooflines(pst, 250, opts.BAND_SIZE, 2)
+        roof = [r for r in rooflines(pst, 250, opts.BAND_SIZE, 2) if r["bound"] == "valu"][0]
         roof["traffic"] = None
         roof.pop("traffic_source", None)
     smp.close()
@@ -599,6 +749,17 @@ def cpu_baseline(d, err, opts, args, gpu_res, gpu_cmp_per_s=None):
         except AssertionError as e:
             whole["parity_vs_gpu"] = False
             whole["parity_error"] = str(e)[:300]
+        # ... and THAT is the baseline's headline: the unextrapolated whole-sample run on top, the prefix timings
+        # (sweep, repeats, -O3, one thread) beside it
+        out["prefix"] = {k: out[k] for k in ("value", "seconds", "partitions", "build", "repeats", "comparisons_per_s", "sample") if k in out}
+        out["prefix"]["comparisons_per_s_ratio_gpu_over_cpu"] = out.get("comparisons_per_s_ratio_gpu_over_cpu")
+        out.update(value=whole["value"], seconds=whole["seconds"], partitions=whole["partitions"], repeats=1,
+                   comparisons_per_s=whole["comparisons_per_s"], cores=tbest,
+                   sample="the WHOLE bench sample (%d uniques), one run of the reference's dada_uniques, multithread=TRUE at the best thread "
+                          "count of the sweep; every output compared with the GPU's (parity_vs_gpu)" % d.nraw)
+        if gpu_cmp_per_s:
+            out["comparisons_per_s_ratio_gpu_over_cpu"] = whole["comparisons_per_s_ratio_gpu_over_cpu"]
+        out["parity_vs_gpu"] = whole["parity_vs_gpu"]
         out["whole_sample"] = whole
     if n == d.nraw:   # same input as the GPU run: EVERY output compared (tests/helpers.assert_results_equal)
         sys.path.insert(0, os.path.join(ROOT, "tests"))

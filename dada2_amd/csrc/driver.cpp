@@ -89,6 +89,7 @@ struct dada2hip_sample {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;    // late fetches (long mover lists) that must not queue behind the next round's kernels
+  hipStream_t cmp = nullptr;     // the NEXT batch's compare while the persistent tail runs the rounds of this one (created on first use)
   SampleDev D;
   DevBuf<uint32_t> seq2, heavy, reads;
   DevBuf<uint8_t> qual, nheavy, prior;
@@ -565,15 +566,15 @@ struct Run {
   // ---- kernel timing with HIP events on the run's stream.  Default: sampled (round 0, every 8th round, the final pass)
   // and extrapolated, because an event pair per kernel per round costs four API calls on an enqueue-bound critical
   // path.  DADA2HIP_PROFILE=1: every launch of every kernel class is timed (stats.kernel_times_sampled = 0).
-  enum { EV_SCREEN = 0, EV_NW, EV_SHUFFLE, EV_PVAL, EV_BIRTH, EV_FINAL, EV_TAIL, EV_NCLS };
-  struct EvRec { hipEvent_t a, b; int cls; uint8_t ok, big; };
+  enum { EV_SCREEN = 0, EV_NW, EV_SHUFFLE, EV_PVAL, EV_BIRTH, EV_FINAL, EV_TAIL, EV_PF_SCREEN, EV_PF_NW, EV_NCLS };
+  struct EvRec { hipEvent_t a, b; int cls; uint8_t ok, big; hipStream_t st; };
   std::vector<EvRec> evs;
   size_t ev_used = 0;
   int ev_round = 0;                             // rounds since the last event-timed one
   int n_round_launches = 0;
   bool profile_all = false;
   long spec_ev_nw = -1, spec_ev_screen = -1;
-  int ev_begin(int cls, bool on, bool spec = false, bool big = false) {
+  int ev_begin(int cls, bool on, bool spec = false, bool big = false, hipStream_t on_stream = nullptr) {
     if (!on) return -1;
     if (ev_used == evs.size()) {
       EvRec r{};
@@ -583,14 +584,16 @@ struct Run {
     }
     EvRec &r = evs[ev_used];
     r.cls = cls; r.ok = spec ? 0 : 1; r.big = big ? 1 : 0;
-    D2_HIP(hipEventRecord(r.a, s->stream));
+    r.st = on_stream ? on_stream : s->stream;
+    D2_HIP(hipEventRecord(r.a, r.st));
     return (int)ev_used++;
   }
-  void ev_end(int idx) { if (idx >= 0) D2_HIP(hipEventRecord(evs[idx].b, s->stream)); }
+  void ev_end(int idx) { if (idx >= 0) D2_HIP(hipEventRecord(evs[idx].b, evs[idx].st)); }
 
   ~Run() {
     for (auto &e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto g : v2_graph) if (g) (void)hipGraphExecDestroy(g);
+    for (auto e : v3_pf_ev) if (e) (void)hipEventDestroy(e);
   }
 
   void logf(const char *fmt, ...) {
@@ -1331,6 +1334,19 @@ struct Run {
   long v3_enq = 0;                    // k3_tail launches enqueued (their ordinals are 1, 2, ...)
   long v3_ord_seen = 0;               // launch ordinal of the last consumed block
   DevBuf<PSync> v3_psync;
+  // ---- the next batch's compare under the tail: a second set of everything a batch compare works with ----
+  bool v3_overlap = false;
+  Eng2 E2P{};                         // argument block of the prefetch compare's kernels (ctl = the prefetch descriptor, own tables / lists / aligner scratch)
+  SampleDev S2{};                     // the sample with the second aligner scratch
+  DevBuf<Ctl2> v3_pfctl;
+  DevBuf<PfSync> v3_pfsync;
+  DevBuf<uint2> v3_pf_tab8;
+  DevBuf<uint16_t> v3_pf_full, v3_pf_ord, v3_pf_foff;
+  DevBuf<int32_t> v3_pf_blist, v3_pf_blistn;
+  DevBuf<uint32_t> v3_pf_ad;
+  DevBuf<AdDesc> v3_pf_fdesc;
+  long v3_pf_launched = 0;            // prefetch compares sent to the second stream (their numbers are 1, 2, ...)
+  hipEvent_t v3_pf_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // end of prefetch compare k: v3_pf_ev[k & 3]
   DevBuf<unsigned long long> v3_ktime;
   PinBuf<int32_t> v3_hflags;          // [0] result blocks the host has finished with, [16] ordinal of the last launch that ended
   std::unique_lock<std::mutex> v3_slot;   // the device's persistent slot (held for the run)
@@ -1373,9 +1389,21 @@ struct Run {
     if (K.v2_mov_inline > 0) E2.mov_inline = std::min(MOV_INLINE2, K.v2_mov_inline);   // test knob: long mover lists
     if (K.v3_ring > 0) E2.ring_limit = std::min(RING2, K.v3_ring);                     // test knob: a host that lags
     E2.fail_ordinal = K.v3_fail_entry > 0 ? K.v3_fail_entry : 0;
+    E2.pf_on = v3_overlap ? 1 : 0; E2.pf_min = 2;
+    E2.pf_ctl = v3_pfctl.p; E2.pf_blist_n = v3_pf_blistn.p; E2.pfsync = v3_pfsync.p;
+    {   // how long a round waits inside the launch for a prefetch compare in flight before the launch is left (the host then
+        // orders the next launch behind the compare): a few compares' worth - a compare is ~0.6 ms per 10^6 uniques
+      const double us = K.v3_pf_wait_us >= 0 ? (double)K.v3_pf_wait_us : 2000.0 * std::max(1.0, (double)N / 5e5);
+      E2.pf_wait_ticks = (unsigned long long)(us * 100.0);
+    }
     E2.has_compare = 1;
     E2.align_at_commit = v2_align_commit ? 1 : 0;
     E2L = E2; E2L.has_compare = 0;
+    if (v3_overlap) {
+      S2 = s->D; S2.ad_ptr = v3_pf_ad.p; S2.ad_foff = v3_pf_foff.p; S2.ad_desc = v3_pf_fdesc.p;
+      E2P = E2; E2P.S = S2; E2P.ctl = v3_pfctl.p; E2P.C.tab8 = v3_pf_tab8.p; E2P.C.full = v3_pf_full.p; E2P.C.ord = v3_pf_ord.p;
+      E2P.blist = v3_pf_blist.p; E2P.blist_n = v3_pf_blistn.p; E2P.pf_on = 0; E2P.has_compare = 1;
+    }
     v2_drop_graph();                 // (captured launches hold the old argument block)
   }
   void v2_alloc(int max_clust) {
@@ -1421,12 +1449,12 @@ struct Run {
     D2_HIP(hipMemsetAsync(v2_dblk.p, 0, sizeof(Round2Out) * RING2, stq));
     D2_HIP(hipMemsetAsync(v2_dlt.p, 0, (size_t)SH_LEVELS * ccap * 4, stq));
     D2_HIP(hipMemsetAsync(v2_slotc.p, 0xFF, slots * 4, stq));
-    v3_setup(stq);
     for (int k = 0; k < RING2; k++) v2_hblk.p[k].seq = 0;
     Ctl2 c;
     memset(&c, 0, sizeof c);
     c.nclust = 1; c.centre = (int32_t)bi[0].center; c.slot = 0; c.max_clust = max_clust;
     c.n0 = N; c.low0 = N; c.need_compare = 0; c.nalign = 0; c.abuf = 0; c.stable = 1; c.bfrom = 0;
+    c.pf_bbuf = -1; c.last_bbuf = -1;
     for (int k = 0; k < KB_MAX; k++) c.acentre[k] = -1;
     for (int k = 0; k < KB_MAX; k++) c.bcentre[k] = -1;
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
@@ -1449,6 +1477,7 @@ struct Run {
     v2_plain_rounds = 0;
     v2_miss_launches = 0;
     v2_enqrec.clear();
+    v3_setup(stq);
     v2_bind();
   }
 
@@ -1464,8 +1493,28 @@ struct Run {
     v3_grid = tail_grid(N, s->device);
     if (K.v3_grid > 0) v3_grid = std::min(K.v3_grid, tail_grid(1 << 30, s->device));
     // refuse up front a grid the device cannot hold at once (the entry barrier would time out): the launch chains serve the run
-    v3_bs = K.v3_block == 512 ? 512 : 1024;
+    // The next batch's compare under the tail: on by default where batches are aligned ahead (not the long reads,
+    // which align at commit time) and the cache is deep enough to give a prefetch a buffer of its own.  The tail then runs on
+    // 512-thread blocks: half of every CU's registers stay free for the compare's kernels.
+    v3_overlap = v3_on && !v2_align_commit && v2_nbuf >= 4 && K.v3_overlap != 0 && N >= 2;
+    v3_bs = K.v3_block == 512 ? 512 : (K.v3_block == 1024 ? 1024 : (v3_overlap ? 512 : 1024));
     if (v3_on) { const int cap = tail_resident_max(s->device, v3_bs); if (cap > 0 && v3_grid > cap) v3_on = false; }
+    if (!v3_on) v3_overlap = false;
+    v3_pf_launched = 0;
+    if (v3_overlap) {
+      if (!s->cmp) D2_HIP(hipStreamCreateWithFlags(&s->cmp, hipStreamNonBlocking));
+      for (auto &e : v3_pf_ev) if (!e) D2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      const size_t npad = ((size_t)N + 31) & ~(size_t)15;
+      v3_pfctl.alloc(1); v3_pfsync.alloc(1); v3_pf_tab8.alloc(NKMER); v3_pf_full.alloc((size_t)KB_MAX * NKMER);
+      v3_pf_ord.alloc((size_t)KB_MAX * s->D.LK + 64); v3_pf_blist.alloc((size_t)2 * KB_MAX * npad); v3_pf_blistn.alloc(2 * KB_MAX);
+      // the second aligner scratch: pointer ring + the factor-offset rows of k_ad_product, sized as the first (ensure_ad_ring)
+      v3_pf_ad.alloc((size_t)s->D.ad_waves * s->D.ad_wpw);
+      v3_pf_foff.alloc((size_t)s->D.ad_fcap * s->D.ad_fstride); v3_pf_fdesc.alloc((size_t)s->D.ad_fcap);
+      D2_HIP(hipMemsetAsync(v3_pf_fdesc.p, 0xFF, (size_t)s->D.ad_fcap * sizeof(AdDesc), stq));
+      D2_HIP(hipMemsetAsync(v3_pfctl.p, 0, sizeof(Ctl2), stq));
+      D2_HIP(hipMemsetAsync(v3_pfsync.p, 0, sizeof(PfSync), stq));
+      D2_HIP(hipMemsetAsync(v3_pf_blistn.p, 0, 2 * KB_MAX * 4, stq));
+    }
     v3_psync.alloc(1); v3_hflags.alloc(32); v3_ktime.alloc(KT_N);
     D2_HIP(hipMemsetAsync(v3_psync.p, 0, sizeof(PSync), stq));
     D2_HIP(hipMemsetAsync(v3_ktime.p, 0, KT_N * 8, stq));
@@ -1493,11 +1542,25 @@ struct Run {
     (void)hipMemcpyAsync(&v2_ctl.p->state, v3_hflags.p + 24, 4, hipMemcpyHostToDevice, s->side);
     (void)hipStreamSynchronize(s->side);
     (void)hipStreamSynchronize(s->stream);
+    if (s->cmp) (void)hipStreamSynchronize(s->cmp);
     (void)hipGetLastError();
+    v3_pf_release();
+  }
+  // the second set of compare buffers goes back to the allocation cache when the rounds are over (nothing of this run is left on
+  // the second stream: the callers have waited for it)
+  void v3_pf_release() {
+    v3_pf_ad.free(); v3_pf_foff.free(); v3_pf_fdesc.free(); v3_pf_blist.free();
   }
   // the entry barrier of a persistent launch failed: clear the failure, give the slot back, continue on the launch chains
   void v3_fallback() {
     sync_spin(s->stream);
+    if (v3_overlap) {                                          // (the launch chains plan no prefetches)
+      sync_spin(s->cmp);
+      v3_pf_totals();
+      v3_overlap = false;
+      v2_bind();
+      v3_pf_release();
+    }
     D2_HIP(hipMemsetAsync(v3_psync.p, 0, sizeof(PSync), s->stream));
     launch2_resume(E2, s->stream, /*keep_list=*/true, /*compare_done=*/true);   // (every launch but the first has its compare in front of it)
     v3_release();
@@ -1537,6 +1600,48 @@ struct Run {
     v3_rec.push_back(rec);
     v3_enq++;
     st.ms_enqueue += ms_since(t_enq);
+  }
+
+  // Prefetch compare number k (the tail planned it: Ctl2::pf_seq reached k in the block just read) on the second stream: tables of
+  // the batch, screen, work lists, gapless pairs, aligner (+ product), completion word.  Everything it reads and writes is its
+  // own (descriptor, tables, lists, aligner scratch, the batch buffer's rows) or constant (the sample) - except the greedy locks
+  // the screen looks at, which only ever make it classify more pairs than the commit will use.
+  void v3_pf_enqueue(long k) {
+    const auto t_enq = clk::now();
+    hipStream_t st2 = s->cmp;
+    Ctl2 *pc = v3_pfctl.p;
+    launch2_pf_tables(E2P, st2);
+    int ev = ev_begin(EV_PF_SCREEN, profile_all, false, false, st2);
+    launch2_screen_multi(E2P, st2);
+    ev_end(ev);
+    launch2_batch_lists(E2P, st2);
+    const NwBatch nb{&pc->nalign, v3_pf_blistn.p, v3_pf_blist.p, pc->acentre, &pc->abuf, E2.C.Npad};
+    launch_gapless_batch(S2, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &pc->state, st2);
+    ev = ev_begin(EV_PF_NW, profile_all, false, false, st2);
+    launch_nw_ad(S2, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, st2,
+                 &pc->state, &nb);
+    ev_end(ev);
+    launch2_pf_done(E2P, st2);
+    D2_HIP(hipEventRecord(v3_pf_ev[k & 3], st2));
+    v3_pf_launched = k;
+    st.ms_enqueue += ms_since(t_enq);
+  }
+  int32_t v3_pf_stat[4] = {0, 0, 0, 0};   // Ctl2::pf_hits / pf_spins / pf_exits / pf_centres as of the last block read
+  void v3_pf_totals() {
+    PfSync ps;
+    D2_HIP(hipMemcpy(&ps, v3_pfsync.p, sizeof ps, hipMemcpyDeviceToHost));
+    st.nnw_run += ps.nnw; st.ngapless_run += ps.ngapless;      // pairs the prefetch compares' aligner launches worked through
+    st.pf_compares = (uint64_t)v3_pf_launched;
+    st.pf_hits = (uint64_t)v3_pf_stat[0]; st.pf_waits = (uint64_t)v3_pf_stat[1]; st.pf_exits = (uint64_t)v3_pf_stat[2]; st.pf_centres = (uint64_t)v3_pf_stat[3];
+    st.overlap_on = 1;
+  }
+  // what a published block says about the prefetch lane: a new plan goes to the second stream at once (before the block's moves
+  // are replayed), and a round that has to wait for a compare still in flight gets the next persistent launch ordered behind it
+  void v3_pf_serve(const Round2Out &b) {
+    if (!v3_overlap) return;
+    for (int k = 0; k < 4; k++) v3_pf_stat[k] = b.pf_stat[k];
+    while (v3_pf_launched < (long)b.pf_seq) v3_pf_enqueue(v3_pf_launched + 1);
+    if (b.pf_wait > 0 && (long)b.pf_wait <= v3_pf_launched) D2_HIP(hipStreamWaitEvent(s->stream, v3_pf_ev[b.pf_wait & 3], 0));
   }
 
   // (a fixed number per call: while the device is halted every launch ends at once, and "fewer than depth in flight" stays true
@@ -1620,6 +1725,7 @@ struct Run {
       }
       const Round2Out &b = *bp;
       n_blocks++;
+      v3_pf_serve(b);
       if (hooks && hooks->should_abort && hooks->should_abort(hooks->user))
         throw RuntimeErr{DADA2HIP_ERR_ABORTED, "dada2hip: aborted by caller"};
       if (v2_debug)
@@ -1683,6 +1789,11 @@ struct Run {
     }
     v3_running = false;
     sync_spin(s->stream);                                      // launches queued behind the final halt
+    if (v3_overlap) {
+      sync_spin(s->cmp);                                       // a last prefetch compare may still be running
+      v3_pf_totals();
+      v3_pf_release();
+    }
     if (profile_all && v3_ktime.p) {                           // phase clocks of block 0 (100 MHz): what the tail's time went into
       unsigned long long kt[KT_N];
       D2_HIP(hipMemcpy(kt, v3_ktime.p, sizeof kt, hipMemcpyDeviceToHost));
@@ -1697,7 +1808,10 @@ struct Run {
         fprintf(stderr, "\n");
       }
     }
-    st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid;
+    st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid; st.tail_threads = (uint32_t)v3_bs;
+    if (knobs().v2_summary && v3_overlap)
+      fprintf(stderr, "[v3] overlap: prefetch compares %ld (centres %d)  rounds served from a prefetched batch %d  waits inside the launch %d  launches left for one %d  threads per block %d\n",
+              v3_pf_launched, v3_pf_stat[3], v3_pf_stat[0], v3_pf_stat[1], v3_pf_stat[2], v3_bs);
     if (knobs().v2_summary)
       fprintf(stderr, "[v3] blocks %ld  launches %ld  grid %d  halts none/nobirth/host/more/cap/max %ld %ld %ld %ld %ld %ld  pauses %ld  ms: wait %.1f replay %.1f enqueue %.1f total %.1f  moves %llu misses %llu\n",
               n_blocks, v3_enq, v3_grid, n_halt[0], n_halt[1], n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_pause, st.ms_wait_device, st.ms_replay,
@@ -2301,7 +2415,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     // kernel times: event-timed launches, summed per kernel class.  Sampled mode: the per-round NW and screen launches
     // are extrapolated from the sampled ones; DADA2HIP_PROFILE=1: every launch was timed, the sums are exact.
     float ems;
-    double cls_ms[Run::EV_NCLS] = {0, 0, 0, 0, 0, 0, 0};
+    double cls_ms[Run::EV_NCLS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double nw_big = 0, nw_small = 0, sc_sum = 0;
     int n_small = 0, n_sc = 0, n_big = 0;
     for (size_t k = 0; k < run.ev_used; k++) {
@@ -2309,8 +2423,10 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       if (!e.ok) continue;                                             // speculative launch that found nothing to do
       D2_HIP(hipEventElapsedTime(&ems, e.a, e.b));
       cls_ms[e.cls] += ems;
-      if (e.cls == Run::EV_NW) { if (e.big) { nw_big += ems; n_big++; } else { nw_small += ems; n_small++; } }
-      if (e.cls == Run::EV_SCREEN) { sc_sum += ems; n_sc++; }
+      // (the prefetch compares of the second stream are aligner / screen launches like the others - they run beside the persistent
+      //  tail, which their durations show)
+      if (e.cls == Run::EV_NW || e.cls == Run::EV_PF_NW) { if (e.big) { nw_big += ems; n_big++; } else { nw_small += ems; n_small++; } }
+      if (e.cls == Run::EV_SCREEN || e.cls == Run::EV_PF_SCREEN) { sc_sum += ems; n_sc++; }
     }
     const int rounds = run.n_round_launches;
     if (run.profile_all) {
@@ -2323,6 +2439,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       run.st.dev_ms_shuffle = cls_ms[Run::EV_SHUFFLE]; run.st.dev_ms_pval = cls_ms[Run::EV_PVAL];
       run.st.dev_ms_birth = cls_ms[Run::EV_BIRTH]; run.st.dev_ms_final = cls_ms[Run::EV_FINAL];
       run.st.dev_ms_tail = cls_ms[Run::EV_TAIL];
+      run.st.dev_ms_pf_screen = cls_ms[Run::EV_PF_SCREEN]; run.st.dev_ms_pf_nw = cls_ms[Run::EV_PF_NW];
     } else {
       run.st.nw_kernel_ms = nw_big + (n_small ? nw_small / n_small * (rounds - 1) : 0.0);
       run.st.nw_kernel_launches = (uint64_t)rounds + 1;
@@ -2334,9 +2451,10 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     {   // algorithmic bytes the screen launches had to read: a unique's ordered k-mer record + 6 B of scalars
       const uint64_t row = 2 * (uint64_t)(D.maxlen - KMER_SIZE + 1);
       if (run.use_v2) {
-        run.st.screen_bytes = (uint64_t)N * (row + 6) * (1 + run.v2_miss_launches);   // round 0 + one pass per batch compare
-        run.st.batch_compares = run.v2_miss_launches;
-        if (!run.profile_all) run.st.screen_kernel_launches = 1 + run.v2_miss_launches;
+        const uint64_t passes = run.v2_miss_launches + run.st.pf_compares;                // batch compares: misses + prefetches
+        run.st.screen_bytes = (uint64_t)N * (row + 6) * (1 + passes);                     // round 0 + one pass per batch compare
+        run.st.batch_compares = passes;
+        if (!run.profile_all) run.st.screen_kernel_launches = 1 + passes;
       } else run.st.screen_bytes = (run.st.ncompare - run.st.nskipped) * row + run.st.ncompare * 6;
     }
   }
@@ -2521,6 +2639,7 @@ int dada2hip_sample_run_sharded(dada2hip_sample *s, const double *err, int32_t e
 void dada2hip_sample_free(dada2hip_sample *s) {
   if (!s) return;
   if (s->stream) { (void)hipSetDevice(s->device); (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+  if (s->cmp) { (void)hipStreamSynchronize(s->cmp); (void)hipStreamDestroy(s->cmp); }
   if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }   // (its buffers return to the allocation cache)
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);

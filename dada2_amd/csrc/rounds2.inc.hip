@@ -965,7 +965,6 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
     ctl->pf_wait = 0;
     s_bc[0] = raw;
     *s_nb = 1;
-    if (E.pf_on) *s_trig = (int32_t)(gcn_load_agent(&E.pfsync->done) - (uint32_t)ctl->pf_seq) >= 0 ? 1 : 0;
   }
   for (int q = tid; q < PLAN_BITS / 32; q += blockDim.x) s_bits[q] = 0;
   __syncthreads();
@@ -979,29 +978,18 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
   plan_select(E, raw, 1, s_bc, s_nb, s_tab, s_bits, s_p, s_rd, s_r, nslots);
   const int nb = *s_nb;
   const int bbuf_now = ctl->bbuf;
-  // (with a prefetch to plan behind this batch, the selection needs the LDS that the tables are built in: remember the batch first)
-  int mine = -1;
+  // (no prefetch is planned here: the compare of THIS batch has the device to itself, and the round that follows - its centre is
+  //  this batch's first position - plans the next one, which then runs under the rounds of this batch)
   if (tid < KB_MAX) {
     const int k = tid;
     if (k < nb) {
       const int c = s_bc[k];
-      mine = c;
       ctl->bcentre[k] = c; ctl->breads[k] = S.reads[c]; ctl->blen[k] = S.len[c];
       C.slot_centre[bbuf_now * KB_MAX + k] = c;
     } else { ctl->bcentre[k] = -1; ctl->breads[k] = 0; ctl->blen[k] = 0; }
   }
-  if (E.pf_on && *s_trig) {
-    if (tid < KB_MAX && mine >= 0) {                                  // the batch just planned counts as cached
-      s_tab[bbuf_now * KB_MAX + tid] = mine;
-      if (mine < PLAN_BITS) atomicOr(&s_bits[mine >> 5], 1u << (mine & 31));
-    }
-    __syncthreads();
-    plan_prefetch(E, raw, bbuf_now, s_misc, s_tab, s_bits, s_p, s_rd);
-    __syncthreads();
-  }
-  // ---- k-mer tables of the batch (the centres are re-read from the control block: the prefetch plan reused the LDS list) ----
   __syncthreads();
-  build_batch_tables(S, C, nb, ctl->bcentre, s_cnt);
+  build_batch_tables(S, C, nb, s_bc, s_cnt);
   if (tid == 0) { ctl->nbatch = nb; ctl->need_compare = 1; }
   plan_aligner(E, raw, bbuf_now * KB_MAX, nb);
 }

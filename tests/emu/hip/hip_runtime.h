@@ -174,6 +174,9 @@ inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSucc
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emuEvent(); return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emuEvent(); return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // (everything has run when it is enqueued)
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

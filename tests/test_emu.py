@@ -53,13 +53,16 @@ def run_cases(emu_lib, names, env=None, timeout=900):
                                  {"DADA2HIP_V3_GRID": "3"}, {"DADA2HIP_V3_GRID": "5", "DADA2HIP_V2_MOV_INLINE": "8"},
                                  {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V3_RING": "1", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_NODE_CAP": "1",
                                   "DADA2HIP_AD_FCAP": "40"},   # (+ a product buffer of 40 rows: the rest is multiplied up inside k_nw_ad)
+                                 # the serial form of the persistent tail (no prefetch compares, 1024-thread blocks), and the overlap with a
+                                 # tail that never waits inside the launch for a prefetch in flight (it leaves and comes back)
+                                 {"DADA2HIP_V3_OVERLAP": "0", "DADA2HIP_V3_GRID": "2"}, {"DADA2HIP_V3_PF_WAIT_US": "0", "DADA2HIP_V3_GRID": "3"},
                                  # the launch chains (DADA2HIP_V2_TAIL=chain: what a second sample on the same device runs on)
                                  {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_ALIGN": "commit"},
                                  {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_MOV_INLINE": "8"},
                                  {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_ALIGN": "commit", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_CHAIN": "1",
                                   "DADA2HIP_NODE_CAP": "1"}],
                          ids=["default", "classic-engine", "lane-kernel", "wide-kernel", "align-at-commit-grid2", "tail-grid3", "tail-grid5-pauses",
-                              "tail-grid2-ring1-nbuf1-grow", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
+                              "tail-grid2-ring1-nbuf1-grow", "tail-serial-grid2", "tail-overlap-no-wait-grid3", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
                               "chains-commit-nbuf1-chain1-grow"])
 def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
     out = run_cases(emu_lib, ("sam1F_default", "sam1R_default") if not env else ("sam1F_default",), env)   # (CPU suite budget: both only once)
@@ -251,8 +254,8 @@ def test_emulated_abort_hook_and_verbose_log_on_every_engine(emu_lib, env):
 
 
 @pytest.mark.parametrize("env", [{"DADA2HIP_V3_FAIL_ENTRY": "1"}, {"DADA2HIP_V3_FAIL_ENTRY": "2", "DADA2HIP_V3_GRID": "3"},
-                                 {"DADA2HIP_V3_FAIL_ENTRY": "4", "DADA2HIP_V2_NBUF": "1"}],
-                         ids=["first-launch", "second-launch-grid3", "fourth-launch-nbuf1"])
+                                 {"DADA2HIP_V3_FAIL_ENTRY": "3", "DADA2HIP_V2_NBUF": "1"}],
+                         ids=["first-launch", "second-launch-grid3", "third-launch-nbuf1"])
 def test_emulated_entry_barrier_failure_continues_on_the_launch_chains(emu_lib, env):
     """A persistent launch whose blocks do not all become resident gives up at its entry barrier, before anything has changed
     (DADA2HIP_V3_FAIL_ENTRY=n makes the n-th launch do exactly that): the run goes on on the launch chains and equals the golden."""
@@ -273,3 +276,31 @@ def test_emulated_entry_barrier_failure_continues_on_the_launch_chains(emu_lib, 
     e.update(env)
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "fallback: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("env", [{}, {"DADA2HIP_V3_GRID": "4", "DADA2HIP_V2_NBUF": "4", "DADA2HIP_V3_RING": "2"},
+                                 {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V2_NBUF": "5", "DADA2HIP_V2_MOV_INLINE": "16", "DADA2HIP_V3_PF_WAIT_US": "0"}],
+                         ids=["default", "grid4-nbuf4-ring2", "grid2-nbuf5-pauses-no-wait"])
+def test_emulated_prefetch_compares_under_the_tail_on_a_deeper_sample(emu_lib, env):
+    """The next batch's compare planned by the persistent tail and run on the second stream on the 20-partition
+    golden: rounds served out of prefetched batches, with the smallest cache that allows it (the buffer whose rows the coming
+    round commits is never the one a prefetch recycles), with pauses, with a host that lags."""
+    code = (
+        "import sys\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from dada2_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "from helpers import case_inputs, assert_results_equal\n"
+        "from dada2_amd import api\n"
+        "d, err, pri, o, exp, meta = case_inputs('synth3000_default')\n"
+        "got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"
+        "assert_results_equal(got, exp)\n"
+        "st = got.stats\n"
+        "assert st['overlap_on'] == 1 and st['pf_compares'] >= 1 and st['pf_hits'] >= 2, {k: st[k] for k in ('overlap_on', 'pf_compares', 'pf_hits')}\n"
+        "assert st['tail_threads'] == 512\n"
+        "print('prefetch: ok', st['pf_compares'], st['pf_hits'], st['pf_exits'])\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "prefetch: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
