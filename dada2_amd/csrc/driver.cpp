@@ -1390,6 +1390,7 @@ struct Run {
     if (K.v3_ring > 0) E2.ring_limit = std::min(RING2, K.v3_ring);                     // test knob: a host that lags
     E2.fail_ordinal = K.v3_fail_entry > 0 ? K.v3_fail_entry : 0;
     E2.pf_on = v3_overlap ? 1 : 0; E2.pf_min = 2;
+    E2.pf_early = K.v3_pf_early >= 0 ? K.v3_pf_early : 4;
     E2.pf_ctl = v3_pfctl.p; E2.pf_blist_n = v3_pf_blistn.p; E2.pfsync = v3_pfsync.p;
     {   // how long a round waits inside the launch for a prefetch compare in flight before the launch is left (the host then
         // orders the next launch behind the compare): a few compares' worth - a compare is ~0.6 ms per 10^6 uniques
@@ -1454,7 +1455,7 @@ struct Run {
     memset(&c, 0, sizeof c);
     c.nclust = 1; c.centre = (int32_t)bi[0].center; c.slot = 0; c.max_clust = max_clust;
     c.n0 = N; c.low0 = N; c.need_compare = 0; c.nalign = 0; c.abuf = 0; c.stable = 1; c.bfrom = 0;
-    c.pf_bbuf = -1; c.last_bbuf = -1;
+    c.pf_bbuf = -1; c.last_bbuf = -1; c.prev_bbuf = -1;
     for (int k = 0; k < KB_MAX; k++) c.acentre[k] = -1;
     for (int k = 0; k < KB_MAX; k++) c.bcentre[k] = -1;
     D2_HIP(hipMemcpyAsync(v2_ctl.p, &c, sizeof c, hipMemcpyHostToDevice, stq));
@@ -1612,7 +1613,7 @@ struct Run {
     Ctl2 *pc = v3_pfctl.p;
     launch2_pf_tables(E2P, st2);
     int ev = ev_begin(EV_PF_SCREEN, profile_all, false, false, st2);
-    launch2_screen_multi(E2P, st2);
+    launch2_screen_multi(E2P, st2, /*beside_tail=*/K_lowreg());
     ev_end(ev);
     launch2_batch_lists(E2P, st2);
     const NwBatch nb{&pc->nalign, v3_pf_blistn.p, v3_pf_blist.p, pc->acentre, &pc->abuf, E2.C.Npad};
@@ -1626,6 +1627,7 @@ struct Run {
     v3_pf_launched = k;
     st.ms_enqueue += ms_since(t_enq);
   }
+  static bool K_lowreg() { return knobs().v3_pf_lowreg != 0; }
   int32_t v3_pf_stat[4] = {0, 0, 0, 0};   // Ctl2::pf_hits / pf_spins / pf_exits / pf_centres as of the last block read
   void v3_pf_totals() {
     PfSync ps;

@@ -331,6 +331,7 @@ struct Ctl2 {
   // prefetch.  pf_wait: the coming round's centre sits in prefetch number pf_wait whose compare had not finished when the round
   // was decided: no round may start before PfSync::done >= pf_wait (0: nothing to wait for).
   int32_t pf_seq, pf_bbuf, last_bbuf, pf_wait;
+  int32_t prev_bbuf;            // the batch buffer planned before last_bbuf (-1: none since the last miss)
   // statistics of the run so far: rounds whose centre came out of a prefetched batch; spins for a prefetch in flight that
   // ended in time / that ended with the launch left; centres prefetched
   int32_t pf_hits, pf_spins, pf_exits, pf_centres;
@@ -443,6 +444,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   //      scratch ARE these (so they run unchanged); the tail's planner fills pf_ctl and clears pf_blist_n ----
   int32_t pf_on;                                    // 1: the tail plans prefetch compares
   int32_t pf_min;                                   // fewest uncached candidates worth a prefetch pass
+  int32_t pf_early;                                 // the next prefetch is planned when the rounds are this many positions into the batch BEFORE the one planned last (KB_MAX: only when they reach the last one)
   Ctl2 *pf_ctl;                                     // descriptor of the prefetch compare (nbatch, bbuf, bcentre / breads / blen, nalign, abuf, acentre; state stays 0)
   int32_t *pf_blist_n;                              // [2 KB_MAX] lengths of its work lists
   struct PfSync *pfsync;                            // PfSync::done = prefetch compares that have run
@@ -466,7 +468,7 @@ enum { KT_S0 = 0, KT_S0_BAR, KT_SL, KT_SL_BAR, KT_P, KT_P_BAR, KT_BIRTH, KT_PUBL
 
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
                     hipStream_t st);
-void launch2_screen_multi(const Eng2 &E, hipStream_t st);
+void launch2_screen_multi(const Eng2 &E, hipStream_t st, bool beside_tail = false);   // beside_tail: the 80-register build (prefetch compares)
 // prefetch compare (second stream): the k-mer tables of the batch pf_ctl describes (the planner only chose its centres) in front
 // of the screen, the completion word behind the aligner.  E = the prefetch's argument block (see Eng2::pf_on)
 void launch2_pf_tables(const Eng2 &E, hipStream_t st);

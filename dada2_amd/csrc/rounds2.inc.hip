@@ -870,7 +870,7 @@ static __device__ __forceinline__ void plan_prefetch(const Eng2 &E, int raw, int
     const int seq = ctl->pf_seq + 1;
     pc->nbatch = nb; pc->bbuf = bbuf; pc->nalign = nb; pc->abuf = bbuf; pc->pf_seq = seq; pc->state = 0;
     ctl->next_bbuf = (bbuf + 1) % C.NBUF;
-    ctl->pf_seq = seq; ctl->pf_bbuf = bbuf; ctl->last_bbuf = bbuf;
+    ctl->pf_seq = seq; ctl->pf_bbuf = bbuf; ctl->prev_bbuf = ctl->last_bbuf; ctl->last_bbuf = bbuf;
     ctl->pf_mask |= 1ull << (bbuf & 63);
     ctl->pf_centres += nb;
   }
@@ -935,8 +935,11 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
           if ((int32_t)(done - seq) < 0) { wait = (int)seq; ctl->pf_exits += 1; } else ctl->pf_spins += 1;
         }
         ctl->pf_wait = wait;
-        // the first round out of the batch planned last: time to plan the one after it, if the second stream is free
-        *s_trig = (hb == ctl->last_bbuf && (int32_t)(done - seq) >= 0) ? 1 : 0;
+        // Time to plan the next prefetch (the second stream being free)?  When the rounds reach the batch planned last - or already
+        // when they are pf_early positions into the one before it: a compare beside the tail takes longer than the rounds of one
+        // batch, so it has to start before the batch in front of it is used up
+        const bool due = hb == ctl->last_bbuf || (hb == ctl->prev_bbuf && (hit % KB_MAX) >= E.pf_early);
+        *s_trig = (due && (int32_t)(done - seq) >= 0) ? 1 : 0;
       }
     }
     plan_aligner(E, raw, hit, 0);
@@ -960,7 +963,7 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
     for (int k = 0; k < KB_MAX; k++) C.slot_centre[bbuf * KB_MAX + k] = -1;
     ctl->bbuf = bbuf;
     ctl->slot = bbuf * KB_MAX;
-    ctl->last_bbuf = bbuf;
+    ctl->prev_bbuf = -1; ctl->last_bbuf = bbuf;
     ctl->pf_mask &= ~(1ull << (bbuf & 63));
     ctl->pf_wait = 0;
     s_bc[0] = raw;
@@ -1397,7 +1400,12 @@ __global__ void k2_pf_done(Eng2 E) {
 // when (and if) a centre's round comes.
 struct ScrIn { uint4 c0, c1; int Lr, nh; uint32_t rd; bool lk; };
 
-__global__ __launch_bounds__(256, 4) void k2_screen_multi(Eng2 E) {
+// CORES: waves per SIMD the kernel is compiled for.  4 (123 registers) when it has the device to itself; 6 (80 registers, a few
+// spilled) for the prefetch compares that run BESIDE the persistent tail, which holds half of every CU's registers: the screen's
+// throughput is its resident blocks (every block waits for its rows most of the time), and three waves per SIMD fit into the
+// other half where two of the wide build do (profiles/r07c: 485 us beside the tail against 246 us alone).
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k2_screen_multi(Eng2 E) {
   const Ctl2 *ctl = E.ctl;
   const int nb = ctl->nbatch;
   if (ctl->state != 0 || nb == 0) return;
@@ -1573,17 +1581,19 @@ void launch2_batch_lists(const Eng2 &E, hipStream_t st) {
 }
 void launch2_pf_tables(const Eng2 &E, hipStream_t st) { hipLaunchKernelGGL(k2_pf_tables, dim3(1), dim3(1024), 0, st, E); }
 void launch2_pf_done(const Eng2 &E, hipStream_t st) { hipLaunchKernelGGL(k2_pf_done, dim3(1), dim3(64), 0, st, E); }
-void launch2_screen_multi(const Eng2 &E, hipStream_t st) {
+void launch2_screen_multi(const Eng2 &E, hipStream_t st, bool beside_tail) {
   const size_t lds = (size_t)NKMER * 8 + (size_t)KB_MAX * E.S.LK * 2 + (size_t)(E.S.maxlen + 2) * 4 + 16;
   static size_t attr_set[64] = {0};
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
   if (lds > attr_set[dev_ & 63]) {
-    (void)hipFuncSetAttribute((const void *)k2_screen_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k2_screen_multi<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k2_screen_multi<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev_ & 63] = lds;
   }
   const int grid = std::min((E.S.N + 63) / 64, 2048);
-  hipLaunchKernelGGL(k2_screen_multi, dim3(grid), dim3(256), lds, st, E);
+  if (beside_tail) hipLaunchKernelGGL(k2_screen_multi<6>, dim3(grid), dim3(256), lds, st, E);
+  else hipLaunchKernelGGL(k2_screen_multi<4>, dim3(grid), dim3(256), lds, st, E);
 }
 void launch2_shuffle(const Eng2 &E, int level, bool store, hipStream_t st) {
   const int grid = std::min((E.S.N + 255) / 256, (int)E.grid_shuffle);   // one device atomic per counter per block
