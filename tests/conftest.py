@@ -22,6 +22,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The at-size tests go LAST, and the reference runs they compare with are started in background processes right away
+    (tests/at_size.py): the rest of the GPU suite runs while the host's cores work through them."""
+    sized = [it for it in items if "at_size" in it.nodeid or "headline_1M" in it.nodeid]
+    if not sized or "not gpu" in (config.getoption("-m") or "") or config.getoption("--collect-only"):
+        return
+    rest = [it for it in items if it not in sized]
+    items[:] = rest + sized
+    try:
+        import torch
+        from oracle import ref
+        if torch.cuda.is_available() and ref.available():
+            import at_size
+            want = [c for c, key in (("cfg3", "headline_1M"), ("cfg4", "config4"), ("cfg5", "at_size_config5")) if any(key in it.nodeid for it in sized)]
+            at_size.start(tuple(want))
+    except Exception:   # pragma: no cover  (no GPU / no reference here: the tests skip themselves)
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle_c():
     """The plain-C restatement (oracle/libdada2oracle.so), built on demand."""

@@ -65,28 +65,14 @@ def test_at_size_selfconsist_every_pass_vs_reference(api, ref):
     assert_results_equal(res, passes[-1][3], exact_float=True)
 
 
-def _cfg4_samples():
-    """bench.py --config 4's pool: 8 samples x 250 k uniques, half of each sample's true variants shared."""
-    from dada2_amd.synth import make_sample, true_variants
-    cfg, n, L, G = 4, 250_000, 250, 512
-    shared = true_variants(np.random.default_rng(20260925 + cfg), G // 2, L)
-    out = []
-    for i in range(8):
-        own = true_variants(np.random.default_rng(20260925 + cfg + 17 * (i + 1)), G - G // 2, L)
-        tv, tl = np.concatenate([shared[0], own[0]]), np.concatenate([shared[1], own[1]])
-        perm = np.random.default_rng(99 + i).permutation(tv.shape[0])
-        out.append(make_sample(tperr1(), n, seed=20260925 + cfg + 1000 * (i + 1), variants=(tv[perm], tl[perm]), L=L, G=G,
-                               chunk=200_000))
-    return out
-
-
 def test_at_size_config4_eight_samples_through_run_multi_and_dada_multi(api, ref):
     import socket
     import torch
     import torch.distributed as dist
+    import at_size
     from dada2_amd.multi import dada_multi
-    dereps = _cfg4_samples()
-    err, o = tperr1(), DadaOpts()
+    dereps, err, o, wants = at_size.get("cfg4")    # bench.py --config 4's pool (8 samples x 250 k uniques) + the reference's results
+    assert len(dereps) == 8 and all(d.nraw == 250_000 for d in dereps)
     got_multi = api.dada_uniques_multi(dereps, err, o, devices=(0, 0))   # C entry: two host threads share this box's one GPU
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -97,8 +83,7 @@ def test_at_size_config4_eight_samples_through_run_multi_and_dada_multi(api, ref
         dist.destroy_process_group()
     assert sorted(got_dist) == list(range(8))
     trans = np.zeros((16, 41), dtype=np.int64)
-    for i, d in enumerate(dereps):
-        want = ref.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o, multithread=True)
+    for i, want in enumerate(wants):
         assert want.nclust > 100
         assert_results_equal(got_multi[i], want, p_rtol=P_RTOL)
         assert_results_equal(got_dist[i], want, p_rtol=P_RTOL)
@@ -108,12 +93,10 @@ def test_at_size_config4_eight_samples_through_run_multi_and_dada_multi(api, ref
 
 
 def test_at_size_config5_long_reads_200k_vs_reference(api, ref):
-    from dada2_amd.synth import make_sample
-    err = extend_err(tperr1(), 93)
-    d = make_sample(err, 200_000, L=1510, G=128, seed=20260925 + 5, Lmin=1450, q_hi=93.0, q_lo=30.0, q_max=93, indel_rate=1e-4,
-                    chunk=20_000)
-    o = DadaOpts(BAND_SIZE=32, MAX_CLUST=32)
+    import at_size
+    dereps, err, o, wants = at_size.get("cfg5")    # bench.py --config 5's sample (200 k uniques of 1 450-1 510 nt) + the reference's result
+    d, want = dereps[0], wants[0]
+    assert d.nraw == 200_000 and o.BAND_SIZE == 32 and o.MAX_CLUST == 32
     got = api.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
-    want = ref.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o, multithread=True)
     assert got.nclust == want.nclust == 32
     assert_results_equal(got, want, p_rtol=P_RTOL)

@@ -302,16 +302,16 @@ def test_dada_multi_with_real_runner_under_nccl(api):
 # ---- BASELINE.json's sizes ------------------------------------------------------------------------------------------------
 def test_headline_1M_uniques_full_parity_vs_reference_itself(api):
     """BASELINE.json's headline size: 1 000 000 unique 250-nt reads (bench.py's default workload, same seed).  EVERY output
-    of the GPU run against the reference's own C++ on all host cores (~1 min of CPU).  Skipped without oracle/_ref."""
+    of the GPU run against the reference's own C++ (about a minute of its multithreaded path, run in the background since the
+    session started: tests/at_size.py).  Skipped without oracle/_ref."""
     from oracle import ref
     if not ref.available():
         pytest.skip("oracle/_ref not present")
-    from dada2_amd.synth import make_sample
-    d = make_sample(tperr1(), 1_000_000, L=250, G=2048, seed=20260925 + 3)
-    got = api.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts())
-    ref.set_threads(os.cpu_count() or 1)
-    want = ref.dada_uniques(d.seqs, d.abundances, None, tperr1(), d.quals, DadaOpts(), multithread=True)
-    ref.set_threads(1)
+    import at_size
+    dereps, err, o, wants = at_size.get("cfg3")
+    d, want = dereps[0], wants[0]
+    assert d.nraw == 1_000_000
+    got = api.dada_uniques(d.seqs, d.abundances, None, err, d.quals, o)
     assert got.nclust == want.nclust > 300
     assert_results_equal(got, want, p_rtol=P_RTOL)
 
