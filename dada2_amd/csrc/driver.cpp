@@ -2256,6 +2256,25 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   std::vector<int32_t> work, chunk_centre, centre_of_cluster(C);
   work.reserve((size_t)N + per * (size_t)C);
   uint64_t n_final_local = 0;
+  if (!shard) {
+    // every member of every partition, a partition's members in list order, padded to whole chunks: the member lists ARE the
+    // work list (one block copy per partition instead of a push per unique: 10^6 uniques cost 5 ms here)
+    size_t tot = 0;
+    for (int i = 0; i < C; i++) tot += (run.bi[i].raw.size() + per - 1) / per * per;
+    work.assign(tot, -1);
+    chunk_centre.resize(tot / per);
+    size_t off = 0;
+    for (int i = 0; i < C; i++) {
+      centre_of_cluster[i] = (int32_t)run.bi[i].center;
+      const auto &m = run.bi[i].raw;
+      static_assert(sizeof(m[0]) == sizeof(int32_t), "member lists are 32-bit");
+      if (!m.empty()) memcpy(work.data() + off, m.data(), m.size() * sizeof(int32_t));
+      const size_t nch = (m.size() + per - 1) / per;
+      std::fill(chunk_centre.begin() + off / per, chunk_centre.begin() + off / per + nch, (int32_t)run.bi[i].center);
+      off += nch * per;
+      n_final_local += m.size();
+    }
+  } else
   for (int i = 0; i < C; i++) {
     centre_of_cluster[i] = (int32_t)run.bi[i].center;
     const auto &m = run.bi[i].raw;
@@ -2515,20 +2534,32 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   R->abundance.assign(C, 0); R->n0.assign(C, 0); R->n1.assign(C, 0); R->nunq.assign(C, 0);
   R->birth_from.assign(C, 0); R->birth_ham.assign(C, 0); R->center.assign(C, 0);
   R->clust_pval.assign(C, 0); R->birth_pval.assign(C, 0); R->birth_fold.assign(C, 0); R->birth_qave.assign(C, 0);
-  for (int i = 0; i < C; i++) {   // b_make_clustering_df (error.cpp:9-127)
-    const Bi &b = run.bi[i];
-    uint32_t max_reads = 0;
-    int max_raw = -1;
-    for (uint32_t raw : b.raw) if (s->h_reads[raw] > max_reads) { max_raw = (int)raw; max_reads = s->h_reads[raw]; }
-    R->sequence[i] = max_raw >= 0 ? seq_string(s, max_raw) : std::string("");
-    R->center[i] = (int32_t)b.center;
-    for (uint32_t raw : b.raw) {
-      if (!correct[raw]) continue;
-      R->abundance[i] += (int32_t)s->h_reads[raw];
+  // b_make_clustering_df (error.cpp:9-127).  The sums over a partition's members are integer sums and the representative
+  // sequence is the member with the most reads, the FIRST such in list order (error.cpp:19-34): one streaming pass over the
+  // uniques in index order with the host mirror's partition / slot of each (the per-partition member loops were 10^6 random
+  // reads into three arrays) gives the same values
+  R->map.assign(N, DADA2HIP_NA_INTEGER);   // Rmain.cpp:268-279
+  {
+    std::vector<uint32_t> max_reads(C, 0);
+    std::vector<int32_t> max_raw(C, -1), max_slot(C, 0);
+    for (int r = 0; r < N; r++) {
+      const int i = run.clust_of[r];
+      const uint32_t rd = s->h_reads[r];
+      if (rd > max_reads[i] || (rd == max_reads[i] && max_raw[i] >= 0 && run.slot_of[r] < max_slot[i])) {
+        max_reads[i] = rd; max_raw[i] = r; max_slot[i] = run.slot_of[r];
+      }
+      if (!correct[r]) continue;
+      R->map[r] = i + 1;
+      R->abundance[i] += (int32_t)rd;
       R->nunq[i]++;
-      if (nsubs[raw] == 0) R->n0[i] += (int32_t)s->h_reads[raw];
-      if (nsubs[raw] == 1) R->n1[i] += (int32_t)s->h_reads[raw];
+      if (nsubs[r] == 0) R->n0[i] += (int32_t)rd;
+      if (nsubs[r] == 1) R->n1[i] += (int32_t)rd;
     }
+    for (int i = 0; i < C; i++) R->sequence[i] = max_raw[i] >= 0 ? seq_string(s, max_raw[i]) : std::string("");
+  }
+  for (int i = 0; i < C; i++) {
+    const Bi &b = run.bi[i];
+    R->center[i] = (int32_t)b.center;
     if (i == 0) {
       R->birth_pval[i] = na_real(); R->birth_from[i] = DADA2HIP_NA_INTEGER; R->birth_fold[i] = na_real();
       R->birth_ham[i] = DADA2HIP_NA_INTEGER; R->birth_qave[i] = na_real();
@@ -2575,9 +2606,6 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       R->clusterquals[(size_t)i * D.maxlen + p0] = ((double)qsum[(size_t)i * D.maxlen + p0]) / qn[(size_t)i * D.maxlen + p0];
     for (int p0 = clen; p0 < D.maxlen; p0++) R->clusterquals[(size_t)i * D.maxlen + p0] = na_real();
   }
-  R->map.assign(N, DADA2HIP_NA_INTEGER);   // Rmain.cpp:268-279
-  for (int i = 0; i < C; i++)
-    for (uint32_t raw : run.bi[i].raw) R->map[raw] = correct[raw] ? i + 1 : DADA2HIP_NA_INTEGER;
   run.st.ms_final = ms_since(t_final);
   run.st.ms_total = ms_since(t_total);
   R->stats = run.st;
