@@ -2211,7 +2211,12 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   // the reference's next iteration, so one device round trip serves both.  After a decision the next round's
   // kernels are launched first; the host mirror (moves replay, birth record) is updated while the GPU works.
   if (run.use_v2 && run.v3_on && run.v3_acquire()) run.run_v3(max_clust);
-  else if (run.use_v2) run.run_v2(max_clust);
+  else if (run.use_v2) {
+    // the launch chains (asked for, or another run holds the device's persistent slot) plan no prefetch compares: nobody would
+    // launch them, and a round must never take its comparisons from a batch that was only planned
+    if (run.v3_overlap) { run.v3_overlap = false; run.v2_bind(); run.v3_pf_release(); }
+    run.run_v2(max_clust);
+  }
   else if (run.nclust_dev < max_clust) {
     run.round_tail(false);                            // b_p_update after round 0, then the first b_bud
     for (;;) {
