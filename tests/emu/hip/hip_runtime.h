@@ -147,7 +147,10 @@ inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-inline hipError_t hipDeviceGetPCIBusId(char *b, int n, int d) { snprintf(b, n, "emu%d_%d", d, (int)getpid()); return hipSuccess; }
+inline hipError_t hipDeviceGetPCIBusId(char *b, int n, int d) {   // (EMU_PCI_ID: a test holds the device's persistent-slot lock file from outside)
+  if (const char *e = getenv("EMU_PCI_ID")) snprintf(b, n, "%s", e); else snprintf(b, n, "emu%d_%d", d, (int)getpid());
+  return hipSuccess;
+}
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::memset(p, 0, sizeof *p); p->multiProcessorCount = 8; p->clockRate = 1000000; return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = *tot = (size_t)16 << 30; return hipSuccess; }
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 1; return hipSuccess; }

@@ -304,3 +304,36 @@ def test_emulated_prefetch_compares_under_the_tail_on_a_deeper_sample(emu_lib, e
     e.update(env)
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "prefetch: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_emulated_run_without_the_persistent_slot_takes_the_chains_and_plans_no_prefetch(emu_lib, tmp_path):
+    """Another process holds the device's persistent slot (its lock file): the run takes the launch chains - and must not carry
+    the persistent tail's prefetch planner with it (a round would take its comparisons from a batch nobody ever compared: found
+    on the MI355X by three ranks sharing one GPU)."""
+    import fcntl
+    pci = "emutest_%d" % os.getpid()
+    lock = open("/tmp/dada2hip_persistent_%s.lock" % pci, "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        code = (
+            "import sys\n"
+            "sys.path[:0] = [%r, %r]\n"
+            "from dada2_amd import _lib\n"
+            "_lib.LIB_PATH = %r\n"
+            "from helpers import case_inputs, assert_results_equal\n"
+            "from dada2_amd import api\n"
+            "d, err, pri, o, exp, meta = case_inputs('synth3000_default')\n"
+            "got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"
+            "assert_results_equal(got, exp)\n"
+            "st = got.stats\n"
+            "assert st['tail_launches'] == 0 and st['overlap_on'] == 0 and st['pf_compares'] == 0, st\n"
+            "print('chains without the slot: ok')\n"
+        ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
+        e = dict(os.environ)
+        e["EMU_PCI_ID"] = pci
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "chains without the slot: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+        os.remove("/tmp/dada2hip_persistent_%s.lock" % pci)
