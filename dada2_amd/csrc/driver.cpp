@@ -165,6 +165,14 @@ struct PersistFile {
   }
   void release() { if (held && fd >= 0) (void)flock(fd, LOCK_UN); held = false; }
 };
+// Boundary calls of THIS process that are running on a device right now (dada2hip_run_multi / several threads of the caller with
+// a sample each): the persistent tail plans prefetch compares only for a run that has the device to itself - with a second
+// sample in flight its kernels already fill the tail's gaps, and a round spinning for a prefetch that queues behind them holds
+// the device's persistent slot for nothing (configs[3] on one GPU, two in flight: 236 ms without, 456 ms with; profiles/r07i)
+std::atomic<int> &active_runs(int device) {
+  static std::atomic<int> n[64];
+  return n[device & 63];
+}
 PersistFile &persistent_file(int device) {
   static PersistFile files[64];
   return files[device & 63];
@@ -1497,7 +1505,7 @@ struct Run {
     // The next batch's compare under the tail: on by default where batches are aligned ahead (not the long reads,
     // which align at commit time) and the cache is deep enough to give a prefetch a buffer of its own.  The tail then runs on
     // 512-thread blocks: half of every CU's registers stay free for the compare's kernels.
-    v3_overlap = v3_on && !v2_align_commit && v2_nbuf >= 4 && K.v3_overlap != 0 && N >= 2;
+    v3_overlap = v3_on && !v2_align_commit && v2_nbuf >= 4 && K.v3_overlap != 0 && N >= 2 && (active_runs(s->device).load() <= 1 || K.v3_overlap == 1);
     v3_bs = K.v3_block == 512 ? 512 : (K.v3_block == 1024 ? 1024 : (v3_overlap ? 512 : 1024));
     if (v3_on) { const int cap = tail_resident_max(s->device, v3_bs); if (cap > 0 && v3_grid > cap) v3_on = false; }
     if (!v3_on) v3_overlap = false;
@@ -2158,6 +2166,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   select_device(s->device);
   if (!err || !opts) throw InputError{"Error matrix must have 16 rows."};
   check_opts(*opts, s->qmax, err_ncol);
+  struct ActiveGuard { int dev; ActiveGuard(int d) : dev(d) { active_runs(dev)++; } ~ActiveGuard() { active_runs(dev)--; } } active_guard{s->device};
   SampleDev &D = s->D;
   const int N = D.N;
   if (shard && (shard->world < 1 || shard->rank < 0 || shard->rank >= shard->world || !shard->exchange))
