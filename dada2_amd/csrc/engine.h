@@ -263,7 +263,10 @@ int nw_adw_apw(const SampleDev &S, const AlignParams &ap);
 constexpr int KB_MAX = 8;          // centres per batch compare (one byte lane each in the packed count table)
 constexpr int SH_CHAIN = 4;        // b_shuffle2 calls enqueued per chain (the first unconditional, the rest guarded)
 constexpr int SH_LEVELS = MAX_SHUFFLE;   // b_shuffle2 calls of one round (Rmain.cpp:321): what the persistent tail kernel runs in one go
-constexpr int RING2 = 16;          // result blocks in flight (device copies + pinned host copies)
+#ifndef D2_RING2
+#define D2_RING2 16
+#endif
+constexpr int RING2 = D2_RING2;    // result blocks in flight (device copies + pinned host copies)
 constexpr int MOV_RING = 4;        // full mover lists in flight (launch chains; the persistent tail keeps one set and pauses on overflow)
 constexpr int TRACE_BLOCKS = 4096, TRACE_KERNELS = 8;   // (slot 0 unused since k2_lists went into the store pass; shuffle 0..3, p-update, birth, spare)
 constexpr int MOV_INLINE2 = 32768; // movers published inline per chain (all its shuffles, concatenated); only the used part is copied

@@ -81,16 +81,7 @@ static __device__ __forceinline__ int32_t gcn_load_system(const int32_t *p) { re
 // wave priority 3 (s_setprio): a latency-bound kernel sharing its CUs with throughput kernels issues ahead of them
 static __device__ __forceinline__ void gcn_raise_priority() { __builtin_amdgcn_s_setprio(3); }
 // what a polling lane does between two looks at a word another workgroup (or the host) will write
-#ifdef D2_EXP_POLL
-static __device__ __forceinline__ void gcn_poll_pause() { __builtin_amdgcn_s_sleep(D2_EXP_POLL); }
-#else
-static __device__ __forceinline__ void gcn_poll_pause() { __builtin_amdgcn_s_sleep(2); }
-#endif
-// a 16-byte load that is used once (streaming hint: no reason to keep the line)
-static __device__ __forceinline__ uint4 gcn_load_stream(const uint4 *p) {
-  const uint32_t *q = (const uint32_t *)p;
-  return make_uint4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
-}
+static __device__ __forceinline__ void gcn_poll_pause() { __builtin_amdgcn_s_sleep(2); }   // (0 and 12 measured: no difference, profiles/r07f)
 // constant-rate clock (100 MHz) for the bounds of those spins
 static __device__ __forceinline__ unsigned long long gcn_wall_clock() { return wall_clock64(); }
 constexpr unsigned long long GCN_WALL_HZ = 100000000ull;

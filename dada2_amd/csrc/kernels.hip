@@ -1150,12 +1150,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
       tA = gcn_readfirstlane(tA);
       tB = gcn_readfirstlane(tB);
-#ifdef D2_EXP_NT
-#define AD_FLUSH(TT) { __builtin_nontemporal_store(pw, &pg[(size_t)((TT) >> 4) * 64 + lane]); pw = 0; }
-#else
-#define AD_FLUSH(TT) { pg[(size_t)((TT) >> 4) * 64 + lane] = pw; pw = 0; }
-#endif
-#define AD_FLUSH_UNUSED(TT) { pg[(size_t)((TT) >> 4) * 64 + lane] = pw; pw = 0; }   /* every lane, unconditionally: one 256-byte store */
+#define AD_FLUSH(TT) { pg[(size_t)((TT) >> 4) * 64 + lane] = pw; pw = 0; }   /* every lane, unconditionally: one 256-byte store */
 #define AD_STEP(PARV, LEANV, VNEXT, FS, KOK, GS)                                                                                   \
   {                                                                                                                             \
     if (DEF) ad_step_k<GL, PARV, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), (PARV) ? gn1 : gn0, L1, L2); \

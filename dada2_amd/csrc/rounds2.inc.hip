@@ -1443,13 +1443,8 @@ __global__ __launch_bounds__(256, WAVES) void k2_screen_multi(Eng2 E) {
     ScrIn in;
     const bool on = r < S.N;
     const uint4 *row = (const uint4 *)(S.kord + (size_t)(on ? r : 0) * S.LK);
-#ifdef D2_EXP_NT
-    in.c0 = (on && sp.use_kmers && sub < nchunk) ? gcn_load_stream(&row[sub]) : pad4;
-    in.c1 = (on && sp.use_kmers && sub + 16 < nchunk) ? gcn_load_stream(&row[sub + 16]) : pad4;
-#else
     in.c0 = (on && sp.use_kmers && sub < nchunk) ? row[sub] : pad4;
     in.c1 = (on && sp.use_kmers && sub + 16 < nchunk) ? row[sub + 16] : pad4;
-#endif
     in.Lr = on ? S.len[r] : 0;
     in.rd = on ? S.reads[r] : 0u;
     in.lk = on && E.greedy && E.P.lock[r];
