@@ -81,6 +81,30 @@ if dbs:
             sv = sorted(v)
             L.append(f"| `{a}` | `{b2}` | {len(v)} | {sum(v) / 1e3:.2f} | {sv[len(sv) // 2]:.0f} |")
         L += ["", f"Total {sum(sum(v) for v in big.values()) / 1e3:.1f} ms in {sum(len(v) for v in big.values())} gaps.", ""]
+    # Concurrency: which kernels ran INSIDE the interval of a persistent round-tail launch (the prefetch compares of the second
+    # stream)?  For every working k3_tail launch: the kernels whose [start, end] intersects it, by name.
+    tails = [(st, en) for n, st, en in ks if "k3_tail" in n and en - st >= 20000]
+    if tails:
+        import bisect
+        starts = [t[0] for t in tails]
+        inside = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        for n, st, en in ks:
+            if "k3_tail" in n:
+                continue
+            i = bisect.bisect_right(starts, en) - 1
+            while i >= 0 and tails[i][1] > st:
+                ov = min(en, tails[i][1]) - max(st, tails[i][0])
+                if ov > 0:
+                    rec = inside[short(n)]
+                    rec[0] += 1; rec[1] += ov / 1e3; rec[2] += (en - st) / 1e3
+                i -= 1
+        tail_ms = sum(en - st for st, en in tails) / 1e6
+        L += ["## Kernels that ran inside the interval of a `k3_tail` launch (two streams: the next batch's compare under the round tail)", "",
+              f"{len(tails)} working `k3_tail` launches, {tail_ms:.1f} ms in all.", "",
+              "| kernel | launches overlapping a tail launch | overlapped ms | their total ms |", "|---|---|---|---|"]
+        for n, (c, ov, tot) in sorted(inside.items(), key=lambda kv: -kv[1][1]):
+            L.append(f"| `{n}` | {c} | {ov / 1e3:.2f} | {tot / 1e3:.2f} |")
+        L += ["", f"Overlapped kernel time {sum(v[1] for v in inside.values()) / 1e3:.1f} ms of {tail_ms:.1f} ms of tail launches.", ""]
     res = list(db.execute("select name, max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
                           "max(workgroup_x), avg(grid_x) from kernels where name like 'd2::%' or name like 'void d2::%' group by name"))
     L += ["## Dispatch resources", "", "| kernel | VGPR | AGPR | SGPR | LDS B | scratch B | wg | avg grid threads |", "|---|---|---|---|---|---|---|---|"]
@@ -111,7 +135,7 @@ for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     # (dispatches shorter than 8 us are the no-op speculative launches of the per-round kernels: not part of the average)
     for k, n, a in db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? and "
                               "(kernel_name like 'd2::%' or kernel_name like 'void d2::%') and "
-                              "(duration >= 8000 or (kernel_name not like '%k_nw_ad%' and kernel_name not like '%k_screen%' and kernel_name not like '%k2_screen_multi%')) "
+                              "(duration >= 8000 or (kernel_name not like '%k_nw_ad%' and kernel_name not like '%k_screen%' and kernel_name not like '%k2_screen_multi%' and kernel_name not like '%k3_tail%')) "
                               "group by kernel_name", (cname,)):
         traffic.setdefault(short(k), {})[cname + "_KB_avg"] = a
         traffic[short(k)]["dispatches"] = n
@@ -124,7 +148,9 @@ if traffic:
     if sc: hot["screen"] = sc[0]
     nw = [v for k, v in traffic.items() if "k_nw_ad" in k or "k_nw_adw" in k]
     if nw: hot["nw"] = max(nw, key=lambda v: v.get("dispatches", 0))
-    json.dump({"tag": tag, "command": desc, "screen": hot.get("screen"), "nw": hot.get("nw"),
+    tl = [v for k, v in traffic.items() if "k3_tail" in k]
+    if tl: hot["tail"] = tl[0]
+    json.dump({"tag": tag, "command": desc, "screen": hot.get("screen"), "nw": hot.get("nw"), "tail": hot.get("tail"),
                "note": "avg per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 half-count on wide reads)",
                "kernels": traffic}, open(os.path.join(root, f"{tag}_traffic.json"), "w"), indent=1)
 open(os.path.join(root, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
