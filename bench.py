@@ -277,14 +277,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ar_ms = []                                    # wall of the all-reduce of each step on this rank (multi-GPU runs explain themselves)
+
     def allreduce_trans(results):
         local_t = np.zeros((16, maxcol), dtype=np.int64)
         for r in results:
             local_t[:, : r.subqual.shape[1]] += r.subqual
         if world > 1:   # accumulateTrans across samples: the path's only exchange (int64, <= 12 KB)
+            ta = time.perf_counter()
             t = torch.from_numpy(local_t).cuda()
             dist.all_reduce(t)
             local_t = t.cpu().numpy()
+            ar_ms.append((time.perf_counter() - ta) * 1e3)
         return local_t
 
     sc_info = None
@@ -311,9 +315,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    del ar_ms[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         results = step()
+    dt_rank = time.perf_counter() - t0            # this rank's own wall, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     n_local = sum(d.nraw for d in dereps)
@@ -324,8 +330,16 @@ def main():
         nn = torch.tensor([n_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(nn)
         total_uniques = n_local if args.shard else int(nn.item())   # --shard: every rank holds the SAME sample
+        # per-rank record: own wall before the closing barrier, samples of the rank, time in the all-reduce
+        rk = torch.tensor([dt_rank / args.steps * 1e3, float(len(mine)), (sum(ar_ms) / max(1, len(ar_ms))) if ar_ms else 0.0],
+                          dtype=torch.float64, device="cuda")
+        allrk = [torch.zeros_like(rk) for _ in range(world)]
+        dist.all_gather(allrk, rk)
+        per_rank = [{"rank": i, "ms_per_step_own_wall": float(v[0]), "samples": int(v[1]), "ms_allreduce_per_step": float(v[2])}
+                    for i, v in enumerate(allrk)]
     else:
         total_uniques = n_local
+        per_rank = [{"rank": 0, "ms_per_step_own_wall": dt_rank / args.steps * 1e3, "samples": len(mine), "ms_allreduce_per_step": 0.0}]
 
     if rank == 0:
         res, d = results[0], dereps[0]
@@ -433,6 +447,9 @@ def main():
             "config4_eight_samples_one_gpu": sub4,
             "phases_ms_last_step": phases(st, pst if prof else None),
             "comparisons_per_s": st["ncompare"] * len(inputs) * world * args.steps / dt,
+            "per_rank": per_rank,
+            "samples_in_flight_per_gpu": (min(args.inflight, len(inputs)) if len(inputs) > 1 else 1),
+            "collective": "one all-reduce(sum) of the 16 x %d int64 transition counts per step (RCCL; accumulateTrans, R/errorModels.R:462-471)" % maxcol if world > 1 else None,
             "gen_s": t_gen,
         }
         print(json.dumps(out))
