@@ -462,9 +462,9 @@ std::string seq_string(const dada2hip_sample *s, int i) {
 
 // items: alignments a launch will hold when that is more than one per unique (the bimera table's pairs: a few thousand
 // sequences, millions of pairs - sized by N the launch would run on a dozen blocks)
-void ensure_scratch(dada2hip_sample *s, int band, size_t items = 0) {
+void ensure_scratch(dada2hip_sample *s, int band, size_t items = 0, bool force_generic = false) {
   SampleDev &D = s->D;
-  int wc = nw_class(band, D.maxlen, D.minlen);
+  int wc = force_generic ? 0 : nw_class(band, D.maxlen, D.minlen);
   const size_t want = std::max<size_t>((size_t)D.N, items);
   if (s->scr_class == wc && s->scr_band == band && s->scr.ptr && s->scr_items >= want) return;
   s->scr_items = want;
@@ -2850,31 +2850,63 @@ int dada2hip_calc_pA(int32_t n, const int32_t *reads, const double *E_reads, con
 }
 
 // ---- pairwise alignment exports (C_nwalign evaluate.cpp:18 / C_nwvec nwalign_vectorized.cpp:321) ---
+// vec_semantics: the call is C_nwvec (raw-byte comparison, any letters); else C_nwalign (nt2int codes: ACGT only)
 static int nwvec_any(int32_t n, const char *const *s1, const char *const *s2, int32_t match, int32_t mismatch,
                      int32_t gap_p, int32_t homo_gap_p, int32_t band, int32_t endsfree, int32_t device, char *const *out, char *errbuf,
-                     size_t errlen) {
+                     size_t errlen, bool vec_semantics = false) {
   return guarded(errbuf, errlen, [&] {
     if (n <= 0) return;
     // a throw-away resident sample holding the 2n strings; pair i = (centre 2i, raw 2i+1), one pair per LANE: the lane kernels
     // take a centre per work item (NwArgs::pair_centre), so 64 unrelated pairs share a wave and the move strings take
     // n x (2 maxlen + 2) bytes (round 2 gave every pair a whole 64-slot chunk: 64x the memory)
     std::vector<const char *> seqs(2 * (size_t)n);
-    std::vector<int32_t> ab(2 * (size_t)n, 1);
     int maxlen = 0;
+    bool acgt = true;
     for (int i = 0; i < n; i++) {
       seqs[2 * i] = s1[i]; seqs[2 * i + 1] = s2[i];
       maxlen = std::max<int>(maxlen, (int)std::max(strlen(s1[i]), strlen(s2[i])));
     }
-    // helper sample without qualities / k-mer records / length checks (C_nwvec accepts any strings; only A/C/G/T can
-    // be represented in the 2-bit rows, anything else is reported as the real limitation)
-    for (int i = 0; i < 2 * n; i++)
+    for (int i = 0; i < 2 * n && acgt; i++)
       for (const char *c = seqs[i]; *c; c++)
-        if (*c != 'A' && *c != 'C' && *c != 'G' && *c != 'T')
-          throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: nwalign on the device takes A/C/G/T only (N and IUPAC codes are not representable in 2 bits)."};
+        if (*c != 'A' && *c != 'C' && *c != 'G' && *c != 'T') { acgt = false; break; }
+    // Letters outside ACGT.  C_nwalign has no defined behaviour for them (nt2int maps N to 5 and the aligners index a 4 x 4
+    // score table with it, evaluate.cpp:28-33); C_nwvec has: it compares the strings' raw BYTES (nwalign_vectorized.cpp:165), so
+    // only the equality pattern of a pair's letters matters.  The letters of each pair are renumbered 0..15 in order of first
+    // appearance and stored as two 2-bit planes (AlignParams::hi_off); more than 16 distinct bytes in one pair is not DNA.
+    const bool planes = !acgt;
+    if (planes && (!vec_semantics || homo_gap_p != gap_p))
+      throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: nwalign on the device takes A/C/G/T only (the reference's own behaviour for N / IUPAC codes is undefined there: evaluate.cpp:28-33)."};
+    std::vector<std::string> coded;          // planes: [0, 2n) low planes, [2n, 4n) high planes, as ACGT strings
+    if (planes) {
+      coded.resize(4 * (size_t)n);
+      for (int i = 0; i < n; i++) {
+        int code_of[256];
+        for (int &c : code_of) c = -1;
+        int ncodes = 0;
+        for (int w = 0; w < 2; w++) {
+          const char *str = seqs[2 * i + w];
+          const size_t len = strlen(str);
+          std::string &lo = coded[2 * i + w], &hi = coded[2 * (size_t)n + 2 * i + w];
+          lo.resize(len); hi.resize(len);
+          for (size_t p = 0; p < len; p++) {
+            int &c = code_of[(unsigned char)str[p]];
+            if (c < 0) {
+              if (ncodes == 16) throw RuntimeErr{DADA2HIP_ERR_UNSUPPORTED, "dada2hip: nwvec: more than 16 distinct letters in one pair of strings."};
+              c = ncodes++;
+            }
+            lo[p] = "ACGT"[c & 3]; hi[p] = "ACGT"[c >> 2];
+          }
+        }
+      }
+      seqs.resize(4 * (size_t)n);
+      for (size_t k = 0; k < coded.size(); k++) seqs[k] = coded[k].c_str();
+    }
+    const int nrows = (int)seqs.size();
+    std::vector<int32_t> ab((size_t)nrows, 1);
     dada2hip_sample *s = new dada2hip_sample();
     std::unique_ptr<dada2hip_sample, void (*)(dada2hip_sample *)> guard(s, dada2hip_sample_free);
-    sample_create(s, 2 * n, seqs.data(), ab.data(), nullptr, nullptr, 0, device, /*lite=*/true);
-    ensure_scratch(s, band);
+    sample_create(s, nrows, seqs.data(), ab.data(), nullptr, nullptr, 0, device, /*lite=*/true);
+    ensure_scratch(s, band, 0, /*force_generic=*/planes);
     std::vector<double> errm(16, 1.0), rowm;
     upload_err(s, errm.data(), 1, rowm);
     dada2hip_opts o;
@@ -2886,6 +2918,7 @@ static int nwvec_any(int32_t n, const char *const *s1, const char *const *s2, in
     ap.endsfree = endsfree ? 1 : 0;
     ap.homo_gap = endsfree ? homo_gap_p : gap_p;
     if (!ap.plain()) ap.sentinel = -9999;
+    ap.hi_off = planes ? 2 * n : 0;
     std::vector<int32_t> work((size_t)n), cc(n);
     for (int i = 0; i < n; i++) { work[i] = 2 * i + 1; cc[i] = 2 * i; }
     const int stride = 2 * maxlen + 2;
@@ -2923,7 +2956,7 @@ static int nwvec_any(int32_t n, const char *const *s1, const char *const *s2, in
 int dada2hip_nwvec(int32_t n, const char *const *s1, const char *const *s2, int32_t match, int32_t mismatch,
                    int32_t gap_p, int32_t band, int32_t endsfree, int32_t device, char *const *out, char *errbuf,
                    size_t errlen) {
-  return nwvec_any(n, s1, s2, match, mismatch, gap_p, gap_p, band, endsfree, device, out, errbuf, errlen);
+  return nwvec_any(n, s1, s2, match, mismatch, gap_p, gap_p, band, endsfree, device, out, errbuf, errlen, /*vec_semantics=*/true);
 }
 
 // ---- bimera identification (chimera.cpp): the step after dada() ---------------------------------------------------

@@ -78,6 +78,10 @@ struct AlignParams {
   int32_t homo_gap = 0;   // gap opposite a base of a homopolymer run of >= 3 (nwalign_endsfree_homo, nwalign_endsfree.cpp:220-396);
                           // equal to `gap` = no homopolymer gapping
   int32_t endsfree = 1;   // 0: global nwalign (nwalign_endsfree.cpp:403-537): end gaps cost `gap`, no free moves on the last row / column
+  // C_nwvec on strings with letters outside ACGT (it compares raw bytes, nwalign_vectorized.cpp:165): every pair's letters are
+  // renumbered 0..15 by the host and each string stored as TWO 2-bit rows - row r holds the low, row r + hi_off the high two
+  // bits of its codes; two positions match when both planes do.  0: plain 2-bit rows.  Honoured by k_nw_gen<PAIRS> only.
+  int32_t hi_off = 0;
   bool plain() const { return endsfree && homo_gap == gap; }   // (whoever fills the struct sets homo_gap = gap for the plain aligner)
 };
 

@@ -664,6 +664,9 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
     const int lband = B + (L1 > L2 ? L1 - L2 : 0), rband = B + (L2 > L1 ? L2 - L1 : 0);
     const int W = lband + rband + 1;
     const uint32_t *crow = S.seq2 + (size_t)c * S.W2, *rrow = S.seq2 + (size_t)r * S.W2;
+    // (C_nwvec on letters outside ACGT: the high two bits of each position's code in a second plane of rows, AlignParams::hi_off)
+    const int HI = PAIRS ? a.ap.hi_off : 0;
+    const uint32_t *crowh = crow + (size_t)HI * S.W2, *rrowh = rrow + (size_t)HI * S.W2;
     const bool EF = a.ap.endsfree != 0, HOMO = EF && a.ap.homo_gap != GAP;   // (see k_nw)
     const int HG = a.ap.homo_gap;
     for (int k = 0; k < Wgen; k++) {
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
       drow[(size_t)k * 64 + lane] = (j >= 0 && j <= rband && j <= L2) ? (EF ? 0 : j * GAP) : SENT;
     }
     for (int i = 1; i <= L1; i++) {
-      const uint32_t cb = base_at(crow, i - 1);
+      const uint32_t cb = base_at(crow, i - 1) | (HI ? base_at(crowh, i - 1) << 2 : 0u);
       const int gapL = (EF && i == L1) ? 0 : GAP;
       const int gapU = (HOMO && homo_at(crow, L1, i - 1)) ? HG : GAP;
       const int kzero = lband - i, kend = L2 - i + lband;
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(256) void k_nw_gen(NwArgs a, int Wgen) {
         int v = (k == kzero) ? (EF ? 0 : i * GAP) : SENT;
         uint32_t p = 0;
         if (valid) {
-          const uint32_t rb = base_at(rrow, j - 1);
+          const uint32_t rb = base_at(rrow, j - 1) | (HI ? base_at(rrowh, j - 1) << 2 : 0u);
           const int diag = dk + (rb == cb ? MATCH : MISMATCH);
           const int up = upn + ((EF && k == kend) ? 0 : gapU);
           const int left = leftv + ((HOMO && !(EF && i == L1) && homo_at(rrow, L2, j - 1)) ? HG : gapL);
@@ -1974,7 +1977,7 @@ void launch_nw(const SampleDev &S, int wclass, int centre, const int32_t *d_chun
     else if (ap.plain()) hipLaunchKernelGGL((k_nw<W, false, true>), dim3(grid), dim3(256), lds, st, a);             \
     else hipLaunchKernelGGL((k_nw<W, false, false>), dim3(grid), dim3(256), lds, st, a);                            \
     break;
-  switch (wclass) {
+  switch (ap.hi_off ? 0 : wclass) {   // (two-plane letters: the generic kernel)
     D2_NW_CLASS(33) D2_NW_CLASS(65) D2_NW_CLASS(129) D2_NW_CLASS(193) D2_NW_CLASS(257)
     default: {
       int Wgen = (ap.band < 0) ? (2 * S.maxlen + 1) : (2 * ap.band + (S.maxlen - S.minlen) + 1);

@@ -154,6 +154,17 @@ def nwalign(s1, s2, match=5, mismatch=-4, gap=-8, band=16, which="vectorized"):
     return o0.value.decode(), o1.value.decode()
 
 
+def nwvec_raw(s1, s2, match=5, mismatch=-4, gap=-8, band=16, endsfree=True):
+    """C_nwvec's call on one pair of strings (nwalign_vectorized.cpp:321-343): raw bytes in, any letters."""
+    L = lib()
+    n = len(s1) + len(s2) + 2
+    o0, o1, eb = C.create_string_buffer(n), C.create_string_buffer(n), C.create_string_buffer(512)
+    rc = L.ref_nwvec_raw(s1.encode(), s2.encode(), match, mismatch, gap, band, int(endsfree), o0, o1, eb, 512)
+    if rc:
+        raise RuntimeError(eb.value.decode())
+    return o0.value.decode(), o1.value.decode()
+
+
 def compare(cseq, cq, rseq, rq, err, opts: DadaOpts = None, kdist_cutoff=None):
     """(lambda, hamming|-1, kdist, kodist) for one centre/raw pair via sub_new + compute_lambda_ts."""
     L = lib()

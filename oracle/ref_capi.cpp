@@ -226,6 +226,23 @@ int ref_nwalign(const char *s1, const char *s2, int match, int mismatch, int gap
   }
 }
 
+// C_nwvec's call (nwalign_vectorized.cpp:321-343) on ONE pair: the strings' raw bytes go to nwalign_vectorized2 as they are (no
+// nt2int), end gaps free when `endsfree`, the band cast to size_t as there.  out0/out1: len1 + len2 + 1 bytes each.
+int ref_nwvec_raw(const char *s1, const char *s2, int match, int mismatch, int gap_p, int band, int endsfree, char *out0, char *out1,
+                  char *errbuf, int errlen) {
+  try {
+    char **al = nwalign_vectorized2(s1, strlen(s1), s2, strlen(s2), (int16_t)match, (int16_t)mismatch, (int16_t)gap_p,
+                                    endsfree ? (int16_t)0 : (int16_t)gap_p, (size_t)band);
+    strcpy(out0, al[0]);
+    strcpy(out1, al[1]);
+    free(al[0]); free(al[1]); free(al);
+    return 0;
+  } catch (std::exception &e) {
+    if (errbuf && errlen > 0) snprintf(errbuf, errlen, "%s", e.what());
+    return 1;
+  }
+}
+
 static Raw *ref_make_raw(const char *s, const double *q, unsigned reads, size_t maxlen,
                          std::vector<uint8_t> &k8, std::vector<uint16_t> &k16, std::vector<uint16_t> &ko) {
   size_t l = strlen(s);

@@ -95,7 +95,7 @@ Rcpp::CharacterVector C_nwvec(std::vector<std::string> s1, std::vector<std::stri
   }
   char msg[512];
   const int rc = dada2hip_nwvec(n, p1.data(), p2.data(), match, mismatch, gap_p, band, endsfree, 0, out.data(), msg, sizeof msg);   // endsfree = 0: end_gap = gap_p (:333)
-  if (rc == DADA2HIP_ERR_UNSUPPORTED) return C_nwvec_cpu(s1, s2, match, mismatch, gap_p, band, endsfree);   // non-ACGT input
+  if (rc == DADA2HIP_ERR_UNSUPPORTED) return C_nwvec_cpu(s1, s2, match, mismatch, gap_p, band, endsfree);   // (a pair with more than 16 distinct letters: not DNA; N / IUPAC run on the device)
   if (rc) Rcpp::stop(msg);
   Rcpp::CharacterVector rval(2 * n);                       // rval[2i], rval[2i+1] as nwalign_vectorized.cpp:336-339
   for (int i = 0; i < 2 * n; i++) rval[i] = std::string(out[i]);

@@ -337,3 +337,38 @@ def test_emulated_run_without_the_persistent_slot_takes_the_chains_and_plans_no_
         fcntl.flock(lock, fcntl.LOCK_UN)
         lock.close()
         os.remove("/tmp/dada2hip_persistent_%s.lock" % pci)
+
+
+NWVEC_LETTERS_CODE = (
+    "import sys\n"
+    "sys.path[:0] = [%r, %r]\n"
+    "from dada2_amd import _lib\n"
+    "if %r: _lib.LIB_PATH = %r\n"
+    "from helpers import nwvec_letter_cases\n"
+    "from dada2_amd import api\n"
+    "from oracle import ref\n"
+    "s1, s2 = nwvec_letter_cases()\n"
+    "for band, ef, sc in ((16, True, (5, -4, -8)), (-1, True, (5, -4, -8)), (8, False, (5, -4, -8)), (16, True, (1, -1, -2))):\n"
+    "    got = api.nwvec(s1, s2, sc[0], sc[1], sc[2], band, ef)\n"
+    "    for i, (a, b) in enumerate(zip(s1, s2)):\n"
+    "        assert tuple(got[i]) == ref.nwvec_raw(a, b, sc[0], sc[1], sc[2], band, ef), (band, ef, sc, a, b, got[i])\n"
+    "try:\n"
+    "    api.nwvec(['ABCDEFGHIJKLMNOPQRS'], ['ABCDEFGHIJKLMNOPQ'])\n"
+    "    raise SystemExit('17 letters accepted')\n"
+    "except _lib.Dada2HipError as ex:\n"
+    "    assert ex.code == 4, ex.code\n"
+    "try:\n"
+    "    api.nwalign('ACGTN', 'ACGT')\n"                       # C_nwalign: the reference's behaviour for N is undefined - still refused
+    "    raise SystemExit('nwalign took N')\n"
+    "except _lib.Dada2HipError as ex:\n"
+    "    assert ex.code == 4, ex.code\n"
+    "print('nwvec letters: ok', len(s1))\n"
+)
+
+
+def test_emulated_nwvec_on_letters_outside_acgt_matches_the_reference(emu_lib, oracle_ref):
+    """C_nwvec compares the strings' raw bytes (nwalign_vectorized.cpp:165): N, IUPAC codes, lower case, anything.  The device
+    path renumbers each pair's letters (<= 16) into two 2-bit planes; every pair against the reference's own call on raw bytes."""
+    code = NWVEC_LETTERS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "nwvec letters: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

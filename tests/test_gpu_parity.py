@@ -359,3 +359,22 @@ def test_full_config2_parity_vs_reference_itself(api):
     ref.set_threads(1)
     assert got.nclust == want.nclust > 50
     assert_results_equal(got, want, p_rtol=P_RTOL)
+
+
+def test_nwvec_on_letters_outside_acgt_matches_the_reference(api, oracle_ref):
+    """C_nwvec on N / IUPAC / arbitrary letters (it compares raw bytes, nwalign_vectorized.cpp:165) on the device: each pair's
+    letters renumbered into two 2-bit planes, every pair against the reference's own call; > 16 letters and C_nwalign with N
+    stay DADA2HIP_ERR_UNSUPPORTED (the latter has no defined behaviour in the reference, evaluate.cpp:28-33)."""
+    from helpers import nwvec_letter_cases
+    from dada2_amd import _lib
+    s1, s2 = nwvec_letter_cases()
+    for band, ef, sc in ((16, True, (5, -4, -8)), (-1, True, (5, -4, -8)), (8, False, (5, -4, -8)), (16, True, (1, -1, -2))):
+        got = api.nwvec(s1, s2, sc[0], sc[1], sc[2], band, ef)
+        for i, (a, b) in enumerate(zip(s1, s2)):
+            assert tuple(got[i]) == oracle_ref.nwvec_raw(a, b, sc[0], sc[1], sc[2], band, ef), (band, ef, sc, a, b)
+    with pytest.raises(_lib.Dada2HipError) as ei:
+        api.nwvec(["ABCDEFGHIJKLMNOPQRS"], ["ABCDEFGHIJKLMNOPQ"])
+    assert ei.value.code == 4
+    with pytest.raises(_lib.Dada2HipError) as ei:
+        api.nwalign("ACGTN", "ACGT")
+    assert ei.value.code == 4
