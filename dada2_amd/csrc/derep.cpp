@@ -11,6 +11,7 @@
 //     a unique's length are NA;
 //   * the final order is a STABLE sort by decreasing abundance (R's order(), :98), ties keep the order above.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <condition_variable>
 #include <cstring>
@@ -129,6 +130,21 @@ struct LineReader {
   }
 };
 
+// quality storage of the uniques seen ONCE (nine in ten of a deep amplicon sample): the read's quality characters as they are,
+// a byte per position - the 8-byte sums below are only set up when a unique is met a second time (a 250-nt singleton then costs
+// 250 bytes of memory traffic instead of 2 000)
+struct ByteArena {
+  static constexpr size_t BLOCK = 8u << 20;
+  std::vector<std::unique_ptr<unsigned char[]>> blocks;
+  size_t used = BLOCK;
+  unsigned char *take(size_t n) {
+    if (n > BLOCK) { blocks.emplace_back(new unsigned char[n]); used = BLOCK; return blocks.back().get(); }
+    if (used + n > BLOCK) { blocks.emplace_back(new unsigned char[BLOCK]); used = 0; }
+    unsigned char *r = blocks.back().get() + used;
+    used += n;
+    return r;
+  }
+};
 // quality-sum storage: fixed blocks, so growing never copies what is already there
 struct SumArena {
   static constexpr size_t BLOCK = 4u << 20;
@@ -147,6 +163,23 @@ struct SumArena {
     return r;
   }
 };
+
+// std::sort over the host pool: sorted runs in parallel, then pairwise merges level by level (each level's merges in parallel).
+// The same order as one std::sort for a strict weak order without equal elements (the uniques of a chunk are distinct strings).
+template <typename It, typename Cmp>
+void pool_sort(It first, It last, Cmp cmp) {
+  const size_t n = (size_t)(last - first);
+  size_t runs = 1;
+  while (runs < (size_t)d2::HostPool::get().nthreads() && n / (runs * 2) >= (size_t)1 << 15) runs *= 2;
+  if (runs == 1) { std::sort(first, last, cmp); return; }
+  auto bound = [&](size_t r, size_t of) { return first + (ptrdiff_t)(n * r / of); };
+  d2::parallel_for(runs, 1, [&](size_t r0, size_t r1) { for (size_t r = r0; r < r1; r++) std::sort(bound(r, runs), bound(r + 1, runs), cmp); });
+  for (size_t width = 1; width < runs; width *= 2)
+    d2::parallel_for(runs / (2 * width), 1, [&](size_t m0, size_t m1) {
+      for (size_t m = m0; m < m1; m++)
+        std::inplace_merge(bound(2 * m * width, runs), bound((2 * m + 1) * width, runs), bound((2 * m + 2) * width, runs), cmp);
+    });
+}
 
 void set_err(char *errbuf, size_t errlen, const char *m) {
   if (errbuf && errlen) snprintf(errbuf, errlen, "%s", m);
@@ -171,10 +204,18 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
   std::deque<std::string> store;                        // provisional id -> sequence (stable addresses)
   std::unordered_map<std::string_view, int32_t> index;  // sequence -> provisional id
   std::vector<int64_t> count;                           // per provisional id
-  std::vector<int64_t *> qacc;                          // per provisional id: raw quality character sums [len]
+  std::vector<int64_t *> qacc;                          // per provisional id: raw quality character sums [len]; null while the unique has one read
+  std::vector<const unsigned char *> qone;              // per provisional id: the quality characters of its first read
   SumArena arena;
+  ByteArena barena;
   std::vector<int32_t> seen;                            // provisional ids in derepFastq's pre-sort order
   std::vector<int32_t> map;                             // per read: provisional id, -1 for zero-length reads
+  d2::knobs_reload();
+  const bool times = d2::knobs().derep_times;
+  using dclk = std::chrono::steady_clock;
+  auto t_start = dclk::now();
+  double ms_sort = 0;
+  auto ms_since = [](dclk::time_point t) { return std::chrono::duration<double, std::milli>(dclk::now() - t).count(); };
   LineReader in(f);
   const char *hp, *sp, *pp, *qp;
   size_t hn, sn, pn, qn;
@@ -186,10 +227,12 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
   auto end_chunk = [&]() {
     if (offset <= 0 && minq < 255) offset = minq < 59 ? 33 : 64;   // qualityType "Auto": below ';' only Phred+33 encodings
     const size_t n0 = seen.size();
+    const auto t_sort = dclk::now();
     for (size_t id = chunk_first; id < store.size(); id++) seen.push_back((int32_t)id);
-    std::sort(seen.begin() + n0, seen.end(), [&](int32_t a, int32_t b) { return store[a] < store[b]; });   // srsort: C locale
+    pool_sort(seen.begin() + n0, seen.end(), [&](int32_t a, int32_t b) { return store[a] < store[b]; });   // srsort: C locale (10^6 string compares x 20: the largest single piece of a chunk's work, so it goes over the host pool)
     chunk_first = store.size();
     in_chunk = 0;
+    ms_sort += ms_since(t_sort);
   };
   std::string s;
   while (in.next(&hp, &hn)) {
@@ -216,16 +259,27 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
         store.push_back(s);
         index.emplace(std::string_view(store.back()), id);
         count.push_back(0);
-        qacc.push_back(arena.take(s.size()));
+        qacc.push_back(nullptr);
+        qone.push_back(nullptr);
       } else {
         id = it->second;
       }
-      count[id]++;
-      int64_t *acc = qacc[id];
       const unsigned char *qq = (const unsigned char *)qp;
       const size_t n = s.size();
       if (offset <= 0 && chunk_first == 0) for (size_t p = 0; p < n; p++) minq = std::min(minq, (int)qq[p]);
-      for (size_t p = 0; p < n; p++) acc[p] += qq[p];
+      if (++count[id] == 1) {                           // first sight: keep the characters
+        unsigned char *b = barena.take(n);
+        memcpy(b, qq, n);
+        qone[id] = b;
+      } else {
+        int64_t *acc = qacc[id];
+        if (!acc) {                                     // second sight: the sums start from the first read's characters
+          acc = qacc[id] = arena.take(n);
+          const unsigned char *b = qone[id];
+          for (size_t p = 0; p < n; p++) acc[p] = b[p];
+        }
+        for (size_t p = 0; p < n; p++) acc[p] += qq[p];
+      }
       map.push_back(id);
     }
     if (in_chunk >= chunk_reads) end_chunk();
@@ -239,6 +293,8 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
     }
   }
   end_chunk();
+  const double ms_parse = ms_since(t_start) - ms_sort;
+  const auto t_out = dclk::now();
   if (store.empty()) { set_err(errbuf, errlen, "Only zero-length sequences detected during dereplication."); return DADA2HIP_ERR_INPUT; }
   if (offset <= 0) offset = 33;
   // stable sort by decreasing abundance (sequenceIO.R:98)
@@ -261,7 +317,8 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
       double *row = &d->quals[k * ml];
       const int64_t *acc = qacc[id];
       const size_t len = store[id].size();
-      for (size_t p = 0; p < len; p++) row[p] = (double)(acc[p] - (int64_t)offset * count[id]) / (double)count[id];   // derepQuals / derepCounts (:95)
+      if (acc) for (size_t p = 0; p < len; p++) row[p] = (double)(acc[p] - (int64_t)offset * count[id]) / (double)count[id];   // derepQuals / derepCounts (:95)
+      else { const unsigned char *b = qone[id]; for (size_t p = 0; p < len; p++) row[p] = (double)((int64_t)b[p] - (int64_t)offset) / 1.0; }
       for (size_t p = len; p < ml; p++) row[p] = na;
     }
   });
@@ -272,6 +329,8 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
   d->map.resize(map.size());
   for (size_t i = 0; i < map.size(); i++) d->map[i] = map[i] < 0 ? DADA2HIP_NA_INTEGER : rank[map[i]];
   *out = d;
+  if (times) fprintf(stderr, "[derep] %lld reads, %zu uniques: read + parse + hash %.0f ms, chunk sorts %.0f ms, output (abundance order, mean qualities, map) %.0f ms\n",
+                     (long long)nreads, U, ms_parse, ms_sort, ms_since(t_out));
   return DADA2HIP_OK;
 }
 
