@@ -388,16 +388,24 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
           const double *src = quals + r * (size_t)maxlen;
           uint8_t *dst = hq.p + r * (size_t)LQ;
           const int L = s->h_len[r];
-          for (int p = 0; p < L; p++) {
-            const double x = src[p];
-            double xr;
-            if (x >= 0.0 && x < 256.0) { const int t = (int)x; xr = (double)(t + ((x - (double)t) >= 0.5 ? 1 : 0)); }   // round(): half away from zero
-            else xr = std::round(x);
-            if (!(xr >= 0.0 && xr <= 255.0)) { bad = 1; xr = 0.0; }
-            const int v = (int)xr;
-            mx = std::max(mx, v);
-            dst[p] = (uint8_t)v;
+          // the row in one branch-free sweep (it vectorises: the scalar form below was 17 cycles per quality, and the 2 GB of a
+          // 10^6-unique matrix made it the largest piece of the upload) - valid for values in [0, 255.5); a row with anything
+          // else (negative, too large, NaN inside the read) is redone by the exact scalar rule
+          int row_mx = 0;
+          if (!d2::round_quality_row(src, dst, L, &row_mx)) {
+            row_mx = 0;
+            for (int p = 0; p < L; p++) {
+              const double x = src[p];
+              double xr;
+              if (x >= 0.0 && x < 256.0) { const int t = (int)x; xr = (double)(t + ((x - (double)t) >= 0.5 ? 1 : 0)); }   // round(): half away from zero
+              else xr = std::round(x);
+              if (!(xr >= 0.0 && xr <= 255.0)) { bad = 1; xr = 0.0; }
+              const int v = (int)xr;
+              row_mx = std::max(row_mx, v);
+              dst[p] = (uint8_t)v;
+            }
           }
+          mx = std::max(mx, row_mx);
           memset(dst + L, 0, (size_t)(LQ - L));
         }
         if (bad) badq.store(1, std::memory_order_relaxed);

@@ -119,6 +119,9 @@ struct BudParams {
   int32_t min_hamming, min_abund;
 };
 
+// (uint8) round(x) of one quality row, branch-free (hostsimd.cpp: plain C++ with an AVX2 clone); false = redo the row by the scalar rule
+bool round_quality_row(const double *src, uint8_t *dst, int L, int *mx_out);
+
 void launch_fill_f64(double *d_p, size_t n, double v, hipStream_t st);
 void launch_fill_null(int n, const uint8_t *d_cls, double *d_lam, uint32_t *d_ham, hipStream_t st);
 void launch_store(const PartState &P, const SampleDev &S, int ci, int centre, double total_reads, const double *d_lam,

@@ -52,7 +52,7 @@ def build(force=False):
             fh.write(text)
     shutil.copy(os.path.join(HERE, "gcn.h"), os.path.join(OUT, "csrc", "gcn.h"))
     shutil.copy(os.path.join(ROOT, "include", "dada2hip.h"), os.path.join(OUT, "include", "dada2hip.h"))
-    tus = ["kernels.hip", "tail.hip", "driver.cpp", "derep.cpp", "merge.cpp"]
+    tus = ["kernels.hip", "tail.hip", "driver.cpp", "derep.cpp", "merge.cpp", "hostsimd.cpp"]
     cmd = [CXX, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-I", HERE, "-o", lib]
     for t in tus:
         cmd += ["-x", "c++", os.path.join(OUT, "csrc", t)]

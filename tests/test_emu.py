@@ -372,3 +372,33 @@ def test_emulated_nwvec_on_letters_outside_acgt_matches_the_reference(emu_lib, o
     code = NWVEC_LETTERS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "nwvec letters: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_emulated_quality_marshalling_vector_sweep_and_its_scalar_redo(emu_lib):
+    """raw_new's (uint8) round(mean quality) (containers.cpp:34) at the boundary: the branch-free sweep (hostsimd.cpp) for rows in
+    [0, 255.5), the exact scalar rule for rows that hold anything else - a value that rounds to -0 stays valid, negative / too
+    large / NaN inside a read are refused with the reference's message."""
+    code = (
+        "import sys\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from dada2_amd import _lib\n"
+        "_lib.LIB_PATH = %r\n"
+        "import numpy as np\n"
+        "from helpers import case_inputs, assert_results_equal\n"
+        "from dada2_amd import api\n"
+        "from oracle import cport\n"
+        "d, err, pri, o, exp, meta = case_inputs('sam1F_default')\n"
+        "for val in (-1.0, 255.6, float('nan')):\n"
+        "    q = d.quals.copy(); q[5, 10] = val\n"
+        "    try:\n"
+        "        api.dada_uniques(d.seqs, d.abundances, pri, err, q, o)\n"
+        "        raise SystemExit('accepted %%r' %% val)\n"
+        "    except _lib.Dada2HipError as ex:\n"
+        "        assert ex.code == 1 and 'Invalid derep$quals matrix' in str(ex), str(ex)\n"
+        "q = d.quals.copy(); q[7, 3] = -0.2; q[9, 0] = 30.5; q[11, 1] = 29.4999\n"
+        "got = api.dada_uniques(d.seqs, d.abundances, pri, err, q, o)\n"
+        "assert_results_equal(got, cport.dada_uniques(d.seqs, d.abundances, pri, err, q, o))\n"
+        "print('quality marshalling: ok')\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "quality marshalling: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
