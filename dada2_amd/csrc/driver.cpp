@@ -626,9 +626,14 @@ struct Run {
   const dada2hip_shard *shard = nullptr;
   int lo = 0, hi = 0;                             // this rank's block of uniques
   std::vector<uint8_t> h_upd;                     // host copy of Bi::update_e (the device only sees its own movers)
+  // (for the failure notification of dada2hip_sample_run_sharded: the exchange itself failed - it is not called again; the run's
+  //  last exchange point lies behind - nobody would answer)
+  bool sh_exchange_failed = false, sh_points_left = true;
   void sh_call(int kind, const void *send, int64_t nbytes, void *recv) {
-    if (shard->exchange(shard->user, kind, send, nbytes, recv) != 0)
+    if (shard->exchange(shard->user, kind, send, nbytes, recv) != 0) {
+      sh_exchange_failed = true;
       throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: the shard exchange callback failed"};
+    }
   }
   // all-gather of payloads of different sizes: sizes first, then the payloads padded to the largest
   std::vector<std::vector<uint8_t>> sh_gatherv(const void *p, size_t n) {
@@ -2190,6 +2195,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   Run &run = *static_cast<Run *>(s->run_cache.get());
   run.hooks = hooks;
   run.shard = shard; run.lo = D.r_lo; run.hi = D.r_hi;
+  run.sh_exchange_failed = false; run.sh_points_left = true;
   run.h_upd.assign(1, 1);
   init_run(run, s, err, err_ncol, opts, opts->kdist_cutoff);
   run.st.ms_upload = s->ms_upload;
@@ -2548,6 +2554,7 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
       run.st.nw_cells = run.st.nnw * run.nw_cells_per_alignment();
       run.st.screen_bytes = (run.st.ncompare - run.st.nskipped) * 2 * (uint64_t)(D.maxlen - KMER_SIZE + 1) + run.st.ncompare * 6;
     }
+    run.sh_points_left = false;   // (what follows - the assembly of the outputs - exchanges nothing)
   }
 
   // ---- assemble the six outputs -------------------------------------------------------------------
@@ -2674,8 +2681,15 @@ int dada2hip_sample_run_sharded(dada2hip_sample *s, const double *err, int32_t e
       throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: another rank of the sharded run failed"};
     } catch (...) {
       // tell the other ranks at their next exchange point (each opens with an 8-byte all-gather of a size: -1 = failed), so
-      // that they return an error too instead of blocking in a collective this rank will never join
-      if (shard->world > 1 && shard->exchange) {
+      // that they return an error too instead of blocking in a collective this rank will never join - unless the
+      // run's last exchange point is behind this rank: its peers are done exchanging, a notification would wait alone (ADVICE
+      // r4).  When the failure IS the exchange callback the notification is still tried, once: a callback that failed before it
+      // entered the collective (the case the tests inject) leaves the peers waiting in it, and this is what releases them; a
+      // callback whose transport is gone fails again, which is ignored.  Either way a collective that never completes is the
+      // transport's to time out (include/dada2hip.h, dada2hip_shard).
+      const Run *rr = s->run_cache ? static_cast<const Run *>(s->run_cache.get()) : nullptr;
+      const bool notify = !rr || rr->sh_points_left;
+      if (notify && shard->world > 1 && shard->exchange) {
         const int64_t failed = -1;
         std::vector<int64_t> all((size_t)shard->world);
         (void)shard->exchange(shard->user, 0, &failed, 8, all.data());

@@ -187,7 +187,11 @@ void dada2hip_sample_free(dada2hip_sample *s);
  *   kind 0  all-gather: every rank contributes send_bytes bytes (the same count on all ranks); recv receives
  *           world * send_bytes bytes in rank order
  *   kind 1  all-reduce(sum) of send_bytes / 8 int64 values; send == recv (in place)
- * `exchange` returns 0 on success; anything else aborts the run with DADA2HIP_ERR_RUNTIME on that rank. */
+ * `exchange` returns 0 on success; anything else aborts the run with DADA2HIP_ERR_RUNTIME on that rank.
+ * Failure protocol: every exchange point opens with an 8-byte kind-0 gather of a size; a rank that has failed between two points
+ * contributes -1 at the next one (one extra call of `exchange`, not made once the run's last exchange point is behind it), and
+ * its peers return DADA2HIP_ERR_RUNTIME there.  A collective that never completes - a rank that died, a transport that is gone -
+ * is `exchange`'s own to time out: the library never waits for a peer by itself. */
 typedef struct dada2hip_shard {
   int32_t rank, world;
   int (*exchange)(void *user, int32_t kind, const void *send, int64_t send_bytes, void *recv);

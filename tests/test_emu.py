@@ -237,16 +237,18 @@ HOOKS_CODE = (
     "print('hooks: ok')\n"
 )
 
-ENGINE_ENVS = [{}, {"DADA2HIP_V3_GRID": "3"}, {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_ENGINE": "classic"}]
-ENGINE_IDS = ["persistent-tail", "persistent-tail-grid3", "chains", "classic-engine"]
+# (the CPU suite's budget: the persistent tail with several blocks, the chains and the classic engine; the -m gpu test adds the
+#  one-block default)
+ENGINE_ENVS = [{"DADA2HIP_V3_GRID": "3"}, {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_ENGINE": "classic"}]
+ENGINE_IDS = ["persistent-tail-grid3", "chains", "classic-engine"]
 
 
 @pytest.mark.parametrize("env", ENGINE_ENVS, ids=ENGINE_IDS)
 def test_emulated_abort_hook_and_verbose_log_on_every_engine(emu_lib, env):
-    """dada2hip_hooks (Rcpp::checkUserInterrupt / the verbose Rprintfs, src/Rmain.cpp:317-333): a run aborted at its first, third and
-    eighth round returns DADA2HIP_ERR_ABORTED with launches still queued, the next run in the same process equals the golden; the
+    """dada2hip_hooks (Rcpp::checkUserInterrupt / the verbose Rprintfs, src/Rmain.cpp:317-333): a run aborted at its first and
+    fourth round returns DADA2HIP_ERR_ABORTED with launches still queued, the next run in the same process equals the golden; the
     log carries one line per birth and the reference's nalign / nshroud."""
-    code = HOOKS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib, (1, 3, 8))
+    code = HOOKS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib, (1, 4))
     e = dict(os.environ)
     e.update(env)
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
@@ -278,9 +280,9 @@ def test_emulated_entry_barrier_failure_continues_on_the_launch_chains(emu_lib, 
     assert out.returncode == 0 and "fallback: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("env", [{}, {"DADA2HIP_V3_GRID": "4", "DADA2HIP_V2_NBUF": "4", "DADA2HIP_V3_RING": "2"},
+@pytest.mark.parametrize("env", [{"DADA2HIP_V3_GRID": "4", "DADA2HIP_V2_NBUF": "4", "DADA2HIP_V3_RING": "2"},
                                  {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V2_NBUF": "5", "DADA2HIP_V2_MOV_INLINE": "16", "DADA2HIP_V3_PF_WAIT_US": "0"}],
-                         ids=["default", "grid4-nbuf4-ring2", "grid2-nbuf5-pauses-no-wait"])
+                         ids=["grid4-nbuf4-ring2", "grid2-nbuf5-pauses-no-wait"])
 def test_emulated_prefetch_compares_under_the_tail_on_a_deeper_sample(emu_lib, env):
     """The next batch's compare planned by the persistent tail and run on the second stream on the 20-partition
     golden: rounds served out of prefetched batches, with the smallest cache that allows it (the buffer whose rows the coming
