@@ -1412,6 +1412,7 @@ struct Run {
     E2.fail_ordinal = K.v3_fail_entry > 0 ? K.v3_fail_entry : 0;
     E2.pf_on = v3_overlap ? 1 : 0; E2.pf_min = 2;
     E2.pf_early = K.v3_pf_early >= 0 ? K.v3_pf_early : 4;
+    E2.pf_sync = K.v3_pf_sync != 0 ? 1 : 0;
     E2.pf_ctl = v3_pfctl.p; E2.pf_blist_n = v3_pf_blistn.p; E2.pfsync = v3_pfsync.p;
     {   // how long a round waits inside the launch for a prefetch compare in flight before the launch is left (the host then
         // orders the next launch behind the compare): a few compares' worth - a compare is ~0.6 ms per 10^6 uniques

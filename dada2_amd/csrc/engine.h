@@ -454,6 +454,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   //      scratch ARE these (so they run unchanged); the tail's planner fills pf_ctl and clears pf_blist_n ----
   int32_t pf_on;                                    // 1: the tail plans prefetch compares
   int32_t pf_min;                                   // fewest uncached candidates worth a prefetch pass
+  int32_t pf_sync;                                  // measurement knob: wait for every prefetch at the next serial end (DADA2HIP_V3_PF_SYNC)
   int32_t pf_early;                                 // the next prefetch is planned when the rounds are this many positions into the batch BEFORE the one planned last (KB_MAX: only when they reach the last one)
   Ctl2 *pf_ctl;                                     // descriptor of the prefetch compare (nbatch, bbuf, bcentre / breads / blen, nalign, abuf, acentre; state stays 0)
   int32_t *pf_blist_n;                              // [2 KB_MAX] lengths of its work lists

@@ -1067,6 +1067,16 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
   const bool tr = E.trace && ctl->pub_seq == E.trace_seq && threadIdx.x == 0;
 #define D2_TRB(PHASE) do { if (tr) E.trace[((size_t)6 * TRACE_BLOCKS) * 8 + (PHASE)] = gcn_clock(); D2_KSUB(6, PHASE, true); } while (0)
   D2_TRB(0);
+  if (kord && E.pf_on && E.pf_sync) {
+    // (measurement knob, DADA2HIP_V3_PF_SYNC=1: every prefetch compare is waited for at the next round's serial end, with the whole
+    //  tail resident and idle - what the compare's kernels cost beside a tail that does nothing)
+    if (tid == 0) {
+      const uint32_t seq = (uint32_t)ctl->pf_seq;
+      const unsigned long long t0 = gcn_wall_clock();
+      while ((int32_t)(gcn_load_agent(&E.pfsync->done) - seq) < 0 && gcn_wall_clock() - t0 < 4 * E.pf_wait_ticks) gcn_poll_pause();
+    }
+    __syncthreads();
+  }
   // ---- stage 1: requests ----
   const int32_t *pa = nullptr;
   switch (tid) {
