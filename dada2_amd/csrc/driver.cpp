@@ -1366,7 +1366,10 @@ struct Run {
   DevBuf<int32_t> v3_pf_blist, v3_pf_blistn;
   DevBuf<uint32_t> v3_pf_ad;
   DevBuf<AdDesc> v3_pf_fdesc;
-  long v3_pf_launched = 0;            // prefetch compares sent to the second stream (their numbers are 1, 2, ...)
+  long v3_pf_launched = 0;            // highest prefetch number whose chain has been sent to the second stream (numbers are 1, 2, ...)
+  long v3_pf_seen = 0;                // highest prefetch number seen planned in a result block
+  long v3_pf_chains = 0;              // chains sent (a chain whose gate gave up is sent again)
+  bool v3_pf_gate_on = true;          // chains go out one AHEAD of their plan behind a gate kernel (else: when the plan is seen)
   hipEvent_t v3_pf_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // end of prefetch compare k: v3_pf_ev[k & 3]
   DevBuf<unsigned long long> v3_ktime;
   PinBuf<int32_t> v3_hflags;          // [0] result blocks the host has finished with, [16] ordinal of the last launch that ended
@@ -1418,6 +1421,9 @@ struct Run {
         // orders the next launch behind the compare): a few compares' worth - a compare is ~0.6 ms per 10^6 uniques
       const double us = K.v3_pf_wait_us >= 0 ? (double)K.v3_pf_wait_us : 2000.0 * std::max(1.0, (double)N / 5e5);
       E2.pf_wait_ticks = (unsigned long long)(us * 100.0);
+      // the gate of a chain enqueued ahead of its plan (k2_pf_gate): plans come every millisecond or so while rounds run
+      v3_pf_gate_on = K.v3_pf_gate_us != 0;
+      E2.pf_gate_ticks = (unsigned long long)((K.v3_pf_gate_us > 0 ? (double)K.v3_pf_gate_us : 500000.0) * 100.0);
     }
     E2.has_compare = 1;
     E2.align_at_commit = v2_align_commit ? 1 : 0;
@@ -1523,7 +1529,7 @@ struct Run {
     v3_bs = K.v3_block == 512 ? 512 : (K.v3_block == 1024 ? 1024 : (v3_overlap ? 512 : 1024));
     if (v3_on) { const int cap = tail_resident_max(s->device, v3_bs); if (cap > 0 && v3_grid > cap) v3_on = false; }
     if (!v3_on) v3_overlap = false;
-    v3_pf_launched = 0;
+    v3_pf_launched = 0; v3_pf_seen = 0; v3_pf_chains = 0;
     if (v3_overlap) {
       if (!s->cmp) D2_HIP(hipStreamCreateWithFlags(&s->cmp, hipStreamNonBlocking));
       for (auto &e : v3_pf_ev) if (!e) D2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1538,10 +1544,10 @@ struct Run {
       D2_HIP(hipMemsetAsync(v3_pfsync.p, 0, sizeof(PfSync), stq));
       D2_HIP(hipMemsetAsync(v3_pf_blistn.p, 0, 2 * KB_MAX * 4, stq));
     }
-    v3_psync.alloc(1); v3_hflags.alloc(32); v3_ktime.alloc(KT_N);
+    v3_psync.alloc(1); v3_hflags.alloc(64); v3_ktime.alloc(KT_N);   // ([32] = "run over" for the prefetch gates, [40..47] = their results)
     D2_HIP(hipMemsetAsync(v3_psync.p, 0, sizeof(PSync), stq));
     D2_HIP(hipMemsetAsync(v3_ktime.p, 0, KT_N * 8, stq));
-    for (int k = 0; k < 32; k++) v3_hflags.p[k] = 0;
+    for (int k = 0; k < 64; k++) v3_hflags.p[k] = 0;
     v3_enq = 0; v3_ord_seen = 0;
   }
   // The device's persistent slot, taken for the rounds only (run_v3 releases it).  Threads of this process take turns - the
@@ -1562,6 +1568,7 @@ struct Run {
   void v3_quiesce() {
     if (!v2_ctl.p || !s) return;
     v3_hflags.p[24] = 1;
+    *(volatile int32_t *)(v3_hflags.p + 32) = 1;   // (a prefetch gate still waiting for a plan gives up)
     (void)hipMemcpyAsync(&v2_ctl.p->state, v3_hflags.p + 24, 4, hipMemcpyHostToDevice, s->side);
     (void)hipStreamSynchronize(s->side);
     (void)hipStreamSynchronize(s->stream);
@@ -1578,6 +1585,7 @@ struct Run {
   void v3_fallback() {
     sync_spin(s->stream);
     if (v3_overlap) {                                          // (the launch chains plan no prefetches)
+      *(volatile int32_t *)(v3_hflags.p + 32) = 1;             // (the gate of the chain sent ahead gives up)
       sync_spin(s->cmp);
       v3_pf_totals();
       v3_overlap = false;
@@ -1633,6 +1641,9 @@ struct Run {
     const auto t_enq = clk::now();
     hipStream_t st2 = s->cmp;
     Ctl2 *pc = v3_pfctl.p;
+    // the gate: waits for plan k (at once when the chain is sent for a plan already seen), opens or halts the descriptor
+    *(volatile int32_t *)(v3_hflags.p + 40 + (k & 7)) = 0;
+    launch2_pf_gate(E2P, (int)k, v3_hflags.p + 32, v3_hflags.p + 40 + (k & 7), st2);
     launch2_pf_tables(E2P, st2);
     int ev = ev_begin(EV_PF_SCREEN, profile_all, false, false, st2);
     launch2_screen_multi(E2P, st2, /*beside_tail=*/K_lowreg());
@@ -1646,16 +1657,18 @@ struct Run {
     ev_end(ev);
     launch2_pf_done(E2P, st2);
     D2_HIP(hipEventRecord(v3_pf_ev[k & 3], st2));
-    v3_pf_launched = k;
+    v3_pf_launched = std::max(v3_pf_launched, k);
+    v3_pf_chains++;
     st.ms_enqueue += ms_since(t_enq);
   }
+  int v3_pf_gate_result(long k) const { return (int)*(volatile int32_t *)(v3_hflags.p + 40 + (k & 7)); }   // 0: waiting / not run yet, 1: passed, 2: gave up
   static bool K_lowreg() { return knobs().v3_pf_lowreg != 0; }
   int32_t v3_pf_stat[4] = {0, 0, 0, 0};   // Ctl2::pf_hits / pf_spins / pf_exits / pf_centres as of the last block read
   void v3_pf_totals() {
     PfSync ps;
     D2_HIP(hipMemcpy(&ps, v3_pfsync.p, sizeof ps, hipMemcpyDeviceToHost));
     st.nnw_run += ps.nnw; st.ngapless_run += ps.ngapless;      // pairs the prefetch compares' aligner launches worked through
-    st.pf_compares = (uint64_t)v3_pf_launched;
+    st.pf_compares = (uint64_t)v3_pf_seen;
     st.pf_hits = (uint64_t)v3_pf_stat[0]; st.pf_waits = (uint64_t)v3_pf_stat[1]; st.pf_exits = (uint64_t)v3_pf_stat[2]; st.pf_centres = (uint64_t)v3_pf_stat[3];
     st.overlap_on = 1;
   }
@@ -1664,7 +1677,15 @@ struct Run {
   void v3_pf_serve(const Round2Out &b) {
     if (!v3_overlap) return;
     for (int k = 0; k < 4; k++) v3_pf_stat[k] = b.pf_stat[k];
-    while (v3_pf_launched < (long)b.pf_seq) v3_pf_enqueue(v3_pf_launched + 1);
+    v3_pf_seen = std::max(v3_pf_seen, (long)b.pf_seq);
+    // a plan whose chain has not been sent (no chain ahead), or whose chain's gate gave up before the plan came: send it (again)
+    if (v3_pf_seen >= 1) {
+      if (v3_pf_launched < v3_pf_seen) v3_pf_enqueue(v3_pf_seen);
+      else if (v3_pf_gate_result(v3_pf_seen) == 2) v3_pf_enqueue(v3_pf_seen);
+    }
+    // ONE chain ahead: the next plan's chain goes out once the chain in front of it has passed its gate (two gates in the
+    // stream would wait for each other: the second plan cannot be made before the first compare is done)
+    if (v3_pf_gate_on && v3_pf_launched == v3_pf_seen && (v3_pf_seen == 0 || v3_pf_gate_result(v3_pf_seen) == 1)) v3_pf_enqueue(v3_pf_seen + 1);
     if (b.pf_wait > 0 && (long)b.pf_wait <= v3_pf_launched) D2_HIP(hipStreamWaitEvent(s->stream, v3_pf_ev[b.pf_wait & 3], 0));
   }
 
@@ -1729,6 +1750,7 @@ struct Run {
     auto t0 = clk::now();
     st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
     v3_rec.clear();
+    if (v3_overlap && v3_pf_gate_on) v3_pf_enqueue(1);         // the first prefetch compare's chain waits at its gate on the second stream
     v3_enqueue(true);                                          // b_p_update after round 0 + the first b_bud (+ the rounds that follow)
     bool done = false;
     long n_halt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_pause = 0, n_blocks = 0;
@@ -1814,6 +1836,7 @@ struct Run {
     v3_running = false;
     sync_spin(s->stream);                                      // launches queued behind the final halt
     if (v3_overlap) {
+      *(volatile int32_t *)(v3_hflags.p + 32) = 1;             // the gate of the chain sent ahead of a plan that never came gives up
       sync_spin(s->cmp);                                       // a last prefetch compare may still be running
       v3_pf_totals();
       v3_pf_release();
@@ -1834,8 +1857,8 @@ struct Run {
     }
     st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid; st.tail_threads = (uint32_t)v3_bs;
     if (knobs().v2_summary && v3_overlap)
-      fprintf(stderr, "[v3] overlap: prefetch compares %ld (centres %d)  rounds served from a prefetched batch %d  waits inside the launch %d  launches left for one %d  threads per block %d\n",
-              v3_pf_launched, v3_pf_stat[3], v3_pf_stat[0], v3_pf_stat[1], v3_pf_stat[2], v3_bs);
+      fprintf(stderr, "[v3] overlap: prefetch compares %ld in %ld chains (centres %d)  rounds served from a prefetched batch %d  waits inside the launch %d  launches left for one %d  threads per block %d\n",
+              v3_pf_seen, v3_pf_chains, v3_pf_stat[3], v3_pf_stat[0], v3_pf_stat[1], v3_pf_stat[2], v3_bs);
     if (knobs().v2_summary)
       fprintf(stderr, "[v3] blocks %ld  launches %ld  grid %d  halts none/nobirth/host/more/cap/max %ld %ld %ld %ld %ld %ld  pauses %ld  ms: wait %.1f replay %.1f enqueue %.1f total %.1f  moves %llu misses %llu\n",
               n_blocks, v3_enq, v3_grid, n_halt[0], n_halt[1], n_halt[2], n_halt[3], n_halt[4], n_halt[5], n_pause, st.ms_wait_device, st.ms_replay,

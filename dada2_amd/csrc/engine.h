@@ -460,6 +460,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   int32_t *pf_blist_n;                              // [2 KB_MAX] lengths of its work lists
   struct PfSync *pfsync;                            // PfSync::done = prefetch compares that have run
   unsigned long long pf_wait_ticks;                 // how long (100 MHz ticks) a round waits inside the launch for a prefetch in flight
+  unsigned long long pf_gate_ticks;                 // how long the gate of a chain enqueued ahead waits for its plan (k2_pf_gate)
 };
 
 // Written by the last kernel of a prefetch compare (k2_pf_done, second stream), polled by the persistent tail.
@@ -482,6 +483,7 @@ void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, c
 void launch2_screen_multi(const Eng2 &E, hipStream_t st, bool beside_tail = false);   // beside_tail: the 80-register build (prefetch compares)
 // prefetch compare (second stream): the k-mer tables of the batch pf_ctl describes (the planner only chose its centres) in front
 // of the screen, the completion word behind the aligner.  E = the prefetch's argument block (see Eng2::pf_on)
+void launch2_pf_gate(const Eng2 &E, int k, const int32_t *h_quit, int32_t *h_result, hipStream_t st);   // first kernel of chain k: waits for plan k (pinned quit / result words)
 void launch2_pf_tables(const Eng2 &E, hipStream_t st);
 void launch2_pf_done(const Eng2 &E, hipStream_t st);
 void launch2_batch_lists(const Eng2 &E, hipStream_t st);                              // classes of a batch screen -> the aligner's work lists

@@ -866,9 +866,15 @@ static __device__ __forceinline__ void plan_prefetch(const Eng2 &E, int raw, int
     C.slot_centre[bbuf * KB_MAX + k] = c;
   }
   if (tid < 2 * KB_MAX) E.pf_blist_n[tid] = 0;
+  if (tid == 0) { pc->nbatch = nb; pc->bbuf = bbuf; pc->nalign = nb; pc->abuf = bbuf; }
+  gcn_drain_stores();
+  __syncthreads();
   if (tid == 0) {
+    // the descriptor is complete: its sequence number goes out last, behind an agent-scope release - the gate kernel of the
+    // compare's chain, already waiting on the second stream (k2_pf_gate), takes it from there
     const int seq = ctl->pf_seq + 1;
-    pc->nbatch = nb; pc->bbuf = bbuf; pc->nalign = nb; pc->abuf = bbuf; pc->pf_seq = seq; pc->state = 0;
+    gcn_release_agent();
+    gcn_store_agent((uint32_t *)&pc->pf_seq, (uint32_t)seq);
     ctl->next_bbuf = (bbuf + 1) % C.NBUF;
     ctl->pf_seq = seq; ctl->pf_bbuf = bbuf; ctl->prev_bbuf = ctl->last_bbuf; ctl->last_bbuf = bbuf;
     ctl->pf_mask |= 1ull << (bbuf & 63);
@@ -1385,14 +1391,35 @@ __global__ void k2_resume(Eng2 E, int keep_list, int compare_done) {
 // ---- a prefetch compare on the second stream (Eng2::pf_on): E is ITS argument block - ctl = the prefetch descriptor, C.tab8 /
 //      full / ord and blist / blist_n its own copies.  The tables of the batch in front of the screen (the planner, inside the
 //      persistent tail's serial section, only chose the centres); the completion word behind the aligner. ----
+// The GATE in front of a prefetch compare's chain.  The host enqueues the chain of prefetch number k on the second stream BEFORE
+// the tail has planned it (one chain ahead), with this kernel first: one lane that waits until the descriptor carries sequence
+// number k - then the chain's kernels, next in the stream, start within microseconds of the plan instead of a host round trip
+// later (the host sees a plan only when it consumes the round's result block, behind the replay of the blocks before it:
+// 0.3-0.5 ms at 10^6 uniques, profiles/r07o).  It gives up when the host says the run is over (`quit`, pinned) or after its bound;
+// it then marks the descriptor halted, which turns the rest of the chain into launches that find nothing to do, and the host
+// sends the chain again when (if) the plan shows up in a block.  result (pinned): 1 = passed, 2 = gave up.
+__global__ void k2_pf_gate(Eng2 E, int k, const int32_t *quit, int32_t *result) {
+  if (threadIdx.x != 0) return;
+  Ctl2 *pc = E.ctl;
+  int res = 2;
+  const unsigned long long t0 = gcn_wall_clock();
+  for (unsigned n = 0;; n++) {
+    if ((int32_t)(gcn_load_agent((const uint32_t *)&pc->pf_seq) - (uint32_t)k) >= 0) { res = 1; break; }
+    if (gcn_wall_clock() - t0 > E.pf_gate_ticks || ((n & 15u) == 0u && gcn_load_system(quit) != 0)) break;
+    gcn_poll_pause();
+  }
+  gcn_acquire_agent();
+  pc->state = res == 1 ? 0 : 1;
+  __hip_atomic_store(result, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ __launch_bounds__(1024) void k2_pf_tables(Eng2 E) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
   const int nb = E.ctl->nbatch;
-  if (nb <= 0) return;
+  if (E.ctl->state != 0 || nb <= 0) return;
   build_batch_tables(E.S, E.C, nb, E.ctl->bcentre, s_cnt);
 }
 __global__ void k2_pf_done(Eng2 E) {
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x != 0 || E.ctl->state != 0) return;   // (a chain whose gate gave up has compared nothing)
   unsigned long long nn = 0, ng = 0;
   for (int k = 0; k < KB_MAX; k++) { nn += (unsigned long long)E.blist_n[k]; ng += (unsigned long long)E.blist_n[KB_MAX + k]; }
   E.pfsync->nnw += nn; E.pfsync->ngapless += ng;
@@ -1588,6 +1615,9 @@ void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, c
 void launch2_batch_lists(const Eng2 &E, hipStream_t st) {
   const int grid = (E.S.N + 256 * LISTS_PER_THREAD - 1) / (256 * LISTS_PER_THREAD);
   hipLaunchKernelGGL(k2_batch_lists, dim3(grid), dim3(256), 0, st, E);
+}
+void launch2_pf_gate(const Eng2 &E, int k, const int32_t *h_quit, int32_t *h_result, hipStream_t st) {
+  hipLaunchKernelGGL(k2_pf_gate, dim3(1), dim3(64), 0, st, E, k, h_quit, h_result);
 }
 void launch2_pf_tables(const Eng2 &E, hipStream_t st) { hipLaunchKernelGGL(k2_pf_tables, dim3(1), dim3(1024), 0, st, E); }
 void launch2_pf_done(const Eng2 &E, hipStream_t st) { hipLaunchKernelGGL(k2_pf_done, dim3(1), dim3(64), 0, st, E); }
