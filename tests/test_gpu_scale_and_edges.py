@@ -232,8 +232,16 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V2_TAIL": "chain"},
     {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_CHAIN": "1", "DADA2HIP_V2_MOV_INLINE": "64"},
     {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_ALIGN": "commit"},
+    # round 5: the next batch's compare runs under the tail by default (the "v2" line above); the same rounds without it,
+    # with compares the HOST launches when it sees the plan (no chain ahead behind a gate), with every prefetch waited for at
+    # the next serial end, and with a tail that leaves the launch at once instead of spinning for a prefetch that is late
+    {"DADA2HIP_V3_OVERLAP": "0"},
+    {"DADA2HIP_V3_PF_GATE_US": "0"},
+    {"DADA2HIP_V3_PF_SYNC": "1", "DADA2HIP_V3_GRID": "5"},
+    {"DADA2HIP_V3_PF_WAIT_US": "0", "DADA2HIP_V3_PF_EARLY": "0", "DADA2HIP_V2_NBUF": "4"},
 ], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph",
-        "tail-grid7-pauses-ring2-fcap", "chains", "chains-chain1-biglists", "chains-nolite-commit"])
+        "tail-grid7-pauses-ring2-fcap", "chains", "chains-chain1-biglists", "chains-nolite-commit",
+        "tail-serial", "overlap-host-launched", "overlap-sync-grid5", "overlap-leave-at-once-nbuf4"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
     20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""
