@@ -1413,6 +1413,10 @@ struct Run {
     if (K.v2_mov_inline > 0) E2.mov_inline = std::min(MOV_INLINE2, K.v2_mov_inline);   // test knob: long mover lists
     if (K.v3_ring > 0) E2.ring_limit = std::min(RING2, K.v3_ring);                     // test knob: a host that lags
     E2.fail_ordinal = K.v3_fail_entry > 0 ? K.v3_fail_entry : 0;
+    E2.spec_eval = K.v3_spec != 0 ? 1 : 0;
+    // (behind a call that moved many uniques the next one mostly moves some too, and a void attempt costs what a standing one
+    //  saves - 10^6 uniques: tail 72.7 ms without, 71.1 / 71.7 / 72.6 / 74.5 / 76.9 ms at <= 8 / 32 / 128 / 1024 / always, profiles/r07v)
+    E2.spec_max_prev = K.v3_spec_max >= 0 ? K.v3_spec_max : 16;
     E2.pf_on = v3_overlap ? 1 : 0; E2.pf_min = 2;
     E2.pf_early = K.v3_pf_early >= 0 ? K.v3_pf_early : 4;
     E2.pf_sync = K.v3_pf_sync != 0 ? 1 : 0;

@@ -448,6 +448,8 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   volatile int32_t *hcons;                          // pinned host word: result blocks the host has finished with
   volatile int32_t *hexit;                          // pinned host word: ordinal of the last k3_tail launch that has ended
   unsigned long long *ktime;                        // [KT_N] phase clocks of block 0 (DADA2HIP_PROFILE=1), else nullptr
+  int32_t spec_max_prev;                            // ... when the call before moved at most this many uniques (DADA2HIP_V3_SPEC_MAX)
+  int32_t spec_eval;                                // 1: the shuffle calls behind the commit's carry the round's evaluation (shuffle_body<.., SPEC>; DADA2HIP_V3_SPEC)
   int32_t fail_ordinal;                             // test knob (DADA2HIP_V3_FAIL_ENTRY): the k3_tail launch of this ordinal fails its entry barrier (0: none)
   // ---- the next batch's compare under the persistent tail: what a prefetch compare works with.  The compare
   //      kernels of the second stream get a copy of this block whose `ctl`, `C.tab8 / full / ord`, `blist / blist_n` and aligner

@@ -102,6 +102,126 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
 }
 
 #endif  // D2_TAIL_TU
+// ---- the evaluation's pieces (b_p_update + b_bud's first stage; their sweep is pupdate_body below) ------------------------
+// Besides the block minima, the candidates whose p-value is significant (within a factor 2 of the thresholds) are listed:
+// k2_birth looks for the ties / near ties of the best key and for the likely next centres among those few, not among all
+// uniques.
+constexpr int PUPD_TAB = 1024;    // partitions whose per-partition facts k2_pupdate keeps in LDS
+constexpr int SIG_CAP = 1024;
+template <int BS>
+struct PupdLds {
+  static constexpr int U = BS >= 512 ? 4096 / BS : 2;                        // uniques per thread per group of the sweep
+  int s_nwork;
+  int32_t s_work[U * BS];                                                // the group's uniques whose p-value / candidacy has to be looked at
+  BudKey s_k[2][BS / 64];
+  int32_t s_sig[SIG_CAP];
+  int s_nsig, s_sbase;
+  // what a unique needs from ITS PARTITION (reads, update / lock flags, the centre and its reads) sits in LDS: the loads
+  // behind clust_of[r] were a chain of three global round trips per unique in a latency-bound kernel
+  uint32_t s_prd[PUPD_TAB], s_cread[PUPD_TAB];
+  int32_t s_cen[PUPD_TAB];
+  uint8_t s_upd[PUPD_TAB], s_chk[PUPD_TAB];
+};
+// b_p_update + the first stage of b_bud's arg-min by a grid of BS-thread blocks, after `nexec` shuffle calls of the round: the
+// body of k2_pupdate (BS = 256) and of the evaluation phase of the persistent tail (BS = 1024).  partial[2 b], [2 b + 1]: block
+// b's best keys.
+// The pieces of the evaluation, so that the persistent tail can also run them INSIDE a shuffle call (shuffle_body<.., SPEC>):
+//   pupd_tables   the per-partition facts in LDS (reads after the round's first `nexec` shuffle calls); the caller synchronises
+//   pupd_wanted   PASS A's test of one unique
+//   pupd_pass_b   PASS B over the work list of a group
+//   pupd_finish   the block's minima and its listed candidates leave the block
+template <int BS>
+static __device__ __forceinline__ int pupd_tables(const Eng2 &E, PupdLds<BS> &L, int nexec) {
+  const PartState &P = E.P;
+  const int ntab = min(E.ctl->nclust, PUPD_TAB);
+  for (int k = threadIdx.x; k < ntab; k += BS) {
+    const int c = P.centre_of[k];
+    L.s_prd[k] = reads_at(E, k, nexec);
+    L.s_cen[k] = c;
+    L.s_cread[k] = E.S.reads[c];
+    L.s_upd[k] = P.update_e[k];
+    L.s_chk[k] = P.check_locks[k];
+  }
+  if (threadIdx.x == 0) L.s_nsig = 0;
+  return ntab;
+}
+// a unique whose partition has not changed and whose p is exactly 1 (nine in ten of a large sample: singletons, pval.cpp:69) can
+// neither be re-evaluated nor be a bud candidate - init is (p = 1, reads of the most abundant unique), and 1 is never below a
+// threshold (omegaA < 1 <= N / 2; omegaP <= 1 / 2 is checked)
+static __device__ __forceinline__ bool pupd_p1_skip(const Eng2 &E) { return 2.0 * E.bp.omegaP <= 1.0 && 2.0 * E.bp.omegaA <= (double)E.S.N; }
+template <int BS>
+static __device__ __forceinline__ bool pupd_wanted(const Eng2 &E, const PupdLds<BS> &L, int ntab, bool p1_skip, int cl, double p) {
+  const bool intab = cl < ntab;
+  const bool touched = (intab ? L.s_upd[cl] : E.P.update_e[cl]) || (E.greedy && (intab ? L.s_chk[cl] : E.P.check_locks[cl]));
+  return touched || !(p1_skip && p == 1.0);
+}
+template <int BS>
+static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L, int nexec, int ntab, int nwork, BudKey &b0, BudKey &b1) {
+  const PartState &P = E.P;
+  const SampleDev &S = E.S;
+  const int32_t *s_work = L.s_work;
+  for (int w = threadIdx.x; w < nwork; w += BS) {
+    const int r = s_work[w];
+    const int cl = P.clust_of[r];
+    const double l = P.comp_lam[r];
+    const uint32_t reads = S.reads[r];
+    const uint32_t ham = P.comp_ham[r];
+    const bool pr = S.prior[r] != 0;
+    const bool s0 = P.slot0[r] != 0;
+    double p = P.p[r];
+    const bool intab = cl < ntab;
+    const uint32_t prd = intab ? L.s_prd[cl] : reads_at(E, cl, nexec);
+    if (intab ? L.s_upd[cl] : P.update_e[cl]) {
+      p = dev_get_pA(reads, pr, E.detect_singletons != 0, l, ham, prd);
+      P.p[r] = p;
+    }
+    if (E.greedy && (intab ? L.s_chk[cl] : P.check_locks[cl])) {          // pval.cpp:29-36
+      const int c = intab ? L.s_cen[cl] : P.centre_of[cl];
+      const uint32_t cr = intab ? L.s_cread[cl] : S.reads[c];
+      if ((cr * l > reads) || r == c) P.lock[r] = 1;
+    }
+    // bud_candidate2 with the values at hand
+    if (s0) continue;                                                    // r = 0 is skipped as "the centre" (cluster.cpp:285)
+    if (reads < (uint32_t)E.bp.min_abund) continue;
+    if ((int)ham < E.bp.min_hamming) continue;
+    if (!(E.bp.min_fold <= 1 || ((double)reads) >= E.bp.min_fold * l * prd)) continue;
+    if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
+    if (pr && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
+    if (p * S.N < 2.0 * E.bp.omegaA || (pr && p < 2.0 * E.bp.omegaP)) {
+      const int q = atomicAdd(&L.s_nsig, 1);
+      if (q < SIG_CAP) L.s_sig[q] = r; else E.sig_list[atomicAdd(E.sig_n, 1)] = r;
+    }
+  }
+}
+template <int BS>
+static __device__ __forceinline__ void pupd_finish(const Eng2 &E, PupdLds<BS> &L, BudKey b0, BudKey b1, BudKey *__restrict__ partial) {
+  BudKey (&s_k)[2][BS / 64] = L.s_k;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    BudKey t;
+    t.p = __shfl_xor(b0.p, o, 64); t.reads = __shfl_xor(b0.reads, o, 64);
+    if (bud_better(t.p, t.reads, b0)) b0 = t;
+    t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
+    if (bud_better(t.p, t.reads, b1)) b1 = t;
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_k[0][w] = b0; s_k[1][w] = b1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < BS / 64; k++) {
+      if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
+      if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
+    }
+    partial[2 * blockIdx.x] = b0;
+    partial[2 * blockIdx.x + 1] = b1;
+    const int n = min(L.s_nsig, SIG_CAP);
+    L.s_sbase = n ? atomicAdd(E.sig_n, n) : 0;                         // one global atomic per block
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < min(L.s_nsig, SIG_CAP); i += BS) E.sig_list[L.s_sbase + i] = L.s_sig[i];
+}
+
+
 // ---- store filter of a round + b_shuffle2 ------------------------------------------------------------------------------
 // STORE (first shuffle of a round): the commit of the round's cached comparisons - class from the batch's class word with
 // the greedy skip (cluster.cpp:127-130) applied with the lock state of the commit, lambda / hamming from the rows the
@@ -135,8 +255,21 @@ struct ShufLds {
 // One b_shuffle2 call (STORE: preceded by the commit of the round's comparisons) by a grid of BS-thread blocks: the body of
 // k2_shuffle (a launch of its own, BS = 256) and of the shuffle phases of the persistent tail k3_tail (BS = 1024).
 // out: the round's result block; mv: where the call's full mover list goes; moved_before: movers of the round's earlier calls.
-template <bool STORE, int BS>
-static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L, int level, int moved_before, int32_t *mv, Round2Out *out) {
+//
+// SPEC (the persistent tail, calls after the commit's): the call also runs the round's EVALUATION (b_p_update + the block minima
+// of b_bud, the pieces above) on the assumption that it moves nothing - which is how every round's shuffle loop ends
+// (Rmain.cpp:320-325), so the last call of a round IS its evaluation: one sweep over the uniques and one grid barrier less per
+// round.  The two PASS A loads of the evaluation travel with the shuffle's own; a block evaluates only while it has moved nothing
+// itself.  If any block moved something the attempt is void and costs nothing but its time: the p-values it wrote belong to
+// members of touched partitions, which the next attempt rewrites (a touched partition stays touched until the round's
+// evaluation stands, and a unique that moves lands in a touched partition); the candidate list is emptied by the barrier's last
+// arriver; the block minima are overwritten; and a lock it set on a member of the new partition is taken back if that member
+// moves out later in the round (only the new partition has check_locks, and whoever joined it this round was unlocked when the
+// round began: a locked unique gets no comparison with the new centre, cluster.cpp:127-130).
+template <bool STORE, int BS, bool SPEC = false>
+static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L, int level, int moved_before, int32_t *mv, Round2Out *out,
+                                                   PupdLds<BS> *LP = nullptr, BudKey init = BudKey{1.0, 0u}, BudKey *partial = nullptr) {
+  static_assert(!(SPEC && STORE), "the speculative evaluation rides on the calls after the commit's");
   const Ctl2 *ctl = E.ctl;
   constexpr int MOVCAP = ShufLds<BS>::MOVCAP, NEWCAP = ShufLds<BS>::NEWCAP;
   int &s_n = L.s_n, &s_base = L.s_base, &s_an = L.s_an, &s_abase = L.s_abase, &s_keep = L.s_keep, &s_anyinc = L.s_anyinc;
@@ -161,6 +294,10 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   const bool filt = !STORE && level >= 1 && E.sh_filter;
   const int32_t *dlp = E.dlt + (size_t)(level >= 1 ? level - 1 : 0) * E.ccap;
   if (filt && threadIdx.x == 0) { s_anyinc = 0; L.s_incmask = nclust > ntab ? ~0ull : 0ull; }
+  int ptab = 0;
+  if (SPEC) ptab = pupd_tables<BS>(E, *LP, level);                       // (reads after `level` calls = after this one, if it moves nothing)
+  const bool p1_skip = SPEC && pupd_p1_skip(E);
+  BudKey eb0 = init, eb1 = init;
   __syncthreads();
   for (int k = threadIdx.x; k < ntab; k += BS) {
     s_delta[k] = 0; s_reads[k] = reads_at(E, k, level);
@@ -206,22 +343,24 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   int32_t *s_work = L.s_work;
   int &s_nwork = L.s_nwork;
   for (int grp = 0; (long long)grp * U * BS * gridDim.x < N; grp++) {
-    if (threadIdx.x == 0) s_nwork = 0;
+    if (threadIdx.x == 0) { s_nwork = 0; if (SPEC) LP->s_nwork = 0; }
     __syncthreads();
     {
       int i1s[U], froms[U];
       uint32_t clw[U], rds[U];
       uint8_t lks[U];
       unsigned long long sms[U];
+      double pps[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = sweep_unique<BS, U>(grp, u);
-        i1s[u] = -1; froms[u] = 0; clw[u] = 0; rds[u] = 0; lks[u] = 0; sms[u] = 0;
+        i1s[u] = -1; froms[u] = 0; clw[u] = 0; rds[u] = 0; lks[u] = 0; sms[u] = 0; pps[u] = 1.0;
         if (r < N) {
           i1s[u] = T.i1[r];
-          if (STORE || filt) froms[u] = P.clust_of[r];
+          if (STORE || filt || SPEC) froms[u] = P.clust_of[r];
           if (STORE) { clw[u] = cls_row[r]; rds[u] = S.reads[r]; lks[u] = P.lock[r]; }
           if (filt) sms[u] = T.smask[r];
+          if (SPEC) pps[u] = P.p[r];
         }
       }
 #pragma unroll
@@ -245,6 +384,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
           else work = true;
         }
         if (work) s_work[atomicAdd(&s_nwork, 1)] = (int32_t)((uint32_t)r | (cl << 30));
+        if (SPEC && pupd_wanted<BS>(E, *LP, ptab, p1_skip, froms[u], pps[u])) LP->s_work[atomicAdd(&LP->s_nwork, 1)] = r;
       }
     }
     __syncthreads();
@@ -330,6 +470,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
         P.clust_of[r] = to;
         P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
         E.moved[r] = 1;
+        if (SPEC && E.greedy && from == ci) P.lock[r] = 0;               // (a lock of an evaluation attempt that did not stand; see above)
         my_n0 += (from == 0 ? 1 : 0) + (to == 0 ? 0x10000 : 0);
         const uint32_t rd = S.reads[r];
         if (to < ntab) atomicAdd(&s_delta[to], (int32_t)rd); else atomicAdd(&dl[to], (int32_t)rd);
@@ -363,8 +504,13 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
     }
     __syncthreads();                                                     // (the list is rewritten by the next group)
     D2_TRACE(1 + level, 6);
+    if (SPEC) {
+      if (s_n == 0) pupd_pass_b<BS>(E, *LP, level, ptab, LP->s_nwork, eb0, eb1);   // (s_n: uniform, the block is behind a barrier)
+      __syncthreads();
+    }
   }
   __syncthreads();                                                       // the block's movers / new blocks are all buffered
+  if (SPEC && s_n == 0) pupd_finish<BS>(E, *LP, eb0, eb1, partial);
   D2_TRACE(1 + level, 2);
   const int nmov = min(s_n, MOVCAP), nnew = min(s_an, NEWCAP);
   if (threadIdx.x == 0) {
@@ -543,61 +689,21 @@ static __device__ __forceinline__ bool bud_candidate2(const Eng2 &E, int r, int 
   return true;
 }
 
-// Besides the block minima, the candidates whose p-value is significant (within a factor 2 of the thresholds) are listed:
-// k2_birth looks for the ties / near ties of the best key and for the likely next centres among those few, not among all
-// uniques.
-constexpr int PUPD_TAB = 1024;    // partitions whose per-partition facts k2_pupdate keeps in LDS
-constexpr int SIG_CAP = 1024;
-template <int BS>
-struct PupdLds {
-  static constexpr int U = BS >= 512 ? 4096 / BS : 2;                        // uniques per thread per group of the sweep
-  int s_nwork;
-  int32_t s_work[U * BS];                                                // the group's uniques whose p-value / candidacy has to be looked at
-  BudKey s_k[2][BS / 64];
-  int32_t s_sig[SIG_CAP];
-  int s_nsig, s_sbase;
-  // what a unique needs from ITS PARTITION (reads, update / lock flags, the centre and its reads) sits in LDS: the loads
-  // behind clust_of[r] were a chain of three global round trips per unique in a latency-bound kernel
-  uint32_t s_prd[PUPD_TAB], s_cread[PUPD_TAB];
-  int32_t s_cen[PUPD_TAB];
-  uint8_t s_upd[PUPD_TAB], s_chk[PUPD_TAB];
-};
-// b_p_update + the first stage of b_bud's arg-min by a grid of BS-thread blocks, after `nexec` shuffle calls of the round: the
-// body of k2_pupdate (BS = 256) and of the evaluation phase of the persistent tail (BS = 1024).  partial[2 b], [2 b + 1]: block
-// b's best keys.
 template <int BS>
 static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L, int nexec, BudKey init, BudKey *__restrict__ partial) {
-  const Ctl2 *ctl = E.ctl;
-  BudKey (&s_k)[2][BS / 64] = L.s_k;
-  int32_t *s_sig = L.s_sig;
-  int &s_nsig = L.s_nsig, &s_sbase = L.s_sbase;
-  uint32_t *s_prd = L.s_prd, *s_cread = L.s_cread;
-  int32_t *s_cen = L.s_cen;
-  uint8_t *s_upd = L.s_upd, *s_chk = L.s_chk;
   const PartState &P = E.P;
   const SampleDev &S = E.S;
-  const int ntab = min(ctl->nclust, PUPD_TAB);
   D2_TRACE(5, 0);
-  for (int k = threadIdx.x; k < ntab; k += BS) {
-    const int c = P.centre_of[k];
-    s_prd[k] = reads_at(E, k, nexec);
-    s_cen[k] = c;
-    s_cread[k] = S.reads[c];
-    s_upd[k] = P.update_e[k];
-    s_chk[k] = P.check_locks[k];
-  }
-  if (threadIdx.x == 0) s_nsig = 0;
+  const int ntab = pupd_tables<BS>(E, L, nexec);
   __syncthreads();
   BudKey b0 = init, b1 = init;
   D2_TRACE(5, 1);
-  // Two passes per U * BS uniques, as in the shuffle sweep.  PASS A reads a unique's partition and p-value: a unique whose
-  // partition has not changed and whose p is exactly 1 (nine in ten of a large sample: singletons, pval.cpp:69) can neither be
-  // re-evaluated nor be a bud candidate - init is (p = 1, reads of the most abundant unique), and 1 is never below a threshold
-  // (omegaA < 1 <= N / 2; omegaP <= 1 / 2 is checked) - and is done with after 12 bytes.  The others go to a work list in LDS.
+  // Two passes per U * BS uniques, as in the shuffle sweep.  PASS A reads a unique's partition and p-value: most uniques are
+  // done with after 12 bytes (pupd_wanted).  The others go to a work list in LDS.
   // PASS B, one listed unique per thread: the reference's b_p_update / lock / candidate code, the special functions of the
   // p-value on full waves instead of in the odd lane.
   constexpr int U = PupdLds<BS>::U;
-  const bool p1_skip = 2.0 * E.bp.omegaP <= 1.0 && 2.0 * E.bp.omegaA <= (double)S.N;
+  const bool p1_skip = pupd_p1_skip(E);
   int32_t *s_work = L.s_work;
   int &s_nwork = L.s_nwork;
   for (int grp = 0; (long long)grp * U * BS * gridDim.x < S.N; grp++) {
@@ -616,73 +722,17 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
       for (int u = 0; u < U; u++) {
         const int r = sweep_unique<BS, U>(grp, u), cl = cls_[u];
         if (cl < 0) continue;
-        const bool intab = cl < ntab;
-        const bool touched = (intab ? s_upd[cl] : P.update_e[cl]) || (E.greedy && (intab ? s_chk[cl] : P.check_locks[cl]));
-        if (touched || !(p1_skip && ps_[u] == 1.0)) s_work[atomicAdd(&s_nwork, 1)] = r;
+        if (pupd_wanted<BS>(E, L, ntab, p1_skip, cl, ps_[u])) s_work[atomicAdd(&s_nwork, 1)] = r;
       }
     }
     __syncthreads();
     D2_TRACE(5, 4);
-    const int nwork = s_nwork;
-    for (int w = threadIdx.x; w < nwork; w += BS) {
-    const int r = s_work[w];
-    const int cl = P.clust_of[r];
-    const double l = P.comp_lam[r];
-    const uint32_t reads = S.reads[r];
-    const uint32_t ham = P.comp_ham[r];
-    const bool pr = S.prior[r] != 0;
-    const bool s0 = P.slot0[r] != 0;
-    double p = P.p[r];
-    const bool intab = cl < ntab;
-    const uint32_t prd = intab ? s_prd[cl] : reads_at(E, cl, nexec);
-    if (intab ? s_upd[cl] : P.update_e[cl]) {
-      p = dev_get_pA(reads, pr, E.detect_singletons != 0, l, ham, prd);
-      P.p[r] = p;
-    }
-    if (E.greedy && (intab ? s_chk[cl] : P.check_locks[cl])) {          // pval.cpp:29-36
-      const int c = intab ? s_cen[cl] : P.centre_of[cl];
-      const uint32_t cr = intab ? s_cread[cl] : S.reads[c];
-      if ((cr * l > reads) || r == c) P.lock[r] = 1;
-    }
-    // bud_candidate2 with the values at hand
-    if (s0) continue;                                                    // r = 0 is skipped as "the centre" (cluster.cpp:285)
-    if (reads < (uint32_t)E.bp.min_abund) continue;
-    if ((int)ham < E.bp.min_hamming) continue;
-    if (!(E.bp.min_fold <= 1 || ((double)reads) >= E.bp.min_fold * l * prd)) continue;
-    if (bud_better(p, reads, b0)) { b0.p = p; b0.reads = reads; }
-    if (pr && bud_better(p, reads, b1)) { b1.p = p; b1.reads = reads; }
-    if (p * S.N < 2.0 * E.bp.omegaA || (pr && p < 2.0 * E.bp.omegaP)) {
-      const int q = atomicAdd(&s_nsig, 1);
-      if (q < SIG_CAP) s_sig[q] = r; else E.sig_list[atomicAdd(E.sig_n, 1)] = r;
-    }
-    }
+    pupd_pass_b<BS>(E, L, nexec, ntab, s_nwork, b0, b1);
     __syncthreads();                                                     // (the list is rewritten by the next group)
     D2_TRACE(5, 5);
   }
   D2_TRACE(5, 2);
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    BudKey t;
-    t.p = __shfl_xor(b0.p, o, 64); t.reads = __shfl_xor(b0.reads, o, 64);
-    if (bud_better(t.p, t.reads, b0)) b0 = t;
-    t.p = __shfl_xor(b1.p, o, 64); t.reads = __shfl_xor(b1.reads, o, 64);
-    if (bud_better(t.p, t.reads, b1)) b1 = t;
-  }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { s_k[0][w] = b0; s_k[1][w] = b1; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < BS / 64; k++) {
-      if (bud_better(s_k[0][k].p, s_k[0][k].reads, b0)) b0 = s_k[0][k];
-      if (bud_better(s_k[1][k].p, s_k[1][k].reads, b1)) b1 = s_k[1][k];
-    }
-    partial[2 * blockIdx.x] = b0;
-    partial[2 * blockIdx.x + 1] = b1;
-    const int n = min(s_nsig, SIG_CAP);
-    s_sbase = n ? atomicAdd(E.sig_n, n) : 0;                           // one global atomic per block
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < min(s_nsig, SIG_CAP); i += BS) E.sig_list[s_sbase + i] = s_sig[i];
+  pupd_finish<BS>(E, L, b0, b1, partial);
   D2_TRACE(5, 3);
 }
 #ifndef D2_TAIL_TU

@@ -6,9 +6,11 @@
 // by grid ramp-up, control-block loads, dependent gathers and the guarded launches that find nothing to do.  k3_tail runs the
 // same phase bodies inside ONE launch of G co-resident blocks (1024 threads, at most one per CU):
 //
-//   round:  commit + shuffle call 0 | barrier | shuffle call 1 | barrier | ... until a call moves nothing | evaluation |
-//           barrier, whose LAST ARRIVER runs the serial end of the round (birth_body: arg-min, ties, decision, birth, plan)
-//           before it releases the others | the same block then publishes the round's result block to the host
+//   round:  commit + shuffle call 0 | barrier | shuffle call 1 + evaluation as if it moved nothing | barrier | ... until a call
+//           moves nothing: ITS barrier's LAST ARRIVER runs the serial end of the round (birth_body: arg-min, ties, decision,
+//           birth, plan) before it releases the others | the same block then publishes the round's result block to the host
+//           (a round whose commit call moves nothing, or whose calls MAX_SHUFFLE cuts short: evaluation | barrier as a phase
+//           of its own, as in round 4)
 //
 // and goes on to the next round for as long as the new centre's comparisons are cached.  It leaves the launch when a compare
 // is due (the launches of the batch compare follow in the stream, then the next k3_tail), when the device halts (the same
@@ -25,10 +27,8 @@ constexpr double GRID_WAIT_S = 2.0;     // bound of a barrier wait (the slowest 
 
 template <int BS>
 struct TailLds {
-  union {
-    ShufLds<BS> sh;
-    PupdLds<BS> pu;
-  };
+  ShufLds<BS> sh;                                       // (both at once: a shuffle call after the commit's also evaluates, shuffle_body<.., SPEC>)
+  PupdLds<BS> pu;
   int last, ok;
 };
 
@@ -146,37 +146,56 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
     const int ring = ctl->pub_seq % RING2;
     Round2Out *out = E.dblk + ring;
     int level = 0;
-    if (!(first && rnd == 0)) {
+    const bool shuffles = !(first && rnd == 0);
+    if (shuffles) {
       // ---- commit of the round's cached comparisons + b_shuffle2 until a call moves nothing (Rmain.cpp:320-325) ----
       shuffle_body<true, BS>(E, L.sh, 0, 0, E.movers, out);
       KT_LAP(KT_S0);
       if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
       KT_LAP(KT_S0_BAR);
-      int moved = out->cnt[0];
       level = 1;
-      while (level < E.max_shuffle && out->cnt[level - 1] > 0) {
-        shuffle_body<false, BS>(E, L.sh, level, moved, E.movers + (size_t)level * 3 * (size_t)E.S.N, out);
+    }
+    int moved = shuffles ? out->cnt[0] : 0;
+    for (;;) {
+      const bool more = shuffles && level < E.max_shuffle && out->cnt[level - 1] > 0;   // another b_shuffle2 call is due
+      int32_t *mv = E.movers + (size_t)level * 3 * (size_t)E.S.N;
+      // (the attempt is worth its time when the call is likely to be the round's last: the call before it moved few uniques)
+      const bool attempt = more && E.spec_eval && out->cnt[level - 1] <= E.spec_max_prev;
+      if (more && !attempt) {
+        shuffle_body<false, BS>(E, L.sh, level, moved, mv, out);
         KT_LAP(KT_SL);
         if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
         KT_LAP(KT_SL_BAR);
         moved += out->cnt[level];
         level++;
+        continue;
       }
+      // The round's evaluation (b_p_update + the block minima of b_bud): riding on the shuffle call that is due, on the
+      // assumption that the call moves nothing - or, when no call is due any more, as a phase of its own.  The last block to
+      // arrive behind an evaluation that stands takes the round's decision.
+      if (more) { shuffle_body<false, BS, true>(E, L.sh, level, moved, mv, out, &L.pu, init, (BudKey *)E.partial); KT_LAP(KT_SL); }
+      else { pupdate_body<BS>(E, L.pu, level, init, (BudKey *)E.partial); KT_LAP(KT_P); }
+      const int lv = level;
+      if (!grid_sync<BS>(E, L, epoch, G, [&]() {
+            if (more && out->cnt[lv] != 0) {              // (every thread of the block reads the same settled word)
+              if (threadIdx.x == 0) *E.sig_n = 0;         // the attempt is void: its listed candidates go
+              return;
+            }
+            const int nlev = more ? lv + 1 : lv;
+            const unsigned long long tb = E.ktime ? gcn_wall_clock() : 0ull;
+            birth_body(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal);
+            if (threadIdx.x == 0) {
+              ctl->pub_seq = ctl->pub_seq + 1;            // (the others find the NEXT round's block through it)
+              if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
+            }
+          }))
+        return;
+      if (!more) { KT_LAP(KT_P_BAR); break; }
+      KT_LAP(KT_SL_BAR);
+      moved += out->cnt[level];
+      level++;
+      if (out->cnt[level - 1] == 0) break;                // the call moved nothing: the round is decided
     }
-    // ---- b_p_update + the block minima of b_bud; the last block to arrive takes the round's decision ----
-    pupdate_body<BS>(E, L.pu, level, init, (BudKey *)E.partial);
-    KT_LAP(KT_P);
-    const int nlev = level;
-    if (!grid_sync<BS>(E, L, epoch, G, [&]() {
-          const unsigned long long tb = E.ktime ? gcn_wall_clock() : 0ull;
-          birth_body(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal);
-          if (threadIdx.x == 0) {
-            ctl->pub_seq = ctl->pub_seq + 1;              // (the others find the NEXT round's block through it)
-            if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
-          }
-        }))
-      return;
-    KT_LAP(KT_P_BAR);
     const bool leave = ctl->kexit != 0;
     if (L.last) {
       // the block that took the decision publishes it while the others are already in the next round's first phase

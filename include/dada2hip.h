@@ -30,6 +30,7 @@
  *   DADA2HIP_ENGINE=classic            one centre per round, a host round trip per decision (round 1's engine)
  *   DADA2HIP_V2_TAIL=chain             the round tail as launch chains instead of the persistent kernel
  *   DADA2HIP_V3_OVERLAP=0|1            the next batch's compare under the persistent tail on a second stream (default: on)
+ *   DADA2HIP_V3_SPEC=0|1               the evaluation of a round rides on its shuffle calls (default: on; 0 = a phase of its own)
  *   DADA2HIP_NW_KERNEL=lane|coop|wide  force one aligner family;  DADA2HIP_AD_HOMO=0  homopolymer gaps on the lane kernels
  *   DADA2HIP_WAIT=block, DADA2HIP_WAIT_TIMEOUT_S=<s>   sleep instead of spin while waiting; bound of every device wait
  *   DADA2HIP_HOST_THREADS=<n>, DADA2HIP_ALLOC_CACHE=0, DADA2HIP_ALLOC_CACHE_GB=<n>   marshalling pool, allocation cache
