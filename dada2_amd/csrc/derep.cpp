@@ -21,7 +21,6 @@
 #include <string>
 #include <string_view>
 #include <thread>
-#include <unordered_map>
 #include <vector>
 
 #include <zlib.h>
@@ -30,7 +29,7 @@
 #include "hostpar.h"
 
 struct dada2hip_derep {
-  std::vector<std::string> seqs;
+  std::unique_ptr<char[]> seq_blob;  // the uniques' sequences, NUL-terminated, in output order
   std::vector<const char *> seq_ptrs;
   std::vector<int32_t> abund, map;
   std::unique_ptr<double[]> quals;   // [nuniques][maxlen], NA past each unique's length (filled by the host pool: first touch in parallel)
@@ -46,11 +45,15 @@ double na_real() {
   return v.d;
 }
 
-// Line reader: a background thread inflates the file (gzread; plain files pass through zlib untouched) into 8 MiB
-// pieces while the caller parses the previous ones; lines are found with memchr.
+// Line reader: a background thread inflates the file (gzread; a plain file is read with fread - through zlib it is one more
+// copy of every byte) into 8 MiB pieces while the caller parses the previous ones; lines are found with memchr.  A buffer the
+// window has moved out of is RETIRED, not freed: the lines handed out stay valid until the caller says release() (the
+// records of a batch are hashed in parallel before they are looked at in order).
 struct LineReader {
   static constexpr size_t PIECE = 8u << 20;
   gzFile f;
+  FILE *plain = nullptr;          // non-null: the file is not compressed (gzdirect) and is read directly
+  std::vector<std::vector<char>> retired;
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
@@ -60,13 +63,14 @@ struct LineReader {
   std::vector<char> buf;
   size_t pos = 0, end = 0;
   bool eof = false;
-  explicit LineReader(gzFile f_) : f(f_) {
+  LineReader(gzFile f_, FILE *plain_) : f(f_), plain(plain_) {
     th = std::thread([this] {
       for (;;) {
         std::vector<char> piece(PIECE);
-        const int got = gzread(f, piece.data(), (unsigned)PIECE);
+        const int got = plain ? (int)fread(piece.data(), 1, PIECE, plain) : gzread(f, piece.data(), (unsigned)PIECE);
         std::unique_lock<std::mutex> lk(mu);
         if (got <= 0) {
+          if (plain) { if (ferror(plain)) zerr = "read error"; done = true; cv.notify_all(); return; }
           // gzread returns 0 at a clean end of file AND at a stream cut short; -1 on a data / CRC error: ask gzerror
           int zrc = Z_OK;
           const char *zm = gzerror(f, &zrc);
@@ -96,13 +100,15 @@ struct LineReader {
       ready.pop_front();
     }
     cv.notify_all();
-    if (pos == end) { buf.swap(piece); pos = 0; end = buf.size(); return true; }
+    if (pos == end) { buf.swap(piece); pos = 0; end = buf.size(); if (!piece.empty()) retired.push_back(std::move(piece)); return true; }
     std::vector<char> nb(end - pos + piece.size());
     memcpy(nb.data(), &buf[pos], end - pos);
     memcpy(nb.data() + (end - pos), piece.data(), piece.size());
     buf.swap(nb); pos = 0; end = buf.size();
+    retired.push_back(std::move(nb));
     return true;
   }
+  void release() { retired.clear(); }   // the lines handed out before the last refill are no longer needed
   std::string error() { std::lock_guard<std::mutex> lk(mu); return zerr; }
   // next line without its terminator as [*p, *p + *n); valid until the next call; false at EOF
   bool next(const char **p, size_t *n) {
@@ -164,22 +170,99 @@ struct SumArena {
   }
 };
 
-// std::sort over the host pool: sorted runs in parallel, then pairwise merges level by level (each level's merges in parallel).
-// The same order as one std::sort for a strict weak order without equal elements (the uniques of a chunk are distinct strings).
-template <typename It, typename Cmp>
-void pool_sort(It first, It last, Cmp cmp) {
-  const size_t n = (size_t)(last - first);
-  size_t runs = 1;
-  while (runs < (size_t)d2::HostPool::get().nthreads() && n / (runs * 2) >= (size_t)1 << 15) runs *= 2;
-  if (runs == 1) { std::sort(first, last, cmp); return; }
-  auto bound = [&](size_t r, size_t of) { return first + (ptrdiff_t)(n * r / of); };
-  d2::parallel_for(runs, 1, [&](size_t r0, size_t r1) { for (size_t r = r0; r < r1; r++) std::sort(bound(r, runs), bound(r + 1, runs), cmp); });
-  for (size_t width = 1; width < runs; width *= 2)
-    d2::parallel_for(runs / (2 * width), 1, [&](size_t m0, size_t m1) {
-      for (size_t m = m0; m < m1; m++)
-        std::inplace_merge(bound(2 * m * width, runs), bound((2 * m + 1) * width, runs), bound((2 * m + 2) * width, runs), cmp);
-    });
+// Sort of DISTINCT elements over the host pool (sample sort): splitters from an evenly spaced sample, every element to its
+// bucket (parallel), the buckets sorted side by side.  Any correct sort of distinct elements gives the one order, so this is
+// std::sort's result.  (The first form - sorted runs, then pairwise merges level by level - spent most of its time in the last
+// levels, where one or two threads merge everything: 0.64 s of a 2.0 s dereplication of 1.2 M uniques.)
+template <typename Cmp>
+void pool_sort(int32_t *first, size_t n, Cmp cmp) {
+  const size_t nt = (size_t)d2::HostPool::get().nthreads();
+  if (nt <= 1 || n < ((size_t)1 << 16)) { std::sort(first, first + n, cmp); return; }
+  size_t B = 16;
+  while (B < 4 * nt && B < 1024 && n / (2 * B) >= 2048) B *= 2;
+  const size_t OVER = 32, ns = B * OVER;
+  std::vector<int32_t> sample(ns);
+  for (size_t i = 0; i < ns; i++) sample[i] = first[(size_t)((double)i * (double)n / (double)ns)];
+  std::sort(sample.begin(), sample.end(), cmp);
+  std::vector<int32_t> split(B - 1);
+  for (size_t k = 1; k < B; k++) split[k - 1] = sample[k * OVER];
+  const size_t nchunk = std::min<size_t>(4 * nt, (n + 4095) / 4096);
+  auto cbound = [&](size_t c) { return n * c / nchunk; };
+  std::vector<uint16_t> bucket(n);
+  std::vector<size_t> cnt(nchunk * B, 0);
+  d2::parallel_for(nchunk, 1, [&](size_t c0, size_t c1) {
+    for (size_t c = c0; c < c1; c++) {
+      size_t *my = &cnt[c * B];
+      for (size_t i = cbound(c); i < cbound(c + 1); i++) {
+        const size_t k = (size_t)(std::upper_bound(split.begin(), split.end(), first[i], cmp) - split.begin());
+        bucket[i] = (uint16_t)k;
+        my[k]++;
+      }
+    }
+  });
+  std::vector<size_t> start(B + 1, 0);
+  for (size_t k = 0; k < B; k++) {                       // bucket-major, chunk-minor offsets
+    size_t run = start[k];
+    for (size_t c = 0; c < nchunk; c++) { const size_t v = cnt[c * B + k]; cnt[c * B + k] = run; run += v; }
+    start[k + 1] = run;
+  }
+  std::vector<int32_t> tmp(n);
+  d2::parallel_for(nchunk, 1, [&](size_t c0, size_t c1) {
+    for (size_t c = c0; c < c1; c++) {
+      size_t *my = &cnt[c * B];
+      for (size_t i = cbound(c); i < cbound(c + 1); i++) tmp[my[bucket[i]]++] = first[i];
+    }
+  });
+  d2::parallel_for(B, 1, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; k++) {
+      std::sort(tmp.begin() + (ptrdiff_t)start[k], tmp.begin() + (ptrdiff_t)start[k + 1], cmp);
+      std::copy(tmp.begin() + (ptrdiff_t)start[k], tmp.begin() + (ptrdiff_t)start[k + 1], first + start[k]);
+    }
+  });
 }
+
+// 64-bit hash of a sequence (multiply-fold over 8-byte words; the table below compares the bytes on a tag match, so quality
+// only matters for speed)
+inline uint64_t fold64(uint64_t a, uint64_t b) { const __uint128_t r = (__uint128_t)a * b; return (uint64_t)r ^ (uint64_t)(r >> 64); }
+inline uint64_t seq_hash(const char *p, size_t n) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n * 0xD6E8FEB86659FD93ull;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = fold64(h ^ w, 0xA0761D6478BD642Full); }
+  if (i < n) { uint64_t w = 0; memcpy(&w, p + i, n - i); h = fold64(h ^ w, 0xE7037ED1A0B428DBull); }
+  return fold64(h, 0x8EBC6AF09C88C6E3ull);
+}
+
+// sequence -> provisional id: open addressing over (32-bit tag, id) pairs, the hash computed by the caller (in parallel, for a
+// whole batch of records) and kept per id for the re-insertion when the table grows
+struct SeqTable {
+  std::vector<uint32_t> tag;
+  std::vector<int32_t> id;
+  size_t mask = 0, used = 0;
+  SeqTable() { resize(1 << 17); }
+  void resize(size_t cap) { tag.assign(cap, 0); id.assign(cap, -1); mask = cap - 1; used = 0; }
+  static uint32_t tag_of(uint64_t h) { return (uint32_t)(h >> 32); }
+  void put(uint64_t h, int32_t v) {                      // (the key is known to be absent)
+    size_t s = (size_t)h & mask;
+    while (id[s] >= 0) s = (s + 1) & mask;
+    id[s] = v; tag[s] = tag_of(h); used++;
+  }
+  template <typename Same>
+  int32_t find(uint64_t h, Same same) const {
+    const uint32_t t = tag_of(h);
+    for (size_t s = (size_t)h & mask;; s = (s + 1) & mask) {
+      const int32_t v = id[s];
+      if (v < 0) return -1;
+      if (tag[s] == t && same(v)) return v;
+    }
+  }
+  void insert(uint64_t h, int32_t v, const std::vector<uint64_t> &hashes) {
+    if ((used + 1) * 2 > mask + 1) {
+      resize((mask + 1) * 4);
+      for (size_t k = 0; k < hashes.size(); k++) if ((int32_t)k != v) put(hashes[k], (int32_t)k);
+    }
+    put(h, v);
+  }
+};
 
 void set_err(char *errbuf, size_t errlen, const char *m) {
   if (errbuf && errlen) snprintf(errbuf, errlen, "%s", m);
@@ -196,13 +279,22 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
   gzFile f = gzopen(path, "rb");
   if (!f) { set_err(errbuf, errlen, "Not all provided files exist."); return DADA2HIP_ERR_INPUT; }
   gzbuffer(f, 1 << 20);
-  struct GzGuard { gzFile f; ~GzGuard() { gzclose(f); } } guard{f};   // closed after the reader thread has joined
+  FILE *plain = gzdirect(f) ? fopen(path, "rb") : nullptr;           // not compressed: read it without the copy through zlib
+  struct GzGuard { gzFile f; FILE *p; ~GzGuard() { gzclose(f); if (p) fclose(p); } } guard{f, plain};   // closed after the reader thread has joined
   if (chunk_reads <= 0) chunk_reads = 1000000;   // derepFastq(n = 1e6)
   // Uniques get a provisional id at first sight; at every chunk end the ids born in that chunk are put in lexical order
   // and appended to `seen` (the order derepFastq's merge produces).  Quality characters are summed raw, the encoding
   // offset is taken off once at the end (exact in integers), so nothing of a chunk has to be buffered.
-  std::deque<std::string> store;                        // provisional id -> sequence (stable addresses)
-  std::unordered_map<std::string_view, int32_t> index;  // sequence -> provisional id
+  //
+  // The records are taken in BATCHES: the reader's lines stay valid until the batch is done (LineReader::release), the
+  // sequences of a batch are hashed over the host pool, and only the table look-ups - which assign the provisional ids in
+  // read order - run one after the other.
+  struct Rec { const char *seq, *qual; uint32_t len; int32_t minq; uint64_t h; };
+  ByteArena seq_arena;                                  // provisional id -> sequence bytes (stable addresses)
+  std::vector<const char *> sptr;                       // per provisional id
+  std::vector<uint32_t> slen;
+  std::vector<uint64_t> shash;
+  SeqTable index;                                       // sequence -> provisional id
   std::vector<int64_t> count;                           // per provisional id
   std::vector<int64_t *> qacc;                          // per provisional id: raw quality character sums [len]; null while the unique has one read
   std::vector<const unsigned char *> qone;              // per provisional id: the quality characters of its first read
@@ -216,30 +308,85 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
   auto t_start = dclk::now();
   double ms_sort = 0;
   auto ms_since = [](dclk::time_point t) { return std::chrono::duration<double, std::milli>(dclk::now() - t).count(); };
-  LineReader in(f);
+  LineReader in(f, plain);
   const char *hp, *sp, *pp, *qp;
   size_t hn, sn, pn, qn;
-  index.reserve(1 << 16);
   int offset = qual_offset, minq = 255;
   int rc = DADA2HIP_OK;
   int64_t nreads = 0, in_chunk = 0;
   size_t chunk_first = 0;   // first provisional id born in the current chunk
+  auto seq_less = [&](int32_t a, int32_t b) {            // srsort: C locale (bytes as unsigned, a prefix first)
+    const size_t la = slen[a], lb = slen[b];
+    const int c = memcmp(sptr[a], sptr[b], std::min(la, lb));
+    return c < 0 || (c == 0 && la < lb);
+  };
   auto end_chunk = [&]() {
     if (offset <= 0 && minq < 255) offset = minq < 59 ? 33 : 64;   // qualityType "Auto": below ';' only Phred+33 encodings
     const size_t n0 = seen.size();
     const auto t_sort = dclk::now();
-    for (size_t id = chunk_first; id < store.size(); id++) seen.push_back((int32_t)id);
-    pool_sort(seen.begin() + n0, seen.end(), [&](int32_t a, int32_t b) { return store[a] < store[b]; });   // srsort: C locale (10^6 string compares x 20: the largest single piece of a chunk's work, so it goes over the host pool)
-    chunk_first = store.size();
+    for (size_t id = chunk_first; id < sptr.size(); id++) seen.push_back((int32_t)id);
+    pool_sort(seen.data() + n0, seen.size() - n0, seq_less);   // (10^6 string compares x 20: the largest single piece of a chunk's work)
+    chunk_first = sptr.size();
     in_chunk = 0;
     ms_sort += ms_since(t_sort);
   };
-  std::string s;
+  std::vector<Rec> batch;
+  const size_t BATCH = 32768;
+  batch.reserve(BATCH);
+  auto flush = [&]() {
+    const bool want_min = offset <= 0;
+    d2::parallel_for(batch.size(), 512, [&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; i++) {
+        Rec &r = batch[i];
+        r.h = seq_hash(r.seq, r.len);
+        int m = 255;
+        if (want_min) for (uint32_t p = 0; p < r.len; p++) m = std::min(m, (int)(unsigned char)r.qual[p]);
+        r.minq = m;
+      }
+    });
+    for (const Rec &r : batch) {
+      nreads++;
+      in_chunk++;
+      if (r.len == 0) {
+        map.push_back(-1);
+      } else {
+        const size_t n = r.len;
+        int32_t id = index.find(r.h, [&](int32_t v) { return slen[v] == r.len && memcmp(sptr[v], r.seq, n) == 0; });
+        if (id < 0) {
+          id = (int32_t)sptr.size();
+          char *b = (char *)seq_arena.take(n);
+          memcpy(b, r.seq, n);
+          sptr.push_back(b); slen.push_back(r.len); shash.push_back(r.h);
+          index.insert(r.h, id, shash);
+          count.push_back(0);
+          qacc.push_back(nullptr);
+          qone.push_back(nullptr);
+        }
+        const unsigned char *qq = (const unsigned char *)r.qual;
+        if (offset <= 0 && chunk_first == 0) minq = std::min(minq, (int)r.minq);
+        if (++count[id] == 1) {                           // first sight: keep the characters
+          unsigned char *b = barena.take(n);
+          memcpy(b, qq, n);
+          qone[id] = b;
+        } else {
+          int64_t *acc = qacc[id];
+          if (!acc) {                                     // second sight: the sums start from the first read's characters
+            acc = qacc[id] = arena.take(n);
+            const unsigned char *b = qone[id];
+            for (size_t p = 0; p < n; p++) acc[p] = b[p];
+          }
+          for (size_t p = 0; p < n; p++) acc[p] += qq[p];
+        }
+        map.push_back(id);
+      }
+      if (in_chunk >= chunk_reads) end_chunk();
+    }
+    batch.clear();
+    in.release();
+  };
   while (in.next(&hp, &hn)) {
     if (hn == 0) continue;
-    bool ok = hp[0] == '@' && in.next(&sp, &sn);
-    if (ok) s.assign(sp, sn);   // the window may move under the next two lines
-    ok = ok && in.next(&pp, &pn) && pn > 0 && pp[0] == '+' && in.next(&qp, &qn) && qn == s.size();
+    const bool ok = hp[0] == '@' && in.next(&sp, &sn) && in.next(&pp, &pn) && pn > 0 && pp[0] == '+' && in.next(&qp, &qn) && qn == sn;
     if (!ok) {
       const std::string ze = in.error();   // a record cut short by a damaged stream is a read error, not a format error
       if (!ze.empty()) set_err(errbuf, errlen, ("dada2hip: error reading " + std::string(path) + ": " + ze).c_str());
@@ -247,42 +394,8 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
       rc = DADA2HIP_ERR_INPUT;
       break;
     }
-    nreads++;
-    in_chunk++;
-    if (s.empty()) {
-      map.push_back(-1);
-    } else {
-      auto it = index.find(std::string_view(s));
-      int32_t id;
-      if (it == index.end()) {
-        id = (int32_t)store.size();
-        store.push_back(s);
-        index.emplace(std::string_view(store.back()), id);
-        count.push_back(0);
-        qacc.push_back(nullptr);
-        qone.push_back(nullptr);
-      } else {
-        id = it->second;
-      }
-      const unsigned char *qq = (const unsigned char *)qp;
-      const size_t n = s.size();
-      if (offset <= 0 && chunk_first == 0) for (size_t p = 0; p < n; p++) minq = std::min(minq, (int)qq[p]);
-      if (++count[id] == 1) {                           // first sight: keep the characters
-        unsigned char *b = barena.take(n);
-        memcpy(b, qq, n);
-        qone[id] = b;
-      } else {
-        int64_t *acc = qacc[id];
-        if (!acc) {                                     // second sight: the sums start from the first read's characters
-          acc = qacc[id] = arena.take(n);
-          const unsigned char *b = qone[id];
-          for (size_t p = 0; p < n; p++) acc[p] = b[p];
-        }
-        for (size_t p = 0; p < n; p++) acc[p] += qq[p];
-      }
-      map.push_back(id);
-    }
-    if (in_chunk >= chunk_reads) end_chunk();
+    batch.push_back(Rec{sp, qp, (uint32_t)sn, 255, 0});
+    if (batch.size() >= BATCH) flush();
   }
   if (rc != DADA2HIP_OK) return rc;
   {
@@ -292,22 +405,31 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
       return DADA2HIP_ERR_INPUT;
     }
   }
+  flush();
   end_chunk();
   const double ms_parse = ms_since(t_start) - ms_sort;
   const auto t_out = dclk::now();
-  if (store.empty()) { set_err(errbuf, errlen, "Only zero-length sequences detected during dereplication."); return DADA2HIP_ERR_INPUT; }
+  if (sptr.empty()) { set_err(errbuf, errlen, "Only zero-length sequences detected during dereplication."); return DADA2HIP_ERR_INPUT; }
   if (offset <= 0) offset = 33;
-  // stable sort by decreasing abundance (sequenceIO.R:98)
+  // stable sort by decreasing abundance (sequenceIO.R:98): (abundance descending, position in `seen` ascending) is a strict
+  // order without equal elements, so the pool's sort gives the stable result
   const size_t U = seen.size();
+  std::vector<int32_t> pos_of(U);
+  d2::parallel_for(U, 4096, [&](size_t k0, size_t k1) { for (size_t k = k0; k < k1; k++) pos_of[seen[k]] = (int32_t)k; });
   std::vector<int32_t> ord(seen);
-  std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return count[a] > count[b]; });
+  pool_sort(ord.data(), U, [&](int32_t a, int32_t b) { return count[a] > count[b] || (count[a] == count[b] && pos_of[a] < pos_of[b]); });
   std::vector<int32_t> rank(U);
-  for (size_t k = 0; k < U; k++) rank[ord[k]] = (int32_t)k;
+  d2::parallel_for(U, 4096, [&](size_t k0, size_t k1) { for (size_t k = k0; k < k1; k++) rank[ord[k]] = (int32_t)k; });
   dada2hip_derep *d = new dada2hip_derep();
+  std::unique_ptr<dada2hip_derep> dguard(d);
   d->nreads = nreads;
-  for (auto &u : store) d->maxlen = std::max<int32_t>(d->maxlen, (int32_t)u.size());
-  d->seqs.resize(U); d->abund.resize(U);
+  for (size_t k = 0; k < U; k++) d->maxlen = std::max<int32_t>(d->maxlen, (int32_t)slen[k]);
+  d->abund.resize(U);
   d->quals.reset(new double[U * (size_t)d->maxlen]);
+  std::vector<size_t> soff(U + 1, 0);
+  for (size_t k = 0; k < U; k++) soff[k + 1] = soff[k] + slen[ord[k]] + 1;
+  d->seq_blob.reset(new char[soff[U]]);
+  d->seq_ptrs.resize(U);
   const double na = na_real();
   const size_t ml = (size_t)d->maxlen;
   d2::parallel_for(U, 256, [&](size_t k0, size_t k1) {
@@ -316,19 +438,21 @@ static int derep_fastq_body(const char *path, int64_t chunk_reads, int32_t qual_
       d->abund[k] = (int32_t)count[id];
       double *row = &d->quals[k * ml];
       const int64_t *acc = qacc[id];
-      const size_t len = store[id].size();
+      const size_t len = slen[id];
       if (acc) for (size_t p = 0; p < len; p++) row[p] = (double)(acc[p] - (int64_t)offset * count[id]) / (double)count[id];   // derepQuals / derepCounts (:95)
       else { const unsigned char *b = qone[id]; for (size_t p = 0; p < len; p++) row[p] = (double)((int64_t)b[p] - (int64_t)offset) / 1.0; }
       for (size_t p = len; p < ml; p++) row[p] = na;
+      char *dst = d->seq_blob.get() + soff[k];
+      memcpy(dst, sptr[id], len);
+      dst[len] = 0;
+      d->seq_ptrs[k] = dst;
     }
   });
-  index.clear();
-  for (size_t k = 0; k < U; k++) d->seqs[k] = std::move(store[ord[k]]);
-  d->seq_ptrs.resize(U);
-  for (size_t k = 0; k < U; k++) d->seq_ptrs[k] = d->seqs[k].c_str();
   d->map.resize(map.size());
-  for (size_t i = 0; i < map.size(); i++) d->map[i] = map[i] < 0 ? DADA2HIP_NA_INTEGER : rank[map[i]];
-  *out = d;
+  d2::parallel_for(map.size(), 65536, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) d->map[i] = map[i] < 0 ? DADA2HIP_NA_INTEGER : rank[map[i]];
+  });
+  *out = dguard.release();
   if (times) fprintf(stderr, "[derep] %lld reads, %zu uniques: read + parse + hash %.0f ms, chunk sorts %.0f ms, output (abundance order, mean qualities, map) %.0f ms\n",
                      (long long)nreads, U, ms_parse, ms_sort, ms_since(t_out));
   return DADA2HIP_OK;
@@ -350,7 +474,7 @@ int dada2hip_derep_fastq(const char *path, int64_t chunk_reads, int32_t qual_off
   return DADA2HIP_ERR_RUNTIME;
 }
 
-int32_t dada2hip_derep_nuniques(const dada2hip_derep *d) { return d ? (int32_t)d->seqs.size() : 0; }
+int32_t dada2hip_derep_nuniques(const dada2hip_derep *d) { return d ? (int32_t)d->seq_ptrs.size() : 0; }
 int64_t dada2hip_derep_nreads(const dada2hip_derep *d) { return d ? d->nreads : 0; }
 int32_t dada2hip_derep_maxlen(const dada2hip_derep *d) { return d ? d->maxlen : 0; }
 const char *const *dada2hip_derep_seqs(const dada2hip_derep *d) { return d ? d->seq_ptrs.data() : nullptr; }
@@ -362,7 +486,7 @@ void dada2hip_derep_free(dada2hip_derep *d) { delete d; }
 int dada2hip_sample_from_derep(const dada2hip_derep *d, const uint8_t *priors, int32_t device, dada2hip_sample **out, char *errbuf,
                                size_t errlen) {
   if (!d) { set_err(errbuf, errlen, "dada2hip: no derep object"); return DADA2HIP_ERR_INPUT; }
-  return dada2hip_sample_create((int32_t)d->seqs.size(), d->seq_ptrs.data(), d->abund.data(), priors, d->quals.get(), d->maxlen, device,
+  return dada2hip_sample_create((int32_t)d->seq_ptrs.size(), d->seq_ptrs.data(), d->abund.data(), priors, d->quals.get(), d->maxlen, device,
                                 out, errbuf, errlen);
 }
 

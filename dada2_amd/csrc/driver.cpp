@@ -1531,6 +1531,18 @@ struct Run {
     // 512-thread blocks: half of every CU's registers stay free for the compare's kernels.
     v3_overlap = v3_on && !v2_align_commit && v2_nbuf >= 4 && K.v3_overlap != 0 && N >= 2 && (active_runs(s->device).load() <= 1 || K.v3_overlap == 1);
     v3_bs = K.v3_block == 512 ? 512 : (K.v3_block == 1024 ? 1024 : (v3_overlap ? 512 : 1024));
+    {
+      // A sample whose 512-thread blocks would sit on more than half of the CUs: the tail takes 3/8 of the CUs WHOLE instead
+      // (1024-thread blocks at 128 registers fill a CU's register file) and the compare's kernels have the other 5/8 to
+      // themselves at their full occupancy, rather than sharing every CU with a tail block.  10^6 uniques, same box, median of
+      // six: 137.8 vs 144.5 ms, 139.9 vs 143.9 ms, 147.4 vs 165.4 ms (profiles/r07s, r07t, r07u); 64 / 80 CUs are too few for the
+      // tail (150 / 145 ms), 160 / 192 leave the compare too little (149 / 182 ms).
+      const int ncu = tail_grid(1 << 30, s->device);
+      if (v3_overlap && K.v3_block == 0 && K.v3_grid == 0 && v3_grid > ncu / 2) {
+        v3_bs = 1024;
+        v3_grid = std::max(1, std::min((N + 8191) / 8192, 3 * ncu / 8));
+      }
+    }
     if (v3_on) { const int cap = tail_resident_max(s->device, v3_bs); if (cap > 0 && v3_grid > cap) v3_on = false; }
     if (!v3_on) v3_overlap = false;
     v3_pf_launched = 0; v3_pf_seen = 0; v3_pf_chains = 0;

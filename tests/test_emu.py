@@ -59,13 +59,17 @@ def run_cases(emu_lib, names, env=None, timeout=900):
                                  # the serial form of the persistent tail (no prefetch compares, 1024-thread blocks), and the overlap with a
                                  # tail that never waits inside the launch for a prefetch in flight (it leaves and comes back)
                                  {"DADA2HIP_V3_OVERLAP": "0", "DADA2HIP_V3_GRID": "2"}, {"DADA2HIP_V3_PF_WAIT_US": "0", "DADA2HIP_V3_GRID": "3"},
+                                 # the round's evaluation riding on EVERY shuffle call behind the commit's (void attempts, locks taken back),
+                                 # and never (a phase of its own: round 4's form); the default attempts behind calls that moved <= 16 uniques
+                                 {"DADA2HIP_V3_SPEC_MAX": "1000000", "DADA2HIP_V3_GRID": "4"}, {"DADA2HIP_V3_SPEC": "0", "DADA2HIP_V3_GRID": "3"},
                                  # the launch chains (DADA2HIP_V2_TAIL=chain: what a second sample on the same device runs on)
                                  {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_ALIGN": "commit"},
                                  {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_MOV_INLINE": "8"},
                                  {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_ALIGN": "commit", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_CHAIN": "1",
                                   "DADA2HIP_NODE_CAP": "1"}],
                          ids=["default", "classic-engine", "lane-kernel", "wide-kernel", "align-at-commit-grid2", "tail-grid3", "tail-grid5-pauses",
-                              "tail-grid2-ring1-nbuf1-grow", "tail-serial-grid2", "tail-overlap-no-wait-grid3", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
+                              "tail-grid2-ring1-nbuf1-grow", "tail-serial-grid2", "tail-overlap-no-wait-grid3", "tail-evaluate-on-every-call-grid4",
+                              "tail-evaluate-apart-grid3", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
                               "chains-commit-nbuf1-chain1-grow"])
 def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
     out = run_cases(emu_lib, ("sam1F_default", "sam1R_default") if not env else ("sam1F_default",), env)   # (CPU suite budget: both only once)

@@ -239,9 +239,15 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V3_PF_GATE_US": "0"},
     {"DADA2HIP_V3_PF_SYNC": "1", "DADA2HIP_V3_GRID": "5"},
     {"DADA2HIP_V3_PF_WAIT_US": "0", "DADA2HIP_V3_PF_EARLY": "0", "DADA2HIP_V2_NBUF": "4"},
+    # ... the round's evaluation on every shuffle call behind the commit's (void attempts: rewritten p-values, locks taken back, the
+    # candidate list emptied), and as a phase of its own (round 4's form); the default attempts behind calls that moved <= 16 uniques
+    {"DADA2HIP_V3_SPEC_MAX": "1000000000"},
+    {"DADA2HIP_V3_SPEC_MAX": "1000000000", "DADA2HIP_V3_GRID": "6", "DADA2HIP_V3_OVERLAP": "0"},
+    {"DADA2HIP_V3_SPEC": "0"},
 ], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph",
         "tail-grid7-pauses-ring2-fcap", "chains", "chains-chain1-biglists", "chains-nolite-commit",
-        "tail-serial", "overlap-host-launched", "overlap-sync-grid5", "overlap-leave-at-once-nbuf4"])
+        "tail-serial", "overlap-host-launched", "overlap-sync-grid5", "overlap-leave-at-once-nbuf4",
+        "evaluate-on-every-call", "evaluate-on-every-call-grid6-serial", "evaluate-apart"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
     20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""

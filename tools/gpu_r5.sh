@@ -35,6 +35,7 @@ for s in $STEPS; do
              echo "$s done" >> $OUT/steps.log ;;
     variants) for v in ${VARIANTS:-v0 v1 v2}; do echo "== $v" >> $OUT/variants.jsonl; L=$ROOT/dada2_amd/libdada2hip_$v.so; [ "$v" = base ] && L=$ROOT/dada2_amd/libdada2hip.so; DADA2HIP_LIB=$L timeout 300 python tools/sweep_env.py --config 3 --reps 3 --list "${SWEEPV:-}" >> $OUT/variants.jsonl 2>> $OUT/variants.err; done; echo "variants rc=$?" >> $OUT/steps.log; cut -c1-900 $OUT/variants.jsonl ;;
     summary3) DADA2HIP_V2_SUMMARY=1 timeout 600 python tools/sweep_env.py --config 3 --reps 2 --list "${SWEEP3:-DADA2HIP_V3_OVERLAP=0}" > $OUT/summary_cfg3.jsonl 2> $OUT/summary_cfg3.err; echo "summary3 rc=$?" >> $OUT/steps.log; cut -c1-1100 $OUT/summary_cfg3.jsonl; grep "^\[v3\]" $OUT/summary_cfg3.err | cut -c1-400 | tail -24 ;;
+    derep)   DADA2HIP_DEREP_TIMES=1 timeout 600 python tools/bench_derep.py ${DEREP_N:-1200000} 250 > $OUT/derep.json 2> $OUT/derep.err; echo "derep rc=$?" >> $OUT/steps.log; cut -c1-700 $OUT/derep.json; grep "^\[derep\]" $OUT/derep.err ;;
     smoke)   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/steps.log; tail -3 $OUT/smoke.log ;;
   esac
   echo "$s took $(( $(date +%s) - t0 )) s" >> $OUT/steps.log
