@@ -28,6 +28,11 @@ if dbs:
     for n, c, tot, avg, pct in rows:
         L.append(f"| `{short(n)}` | {c} | {tot / 1e3:.3f} | {avg:.2f} | {pct:.2f} |")
     L.append("")
+    if any("k2_pf_gate" in n for n, *_ in rows):
+        L += ["(`k2_pf_gate` is ONE lane that waits on the second stream for the persistent tail's next plan - the first kernel of a "
+              "prefetch compare's chain, enqueued one plan ahead, DESIGN.md 5c: its duration is waiting, not work, and it runs beside "
+              "`k3_tail`, whose own durations include its barrier waits.  The percentages are of the summed kernel time of two streams, "
+              "not of wall time.)", ""]
     # The per-round screen / NW kernels are also launched speculatively behind k_auto_birth, before the host has seen the
     # bud decision; when no birth was applied on the device those launches find nothing to do and return in a few us.
     # bench.py's HIP-event averages exclude them, so the comparable rocprofv3 average is over the working launches.
