@@ -34,6 +34,7 @@
  *   DADA2HIP_NW_KERNEL=lane|coop|wide  force one aligner family;  DADA2HIP_AD_HOMO=0  homopolymer gaps on the lane kernels
  *   DADA2HIP_WAIT=block, DADA2HIP_WAIT_TIMEOUT_S=<s>   sleep instead of spin while waiting; bound of every device wait
  *   DADA2HIP_HOST_THREADS=<n>, DADA2HIP_ALLOC_CACHE=0, DADA2HIP_ALLOC_CACHE_GB=<n>   marshalling pool, allocation cache
+ *   DADA2HIP_DEREP_INFLATE=zlib        dada2hip_derep_fastq: .gz files through zlib's streaming inflate even where libdeflate is installed
  *   DADA2HIP_PROFILE=1, DADA2HIP_V2_SUMMARY, DADA2HIP_V2_DEBUG   per-launch device times in the stats; traces on stderr
  * Test / tuning knobs (sizes of rings and grids, forced growth paths, injected failures) are listed with their meaning in
  * knobs.h and DESIGN.md §10b; they are not part of the interface.
