@@ -53,11 +53,20 @@ def build(force=False):
     shutil.copy(os.path.join(HERE, "gcn.h"), os.path.join(OUT, "csrc", "gcn.h"))
     shutil.copy(os.path.join(ROOT, "include", "dada2hip.h"), os.path.join(OUT, "include", "dada2hip.h"))
     tus = ["kernels.hip", "tail.hip", "driver.cpp", "derep.cpp", "merge.cpp", "hostsimd.cpp"]
-    cmd = [CXX, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-I", HERE, "-o", lib]
-    for t in tus:
-        cmd += ["-x", "c++", os.path.join(OUT, "csrc", t)]
-    cmd += ["-x", "c++", os.path.join(HERE, "emu.cpp"), "-lz", "-lpthread"]
-    subprocess.check_call(cmd)
+    # one compiler process per translation unit, side by side (kernels.hip alone is two thirds of the work), then the link
+    opt = os.environ.get("EMU_OPT", "-O1")
+    base = [CXX, "-std=c++17", opt, "-g", "-fPIC", "-ffp-contract=off", "-w", "-I", HERE, "-x", "c++", "-c"]
+    jobs = []
+    objs = []
+    for t in tus + ["emu.cpp"]:
+        src = os.path.join(HERE, t) if t == "emu.cpp" else os.path.join(OUT, "csrc", t)
+        obj = os.path.join(OUT, os.path.splitext(t)[0] + ".o")
+        objs.append(obj)
+        jobs.append((t, subprocess.Popen(base + [src, "-o", obj])))
+    bad = [t for t, j in jobs if j.wait() != 0]
+    if bad:
+        raise RuntimeError("emulator build failed: " + ", ".join(bad))
+    subprocess.check_call([CXX, "-shared", "-o", lib] + objs + ["-lz", "-lpthread"])
     return lib
 
 

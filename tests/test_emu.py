@@ -248,14 +248,15 @@ HOOKS_CODE = (
 #  one-block default)
 ENGINE_ENVS = [{"DADA2HIP_V3_GRID": "3"}, {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_ENGINE": "classic"}]
 ENGINE_IDS = ["persistent-tail-grid3", "chains", "classic-engine"]
+ENGINE_ABORT_POLLS = [(1, 4), (4,), (1,)]   # (the CPU suite's budget: both polls on the persistent tail, one each on the others)
 
 
-@pytest.mark.parametrize("env", ENGINE_ENVS, ids=ENGINE_IDS)
-def test_emulated_abort_hook_and_verbose_log_on_every_engine(emu_lib, env):
+@pytest.mark.parametrize("env,polls", list(zip(ENGINE_ENVS, ENGINE_ABORT_POLLS)), ids=ENGINE_IDS)
+def test_emulated_abort_hook_and_verbose_log_on_every_engine(emu_lib, env, polls):
     """dada2hip_hooks (Rcpp::checkUserInterrupt / the verbose Rprintfs, src/Rmain.cpp:317-333): a run aborted at its first and
     fourth round returns DADA2HIP_ERR_ABORTED with launches still queued, the next run in the same process equals the golden; the
     log carries one line per birth and the reference's nalign / nshroud."""
-    code = HOOKS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib, (1, 4))
+    code = HOOKS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib, polls)
     e = dict(os.environ)
     e.update(env)
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
