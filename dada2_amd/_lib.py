@@ -42,10 +42,11 @@ class CStats(C.Structure):
         ("pf_compares", C.c_uint64), ("pf_hits", C.c_uint64), ("pf_waits", C.c_uint64), ("pf_exits", C.c_uint64),
         ("pf_centres", C.c_uint64), ("tail_threads", C.c_uint32), ("overlap_on", C.c_uint32),
         ("dev_ms_pf_screen", C.c_double), ("dev_ms_pf_nw", C.c_double),
+        ("tail_xcd_barrier", C.c_uint32), ("reserved2", C.c_uint32),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
 
 # dada2hip_shard (include/dada2hip.h): rank / world + the collective the library calls at its exchange points

@@ -1414,6 +1414,9 @@ struct Run {
     if (K.v3_ring > 0) E2.ring_limit = std::min(RING2, K.v3_ring);                     // test knob: a host that lags
     E2.fail_ordinal = K.v3_fail_entry > 0 ? K.v3_fail_entry : 0;
     E2.spec_eval = K.v3_spec != 0 ? 1 : 0;
+    // grid barriers inside a persistent launch: XCD-hierarchical from 48 blocks on (rounds3.inc.hip::grid_sync; a small grid is
+    // faster on the flat one).  (v3_grid is v3_setup's, which runs in front of every bind)
+    E2.xbar = K.v3_xbar >= 0 ? K.v3_xbar : (v3_grid >= 48 ? 1 : 0);
     // (behind a call that moved many uniques the next one mostly moves some too, and a void attempt costs what a standing one
     //  saves - 10^6 uniques: tail 72.7 ms without, 71.1 / 71.7 / 72.6 / 74.5 / 76.9 ms at <= 8 / 32 / 128 / 1024 / always, profiles/r07v)
     E2.spec_max_prev = K.v3_spec_max >= 0 ? K.v3_spec_max : 16;
@@ -1532,15 +1535,16 @@ struct Run {
     v3_overlap = v3_on && !v2_align_commit && v2_nbuf >= 4 && K.v3_overlap != 0 && N >= 2 && (active_runs(s->device).load() <= 1 || K.v3_overlap == 1);
     v3_bs = K.v3_block == 512 ? 512 : (K.v3_block == 1024 ? 1024 : (v3_overlap ? 512 : 1024));
     {
-      // A sample whose 512-thread blocks would sit on more than half of the CUs: the tail takes 3/8 of the CUs WHOLE instead
-      // (1024-thread blocks at 128 registers fill a CU's register file) and the compare's kernels have the other 5/8 to
-      // themselves at their full occupancy, rather than sharing every CU with a tail block.  10^6 uniques, same box, median of
-      // six: 137.8 vs 144.5 ms, 139.9 vs 143.9 ms, 147.4 vs 165.4 ms (profiles/r07s, r07t, r07u); 64 / 80 CUs are too few for the
-      // tail (150 / 145 ms), 160 / 192 leave the compare too little (149 / 182 ms).
+      // A sample whose 512-thread blocks would sit on more than half of the CUs: the tail takes HALF of the CUs WHOLE instead
+      // (1024-thread blocks at 128 registers fill a CU's register file) and the compare's kernels have the other half to
+      // themselves at their full occupancy, rather than sharing every CU with a tail block.  10^6 uniques, one box, median of
+      // nine with the XCD-hierarchical barrier: 128 x 1024 135.0-136.5 ms, 245 x 512 136.5-137.4, 96 x 1024 139.3-141.6
+      // (profiles/r08b); with the flat barrier 96 x 1024 led (137.8 vs 144.5 for 245 x 512: r07s, r07t); 64 / 80 CUs are too few
+      // for the tail (150 / 145 ms), 160 / 192 leave the compare too little (149 / 182 ms).
       const int ncu = tail_grid(1 << 30, s->device);
       if (v3_overlap && K.v3_block == 0 && K.v3_grid == 0 && v3_grid > ncu / 2) {
         v3_bs = 1024;
-        v3_grid = std::max(1, std::min((N + 8191) / 8192, 3 * ncu / 8));
+        v3_grid = std::max(1, std::min((N + 8191) / 8192, ncu / 2));
       }
     }
     if (v3_on) { const int cap = tail_resident_max(s->device, v3_bs); if (cap > 0 && v3_grid > cap) v3_on = false; }
@@ -1871,6 +1875,7 @@ struct Run {
         fprintf(stderr, "\n");
       }
     }
+    st.tail_xcd_barrier = (E2.xbar && v3_grid > 1) ? 1u : 0u;
     st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid; st.tail_threads = (uint32_t)v3_bs;
     if (knobs().v2_summary && v3_overlap)
       fprintf(stderr, "[v3] overlap: prefetch compares %ld in %ld chains (centres %d)  rounds served from a prefetched batch %d  waits inside the launch %d  launches left for one %d  threads per block %d\n",

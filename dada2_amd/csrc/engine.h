@@ -448,6 +448,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   volatile int32_t *hcons;                          // pinned host word: result blocks the host has finished with
   volatile int32_t *hexit;                          // pinned host word: ordinal of the last k3_tail launch that has ended
   unsigned long long *ktime;                        // [KT_N] phase clocks of block 0 (DADA2HIP_PROFILE=1), else nullptr
+  int32_t xbar;                                     // 1: XCD-hierarchical barriers inside a launch (PSync; DADA2HIP_V3_XBAR, default: from 48 blocks on)
   int32_t spec_max_prev;                            // ... when the call before moved at most this many uniques (DADA2HIP_V3_SPEC_MAX)
   int32_t spec_eval;                                // 1: the shuffle calls behind the commit's carry the round's evaluation (shuffle_body<.., SPEC>; DADA2HIP_V3_SPEC)
   int32_t fail_ordinal;                             // test knob (DADA2HIP_V3_FAIL_ENTRY): the k3_tail launch of this ordinal fails its entry barrier (0: none)
@@ -473,10 +474,17 @@ struct PfSync {
 
 // Grid barrier of the persistent tail kernel: one monotonic arrival counter and one generation word, each on a cache line of
 // its own (rounds3.inc.hip).  Zeroed when a run starts; a launch continues where the previous one left them.
+// From 48 blocks on the barriers INSIDE a launch are XCD-hierarchical (Eng2::xbar; the guide's barrier-xcd): the blocks are grouped
+// by the XCC they run on (hardware register, not blockIdx), each group has an arrival counter and a generation word of its own,
+// and only a group's last arriver writes the XCC's L2 back and arrives on `top`.  These words are per launch: the entry barrier
+// (always the flat one) counts the blocks of each XCC in xcount, and its last arriver turns that into xn / ngrp and clears the rest.
 struct PSync {
   uint32_t arrive, pad0[31];
   uint32_t gen, pad1[31];
   uint32_t fail, pad2[31];
+  uint32_t top, pad3[31];
+  uint32_t ngrp, pad4[31];
+  uint32_t xarr[8][32], xgen[8][32], xcount[8][32], xn[8][32];
 };
 enum { KT_S0 = 0, KT_S0_BAR, KT_SL, KT_SL_BAR, KT_P, KT_P_BAR, KT_BIRTH, KT_PUBLISH, KT_ROUNDS, KT_LEVELS, KT_LAUNCH, KT_RELEASE, KT_SUB_LAST = 14, KT_SUB = 16, KT_N = 80 };
 

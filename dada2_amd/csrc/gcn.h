@@ -78,6 +78,8 @@ static __device__ __forceinline__ uint32_t gcn_load_agent(const uint32_t *p) { r
 static __device__ __forceinline__ void gcn_store_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static __device__ __forceinline__ uint32_t gcn_add_agent(uint32_t *p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static __device__ __forceinline__ int32_t gcn_load_system(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// the XCC (XCD) this wave runs on, 0-7
+static __device__ __forceinline__ int gcn_xcc_id() { int x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x)); return x & 7; }
 // wave priority 3 (s_setprio): a latency-bound kernel sharing its CUs with throughput kernels issues ahead of them
 static __device__ __forceinline__ void gcn_raise_priority() { __builtin_amdgcn_s_setprio(3); }
 // what a polling lane does between two looks at a word another workgroup (or the host) will write

@@ -30,7 +30,11 @@ struct TailLds {
   ShufLds<BS> sh;                                       // (both at once: a shuffle call after the commit's also evaluates, shuffle_body<.., SPEC>)
   PupdLds<BS> pu;
   int last, ok;
+  int xtmp[8];
+  int xcc, xn, ngrp;                                    // XCD-hierarchical barriers: this block's XCC, the launch's blocks on it, XCCs in use
 };
+// the XCD-hierarchical barriers' state of a launch (engine.h, PSync): which of them a barrier call uses
+struct XBar { int on; uint32_t epoch; };
 
 // code: TAIL_FAIL_ENTRY = the launch's entry barrier (not every block became resident: nothing has changed yet, the host sends the
 // run to the launch chains), TAIL_FAIL_LATE = a barrier inside a round (the run is lost)
@@ -43,12 +47,43 @@ static __device__ __forceinline__ void tail_fail(const Eng2 &E, uint32_t code) {
 
 // Grid barrier with a serial section: every block arrives; the last one runs `serial` (the whole block, block barriers allowed)
 // between its acquire and the release of the others.  Returns false when the wait ran into its bound (every block then leaves).
+//
+// xb (XBar::on): the XCD-hierarchical form (MI355X_MICROARCH.md, barrier-xcd; tools/micro/grid_barrier.hip measured both on this
+// device: 7.1 -> 3.7 us at 245 blocks, 3.4 -> 2.5 at 96, and 1.8 -> 2.0 at 25, which is why small grids keep the flat one).  The
+// blocks of one XCC share its L2: every wave has drained its stores into it before its block arrives on the XCC's counter, so ONE
+// write-back by the XCC's last arriver covers them all (245 blocks each writing an L2 back that 30 others are writing back too
+// was most of the flat barrier's time); that block arrives on the top counter, the last one there runs `serial` and then bumps
+// every XCC's generation word.  Every block acquires behind its wait, as before.
 template <int BS, typename F>
-static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, uint32_t &epoch, int G, F &&serial, uint32_t fail_code = TAIL_FAIL_LATE) {
+static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, uint32_t &epoch, int G, F &&serial, uint32_t fail_code = TAIL_FAIL_LATE,
+                                                 XBar *xb = nullptr) {
   PSync *ps = E.psync;
   gcn_drain_stores();                                   // every wave: its own stores have left the CU
   __syncthreads();
-  if (threadIdx.x == 0) {
+  const bool xmode = xb != nullptr && xb->on != 0 && G > 1;
+  if (threadIdx.x == 0 && xmode) {
+    int last = 0, ok = 1;
+    const uint32_t e1 = xb->epoch + 1u;
+    const int x = L.xcc;
+    const uint32_t t = gcn_add_agent(&ps->xarr[x][0], 1u);
+    if (t == e1 * (uint32_t)L.xn - 1u) {                // the XCC's last arriver: its L2 holds the stores of all the XCC's blocks
+      gcn_release_agent();
+      const uint32_t t2 = gcn_add_agent(&ps->top, 1u);
+      last = t2 == e1 * (uint32_t)L.ngrp - 1u;
+    }
+    if (!last) {
+      const unsigned long long t0 = gcn_wall_clock();
+      for (unsigned n = 1;; n++) {
+        if ((int32_t)(gcn_load_agent(&ps->xgen[x][0]) - e1) >= 0) break;
+        gcn_poll_pause();
+        if ((n & 63u) == 0u && (gcn_load_agent(&ps->fail) != 0u || gcn_wall_clock() - t0 > (unsigned long long)(GRID_WAIT_S * GCN_WALL_HZ))) { ok = 0; break; }
+      }
+      if (!ok) tail_fail(E, fail_code);
+    }
+    gcn_acquire_agent();
+    L.last = last; L.ok = ok;
+  }
+  if (threadIdx.x == 0 && !xmode) {
     int last = 1, ok = 1;
     if (G > 1) {
       const bool tm = E.ktime != nullptr && blockIdx.x == 0;
@@ -81,7 +116,11 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
     serial();
     gcn_drain_stores();
     __syncthreads();                                    // the whole block is through the serial section
-    if (G > 1) {
+    if (xmode) {
+      if (threadIdx.x == 0) gcn_release_agent();
+      __syncthreads();
+      if (threadIdx.x < 8) gcn_store_agent(&ps->xgen[threadIdx.x][0], xb->epoch + 1u);   // (the write-back is done: lanes of the same wave)
+    } else if (G > 1) {
       if (threadIdx.x == 0) { gcn_release_agent(); gcn_store_agent(&ps->gen, epoch + 1u); }
     } else {
       // one block: its own waves read next what the serial section just wrote (the control block, the new centre's state)
@@ -89,7 +128,7 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
       __syncthreads();
     }
   }
-  epoch++;
+  if (xmode) xb->epoch++; else epoch++;
   return true;
 }
 
@@ -112,9 +151,30 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
     return;
   }
   uint32_t epoch = E.psync->gen;                         // barriers completed by earlier launches (arrive == gen * G between launches)
+  XBar xb{E.xbar && G > 1 ? 1 : 0, 0u};
+  if (xb.on && threadIdx.x == 0) { L.xcc = gcn_xcc_id(); gcn_add_agent(&E.psync->xcount[L.xcc][0], 1u); }   // (counted before the entry barrier)
   // entry: every block is resident before any state changes, and ONE block decides whether the host's ring takes the first
   // result block of this launch (the host may still be reading the slot it goes to)
   if (!grid_sync<BS>(E, L, epoch, G, [&]() {
+        if (xb.on && threadIdx.x < 8) {
+          // every block of the launch has counted itself on its XCC: the launch's group sizes, and a clean slate for its barriers
+          PSync *ps = E.psync;
+          const uint32_t n = gcn_load_agent(&ps->xcount[threadIdx.x][0]);
+          gcn_store_agent(&ps->xn[threadIdx.x][0], n);
+          gcn_store_agent(&ps->xcount[threadIdx.x][0], 0u);
+          gcn_store_agent(&ps->xarr[threadIdx.x][0], 0u);
+          gcn_store_agent(&ps->xgen[threadIdx.x][0], 0u);
+          L.xtmp[threadIdx.x] = (int)n;
+        }
+        if (xb.on) {
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            uint32_t ng = 0;
+            for (int g = 0; g < 8; g++) ng += L.xtmp[g] != 0;
+            gcn_store_agent(&E.psync->ngrp, ng);
+            gcn_store_agent(&E.psync->top, 0u);
+          }
+        }
         if (threadIdx.x == 0) {
           const int seq = ctl->pub_seq + 1;
           int ex = 0;
@@ -141,6 +201,10 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
     if (blockIdx.x == 0 && threadIdx.x == 0) *E.hexit = ordinal;
     return;
   }
+  if (xb.on) {
+    if (threadIdx.x == 0) { L.xn = (int)gcn_load_agent(&E.psync->xn[L.xcc][0]); L.ngrp = (int)gcn_load_agent(&E.psync->ngrp); }
+    __syncthreads();
+  }
   KT_LAP(KT_LAUNCH);
   for (int rnd = 0;; rnd++) {
     const int ring = ctl->pub_seq % RING2;
@@ -151,7 +215,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       // ---- commit of the round's cached comparisons + b_shuffle2 until a call moves nothing (Rmain.cpp:320-325) ----
       shuffle_body<true, BS>(E, L.sh, 0, 0, E.movers, out);
       KT_LAP(KT_S0);
-      if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
+      if (!grid_sync<BS>(E, L, epoch, G, []() {}, TAIL_FAIL_LATE, &xb)) return;
       KT_LAP(KT_S0_BAR);
       level = 1;
     }
@@ -164,7 +228,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       if (more && !attempt) {
         shuffle_body<false, BS>(E, L.sh, level, moved, mv, out);
         KT_LAP(KT_SL);
-        if (!grid_sync<BS>(E, L, epoch, G, []() {})) return;
+        if (!grid_sync<BS>(E, L, epoch, G, []() {}, TAIL_FAIL_LATE, &xb)) return;
         KT_LAP(KT_SL_BAR);
         moved += out->cnt[level];
         level++;
@@ -188,7 +252,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
               ctl->pub_seq = ctl->pub_seq + 1;            // (the others find the NEXT round's block through it)
               if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
             }
-          }))
+          }, TAIL_FAIL_LATE, &xb))
         return;
       if (!more) { KT_LAP(KT_P_BAR); break; }
       KT_LAP(KT_SL_BAR);

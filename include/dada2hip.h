@@ -127,6 +127,7 @@ typedef struct dada2hip_stats {
   uint64_t pf_compares, pf_hits, pf_waits, pf_exits, pf_centres;
   uint32_t tail_threads, overlap_on;
   double dev_ms_pf_screen, dev_ms_pf_nw;
+  uint32_t tail_xcd_barrier, reserved2;   /* 1: the persistent launches of the run used the XCD-hierarchical grid barrier */
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------

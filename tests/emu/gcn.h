@@ -37,6 +37,7 @@ static inline void gcn_store_agent(uint32_t *p, uint32_t v) { *(volatile uint32_
 static inline uint32_t gcn_add_agent(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 static inline int32_t gcn_load_system(const int32_t *p) { return *(const volatile int32_t *)p; }
 static inline void gcn_raise_priority() {}
+static inline int gcn_xcc_id() { return (int)(((blockIdx.x * 3u) % 7u) % 3u); }   // (uneven groups, not blockIdx order: what the barrier must not depend on)
 static inline void gcn_poll_pause() { emu::grid_yield(); }   // the other blocks of the launch run while this lane waits
 // a counter instead of a clock: every look at it is one "tick", so a wait that can never end still runs into its bound
 static inline unsigned long long gcn_wall_clock() { static unsigned long long t = 0; return t += 64; }

@@ -40,7 +40,7 @@ def run_cases(emu_lib, names, env=None, timeout=900):
         "    got = api.dada_uniques(d.seqs, d.abundances, pri, err, d.quals, o)\n"
         "    assert_results_equal(got, exp, check_birth_from=pri is None)\n"
         "    st = got.stats\n"
-        "    print('ok', name, got.nclust, st['nnw'], st['ngapless'], st['nshroud'])\n"
+        "    print('ok', name, got.nclust, st['nnw'], st['ngapless'], st['nshroud'], 'xcd-barrier' if st['tail_xcd_barrier'] else 'flat-barrier')\n"
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib, tuple(names))
     e = dict(os.environ)
     e.update(env or {})
@@ -62,6 +62,9 @@ def run_cases(emu_lib, names, env=None, timeout=900):
                                  # the round's evaluation riding on EVERY shuffle call behind the commit's (void attempts, locks taken back),
                                  # and never (a phase of its own: round 4's form); the default attempts behind calls that moved <= 16 uniques
                                  {"DADA2HIP_V3_SPEC_MAX": "1000000", "DADA2HIP_V3_GRID": "4"}, {"DADA2HIP_V3_SPEC": "0", "DADA2HIP_V3_GRID": "3"},
+                                 # the XCD-hierarchical grid barrier (the default from 48 blocks on) on seven blocks in uneven groups: the
+                                 # emulated XCC ids are not in block order and one XCC stays empty
+                                 {"DADA2HIP_V3_XBAR": "1", "DADA2HIP_V3_GRID": "7"}, {"DADA2HIP_V3_XBAR": "1", "DADA2HIP_V3_GRID": "5", "DADA2HIP_V2_MOV_INLINE": "8", "DADA2HIP_V3_RING": "2"},
                                  # the launch chains (DADA2HIP_V2_TAIL=chain: what a second sample on the same device runs on)
                                  {"DADA2HIP_V2_TAIL": "chain"}, {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_ALIGN": "commit"},
                                  {"DADA2HIP_V2_TAIL": "chain", "DADA2HIP_V2_LITE": "0", "DADA2HIP_V2_NBUF": "1", "DADA2HIP_V2_MOV_INLINE": "8"},
@@ -69,11 +72,12 @@ def run_cases(emu_lib, names, env=None, timeout=900):
                                   "DADA2HIP_NODE_CAP": "1"}],
                          ids=["default", "classic-engine", "lane-kernel", "wide-kernel", "align-at-commit-grid2", "tail-grid3", "tail-grid5-pauses",
                               "tail-grid2-ring1-nbuf1-grow", "tail-serial-grid2", "tail-overlap-no-wait-grid3", "tail-evaluate-on-every-call-grid4",
-                              "tail-evaluate-apart-grid3", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
+                              "tail-evaluate-apart-grid3", "tail-xcd-barrier-grid7", "tail-xcd-barrier-grid5-pauses-ring2", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
                               "chains-commit-nbuf1-chain1-grow"])
 def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
     out = run_cases(emu_lib, ("sam1F_default", "sam1R_default") if not env else ("sam1F_default",), env)   # (CPU suite budget: both only once)
     assert "ok sam1F_default 10 " in out
+    assert ("xcd-barrier" in out) == (env.get("DADA2HIP_V3_XBAR") == "1")   # (the small grids of these cases take the flat barrier unless told otherwise)
 
 
 def test_emulated_long_read_band32_case(emu_lib):

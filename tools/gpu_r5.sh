@@ -17,6 +17,7 @@ for s in $STEPS; do
     tests)   timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=20 > $OUT/gputests.log 2>&1; echo "tests rc=$?" >> $OUT/steps.log; tail -8 $OUT/gputests.log ;;
     sweep3)  timeout 600 python tools/sweep_env.py --config 3 --reps ${REPS3:-3} --list "${SWEEP3:-DADA2HIP_V3_BLOCK=512;DADA2HIP_V2_TAIL=chain}" > $OUT/sweep_cfg3.jsonl 2> $OUT/sweep_cfg3.err; echo "sweep3 rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/sweep_cfg3.jsonl; tail -3 $OUT/sweep_cfg3.err ;;
     sweep2)  timeout 300 python tools/sweep_env.py --config 2 --reps 5 --list "${SWEEP2:-DADA2HIP_V3_BLOCK=512;DADA2HIP_V2_TAIL=chain}" > $OUT/sweep_cfg2.jsonl 2> $OUT/sweep_cfg2.err; echo "sweep2 rc=$?" >> $OUT/steps.log; cut -c1-600 $OUT/sweep_cfg2.jsonl; tail -3 $OUT/sweep_cfg2.err ;;
+    sweepu)  timeout 600 python tools/sweep_env.py --config 3 --uniques ${SWEEP_UNIQUES:-250000} --reps ${REPS3:-5} --list "${SWEEPU:-DADA2HIP_V3_XBAR=0}" > $OUT/sweep_u${SWEEP_UNIQUES:-250000}.jsonl 2> $OUT/sweep_u.err; echo "sweepu rc=$?" >> $OUT/steps.log; cut -c1-400 $OUT/sweep_u${SWEEP_UNIQUES:-250000}.jsonl; tail -3 $OUT/sweep_u.err ;;
     bench3q) timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS:-} > $OUT/bench_cfg3_quick.json 2> $OUT/bench_cfg3_quick.err; echo "bench3q rc=$?" >> $OUT/steps.log; cut -c1-1500 $OUT/bench_cfg3_quick.json; tail -3 $OUT/bench_cfg3_quick.err ;;
     bench3)  timeout 1200 python bench.py ${BENCH_ARGS:-} > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err; echo "bench3 rc=$?" >> $OUT/steps.log; cut -c1-1500 $OUT/bench_cfg3.json; tail -3 $OUT/bench_cfg3.err ;;
     bench2|bench4|bench5)
