@@ -43,11 +43,17 @@ def main():
         os.environ.update(kv)
         os.environ["DADA2HIP_PROFILE"] = "0"
         walls = []
+        per_pass = []          # what the library itself timed in each pass (a slow pass: where?)
         res = None
         for _ in range(a.reps):
             t0 = time.perf_counter()
             res = s.run(err, opts)
             walls.append((time.perf_counter() - t0) * 1e3)
+            rs = res.stats
+            per_pass.append({"wall": round(walls[-1], 1), "total": round(rs["ms_total"], 1), "bookkeep": round(rs["ms_bookkeep"], 1), "wait": round(rs["ms_wait_device"], 1),
+                             "replay": round(rs["ms_replay"], 1), "enqueue": round(rs["ms_enqueue"], 1), "final": round(rs["ms_final"], 1),
+                             "launches": int(rs["tail_launches"]), "pauses": int(rs["tail_pauses"]), "pf_waits": int(rs["pf_waits"]), "pf_exits": int(rs["pf_exits"]),
+                             "compares": int(rs["batch_compares"]), "pf": int(rs["pf_compares"])})
         os.environ["DADA2HIP_PROFILE"] = "1"
         prof = s.run(err, opts)
         st = prof.stats
@@ -63,7 +69,8 @@ def main():
                           "overlap": {k: int(st[k]) for k in ("pf_compares", "pf_centres", "pf_hits", "pf_waits", "pf_exits", "batch_compares", "tail_launches")},
                           "aligned_in_vain_frac": round(1.0 - st["nnw"] / max(1, st["nnw_run"] + (st["nnw"] - st["nnw_run"] if st["nnw_run"] == 0 else 0)), 3) if False else None,
                           "nnw": int(st["nnw"]), "nnw_run": int(st["nnw_run"]),
-                          "wait_device": round(st.get("ms_wait_device", 0), 1), "replay": round(st.get("ms_replay", 0), 1)}), flush=True)
+                          "wait_device": round(st.get("ms_wait_device", 0), 1), "replay": round(st.get("ms_replay", 0), 1),
+                          "per_pass": per_pass}), flush=True)
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
