@@ -232,3 +232,46 @@ def test_native_derep_feeds_a_resident_sample_without_a_host_copy(tmp_path):
     assert_results_equal(got, want)
     s.close()
     nd.close()
+
+
+def test_large_chunks_take_the_pool_sorts_and_batched_hashing(tmp_path, monkeypatch):
+    """Enough distinct reads in a chunk (> 65 536) that the chunk order and the abundance order go through the sample sort over the
+    host pool, several batches of records per chunk, the table grown several times - against the restatement, with two chunk sizes
+    (one chunk; a boundary inside the file), shared 20-nt prefixes (what a primer does to the leading bytes of every key) and reads
+    that are prefixes of other reads."""
+    monkeypatch.setenv("DADA2HIP_HOST_THREADS", "4")
+    rng = np.random.default_rng(77)
+    n = 90000
+    prefix = "ACGTTGCAAGGCTTAACCGT"
+    codes = rng.integers(0, 4, size=(n, 40), dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    body = lut[codes]
+    lens = rng.integers(25, 41, size=n)
+    seqs = [prefix + body[i, : lens[i]].tobytes().decode() for i in range(n)]
+    for i in range(0, n, 9):            # duplicates and prefixes of other reads
+        seqs[i] = seqs[(i * 7 + 3) % n]
+    for i in range(1, n, 1000):
+        seqs[i] = seqs[i - 1][:30]
+    quals = [bytes(rng.integers(40, 70, size=len(s)).astype(np.uint8)) for s in seqs]
+    p = tmp_path / "big.fastq"
+    write_fastq(p, seqs, quals)
+    want = dio.derep_from_reads(seqs, quals)
+    got = api.derep_fastq(str(p))
+    assert len(got.seqs) > 65536
+    assert_same(got, want)
+    assert_same(api.derep_fastq(str(p), n=70001), dio.derep_from_reads(seqs, quals, n=70001))
+
+
+def test_gzip_members_and_both_inflate_paths_agree(tmp_path, monkeypatch):
+    """A .gz made of several members (cat a.gz b.gz) is read through, as gzread does; the one-shot libdeflate path (where the
+    system has the library) and zlib's streaming inflate give the same object."""
+    seqs, quals = random_reads(21, 5000, zero_every=211)
+    a, b = tmp_path / "a.fastq.gz", tmp_path / "b.fastq.gz"
+    write_fastq(a, seqs[:2000], quals[:2000], gz=True)
+    write_fastq(b, seqs[2000:], quals[2000:], gz=True)
+    both = tmp_path / "both.fastq.gz"
+    both.write_bytes(a.read_bytes() + b.read_bytes())
+    want = dio.derep_from_reads(seqs, quals)
+    assert_same(api.derep_fastq(str(both)), want)
+    monkeypatch.setenv("DADA2HIP_DEREP_INFLATE", "zlib")
+    assert_same(api.derep_fastq(str(both)), want)
