@@ -1420,7 +1420,7 @@ struct Run {
     // (behind a call that moved many uniques the next one mostly moves some too, and a void attempt costs what a standing one
     //  saves - 10^6 uniques: tail 72.7 ms without, 71.1 / 71.7 / 72.6 / 74.5 / 76.9 ms at <= 8 / 32 / 128 / 1024 / always, profiles/r07v)
     E2.spec_max_prev = K.v3_spec_max >= 0 ? K.v3_spec_max : 16;
-    E2.pf_on = v3_overlap ? 1 : 0; E2.pf_min = 2;
+    E2.pf_on = v3_overlap ? 1 : 0; E2.pf_min = 2; E2.pf_plan = E2.pf_on;
     E2.pf_early = K.v3_pf_early >= 0 ? K.v3_pf_early : 4;
     E2.pf_sync = K.v3_pf_sync != 0 ? 1 : 0;
     E2.pf_ctl = v3_pfctl.p; E2.pf_blist_n = v3_pf_blistn.p; E2.pfsync = v3_pfsync.p;
@@ -1646,6 +1646,11 @@ struct Run {
     const int ev = ev_begin(EV_TAIL, profile_all);
     Eng2 Ek = E2;
     if (!profile_all) Ek.ktime = nullptr;
+    // (the rule of v3_setup - no prefetching beside another sample of this process - again for every launch: the other sample may
+    //  have arrived since.  Its kernels share the runtime's hardware queues with this run's second stream, and a tail spinning
+    //  for a compare queued behind them holds the device's persistent slot for nothing: configs[3] on one GPU 233 -> 603 ms
+    //  when the first sample of each wave happened to start alone, profiles/r08g)
+    Ek.pf_plan = (v3_overlap && (active_runs(s->device).load() <= 1 || knobs().v3_overlap == 1)) ? 1 : 0;
     launch3_tail(Ek, v3_grid, v3_bs, first, (int)(v3_enq + 1), s->h_reads[bi[0].center], stq);
     ev_end(ev);
     v3_rec.push_back(rec);

@@ -456,6 +456,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   //      kernels of the second stream get a copy of this block whose `ctl`, `C.tab8 / full / ord`, `blist / blist_n` and aligner
   //      scratch ARE these (so they run unchanged); the tail's planner fills pf_ctl and clears pf_blist_n ----
   int32_t pf_on;                                    // 1: the tail plans prefetch compares
+  int32_t pf_plan;                                  // 1: this LAUNCH may plan further prefetches (0: another sample of the process is in flight on the device now; what is planned already is still waited for and used)
   int32_t pf_min;                                   // fewest uncached candidates worth a prefetch pass
   int32_t pf_sync;                                  // measurement knob: wait for every prefetch at the next serial end (DADA2HIP_V3_PF_SYNC)
   int32_t pf_early;                                 // the next prefetch is planned when the rounds are this many positions into the batch BEFORE the one planned last (KB_MAX: only when they reach the last one)

@@ -994,7 +994,8 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
         // Time to plan the next prefetch (the second stream being free)?  When the rounds reach the batch planned last - or already
         // when they are pf_early positions into the one before it: a compare beside the tail takes longer than the rounds of one
         // batch, so it has to start before the batch in front of it is used up
-        const bool due = hb == ctl->last_bbuf || (hb == ctl->prev_bbuf && (hit % KB_MAX) >= E.pf_early);
+        // (... and only while the run has the device to itself: Eng2::pf_plan, per launch)
+        const bool due = E.pf_plan && (hb == ctl->last_bbuf || (hb == ctl->prev_bbuf && (hit % KB_MAX) >= E.pf_early));
         *s_trig = (due && (int32_t)(done - seq) >= 0) ? 1 : 0;
       }
     }
