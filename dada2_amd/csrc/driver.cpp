@@ -1430,7 +1430,13 @@ struct Run {
       E2.pf_wait_ticks = (unsigned long long)(us * 100.0);
       // the gate of a chain enqueued ahead of its plan (k2_pf_gate): plans come every millisecond or so while rounds run
       v3_pf_gate_on = K.v3_pf_gate_us != 0;
-      E2.pf_gate_ticks = (unsigned long long)((K.v3_pf_gate_us > 0 ? (double)K.v3_pf_gate_us : 500000.0) * 100.0);
+      // (5 ms: plans come every millisecond while rounds run, and a gate that gives up only sends its chain down the slower path -
+      //  the host launches it when it sees the plan.  The bound was 500 ms until the last hour of round 5: a waiting gate is a
+      //  kernel at the head of a hardware queue, and when the runtime has mapped the stream of the TAIL onto the same queue -
+      //  which it does, now and then, once two samples' streams exist - the tail's next launch waits for the gate that waits for
+      //  the tail's plan: configs[3] on one GPU read 234 ms or 574-1 250 ms, one sample of a slow run waiting 1 024 ms = two bounds,
+      //  profiles/r08k)
+      E2.pf_gate_ticks = (unsigned long long)((K.v3_pf_gate_us > 0 ? (double)K.v3_pf_gate_us : 5000.0) * 100.0);
     }
     E2.has_compare = 1;
     E2.align_at_commit = v2_align_commit ? 1 : 0;
@@ -1710,7 +1716,10 @@ struct Run {
     }
     // ONE chain ahead: the next plan's chain goes out once the chain in front of it has passed its gate (two gates in the
     // stream would wait for each other: the second plan cannot be made before the first compare is done)
-    if (v3_pf_gate_on && v3_pf_launched == v3_pf_seen && (v3_pf_seen == 0 || v3_pf_gate_result(v3_pf_seen) == 1)) v3_pf_enqueue(v3_pf_seen + 1);
+    // (... and not while another sample of the process is active: no plan will come - Eng2::pf_plan)
+    if (v3_pf_gate_on && (active_runs(s->device).load() <= 1 || knobs().v3_overlap == 1) && v3_pf_launched == v3_pf_seen &&
+        (v3_pf_seen == 0 || v3_pf_gate_result(v3_pf_seen) == 1))
+      v3_pf_enqueue(v3_pf_seen + 1);
     if (b.pf_wait > 0 && (long)b.pf_wait <= v3_pf_launched) D2_HIP(hipStreamWaitEvent(s->stream, v3_pf_ev[b.pf_wait & 3], 0));
   }
 
@@ -1775,7 +1784,7 @@ struct Run {
     auto t0 = clk::now();
     st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
     v3_rec.clear();
-    if (v3_overlap && v3_pf_gate_on) v3_pf_enqueue(1);         // the first prefetch compare's chain waits at its gate on the second stream
+    if (v3_overlap && v3_pf_gate_on && (active_runs(s->device).load() <= 1 || knobs().v3_overlap == 1)) v3_pf_enqueue(1);         // the first prefetch compare's chain waits at its gate on the second stream
     v3_enqueue(true);                                          // b_p_update after round 0 + the first b_bud (+ the rounds that follow)
     bool done = false;
     long n_halt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_pause = 0, n_blocks = 0;
