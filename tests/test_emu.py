@@ -20,10 +20,81 @@ CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 pytestmark = pytest.mark.skipif(not (os.path.exists(CXX) or shutil.which(CXX)), reason="no host clang++ for the emulator build")
 
 
+# ---- the emulator jobs of this module run SIDE BY SIDE --------------------------------------------------------------------
+# Every test here is one subprocess (the emulated library is opened in a process of its own) and the emulator is slow: one after
+# the other they were seven of the CPU suite's ten minutes.  When the first test asks for the library, every collected test of the
+# module that needs nothing but the library is called once "dry" - its body builds the command, _run records it and stops the
+# body - and the recorded commands are started on a small pool; the tests then find their result waiting.  A command that was
+# not recorded (a test with other fixtures, a second command of a test) simply runs when it is asked for.
+class _DryStop(Exception):
+    pass
+
+
+_DRY = None          # a list while test bodies are being called dry
+_POOL = None
+_FUTS = {}
+
+
+def _job_key(argv, env):
+    e = env if env is not None else os.environ
+    return (tuple(argv), tuple(sorted((k, v) for k, v in e.items() if k.startswith(("DADA2HIP_", "EMU_")))))
+
+
+def _spawn(argv, env, timeout):
+    return subprocess.run(argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _run(argv, env=None, capture_output=True, text=True, timeout=900):
+    global _POOL
+    if _DRY is not None:
+        _DRY.append((list(argv), None if env is None else dict(env), timeout))
+        raise _DryStop()
+    k = _job_key(argv, env)
+    if _POOL is None or k not in _FUTS:
+        return _spawn(argv, env, timeout)
+    return _FUTS.pop(k).result()
+
+
+def _prefetch(items, lib):
+    global _DRY, _POOL
+    if _POOL is not None or os.environ.get("EMU_SERIAL"):
+        return
+    me = sys.modules[__name__]
+    jobs = []
+    for it in items:
+        if getattr(it, "module", None) is not me or not hasattr(it, "obj"):
+            continue
+        params = dict(it.callspec.params) if hasattr(it, "callspec") else {}
+        if not set(it.fixturenames) - {"request"} <= {"emu_lib"} | set(params):
+            continue                                  # (tmp_path, the reference, ...: on demand)
+        kw = dict(params)
+        if "emu_lib" in it.fixturenames:
+            kw["emu_lib"] = lib
+        _DRY = []
+        try:
+            it.obj(**kw)
+        except _DryStop:
+            pass
+        except Exception:                             # noqa: BLE001  (whatever it is, the real call will show it)
+            pass
+        jobs += _DRY
+        _DRY = None
+    if len(jobs) < 2:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    _POOL = ThreadPoolExecutor(max_workers=max(2, min(6, (os.cpu_count() or 2) // 2)))
+    for argv, env, timeout in jobs:
+        k = _job_key(argv, env)
+        if k not in _FUTS:
+            _FUTS[k] = _POOL.submit(_spawn, argv, env, timeout)
+
+
 @pytest.fixture(scope="module")
-def emu_lib():
+def emu_lib(request):
     import build as emu_build
-    return emu_build.build()
+    lib = emu_build.build()
+    _prefetch(request.session.items, lib)
+    return lib
 
 
 def run_cases(emu_lib, names, env=None, timeout=900):
@@ -44,7 +115,7 @@ def run_cases(emu_lib, names, env=None, timeout=900):
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib, tuple(names))
     e = dict(os.environ)
     e.update(env or {})
-    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=timeout)
+    out = _run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0 and out.stdout.count("ok ") == len(names), out.stdout[-2000:] + out.stderr[-4000:]
     return out.stdout
 
@@ -112,12 +183,12 @@ def test_emulated_bimera_pair_quantities_both_kernels(emu_lib):
         "        assert np.array_equal(api.bimera_pairs(qs, ps, oo, max_shift=ms), cport.bimera_pairs(qs, ps, oo, max_shift=ms)), (oo, ms, kern)\n"
         "print('bimera pairs: ok')\n"
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "bimera pairs: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_emulated_bimera_table_and_nwvec_goldens(emu_lib):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_bimera.py")], capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, os.path.join(ROOT, "tools", "emu_bimera.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "bimera table goldens: ok" in out.stdout and "nwvec goldens: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -149,21 +220,21 @@ def test_emulated_homopolymer_rich_samples_on_the_anti_diagonal_kernel(emu_lib):
         "    assert got.stats['tail_launches'] > 0\n"
         "print('homopolymer samples: ok')\n"
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "homopolymer samples: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_emulated_exact_bud_ties_settled_on_the_device_or_the_host(emu_lib):
     """tests/helpers.zero_tie_sample: ties of b_bud's best key that k2_birth settles itself (first-slot members of partition 0,
     one candidate in the lowest partition) next to those it must leave to the host (moved members, several in one partition)."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_ties.py"), "1", "2"], capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, os.path.join(ROOT, "tools", "emu_ties.py"), "1", "2"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "zero ties: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_emulated_merge_pairs_goldens_with_packed_pairs(emu_lib):
     """dada2hip_merge_pairs on the emulated library: unbanded alignments on the lane kernel with a centre per work item (64
     unrelated pairs to a wave), rows equal to the goldens made with the reference's C_nwalign / C_eval_pair / C_pair_consensus."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_merge.py"), "1"], capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, os.path.join(ROOT, "tools", "emu_merge.py"), "1"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "merge goldens: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -187,7 +258,7 @@ def _seeded_through_emulator(emu_lib, cases, env=None, timeout=1500):
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib, list(cases))
     e = dict(os.environ)
     e.update(env or {})
-    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=timeout)
+    out = _run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0 and out.stdout.count("ok ") == len(cases), out.stdout[-2000:] + out.stderr[-4000:]
 
 
@@ -263,7 +334,7 @@ def test_emulated_abort_hook_and_verbose_log_on_every_engine(emu_lib, env, polls
     code = HOOKS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib, polls)
     e = dict(os.environ)
     e.update(env)
-    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "hooks: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -288,7 +359,7 @@ def test_emulated_entry_barrier_failure_continues_on_the_launch_chains(emu_lib, 
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
     e = dict(os.environ)
     e.update(env)
-    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "fallback: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -316,7 +387,7 @@ def test_emulated_prefetch_compares_under_the_tail_on_a_deeper_sample(emu_lib, e
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
     e = dict(os.environ)
     e.update(env)
-    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "prefetch: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -345,7 +416,7 @@ def test_emulated_run_without_the_persistent_slot_takes_the_chains_and_plans_no_
         ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
         e = dict(os.environ)
         e["EMU_PCI_ID"] = pci
-        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+        out = _run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "chains without the slot: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
     finally:
         fcntl.flock(lock, fcntl.LOCK_UN)
@@ -384,7 +455,7 @@ def test_emulated_nwvec_on_letters_outside_acgt_matches_the_reference(emu_lib, o
     """C_nwvec compares the strings' raw bytes (nwalign_vectorized.cpp:165): N, IUPAC codes, lower case, anything.  The device
     path renumbers each pair's letters (<= 16) into two 2-bit planes; every pair against the reference's own call on raw bytes."""
     code = NWVEC_LETTERS_CODE % (ROOT, os.path.join(ROOT, "tests"), True, emu_lib)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "nwvec letters: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -414,5 +485,5 @@ def test_emulated_quality_marshalling_vector_sweep_and_its_scalar_redo(emu_lib):
         "assert_results_equal(got, cport.dada_uniques(d.seqs, d.abundances, pri, err, q, o))\n"
         "print('quality marshalling: ok')\n"
     ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    out = _run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "quality marshalling: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
