@@ -43,6 +43,7 @@ class CStats(C.Structure):
         ("pf_centres", C.c_uint64), ("tail_threads", C.c_uint32), ("overlap_on", C.c_uint32),
         ("dev_ms_pf_screen", C.c_double), ("dev_ms_pf_nw", C.c_double),
         ("tail_xcd_barrier", C.c_uint32), ("reserved2", C.c_uint32),
+        ("ms_setup", C.c_double), ("ms_round0", C.c_double), ("tail_ms_pf_wait", C.c_double), ("tail_ms_pf_plan", C.c_double),
     ]
 
     def as_dict(self):

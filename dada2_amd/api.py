@@ -531,14 +531,17 @@ def dada(dereps, err=None, *, self_consist=False, err_fun=noqual_errfun, opts: D
     initialize = self_consist and err is None
     nconsist = 0 if initialize else 1
     errs = []
+    # the largest rounded quality of each sample (R/dada.R:297-313 extends err to it): a property of the sample, taken ONCE - as a
+    # statement inside the pass loop it re-read the whole maxlen x nraw double matrix every pass (2 GB at 10^6 uniques: 70 ms of
+    # every selfConsist pass, profiles/r09a_selfconsist_passes.txt)
+    qmaxes = [d.qmax() for d in dereps]
     try:
         while True:
             if nconsist > 0:
                 errs.append(np.array(err, copy=True))
             results, used = [], []
             t_pass = time.perf_counter()
-            for d, smp in zip(dereps, samples):
-                qmax = int(np.ceil(np.nanmax(d.quals)))
+            for d, smp, qmax in zip(dereps, samples, qmaxes):
                 erri = np.ones((16, max(41, qmax + 1))) if initialize else extend_err(err, qmax)   # R/dada.R:297-313
                 results.append(smp.run(erri, o, max_clust=1 if initialize else None, verbose=verbose))
                 used.append(erri)

@@ -710,6 +710,7 @@ struct Run {
   // ---- device state -----------------------------------------------------------------------------
   void alloc_state() {
     const size_t n = (size_t)N;
+    const auto t_as = clk::now();
     d_Emin.alloc(n); d_clam.alloc(n); d_p.alloc(n); d_lock.alloc(n); d_slot0.alloc(n); d_clof.alloc(n); d_ci.alloc(n);
     d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(6 * n); d_nmovers.alloc(1);
     d_ties0.alloc(n); d_ties1.alloc(n); d_totals.alloc(4); d_partial.alloc(2 * (size_t)8192); d_rout.alloc(2); d_next.alloc(4); d_lock_tmp.alloc(n);   // (d_partial: block partials of k2_pupdate, grid capped at 8192)
@@ -725,6 +726,7 @@ struct Run {
     }
     grow_clusters(256);
     hipStream_t stq = s->stream;
+    const double ms_as_alloc = ms_since(t_as);
     // (buffers persist across runs of the same sample: clear what a previous run left behind)
     D2_HIP(hipMemsetAsync(P.creads, 0, (size_t)ccap * 4, stq));
     D2_HIP(hipMemsetAsync(d_creads_snap.p, 0, (size_t)ccap * 4, stq));
@@ -759,7 +761,9 @@ struct Run {
     pool_next = 0;
     D2_HIP(hipMemcpyAsync(d_thresh_one.p, thresh_one.data(), thresh_one.size() * 4, hipMemcpyHostToDevice, stq));
     D2_HIP(hipMemcpyAsync(d_thresh_round.p, thresh_round.data(), thresh_round.size() * 4, hipMemcpyHostToDevice, stq));
+    const double ms_as_enq = ms_since(t_as);
     D2_HIP(hipStreamSynchronize(stq));                           // the threshold vectors may be rebuilt by the next run
+    if (knobs().v2_summary) fprintf(stderr, "[run] alloc_state: buffers %.2f ms, + clears enqueued %.2f, + stream drained %.2f\n", ms_as_alloc, ms_as_enq, ms_since(t_as));
   }
 
   void grow_nodes(size_t cap) {
@@ -1333,6 +1337,7 @@ struct Run {
   DevBuf<int32_t> v2_i1;
   DevBuf<unsigned long long> v2_smask;
   DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_sig, v2_n0d, v2_blist, v2_blistn;
+  DevBuf<int32_t> v2_bretry, v2_bretryn;   // retry lists of the aligner's pointer-free pass (NwBatch::retry_list / retry_n)
   DevBuf<double> v2_lamB;
   DevBuf<uint32_t> v2_hamB;
   DevBuf<uint8_t> v2_moved;
@@ -1355,6 +1360,9 @@ struct Run {
   long v3_enq = 0;                    // k3_tail launches enqueued (their ordinals are 1, 2, ...)
   long v3_ord_seen = 0;               // launch ordinal of the last consumed block
   DevBuf<PSync> v3_psync;
+  DevBuf<int32_t> v3_lockbuf;         // Eng2::spec_lock_buf: per block, the locks an evaluation attempt has decided (published when it stands)
+  int v3_lock_stride = 0;
+  bool v3_pf_lowreg = false;          // prefetch screens on the 80-register build of the screen kernel (the tail shares every CU with them)
   // ---- the next batch's compare under the tail: a second set of everything a batch compare works with ----
   bool v3_overlap = false;
   Eng2 E2P{};                         // argument block of the prefetch compare's kernels (ctl = the prefetch descriptor, own tables / lists / aligner scratch)
@@ -1363,7 +1371,7 @@ struct Run {
   DevBuf<PfSync> v3_pfsync;
   DevBuf<uint2> v3_pf_tab8;
   DevBuf<uint16_t> v3_pf_full, v3_pf_ord, v3_pf_foff;
-  DevBuf<int32_t> v3_pf_blist, v3_pf_blistn;
+  DevBuf<int32_t> v3_pf_blist, v3_pf_blistn, v3_pf_bretry, v3_pf_bretryn;
   DevBuf<uint32_t> v3_pf_ad;
   DevBuf<AdDesc> v3_pf_fdesc;
   long v3_pf_launched = 0;            // highest prefetch number whose chain has been sent to the second stream (numbers are 1, 2, ...)
@@ -1391,7 +1399,7 @@ struct Run {
     E2.T.blk_cap = (int32_t)std::min<size_t>(v2_blk.n, 0x7FFFFFF0u);
     E2.C.NBUF = v2_nbuf; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
     E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15;
-    E2.C.lamB = v2_lamB.p; E2.C.hamB = v2_hamB.p; E2.blist = v2_blist.p; E2.blist_n = v2_blistn.p;
+    E2.C.lamB = v2_lamB.p; E2.C.hamB = v2_hamB.p; E2.blist = v2_blist.p; E2.blist_n = v2_blistn.p; E2.bretry = v2_bretry.p; E2.bretry_n = v2_bretryn.p;
     E2.ctl = v2_ctl.p; E2.dblk = v2_dblk.p; E2.hblk = v2_hblk.p; E2.dlt = v2_dlt.p; E2.movers = v2_movers.p;
     E2.partial = d_partial.p; E2.ties0 = d_ties0.p; E2.ties1 = d_ties1.p; E2.ccap = ccap;
     E2.sig_list = v2_sig.p + 4; E2.sig_n = v2_sig.p; E2.ties_rec = v2_tiesrec.p;
@@ -1413,6 +1421,8 @@ struct Run {
     if (K.v2_mov_inline > 0) E2.mov_inline = std::min(MOV_INLINE2, K.v2_mov_inline);   // test knob: long mover lists
     if (K.v3_ring > 0) E2.ring_limit = std::min(RING2, K.v3_ring);                     // test knob: a host that lags
     E2.fail_ordinal = K.v3_fail_entry > 0 ? K.v3_fail_entry : 0;
+    E2.grid_wait_ticks = (unsigned long long)((2.0 + (double)N / 1e6) * 1e8);   // 100 MHz ticks: 2 s + 1 s per 10^6 uniques
+    E2.spec_lock_buf = v3_lockbuf.p; E2.spec_lock_stride = v3_lock_stride;
     E2.spec_eval = K.v3_spec != 0 ? 1 : 0;
     // grid barriers inside a persistent launch: XCD-hierarchical from 48 blocks on (rounds3.inc.hip::grid_sync; a small grid is
     // faster on the flat one).  (v3_grid is v3_setup's, which runs in front of every bind)
@@ -1444,7 +1454,7 @@ struct Run {
     if (v3_overlap) {
       S2 = s->D; S2.ad_ptr = v3_pf_ad.p; S2.ad_foff = v3_pf_foff.p; S2.ad_desc = v3_pf_fdesc.p;
       E2P = E2; E2P.S = S2; E2P.ctl = v3_pfctl.p; E2P.C.tab8 = v3_pf_tab8.p; E2P.C.full = v3_pf_full.p; E2P.C.ord = v3_pf_ord.p;
-      E2P.blist = v3_pf_blist.p; E2P.blist_n = v3_pf_blistn.p; E2P.pf_on = 0; E2P.has_compare = 1;
+      E2P.blist = v3_pf_blist.p; E2P.blist_n = v3_pf_blistn.p; E2P.bretry = v3_pf_bretry.p; E2P.bretry_n = v3_pf_bretryn.p; E2P.pf_on = 0; E2P.has_compare = 1;
     }
     v2_drop_graph();                 // (captured launches hold the old argument block)
   }
@@ -1469,7 +1479,9 @@ struct Run {
     hipStream_t stq = s->stream;
     v2_lam0.alloc(n); v2_ham0.alloc(n); v2_lam1.alloc(n); v2_ham1.alloc(n); v2_i1.alloc(n); v2_smask.alloc(n); v2_head.alloc(n); v2_blkcount.alloc(1);
     {
-      size_t cap0 = std::max<size_t>(2 * n, (size_t)1 << 16);
+      // (4 blocks per unique: a selfConsist pass with a half-converged error matrix stores more than the converged ones, and a
+      //  halt for capacity is a drained device, a 2x allocation and a copy - two of them in pass 3 of configs[2]'s loop, profiles/r09a)
+      size_t cap0 = std::max<size_t>(4 * n, (size_t)1 << 16);
       if (K.node_cap > 0) cap0 = std::max<size_t>((size_t)K.node_cap, n + 16);   // test knob: forces growth
       if (v2_blk.n < cap0) v2_blk.alloc(cap0);
     }
@@ -1480,7 +1492,9 @@ struct Run {
     v2_bcls.alloc((size_t)v2_nbuf * (((size_t)N + 31) & ~(size_t)15));
     v2_lamB.alloc(slots * (((size_t)N + 31) & ~(size_t)15)); v2_hamB.alloc(slots * (((size_t)N + 31) & ~(size_t)15));
     v2_blist.alloc((size_t)2 * KB_MAX * (((size_t)N + 31) & ~(size_t)15)); v2_blistn.alloc(2 * KB_MAX);
+    v2_bretry.alloc((size_t)KB_MAX * (((size_t)N + 31) & ~(size_t)15)); v2_bretryn.alloc(KB_MAX);
     D2_HIP(hipMemsetAsync(v2_blistn.p, 0, 2 * KB_MAX * 4, stq));
+    D2_HIP(hipMemsetAsync(v2_bretryn.p, 0, KB_MAX * 4, stq));
     v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
     v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
     v2_moved.alloc(n); v2_n0d.alloc(2 * SH_LEVELS + 4); v2_statpart.alloc((size_t)4 * 8192);
@@ -1553,8 +1567,22 @@ struct Run {
         v3_grid = std::max(1, std::min((N + 8191) / 8192, ncu / 2));
       }
     }
-    if (v3_on) { const int cap = tail_resident_max(s->device, v3_bs); if (cap > 0 && v3_grid > cap) v3_on = false; }
+    // (cap: blocks the device can hold at once; 0 = the kernel cannot be resident at all on this part, -1 = the query failed and
+    //  the bounded entry barrier is the only guard)
+    if (v3_on) { const int cap = tail_resident_max(s->device, v3_bs); if (cap == 0 || (cap > 0 && v3_grid > cap)) v3_on = false; }
     if (!v3_on) v3_overlap = false;
+    // prefetch screens: the 80-register build where a tail block sits on EVERY CU beside them (three waves per SIMD fit into the
+    // registers the tail leaves, where two of the wide build do); the full build where the tail has taken half of the CUs whole
+    // and the compares have the others to themselves - there the narrow build only spills (29 VGPRs) and moves 1.8x the bytes
+    // (same box, 10^6 uniques: tail 102.7 -> 97.0 ms, pass 143.0 -> 138.7 ms, profiles/r09a_sweep_cfg3_lowreg.jsonl)
+    v3_pf_lowreg = K.v3_pf_lowreg >= 0 ? K.v3_pf_lowreg != 0 : (v3_overlap && v3_bs == 512);
+    v3_lock_stride = 0;
+    if (v3_on) {
+      // uniques one block sweeps: groups of 4096 (ShufLds::U x BS), dealt wave by wave over the blocks (sweep_unique)
+      const long long per_group = 4096ll * v3_grid;
+      v3_lock_stride = (int)(((long long)N + per_group - 1) / per_group * 4096ll);
+      v3_lockbuf.alloc((size_t)v3_lock_stride * (size_t)v3_grid);
+    }
     v3_pf_launched = 0; v3_pf_seen = 0; v3_pf_chains = 0;
     if (v3_overlap) {
       if (!s->cmp) D2_HIP(hipStreamCreateWithFlags(&s->cmp, hipStreamNonBlocking));
@@ -1562,6 +1590,8 @@ struct Run {
       const size_t npad = ((size_t)N + 31) & ~(size_t)15;
       v3_pfctl.alloc(1); v3_pfsync.alloc(1); v3_pf_tab8.alloc(NKMER); v3_pf_full.alloc((size_t)KB_MAX * NKMER);
       v3_pf_ord.alloc((size_t)KB_MAX * s->D.LK + 64); v3_pf_blist.alloc((size_t)2 * KB_MAX * npad); v3_pf_blistn.alloc(2 * KB_MAX);
+      v3_pf_bretry.alloc((size_t)KB_MAX * npad); v3_pf_bretryn.alloc(KB_MAX);
+      D2_HIP(hipMemsetAsync(v3_pf_bretryn.p, 0, KB_MAX * 4, stq));
       // the second aligner scratch: pointer ring + the factor-offset rows of k_ad_product, sized as the first (ensure_ad_ring)
       v3_pf_ad.alloc((size_t)s->D.ad_waves * s->D.ad_wpw);
       v3_pf_foff.alloc((size_t)s->D.ad_fcap * s->D.ad_fstride); v3_pf_fdesc.alloc((size_t)s->D.ad_fcap);
@@ -1605,7 +1635,7 @@ struct Run {
   // the second set of compare buffers goes back to the allocation cache when the rounds are over (nothing of this run is left on
   // the second stream: the callers have waited for it)
   void v3_pf_release() {
-    v3_pf_ad.free(); v3_pf_foff.free(); v3_pf_fdesc.free(); v3_pf_blist.free();
+    v3_pf_ad.free(); v3_pf_foff.free(); v3_pf_fdesc.free(); v3_pf_blist.free(); v3_pf_bretry.free();
   }
   // the entry barrier of a persistent launch failed: clear the failure, give the slot back, continue on the launch chains
   void v3_fallback() {
@@ -1642,7 +1672,7 @@ struct Run {
       launch2_screen_multi(E2, stq);
       ev_end(rec.ev_screen);
       launch2_batch_lists(E2, stq);
-      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad};
+      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad, v2_bretry.p, v2_bretryn.p};
       launch_gapless_batch(s->D, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &v2_ctl.p->state, stq);
       rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
       launch_nw_ad(s->D, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, stq,
@@ -1677,10 +1707,10 @@ struct Run {
     launch2_pf_gate(E2P, (int)k, v3_hflags.p + 32, v3_hflags.p + 40 + (k & 7), st2);
     launch2_pf_tables(E2P, st2);
     int ev = ev_begin(EV_PF_SCREEN, profile_all, false, false, st2);
-    launch2_screen_multi(E2P, st2, /*beside_tail=*/K_lowreg());
+    launch2_screen_multi(E2P, st2, /*beside_tail=*/v3_pf_lowreg);
     ev_end(ev);
     launch2_batch_lists(E2P, st2);
-    const NwBatch nb{&pc->nalign, v3_pf_blistn.p, v3_pf_blist.p, pc->acentre, &pc->abuf, E2.C.Npad};
+    const NwBatch nb{&pc->nalign, v3_pf_blistn.p, v3_pf_blist.p, pc->acentre, &pc->abuf, E2.C.Npad, v3_pf_bretry.p, v3_pf_bretryn.p};
     launch_gapless_batch(S2, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &pc->state, st2);
     ev = ev_begin(EV_PF_NW, profile_all, false, false, st2);
     launch_nw_ad(S2, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, st2,
@@ -1693,7 +1723,6 @@ struct Run {
     st.ms_enqueue += ms_since(t_enq);
   }
   int v3_pf_gate_result(long k) const { return (int)*(volatile int32_t *)(v3_hflags.p + 40 + (k & 7)); }   // 0: waiting / not run yet, 1: passed, 2: gave up
-  static bool K_lowreg() { return knobs().v3_pf_lowreg != 0; }
   int32_t v3_pf_stat[4] = {0, 0, 0, 0};   // Ctl2::pf_hits / pf_spins / pf_exits / pf_centres as of the last block read
   void v3_pf_totals() {
     PfSync ps;
@@ -1883,6 +1912,7 @@ struct Run {
       st.tail_ms_barriers = (kt[KT_S0_BAR] + kt[KT_SL_BAR] + kt[KT_P_BAR]) * ms; st.tail_ms_birth = kt[KT_BIRTH] * ms;
       st.tail_ms_publish = kt[KT_PUBLISH] * ms; st.tail_ms_entry = kt[KT_LAUNCH] * ms;
       st.tail_levels = kt[KT_LEVELS]; st.tail_ms_release = kt[KT_RELEASE] * ms;
+      st.tail_ms_pf_wait = kt[KT_PFWAIT] * ms; st.tail_ms_pf_plan = kt[KT_PLAN] * ms;
       if (knobs().v2_summary) {
         fprintf(stderr, "[v3] block-0 sub-phase ms (kid: 1 commit+shuffle0, 2 later shuffles, 5 p-update, 6 serial end):");
         for (int kid : {1, 2, 5, 6}) { fprintf(stderr, "  kid%d:", kid); for (int ph = 1; ph < 8; ph++) fprintf(stderr, " %.2f", kt[KT_SUB + 8 * kid + ph] * ms); }
@@ -1966,7 +1996,7 @@ struct Run {
       ev_end(rec.ev_screen);
       // ... its survivors through the aligner, all batch positions in one launch (both no-ops on a cache hit) ...
       launch2_batch_lists(E2, stq);
-      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad};
+      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad, v2_bretry.p, v2_bretryn.p};
       launch_gapless_batch(s->D, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &v2_ctl.p->state, stq);
       rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
       launch_nw_ad(s->D, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, stq,
@@ -2248,10 +2278,14 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   struct RangeGuard { SampleDev &D; ~RangeGuard() { D.r_lo = 0; D.r_hi = D.N; } } range_guard{D};
   D.r_lo = shard ? (int32_t)((int64_t)N * shard->rank / shard->world) : 0;
   D.r_hi = shard ? (int32_t)((int64_t)N * (shard->rank + 1) / shard->world) : N;
+  double t_sub[5] = {0, 0, 0, 0, 0};                  // (DADA2HIP_V2_SUMMARY: where the time in front of round 0 goes)
+  auto t_lap = clk::now();
+  auto lap = [&](int k) { t_sub[k] = ms_since(t_lap); t_lap = clk::now(); };
   ensure_ad_ring(s);
   AdRingGuard ring_guard{s};
   if (!s->run_cache) s->run_cache = std::make_shared<Run>();
   Run &run = *static_cast<Run *>(s->run_cache.get());
+  lap(0);
   run.hooks = hooks;
   run.shard = shard; run.lo = D.r_lo; run.hi = D.r_hi;
   run.sh_exchange_failed = false; run.sh_points_left = true;
@@ -2259,7 +2293,9 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   init_run(run, s, err, err_ncol, opts, opts->kdist_cutoff);
   run.st.ms_upload = s->ms_upload;
   hipStream_t stq = s->stream;
+  lap(1);
   run.alloc_state();
+  lap(2);
   // b_init (containers.cpp:111-137): one partition holding every unique, centre = first max-reads member
   run.clust_of.assign(N, 0);
   run.slot_of.resize(N);
@@ -2287,8 +2323,17 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
   int max_clust = opts->max_clust < 1 ? N : opts->max_clust;
   run.max_clust_run = max_clust;
   run.use_v2 = max_clust > 1 && !shard && run.want_v2();
+  lap(3);
   if (run.use_v2) run.v2_alloc(max_clust);
+  lap(4);
+  run.st.ms_setup = ms_since(t_total);
+  if (knobs().v2_summary)
+    fprintf(stderr, "[run] setup %.2f ms: aligner ring / run cache %.2f  init_run %.2f  alloc_state %.2f  b_init mirror %.2f  v2_alloc %.2f\n", run.st.ms_setup,
+            t_sub[0], t_sub[1], t_sub[2], t_sub[3], t_sub[4]);
+  const auto t_round0 = clk::now();
   run.compare_round(0, (int)run.bi[0].center, 1.0);   // Rmain.cpp:309-310: no k-mer screen in round 0
+  run.st.ms_round0 = ms_since(t_round0);
+  if (knobs().v2_summary) fprintf(stderr, "[run] round 0 (host side): %.2f ms\n", run.st.ms_round0);
   // run_dada's loop (Rmain.cpp:312-331), rotated: every iteration ends with b_p_update + the b_bud that opens
   // the reference's next iteration, so one device round trip serves both.  After a decision the next round's
   // kernels are launched first; the host mirror (moves replay, birth record) is updated while the GPU works.

@@ -221,6 +221,10 @@ struct NwBatch {
   const int32_t *centre;    // [KB_MAX]
   const int32_t *bbuf;      // batch buffer: results go to row (*bbuf * KB_MAX + k) of d_lambda / d_ham, rows of `stride` entries
   size_t stride;
+  // the pointer-free pass (k_nw_ad<.., FAST>) hands the pairs it cannot finish to the full kernel through these: row k of
+  // retry_list ([KB_MAX][stride]) / retry_n[k], zeroed by k2_batch_lists.  nullptr: one launch of the full kernel as before
+  int32_t *retry_list = nullptr;
+  int32_t *retry_n = nullptr;
 };
 void launch_gapless_batch(const SampleDev &S, const NwBatch &b, const AlignParams &ap, const double *d_err, double *d_lambda,
                           uint32_t *d_ham, const int32_t *d_stop_dev, hipStream_t st);
@@ -412,6 +416,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   uint32_t *stat_part;            // [grid of the store pass][4] per-block class counts of the round (NW, gapless, shrouded, skipped)
   int32_t *stat_n;                // number of entries in stat_part (0: the chain had no store pass), consumed by k2_birth
   int32_t *blist, *blist_n;       // [2 KB_MAX][Npad] / [2 KB_MAX]: work lists of the batch compare (NwBatch)
+  int32_t *bretry, *bretry_n;     // [KB_MAX][Npad] / [KB_MAX]: NwBatch::retry_list / retry_n of that compare (nullptr: no pointer-free pass)
   void *partial;                  // block partials of the bud arg-min
   int32_t *ties0, *ties1;         // full tie lists
   BudTie *ties_rec;               // [2][TIES_FULL] full records of the first TIES_FULL listed candidates per track
@@ -452,6 +457,13 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   int32_t spec_max_prev;                            // ... when the call before moved at most this many uniques (DADA2HIP_V3_SPEC_MAX)
   int32_t spec_eval;                                // 1: the shuffle calls behind the commit's carry the round's evaluation (shuffle_body<.., SPEC>; DADA2HIP_V3_SPEC)
   int32_t fail_ordinal;                             // test knob (DADA2HIP_V3_FAIL_ENTRY): the k3_tail launch of this ordinal fails its entry barrier (0: none)
+  unsigned long long grid_wait_ticks;               // bound of a grid-barrier wait (100 MHz ticks; the host scales it with the sample: 2 s + 1 s per 10^6 uniques)
+  // The locks an evaluation ATTEMPT on a shuffle call decides (pval.cpp:29-36) are not written to PartState::lock while it is unknown
+  // whether the attempt stands: the prefetch compare of the second stream reads lock[] at any time, and a lock that is published
+  // and then taken back breaks "locks only grow between a compare and its commit" (ADVICE r5).  Block b collects them in
+  // spec_lock_buf[b * spec_lock_stride ...] and writes them out behind the barrier that made the attempt stand (k3_tail).
+  int32_t *spec_lock_buf;
+  int32_t spec_lock_stride;                         // entries per block = uniques one block sweeps
   // ---- the next batch's compare under the persistent tail: what a prefetch compare works with.  The compare
   //      kernels of the second stream get a copy of this block whose `ctl`, `C.tab8 / full / ord`, `blist / blist_n` and aligner
   //      scratch ARE these (so they run unchanged); the tail's planner fills pf_ctl and clears pf_blist_n ----
@@ -487,7 +499,8 @@ struct PSync {
   uint32_t ngrp, pad4[31];
   uint32_t xarr[8][32], xgen[8][32], xcount[8][32], xn[8][32];
 };
-enum { KT_S0 = 0, KT_S0_BAR, KT_SL, KT_SL_BAR, KT_P, KT_P_BAR, KT_BIRTH, KT_PUBLISH, KT_ROUNDS, KT_LEVELS, KT_LAUNCH, KT_RELEASE, KT_SUB_LAST = 14, KT_SUB = 16, KT_N = 80 };
+enum { KT_S0 = 0, KT_S0_BAR, KT_SL, KT_SL_BAR, KT_P, KT_P_BAR, KT_BIRTH, KT_PUBLISH, KT_ROUNDS, KT_LEVELS, KT_LAUNCH, KT_RELEASE,
+       KT_PFWAIT /* serial end: spinning for a prefetch compare in flight */, KT_PLAN /* planning the next prefetch */, KT_SUB_LAST = 14, KT_SUB = 16, KT_N = 80 };
 
 void launch2_store0(const Eng2 &E, const double *d_lam, const uint32_t *d_ham, const uint8_t *d_cls, const int32_t *d_round_counters,
                     hipStream_t st);

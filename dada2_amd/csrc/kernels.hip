@@ -462,6 +462,10 @@ struct NwArgs {
   const int32_t *batch_centre; // [KB_MAX] centre of each batch position
   const int32_t *batch_bbuf;   // batch buffer the results belong to
   size_t batch_stride;         // row length of batch_list and of lam / ham
+  // k_nw_ad<.., FAST> (batch mode): the pairs whose walk back is NOT "free end run + one whole diagonal + border run" - the pass
+  // keeps no pointers, so it cannot finish them - go to row k of retry_list / retry_n[k], which the full kernel works through next
+  int32_t *retry_list;
+  int32_t *retry_n;
 };
 
 // shared tail: traceback + lambda.  NPW = pointer words per row.
@@ -842,10 +846,15 @@ static __device__ __forceinline__ void ad_step(int &d0, int &d1, int &i, int &j,
 // at once - equal values are separated by their tags exactly as the reference breaks the tie.  One v_alignbit_b32 moves
 // the tag into the pointer word, one v_and_or_b32 re-tags the cell: 6 vector instructions per cell (round 2: 11.25).
 constexpr int ADK_BIG = 1 << 24, ADK_MIS = 72, ADK_GAP = 84, ADK_FREE = 20, ADK_HOT = 36;
-template <int GL, int PAR, bool LEAN, bool EDGE>
+// FAST (the pointer-free pass, k_nw_ad<.., FAST>): no pointer word.  `pw` is then the cell's DIAGONAL ACCUMULATOR - the AND of the
+// move codes of every interior cell this lane has computed on the diagonal its cell of this parity runs along (a lane's cell
+// k' = 2g + PAR keeps its j - i for the whole sweep): bit 1 stays set exactly while every one of them was AD_DIAG (0b10; the
+// other codes are 0b00 and 0b01) - and `ep` receives the move code of the diagonal's LAST interior cell, the one on the last row
+// or the last column.  That is all the traceback of an alignment without interior gaps needs (fast_walk below).
+template <int GL, int PAR, bool LEAN, bool EDGE, bool FAST = false>
 static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &j, uint32_t &cb, uint32_t &rb, uint32_t &pw,
                                                  uint32_t vnext, int fs, bool g_first, bool g_last, bool kok, int gsel, int gsel_nb,
-                                                 int L1, int L2) {
+                                                 int L1, int L2, uint32_t *ep = nullptr) {
   if (LEAN) {
     // gsel_nb is the addend of the neighbour LANE's cell: the gap cost, or BIG where that neighbour must not be seen (out of
     // band, or - when the band fills the group's cells, EDGE - the last lane of the group before / the first of the next one;
@@ -856,7 +865,8 @@ static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &
     const int diag = gcn_sad_u8(cb, rb, own);
     const int left = PAR == 0 ? nb + gsel_nb : other + gsel, up = PAR == 0 ? other + gsel : nb + gsel_nb;
     const int et = gcn_min3(left, diag, up);                  // value | move code
-    pw = gcn_push_low2(pw, (uint32_t)et);
+    if (FAST) pw &= (uint32_t)et;                             // (one v_and in place of the v_alignbit; nothing is ever flushed)
+    else pw = gcn_push_low2(pw, (uint32_t)et);
     const int e = (et & ~3) | (int)AD_DIAG;
     if (PAR == 0) { d0 = e; rb = vnext; j++; } else { d1 = e; cb = vnext; i++; }
     return;
@@ -882,9 +892,13 @@ static __device__ __forceinline__ void ad_step_k(int &d0, int &d1, int &i, int &
     const bool interior = kok && ((unsigned)(i - 1) < (unsigned)L1) && ((unsigned)(j - 1) < (unsigned)L2);
     val = interior ? e : (kok ? ADK_FREE * (i + j) + (int)AD_DIAG : ADK_BIG);  // axis cells: H = 0
     if (!interior) p = (i <= 0 ? 2u : 3u);                     // first row: left, first column: up
+    if (FAST && interior) {
+      pw &= 3u - p;
+      if (i == L1 || j == L2) *ep = 3u - p;                    // the diagonal's last cell: where the walk back enters or leaves it
+    }
   }
   if (PAR == 0) { d0 = val; rb = vnext; j++; } else { d1 = val; cb = vnext; i++; }
-  pw = gcn_push_low2(pw, 3u - p);                           // (up / left / diagonal as ad_ptr_code)
+  if (!FAST) pw = gcn_push_low2(pw, 3u - p);                 // (up / left / diagonal as ad_ptr_code)
 }
 
 // LDS geometry of k_nw_ad, shared by host and device.  Per WAVE: the staged centre (every alignment of a wave has the same
@@ -1015,9 +1029,19 @@ static __device__ __forceinline__ void bimera_lr_bits(const uint32_t *NE, const 
   o[4] = len - 1 - is >= ntrail ? bm_count(NE, ntrail, len - 1 - is) : 0;
 }
 
-template <int GL, bool DEF, bool EDGE, bool LR = false, bool HOMO = false>
+// FAST: the pointer-free pass of a batch compare (launch_nw_ad).  Most pairs a round aligns differ by substitutions only (or by
+// that and a free end gap): their walk back from (L1, L2) - the reference takes the diagonal only where it is STRICTLY best
+// (nwalign_endsfree.cpp:146-156) and walks pointer by pointer (:164-188) - is a run of free moves along the last column or row, then
+// ONE diagonal from its last cell all the way to the first row / column, then the forced moves along that border.  Whether a
+// diagonal is walked whole is the AND of its cells' move codes, and where the walk enters it is decided by the move codes of the
+// diagonals' LAST cells: two registers per lane instead of 2 bits per cell in memory (the pointer ring took 286 MB of stores and
+// 2 x 93 MB of fetches per batch launch at 10^6 uniques - 19x the launch's algorithmic bytes, profiles/r08c_traffic_cfg3.json),
+// no traceback, and the expansion / product work on the same run descriptors as ever.  A pair that is not of this form is
+// appended to the retry list of its batch position (NwArgs::retry_list) and aligned by the full kernel in a second launch.
+template <int GL, bool DEF, bool EDGE, bool LR = false, bool HOMO = false, bool FAST = false>
 __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__restrict__ gl_work, const int32_t *__restrict__ gl_nwork_dev,
                                                AdGeom G) {
+  static_assert(!FAST || (DEF && !LR && !HOMO), "the pointer-free pass exists for the default scores of the denoising path");
   constexpr int APW = 64 / GL;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double *s_err = s_dyn;
@@ -1131,6 +1155,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     const int dbg = a.moves_stride;
     Tmax = gcn_readfirstlane(Tmax);
     const int org = (EDGE ? 0 : 2) + (lband & 1), lbo = lband + org;   // origin shift: lbo is even
+    uint32_t acc0 = ~0u, acc1 = ~0u, ep0 = 3u, ep1 = 3u;   // FAST: diagonal accumulators / last-cell move codes of the lane's two cells
     if (Tmax >= 0 && !(dbg & 1)) {
       int d0 = SENT, d1 = SENT;
       uint32_t pw = 0;
@@ -1153,10 +1178,11 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
       for (int o = 32; o >= 1; o >>= 1) { tA = max(tA, __shfl_xor(tA, o, 64)); tB = min(tB, __shfl_xor(tB, o, 64)); }
       tA = gcn_readfirstlane(tA);
       tB = gcn_readfirstlane(tB);
-#define AD_FLUSH(TT) { pg[(size_t)((TT) >> 4) * 64 + lane] = pw; pw = 0; }   /* every lane, unconditionally: one 256-byte store */
+#define AD_FLUSH(TT) { if (!FAST) { pg[(size_t)((TT) >> 4) * 64 + lane] = pw; pw = 0; } }   /* every lane, unconditionally: one 256-byte store */
 #define AD_STEP(PARV, LEANV, VNEXT, FS, KOK, GS)                                                                                   \
   {                                                                                                                             \
-    if (DEF) ad_step_k<GL, PARV, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), (PARV) ? gn1 : gn0, L1, L2); \
+    if (FAST) ad_step_k<GL, PARV, LEANV, EDGE, true>(d0, d1, i, j, cb, rb, (PARV) ? acc1 : acc0, (VNEXT), (FS), g_first, g_last, (KOK), (GS), (PARV) ? gn1 : gn0, L1, L2, (PARV) ? &ep1 : &ep0); \
+    else if (DEF) ad_step_k<GL, PARV, LEANV, EDGE>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), (PARV) ? gn1 : gn0, L1, L2); \
     else ad_step<GL, PARV, DEF, LEANV, EDGE, HOMO>(d0, d1, i, j, cb, rb, pw, (VNEXT), (FS), g_first, g_last, (KOK), (GS), L1, L2, SENT, MATCH, MISMATCH, GAP, HGAP); \
   }
 #define AD_FULL_STEP(TT)                                                                                                        \
@@ -1195,7 +1221,31 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 #undef AD_FULL_STEP
 #undef AD_STEP
 #undef AD_FLUSH
-      if (((t - 1) & 15) != 15) pg[(size_t)((t - 1) >> 4) * 64 + lane] = pw >> (2 * (15 - ((t - 1) & 15)));   // (the last, partial block: step s at bits 2s too)
+      if (!FAST && ((t - 1) & 15) != 15) pg[(size_t)((t - 1) >> 4) * 64 + lane] = pw >> (2 * (15 - ((t - 1) & 15)));   // (the last, partial block: step s at bits 2s too)
+    }
+    // ---- FAST: the walk back without pointers.  Every lane of a group follows it redundantly (what it reads comes from the lane
+    //      that owns the band cell in question, so all of them see the same): from (L1, L2) - the last cell of the diagonal
+    //      j - i = L2 - L1, band cell k' = L2 - L1 + lbo - along the last column (free up moves: the next diagonal's last cell) or
+    //      the last row (free left moves: the previous one's) until a last cell says "diagonal"; that diagonal must then have been
+    //      walked whole.  fres: 1 = the alignment is (dir, fm free moves, diagonal fk), 2 = not of this form (retry list).
+    int fres = 0, fk = 0, fm = 0, fdir = -1;
+    if (FAST) {
+      fk = L2 - L1 + lbo;
+      if (T < 0) fres = 2;                                  // (idle slots: nothing to decide)
+      for (int itw = 0; itw <= 2 * GL + 1; itw++) {         // (a walk visits each band cell at most once)
+        if (__all(fres != 0)) break;
+        const bool inband = fk >= org && fk < W + org;
+        const int src = al * GL + (inband ? (fk >> 1) : 0);
+        const uint32_t e0 = (uint32_t)__shfl((int)ep0, src, 64), e1 = (uint32_t)__shfl((int)ep1, src, 64);
+        const uint32_t a0 = (uint32_t)__shfl((int)acc0, src, 64), a1 = (uint32_t)__shfl((int)acc1, src, 64);
+        if (fres != 0) continue;
+        const uint32_t pe = (fk & 1) ? e1 : e0, whole = (((fk & 1) ? a1 : a0) >> 1) & 1u;
+        if (!inband || pe > AD_DIAG) fres = 2;              // (pe == 3: a cell the sweep never reached - cannot happen on a walk, but never trusted)
+        else if (pe == AD_DIAG) fres = whole ? 1 : 2;
+        else if (fdir < 0 || (int)pe == fdir) { fdir = (int)pe; fm++; fk += pe == AD_UP ? 1 : -1; }
+        else fres = 2;                                      // the free run turned: an interior gap
+      }
+      if (fres == 0) fres = 2;
     }
     // ---- traceback (first lane of each group) in chunks of <= AD_RCAP merged runs, expanded by all lanes into one
     //      transition code per raw position.  Run: pj_lo (12 b) | n (12 b) << 12 | (delta + 128) << 24, delta = pi - pj;
@@ -1223,10 +1273,27 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         if (L2 > n) runs[nruns++] = (uint32_t)n | ((uint32_t)(L2 - n) << 12) | (255u << 24);
         done = true;
       }
+      if (FAST && lead && !done) {
+        // the alignment fast_walk found, as the run descriptors the pointer walk would have pushed: fm raw positions facing the
+        // free end gap (left moves along the last row; up moves consume centre positions only), the diagonal j - i = dd from the
+        // border to its last cell, the raw positions in front of it on the first row
+        if (fres == 1) {
+          const int dd = fk - lbo;
+          const int n = dd >= 0 ? min(L1, L2 - dd) : min(L1 + dd, L2);
+          if (fdir == (int)AD_LEFT && fm > 0) runs[nruns++] = (uint32_t)(L2 - fm) | ((uint32_t)fm << 12) | (255u << 24);
+          if (n > 0) runs[nruns++] = (uint32_t)(dd >= 0 ? dd : 0) | ((uint32_t)n << 12) | ((uint32_t)(128 - dd) << 24);
+          if (dd > 0) runs[nruns++] = 0u | ((uint32_t)dd << 12) | (255u << 24);
+        } else if (active && !gapless) {
+          const int q = atomicAdd(&a.retry_n[kcur], 1);
+          a.retry_list[(size_t)kcur * a.batch_stride + q] = r;
+        }
+        done = true; ti = 0; tj = 0;
+      }
       // The path is walked by the group's first lane, but every diagonal stretch is measured by the whole group at once:
       // lane q looks at the pointer word q blocks of 16 steps further back in the path's column, so one round finds the
       // next non-diagonal move up to 16 GL steps away (a gap-free 250-nt alignment takes 2 rounds instead of 32).
       const int gl0 = al * GL;
+      if (!FAST)
       for (;;) {
         const bool act = lead && !done && (ti > 0 || tj > 0) && nruns < AD_RCAP - 2 && guard > 0;
         if (!__any(act)) break;
@@ -1355,6 +1422,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     // multiplied up here.
     const long long fid = ((long long)it * 4 + wib) * APW + al;
     const bool offload = S.ad_foff != nullptr && fid < (long long)S.ad_fcap && !(dbg & 8);
+    if (FAST && fres != 1) continue;                       // (on the retry list: the full kernel will write this pair's results)
     if (offload) {
       if (active && !ghost) {
         uint16_t *fo = S.ad_foff + (size_t)fid * S.ad_fstride;
@@ -1466,36 +1534,56 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   int grid = std::max(1, std::min((waves + 3) / 4, std::min(256 * 8, S.ad_waves / 4)));   // one slot of the pointer ring per wave
   const bool homo = ap.endsfree && ap.homo_gap != ap.gap;   // nwalign_endsfree_homo: the generic-score step with per-base gap costs
   const bool def = !homo && ap.match == 5 && ap.mismatch == -4 && ap.gap == -8 && ap.sentinel == -32760;
-#define D2_LAUNCH_AD(GLV, DEFV, EDGEV, HOMOV)                                                                                      \
+  // a batch compare on the default scores: first the pointer-free pass over the batch's lists (k_nw_ad<.., FAST>), then the full
+  // kernel over the pairs that pass could not finish (its retry lists: usually a few per cent of the pairs, often none)
+  const bool fast = batch && def && batch->retry_list && batch->retry_n && knobs().ad_fast != 0 && a.moves_stride == 0;
+  // per (instance, device): the dynamic-LDS attribute belongs to the function ON a device
+  auto set_lds = [&](const void *fn, std::atomic<size_t> (&done)[64]) {
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    std::atomic<size_t> &d = done[dev_ & 63];
+    if (lds > d.load(std::memory_order_acquire)) {
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      d.store(lds, std::memory_order_release);
+    }
+  };
+#define D2_LAUNCH_AD(GLV, DEFV, EDGEV, HOMOV, FASTV)                                                                     \
   do {                                                                                                                   \
-    static size_t attr_set[64] = {0};   /* per device: the attribute belongs to the function ON a device */            \
-    int dev_ = 0;                                                                                                        \
-    (void)hipGetDevice(&dev_);                                                                                           \
-    if (lds > attr_set[dev_ & 63]) {                                                                                     \
-      (void)hipFuncSetAttribute((const void *)k_nw_ad<GLV, DEFV, EDGEV, false, HOMOV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_set[dev_ & 63] = lds;                                                                                         \
-    }                                                                                                                    \
-    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV, false, HOMOV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);  \
+    static std::atomic<size_t> attr_set[64];                                                                             \
+    set_lds((const void *)k_nw_ad<GLV, DEFV, EDGEV, false, HOMOV, FASTV>, attr_set);                                     \
+    hipLaunchKernelGGL((k_nw_ad<GLV, DEFV, EDGEV, false, HOMOV, FASTV>), dim3(grid), dim3(256), lds, st, a, d_gl_work, d_gl_nwork, G);  \
   } while (0)
-#define D2_LAUNCH_AD2(GLV)                                                                                               \
+#define D2_LAUNCH_AD2(GLV, FASTV)                                                                                        \
   do {                                                                                                                   \
-    if (homo) { if (G.edge) D2_LAUNCH_AD(GLV, false, true, true); else D2_LAUNCH_AD(GLV, false, false, true); } \
-    else if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true, false); else D2_LAUNCH_AD(GLV, true, false, false); } \
-    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true, false); else D2_LAUNCH_AD(GLV, false, false, false); }   \
+    if (FASTV) { if (G.edge) D2_LAUNCH_AD(GLV, true, true, false, FASTV); else D2_LAUNCH_AD(GLV, true, false, false, FASTV); } \
+    else if (homo) { if (G.edge) D2_LAUNCH_AD(GLV, false, true, true, false); else D2_LAUNCH_AD(GLV, false, false, true, false); } \
+    else if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true, false, false); else D2_LAUNCH_AD(GLV, true, false, false, false); } \
+    else { if (G.edge) D2_LAUNCH_AD(GLV, false, true, false, false); else D2_LAUNCH_AD(GLV, false, false, false, false); }   \
   } while (0)
-  if (G.GL == 21) D2_LAUNCH_AD2(21);
-  else if (G.GL == 32) D2_LAUNCH_AD2(32);
-  else D2_LAUNCH_AD2(64);
-#undef D2_LAUNCH_AD2
-#undef D2_LAUNCH_AD
-  if (S.ad_foff && a.moves_stride == 0) {   // the products of what the launch aligned (its work slots: ids below the bound)
+  auto product = [&](const int32_t *list_n) {   // the products of what a launch aligned (its work slots: ids below the bound)
+    if (!(S.ad_foff && a.moves_stride == 0)) return;
     const int nerr = 16 * ap.ncol;
     long long bound = batch ? (long long)S.ad_fcap : (long long)((maxwork + (d_gl_work ? S.N : 0) + 4 * G.APW - 1) / (4 * G.APW) + 1) * 4 * G.APW;
     const int nscan = (int)std::min<long long>(bound, S.ad_fcap);
     const int pgrid = std::max(1, std::min((nscan + 255) / 256, 2048));
     hipLaunchKernelGGL(k_ad_product, dim3(pgrid), dim3(256), (size_t)nerr * 8, st, (const uint16_t *)S.ad_foff, (int)S.ad_fstride, S.ad_desc, nscan, d_err, nerr,
-                       d_lambda, d_stop_dev, batch ? batch->on : nullptr, batch ? batch->n : nullptr, 4 * G.APW);
+                       d_lambda, d_stop_dev, batch ? batch->on : nullptr, list_n, 4 * G.APW);
+  };
+  if (fast) {
+    a.retry_list = batch->retry_list; a.retry_n = batch->retry_n;
+    if (G.GL == 21) D2_LAUNCH_AD2(21, true);
+    else if (G.GL == 32) D2_LAUNCH_AD2(32, true);
+    else D2_LAUNCH_AD2(64, true);
+    product(batch->n);
+    a.batch_list = batch->retry_list; a.batch_n = batch->retry_n;   // (rows k < KB_MAX are all either kernel reads)
+    a.retry_list = nullptr; a.retry_n = nullptr;
   }
+  if (G.GL == 21) D2_LAUNCH_AD2(21, false);
+  else if (G.GL == 32) D2_LAUNCH_AD2(32, false);
+  else D2_LAUNCH_AD2(64, false);
+#undef D2_LAUNCH_AD2
+#undef D2_LAUNCH_AD
+  product(batch ? (fast ? batch->retry_n : batch->n) : nullptr);
 }
 
 // Bimera mode: the pairs (query = chunk centre, parent = work item; chunks of nw_ad_apw() slots, -1 = empty slot) aligned by

@@ -5,6 +5,7 @@
 // library calls getenv.  The supported set is listed in include/dada2hip.h ("Environment"); all default to "off" / automatic,
 // and none changes a result - they choose engines, kernel families and buffer sizes, which the parity tests sweep.
 #pragma once
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -45,7 +46,7 @@ struct Knobs {
   int v3_spec = 1;                     // DADA2HIP_V3_SPEC=0|1           the round's evaluation rides on its shuffle calls (0: a phase of its own behind them, round 4's form)
   int v3_spec_max = -1;               // DADA2HIP_V3_SPEC_MAX=n         (tuning) ... only behind a call that moved at most n uniques
   int v3_pf_sync = 0;                 // DADA2HIP_V3_PF_SYNC=1          (measurement) every prefetch is waited for at the next serial end, the tail resident and idle
-  int v3_pf_lowreg = 1;               // DADA2HIP_V3_PF_LOWREG=0|1      (tuning) prefetch screens on the 80-register build of the screen kernel
+  int v3_pf_lowreg = -1;              // DADA2HIP_V3_PF_LOWREG=0|1      (tuning) prefetch screens on the 80-register build of the screen kernel (-1 = automatic: where the tail shares every CU)
   int v3_fail_entry = 0;              // DADA2HIP_V3_FAIL_ENTRY=n       test knob: the n-th persistent launch fails its entry barrier (-> launch chains)
   bool v2_debug = false;              // DADA2HIP_V2_DEBUG              per-block trace on stderr
   bool v2_summary = false;            // DADA2HIP_V2_SUMMARY            per-pass summary on stderr
@@ -61,6 +62,7 @@ struct Knobs {
   bool kord_align = false;            // DADA2HIP_KORD_ALIGN=1          (experiment) k-mer rows padded to 64 bytes
   int screen_grid = 2048;             // DADA2HIP_SCREEN_GRID           (experiment) block cap of k_screen
   long long ad_fcap = 0;              // DADA2HIP_AD_FCAP               rows of k_ad_product's offset buffer (tests: the in-kernel product)
+  int ad_fast = 1;                    // DADA2HIP_AD_FAST=0             batch compares on the full aligner only (no pointer-free first pass)
   int ad_debug = 0;                   // DADA2HIP_AD_DEBUG              profiling build only (make prof): skips phases of k_nw_ad, results void
   bool bimera_times = false;          // DADA2HIP_BIMERA_TIMES=1        stderr: host / device split of a bimera call
   bool derep_zlib = false;            // DADA2HIP_DEREP_INFLATE=zlib    .gz files through zlib's streaming inflate even where libdeflate is installed
@@ -93,7 +95,7 @@ struct Knobs {
     k.v3_grid = I("DADA2HIP_V3_GRID", 0); k.v3_ring = I("DADA2HIP_V3_RING", 0); k.v3_block = I("DADA2HIP_V3_BLOCK", 0);
     k.v3_overlap = T("DADA2HIP_V3_OVERLAP"); k.v3_pf_wait_us = I("DADA2HIP_V3_PF_WAIT_US", -1);
     k.v3_fail_entry = I("DADA2HIP_V3_FAIL_ENTRY", 0); k.v3_spec = I("DADA2HIP_V3_SPEC", 1); k.v3_xbar = T("DADA2HIP_V3_XBAR"); k.v3_spec_max = I("DADA2HIP_V3_SPEC_MAX", -1);
-    k.v3_pf_early = I("DADA2HIP_V3_PF_EARLY", -1); k.v3_pf_lowreg = I("DADA2HIP_V3_PF_LOWREG", 1); k.v3_pf_sync = I("DADA2HIP_V3_PF_SYNC", 0); k.v3_pf_gate_us = I("DADA2HIP_V3_PF_GATE_US", -1);
+    k.v3_pf_early = I("DADA2HIP_V3_PF_EARLY", -1); k.v3_pf_lowreg = T("DADA2HIP_V3_PF_LOWREG"); k.v3_pf_sync = I("DADA2HIP_V3_PF_SYNC", 0); k.v3_pf_gate_us = I("DADA2HIP_V3_PF_GATE_US", -1);
     k.v2_debug = S("DADA2HIP_V2_DEBUG") != nullptr; k.v2_summary = S("DADA2HIP_V2_SUMMARY") != nullptr;
     if (const char *e = S("DADA2HIP_V2_TRACE")) {
       k.v2_trace_on = true; k.v2_trace_seq = std::atoi(e);
@@ -108,7 +110,7 @@ struct Knobs {
     if (const char *e = S("DADA2HIP_KORD_ALIGN")) k.kord_align = !std::strcmp(e, "1");
     k.screen_grid = I("DADA2HIP_SCREEN_GRID", 2048);
     if (const char *e = S("DADA2HIP_AD_FCAP")) k.ad_fcap = std::atoll(e);
-    k.ad_debug = I("DADA2HIP_AD_DEBUG", 0);
+    k.ad_debug = I("DADA2HIP_AD_DEBUG", 0); k.ad_fast = I("DADA2HIP_AD_FAST", 1);
     if (const char *e = S("DADA2HIP_BIMERA_TIMES")) k.bimera_times = !std::strcmp(e, "1");
     if (const char *e = S("DADA2HIP_DEREP_INFLATE")) k.derep_zlib = !std::strcmp(e, "zlib");
     if (const char *e = S("DADA2HIP_DEREP_TIMES")) k.derep_times = !std::strcmp(e, "1");
@@ -120,8 +122,8 @@ struct Knobs {
 };
 
 namespace knobs_detail {
-inline std::mutex &mu() { static std::mutex m; return m; }
-inline const Knobs *&cur() { static const Knobs *p = nullptr; return p; }
+inline std::mutex &mu() { static std::mutex m; return m; }          // serialises reloads only
+inline std::atomic<const Knobs *> &cur() { static std::atomic<const Knobs *> p{nullptr}; return p; }
 inline bool same(const Knobs &a, const Knobs &b) {
   // (field-wise: the struct holds a std::string)
   return a.engine_classic == b.engine_classic && a.nw_kernel == b.nw_kernel && a.ad_homo == b.ad_homo && a.no_speculation == b.no_speculation &&
@@ -132,7 +134,7 @@ inline bool same(const Knobs &a, const Knobs &b) {
          a.v3_fail_entry == b.v3_fail_entry && a.v3_spec == b.v3_spec && a.v3_xbar == b.v3_xbar && a.v3_spec_max == b.v3_spec_max && a.v3_pf_early == b.v3_pf_early && a.v3_pf_lowreg == b.v3_pf_lowreg && a.v3_pf_sync == b.v3_pf_sync && a.v3_pf_gate_us == b.v3_pf_gate_us && a.v2_debug == b.v2_debug && a.v2_summary == b.v2_summary && a.v2_trace_on == b.v2_trace_on &&
          a.v2_trace_seq == b.v2_trace_seq && a.v2_trace_file == b.v2_trace_file && a.profile == b.profile && a.node_cap == b.node_cap &&
          a.wait_block == b.wait_block && a.wait_timeout_s == b.wait_timeout_s && a.coop_max == b.coop_max && a.kord_align == b.kord_align &&
-         a.screen_grid == b.screen_grid && a.ad_fcap == b.ad_fcap && a.ad_debug == b.ad_debug && a.bimera_times == b.bimera_times && a.derep_times == b.derep_times && a.derep_zlib == b.derep_zlib &&
+         a.screen_grid == b.screen_grid && a.ad_fcap == b.ad_fcap && a.ad_debug == b.ad_debug && a.ad_fast == b.ad_fast && a.bimera_times == b.bimera_times && a.derep_times == b.derep_times && a.derep_zlib == b.derep_zlib &&
          a.host_threads == b.host_threads && a.alloc_cache == b.alloc_cache && a.alloc_cache_gb == b.alloc_cache_gb;
 }
 }  // namespace knobs_detail
@@ -143,17 +145,15 @@ inline bool same(const Knobs &a, const Knobs &b) {
 inline void knobs_reload() {
   Knobs k = Knobs::from_env();
   std::lock_guard<std::mutex> g(knobs_detail::mu());
-  const Knobs *&c = knobs_detail::cur();
-  if (!c || !knobs_detail::same(*c, k)) c = new Knobs(std::move(k));
+  const Knobs *c = knobs_detail::cur().load(std::memory_order_relaxed);
+  if (!c || !knobs_detail::same(*c, k)) knobs_detail::cur().store(new Knobs(std::move(k)), std::memory_order_release);
 }
+// (an acquire load: knobs() is called from polling loops and per-round paths of several host threads - no lock on the read side)
 inline const Knobs &knobs() {
-  {
-    std::lock_guard<std::mutex> g(knobs_detail::mu());
-    if (knobs_detail::cur()) return *knobs_detail::cur();
-  }
+  const Knobs *c = knobs_detail::cur().load(std::memory_order_acquire);
+  if (c) return *c;
   knobs_reload();
-  std::lock_guard<std::mutex> g(knobs_detail::mu());
-  return *knobs_detail::cur();
+  return *knobs_detail::cur().load(std::memory_order_acquire);
 }
 
 }  // namespace d2

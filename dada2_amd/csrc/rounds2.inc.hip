@@ -116,6 +116,7 @@ struct PupdLds {
   BudKey s_k[2][BS / 64];
   int32_t s_sig[SIG_CAP];
   int s_nsig, s_sbase;
+  int s_nlock;                                                           // locks an evaluation ATTEMPT has decided so far (Eng2::spec_lock_buf)
   // what a unique needs from ITS PARTITION (reads, update / lock flags, the centre and its reads) sits in LDS: the loads
   // behind clust_of[r] were a chain of three global round trips per unique in a latency-bound kernel
   uint32_t s_prd[PUPD_TAB], s_cread[PUPD_TAB];
@@ -142,7 +143,7 @@ static __device__ __forceinline__ int pupd_tables(const Eng2 &E, PupdLds<BS> &L,
     L.s_upd[k] = P.update_e[k];
     L.s_chk[k] = P.check_locks[k];
   }
-  if (threadIdx.x == 0) L.s_nsig = 0;
+  if (threadIdx.x == 0) { L.s_nsig = 0; L.s_nlock = 0; }
   return ntab;
 }
 // a unique whose partition has not changed and whose p is exactly 1 (nine in ten of a large sample: singletons, pval.cpp:69) can
@@ -155,7 +156,9 @@ static __device__ __forceinline__ bool pupd_wanted(const Eng2 &E, const PupdLds<
   const bool touched = (intab ? L.s_upd[cl] : E.P.update_e[cl]) || (E.greedy && (intab ? L.s_chk[cl] : E.P.check_locks[cl]));
   return touched || !(p1_skip && p == 1.0);
 }
-template <int BS>
+// DEFER (an evaluation attempt riding on a shuffle call, shuffle_body<.., SPEC>): the locks it decides go to the block's list in
+// Eng2::spec_lock_buf instead of PartState::lock - k3_tail writes them out once the attempt is known to stand (spec_locks_flush)
+template <int BS, bool DEFER = false>
 static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L, int nexec, int ntab, int nwork, BudKey &b0, BudKey &b1) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -178,7 +181,12 @@ static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L
     if (E.greedy && (intab ? L.s_chk[cl] : P.check_locks[cl])) {          // pval.cpp:29-36
       const int c = intab ? L.s_cen[cl] : P.centre_of[cl];
       const uint32_t cr = intab ? L.s_cread[cl] : S.reads[c];
-      if ((cr * l > reads) || r == c) P.lock[r] = 1;
+      if ((cr * l > reads) || r == c) {
+        if (DEFER) {
+          const int k = atomicAdd(&L.s_nlock, 1);                          // (a block lists a unique at most once per attempt: k < stride)
+          if (k < E.spec_lock_stride) E.spec_lock_buf[(size_t)blockIdx.x * E.spec_lock_stride + k] = r;
+        } else P.lock[r] = 1;
+      }
     }
     // bud_candidate2 with the values at hand
     if (s0) continue;                                                    // r = 0 is skipped as "the centre" (cluster.cpp:285)
@@ -192,6 +200,24 @@ static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L
       if (q < SIG_CAP) L.s_sig[q] = r; else E.sig_list[atomicAdd(E.sig_n, 1)] = r;
     }
   }
+}
+// The attempt stood (the barrier behind it saw that its shuffle call moved nothing, and the round's decision has been taken): the
+// locks it decided become visible now.  A new centre the decision has just made is skipped: the birth unlocked it
+// (bi_assign_center, cluster.cpp:377; apply_birth_and_plan) BEFORE this runs, and a lock of its own must not land behind that.
+template <int BS>
+static __device__ __forceinline__ void spec_locks_flush(const Eng2 &E, const PupdLds<BS> &L, const Round2Out *out) {
+  const int n = min(L.s_nlock, E.spec_lock_stride);
+  const int skip = out->birth_applied ? E.ctl->centre : -1;
+  const int32_t *buf = E.spec_lock_buf + (size_t)blockIdx.x * E.spec_lock_stride;
+  if (n == 0) return;                                                     // (uniform: an LDS word)
+  for (int k = threadIdx.x; k < n; k += BS) {
+    const int r = buf[k];
+    if (r != skip) E.P.lock[r] = 1;
+  }
+  // the coming round's commit reads lock[] of these very uniques, in other waves of this block: the stores have left the wave
+  // before any of them goes on
+  gcn_drain_stores();
+  __syncthreads();
 }
 template <int BS>
 static __device__ __forceinline__ void pupd_finish(const Eng2 &E, PupdLds<BS> &L, BudKey b0, BudKey b1, BudKey *__restrict__ partial) {
@@ -263,9 +289,9 @@ struct ShufLds {
 // itself.  If any block moved something the attempt is void and costs nothing but its time: the p-values it wrote belong to
 // members of touched partitions, which the next attempt rewrites (a touched partition stays touched until the round's
 // evaluation stands, and a unique that moves lands in a touched partition); the candidate list is emptied by the barrier's last
-// arriver; the block minima are overwritten; and a lock it set on a member of the new partition is taken back if that member
-// moves out later in the round (only the new partition has check_locks, and whoever joined it this round was unlocked when the
-// round began: a locked unique gets no comparison with the new centre, cluster.cpp:127-130).
+// arriver; the block minima are overwritten; and the locks it decided were never published: they wait in the block's list
+// (Eng2::spec_lock_buf) for the barrier that makes the attempt stand - the prefetch compare of the second stream reads lock[] at
+// any time and relies on locks only growing between a compare and its commit.
 template <bool STORE, int BS, bool SPEC = false>
 static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L, int level, int moved_before, int32_t *mv, Round2Out *out,
                                                    PupdLds<BS> *LP = nullptr, BudKey init = BudKey{1.0, 0u}, BudKey *partial = nullptr) {
@@ -470,7 +496,6 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
         P.clust_of[r] = to;
         P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
         E.moved[r] = 1;
-        if (SPEC && E.greedy && from == ci) P.lock[r] = 0;               // (a lock of an evaluation attempt that did not stand; see above)
         my_n0 += (from == 0 ? 1 : 0) + (to == 0 ? 0x10000 : 0);
         const uint32_t rd = S.reads[r];
         if (to < ntab) atomicAdd(&s_delta[to], (int32_t)rd); else atomicAdd(&dl[to], (int32_t)rd);
@@ -505,7 +530,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
     __syncthreads();                                                     // (the list is rewritten by the next group)
     D2_TRACE(1 + level, 6);
     if (SPEC) {
-      if (s_n == 0) pupd_pass_b<BS>(E, *LP, level, ptab, LP->s_nwork, eb0, eb1);   // (s_n: uniform, the block is behind a barrier)
+      if (s_n == 0) pupd_pass_b<BS, true>(E, *LP, level, ptab, LP->s_nwork, eb0, eb1);   // (s_n: uniform, the block is behind a barrier)
       __syncthreads();
     }
   }
@@ -602,6 +627,8 @@ __global__ __launch_bounds__(256) void k2_batch_lists(Eng2 E) {
   const Ctl2 *ctl = E.ctl;
   const int nb = ctl->nalign;
   if (ctl->state != 0 || nb == 0) return;
+  // (the retry lists of the aligner's pointer-free pass, which follows in the stream, start empty)
+  if (blockIdx.x == 0 && threadIdx.x < KB_MAX && E.bretry_n) E.bretry_n[threadIdx.x] = 0;
   __shared__ int s_cnt[2 * KB_MAX], s_base[2 * KB_MAX];
   const SampleDev &S = E.S;
   const uint16_t *bcls = E.C.bcls + (size_t)ctl->abuf * E.C.Npad;
@@ -989,6 +1016,7 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
           const unsigned long long t0 = gcn_wall_clock();
           while ((int32_t)(done - seq) < 0 && gcn_wall_clock() - t0 < E.pf_wait_ticks) { gcn_poll_pause(); done = gcn_load_agent(&E.pfsync->done); }
           if ((int32_t)(done - seq) < 0) { wait = (int)seq; ctl->pf_exits += 1; } else ctl->pf_spins += 1;
+          if (E.ktime) E.ktime[KT_PFWAIT] += gcn_wall_clock() - t0;
         }
         ctl->pf_wait = wait;
         // Time to plan the next prefetch (the second stream being free)?  When the rounds reach the batch planned last - or already
@@ -1011,7 +1039,9 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
       if (c >= 0 && c < PLAN_BITS) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
     }
     __syncthreads();
+    const unsigned long long tpl = E.ktime ? gcn_wall_clock() : 0ull;
     plan_prefetch(E, raw, hit / KB_MAX, s_misc, s_tab, s_bits, s_p, s_rd);
+    if (E.ktime && tid == 0) E.ktime[KT_PLAN] += gcn_wall_clock() - tpl;
     return;
   }
   if (tid == 0) {

@@ -23,7 +23,8 @@
 // then read.  Every spin is bounded (GRID_WAIT_S): a launch that cannot become co-resident fails loudly instead of hanging.
 // Nothing here depends on which XCD or in which order blocks run.
 
-constexpr double GRID_WAIT_S = 2.0;     // bound of a barrier wait (the slowest phase is tens of microseconds)
+// bound of a barrier wait: Eng2::grid_wait_ticks (100 MHz ticks; the host scales it with the sample - 2 s + 1 s per 10^6 uniques -
+// the slowest phase of 10^6 uniques being tens of microseconds)
 
 template <int BS>
 struct TailLds {
@@ -76,7 +77,7 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
       for (unsigned n = 1;; n++) {
         if ((int32_t)(gcn_load_agent(&ps->xgen[x][0]) - e1) >= 0) break;
         gcn_poll_pause();
-        if ((n & 63u) == 0u && (gcn_load_agent(&ps->fail) != 0u || gcn_wall_clock() - t0 > (unsigned long long)(GRID_WAIT_S * GCN_WALL_HZ))) { ok = 0; break; }
+        if ((n & 63u) == 0u && (gcn_load_agent(&ps->fail) != 0u || gcn_wall_clock() - t0 > E.grid_wait_ticks)) { ok = 0; break; }
       }
       if (!ok) tail_fail(E, fail_code);
     }
@@ -97,7 +98,7 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
         for (unsigned n = 1;; n++) {
           if ((int32_t)(gcn_load_agent(&ps->gen) - (epoch + 1u)) >= 0) break;
           gcn_poll_pause();
-          if ((n & 63u) == 0u && (gcn_load_agent(&ps->fail) != 0u || gcn_wall_clock() - t0 > (unsigned long long)(GRID_WAIT_S * GCN_WALL_HZ))) { ok = 0; break; }
+          if ((n & 63u) == 0u && (gcn_load_agent(&ps->fail) != 0u || gcn_wall_clock() - t0 > E.grid_wait_ticks)) { ok = 0; break; }
         }
         if (!ok) tail_fail(E, fail_code);
       } else if (fail_code == TAIL_FAIL_ENTRY && gcn_load_agent(&ps->fail) != 0u) ok = 0;   // (the others gave up waiting for this block: leave with them)
@@ -258,7 +259,10 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       KT_LAP(KT_SL_BAR);
       moved += out->cnt[level];
       level++;
-      if (out->cnt[level - 1] == 0) break;                // the call moved nothing: the round is decided
+      if (out->cnt[level - 1] == 0) {                     // the call moved nothing: the attempt stood, the round is decided
+        if (E.greedy) spec_locks_flush<BS>(E, L.pu, out); // (before the block can leave the launch: the locks belong to this round)
+        break;
+      }
     }
     const bool leave = ctl->kexit != 0;
     if (L.last) {
@@ -275,43 +279,50 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
 #undef KT_LAP
 }
 
-// How many blocks of the persistent tail can be resident on the device at once (0: the query failed).  The launch is an ordinary
-// one - nothing but this check and the bounded entry barrier stands between a grid that cannot be co-resident and a hang.
-int tail_resident_max(int device, int bs) {
-  static int cap[2][64] = {{0}, {0}};
-  const int d = device & 63, w = bs == 512 ? 1 : 0;
-  if (!cap[w][d]) {
-    int per_cu = 0;
+// Per-device facts of the persistent tail, established ONCE per device and process (std::call_once: dada2hip_run_multi's host threads
+// come through here side by side): the CU count, the dynamic-LDS attribute of both instances, and how many blocks of each the
+// device can hold at once.  cap: > 0 blocks, 0 = the kernel cannot be resident at all (its LDS does not fit this part, or the
+// attribute was refused: the run then goes to the launch chains instead of failing at its first launch), -1 = the query failed
+// (unknown: the bounded entry barrier is what stands between a grid that cannot be co-resident and a hang).
+struct TailDev {
+  std::once_flag once;
+  int ncu = 64;
+  int cap[2] = {-1, -1};            // [0]: 1024-thread blocks, [1]: 512
+};
+static TailDev &tail_dev(int device) {
+  static TailDev devs[64];
+  TailDev &d = devs[device & 63];
+  std::call_once(d.once, [&]() {
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (have_cur && cur != device) (void)hipSetDevice(device);
     hipDeviceProp_t prop;
-    const hipError_t e = w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k3_tail<512>, 512, sizeof(TailLds<512>))
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k3_tail<1024>, 1024, sizeof(TailLds<1024>));
-    if (e != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    cap[w][d] = std::max(0, per_cu) * std::max(1, prop.multiProcessorCount);
-    if (!cap[w][d]) cap[w][d] = -1;
-  }
-  return std::max(0, cap[w][d]);
+    const bool have_prop = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0;
+    if (have_prop) d.ncu = prop.multiProcessorCount;
+    for (int w = 0; w < 2; w++) {
+      const void *fn = w ? (const void *)k3_tail<512> : (const void *)k3_tail<1024>;
+      const int bs = w ? 512 : 1024;
+      const size_t lds = w ? sizeof(TailLds<512>) : sizeof(TailLds<1024>);
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); d.cap[w] = 0; continue; }
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, bs, lds) != hipSuccess || !have_prop) { (void)hipGetLastError(); d.cap[w] = -1; continue; }
+      d.cap[w] = std::max(0, per_cu) * d.ncu;
+    }
+    if (have_cur && cur != device) (void)hipSetDevice(cur);
+  });
+  return d;
 }
+int tail_resident_max(int device, int bs) { return tail_dev(device).cap[bs == 512 ? 1 : 0]; }
 int tail_grid(int N, int device) {
-  static int ncu[64] = {0};
-  const int d = device & 63;
-  if (!ncu[d]) {
-    hipDeviceProp_t prop;
-    ncu[d] = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
-  }
   // one block (of 1024 or 512 threads) per CU at most (they have to be co-resident); 4096 uniques per block at 10^6 uniques
   const int want = (N + 4095) / 4096;
-  return std::max(1, std::min(want, ncu[d]));
+  return std::max(1, std::min(want, tail_dev(device).ncu));
 }
 void launch3_tail(const Eng2 &E, int grid, int bs, bool first, int ordinal, uint32_t init_reads, hipStream_t st) {
   BudKey init{1.0, init_reads};
-  static bool attr_set[64] = {false};
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
-  if (!attr_set[dev_ & 63]) {
-    (void)hipFuncSetAttribute((const void *)k3_tail<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailLds<1024>));
-    (void)hipFuncSetAttribute((const void *)k3_tail<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailLds<512>));
-    attr_set[dev_ & 63] = true;
-  }
+  (void)tail_dev(dev_);                                    // (the dynamic-LDS attribute of both instances is set there)
   if (bs == 512) hipLaunchKernelGGL(k3_tail<512>, dim3(grid), dim3(512), sizeof(TailLds<512>), st, E, init, first ? 1 : 0, ordinal);
   else hipLaunchKernelGGL(k3_tail<1024>, dim3(grid), dim3(1024), sizeof(TailLds<1024>), st, E, init, first ? 1 : 0, ordinal);
 }

@@ -28,6 +28,15 @@ class Derep:
     def nraw(self) -> int:
         return len(self.seqs)
 
+    def qmax(self) -> int:
+        """``ceiling(max(derep$quals, na.rm=TRUE))`` (R/dada.R:307), taken once per object: the quality matrix is 2 GB at 10^6
+        uniques x 250 nt, and the pass loop of ``dada()`` asked for it in every pass."""
+        q = self.__dict__.get("_qmax")
+        if q is None:
+            q = int(np.ceil(np.nanmax(self.quals)))
+            self.__dict__["_qmax"] = q
+        return q
+
 
 TRANS_NAMES = [a + "2" + b for a in "ACGT" for b in "ACGT"]  # A2A, A2C, ..., T2T (R/dada.R:362)
 

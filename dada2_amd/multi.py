@@ -75,7 +75,7 @@ def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts 
         dev_index = device.index if device is not None and getattr(device, "index", None) is not None else 0
         make_runner = lambda d: Sample.from_derep(d, device=dev_index)   # noqa: E731
     runners = {i: make_runner(dereps[i]) for i in mine}
-    qmax_all = max(int(np.ceil(np.nanmax(d.quals))) for d in dereps)
+    qmax_all = max(d.qmax() for d in dereps)
     maxcol = max_col or max(41, qmax_all + 1, 0 if err is None else np.asarray(err).shape[1])
     initialize = self_consist and err is None
     nconsist = 0 if initialize else 1
@@ -88,7 +88,7 @@ def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts 
             used = {}
             def one(i):
                 d = dereps[i]
-                qmax = int(np.ceil(np.nanmax(d.quals)))
+                qmax = d.qmax()
                 erri = np.ones((16, max(41, qmax + 1))) if initialize else extend_err(err, qmax)
                 return i, erri, runners[i].run(erri, o, max_clust=1 if initialize else None)
             # a rank's samples `inflight` at a time (threads; the library call releases the GIL): the rounds of one sample fill the

@@ -128,6 +128,12 @@ typedef struct dada2hip_stats {
   uint32_t tail_threads, overlap_on;
   double dev_ms_pf_screen, dev_ms_pf_nw;
   uint32_t tail_xcd_barrier, reserved2;   /* 1: the persistent launches of the run used the XCD-hierarchical grid barrier */
+  /* host wall of what stands in front of the rounds: setup = state buffers, memsets, the host mirror of b_init; round0 = the
+   * comparison of every unique with the first centre (Rmain.cpp:309-310) up to the first enqueue of the rounds */
+  double ms_setup, ms_round0;
+  /* under DADA2HIP_PROFILE=1: what the serial end of the rounds spent spinning for a prefetch compare still in flight, and
+   * planning the next prefetch (both are part of tail_ms_birth) */
+  double tail_ms_pf_wait, tail_ms_pf_plan;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------

@@ -244,6 +244,11 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V3_SPEC_MAX": "1000000000"},
     {"DADA2HIP_V3_SPEC_MAX": "1000000000", "DADA2HIP_V3_GRID": "6", "DADA2HIP_V3_OVERLAP": "0"},
     {"DADA2HIP_V3_SPEC": "0"},
+    # ... and attempts only behind calls that moved <= 2 / <= 3 uniques: attempts that stand, attempts that are void and PLAIN calls
+    # mix within one round (a lock decided by a void attempt must never be seen by anybody - the locks of an attempt are
+    # published only once it stands, Eng2::spec_lock_buf)
+    {"DADA2HIP_V3_SPEC_MAX": "2"},
+    {"DADA2HIP_V3_SPEC_MAX": "3", "DADA2HIP_V3_GRID": "5", "DADA2HIP_V3_PF_EARLY": "0"},
     # the XCD-hierarchical grid barrier (default from 48 blocks on) forced onto small grids, and the flat one forced onto the defaults
     {"DADA2HIP_V3_XBAR": "1", "DADA2HIP_V3_GRID": "9"},
     {"DADA2HIP_V3_XBAR": "1", "DADA2HIP_V3_GRID": "64", "DADA2HIP_V2_MOV_INLINE": "64"},
@@ -251,7 +256,8 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
 ], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph",
         "tail-grid7-pauses-ring2-fcap", "chains", "chains-chain1-biglists", "chains-nolite-commit",
         "tail-serial", "overlap-host-launched", "overlap-sync-grid5", "overlap-leave-at-once-nbuf4",
-        "evaluate-on-every-call", "evaluate-on-every-call-grid6-serial", "evaluate-apart",
+        "evaluate-on-every-call", "evaluate-on-every-call-grid6-serial", "evaluate-apart", "attempts-and-plain-calls-mixed",
+        "attempts-and-plain-calls-mixed-grid5",
         "xcd-barrier-grid9", "xcd-barrier-grid64-pauses", "flat-barrier"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--uniques", type=int, default=0)
+    ap.add_argument("--deep", action="store_true", help="bench.py's --deep variant of the configuration (28 reads per unique at config 2)")
     ap.add_argument("settings", nargs="*")
     ap.add_argument("--list", default="", help="settings separated by ';'")
     a = ap.parse_args()
@@ -31,7 +32,7 @@ def main():
         _lib.LIB_PATH = os.environ["DADA2HIP_LIB"]
     from dada2_amd import api
     from dada2_amd.opts import DadaOpts
-    args = types.SimpleNamespace(uniques=a.uniques, length=0, variants=0, deep=False)
+    args = types.SimpleNamespace(uniques=a.uniques, length=0, variants=0, deep=a.deep)
     dereps, inputs, err, mine, c = bench.make_inputs(a.config, args, 0)
     d = dereps[0]
     opts = DadaOpts(BAND_SIZE=c["band"])
