@@ -475,7 +475,10 @@ def phases(st, prof):
            "moves": st["nmoves"], "batch_compares": st["batch_compares"],
            "chains_without_compare": st["lite_chains"], "of_which_needed_one": st["lite_misses"],
            "alignments": {"committed_nw": st["nnw"], "committed_gapless": st["ngapless"], "run_for_rounds_nw": st["nnw_run"],
-                          "run_for_rounds_gapless": st["ngapless_run"],
+                          "run_for_rounds_gapless": st["ngapless_run"], "committed_by_the_rounds_nw": st["nnw_rounds"],
+                          "aligned_in_vain_frac": (round(1.0 - st["nnw_rounds"] / st["nnw_run"], 4) if st["nnw_run"] else None),
+                          "pointer_free_pass": {"pairs": st["nnw_fast"], "handed_to_the_full_kernel": st["nnw_retry"]},
+                          "screen_uniques_through_the_exact_walk": st["screen_stage2"],
                           "note": "committed = the reference's counts (round 0 and the final pass included); run_for_rounds = pairs the aligner "
                                   "processed for the batch compares of the rounds, incl. those a later greedy skip or an unused batch position wasted"},
            "host_wall_note": "upload = marshalling + H2D + k-mer build; screen = enqueue of the compare kernels; "

@@ -44,6 +44,7 @@ class CStats(C.Structure):
         ("dev_ms_pf_screen", C.c_double), ("dev_ms_pf_nw", C.c_double),
         ("tail_xcd_barrier", C.c_uint32), ("reserved2", C.c_uint32),
         ("ms_setup", C.c_double), ("ms_round0", C.c_double), ("tail_ms_pf_wait", C.c_double), ("tail_ms_pf_plan", C.c_double),
+        ("nnw_retry", C.c_uint64), ("nnw_fast", C.c_uint64), ("screen_stage2", C.c_uint64), ("nnw_rounds", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -93,7 +93,8 @@ struct dada2hip_sample {
   SampleDev D;
   DevBuf<uint32_t> seq2, heavy, reads;
   DevBuf<uint8_t> qual, nheavy, prior;
-  DevBuf<uint16_t> kord;
+  DevBuf<uint16_t> kord, kmult;
+  DevBuf<uint32_t> kbits;
   DevBuf<int32_t> len, nwflag;
   PinBuf<uint32_t> h_seq2;          // host mirror of the packed sequences (pinned: it is the upload source)
   std::vector<int32_t> h_len;
@@ -368,6 +369,12 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
   s->kord.alloc((size_t)nraw * D.LK);
   s->heavy.alloc((size_t)nraw * std::max(D.HMAX, 1));
   D.kord = s->kord.p; D.heavy = s->heavy.p;
+  // 5-mer presence bitmaps for the batch screen's prefilter: worth their 128 B per unique while a read's k-mers leave most of
+  // the 1024 bits clear (250 nt: ~215 set).  Long reads fill them (1 500 nt: ~800 set, the bound never decides) - none there
+  if (maxlen - KMER_SIZE + 1 <= 512 && knobs().screen_bits != 0) {
+    s->kbits.alloc((size_t)nraw * 32); s->kmult.alloc(nraw);
+    D.kbits = s->kbits.p; D.kmult = s->kmult.p;
+  } else { D.kbits = nullptr; D.kmult = nullptr; }
   launch_build_kmers(D, s->stream);          // overlaps the quality upload below (side stream)
 
   // qualities: raw_new's (uint8) round(mean quality) (containers.cpp:34) is part of the marshalling here as it is in the
@@ -1337,6 +1344,7 @@ struct Run {
   DevBuf<int32_t> v2_i1;
   DevBuf<unsigned long long> v2_smask;
   DevBuf<int32_t> v2_head, v2_blkcount, v2_dlt, v2_movers, v2_slotc, v2_sig, v2_n0d, v2_blist, v2_blistn;
+  DevBuf<unsigned long long> v2_retrytot;   // NwBatch::fast_ctl [4]
   DevBuf<int32_t> v2_bretry, v2_bretryn;   // retry lists of the aligner's pointer-free pass (NwBatch::retry_list / retry_n)
   DevBuf<double> v2_lamB;
   DevBuf<uint32_t> v2_hamB;
@@ -1348,6 +1356,7 @@ struct Run {
   DevBuf<Round2Out> v2_dblk;
   DevBuf<uint16_t> v2_bcls, v2_full, v2_ord;
   DevBuf<uint2> v2_tab8;
+  DevBuf<uint32_t> v2_cbits, v3_pf_cbits;   // Cache2::cbits of the two compare sets
   PinBuf<Round2Out> v2_hblk;
   DevBuf<unsigned long long> v2_trace;   // phase stamps of one traced round (DADA2HIP_V2_TRACE=<sequence number>[:<file>])
   int v2_trace_seq = -1;
@@ -1398,8 +1407,8 @@ struct Run {
     E2.T.lam0 = v2_lam0.p; E2.T.ham0 = v2_ham0.p; E2.T.lam1 = v2_lam1.p; E2.T.ham1 = v2_ham1.p; E2.T.i1 = v2_i1.p; E2.T.smask = v2_smask.p; E2.T.head = v2_head.p; E2.T.blk = v2_blk.p; E2.T.blk_count = v2_blkcount.p;
     E2.T.blk_cap = (int32_t)std::min<size_t>(v2_blk.n, 0x7FFFFFF0u);
     E2.C.NBUF = v2_nbuf; E2.C.bcls = v2_bcls.p; E2.C.slot_centre = v2_slotc.p;
-    E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15;
-    E2.C.lamB = v2_lamB.p; E2.C.hamB = v2_hamB.p; E2.blist = v2_blist.p; E2.blist_n = v2_blistn.p; E2.bretry = v2_bretry.p; E2.bretry_n = v2_bretryn.p;
+    E2.C.tab8 = v2_tab8.p; E2.C.full = v2_full.p; E2.C.ord = v2_ord.p; E2.C.cbits = v2_cbits.p; E2.C.Npad = ((size_t)N + 31) & ~(size_t)15;
+    E2.C.lamB = v2_lamB.p; E2.C.hamB = v2_hamB.p; E2.blist = v2_blist.p; E2.blist_n = v2_blistn.p; E2.bretry = v2_bretry.p; E2.bretry_n = v2_bretryn.p; E2.fast_ctl = v2_retrytot.p;
     E2.ctl = v2_ctl.p; E2.dblk = v2_dblk.p; E2.hblk = v2_hblk.p; E2.dlt = v2_dlt.p; E2.movers = v2_movers.p;
     E2.partial = d_partial.p; E2.ties0 = d_ties0.p; E2.ties1 = d_ties1.p; E2.ccap = ccap;
     E2.sig_list = v2_sig.p + 4; E2.sig_n = v2_sig.p; E2.ties_rec = v2_tiesrec.p;
@@ -1436,7 +1445,10 @@ struct Run {
     E2.pf_ctl = v3_pfctl.p; E2.pf_blist_n = v3_pf_blistn.p; E2.pfsync = v3_pfsync.p;
     {   // how long a round waits inside the launch for a prefetch compare in flight before the launch is left (the host then
         // orders the next launch behind the compare): a few compares' worth - a compare is ~0.6 ms per 10^6 uniques
-      const double us = K.v3_pf_wait_us >= 0 ? (double)K.v3_pf_wait_us : 2000.0 * std::max(1.0, (double)N / 5e5);
+      // (100 us: a tail that waits holds half of the CUs idle beside a compare that would finish sooner on all of them; leaving
+      //  costs a launch and an entry barrier, ~20-30 us.  10^6 uniques, same box: 4 ms bound 128.8 ms / tail 93.0, 100 us 128.3 /
+      //  88.9, none 137 before the bitmaps - profiles/r09d, r09e)
+      const double us = K.v3_pf_wait_us >= 0 ? (double)K.v3_pf_wait_us : 100.0;
       E2.pf_wait_ticks = (unsigned long long)(us * 100.0);
       // the gate of a chain enqueued ahead of its plan (k2_pf_gate): plans come every millisecond or so while rounds run
       v3_pf_gate_on = K.v3_pf_gate_us != 0;
@@ -1453,7 +1465,7 @@ struct Run {
     E2L = E2; E2L.has_compare = 0;
     if (v3_overlap) {
       S2 = s->D; S2.ad_ptr = v3_pf_ad.p; S2.ad_foff = v3_pf_foff.p; S2.ad_desc = v3_pf_fdesc.p;
-      E2P = E2; E2P.S = S2; E2P.ctl = v3_pfctl.p; E2P.C.tab8 = v3_pf_tab8.p; E2P.C.full = v3_pf_full.p; E2P.C.ord = v3_pf_ord.p;
+      E2P = E2; E2P.S = S2; E2P.ctl = v3_pfctl.p; E2P.C.tab8 = v3_pf_tab8.p; E2P.C.full = v3_pf_full.p; E2P.C.ord = v3_pf_ord.p; E2P.C.cbits = v3_pf_cbits.p;
       E2P.blist = v3_pf_blist.p; E2P.blist_n = v3_pf_blistn.p; E2P.bretry = v3_pf_bretry.p; E2P.bretry_n = v3_pf_bretryn.p; E2P.pf_on = 0; E2P.has_compare = 1;
     }
     v2_drop_graph();                 // (captured launches hold the old argument block)
@@ -1495,7 +1507,9 @@ struct Run {
     v2_bretry.alloc((size_t)KB_MAX * (((size_t)N + 31) & ~(size_t)15)); v2_bretryn.alloc(KB_MAX);
     D2_HIP(hipMemsetAsync(v2_blistn.p, 0, 2 * KB_MAX * 4, stq));
     D2_HIP(hipMemsetAsync(v2_bretryn.p, 0, KB_MAX * 4, stq));
-    v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
+    v2_retrytot.alloc(4);
+    D2_HIP(hipMemsetAsync(v2_retrytot.p, 0, 32, stq));
+    v2_slotc.alloc(slots); v2_tab8.alloc(NKMER); v2_cbits.alloc(KB_MAX * 32); v2_full.alloc((size_t)KB_MAX * NKMER); v2_ord.alloc((size_t)KB_MAX * s->D.LK + 64);
     v2_sig.alloc(n + 4); v2_tiesrec.alloc((size_t)2 * TIES_FULL);
     v2_moved.alloc(n); v2_n0d.alloc(2 * SH_LEVELS + 4); v2_statpart.alloc((size_t)4 * 8192);
     D2_HIP(hipMemsetAsync(v2_moved.p, 0, n, stq));
@@ -1588,7 +1602,7 @@ struct Run {
       if (!s->cmp) D2_HIP(hipStreamCreateWithFlags(&s->cmp, hipStreamNonBlocking));
       for (auto &e : v3_pf_ev) if (!e) D2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       const size_t npad = ((size_t)N + 31) & ~(size_t)15;
-      v3_pfctl.alloc(1); v3_pfsync.alloc(1); v3_pf_tab8.alloc(NKMER); v3_pf_full.alloc((size_t)KB_MAX * NKMER);
+      v3_pfctl.alloc(1); v3_pfsync.alloc(1); v3_pf_tab8.alloc(NKMER); v3_pf_cbits.alloc(KB_MAX * 32); v3_pf_full.alloc((size_t)KB_MAX * NKMER);
       v3_pf_ord.alloc((size_t)KB_MAX * s->D.LK + 64); v3_pf_blist.alloc((size_t)2 * KB_MAX * npad); v3_pf_blistn.alloc(2 * KB_MAX);
       v3_pf_bretry.alloc((size_t)KB_MAX * npad); v3_pf_bretryn.alloc(KB_MAX);
       D2_HIP(hipMemsetAsync(v3_pf_bretryn.p, 0, KB_MAX * 4, stq));
@@ -1672,7 +1686,7 @@ struct Run {
       launch2_screen_multi(E2, stq);
       ev_end(rec.ev_screen);
       launch2_batch_lists(E2, stq);
-      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad, v2_bretry.p, v2_bretryn.p};
+      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad, v2_bretry.p, v2_bretryn.p, v2_retrytot.p};
       launch_gapless_batch(s->D, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &v2_ctl.p->state, stq);
       rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
       launch_nw_ad(s->D, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, stq,
@@ -1710,7 +1724,7 @@ struct Run {
     launch2_screen_multi(E2P, st2, /*beside_tail=*/v3_pf_lowreg);
     ev_end(ev);
     launch2_batch_lists(E2P, st2);
-    const NwBatch nb{&pc->nalign, v3_pf_blistn.p, v3_pf_blist.p, pc->acentre, &pc->abuf, E2.C.Npad, v3_pf_bretry.p, v3_pf_bretryn.p};
+    const NwBatch nb{&pc->nalign, v3_pf_blistn.p, v3_pf_blist.p, pc->acentre, &pc->abuf, E2.C.Npad, v3_pf_bretry.p, v3_pf_bretryn.p, v2_retrytot.p};
     launch_gapless_batch(S2, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &pc->state, st2);
     ev = ev_begin(EV_PF_NW, profile_all, false, false, st2);
     launch_nw_ad(S2, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, st2,
@@ -1996,7 +2010,7 @@ struct Run {
       ev_end(rec.ev_screen);
       // ... its survivors through the aligner, all batch positions in one launch (both no-ops on a cache hit) ...
       launch2_batch_lists(E2, stq);
-      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad, v2_bretry.p, v2_bretryn.p};
+      const NwBatch nb{&v2_ctl.p->nalign, v2_blistn.p, v2_blist.p, v2_ctl.p->acentre, &v2_ctl.p->abuf, E2.C.Npad, v2_bretry.p, v2_bretryn.p, v2_retrytot.p};
       launch_gapless_batch(s->D, nb, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, &v2_ctl.p->state, stq);
       rec.ev_nw = ev_begin(EV_NW, profile_all, /*spec=*/true);
       launch_nw_ad(s->D, -1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, ap, s->d_err.p, v2_lamB.p, v2_hamB.p, nullptr, 0, 0, nullptr, stq,
@@ -2070,6 +2084,7 @@ struct Run {
     }
     st.nshuffle += (uint64_t)b.nsh;
     st.nnw += b.stat[0]; st.ngapless += b.stat[1]; st.nshroud += b.stat[2]; st.nskipped += b.stat[3];
+    st.nnw_rounds += b.stat[0];                                // (what the rounds COMMITTED: nnw_run - this = aligned in vain)
     st.nstored += (uint64_t)b.pad0[0];                      // comparisons kept by the chain's store filter
     st.ms_replay += ms_since(t_rep);
     if (b.err_flag & 4) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "N-W Align out of range."};
@@ -2366,6 +2381,11 @@ void sample_run(dada2hip_sample *s, const double *err, int err_ncol, const dada2
     }
   }
   run.st.rounds = (uint32_t)run.bi.size();
+  if (run.use_v2 && run.v2_retrytot.p) {   // (the rounds are over and their streams drained: a plain copy)
+    unsigned long long rt[4] = {0, 0, 0, 0};
+    D2_HIP(hipMemcpy(rt, run.v2_retrytot.p, 32, hipMemcpyDeviceToHost));
+    run.st.nnw_retry = rt[0]; run.st.nnw_fast = rt[1]; run.st.screen_stage2 = rt[3];
+  }
 
   // ---- final alignments (Rmain.cpp:172-236): every member vs its centre, use_kmers = false ----------
   auto t_final = clk::now();

@@ -52,6 +52,12 @@ struct SampleDev {
   uint16_t *kord = nullptr;   // [N][LK]   k-mer id (10 bits) | min(occurrence rank, 63) << 10
   uint32_t *heavy = nullptr;  // [N][HMAX] k-mers occurring > 63 times: id | count << 16
   uint8_t *nheavy = nullptr;  // [N]
+  // which of the 1024 5-mers occur in the unique at all (one bit each, 128 B per unique) and how many of its k-mer positions
+  // repeat an earlier one (kmult = positions - distinct 5-mers): popcount(bits_raw & bits_centre) + kmult is an UPPER bound of the
+  // k-mer overlap sum_k min(a_k, b_k) of kmers.cpp:29-48, which lets the batch screen call most pairs "shrouded" from 128 bytes
+  // without walking the unique's k-mer record (k2_screen_multi).  nullptr: no prefilter (long reads: the bitmaps saturate)
+  uint32_t *kbits = nullptr;  // [N][32]
+  uint16_t *kmult = nullptr;  // [N]
   int32_t *len = nullptr;     // [N]
   uint32_t *reads = nullptr;  // [N]
   uint8_t *prior = nullptr;   // [N]
@@ -225,6 +231,7 @@ struct NwBatch {
   // retry_list ([KB_MAX][stride]) / retry_n[k], zeroed by k2_batch_lists.  nullptr: one launch of the full kernel as before
   int32_t *retry_list = nullptr;
   int32_t *retry_n = nullptr;
+  unsigned long long *fast_ctl = nullptr;   // [0] pairs handed over so far, [1] pairs the pass has looked at, [2] != 0: the pass is off (Eng2::fast_ctl)
 };
 void launch_gapless_batch(const SampleDev &S, const NwBatch &b, const AlignParams &ap, const double *d_err, double *d_lambda,
                           uint32_t *d_ham, const int32_t *d_stop_dev, hipStream_t st);
@@ -346,6 +353,7 @@ struct Ctl2 {
   // was decided: no round may start before PfSync::done >= pf_wait (0: nothing to wait for).
   int32_t pf_seq, pf_bbuf, last_bbuf, pf_wait;
   int32_t prev_bbuf;            // the batch buffer planned before last_bbuf (-1: none since the last miss)
+  int32_t n_miss;               // rounds so far whose centre was not cached (each cost a batch compare in front of a launch)
   // statistics of the run so far: rounds whose centre came out of a prefetched batch; spins for a prefetch in flight that
   // ended in time / that ended with the launch left; centres prefetched
   int32_t pf_hits, pf_spins, pf_exits, pf_centres;
@@ -362,6 +370,7 @@ struct Cache2 {
   uint2 *tab8 = nullptr;          // [1024]  byte k = min(count of the 5-mer in batch centre k, 63) + 0x7F
   uint16_t *full = nullptr;       // [KB_MAX][1024] full counts (heavy k-mer correction)
   uint16_t *ord = nullptr;        // [KB_MAX][LK] ordered 5-mers, 0xFFFF past the end
+  uint32_t *cbits = nullptr;      // [KB_MAX][32] presence bitmaps of the batch's centres (SampleDev::kbits rows; zeros past the batch)
   // lambda / hamming of the batch's alignments, row = cache slot (batch buffer * KB_MAX + position): written by the ONE
   // aligner launch that follows a batch screen, read (sparsely: NW / gapless classes only) when the slot's round commits
   double *lamB = nullptr;         // [NBUF * KB_MAX][Npad]
@@ -417,6 +426,7 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   int32_t *stat_n;                // number of entries in stat_part (0: the chain had no store pass), consumed by k2_birth
   int32_t *blist, *blist_n;       // [2 KB_MAX][Npad] / [2 KB_MAX]: work lists of the batch compare (NwBatch)
   int32_t *bretry, *bretry_n;     // [KB_MAX][Npad] / [KB_MAX]: NwBatch::retry_list / retry_n of that compare (nullptr: no pointer-free pass)
+  unsigned long long *fast_ctl;   // [4] the run's NwBatch::fast_ctl words (shared by the compares of both streams)
   void *partial;                  // block partials of the bud arg-min
   int32_t *ties0, *ties1;         // full tie lists
   BudTie *ties_rec;               // [2][TIES_FULL] full records of the first TIES_FULL listed candidates per track

@@ -63,11 +63,20 @@ __global__ __launch_bounds__(64) void k_build_kmers(SampleDev S) {
       }
       for (int i = nk; i < S.LK; i++) ko[i] = 0xFFFFu;
       int nh = 0;
-      if (S.HMAX > 0)
-        for (int k = 0; k < NKMER; k++) {
-          uint32_t c = t[k * 64];
-          if (c > RANK_SAT) S.heavy[(size_t)r * S.HMAX + nh++] = (uint32_t)k | (c << 16);
+      if (S.HMAX > 0 || S.kbits) {
+        int distinct = 0;
+        for (int w = 0; w < NKMER / 32; w++) {
+          uint32_t bits = 0;
+          for (int b = 0; b < 32; b++) {
+            const int k = 32 * w + b;
+            const uint32_t c = t[k * 64];
+            if (c) { bits |= 1u << b; distinct++; }
+            if (S.HMAX > 0 && c > RANK_SAT) S.heavy[(size_t)r * S.HMAX + nh++] = (uint32_t)k | (c << 16);
+          }
+          if (S.kbits) S.kbits[(size_t)r * 32 + w] = bits;
         }
+        if (S.kmult) S.kmult[r] = (uint16_t)min(max(nk, 0) - distinct, 65535);
+      }
       S.nheavy[r] = (uint8_t)nh;
     }
   }
@@ -466,6 +475,13 @@ struct NwArgs {
   // keeps no pointers, so it cannot finish them - go to row k of retry_list / retry_n[k], which the full kernel works through next
   int32_t *retry_list;
   int32_t *retry_n;
+  // fast_ctl[0] = pairs handed over so far in this run, [1] = pairs the pointer-free pass has looked at, [2] != 0: the pass is OFF
+  // for the rest of the run - it handed more than a quarter of its pairs over (reads with indels everywhere: PacBio-style), so two
+  // sweeps cost more than one.  Decided by k2_batch_lists in front of each compare; while off the FAST launch returns at once and
+  // the full kernel, launched on the retry lists, works through the batch's OWN lists instead (alt_list / alt_n)
+  unsigned long long *fast_ctl;
+  const int32_t *alt_list;
+  const int32_t *alt_n;
 };
 
 // shared tail: traceback + lambda.  NPW = pointer words per row.
@@ -1055,6 +1071,17 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
     if (batch) {
       const int nb = *a.batch_on;
       if (nb <= 0) return;
+      if (a.fast_ctl) {
+        const bool off = a.fast_ctl[2] != 0ull;
+        if (FAST) {
+          if (off) return;
+          if (blockIdx.x == 0 && threadIdx.x == 0) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < KB_MAX; k++) tot += k < nb ? (unsigned long long)a.batch_n[k] : 0ull;
+            atomicAdd(&a.fast_ctl[1], tot);
+          }
+        } else if (off && a.alt_list) { a.batch_list = a.alt_list; a.batch_n = a.alt_n; }
+      }
 #pragma unroll
       for (int k = 0; k < KB_MAX; k++) bk[k + 1] = bk[k] + (k < nb ? (a.batch_n[k] + 4 * APW - 1) / (4 * APW) : 0);   // (the gapless rows: k_gapless_batch)
       if ((int)blockIdx.x >= bk[KB_MAX]) return;
@@ -1286,6 +1313,7 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
         } else if (active && !gapless) {
           const int q = atomicAdd(&a.retry_n[kcur], 1);
           a.retry_list[(size_t)kcur * a.batch_stride + q] = r;
+          if (a.fast_ctl) atomicAdd(&a.fast_ctl[0], 1ull);
         }
         done = true; ti = 0; tj = 0;
       }
@@ -1473,9 +1501,11 @@ __global__ __launch_bounds__(256, 4) void k_nw_ad(NwArgs a, const int32_t *__res
 __global__ __launch_bounds__(256) void k_ad_product(const uint16_t *__restrict__ foff, int stride, AdDesc *__restrict__ desc, int nscan,
                                                     const double *__restrict__ err, int nerr, double *__restrict__ lam,
                                                     const int32_t *__restrict__ stop_dev, const int32_t *__restrict__ batch_on,
-                                                    const int32_t *__restrict__ batch_n, int slots_per_slice) {
+                                                    const int32_t *__restrict__ batch_n, int slots_per_slice,
+                                                    const unsigned long long *__restrict__ fast_ctl = nullptr, const int32_t *__restrict__ alt_n = nullptr) {
   extern __shared__ double s_err[];
   if (stop_dev && *stop_dev != 0) return;
+  if (fast_ctl && alt_n && fast_ctl[2] != 0ull) batch_n = alt_n;   // (the pointer-free pass is off: the launch in front worked on the batch's own lists)
   if (batch_on) {   // batch mode: the launch's work slots are known on the device only (the lists' lengths, as k_nw_ad counts them)
     const int nb = *batch_on;
     if (nb <= 0) return;
@@ -1560,21 +1590,22 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
     else if (def) { if (G.edge) D2_LAUNCH_AD(GLV, true, true, false, false); else D2_LAUNCH_AD(GLV, true, false, false, false); } \
     else { if (G.edge) D2_LAUNCH_AD(GLV, false, true, false, false); else D2_LAUNCH_AD(GLV, false, false, false, false); }   \
   } while (0)
-  auto product = [&](const int32_t *list_n) {   // the products of what a launch aligned (its work slots: ids below the bound)
+  auto product = [&](const int32_t *list_n, const unsigned long long *fctl = nullptr, const int32_t *alt_n = nullptr) {   // the products of what a launch aligned (its work slots: ids below the bound)
     if (!(S.ad_foff && a.moves_stride == 0)) return;
     const int nerr = 16 * ap.ncol;
     long long bound = batch ? (long long)S.ad_fcap : (long long)((maxwork + (d_gl_work ? S.N : 0) + 4 * G.APW - 1) / (4 * G.APW) + 1) * 4 * G.APW;
     const int nscan = (int)std::min<long long>(bound, S.ad_fcap);
     const int pgrid = std::max(1, std::min((nscan + 255) / 256, 2048));
     hipLaunchKernelGGL(k_ad_product, dim3(pgrid), dim3(256), (size_t)nerr * 8, st, (const uint16_t *)S.ad_foff, (int)S.ad_fstride, S.ad_desc, nscan, d_err, nerr,
-                       d_lambda, d_stop_dev, batch ? batch->on : nullptr, list_n, 4 * G.APW);
+                       d_lambda, d_stop_dev, batch ? batch->on : nullptr, list_n, 4 * G.APW, fctl, alt_n);
   };
   if (fast) {
-    a.retry_list = batch->retry_list; a.retry_n = batch->retry_n;
+    a.retry_list = batch->retry_list; a.retry_n = batch->retry_n; a.fast_ctl = batch->fast_ctl;
     if (G.GL == 21) D2_LAUNCH_AD2(21, true);
     else if (G.GL == 32) D2_LAUNCH_AD2(32, true);
     else D2_LAUNCH_AD2(64, true);
     product(batch->n);
+    a.alt_list = a.batch_list; a.alt_n = a.batch_n;                 // (what the full kernel works through while the pass is off)
     a.batch_list = batch->retry_list; a.batch_n = batch->retry_n;   // (rows k < KB_MAX are all either kernel reads)
     a.retry_list = nullptr; a.retry_n = nullptr;
   }
@@ -1583,7 +1614,8 @@ void launch_nw_ad(const SampleDev &S, int centre, const int32_t *d_chunk_centre,
   else D2_LAUNCH_AD2(64, false);
 #undef D2_LAUNCH_AD2
 #undef D2_LAUNCH_AD
-  product(batch ? (fast ? batch->retry_n : batch->n) : nullptr);
+  if (fast) product(batch->retry_n, batch->fast_ctl, batch->n);
+  else product(batch ? batch->n : nullptr);
 }
 
 // Bimera mode: the pairs (query = chunk centre, parent = work item; chunks of nw_ad_apw() slots, -1 = empty slot) aligned by

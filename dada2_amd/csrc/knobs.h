@@ -62,6 +62,7 @@ struct Knobs {
   bool kord_align = false;            // DADA2HIP_KORD_ALIGN=1          (experiment) k-mer rows padded to 64 bytes
   int screen_grid = 2048;             // DADA2HIP_SCREEN_GRID           (experiment) block cap of k_screen
   long long ad_fcap = 0;              // DADA2HIP_AD_FCAP               rows of k_ad_product's offset buffer (tests: the in-kernel product)
+  int screen_bits = 1;                // DADA2HIP_SCREEN_BITS=0         no 5-mer presence bitmaps: the batch screen walks every unique's k-mer record
   int ad_fast = 1;                    // DADA2HIP_AD_FAST=0             batch compares on the full aligner only (no pointer-free first pass)
   int ad_debug = 0;                   // DADA2HIP_AD_DEBUG              profiling build only (make prof): skips phases of k_nw_ad, results void
   bool bimera_times = false;          // DADA2HIP_BIMERA_TIMES=1        stderr: host / device split of a bimera call
@@ -110,7 +111,7 @@ struct Knobs {
     if (const char *e = S("DADA2HIP_KORD_ALIGN")) k.kord_align = !std::strcmp(e, "1");
     k.screen_grid = I("DADA2HIP_SCREEN_GRID", 2048);
     if (const char *e = S("DADA2HIP_AD_FCAP")) k.ad_fcap = std::atoll(e);
-    k.ad_debug = I("DADA2HIP_AD_DEBUG", 0); k.ad_fast = I("DADA2HIP_AD_FAST", 1);
+    k.ad_debug = I("DADA2HIP_AD_DEBUG", 0); k.ad_fast = I("DADA2HIP_AD_FAST", 1); k.screen_bits = I("DADA2HIP_SCREEN_BITS", 1);
     if (const char *e = S("DADA2HIP_BIMERA_TIMES")) k.bimera_times = !std::strcmp(e, "1");
     if (const char *e = S("DADA2HIP_DEREP_INFLATE")) k.derep_zlib = !std::strcmp(e, "zlib");
     if (const char *e = S("DADA2HIP_DEREP_TIMES")) k.derep_times = !std::strcmp(e, "1");
@@ -134,7 +135,7 @@ inline bool same(const Knobs &a, const Knobs &b) {
          a.v3_fail_entry == b.v3_fail_entry && a.v3_spec == b.v3_spec && a.v3_xbar == b.v3_xbar && a.v3_spec_max == b.v3_spec_max && a.v3_pf_early == b.v3_pf_early && a.v3_pf_lowreg == b.v3_pf_lowreg && a.v3_pf_sync == b.v3_pf_sync && a.v3_pf_gate_us == b.v3_pf_gate_us && a.v2_debug == b.v2_debug && a.v2_summary == b.v2_summary && a.v2_trace_on == b.v2_trace_on &&
          a.v2_trace_seq == b.v2_trace_seq && a.v2_trace_file == b.v2_trace_file && a.profile == b.profile && a.node_cap == b.node_cap &&
          a.wait_block == b.wait_block && a.wait_timeout_s == b.wait_timeout_s && a.coop_max == b.coop_max && a.kord_align == b.kord_align &&
-         a.screen_grid == b.screen_grid && a.ad_fcap == b.ad_fcap && a.ad_debug == b.ad_debug && a.ad_fast == b.ad_fast && a.bimera_times == b.bimera_times && a.derep_times == b.derep_times && a.derep_zlib == b.derep_zlib &&
+         a.screen_grid == b.screen_grid && a.ad_fcap == b.ad_fcap && a.ad_debug == b.ad_debug && a.ad_fast == b.ad_fast && a.screen_bits == b.screen_bits && a.bimera_times == b.bimera_times && a.derep_times == b.derep_times && a.derep_zlib == b.derep_zlib &&
          a.host_threads == b.host_threads && a.alloc_cache == b.alloc_cache && a.alloc_cache_gb == b.alloc_cache_gb;
 }
 }  // namespace knobs_detail

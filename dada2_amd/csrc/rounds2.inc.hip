@@ -629,6 +629,9 @@ __global__ __launch_bounds__(256) void k2_batch_lists(Eng2 E) {
   if (ctl->state != 0 || nb == 0) return;
   // (the retry lists of the aligner's pointer-free pass, which follows in the stream, start empty)
   if (blockIdx.x == 0 && threadIdx.x < KB_MAX && E.bretry_n) E.bretry_n[threadIdx.x] = 0;
+  // ... and the pass is switched off for the rest of the run once it has handed more than a quarter of its pairs to the full
+  // kernel (a sweep without pointers costs about 0.8 of one with: beyond that two sweeps lose to one)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && E.fast_ctl && E.fast_ctl[1] >= 2048ull && 4ull * E.fast_ctl[0] > E.fast_ctl[1]) E.fast_ctl[2] = 1ull;
   __shared__ int s_cnt[2 * KB_MAX], s_base[2 * KB_MAX];
   const SampleDev &S = E.S;
   const uint16_t *bcls = E.C.bcls + (size_t)ctl->abuf * E.C.Npad;
@@ -898,6 +901,8 @@ static __device__ __forceinline__ void build_batch_tables(const SampleDev &S, co
     }
     C.tab8[id] = make_uint2(lo, hi);
   }
+  if (C.cbits && S.kbits)   // presence bitmaps of the batch's centres (the screen's prefilter): their rows of SampleDev::kbits
+    for (int q = tid; q < KB_MAX * 32; q += blockDim.x) C.cbits[q] = (q >> 5) < nb ? S.kbits[(size_t)bc[q >> 5] * 32 + (q & 31)] : 0u;
 }
 
 // The next batch's compare under the persistent tail (Eng2::pf_on): choose up to KB_MAX of the best candidates
@@ -1023,7 +1028,13 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
         // when they are pf_early positions into the one before it: a compare beside the tail takes longer than the rounds of one
         // batch, so it has to start before the batch in front of it is used up
         // (... and only while the run has the device to itself: Eng2::pf_plan, per launch)
-        const bool due = E.pf_plan && (hb == ctl->last_bbuf || (hb == ctl->prev_bbuf && (hit % KB_MAX) >= E.pf_early));
+        // (... and while the prediction works at all: a run whose rounds keep MISSING the cache - more than one round in eight, where
+        //  a batch that is predicted right serves eight - gains nothing from comparing further down the same candidate order ahead
+        //  of time; it only aligns in vain and slows the tail and the missed batches' own compares.  The deep 100 k workload of
+        //  bench.py, 28 reads per unique: 50 misses in 256 rounds with prefetching, 39 without, 37.0 against 34.9 ms per pass,
+        //  profiles/r09e_sweep_cfg2_deep.jsonl.  The test is made afresh at every opportunity: it comes back when the misses stop)
+        const bool predictable = 8 * ctl->n_miss <= ctl->nclust + 8;
+        const bool due = E.pf_plan && predictable && (hb == ctl->last_bbuf || (hb == ctl->prev_bbuf && (hit % KB_MAX) >= E.pf_early));
         *s_trig = (due && (int32_t)(done - seq) >= 0) ? 1 : 0;
       }
     }
@@ -1053,6 +1064,7 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
     ctl->prev_bbuf = -1; ctl->last_bbuf = bbuf;
     ctl->pf_mask &= ~(1ull << (bbuf & 63));
     ctl->pf_wait = 0;
+    ctl->n_miss += 1;
     s_bc[0] = raw;
     *s_nb = 1;
   }
@@ -1621,8 +1633,8 @@ __global__ __launch_bounds__(256, WAVES) void k2_screen_multi(Eng2 E) {
     while (mask) {
       const int kk = __builtin_ctz(mask);
       mask &= mask - 1;
-      const int dk = __shfl(d, (lane & 48) | kk, 64);
-      const uint32_t dotk = (uint32_t)__shfl((int)dot, (lane & 48) | kk, 64);
+      const int dk = __shfl(d, kk, 16);                      // (lane kk of this lane group)
+      const uint32_t dotk = (uint32_t)__shfl((int)dot, kk, 16);
       const uint16_t *ck = cord + (size_t)kk * S.LK;
       uint32_t ord = 0;
       for (int ch = sub, j = 0; ch < nchunk; ch += 16, j++) {
@@ -1646,18 +1658,116 @@ __global__ __launch_bounds__(256, WAVES) void k2_screen_multi(Eng2 E) {
     code |= __shfl_xor(code, 1, 16); code |= __shfl_xor(code, 2, 16); code |= __shfl_xor(code, 4, 16);
     return code & 0xFFFFu;
   };
-  for (int base16 = gwave * 16; base16 < S.N; base16 += nwaves * 16) {
-    // request everything the four uniques of this lane group need, then work through them
-    const int r0 = base16 + 4 * g;
-    const ScrIn i0 = load(r0), i1 = load(r0 + 1);
-    unsigned long long clsacc = one(r0, i0);
-    const ScrIn i2 = load(r0 + 2);
-    clsacc |= (unsigned long long)one(r0 + 1, i1) << 16;
-    const ScrIn i3 = load(r0 + 3);
-    clsacc |= (unsigned long long)one(r0 + 2, i2) << 32;
-    clsacc |= (unsigned long long)one(r0 + 3, i3) << 48;
-    if (sub == 0 && r0 < S.N) *(unsigned long long *)(bcls + r0) = clsacc;
+  const bool pre = sp.use_kmers && S.kbits != nullptr && S.kmult != nullptr && C.cbits != nullptr;
+  if (!pre) {
+    for (int base16 = gwave * 16; base16 < S.N; base16 += nwaves * 16) {
+      // request everything the four uniques of this lane group need, then work through them
+      const int r0 = base16 + 4 * g;
+      const ScrIn i0 = load(r0), i1 = load(r0 + 1);
+      unsigned long long clsacc = one(r0, i0);
+      const ScrIn i2 = load(r0 + 2);
+      clsacc |= (unsigned long long)one(r0 + 1, i1) << 16;
+      const ScrIn i3 = load(r0 + 3);
+      clsacc |= (unsigned long long)one(r0 + 2, i2) << 32;
+      clsacc |= (unsigned long long)one(r0 + 3, i3) << 48;
+      if (sub == 0 && r0 < S.N) *(unsigned long long *)(bcls + r0) = clsacc;
+    }
+    return;
   }
+  // ---- with the presence bitmaps (SampleDev::kbits): two stages.  STAGE 1 reads 128 bytes per unique - lane `sub` of its group
+  //      two of the 32 bitmap words - and bounds the overlap with every centre of the batch from above:
+  //          sum_k min(a_k, b_k)  <=  |{k : a_k > 0 and b_k > 0}| + sum_k (a_k - 1)+  =  popcount(bits_r & bits_c) + kmult_r,
+  //      so where that bound is below the threshold of kmers.cpp:47 the pair is shrouded whatever its exact overlap is (and a greedy
+  //      skip is decided from reads and lock alone): most uniques get their whole class word here, 55 instructions per lane
+  //      instead of 180 + 16 gathers.  The uniques with a centre the bound does not settle go to a list in LDS.  STAGE 2 takes that
+  //      list through the exact code above, every lane group busy.  The class words are the same either way: stage 1 only ever
+  //      says "shrouded" where the exact overlap, being no larger than the bound, says so too.
+  constexpr int SCR_ITERS = 8, SCR_LIST = SCR_ITERS * 64;      // uniques a block looks at between two flushes of its list
+  __shared__ int s_list[SCR_LIST];
+  __shared__ int s_nlist;
+  __shared__ uint2 s_cbits[KB_MAX][16];
+  if (tid < KB_MAX * 16) s_cbits[tid >> 4][tid & 15] = ((const uint2 *)C.cbits)[tid];
+  if (tid == 0) s_nlist = 0;
+  __syncthreads();
+  const int wv = tid >> 6, grp = tid >> 4;
+  auto flush = [&]() __attribute__((always_inline)) {
+    __syncthreads();
+    const int n = s_nlist;
+    for (int q = grp; q < ((n + 15) & ~15); q += 32) {          // (wave-uniform trip count: the exact code ballots over the wave)
+      // (a group without an entry of its own walks the list's first unique again and stores nothing: every lane of the wave goes
+      //  through the same cross-lane operations)
+      const bool ha = q < n, hb = q + 16 < n;
+      const int ra = ha ? s_list[q] : s_list[0], rb = hb ? s_list[q + 16] : s_list[0];
+      const ScrIn ia = load(ra), ib = load(rb);
+      const uint32_t ca = one(ra, ia), cb = one(rb, ib);
+      if (sub == 0 && ha) bcls[ra] = (uint16_t)ca;
+      if (sub == 0 && hb) bcls[rb] = (uint16_t)cb;
+    }
+    __syncthreads();
+    if (tid == 0) { if (n && E.fast_ctl) atomicAdd(&E.fast_ctl[3], (unsigned long long)n); s_nlist = 0; }   // (statistics: uniques that needed stage 2)
+    __syncthreads();
+  };
+  int iter = 0;
+  for (long long bb = (long long)blockIdx.x * 64; bb < S.N; bb += (long long)gridDim.x * 64, iter++) {
+    const int r0 = (int)bb + 16 * wv + 4 * g;
+    uint2 bw[4];
+    int Ls[4], kms[4];
+    uint32_t rds[4];
+    bool lks[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + u;
+      const bool on = r < S.N;
+      bw[u] = on ? ((const uint2 *)(S.kbits + (size_t)r * 32))[sub] : make_uint2(0u, 0u);
+      Ls[u] = on ? S.len[r] : 0;
+      rds[u] = on ? S.reads[r] : 0u;
+      lks[u] = on && E.greedy && E.P.lock[r];
+      kms[u] = on ? (int)S.kmult[r] : 0;
+    }
+    unsigned long long clsacc = 0;
+    uint32_t survs = 0;                                         // bit u: unique r0 + u goes to stage 2
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + u;
+      uint32_t p[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const uint2 c0 = s_cbits[2 * kk][sub], c1 = s_cbits[2 * kk + 1][sub];
+        const uint32_t n0 = (uint32_t)__popc(bw[u].x & c0.x) + (uint32_t)__popc(bw[u].y & c0.y);
+        const uint32_t n1 = (uint32_t)__popc(bw[u].x & c1.x) + (uint32_t)__popc(bw[u].y & c1.y);
+        p[kk] = n0 | (n1 << 16);
+      }
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {
+        p[0] += __shfl_xor(p[0], o, 16); p[1] += __shfl_xor(p[1], o, 16);
+        p[2] += __shfl_xor(p[2], o, 16); p[3] += __shfl_xor(p[3], o, 16);
+      }
+      const uint32_t pk = (kc & 4) ? ((kc & 2) ? p[3] : p[2]) : ((kc & 2) ? p[1] : p[0]);
+      const int bound = (int)((pk >> ((kc & 1) ? 16 : 0)) & 0xFFFFu) + kms[u];
+      const int d = (Lc < Ls[u] ? Lc : Ls[u]) - KMER_SIZE + 1;
+      const bool skipped = E.greedy && (rds[u] > Rc || (lks[u] && r != Cc));
+      const bool open = kvalid && r < S.N && !skipped && !(bound < thr[d > 0 ? d : 0]);
+      uint32_t code = (kvalid ? (skipped ? (uint32_t)CLS_SKIP : (uint32_t)CLS_SHROUD) : 0u) << (2 * kc);
+      code |= __shfl_xor(code, 1, 16); code |= __shfl_xor(code, 2, 16); code |= __shfl_xor(code, 4, 16);
+      const bool any_open = ((__ballot(open) >> (16 * g)) & 0xFFFFull) != 0ull;
+      if (any_open) survs |= 1u << u;
+      clsacc |= (unsigned long long)(code & 0xFFFFu) << (16 * u);
+    }
+    if (sub == 0 && r0 < S.N) {
+      if (survs == 0) *(unsigned long long *)(bcls + r0) = clsacc;   // (the row is padded: Npad >= N + 15)
+      else {
+        int at = atomicAdd(&s_nlist, __popc(survs));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (r0 + u >= S.N) continue;
+          if ((survs >> u) & 1u) s_list[at++] = r0 + u;
+          else bcls[r0 + u] = (uint16_t)(clsacc >> (16 * u));
+        }
+      }
+    }
+    if ((iter % SCR_ITERS) == SCR_ITERS - 1) flush();
+  }
+  flush();
 }
 
 // post-hoc partition p-value inputs (error.cpp:101-119) from the v2 store

@@ -134,6 +134,16 @@ typedef struct dada2hip_stats {
   /* under DADA2HIP_PROFILE=1: what the serial end of the rounds spent spinning for a prefetch compare still in flight, and
    * planning the next prefetch (both are part of tail_ms_birth) */
   double tail_ms_pf_wait, tail_ms_pf_plan;
+  /* batch compares on the default scores run a pointer-free first pass of the aligner (k_nw_ad<.., FAST>): the pairs it could
+   * not finish - walks with an interior gap - and handed to the full kernel, and the pairs the pass looked at (of nnw_run: the pass
+   * switches itself off for the rest of a run once more than a quarter came back) */
+  uint64_t nnw_retry, nnw_fast;
+  /* batch screens with the 5-mer presence bitmaps: uniques (summed over the batch screens, each up to 8 centres) whose class
+   * word the 128-byte bound did not settle, i.e. that went through the exact k-mer walk */
+  uint64_t screen_stage2;
+  /* NW pairs the rounds committed (nnw without round 0, the final pass and the birth pairs): nnw_run - nnw_rounds were aligned in
+   * vain - their batch position was never used, or a greedy skip dropped the pair when its round committed */
+  uint64_t nnw_rounds;
 } dada2hip_stats;
 
 /* ---- whole-call form: exactly dada_uniques (src/Rmain.cpp:30) ---------------------------------

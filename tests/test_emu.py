@@ -135,6 +135,8 @@ def run_cases(emu_lib, names, env=None, timeout=900):
                                  {"DADA2HIP_V3_SPEC_MAX": "1000000", "DADA2HIP_V3_GRID": "4"}, {"DADA2HIP_V3_SPEC": "0", "DADA2HIP_V3_GRID": "3"},
                                  # ... and only behind calls that moved <= 2 uniques: standing attempts, void attempts and plain calls in one round
                                  {"DADA2HIP_V3_SPEC_MAX": "2", "DADA2HIP_V3_GRID": "3"},
+                                 # the batch screen without its presence bitmaps and the batch aligner without its pointer-free first pass
+                                 {"DADA2HIP_SCREEN_BITS": "0", "DADA2HIP_AD_FAST": "0", "DADA2HIP_V3_GRID": "2"},
                                  # the XCD-hierarchical grid barrier (the default from 48 blocks on) on seven blocks in uneven groups: the
                                  # emulated XCC ids are not in block order and one XCC stays empty
                                  {"DADA2HIP_V3_XBAR": "1", "DADA2HIP_V3_GRID": "7"}, {"DADA2HIP_V3_XBAR": "1", "DADA2HIP_V3_GRID": "5", "DADA2HIP_V2_MOV_INLINE": "8", "DADA2HIP_V3_RING": "2"},
@@ -145,7 +147,7 @@ def run_cases(emu_lib, names, env=None, timeout=900):
                                   "DADA2HIP_NODE_CAP": "1"}],
                          ids=["default", "classic-engine", "lane-kernel", "wide-kernel", "align-at-commit-grid2", "tail-grid3", "tail-grid5-pauses",
                               "tail-grid2-ring1-nbuf1-grow", "tail-serial-grid2", "tail-overlap-no-wait-grid3", "tail-evaluate-on-every-call-grid4",
-                              "tail-evaluate-apart-grid3", "tail-attempts-and-plain-calls-mixed-grid3", "tail-xcd-barrier-grid7", "tail-xcd-barrier-grid5-pauses-ring2", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
+                              "tail-evaluate-apart-grid3", "tail-attempts-and-plain-calls-mixed-grid3", "exact-screen-full-aligner-grid2", "tail-xcd-barrier-grid7", "tail-xcd-barrier-grid5-pauses-ring2", "chains", "chains-align-at-commit", "chains-nolite-nbuf1-biglists",
                               "chains-commit-nbuf1-chain1-grow"])
 def test_emulated_kernels_reproduce_the_reference_goldens(emu_lib, env):
     out = run_cases(emu_lib, ("sam1F_default", "sam1R_default") if not env else ("sam1F_default",), env)   # (CPU suite budget: both only once)

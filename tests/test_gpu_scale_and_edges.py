@@ -248,6 +248,10 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     # mix within one round (a lock decided by a void attempt must never be seen by anybody - the locks of an attempt are
     # published only once it stands, Eng2::spec_lock_buf)
     {"DADA2HIP_V3_SPEC_MAX": "2"},
+    # round 6: the batch screen without its 5-mer presence bitmaps (every unique through the exact k-mer walk) and the batch aligner
+    # without its pointer-free first pass (every pair through the full kernel) - what the defaults above must agree with
+    {"DADA2HIP_SCREEN_BITS": "0", "DADA2HIP_AD_FAST": "0"},
+    {"DADA2HIP_SCREEN_BITS": "0", "DADA2HIP_V2_TAIL": "chain"},
     {"DADA2HIP_V3_SPEC_MAX": "3", "DADA2HIP_V3_GRID": "5", "DADA2HIP_V3_PF_EARLY": "0"},
     # the XCD-hierarchical grid barrier (default from 48 blocks on) forced onto small grids, and the flat one forced onto the defaults
     {"DADA2HIP_V3_XBAR": "1", "DADA2HIP_V3_GRID": "9"},
@@ -256,7 +260,7 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
 ], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph",
         "tail-grid7-pauses-ring2-fcap", "chains", "chains-chain1-biglists", "chains-nolite-commit",
         "tail-serial", "overlap-host-launched", "overlap-sync-grid5", "overlap-leave-at-once-nbuf4",
-        "evaluate-on-every-call", "evaluate-on-every-call-grid6-serial", "evaluate-apart", "attempts-and-plain-calls-mixed",
+        "evaluate-on-every-call", "evaluate-on-every-call-grid6-serial", "evaluate-apart", "attempts-and-plain-calls-mixed", "exact-screen-full-aligner", "exact-screen-chains",
         "attempts-and-plain-calls-mixed-grid5",
         "xcd-barrier-grid9", "xcd-barrier-grid64-pauses", "flat-barrier"])
 def test_round_engines_agree_with_the_reference(env):
