@@ -1567,7 +1567,11 @@ struct Run {
     // which align at commit time) and the cache is deep enough to give a prefetch a buffer of its own.  The tail then runs on
     // 512-thread blocks: half of every CU's registers stay free for the compare's kernels.
     v3_overlap = v3_on && !v2_align_commit && v2_nbuf >= 4 && K.v3_overlap != 0 && N >= 2 && (active_runs(s->device).load() <= 1 || K.v3_overlap == 1);
-    v3_bs = K.v3_block == 512 ? 512 : (K.v3_block == 1024 ? 1024 : (v3_overlap ? 512 : 1024));
+    // (1024-thread blocks: under the overlap the tail takes its CUs WHOLE - ceil(N / 4096) of them for a sample of up to half the
+    //  device, half of the device beyond that (below) - and the compares' kernels have the others to themselves.  Round 5 put
+    //  512-thread blocks beside the compares on every CU up to 5 10^5 uniques: the same time at 10^5 plain uniques (12.9 ms both),
+    //  and 38.3 against 33.9 ms on the deep 10^5 workload, profiles/r09h; DADA2HIP_V3_BLOCK=512 keeps that form for the tests)
+    v3_bs = K.v3_block == 512 ? 512 : 1024;
     {
       // A sample whose 512-thread blocks would sit on more than half of the CUs: the tail takes HALF of the CUs WHOLE instead
       // (1024-thread blocks at 128 registers fill a CU's register file) and the compare's kernels have the other half to

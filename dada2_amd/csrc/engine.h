@@ -353,7 +353,6 @@ struct Ctl2 {
   // was decided: no round may start before PfSync::done >= pf_wait (0: nothing to wait for).
   int32_t pf_seq, pf_bbuf, last_bbuf, pf_wait;
   int32_t prev_bbuf;            // the batch buffer planned before last_bbuf (-1: none since the last miss)
-  int32_t n_miss;               // rounds so far whose centre was not cached (each cost a batch compare in front of a launch)
   // statistics of the run so far: rounds whose centre came out of a prefetched batch; spins for a prefetch in flight that
   // ended in time / that ended with the launch left; centres prefetched
   int32_t pf_hits, pf_spins, pf_exits, pf_centres;

@@ -836,22 +836,52 @@ static __device__ __forceinline__ void plan_select(const Eng2 &E, int raw, int f
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   const int tid = threadIdx.x;
-  const int M = min(*E.sig_n, PLAN_PER * (int)blockDim.x);
+  // EVERY listed candidate is looked at (a deep sample lists tens of thousands, in no order: the first 8 blockDim of them - all
+  // that round 5 looked at - need not hold the best ones, and with 512-thread blocks held half as many: the deep 100 k workload of
+  // bench.py missed the cache 55 times in 256 rounds that way, 38 times with 1024-thread blocks, profiles/r09h).  A thread keeps the
+  // PLAN_PER best keys it has seen - the KB_MAX best of all are among the threads' own KB_MAX best.
+  const int M = *E.sig_n;
+  auto before = [](double p, uint32_t rd, int r, double p2, uint32_t rd2, int r2) __attribute__((always_inline)) -> bool {   // b_bud's order (+ index)
+    return r2 < 0 || p < p2 || (p == p2 && (rd > rd2 || (rd == rd2 && r < r2)));
+  };
   double kp[PLAN_PER];
   uint32_t krd[PLAN_PER];
   int kr[PLAN_PER];
 #pragma unroll
-  for (int j = 0; j < PLAN_PER; j++) {
-    const int q = tid + j * (int)blockDim.x;
-    kr[j] = -1; kp[j] = 0.0; krd[j] = 0;
-    if (q < M) {
-      const int r = E.sig_list[q];
-      bool ok = r != raw && !P.slot0[r];
-      if (ok) {
-        if (r < PLAN_BITS) ok = !((s_bits[r >> 5] >> (r & 31)) & 1u);
-        else for (int t = 0; ok && t < nslots; t++) if (s_tab[t] == r) ok = false;
+  for (int j = 0; j < PLAN_PER; j++) { kr[j] = -1; kp[j] = 0.0; krd[j] = 0; }
+  for (int base = 0; base < M; base += PLAN_PER * (int)blockDim.x) {
+    double np[PLAN_PER];
+    uint32_t nrd[PLAN_PER];
+    int nr[PLAN_PER];
+#pragma unroll
+    for (int j = 0; j < PLAN_PER; j++) {                       // (the chunk's candidates requested together)
+      const int q = base + tid + j * (int)blockDim.x;
+      nr[j] = -1; np[j] = 0.0; nrd[j] = 0;
+      if (q < M) {
+        const int r = E.sig_list[q];
+        bool ok = r != raw && !P.slot0[r];
+        if (ok) {
+          if (r < PLAN_BITS) ok = !((s_bits[r >> 5] >> (r & 31)) & 1u);
+          else for (int t = 0; ok && t < nslots; t++) if (s_tab[t] == r) ok = false;
+        }
+        if (ok) { nr[j] = r; np[j] = P.p[r]; nrd[j] = S.reads[r]; }
       }
-      if (ok) { kr[j] = r; kp[j] = P.p[r]; krd[j] = S.reads[r]; }
+    }
+    if (base == 0) {
+#pragma unroll
+      for (int j = 0; j < PLAN_PER; j++) { kr[j] = nr[j]; kp[j] = np[j]; krd[j] = nrd[j]; }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < PLAN_PER; j++) {                       // a further chunk: each of its candidates against the worst key kept
+      if (nr[j] < 0) continue;
+      int w = 0;
+#pragma unroll
+      for (int k = 1; k < PLAN_PER; k++) if (kr[w] >= 0 && before(kp[w], krd[w], kr[w], kp[k], krd[k], kr[k])) w = k;   // w: an empty place, else the worst key
+      if (before(np[j], nrd[j], nr[j], kp[w], krd[w], kr[w])) {
+#pragma unroll
+        for (int k = 0; k < PLAN_PER; k++) if (k == w) { kr[k] = nr[j]; kp[k] = np[j]; krd[k] = nrd[j]; }
+      }
     }
   }
   for (int sel = first; sel < KB_MAX; sel++) {
@@ -1028,13 +1058,7 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
         // when they are pf_early positions into the one before it: a compare beside the tail takes longer than the rounds of one
         // batch, so it has to start before the batch in front of it is used up
         // (... and only while the run has the device to itself: Eng2::pf_plan, per launch)
-        // (... and while the prediction works at all: a run whose rounds keep MISSING the cache - more than one round in eight, where
-        //  a batch that is predicted right serves eight - gains nothing from comparing further down the same candidate order ahead
-        //  of time; it only aligns in vain and slows the tail and the missed batches' own compares.  The deep 100 k workload of
-        //  bench.py, 28 reads per unique: 50 misses in 256 rounds with prefetching, 39 without, 37.0 against 34.9 ms per pass,
-        //  profiles/r09e_sweep_cfg2_deep.jsonl.  The test is made afresh at every opportunity: it comes back when the misses stop)
-        const bool predictable = 8 * ctl->n_miss <= ctl->nclust + 8;
-        const bool due = E.pf_plan && predictable && (hb == ctl->last_bbuf || (hb == ctl->prev_bbuf && (hit % KB_MAX) >= E.pf_early));
+        const bool due = E.pf_plan && (hb == ctl->last_bbuf || (hb == ctl->prev_bbuf && (hit % KB_MAX) >= E.pf_early));
         *s_trig = (due && (int32_t)(done - seq) >= 0) ? 1 : 0;
       }
     }
@@ -1064,7 +1088,6 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
     ctl->prev_bbuf = -1; ctl->last_bbuf = bbuf;
     ctl->pf_mask &= ~(1ull << (bbuf & 63));
     ctl->pf_wait = 0;
-    ctl->n_miss += 1;
     s_bc[0] = raw;
     *s_nb = 1;
   }
