@@ -994,10 +994,34 @@ static __device__ __forceinline__ void plan_prefetch(const Eng2 &E, int raw, int
   }
 }
 
+// The plan itself, given the LDS layout of apply_birth_and_plan (s_misc + 32: the slot table, if have_tab says it is there already)
+static __device__ __forceinline__ void prefetch_plan_now(const Eng2 &E, int raw, int keepbuf, uint32_t *s_cnt, int *s_misc, bool have_tab) {
+  const Cache2 &C = E.C;
+  const int tid = threadIdx.x;
+  const int nslots = C.NBUF * KB_MAX;
+  int *s_tab = s_misc + 32;
+  uint32_t *s_bits = s_cnt;
+  double *s_p = (double *)(s_cnt + PLAN_BITS / 32);
+  uint32_t *s_rd = (uint32_t *)(s_p + 16);
+  const unsigned long long tpl = E.ktime ? gcn_wall_clock() : 0ull;
+  for (int q = tid; q < PLAN_BITS / 32; q += blockDim.x) s_bits[q] = 0;
+  __syncthreads();
+  for (int q = tid; q < nslots; q += blockDim.x) {
+    const int c = have_tab ? s_tab[q] : C.slot_centre[q];
+    s_tab[q] = c;
+    if (c >= 0 && c < PLAN_BITS) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
+  }
+  __syncthreads();
+  plan_prefetch(E, raw, keepbuf, s_misc, s_tab, s_bits, s_p, s_rd);
+  if (E.ktime && tid == 0) E.ktime[KT_PLAN] += gcn_wall_clock() - tpl;
+}
+
 // hint (optional, the serial end of a round has them at hand; nullptr: read from memory): hint[0] = reads of `raw`,
 // hint[1], hint[2] = Ctl2::n0 / low0 as of now, hint[3] != 0: s_misc + 32 already holds a copy of Cache2::slot_centre
-static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc,
-                                                            const int32_t *hint = nullptr) {
+// defer_prefetch: the plan of the next prefetch compare - nobody but the second stream waits for it - is left to the caller
+// (prefetch_plan_deferred below, behind the release of the other blocks); returns true when one is due
+static __device__ __forceinline__ bool apply_birth_and_plan(const Eng2 &E, int raw, int from, uint32_t *s_cnt /*[KB_MAX][1024]*/, int *s_misc,
+                                                            const int32_t *hint = nullptr, bool defer_prefetch = false) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   Ctl2 *ctl = E.ctl;
@@ -1063,21 +1087,12 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
       }
     }
     plan_aligner(E, raw, hit, 0);
-    if (!E.pf_on) return;
+    if (!E.pf_on) return false;
     __syncthreads();
-    if (!*s_trig) return;
-    for (int q = tid; q < PLAN_BITS / 32; q += blockDim.x) s_bits[q] = 0;
-    __syncthreads();
-    for (int q = tid; q < nslots; q += blockDim.x) {
-      const int c = have_tab ? s_tab[q] : C.slot_centre[q];
-      s_tab[q] = c;
-      if (c >= 0 && c < PLAN_BITS) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
-    }
-    __syncthreads();
-    const unsigned long long tpl = E.ktime ? gcn_wall_clock() : 0ull;
-    plan_prefetch(E, raw, hit / KB_MAX, s_misc, s_tab, s_bits, s_p, s_rd);
-    if (E.ktime && tid == 0) E.ktime[KT_PLAN] += gcn_wall_clock() - tpl;
-    return;
+    if (!*s_trig) return false;
+    if (defer_prefetch) return true;
+    prefetch_plan_now(E, raw, hit / KB_MAX, s_cnt, s_misc, have_tab);
+    return false;
   }
   if (tid == 0) {
     const int bbuf = ctl->next_bbuf;
@@ -1117,6 +1132,7 @@ static __device__ __forceinline__ void apply_birth_and_plan(const Eng2 &E, int r
   build_batch_tables(S, C, nb, s_bc, s_cnt);
   if (tid == 0) { ctl->nbatch = nb; ctl->need_compare = 1; }
   plan_aligner(E, raw, bbuf_now * KB_MAX, nb);
+  return false;
 }
 
 static __device__ __forceinline__ void publish_copy(const Eng2 &E, Round2Out *out, int ring, int seq) {
@@ -1163,7 +1179,12 @@ static __device__ __forceinline__ void clear_block(Round2Out *nx) {
 // publishes.  cs: which of the chain's `nlev` shuffle calls ran and whether the evaluation behind them stands.
 // kord: 0 in a launch chain (k2_birth); the launch ordinal in the persistent tail (k3_tail), which also wants to know whether to
 // leave the launch after this round (Ctl2::kexit) and pauses when the round's movers do not fit the block.
-static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const Chain2 cs, BudKey init, const BudKey *__restrict__ partial, int nblocks, int kord) {
+// go (the persistent tail): called once everything the OTHER blocks read in their next phase is written - it lets them go; what
+// follows it is this block's and the host's alone (the plan of the next prefetch compare, the prefetch fields of the result block)
+struct BirthNoGo { __device__ void operator()() const {} };
+template <typename GO = BirthNoGo>
+static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const Chain2 cs, BudKey init, const BudKey *__restrict__ partial, int nblocks, int kord,
+                                                  GO &&go = GO()) {
   // The section is one block's work while (in the persistent tail) every other block waits: it is written as few dependent
   // memory round trips as the logic allows.  STAGE 1 requests everything that depends on nothing computed here - the scalars
   // thread 0 will want (one lane each, into LDS), the reads deltas, the blocks' statistics and minima, the head of the
@@ -1424,11 +1445,8 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
   if (s_evalok)   // b_p_update has consumed the flags (pval.cpp:24,37)
     for (int k = tid; k < nclust; k += blockDim.x) { P.update_e[k] = 0; P.check_locks[k] = 0; }
   __syncthreads();
-  if (s_halt == H2_NONE) {
-    apply_birth_and_plan(E, s_raw, s_from, s_cnt, s_misc, s_hint);
-    __syncthreads();
-    if (tid == 0) *E.sig_n = 0;                              // consumed: the next evaluation lists afresh
-  }
+  bool plan_due = false;
+  if (s_halt == H2_NONE) plan_due = apply_birth_and_plan(E, s_raw, s_from, s_cnt, s_misc, s_hint, /*defer_prefetch=*/kord != 0);
   D2_TRB(4);
   if (kord && tid == 0) {
     int tot = 0;
@@ -1448,11 +1466,18 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
     }
     ctl->kexit = ex;
   }
+  clear_block(E.dblk + ((ring + 1) % RING2));
+  go();
+  // ---- behind the release of the other blocks (persistent tail): they are in the coming round's commit, which touches none of
+  //      what the plan reads (the candidate list, p-values, the slot table) - the next evaluation, which rewrites the list, lies
+  //      behind a barrier this block has yet to arrive at ----
+  if (plan_due) prefetch_plan_now(E, s_raw, s_misc[1] / KB_MAX, s_cnt, s_misc, /*have_tab=*/true);   // (s_misc[1]: the new centre's cache slot, apply_birth_and_plan's s_hit)
+  __syncthreads();
   if (tid == 0) {
+    if (s_halt == H2_NONE) *E.sig_n = 0;                     // consumed: the next evaluation lists afresh
     out->pf_seq = ctl->pf_seq; out->pf_wait = ctl->pf_wait;
     out->pf_stat[0] = ctl->pf_hits; out->pf_stat[1] = ctl->pf_spins; out->pf_stat[2] = ctl->pf_exits; out->pf_stat[3] = ctl->pf_centres;
   }
-  clear_block(E.dblk + ((ring + 1) % RING2));
 #undef D2_TRB
 }
 

@@ -114,20 +114,28 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
   __syncthreads();
   if (!L.ok) return false;
   if (L.last) {
-    serial();
-    gcn_drain_stores();
-    __syncthreads();                                    // the whole block is through the serial section
-    if (xmode) {
-      if (threadIdx.x == 0) gcn_release_agent();
-      __syncthreads();
-      if (threadIdx.x < 8) gcn_store_agent(&ps->xgen[threadIdx.x][0], xb->epoch + 1u);   // (the write-back is done: lanes of the same wave)
-    } else if (G > 1) {
-      if (threadIdx.x == 0) { gcn_release_agent(); gcn_store_agent(&ps->gen, epoch + 1u); }
-    } else {
-      // one block: its own waves read next what the serial section just wrote (the control block, the new centre's state)
-      if (threadIdx.x == 0) { gcn_release_agent(); gcn_acquire_agent(); }
-      __syncthreads();
-    }
+    // `serial` gets the release as a callable: a section with work that nobody waits for (the plan of the next prefetch compare,
+    // birth_body) lets the other blocks go BEFORE that work and does it while they are in their next phase; a section that does
+    // not call it is released behind its last statement as before
+    bool released = false;
+    auto release = [&]() __attribute__((always_inline)) {
+      gcn_drain_stores();
+      __syncthreads();                                  // the whole block is through what the others will read
+      if (xmode) {
+        if (threadIdx.x == 0) gcn_release_agent();
+        __syncthreads();
+        if (threadIdx.x < 8) gcn_store_agent(&ps->xgen[threadIdx.x][0], xb->epoch + 1u);   // (the write-back is done: lanes of the same wave)
+      } else if (G > 1) {
+        if (threadIdx.x == 0) { gcn_release_agent(); gcn_store_agent(&ps->gen, epoch + 1u); }
+      } else {
+        // one block: its own waves read next what the serial section just wrote (the control block, the new centre's state)
+        if (threadIdx.x == 0) { gcn_release_agent(); gcn_acquire_agent(); }
+        __syncthreads();
+      }
+      released = true;
+    };
+    serial(release);
+    if (!released) release();
   }
   if (xmode) xb->epoch++; else epoch++;
   return true;
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
   if (xb.on && threadIdx.x == 0) { L.xcc = gcn_xcc_id(); gcn_add_agent(&E.psync->xcount[L.xcc][0], 1u); }   // (counted before the entry barrier)
   // entry: every block is resident before any state changes, and ONE block decides whether the host's ring takes the first
   // result block of this launch (the host may still be reading the slot it goes to)
-  if (!grid_sync<BS>(E, L, epoch, G, [&]() {
+  if (!grid_sync<BS>(E, L, epoch, G, [&](auto &&) {
         if (xb.on && threadIdx.x < 8) {
           // every block of the launch has counted itself on its XCC: the launch's group sizes, and a clean slate for its barriers
           PSync *ps = E.psync;
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       // ---- commit of the round's cached comparisons + b_shuffle2 until a call moves nothing (Rmain.cpp:320-325) ----
       shuffle_body<true, BS>(E, L.sh, 0, 0, E.movers, out);
       KT_LAP(KT_S0);
-      if (!grid_sync<BS>(E, L, epoch, G, []() {}, TAIL_FAIL_LATE, &xb)) return;
+      if (!grid_sync<BS>(E, L, epoch, G, [](auto &&) {}, TAIL_FAIL_LATE, &xb)) return;
       KT_LAP(KT_S0_BAR);
       level = 1;
     }
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       if (more && !attempt) {
         shuffle_body<false, BS>(E, L.sh, level, moved, mv, out);
         KT_LAP(KT_SL);
-        if (!grid_sync<BS>(E, L, epoch, G, []() {}, TAIL_FAIL_LATE, &xb)) return;
+        if (!grid_sync<BS>(E, L, epoch, G, [](auto &&) {}, TAIL_FAIL_LATE, &xb)) return;
         KT_LAP(KT_SL_BAR);
         moved += out->cnt[level];
         level++;
@@ -241,18 +249,22 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       if (more) { shuffle_body<false, BS, true>(E, L.sh, level, moved, mv, out, &L.pu, init, (BudKey *)E.partial); KT_LAP(KT_SL); }
       else { pupdate_body<BS>(E, L.pu, level, init, (BudKey *)E.partial); KT_LAP(KT_P); }
       const int lv = level;
-      if (!grid_sync<BS>(E, L, epoch, G, [&]() {
+      if (!grid_sync<BS>(E, L, epoch, G, [&](auto &&release) {
             if (more && out->cnt[lv] != 0) {              // (every thread of the block reads the same settled word)
               if (threadIdx.x == 0) *E.sig_n = 0;         // the attempt is void: its listed candidates go
               return;
             }
             const int nlev = more ? lv + 1 : lv;
             const unsigned long long tb = E.ktime ? gcn_wall_clock() : 0ull;
-            birth_body(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal);
-            if (threadIdx.x == 0) {
-              ctl->pub_seq = ctl->pub_seq + 1;            // (the others find the NEXT round's block through it)
-              if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
-            }
+            // the decision and everything the other blocks read next, THEN their release, then what only this block and the host
+            // need (birth_body calls `go` in between)
+            birth_body(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal, [&]() {
+              if (threadIdx.x == 0) {
+                ctl->pub_seq = ctl->pub_seq + 1;          // (the others find the NEXT round's block through it)
+                if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
+              }
+              release();
+            });
           }, TAIL_FAIL_LATE, &xb))
         return;
       if (!more) { KT_LAP(KT_P_BAR); break; }

@@ -252,6 +252,7 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     # without its pointer-free first pass (every pair through the full kernel) - what the defaults above must agree with
     {"DADA2HIP_SCREEN_BITS": "0", "DADA2HIP_AD_FAST": "0"},
     {"DADA2HIP_SCREEN_BITS": "0", "DADA2HIP_V2_TAIL": "chain"},
+    {"DADA2HIP_V3_BLOCK": "512"},                         # round 5's tail under the overlap: 512-thread blocks beside the compares on every CU
     {"DADA2HIP_V3_SPEC_MAX": "3", "DADA2HIP_V3_GRID": "5", "DADA2HIP_V3_PF_EARLY": "0"},
     # the XCD-hierarchical grid barrier (default from 48 blocks on) forced onto small grids, and the flat one forced onto the defaults
     {"DADA2HIP_V3_XBAR": "1", "DADA2HIP_V3_GRID": "9"},
@@ -260,7 +261,7 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
 ], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph",
         "tail-grid7-pauses-ring2-fcap", "chains", "chains-chain1-biglists", "chains-nolite-commit",
         "tail-serial", "overlap-host-launched", "overlap-sync-grid5", "overlap-leave-at-once-nbuf4",
-        "evaluate-on-every-call", "evaluate-on-every-call-grid6-serial", "evaluate-apart", "attempts-and-plain-calls-mixed", "exact-screen-full-aligner", "exact-screen-chains",
+        "evaluate-on-every-call", "evaluate-on-every-call-grid6-serial", "evaluate-apart", "attempts-and-plain-calls-mixed", "exact-screen-full-aligner", "exact-screen-chains", "tail-512-thread-blocks",
         "attempts-and-plain-calls-mixed-grid5",
         "xcd-barrier-grid9", "xcd-barrier-grid64-pauses", "flat-barrier"])
 def test_round_engines_agree_with_the_reference(env):
