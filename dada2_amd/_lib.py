@@ -42,7 +42,7 @@ class CStats(C.Structure):
         ("pf_compares", C.c_uint64), ("pf_hits", C.c_uint64), ("pf_waits", C.c_uint64), ("pf_exits", C.c_uint64),
         ("pf_centres", C.c_uint64), ("tail_threads", C.c_uint32), ("overlap_on", C.c_uint32),
         ("dev_ms_pf_screen", C.c_double), ("dev_ms_pf_nw", C.c_double),
-        ("tail_xcd_barrier", C.c_uint32), ("reserved2", C.c_uint32),
+        ("tail_xcd_barrier", C.c_uint32), ("tail_mirror", C.c_uint32),
         ("ms_setup", C.c_double), ("ms_round0", C.c_double), ("tail_ms_pf_wait", C.c_double), ("tail_ms_pf_plan", C.c_double),
         ("nnw_retry", C.c_uint64), ("nnw_fast", C.c_uint64), ("screen_stage2", C.c_uint64), ("nnw_rounds", C.c_uint64),
     ]

@@ -1331,6 +1331,7 @@ struct Run {
   void check_errflag(int32_t f) {
     if (f & 1) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "Lambda out-of-range error."};
     if (f & 2) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: comparison store overflow"};
+    if (f & 16) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: the persistent tail's LDS mirror disagrees with the state arrays"};   // (DADA2HIP_V3_MIRROR=2 checks)
   }
 
   // =================================================================================================================
@@ -1433,6 +1434,11 @@ struct Run {
     E2.grid_wait_ticks = (unsigned long long)((2.0 + (double)N / 1e6) * 1e8);   // 100 MHz ticks: 2 s + 1 s per 10^6 uniques
     E2.spec_lock_buf = v3_lockbuf.p; E2.spec_lock_stride = v3_lock_stride;
     E2.spec_eval = K.v3_spec != 0 ? 1 : 0;
+    {   // the tail's LDS mirror of the per-unique facts its sweeps ask for (Eng2::mirror_on): where the uniques one block sweeps fit it
+      const long long per_group = 4096ll * std::max(1, v3_grid);
+      const long long per_block = ((long long)N + per_group - 1) / per_group * 4096ll;
+      E2.mirror_on = (v3_on && K.v3_mirror != 0 && N < (1 << 24) && per_block <= (long long)tail_mirror_cap(s->device, v3_bs)) ? (K.v3_mirror == 2 ? 2 : 1) : 0;   // (2: test knob - every round ends with a comparison of the mirror with the arrays)
+    }
     // grid barriers inside a persistent launch: XCD-hierarchical from 48 blocks on (rounds3.inc.hip::grid_sync; a small grid is
     // faster on the flat one).  (v3_grid is v3_setup's, which runs in front of every bind)
     E2.xbar = K.v3_xbar >= 0 ? K.v3_xbar : (v3_grid >= 48 ? 1 : 0);
@@ -1938,6 +1944,7 @@ struct Run {
       }
     }
     st.tail_xcd_barrier = (E2.xbar && v3_grid > 1) ? 1u : 0u;
+    st.tail_mirror = (v3_enq > 0 && E2.mirror_on) ? 1u : 0u;
     st.tail_launches = (uint64_t)v3_enq; st.tail_pauses = (uint64_t)n_pause; st.tail_blocks = (uint32_t)v3_grid; st.tail_threads = (uint32_t)v3_bs;
     if (knobs().v2_summary && v3_overlap)
       fprintf(stderr, "[v3] overlap: prefetch compares %ld in %ld chains (centres %d)  rounds served from a prefetched batch %d  waits inside the launch %d  launches left for one %d  threads per block %d\n",

@@ -473,6 +473,12 @@ struct Eng2 {   // everything the v2 kernels share, passed by value
   // spec_lock_buf[b * spec_lock_stride ...] and writes them out behind the barrier that made the attempt stand (k3_tail).
   int32_t *spec_lock_buf;
   int32_t spec_lock_stride;                         // entries per block = uniques one block sweeps
+  // 1: every block of the persistent tail keeps, for the life of a launch, one word per unique it sweeps in LDS (the dynamic LDS
+  // behind TailLds: rounds3.inc.hip, "the mirror") - partition, "holds a second stored comparison", lock, "p != 1": what PASS A of
+  // the shuffle and evaluation sweeps asks of every unique.  A unique is swept, and those facts written, by ONE block only (the
+  // birth's new centre excepted, which its owner patches behind the round's last barrier), so the global arrays stay the truth
+  // (every write goes to both) and the mirror is refilled at every launch entry.  DADA2HIP_V3_MIRROR=0 turns it off.
+  int32_t mirror_on;
   // ---- the next batch's compare under the persistent tail: what a prefetch compare works with.  The compare
   //      kernels of the second stream get a copy of this block whose `ctl`, `C.tab8 / full / ord`, `blist / blist_n` and aligner
   //      scratch ARE these (so they run unchanged); the tail's planner fills pf_ctl and clears pf_blist_n ----
@@ -531,6 +537,7 @@ void launch2_posthoc(const Eng2 &E, const int32_t *d_cluster_of_centre, int32_t 
 // device halts or the host's ring fills up.  first: the evaluation behind round 0 (no shuffle).  ordinal: this launch's number.
 int tail_grid(int N, int device);
 int tail_resident_max(int device, int bs);                  // blocks of k3_tail the device can hold at once (occupancy query; 0 = unknown)
+int tail_mirror_cap(int device, int bs);                    // uniques per block the tail's LDS mirror holds (Eng2::mirror_on; 0: its LDS does not fit this part)
 void launch3_tail(const Eng2 &E, int grid, int bs, bool first, int ordinal, uint32_t init_reads, hipStream_t st);   // bs: 1024 or 512 threads per block
 
 // get_lr + get_ham_endsfree (chimera.cpp:211-293) on the move strings k_nw left behind: out[slot] = {left, right, left_oo, right_oo, ham}

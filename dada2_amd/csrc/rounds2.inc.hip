@@ -17,21 +17,33 @@
 #define D2_SHUF_INLINE __forceinline__
 #endif
 // phase stamps of the traced round (Eng2::trace; nullptr in every normal run)
-#define D2_TRACE(KID, PHASE)                                                                                       \
+#define D2_TRACE2(KID, SUBKID, PHASE)                                                                              \
   do {                                                                                                             \
     if (E.trace && threadIdx.x == 0 && (int)blockIdx.x < TRACE_BLOCKS && E.ctl->pub_seq == E.trace_seq)           \
       E.trace[((size_t)(KID) * TRACE_BLOCKS + blockIdx.x) * 8 + (PHASE)] = gcn_clock();                            \
-    D2_KSUB((KID) > 2 ? (KID) : ((KID) == 1 ? 1 : 2), PHASE, blockIdx.x == 0);                                     \
+    D2_KSUB(SUBKID, PHASE, blockIdx.x == 0);                                                                       \
   } while (0)
+#define D2_TRACE(KID, PHASE) D2_TRACE2(KID, KID, PHASE)
+// (a shuffle call: trace slot 1 + level; block 0's sub-phase clocks go to kid 1 for the commit's call and kid 2 for every later one)
+#define D2_TRACE_SH(LEVEL, PHASE) D2_TRACE2(1 + (LEVEL), (LEVEL) == 0 ? 1 : 2, PHASE)
 // persistent tail under DADA2HIP_PROFILE=1: what block 0 (the deciding block for the serial section) spends between the stamps
 // of a phase body, summed over the run: ktime[KT_SUB + 8 kid + phase] (kid 1 = commit + first shuffle call, 2 = later calls,
 // 5 = p-update, 6 = serial end of the round)
+// (the persistent tail accumulates in LDS - D2_KT = s_ktime, flushed to Eng2::ktime once per round by k3_tail: a stamp that is a
+//  read-modify-write of global memory costs the stamping lane a round trip, which the rest of its block then waits for at the
+//  next block barrier - with seven stamps per shuffle call the clocks measured mostly themselves)
+#ifdef D2_TAIL_TU
+static __shared__ unsigned long long s_ktime[KT_N];
+#define D2_KT s_ktime
+#else
+#define D2_KT E.ktime
+#endif
 #define D2_KSUB(KID, PHASE, WHO)                                                                                   \
   do {                                                                                                             \
     if (E.ktime && threadIdx.x == 0 && (WHO)) {                                                                    \
       const unsigned long long now_ = gcn_wall_clock();                                                            \
-      unsigned long long *last_ = E.ktime + KT_SUB_LAST + ((KID) == 6 ? 1 : 0);                                    \
-      if ((PHASE) > 0) E.ktime[KT_SUB + 8 * (KID) + (PHASE)] += now_ - *last_;                                      \
+      unsigned long long *last_ = D2_KT + KT_SUB_LAST + ((KID) == 6 ? 1 : 0);                                      \
+      if ((PHASE) > 0) D2_KT[KT_SUB + 8 * (KID) + (PHASE)] += now_ - *last_;                                        \
       *last_ = now_;                                                                                               \
     }                                                                                                              \
   } while (0)
@@ -48,6 +60,40 @@ static __device__ __forceinline__ int sweep_unique(int grp, int u) {
   const long long chunk = ((long long)(grp * U + u) * (BS / 64) + (t >> 6)) * gridDim.x + blockIdx.x;
   const long long r = chunk * 64 + (t & 63);
   return r > 0x7FFFFFF0ll ? 0x7FFFFFF0 : (int)r;
+}
+
+// ---- the persistent tail's LDS mirror (Eng2::mirror_on): one word per unique a block sweeps, at the place the sweeps visit it
+// (slot = (grp * U + u) * BS + thread, which is mir_slot(r) of the unique r = sweep_unique(grp, u) whatever BS is).  nullptr in
+// the launch chains and wherever the mirror is off: every reader falls back to the global arrays, which stay the truth.
+constexpr uint32_t MIR_I1 = 1u << 31;      // T.i1[r] >= 0: the unique holds a second stored comparison
+constexpr uint32_t MIR_LOCK = 1u << 30;    // P.lock[r]
+constexpr uint32_t MIR_PNE1 = 1u << 29;    // P.p[r] != 1.0
+constexpr uint32_t MIR_CL = 0xFFFFFFu;     // P.clust_of[r] (the host leaves the mirror off where partitions could number 2^24)
+constexpr int MIR_CAP = 8192;              // uniques per block: two groups of 4096 (10^6 uniques on 123 blocks)
+// A second word per unique sits MIR_CAP words behind the first: Store2::smask folded to 32 bits (bit k & 31 for a stored comparison
+// with partition k) - what a filtered shuffle call asks of a unique that holds several (a coarser filter only lists more uniques
+// for PASS B, which decides exactly).
+// With the mirror a sweep is ONE pass over all the slots of the block instead of one per group of 4096 uniques (PASS A costs LDS
+// reads, so nothing is gained by overlapping its loads group by group, and every group costs PASS B's round trips again); the
+// work lists then hold 16-bit slots (| class << 13) instead of 32-bit unique indices, in the same LDS.
+constexpr uint32_t MIR_INVALID = 0x1F000000u;   // the word of a slot behind the last unique (bits no valid word has)
+// A lane's position in an LDS list it appends to, with ONE atomic per wave (every lane of the wave calls it, converged): a sweep
+// appends hundreds of entries per block, and same-address LDS atomics are served one lane at a time
+static __device__ __forceinline__ int wave_push(int *counter, bool want) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0ull) return 0;
+  const int lane = (int)(threadIdx.x & 63u);
+  int base = 0;
+  if (lane == 0) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, 0, 64);
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+static __device__ __forceinline__ int mir_slot(int r) { return ((r >> 6) / (int)gridDim.x) * 64 + (r & 63); }
+static __device__ __forceinline__ int mir_unique(int slot) { return ((((slot >> 6) * (int)gridDim.x) + (int)blockIdx.x) << 6) | (slot & 63); }
+static __device__ __forceinline__ uint32_t mir_fold(unsigned long long m) { return (uint32_t)m | (uint32_t)(m >> 32); }
+static __device__ __forceinline__ void mir_upd(uint32_t *mir, int slot, uint32_t clear, uint32_t set) { mir[slot] = (mir[slot] & ~clear) | set; }
+static __device__ __forceinline__ void mir_set(uint32_t *mir, int r, uint32_t clear, uint32_t set) {
+  if (mir) mir_upd(mir, mir_slot(r), clear, set);
 }
 
 // ---- chain bookkeeping: which shuffle launches of the chain ran, and whether the evaluation after them stands -------
@@ -159,12 +205,13 @@ static __device__ __forceinline__ bool pupd_wanted(const Eng2 &E, const PupdLds<
 // DEFER (an evaluation attempt riding on a shuffle call, shuffle_body<.., SPEC>): the locks it decides go to the block's list in
 // Eng2::spec_lock_buf instead of PartState::lock - k3_tail writes them out once the attempt is known to stand (spec_locks_flush)
 template <int BS, bool DEFER = false>
-static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L, int nexec, int ntab, int nwork, BudKey &b0, BudKey &b1) {
+static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L, int nexec, int ntab, int nwork, BudKey &b0, BudKey &b1, uint32_t *mir = nullptr) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   const int32_t *s_work = L.s_work;
   for (int w = threadIdx.x; w < nwork; w += BS) {
-    const int r = s_work[w];
+    const int slot = mir ? (int)((const uint16_t *)s_work)[w] : 0;
+    const int r = mir ? mir_unique(slot) : s_work[w];
     const int cl = P.clust_of[r];
     const double l = P.comp_lam[r];
     const uint32_t reads = S.reads[r];
@@ -177,6 +224,7 @@ static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L
     if (intab ? L.s_upd[cl] : P.update_e[cl]) {
       p = dev_get_pA(reads, pr, E.detect_singletons != 0, l, ham, prd);
       P.p[r] = p;
+      if (mir) mir_upd(mir, slot, MIR_PNE1, p != 1.0 ? MIR_PNE1 : 0u);
     }
     if (E.greedy && (intab ? L.s_chk[cl] : P.check_locks[cl])) {          // pval.cpp:29-36
       const int c = intab ? L.s_cen[cl] : P.centre_of[cl];
@@ -185,7 +233,7 @@ static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L
         if (DEFER) {
           const int k = atomicAdd(&L.s_nlock, 1);                          // (a block lists a unique at most once per attempt: k < stride)
           if (k < E.spec_lock_stride) E.spec_lock_buf[(size_t)blockIdx.x * E.spec_lock_stride + k] = r;
-        } else P.lock[r] = 1;
+        } else { P.lock[r] = 1; if (mir) mir_upd(mir, slot, 0u, MIR_LOCK); }
       }
     }
     // bud_candidate2 with the values at hand
@@ -205,14 +253,14 @@ static __device__ __forceinline__ void pupd_pass_b(const Eng2 &E, PupdLds<BS> &L
 // locks it decided become visible now.  A new centre the decision has just made is skipped: the birth unlocked it
 // (bi_assign_center, cluster.cpp:377; apply_birth_and_plan) BEFORE this runs, and a lock of its own must not land behind that.
 template <int BS>
-static __device__ __forceinline__ void spec_locks_flush(const Eng2 &E, const PupdLds<BS> &L, const Round2Out *out) {
+static __device__ __forceinline__ void spec_locks_flush(const Eng2 &E, const PupdLds<BS> &L, const Round2Out *out, uint32_t *mir = nullptr) {
   const int n = min(L.s_nlock, E.spec_lock_stride);
   const int skip = out->birth_applied ? E.ctl->centre : -1;
   const int32_t *buf = E.spec_lock_buf + (size_t)blockIdx.x * E.spec_lock_stride;
   if (n == 0) return;                                                     // (uniform: an LDS word)
   for (int k = threadIdx.x; k < n; k += BS) {
     const int r = buf[k];
-    if (r != skip) E.P.lock[r] = 1;
+    if (r != skip) { E.P.lock[r] = 1; mir_set(mir, r, 0u, MIR_LOCK); }
   }
   // the coming round's commit reads lock[] of these very uniques, in other waves of this block: the stores have left the wave
   // before any of them goes on
@@ -268,7 +316,9 @@ struct ShufLds {
   static constexpr int U = BS >= 512 ? 4096 / BS : 2;                        // uniques per thread per group of the sweep (4096 per block in the persistent tail)
   int s_n, s_base, s_an, s_abase, s_keep, s_anyinc, s_nwork;
   unsigned long long s_incmask;                                          // bit (k & 63) of every partition k whose reads rose in the previous call
-  int32_t s_work[U * BS];                                                // the group's uniques that have work to do: index | class << 30
+  // (16-byte aligned: k3_tail lends the 32 KB from here on - every array behind it is rewritten at the start of a call - to the
+  //  serial end of a round, birth_body<EXT_CNT>)
+  alignas(16) int32_t s_work[U * BS];                                    // the group's uniques that have work to do: index | class << 30
   int32_t s_mov[3 * MOVCAP];
   int32_t s_newr[NEWCAP], s_newhead[NEWCAP];
   uint32_t s_newh[NEWCAP];
@@ -294,7 +344,7 @@ struct ShufLds {
 // any time and relies on locks only growing between a compare and its commit.
 template <bool STORE, int BS, bool SPEC = false>
 static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L, int level, int moved_before, int32_t *mv, Round2Out *out,
-                                                   PupdLds<BS> *LP = nullptr, BudKey init = BudKey{1.0, 0u}, BudKey *partial = nullptr) {
+                                                   PupdLds<BS> *LP = nullptr, BudKey init = BudKey{1.0, 0u}, BudKey *partial = nullptr, uint32_t *mir = nullptr) {
   static_assert(!(SPEC && STORE), "the speculative evaluation rides on the calls after the commit's");
   const Ctl2 *ctl = E.ctl;
   constexpr int MOVCAP = ShufLds<BS>::MOVCAP, NEWCAP = ShufLds<BS>::NEWCAP;
@@ -303,7 +353,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   uint32_t *s_newh = L.s_newh, *s_reads = L.s_reads;
   double *s_newl = L.s_newl;
   int8_t *s_sgn = L.s_sgn;
-  D2_TRACE(1 + level, 0);
+  D2_TRACE_SH(level, 0);
   if (threadIdx.x == 0) { s_n = 0; s_an = 0; s_keep = 0; }
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -335,7 +385,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   }
   __syncthreads();
   const bool anyinc = filt ? (s_anyinc != 0 || nclust > ntab) : true;
-  const unsigned long long incmask = filt ? L.s_incmask : ~0ull;
+  const unsigned long long incmask = filt ? (mir ? (unsigned long long)mir_fold(L.s_incmask) : L.s_incmask) : ~0ull;   // (the mirror's masks are folded to 32 bits)
   // the commit of a round: who can move in the round's FIRST call?  Whoever stores a comparison with the new centre now; and,
   // if the previous round ended stable, only the members of the partition the birth took the centre from (its reads fell) -
   // nobody else's home lost reads, and the only partition that gained is the new one
@@ -356,7 +406,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   const uint32_t reads_0 = rd_at(0);
   int my_keep = 0;                                                       // comparisons this thread stored (STORE)
   int my_n0 = 0;                                                         // members partition 0 lost (low half) / gained (high half)
-  D2_TRACE(1 + level, 1);
+  D2_TRACE_SH(level, 1);
   // The sweep in two passes per U * BS uniques of the block.  PASS A, a few instructions per unique with the U uniques of a
   // thread requested together: does the unique hold a second stored comparison (only such a unique can ever move), and - the
   // commit of the round - the class of its comparison with the new centre after the greedy skip, counted.  The rest (most
@@ -367,21 +417,37 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
   // of 10^6 uniques for 12-50 MB of traffic).
   constexpr int U = ShufLds<BS>::U;
   int32_t *s_work = L.s_work;
+  uint16_t *s_work16 = (uint16_t *)L.s_work;                             // (under the mirror: slot | class << 13)
   int &s_nwork = L.s_nwork;
-  for (int grp = 0; (long long)grp * U * BS * gridDim.x < N; grp++) {
+  const int ngrp = (int)(((long long)N + (long long)U * BS * gridDim.x - 1) / ((long long)U * BS * gridDim.x));
+  const int gspan = mir ? ngrp : 1;                                      // groups per pass (the mirror: all of them at once)
+  for (int grp0 = 0; grp0 < ngrp; grp0 += gspan) {
     if (threadIdx.x == 0) { s_nwork = 0; if (SPEC) LP->s_nwork = 0; }
     __syncthreads();
-    {
+    for (int grp = grp0; grp < grp0 + gspan; grp++) {
       int i1s[U], froms[U];
       uint32_t clw[U], rds[U];
-      uint8_t lks[U];
+      uint8_t lks[U], oks[U];
       unsigned long long sms[U];
       double pps[U];
+      const bool need_r = STORE || !mir;                                 // (a sweep over the mirror that reads nothing else needs no index)
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = sweep_unique<BS, U>(grp, u);
-        i1s[u] = -1; froms[u] = 0; clw[u] = 0; rds[u] = 0; lks[u] = 0; sms[u] = 0; pps[u] = 1.0;
-        if (r < N) {
+        const int r = need_r ? sweep_unique<BS, U>(grp, u) : 0;
+        i1s[u] = -1; froms[u] = 0; clw[u] = 0; rds[u] = 0; lks[u] = 0; sms[u] = 0; pps[u] = 1.0; oks[u] = 0;
+        if (mir) {
+          // (the mirror: what is left for memory is the round's class word and the reads at the commit)
+          const uint32_t mw = mir[(grp * U + u) * BS + (int)threadIdx.x];
+          if (!(mw & MIR_INVALID)) {
+            oks[u] = 1;
+            i1s[u] = (mw & MIR_I1) ? 0 : -1;                            // (PASS A only asks whether there is one)
+            froms[u] = (int)(mw & MIR_CL);
+            if (STORE) { clw[u] = cls_row[r]; rds[u] = S.reads[r]; lks[u] = (mw & MIR_LOCK) ? 1 : 0; }
+            if (filt && (mw & MIR_I1)) sms[u] = (unsigned long long)mir[MIR_CAP + (grp * U + u) * BS + (int)threadIdx.x];
+            if (SPEC) pps[u] = (mw & MIR_PNE1) ? 0.0 : 1.0;             // (... and whether p is 1)
+          }
+        } else if (r < N) {
+          oks[u] = 1;
           i1s[u] = T.i1[r];
           if (STORE || filt || SPEC) froms[u] = P.clust_of[r];
           if (STORE) { clw[u] = cls_row[r]; rds[u] = S.reads[r]; lks[u] = P.lock[r]; }
@@ -391,10 +457,10 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = sweep_unique<BS, U>(grp, u);
-        if (r >= N) continue;
+        const int r = need_r ? sweep_unique<BS, U>(grp, u) : 0;
+        const bool ok = oks[u] != 0;
         uint32_t cl = 0;
-        if (STORE) {
+        if (STORE && ok) {
           cl = (clw[u] >> kpos2) & 3u;
           const bool skip = E.greedy && (rds[u] > creads_c || lks[u] != 0);
           if (skip) cl = CLS_SKIP;
@@ -409,17 +475,27 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
           else if (filt) work = sgn_of(froms[u]) < 0 || (anyinc && (sms[u] & incmask) != 0ull);
           else work = true;
         }
-        if (work) s_work[atomicAdd(&s_nwork, 1)] = (int32_t)((uint32_t)r | (cl << 30));
-        if (SPEC && pupd_wanted<BS>(E, *LP, ptab, p1_skip, froms[u], pps[u])) LP->s_work[atomicAdd(&LP->s_nwork, 1)] = r;
+        work = work && ok;
+        const int slot = (grp * U + u) * BS + (int)threadIdx.x;
+        {
+          const int k = wave_push(&s_nwork, work);
+          if (work) { if (mir) s_work16[k] = (uint16_t)((uint32_t)slot | (cl << 13)); else s_work[k] = (int32_t)((uint32_t)r | (cl << 30)); }
+        }
+        if (SPEC) {
+          const bool want = ok && pupd_wanted<BS>(E, *LP, ptab, p1_skip, froms[u], pps[u]);
+          const int k = wave_push(&LP->s_nwork, want);
+          if (want) { if (mir) ((uint16_t *)LP->s_work)[k] = (uint16_t)slot; else LP->s_work[k] = r; }
+        }
       }
     }
     __syncthreads();
-    D2_TRACE(1 + level, 5);
+    D2_TRACE_SH(level, 5);
     const int nwork = s_nwork;
     for (int w = threadIdx.x; w < nwork; w += BS) {
-      const uint32_t item = (uint32_t)s_work[w];
-      const int r = (int)(item & 0x3FFFFFFFu);
-      const uint32_t cl = item >> 30;
+      const uint32_t item = mir ? (uint32_t)s_work16[w] : (uint32_t)s_work[w];
+      const int slot = (int)(item & 0x1FFFu);                            // (the mirror's lists only)
+      const int r = mir ? mir_unique(slot) : (int)(item & 0x3FFFFFFFu);
+      const uint32_t cl = mir ? item >> 13 : item >> 30;
       // one round trip: everything the decision can need (a unique on this list is one in five to ten)
       const int i1 = T.i1[r];
       const int from = P.clust_of[r];
@@ -443,6 +519,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
             if (l * creads_c > em) P.E_minmax[r] = l * creads_c;
             if (r == centre) { P.comp_i[r] = ci; P.comp_lam[r] = l; P.comp_ham[r] = h; }
             T.smask[r] |= 1ull << (ci & 63);
+            if (mir) mir[MIR_CAP + slot] |= 1u << (ci & 31);
           }
         }
       }
@@ -474,7 +551,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
           b = cb->next;
         }
         if (keep) {
-          if (i1 < 0) { T.i1[r] = ci; T.lam1[r] = l; T.ham1[r] = h; }  // the unique's second stored comparison: inline
+          if (i1 < 0) { T.i1[r] = ci; T.lam1[r] = l; T.ham1[r] = h; if (mir) mir[slot] |= MIR_I1; }  // the unique's second stored comparison: inline
           else {
             need_new = head < 0 || hcnt >= 3;
             if (!need_new) {                                           // room in the newest block: append in place
@@ -494,6 +571,7 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
         else if (best_src == 2) best_h = best_cb->ham[best_k];
         else best_h = h;
         P.clust_of[r] = to;
+        if (mir) mir_upd(mir, slot, MIR_CL, (uint32_t)to);
         P.comp_i[r] = to; P.comp_lam[r] = best_l; P.comp_ham[r] = best_h;
         E.moved[r] = 1;
         my_n0 += (from == 0 ? 1 : 0) + (to == 0 ? 0x10000 : 0);
@@ -528,15 +606,16 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
       }
     }
     __syncthreads();                                                     // (the list is rewritten by the next group)
-    D2_TRACE(1 + level, 6);
+    D2_TRACE_SH(level, 6);
     if (SPEC) {
-      if (s_n == 0) pupd_pass_b<BS, true>(E, *LP, level, ptab, LP->s_nwork, eb0, eb1);   // (s_n: uniform, the block is behind a barrier)
+      if (s_n == 0) pupd_pass_b<BS, true>(E, *LP, level, ptab, LP->s_nwork, eb0, eb1, mir);   // (s_n: uniform, the block is behind a barrier)
       __syncthreads();
+      D2_TRACE_SH(level, 7);
     }
   }
   __syncthreads();                                                       // the block's movers / new blocks are all buffered
   if (SPEC && s_n == 0) pupd_finish<BS>(E, *LP, eb0, eb1, partial);
-  D2_TRACE(1 + level, 2);
+  D2_TRACE_SH(level, 2);
   const int nmov = min(s_n, MOVCAP), nnew = min(s_an, NEWCAP);
   if (threadIdx.x == 0) {
     s_base = nmov ? atomicAdd(&out->cnt[level], nmov) : 0;
@@ -592,12 +671,12 @@ static __device__ D2_SHUF_INLINE void shuffle_body(const Eng2 &E, ShufLds<BS> &L
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *E.stat_n = (int32_t)gridDim.x;
   }
-  D2_TRACE(1 + level, 3);
+  D2_TRACE_SH(level, 3);
   for (int k = threadIdx.x; k < ntab; k += BS) {
     const int32_t d = s_delta[k];
     if (d) atomicAdd(&dl[k], d);
   }
-  D2_TRACE(1 + level, 4);
+  D2_TRACE_SH(level, 4);
 }
 
 #ifndef D2_TAIL_TU
@@ -720,7 +799,7 @@ static __device__ __forceinline__ bool bud_candidate2(const Eng2 &E, int r, int 
 }
 
 template <int BS>
-static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L, int nexec, BudKey init, BudKey *__restrict__ partial) {
+static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L, int nexec, BudKey init, BudKey *__restrict__ partial, uint32_t *mir = nullptr) {
   const PartState &P = E.P;
   const SampleDev &S = E.S;
   D2_TRACE(5, 0);
@@ -736,28 +815,38 @@ static __device__ D2_PUPD_INLINE void pupdate_body(const Eng2 &E, PupdLds<BS> &L
   const bool p1_skip = pupd_p1_skip(E);
   int32_t *s_work = L.s_work;
   int &s_nwork = L.s_nwork;
-  for (int grp = 0; (long long)grp * U * BS * gridDim.x < S.N; grp++) {
+  const int ngrp = (int)(((long long)S.N + (long long)U * BS * gridDim.x - 1) / ((long long)U * BS * gridDim.x));
+  const int gspan = mir ? ngrp : 1;                                      // (the mirror: one pass over all the block's slots, shuffle_body)
+  for (int grp0 = 0; grp0 < ngrp; grp0 += gspan) {
     if (threadIdx.x == 0) s_nwork = 0;
     __syncthreads();
-    {
+    for (int grp = grp0; grp < grp0 + gspan; grp++) {
       int cls_[U];
       double ps_[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = sweep_unique<BS, U>(grp, u);
         cls_[u] = -1; ps_[u] = 1.0;
-        if (r < S.N) { cls_[u] = P.clust_of[r]; ps_[u] = P.p[r]; }
+        if (mir) {
+          const uint32_t mw = mir[(grp * U + u) * BS + (int)threadIdx.x];
+          if (!(mw & MIR_INVALID)) { cls_[u] = (int)(mw & MIR_CL); ps_[u] = (mw & MIR_PNE1) ? 0.0 : 1.0; }
+        } else {
+          const int r = sweep_unique<BS, U>(grp, u);
+          if (r < S.N) { cls_[u] = P.clust_of[r]; ps_[u] = P.p[r]; }
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int r = sweep_unique<BS, U>(grp, u), cl = cls_[u];
-        if (cl < 0) continue;
-        if (pupd_wanted<BS>(E, L, ntab, p1_skip, cl, ps_[u])) s_work[atomicAdd(&s_nwork, 1)] = r;
+        const int cl = cls_[u];
+        const bool want = cl >= 0 && pupd_wanted<BS>(E, L, ntab, p1_skip, cl, ps_[u]);
+        const int k = wave_push(&s_nwork, want);
+        if (want) {
+          if (mir) ((uint16_t *)s_work)[k] = (uint16_t)((grp * U + u) * BS + (int)threadIdx.x); else s_work[k] = sweep_unique<BS, U>(grp, u);
+        }
       }
     }
     __syncthreads();
     D2_TRACE(5, 4);
-    pupd_pass_b<BS>(E, L, nexec, ntab, s_nwork, b0, b1);
+    pupd_pass_b<BS>(E, L, nexec, ntab, s_nwork, b0, b1, mir);
     __syncthreads();                                                     // (the list is rewritten by the next group)
     D2_TRACE(5, 5);
   }
@@ -1181,17 +1270,24 @@ static __device__ __forceinline__ void clear_block(Round2Out *nx) {
 // leave the launch after this round (Ctl2::kexit) and pauses when the round's movers do not fit the block.
 // go (the persistent tail): called once everything the OTHER blocks read in their next phase is written - it lets them go; what
 // follows it is this block's and the host's alone (the plan of the next prefetch compare, the prefetch fields of the result block)
+// EXT_CNT / ext_cnt (the persistent tail): the 32 KB of LDS the plan's k-mer tables and bitmaps want are the caller's - k3_tail
+// lends the work lists of its sweeps, which are dead while the serial section runs - instead of a static array of this function
 struct BirthNoGo { __device__ void operator()() const {} };
-template <typename GO = BirthNoGo>
+template <bool EXT_CNT = false, typename GO = BirthNoGo>
 static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const Chain2 cs, BudKey init, const BudKey *__restrict__ partial, int nblocks, int kord,
-                                                  GO &&go = GO()) {
+                                                  GO &&go = GO(), uint32_t *ext_cnt = nullptr) {
   // The section is one block's work while (in the persistent tail) every other block waits: it is written as few dependent
   // memory round trips as the logic allows.  STAGE 1 requests everything that depends on nothing computed here - the scalars
   // thread 0 will want (one lane each, into LDS), the reads deltas, the blocks' statistics and minima, the head of the
   // candidate list, the cache's slot table - in one go; STAGE 2 the p-values of the listed candidates; the ties then sit in
   // LDS for the decision.  (Round 3's form took about fifteen trips, 24 us a round at 10^6 uniques.)
   Ctl2 *ctl = E.ctl;
-  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[KB_MAX * NKMER];
+  uint32_t *s_cnt;
+  if constexpr (EXT_CNT) s_cnt = ext_cnt;
+  else {
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt_own[KB_MAX * NKMER];
+    s_cnt = s_cnt_own;
+  }
   __shared__ int s_misc[32 + NBUF_MAX * KB_MAX];
   __shared__ int s_halt, s_raw, s_from, s_evalok, s_nt[2], s_nnear;
   __shared__ BudKey s_k[2][16];

@@ -90,7 +90,7 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
       const bool tm = E.ktime != nullptr && blockIdx.x == 0;
       const unsigned long long tr0 = tm ? gcn_wall_clock() : 0ull;
       gcn_release_agent();
-      if (tm) E.ktime[KT_RELEASE] += gcn_wall_clock() - tr0;
+      if (tm) s_ktime[KT_RELEASE] += gcn_wall_clock() - tr0;
       const uint32_t t = gcn_add_agent(&ps->arrive, 1u);
       last = t == (epoch + 1u) * (uint32_t)G - 1u;
       if (!last) {
@@ -141,16 +141,66 @@ static __device__ __forceinline__ bool grid_sync(const Eng2 &E, TailLds<BS> &L, 
   return true;
 }
 
+// the launch's dynamic LDS: TailLds, and behind it the mirror's 2 x MIR_CAP words where Eng2::mirror_on says so
 template <int BS>
-__global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first, int ordinal) {
+constexpr size_t tail_lds_bytes(bool mirror) { return ((sizeof(TailLds<BS>) + 15) & ~(size_t)15) + (mirror ? (size_t)MIR_CAP * 8 : 0); }
+
+// Fill the mirror from the global arrays (launch entry, behind the entry barrier's acquire): the same deal of uniques as every sweep
+template <int BS>
+static __device__ __forceinline__ void mir_fill(const Eng2 &E, uint32_t *mir) {
+  constexpr int U = ShufLds<BS>::U;
+  const int N = E.S.N;
+  for (int grp = 0; (long long)grp * U * BS * gridDim.x < N; grp++) {
+    int i1s[U], cls_[U];
+    uint8_t lks[U];
+    double ps_[U];
+    unsigned long long sms[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = sweep_unique<BS, U>(grp, u);
+      i1s[u] = -1; cls_[u] = 0; lks[u] = 0; ps_[u] = 1.0; sms[u] = 0ull;
+      if (r < N) { i1s[u] = E.T.i1[r]; cls_[u] = E.P.clust_of[r]; lks[u] = E.P.lock[r]; ps_[u] = E.P.p[r]; sms[u] = E.T.smask[r]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int slot = (grp * U + u) * BS + (int)threadIdx.x;
+      mir[slot] = sweep_unique<BS, U>(grp, u) < N ? ((uint32_t)cls_[u] & MIR_CL) | (i1s[u] >= 0 ? MIR_I1 : 0u) | (lks[u] ? MIR_LOCK : 0u) | (ps_[u] != 1.0 ? MIR_PNE1 : 0u) : MIR_INVALID;
+      mir[MIR_CAP + slot] = mir_fold(sms[u]);
+    }
+  }
+  __syncthreads();
+}
+
+// test knob (Eng2::mirror_on == 2): the mirror against the arrays it shadows, at the end of a round - a difference is an internal error
+template <int BS>
+static __device__ __forceinline__ void mir_verify(const Eng2 &E, const uint32_t *mir) {
+  constexpr int U = ShufLds<BS>::U;
+  const int N = E.S.N;
+  __syncthreads();
+  for (int grp = 0; (long long)grp * U * BS * gridDim.x < N; grp++)
+    for (int u = 0; u < U; u++) {
+      const int r = sweep_unique<BS, U>(grp, u);
+      if (r >= N) { if (mir[(grp * U + u) * BS + (int)threadIdx.x] != MIR_INVALID) atomicOr(E.P.err_flag, 16); continue; }
+      const uint32_t want = ((uint32_t)E.P.clust_of[r] & MIR_CL) | (E.T.i1[r] >= 0 ? MIR_I1 : 0u) | (E.P.lock[r] ? MIR_LOCK : 0u) | (E.P.p[r] != 1.0 ? MIR_PNE1 : 0u);
+      const int slot = (grp * U + u) * BS + (int)threadIdx.x;
+      if (mir[slot] != want || mir[MIR_CAP + slot] != mir_fold(E.T.smask[r])) atomicOr(E.P.err_flag, 16);
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS, BS == 512 ? 2 : 4) void k3_tail(Eng2 E, BudKey init, int first, int ordinal) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn3[];
   TailLds<BS> &L = *(TailLds<BS> *)s_dyn3;
+  uint32_t *const mir = E.mirror_on ? (uint32_t *)(s_dyn3 + tail_lds_bytes<BS>(false)) : nullptr;
   gcn_raise_priority();                                  // (its waves are few and wait most of the time: when they can issue, they go first)
   Ctl2 *ctl = E.ctl;
   const int G = (int)gridDim.x;
   const bool timer = E.ktime != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long tk = timer ? gcn_wall_clock() : 0ull;
-#define KT_LAP(SLOT) do { if (timer) { const unsigned long long now_ = gcn_wall_clock(); E.ktime[SLOT] += now_ - tk; tk = now_; } } while (0)
+#define KT_LAP(SLOT) do { if (timer) { const unsigned long long now_ = gcn_wall_clock(); s_ktime[SLOT] += now_ - tk; tk = now_; } } while (0)
+  // the block's phase clocks of this launch collect in LDS (rounds2.inc.hip, D2_KT) and are added to Eng2::ktime once per round
+  if (E.ktime) { for (int k = threadIdx.x; k < KT_N; k += BS) s_ktime[k] = 0ull; __syncthreads(); }
+#define KT_FLUSH() do { if (E.ktime) { __syncthreads(); for (int k_ = threadIdx.x; k_ < KT_N; k_ += BS) if (k_ != KT_SUB_LAST && k_ != KT_SUB_LAST + 1) { const unsigned long long v_ = s_ktime[k_]; if (v_) { atomicAdd(&E.ktime[k_], v_); s_ktime[k_] = 0ull; } } } } while (0)
   if (ctl->state != 0) {                                 // halted before the launch (written by an earlier kernel: every block sees it)
     if (blockIdx.x == 0 && threadIdx.x == 0) *E.hexit = ordinal;
     return;
@@ -214,6 +264,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
     if (threadIdx.x == 0) { L.xn = (int)gcn_load_agent(&E.psync->xn[L.xcc][0]); L.ngrp = (int)gcn_load_agent(&E.psync->ngrp); }
     __syncthreads();
   }
+  if (mir) mir_fill<BS>(E, mir);
   KT_LAP(KT_LAUNCH);
   for (int rnd = 0;; rnd++) {
     const int ring = ctl->pub_seq % RING2;
@@ -222,7 +273,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
     const bool shuffles = !(first && rnd == 0);
     if (shuffles) {
       // ---- commit of the round's cached comparisons + b_shuffle2 until a call moves nothing (Rmain.cpp:320-325) ----
-      shuffle_body<true, BS>(E, L.sh, 0, 0, E.movers, out);
+      shuffle_body<true, BS>(E, L.sh, 0, 0, E.movers, out, nullptr, BudKey{1.0, 0u}, nullptr, mir);
       KT_LAP(KT_S0);
       if (!grid_sync<BS>(E, L, epoch, G, [](auto &&) {}, TAIL_FAIL_LATE, &xb)) return;
       KT_LAP(KT_S0_BAR);
@@ -235,7 +286,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       // (the attempt is worth its time when the call is likely to be the round's last: the call before it moved few uniques)
       const bool attempt = more && E.spec_eval && out->cnt[level - 1] <= E.spec_max_prev;
       if (more && !attempt) {
-        shuffle_body<false, BS>(E, L.sh, level, moved, mv, out);
+        shuffle_body<false, BS>(E, L.sh, level, moved, mv, out, nullptr, BudKey{1.0, 0u}, nullptr, mir);
         KT_LAP(KT_SL);
         if (!grid_sync<BS>(E, L, epoch, G, [](auto &&) {}, TAIL_FAIL_LATE, &xb)) return;
         KT_LAP(KT_SL_BAR);
@@ -246,8 +297,8 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       // The round's evaluation (b_p_update + the block minima of b_bud): riding on the shuffle call that is due, on the
       // assumption that the call moves nothing - or, when no call is due any more, as a phase of its own.  The last block to
       // arrive behind an evaluation that stands takes the round's decision.
-      if (more) { shuffle_body<false, BS, true>(E, L.sh, level, moved, mv, out, &L.pu, init, (BudKey *)E.partial); KT_LAP(KT_SL); }
-      else { pupdate_body<BS>(E, L.pu, level, init, (BudKey *)E.partial); KT_LAP(KT_P); }
+      if (more) { shuffle_body<false, BS, true>(E, L.sh, level, moved, mv, out, &L.pu, init, (BudKey *)E.partial, mir); KT_LAP(KT_SL); }
+      else { pupdate_body<BS>(E, L.pu, level, init, (BudKey *)E.partial, mir); KT_LAP(KT_P); }
       const int lv = level;
       if (!grid_sync<BS>(E, L, epoch, G, [&](auto &&release) {
             if (more && out->cnt[lv] != 0) {              // (every thread of the block reads the same settled word)
@@ -258,13 +309,15 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
             const unsigned long long tb = E.ktime ? gcn_wall_clock() : 0ull;
             // the decision and everything the other blocks read next, THEN their release, then what only this block and the host
             // need (birth_body calls `go` in between)
-            birth_body(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal, [&]() {
+            // (its 32 KB of table scratch: the sweeps' work lists, dead until this block's next phase)
+            static_assert(sizeof(ShufLds<BS>) - offsetof(ShufLds<BS>, s_work) >= sizeof(uint32_t) * KB_MAX * NKMER && offsetof(ShufLds<BS>, s_work) % 16 == 0, "ShufLds lends 32 KB to birth_body");
+            birth_body<true>(E, nlev, Chain2{nlev, true}, init, (const BudKey *)E.partial, G, ordinal, [&]() {
               if (threadIdx.x == 0) {
                 ctl->pub_seq = ctl->pub_seq + 1;          // (the others find the NEXT round's block through it)
                 if (E.ktime) { atomicAdd(&E.ktime[KT_BIRTH], gcn_wall_clock() - tb); atomicAdd(&E.ktime[KT_ROUNDS], 1ull); atomicAdd(&E.ktime[KT_LEVELS], (unsigned long long)nlev); }
               }
               release();
-            });
+            }, (uint32_t *)L.sh.s_work);
           }, TAIL_FAIL_LATE, &xb))
         return;
       if (!more) { KT_LAP(KT_P_BAR); break; }
@@ -272,11 +325,20 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
       moved += out->cnt[level];
       level++;
       if (out->cnt[level - 1] == 0) {                     // the call moved nothing: the attempt stood, the round is decided
-        if (E.greedy) spec_locks_flush<BS>(E, L.pu, out); // (before the block can leave the launch: the locks belong to this round)
+        if (E.greedy) spec_locks_flush<BS>(E, L.pu, out, mir); // (before the block can leave the launch: the locks belong to this round)
         break;
       }
     }
     const bool leave = ctl->kexit != 0;
+    if (mir && out->birth_applied) {
+      // the round's birth (apply_birth_and_plan, by the deciding block): the new centre sits in partition nclust - 1 now, unlocked -
+      // the block that sweeps it brings its mirror word up to date before the coming commit reads it (shuffle_body synchronises
+      // the block in front of its sweep)
+      const int raw = ctl->centre;
+      if (threadIdx.x == 0 && (raw >> 6) % G == (int)blockIdx.x) mir_set(mir, raw, MIR_CL | MIR_LOCK, (uint32_t)(ctl->nclust - 1) & MIR_CL);
+    }
+    if (E.mirror_on == 2) mir_verify<BS>(E, mir);
+    KT_FLUSH();
     if (L.last) {
       // the block that took the decision publishes it while the others are already in the next round's first phase
       const unsigned long long tp = E.ktime ? gcn_wall_clock() : 0ull;
@@ -289,6 +351,7 @@ __global__ __launch_bounds__(BS, 4) void k3_tail(Eng2 E, BudKey init, int first,
     if (leave) return;
   }
 #undef KT_LAP
+#undef KT_FLUSH
 }
 
 // Per-device facts of the persistent tail, established ONCE per device and process (std::call_once: dada2hip_run_multi's host threads
@@ -300,6 +363,7 @@ struct TailDev {
   std::once_flag once;
   int ncu = 64;
   int cap[2] = {-1, -1};            // [0]: 1024-thread blocks, [1]: 512
+  bool mirror[2] = {false, false};  // the launch may carry the mirror's LDS behind TailLds (tail_lds_bytes(true) fits a workgroup of this part)
 };
 static TailDev &tail_dev(int device) {
   static TailDev devs[64];
@@ -314,8 +378,19 @@ static TailDev &tail_dev(int device) {
     for (int w = 0; w < 2; w++) {
       const void *fn = w ? (const void *)k3_tail<512> : (const void *)k3_tail<1024>;
       const int bs = w ? 512 : 1024;
-      const size_t lds = w ? sizeof(TailLds<512>) : sizeof(TailLds<1024>);
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); d.cap[w] = 0; continue; }
+      const size_t lds_m = w ? tail_lds_bytes<512>(true) : tail_lds_bytes<1024>(true), lds_0 = w ? tail_lds_bytes<512>(false) : tail_lds_bytes<1024>(false);
+      // with the mirror if the part's LDS takes it (160 KB per workgroup on gfx950), else without
+      size_t lds = lds_m;
+      d.mirror[w] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m) == hipSuccess;
+      if (d.mirror[w]) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, bs, lds_m) == hipSuccess && per_cu <= 0) d.mirror[w] = false;   // (accepted but not resident)
+      }
+      if (!d.mirror[w]) {
+        (void)hipGetLastError();
+        lds = lds_0;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_0) != hipSuccess) { (void)hipGetLastError(); d.cap[w] = 0; continue; }
+      }
       int per_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, bs, lds) != hipSuccess || !have_prop) { (void)hipGetLastError(); d.cap[w] = -1; continue; }
       d.cap[w] = std::max(0, per_cu) * d.ncu;
@@ -325,6 +400,7 @@ static TailDev &tail_dev(int device) {
   return d;
 }
 int tail_resident_max(int device, int bs) { return tail_dev(device).cap[bs == 512 ? 1 : 0]; }
+int tail_mirror_cap(int device, int bs) { return tail_dev(device).mirror[bs == 512 ? 1 : 0] ? MIR_CAP : 0; }
 int tail_grid(int N, int device) {
   // one block (of 1024 or 512 threads) per CU at most (they have to be co-resident); 4096 uniques per block at 10^6 uniques
   const int want = (N + 4095) / 4096;
@@ -335,6 +411,6 @@ void launch3_tail(const Eng2 &E, int grid, int bs, bool first, int ordinal, uint
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
   (void)tail_dev(dev_);                                    // (the dynamic-LDS attribute of both instances is set there)
-  if (bs == 512) hipLaunchKernelGGL(k3_tail<512>, dim3(grid), dim3(512), sizeof(TailLds<512>), st, E, init, first ? 1 : 0, ordinal);
-  else hipLaunchKernelGGL(k3_tail<1024>, dim3(grid), dim3(1024), sizeof(TailLds<1024>), st, E, init, first ? 1 : 0, ordinal);
+  if (bs == 512) hipLaunchKernelGGL(k3_tail<512>, dim3(grid), dim3(512), tail_lds_bytes<512>(E.mirror_on != 0), st, E, init, first ? 1 : 0, ordinal);
+  else hipLaunchKernelGGL(k3_tail<1024>, dim3(grid), dim3(1024), tail_lds_bytes<1024>(E.mirror_on != 0), st, E, init, first ? 1 : 0, ordinal);
 }

@@ -31,6 +31,7 @@
  *   DADA2HIP_V2_TAIL=chain             the round tail as launch chains instead of the persistent kernel
  *   DADA2HIP_V3_OVERLAP=0|1            the next batch's compare under the persistent tail on a second stream (default: on)
  *   DADA2HIP_V3_SPEC=0|1               the evaluation of a round rides on its shuffle calls (default: on; 0 = a phase of its own)
+ *   DADA2HIP_V3_MIRROR=0|1             the persistent tail keeps the per-unique facts its sweeps ask for in LDS (default: on)
  *   DADA2HIP_NW_KERNEL=lane|coop|wide  force one aligner family;  DADA2HIP_AD_HOMO=0  homopolymer gaps on the lane kernels
  *   DADA2HIP_WAIT=block, DADA2HIP_WAIT_TIMEOUT_S=<s>   sleep instead of spin while waiting; bound of every device wait
  *   DADA2HIP_HOST_THREADS=<n>, DADA2HIP_ALLOC_CACHE=0, DADA2HIP_ALLOC_CACHE_GB=<n>   marshalling pool, allocation cache
@@ -127,7 +128,8 @@ typedef struct dada2hip_stats {
   uint64_t pf_compares, pf_hits, pf_waits, pf_exits, pf_centres;
   uint32_t tail_threads, overlap_on;
   double dev_ms_pf_screen, dev_ms_pf_nw;
-  uint32_t tail_xcd_barrier, reserved2;   /* 1: the persistent launches of the run used the XCD-hierarchical grid barrier */
+  uint32_t tail_xcd_barrier;   /* 1: the persistent launches of the run used the XCD-hierarchical grid barrier */
+  uint32_t tail_mirror;        /* 1: ... and kept the per-unique facts their sweeps ask for in LDS for the life of a launch (DADA2HIP_V3_MIRROR) */
   /* host wall of what stands in front of the rounds: setup = state buffers, memsets, the host mirror of b_init; round0 = the
    * comparison of every unique with the first centre (Rmain.cpp:309-310) up to the first enqueue of the rounds */
   double ms_setup, ms_round0;

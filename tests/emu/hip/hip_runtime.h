@@ -96,6 +96,7 @@ inline void __threadfence_block() {}
 inline void __threadfence_system() {}
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned __brev(unsigned x) {
   x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
   x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);

@@ -370,8 +370,12 @@ def test_emulated_entry_barrier_failure_continues_on_the_launch_chains(emu_lib, 
 @pytest.mark.parametrize("env", [{"DADA2HIP_V3_GRID": "4", "DADA2HIP_V2_NBUF": "4", "DADA2HIP_V3_RING": "2"},
                                  {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V2_NBUF": "5", "DADA2HIP_V2_MOV_INLINE": "16", "DADA2HIP_V3_PF_WAIT_US": "0"},
                                  # round 5's form of the tail under the overlap: 512-thread blocks beside the compares on every CU
-                                 {"DADA2HIP_V3_GRID": "3", "DADA2HIP_V3_BLOCK": "512"}],
-                         ids=["grid4-nbuf4-ring2", "grid2-nbuf5-pauses-no-wait", "grid3-512-thread-blocks"])
+                                 {"DADA2HIP_V3_GRID": "3", "DADA2HIP_V3_BLOCK": "512"},
+                                 # round 6: the tail's LDS mirror compared with the state arrays at the end of every round
+                                 # (DADA2HIP_V3_MIRROR=2), with pauses and attempts / plain calls mixed; and the tail without it
+                                 {"DADA2HIP_V3_GRID": "3", "DADA2HIP_V3_MIRROR": "2", "DADA2HIP_V2_MOV_INLINE": "16", "DADA2HIP_V3_SPEC_MAX": "3"},
+                                 {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V3_MIRROR": "0"}],
+                         ids=["grid4-nbuf4-ring2", "grid2-nbuf5-pauses-no-wait", "grid3-512-thread-blocks", "grid3-mirror-checked-pauses", "grid2-no-mirror"])
 def test_emulated_prefetch_compares_under_the_tail_on_a_deeper_sample(emu_lib, env):
     """The next batch's compare planned by the persistent tail and run on the second stream on the 20-partition
     golden: rounds served out of prefetched batches, with the smallest cache that allows it (the buffer whose rows the coming
@@ -388,9 +392,9 @@ def test_emulated_prefetch_compares_under_the_tail_on_a_deeper_sample(emu_lib, e
         "assert_results_equal(got, exp)\n"
         "st = got.stats\n"
         "assert st['overlap_on'] == 1 and st['pf_compares'] >= 1 and st['pf_hits'] >= 2, {k: st[k] for k in ('overlap_on', 'pf_compares', 'pf_hits')}\n"
-        "assert st['tail_threads'] == %d\n"
+        "assert st['tail_threads'] == %d and st['tail_mirror'] == %d, (st['tail_threads'], st['tail_mirror'])\n"
         "print('prefetch: ok', st['pf_compares'], st['pf_hits'], st['pf_exits'])\n"
-    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib, int(env.get("DADA2HIP_V3_BLOCK", "1024")))
+    ) % (ROOT, os.path.join(ROOT, "tests"), emu_lib, int(env.get("DADA2HIP_V3_BLOCK", "1024")), 0 if env.get("DADA2HIP_V3_MIRROR") == "0" else 1)
     e = dict(os.environ)
     e.update(env)
     out = _run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)

@@ -10,6 +10,7 @@ mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
 export DADA2HIP_WAIT_TIMEOUT_S=${DADA2HIP_WAIT_TIMEOUT_S:-90}
+(rocm-smi --showclocks 2>/dev/null | grep -i "sclk\|mclk" | head -4; rocm-smi --showpower 2>/dev/null | grep -i "power" | head -2) > $OUT/clocks.txt 2>&1
 for s in $STEPS; do
   t0=$(date +%s)
   case $s in
