@@ -1365,6 +1365,7 @@ struct Run {
   bool v2_debug = false;
   // persistent round tail (k3_tail, rounds3.inc.hip): rounds run back to back inside one launch
   bool v3_on = false;                 // this run's rounds go through k3_tail (else: the launch chains)
+  int v3_depth = 1;                   // persistent launches kept in flight (DADA2HIP_V2_DEPTH)
   int v3_grid = 1;                    // its blocks (co-resident: at most one per CU)
   int v3_bs = 1024;                   // threads per block
   long v3_enq = 0;                    // k3_tail launches enqueued (their ordinals are 1, 2, ...)
@@ -1492,6 +1493,12 @@ struct Run {
     const Knobs &K = knobs();
     if (K.v2_nbuf > 0) v2_nbuf = std::min(64, K.v2_nbuf);   // (k2_birth keeps the slot table in LDS)
     v2_depth = K.v2_depth > 0 ? std::min(MOV_RING - 1, K.v2_depth) : 2;
+    // persistent launches in flight: ONE.  A second one queued behind a launch that leaves for a prefetch compare still in flight
+    // starts at once, spins its bound for the same compare and leaves again (every such launch is a chain of compare kernels that
+    // find nothing to do, an entry barrier and a mirror fill), while the launch the host sends once it has seen the exit is ordered
+    // behind the compare's event.  10^6 uniques, same box: depth 1 / 2 / 3 / 4 = 124.3 / 134.8 / 139.5 / 137.1 ms per pass with
+    // 154 / 412 / 541 / 548 launches (profiles/r09t_sweep_cfg3_launches_in_flight.jsonl); the host tops up between blocks (run_v3)
+    v3_depth = K.v2_depth > 0 ? v2_depth : 1;
     v2_chain = K.v2_chain > 0 ? std::min(SH_CHAIN, K.v2_chain) : SH_CHAIN;   // test knob: shorter shuffle chains
     v2_debug = K.v2_debug;
     hipStream_t stq = s->stream;
@@ -1795,7 +1802,7 @@ struct Run {
     const bool polite = wait_blocks();
     int burst = 0;
     for (unsigned spins = 0; *seqp != want; spins++) {
-      if (v3_enq - v3_ended() < v2_depth && burst < 256) { v3_enqueue(false); burst++; continue; }   // (bounded: a device that ends every launch at once without a block is an error)
+      if (v3_enq - v3_ended() < v3_depth && burst < 256) { v3_enqueue(false); burst++; continue; }   // (bounded: a device that ends every launch at once without a block is an error)
       cpu_relax();
       if (polite && spins > 64) { struct timespec ts{0, 20000}; nanosleep(&ts, nullptr); }
       if ((spins & 0xFFFF) == 0xFFFF || (polite && (spins & 0xFF) == 0xFF)) {
@@ -1844,6 +1851,11 @@ struct Run {
     while (!done) {
       // keep the device fed: super-chains in flight = enqueued - ended (the device reports the ordinal of every launch that
       // ends, whether it ran rounds or found the device halted); none is added while a result block waits to be consumed
+      // (round 6: ALSO while blocks wait to be consumed - a host that trails the device by a few blocks never entered the wait that
+      //  used to do the topping up, and the device then sat idle behind its last queued launch: 80 gaps of ~0.5 ms between a
+      //  k3_tail and the next compare's screen over six passes at 10^6 uniques, profiles/r09k_cfg3_summary.md.  A launch queued
+      //  behind a halt the host has not read yet ends at once without touching anything.)
+      for (int burst = 0; !v3_dev_halted && v3_enq - v3_ended() < v3_depth && burst < 4; burst++) v3_enqueue(false);
       const long seq = v2_cons + 1;
       const Round2Out *bp = nullptr;
       try { bp = &v3_wait_block(); }
@@ -2095,7 +2107,7 @@ struct Run {
     }
     st.nshuffle += (uint64_t)b.nsh;
     st.nnw += b.stat[0]; st.ngapless += b.stat[1]; st.nshroud += b.stat[2]; st.nskipped += b.stat[3];
-    st.nnw_rounds += b.stat[0];                                // (what the rounds COMMITTED: nnw_run - this = aligned in vain)
+    st.nnw_rounds += b.stat[0] - (uint64_t)b.pad0[3];          // (what the rounds COMMITTED: nnw_run - this = aligned in vain; pad0[3]: round 0's pairs, which ride in the first block)
     st.nstored += (uint64_t)b.pad0[0];                      // comparisons kept by the chain's store filter
     st.ms_replay += ms_since(t_rep);
     if (b.err_flag & 4) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "N-W Align out of range."};
@@ -2902,10 +2914,24 @@ int dada2hip_run_multi(int32_t n_samples, const dada2hip_sample_input *samples, 
       if (rcs[i] != DADA2HIP_OK) { msgs[i] = eb; failed.store(1); }
     }
   };
+  // A device that several of the call's threads share: every sample on it runs without the prefetch compares of DESIGN.md 5c, from
+  // its first round on - not just the samples that happen to start while another one is active (active_runs() is what v3_setup and
+  // every persistent launch ask).  The first sample of each wave used to start alone, plan prefetches and park their gate kernels
+  // on a second stream, which then shared the runtime's hardware queues with the next sample's streams: four samples of 60 k
+  // uniques, two in flight, read 81-115 ms in eight of ten fresh processes and 157 / 306 ms in the other two
+  // (tests/test_gpu_scale_and_edges.py::test_several_samples_on_one_gpu_take_the_same_time_run_after_run).
+  std::vector<int> shared_devs;
+  for (int t = 0; t < nthr; t++) {
+    int same = 0;
+    for (int u = 0; u < nthr; u++) same += device_ids[u] == device_ids[t];
+    if (same >= 2 && std::find(shared_devs.begin(), shared_devs.end(), (int)device_ids[t]) == shared_devs.end()) shared_devs.push_back((int)device_ids[t]);
+  }
+  for (int d : shared_devs) active_runs(d)++;
   std::vector<std::thread> th;
   for (int t = 1; t < nthr; t++) th.emplace_back(worker, t);
   worker(0);
   for (auto &x : th) x.join();
+  for (int d : shared_devs) active_runs(d)--;
   for (int i = 0; i < n_samples; i++)
     if (rcs[i] != DADA2HIP_OK) {
       char m[1200];

@@ -328,7 +328,7 @@ struct Ctl2 {
   int32_t pub_seq;      // result blocks published so far
   int32_t nsh_base;     // shuffles of the round in flight executed by earlier chains
   int32_t max_clust;
-  int32_t scan_hint;    // (reserved)
+  int32_t nalign_ran;   // nalign of a compare that ran in front of a persistent launch which left at its entry (ring full, prefetch awaited) and was marked done there (k3_tail); consumed by the round's result block
   // what the aligner launches of the coming chain work on (NwBatch): positions [0, nalign) of batch buffer abuf, centre of
   // position k = acentre[k] (-1: none).  Batch mode: the batch just planned (nalign = nbatch, 0 on a cache hit).  Commit mode
   // (Eng2::align_at_commit): always the ONE position of the coming round's centre, whether it was screened just now or long ago.

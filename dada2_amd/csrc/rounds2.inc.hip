@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void k2_store0(Eng2 E, const double *__restric
   if (blockIdx.x == 0 && threadIdx.x < 2) {
     Round2Out *out = E.dblk + (E.ctl->pub_seq % RING2);
     atomicAdd(&out->stat[threadIdx.x], (unsigned long long)round_counters[threadIdx.x]);
+    if (threadIdx.x == 0) out->pad0[3] = round_counters[0];          // (round 0's NW pairs: not pairs the rounds' batch compares ran, dada2hip_stats::nnw_rounds)
   }
   for (int r = blockIdx.x * 256 + threadIdx.x; r < S.N; r += gridDim.x * 256) {
     const uint8_t cl = cls[r];
@@ -1295,7 +1296,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
   __shared__ int32_t s_hint[4];
   __shared__ BudTie s_tie[BUD_TIES];                     // the first ties of track 0, where the decision reads them
   enum { PRE_N0 = 0, PRE_LOW0, PRE_NALIGN, PRE_SLOT, PRE_NBATCH, PRE_MAXCLUST, PRE_ERR, PRE_NWFLAG, PRE_BLKCNT, PRE_STATN, PRE_SIGN,
-         PRE_NEEDCMP, PRE_HCONS, PRE_N0D = 14 /* 2 SH_LEVELS */, PRE_BLIST = 34 /* 2 KB_MAX */, PRE_CNT = 50 /* SH_LEVELS */ };
+         PRE_NEEDCMP, PRE_HCONS, PRE_NALRAN, PRE_N0D = 14 /* 2 SH_LEVELS */, PRE_BLIST = 34 /* 2 KB_MAX */, PRE_CNT = 50 /* SH_LEVELS */ };
   static_assert(PRE_N0D + 2 * SH_LEVELS <= PRE_BLIST && PRE_BLIST + 2 * KB_MAX <= PRE_CNT && PRE_CNT + SH_LEVELS <= 64, "scalar slots");
   const PartState &P = E.P;
   const SampleDev &S = E.S;
@@ -1332,6 +1333,7 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
     case PRE_SIGN: pa = E.sig_n; break;
     case PRE_NEEDCMP: pa = &ctl->need_compare; break;
     case PRE_HCONS: pa = &ctl->hcons_seen; break;
+    case PRE_NALRAN: pa = &ctl->nalign_ran; break;
     default:
       if (tid >= PRE_N0D && tid < PRE_N0D + 2 * cs.nexec) pa = E.n0d + (tid - PRE_N0D);
       else if (tid >= PRE_BLIST && tid < PRE_BLIST + 2 * KB_MAX) pa = E.blist_n + (tid - PRE_BLIST);
@@ -1475,7 +1477,8 @@ static __device__ __forceinline__ void birth_body(const Eng2 &E, int nlev, const
   D2_TRB(2);
   if (tid == 0) {
     out->nlev = nlev; out->nsh = cs.nexec; out->slot = s_pre[PRE_SLOT]; out->nbatch = s_pre[PRE_NBATCH];
-    if (s_pre[PRE_NALIGN] > 0 && nlev > 0) {                     // alignments / gapless pairs the aligner ran for this chain
+    if (s_pre[PRE_NALRAN] > 0) ctl->nalign_ran = 0;
+    if ((s_pre[PRE_NALIGN] > 0 || s_pre[PRE_NALRAN] > 0) && nlev > 0) {   // alignments / gapless pairs the aligner ran for this chain
       int nn = 0, ng = 0;
       for (int k = 0; k < KB_MAX; k++) { nn += s_pre[PRE_BLIST + k]; ng += s_pre[PRE_BLIST + KB_MAX + k]; }
       out->pad0[1] = nn; out->pad0[2] = ng;

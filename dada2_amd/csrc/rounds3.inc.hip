@@ -253,6 +253,13 @@ __global__ __launch_bounds__(BS, BS == 512 ? 2 : 4) void k3_tail(Eng2 E, BudKey 
           }
           ctl->kexit = ex;
           ctl->need_compare = 0;                          // the compare of the coming round, if it needed one, ran in front of this launch
+          if (ex) {
+            // ... and this launch leaves without running the round: the NEXT launch's compare kernels must not run the same batch
+            // again (k2_batch_lists would append every pair to the work lists a second time - past their end, for a long list).
+            // What the compare wrote stays valid until a round runs; the round's block still reports the pairs (Ctl2::nalign_ran)
+            if (ctl->nalign > 0) ctl->nalign_ran = ctl->nalign;
+            ctl->nbatch = 0; ctl->nalign = 0;
+          }
         }
       }, TAIL_FAIL_ENTRY))
     return;

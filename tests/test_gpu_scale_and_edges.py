@@ -160,6 +160,55 @@ def test_run_multi_equals_per_sample_calls(api, oracle_c):
         api.dada_uniques_multi([dereps[0], bad], tperr1(), DadaOpts(), devices=(0,))
 
 
+def test_several_samples_on_one_gpu_take_the_same_time_run_after_run(tmp_path):
+    """dada2hip_run_multi with four samples of 60 k uniques, two in flight on the one GPU, ten times in fresh
+    processes - no run may take more than 1.5 x the median (round 5 saw a bimodal 234 / 574-1 250 ms on configs[3] before the
+    prefetch gate's bound went from 500 to 5 ms: a waiting gate kernel at the head of a hardware queue the tail's stream shared),
+    and every run returns the same partitions.  (The four samples are one seeded sample and three copies whose abundances differ:
+    drawing a 60 k sample takes half a minute of numpy.)"""
+    import json, pickle, subprocess, sys
+    from dada2_amd.synth import make_sample
+    d0 = make_sample(tperr1(), 60000, L=250, G=48, seed=5100, chunk=60000)
+    with open(tmp_path / "sample.pkl", "wb") as fh:
+        pickle.dump((d0.seqs, d0.abundances, d0.quals), fh, protocol=4)
+    code = (
+        "import sys, time, json, pickle\n"
+        "import numpy as np\n"
+        "root = %r\n"
+        "sys.path[:0] = [root, root + '/tests']\n"
+        "from helpers import tperr1\n"
+        "from dada2_amd import api\n"
+        "from dada2_amd.io import Derep\n"
+        "from dada2_amd.opts import DadaOpts\n"
+        "seqs, ab, q = pickle.load(open(%r, 'rb'))\n"
+        "dereps = []\n"
+        "for i in range(4):\n"
+        "    a = ab.copy(); a[: 40 * i] += 1            # (still sorted: the first uniques are the abundant ones)\n"
+        "    dereps.append(Derep(seqs, a, q, np.zeros(0, np.int32)))\n"
+        "his = [api.HostInput.from_derep(d) for d in dereps]        # (the C-side buffers, outside the timed call: 60 k Python strings each)\n"
+        "api.dada_uniques_multi(his[:2], tperr1(), DadaOpts(), devices=(0, 0))\n"      # (warm-up: allocation cache, attributes)
+        "t0 = time.perf_counter()\n"
+        "res = api.dada_uniques_multi(his, tperr1(), DadaOpts(), devices=(0, 0))\n"
+        "print(json.dumps({'ms': (time.perf_counter() - t0) * 1e3, 'nclust': [int(r.nclust) for r in res]}))\n"
+    ) % (ROOT, str(tmp_path / "sample.pkl"))
+    runs = []
+    for k in range(10):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    ms = sorted(r["ms"] for r in runs)
+    med = 0.5 * (ms[4] + ms[5])
+    print("four samples of 60 k uniques, two in flight, ten processes: ms", [round(m, 1) for m in ms], runs[0]["nclust"])
+    assert all(r["nclust"] == runs[0]["nclust"] for r in runs), [r["nclust"] for r in runs]
+    assert min(runs[0]["nclust"]) > 20
+    # What is guarded: the bimodal stall of round 5 (half of the runs 2.5-5 x the others).  What is tolerated: ONE or TWO runs of ten
+    # held up on the host side - the library's own clocks put such a run's extra time into a sample's upload or final pass (host
+    # pool, allocations), never into its rounds (tools/multi_stall.py, profiles/r09w_four_samples_two_in_flight_*.jsonl: 48 fresh
+    # processes at 28.7-41.0 ms; a pytest session with the reference's 32-thread runs beside it has shown 73 / 105 / 254 ms)
+    assert ms[7] <= 1.5 * med, ("runs stalled", [round(m, 1) for m in ms])
+    assert ms[-1] <= 12.0 * med, ("a run stalled badly", [round(m, 1) for m in ms])
+
+
 def test_nwalign_short_strings_and_limits(api):
     """C_nwalign / C_nwvec accept any length (evaluate.cpp:18); the device helper path has no k-mer-size limit."""
     from oracle import cport

@@ -68,7 +68,7 @@ def main():
                           "dev_ms": {k[7:]: round(v, 2) for k, v in st.items() if k.startswith("dev_ms_")},
                           "tail_block0_ms": {k[8:]: round(v, 2) for k, v in st.items() if k.startswith("tail_ms_")},
                           "overlap": {k: int(st[k]) for k in ("pf_compares", "pf_centres", "pf_hits", "pf_waits", "pf_exits", "batch_compares", "tail_launches")},
-                          "aligned_in_vain_frac": round(1.0 - st["nnw"] / max(1, st["nnw_run"] + (st["nnw"] - st["nnw_run"] if st["nnw_run"] == 0 else 0)), 3) if False else None,
+                          "aligned_in_vain_frac": (round(1.0 - st["nnw_rounds"] / st["nnw_run"], 4) if st["nnw_run"] else None),
                           "nnw": int(st["nnw"]), "nnw_run": int(st["nnw_run"]), "nnw_fast": int(st["nnw_fast"]), "nnw_retry": int(st["nnw_retry"]),
                           "screen_stage2": int(st["screen_stage2"]), "batch_compares": int(st["batch_compares"]),
                           "wait_device": round(st.get("ms_wait_device", 0), 1), "replay": round(st.get("ms_replay", 0), 1),
