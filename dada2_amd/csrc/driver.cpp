@@ -15,6 +15,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -717,6 +721,11 @@ struct Run {
   // ---- device state -----------------------------------------------------------------------------
   void alloc_state() {
     const size_t n = (size_t)N;
+    if (knobs().v2_summary) {   // (what the stream still holds from before this run: not this function's time)
+      const auto t_pre = clk::now();
+      D2_HIP(hipStreamSynchronize(s->stream));
+      fprintf(stderr, "[run] alloc_state: stream busy at entry for %.2f ms\n", ms_since(t_pre));
+    }
     const auto t_as = clk::now();
     d_Emin.alloc(n); d_clam.alloc(n); d_p.alloc(n); d_lock.alloc(n); d_slot0.alloc(n); d_clof.alloc(n); d_ci.alloc(n);
     d_cham.alloc(n); d_head.alloc(n); d_ncount.alloc(1); d_errflag.alloc(1); d_movers.alloc(6 * n); d_nmovers.alloc(1);
@@ -936,7 +945,8 @@ struct Run {
   // it looks at the device's launch counter every few thousand moves
   bool v3_running = false;
   void replay_moves(const int32_t *mv, int nm) {
-    if (v3_running && nm > 2048) v3_topup();
+    const bool feed = v3_running && !lane_is_me();                  // (launches are the boundary thread's to send)
+    if (feed && nm > 2048) v3_topup();
     std::vector<int32_t> order(nm);
     for (int k = 0; k < nm; k++) order[k] = k;
     std::sort(order.begin(), order.end(), [&](int a, int b) {
@@ -947,7 +957,7 @@ struct Run {
     bool slot0_changed = false;
     int tick = 0;
     for (int k : order) {
-      if (v3_running && (++tick & 4095) == 0) v3_topup();
+      if (feed && (++tick & 4095) == 0) v3_topup();
       const uint32_t r = (uint32_t)mv[3 * k];
       const int from = mv[3 * k + 1], to = mv[3 * k + 2];
       Bi &bf = bi[from];
@@ -1161,6 +1171,7 @@ struct Run {
   }
 
   void push_slot0() {   // only reachable when a slot-0 unique is not its partition's centre (unsorted input: plain mode)
+    if (lane_is_me()) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: a slot-0 member moved under the device-driven rounds"};
     std::vector<uint8_t> f(N, 0);
     for (auto &b : bi) if (!b.raw.empty()) f[b.raw[0]] = 1;
     D2_HIP(hipMemcpyAsync(P.slot0, f.data(), (size_t)N, hipMemcpyHostToDevice, s->stream));   // ordered with the evaluations
@@ -1786,9 +1797,97 @@ struct Run {
   // (a fixed number per call: while the device is halted every launch ends at once, and "fewer than depth in flight" stays true
   //  however many are sent)
   bool v3_dev_halted = false;          // the block in the host's hands halted the device: nothing to keep fed until it is answered
+
+  // ---- the replay lane (persistent tail) ---------------------------------------------------------------------------------------
+  // The host's mirror of the partitions (member lists in the reference's order: b_bud's ties, the final clustering) trails the device
+  // through the published moves and births.  That replay is 45-55 ms of a 10^6-unique pass and used to run between the waits of
+  // the thread that also feeds the device: a persistent launch that left (a compare due) found nobody to send the next one until
+  // the block in hand was replayed - with ONE launch in flight that is device time.  A block that asks nothing of the host (birth
+  // applied on the device, movers inline) is now copied out of the ring and handed to a second host thread, which replays it,
+  // re-derives the decision from the published candidates (decide_bud: must equal the device's) and books the birth, in block
+  // order; the boundary thread drains the lane before it touches the mirror itself (a halt that wants the host's decision, a
+  // paused block, the end of the rounds).  Off when the caller wants the verbose log (its callback runs on the calling thread).
+  struct ReplayLane {
+    std::thread th;
+    std::mutex mu;                                       // guards q and err
+    std::deque<std::unique_ptr<unsigned char[]>> q;
+    std::atomic<long> pushed{0}, done{0};                // blocks handed over / worked through (the lane polls: a futex wake per
+    std::atomic<bool> stop{false};                       //  block on the thread that feeds the device cost 2-3 ms of a pass)
+    std::exception_ptr err;
+    std::thread::id tid;
+  } lane;
+  bool lane_on = false;
+  bool lane_is_me() const { return lane_on && std::this_thread::get_id() == lane.tid; }
+  void lane_start() {
+    lane.stop.store(false); lane.pushed.store(0); lane.done.store(0); lane.err = nullptr;
+    const bool polite = wait_blocks();
+    std::unique_lock<std::mutex> hold(lane.mu);                    // (the thread's first look at the queue waits until tid is written)
+    lane.th = std::thread([this, polite]() {
+      (void)hipSetDevice(s->device);
+      for (unsigned idle = 0;;) {
+        if (lane.done.load(std::memory_order_relaxed) == lane.pushed.load(std::memory_order_acquire)) {
+          if (lane.stop.load(std::memory_order_acquire)) return;
+          cpu_relax();
+          if (polite || ++idle > 200000u) { struct timespec ts{0, 20000}; nanosleep(&ts, nullptr); }   // (a lane nobody feeds stops burning its core)
+          continue;
+        }
+        idle = 0;
+        std::unique_ptr<unsigned char[]> job;
+        bool failed;
+        {
+          std::lock_guard<std::mutex> lk(lane.mu);
+          job = std::move(lane.q.front());
+          lane.q.pop_front();
+          failed = (bool)lane.err;
+        }
+        try {
+          if (!failed) {
+            const Round2Out &b = *(const Round2Out *)job.get();
+            v2_replay(b, 0);
+            Birth bb = decide_bud(b.bud);
+            if (!bb.yes || bb.type != 'A' || bb.c.raw != b.bud.ties[0][0].raw)
+              throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: device and host bud decisions differ"};
+            record_birth(bb);
+          }
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(lane.mu);
+          if (!lane.err) lane.err = std::current_exception();
+        }
+        lane.done.fetch_add(1, std::memory_order_release);
+      }
+    });
+    lane.tid = lane.th.get_id();
+    lane_on = true;
+  }
+  // a block the host has nothing to answer: its used part copied out of the ring (header, candidates, inline movers)
+  void lane_push(const Round2Out &b, int tot) {
+    const size_t bytes = offsetof(Round2Out, mov) + (size_t)3 * (size_t)tot * 4;
+    std::unique_ptr<unsigned char[]> job(new unsigned char[(bytes + 15) & ~(size_t)15]);
+    memcpy(job.get(), &b, bytes);
+    {
+      std::lock_guard<std::mutex> lk(lane.mu);
+      lane.q.push_back(std::move(job));
+    }
+    lane.pushed.fetch_add(1, std::memory_order_release);
+  }
+  // everything handed over has been replayed (its exception, if it raised one, surfaces here)
+  void lane_drain() {
+    if (!lane_on) return;
+    while (lane.done.load(std::memory_order_acquire) != lane.pushed.load(std::memory_order_relaxed)) cpu_relax();
+    std::lock_guard<std::mutex> lk(lane.mu);
+    if (lane.err) { std::exception_ptr e = lane.err; lane.err = nullptr; std::rethrow_exception(e); }
+  }
+  bool lane_failed() { std::lock_guard<std::mutex> lk(lane.mu); return (bool)lane.err; }
+  void lane_stop() noexcept {
+    if (!lane.th.joinable()) { lane_on = false; return; }
+    lane.stop.store(true, std::memory_order_release);
+    lane.th.join();                                      // (it works through what is queued first: nothing it touches goes away before)
+    { std::lock_guard<std::mutex> lk(lane.mu); lane.q.clear(); }
+    lane_on = false;
+  }
   void v3_topup() {
     if (v3_dev_halted) return;
-    const long need = (long)v2_depth - (v3_enq - v3_ended());
+    const long need = (long)v3_depth - (v3_enq - v3_ended());
     for (long k = 0; k < need; k++) v3_enqueue(false);
   }
   // Wait for the next result block, keeping v2_depth super-chains queued meanwhile.  The device reports the end of every launch
@@ -1839,8 +1938,9 @@ struct Run {
     // the device's persistent slot is held for the rounds only.  An exception (abort hook, time-out, internal error) can leave
     // launches of this run queued or running: they are halted and waited for BEFORE the slot goes to the next run, which would
     // otherwise put its own persistent kernel beside a dying one
-    struct SlotGuard { Run *r; ~SlotGuard() { if (r->v3_running) r->v3_quiesce(); r->v3_release(); r->v3_running = false; } } slot_guard{this};
+    struct SlotGuard { Run *r; ~SlotGuard() { r->lane_stop(); if (r->v3_running) r->v3_quiesce(); r->v3_release(); r->v3_running = false; } } slot_guard{this};
     v3_running = true;
+    if (knobs().v3_lane != 0 && !(o.verbose && hooks && hooks->log) && !v2_debug) lane_start();
     auto t0 = clk::now();
     st.nstored = (uint64_t)N;                                  // round 0 keeps every comparison (E_minmax starts at -999)
     v3_rec.clear();
@@ -1862,6 +1962,8 @@ struct Run {
       catch (const TailEntryFailed &) {
         // every queued launch has ended and none of them has touched the state since the last consumed block: hand the rounds
         // to the launch chains from exactly here
+        lane_drain();                                          // (the mirror is the boundary thread's again)
+        lane_stop();
         v3_running = false;
         v3_fallback();
         st.ms_bookkeep += ms_since(t0);
@@ -1878,7 +1980,13 @@ struct Run {
                 b.kord, b.halt, b.paused, b.nclust, b.nsh, b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3], b.nbatch, b.slot, b.birth_applied, b.bud.found[0],
                 b.bud.nties[0], b.bud.best_p[0], b.blk_count);
       v3_dev_halted = b.halt != H2_NONE;                       // (a paused block is resumed inside v2_replay, before its moves are replayed)
-      v2_replay(b, seq, /*resume_after_fetch=*/b.paused != 0 && b.halt == H2_NONE);
+      int tot_mov = 0;
+      for (int l = 0; l < b.nsh; l++) tot_mov += b.cnt[l];
+      // the replay lane takes the block when the host has nothing to answer (the lane raises what the block's flags or its
+      // decision would have raised here; a lane that has failed hands everything back so that the error surfaces at once)
+      const bool to_lane = lane_on && b.halt == H2_NONE && b.paused == 0 && tot_mov <= E2.mov_inline && b.birth_applied != 0 && !lane_failed();
+      if (to_lane) lane_push(b, tot_mov);
+      else { lane_drain(); v2_replay(b, seq, /*resume_after_fetch=*/b.paused != 0 && b.halt == H2_NONE); }
       n_halt[b.halt & 7]++;
       if (b.kord > v3_ord_seen) {                              // first block of its launch: the compare in front of that launch served it
         v3_ord_seen = b.kord;
@@ -1894,6 +2002,11 @@ struct Run {
       }
       switch (b.halt) {
         case H2_NONE: {                                        // birth applied on the device: book it
+          if (to_lane) {                                       // (the lane books it behind the block's moves)
+            nclust_dev = b.nclust;
+            st.ncompare += (uint64_t)N;
+            break;
+          }
           Birth bb = decide_bud(b.bud);
           if (!bb.yes || bb.type != 'A' || bb.c.raw != b.bud.ties[0][0].raw)
             throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: device and host bud decisions differ"};
@@ -1932,6 +2045,8 @@ struct Run {
       v3_dev_halted = false;                                   // (answered: host birth / resume are in the stream)
       *(volatile int32_t *)v3_hflags.p = (int32_t)v2_cons;     // the device may reuse the ring slots of everything consumed
     }
+    lane_drain();
+    lane_stop();
     v3_running = false;
     sync_spin(s->stream);                                      // launches queued behind the final halt
     if (v3_overlap) {

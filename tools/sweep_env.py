@@ -53,6 +53,7 @@ def main():
             rs = res.stats
             per_pass.append({"wall": round(walls[-1], 1), "total": round(rs["ms_total"], 1), "bookkeep": round(rs["ms_bookkeep"], 1), "wait": round(rs["ms_wait_device"], 1),
                              "replay": round(rs["ms_replay"], 1), "enqueue": round(rs["ms_enqueue"], 1), "final": round(rs["ms_final"], 1),
+                             "setup": round(rs["ms_setup"], 1), "round0": round(rs["ms_round0"], 1), "upload": round(rs["ms_upload"], 1),
                              "launches": int(rs["tail_launches"]), "pauses": int(rs["tail_pauses"]), "pf_waits": int(rs["pf_waits"]), "pf_exits": int(rs["pf_exits"]),
                              "compares": int(rs["batch_compares"]), "pf": int(rs["pf_compares"])})
         os.environ["DADA2HIP_PROFILE"] = "1"
