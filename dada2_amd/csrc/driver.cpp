@@ -944,20 +944,42 @@ struct Run {
   // (persistent tail) the replay of a long mover list takes milliseconds in which the device can run out of queued launches:
   // it looks at the device's launch counter every few thousand moves
   bool v3_running = false;
+  std::vector<std::pair<uint64_t, int32_t>> replay_keys;
+  std::vector<int32_t> replay_order;
   void replay_moves(const int32_t *mv, int nm) {
     const bool feed = v3_running && !lane_is_me();                  // (launches are the boundary thread's to send)
     if (feed && nm > 2048) v3_topup();
-    std::vector<int32_t> order(nm);
-    for (int k = 0; k < nm; k++) order[k] = k;
-    std::sort(order.begin(), order.end(), [&](int a, int b) {
-      const int fa = mv[3 * a + 1], fb = mv[3 * b + 1];
-      if (fa != fb) return fa < fb;
-      return slot_of[mv[3 * a]] > slot_of[mv[3 * b]];
-    });
+    // The reference pops the movers of one b_shuffle2 call partition by partition, each partition's from its LAST slot down
+    // (cluster.cpp:241-262 walks r = nraw - 1 .. 0): by source partition ascending, then by the slot the unique holds now, descending.
+    // One 64-bit key per move (the keys are distinct: a slot holds one unique), sorted as integers - the comparator used to look
+    // slot_of[] up twice per comparison.
+    replay_keys.resize((size_t)nm);
+    for (int k = 0; k < nm; k++)
+      replay_keys[k] = {((uint64_t)(uint32_t)mv[3 * k + 1] << 32) | (uint64_t)(0x7FFFFFFFu - (uint32_t)slot_of[mv[3 * k]]), (int32_t)k};
+    std::sort(replay_keys.begin(), replay_keys.end(), [](const std::pair<uint64_t, int32_t> &x, const std::pair<uint64_t, int32_t> &y) { return x.first < y.first; });
+    std::vector<int32_t> &order = replay_order;
+    order.resize((size_t)nm);
+    for (int k = 0; k < nm; k++) order[k] = replay_keys[k].second;
     bool slot0_changed = false;
     int tick = 0;
-    for (int k : order) {
+    const uint32_t *h_reads = s->h_reads.data();
+    for (int q = 0; q < nm; q++) {
+      const int k = order[q];
       if (feed && (++tick & 4095) == 0) v3_topup();
+      // (a move is half a dozen dependent cache misses on a 10^6-unique mirror: the lines of the moves to come are requested in two
+      //  stages - the unique's own words 24 moves ahead; 12 ahead, with its slot at hand, the member-list cells it will touch)
+      if (q + 24 < nm) {
+        const uint32_t rn = (uint32_t)mv[3 * order[q + 24]];
+        __builtin_prefetch(&slot_of[rn], 1); __builtin_prefetch(&clust_of[rn], 1); __builtin_prefetch(&h_reads[rn], 0);
+      }
+      if (q + 12 < nm) {
+        const int kn = order[q + 12];
+        const Bi &bfn = bi[mv[3 * kn + 1]], &btn = bi[mv[3 * kn + 2]];
+        const size_t sl = (size_t)slot_of[(uint32_t)mv[3 * kn]];
+        if (sl < bfn.raw.size()) __builtin_prefetch(bfn.raw.data() + sl, 1);
+        if (!bfn.raw.empty()) { __builtin_prefetch(bfn.raw.data() + bfn.raw.size() - 1, 0); __builtin_prefetch(&slot_of[bfn.raw.back()], 1); }
+        if (btn.raw.capacity()) __builtin_prefetch(btn.raw.data() + btn.raw.size(), 1);
+      }
       const uint32_t r = (uint32_t)mv[3 * k];
       const int from = mv[3 * k + 1], to = mv[3 * k + 2];
       Bi &bf = bi[from];
