@@ -393,11 +393,22 @@ def main():
         if args.config == 3 and world == 1 and not args.selfconsist and not args.no_extras and not args.deep and not args.shard:
             tm = []
             t_sc = time.perf_counter()
+            sc_passes = []
+
+            def sc_pass(k, used, max_clust, results):   # what each pass of the loop was: partitions, calls, pairs, where the host's time went
+                ps = results[0].stats
+                sc_passes.append({"partitions": int(results[0].nclust), "shuffle_calls": int(ps["nshuffle"]), "stored": int(ps["nstored"]),
+                                  "nw": int(ps["nnw"]), "nw_run_for_rounds": int(ps["nnw_run"]), "moves": int(ps["nmoves"]),
+                                  "tail_launches": int(ps["tail_launches"]), "batch_compares": int(ps["batch_compares"]),
+                                  "ms": {kk[3:]: round(float(ps[kk]), 2) for kk in ("ms_total", "ms_setup", "ms_round0", "ms_bookkeep", "ms_wait_device",
+                                                                                   "ms_replay", "ms_enqueue", "ms_final")}})
+
             res_sc, err_sc, errs_sc = api.dada(dereps[0], None, self_consist=True, opts=opts, device=local, timings=tm,
-                                               host_input=inputs[0])
+                                               host_input=inputs[0], on_pass=sc_pass)
             sc_info = {"what": "BASELINE.json configs[2]: learnErrors-style selfConsist loop on the bench sample (err from all-ones with "
                                "MAX_CLUST=1, noqualErrfun refit per pass, resident sample; R/dada.R:256-405)",
                        "passes": len(tm) - 1, "ms_create": tm[0], "ms_per_pass": tm[1:], "ms_total": (time.perf_counter() - t_sc) * 1e3,
+                       "per_pass": sc_passes,
                        "partitions_last": res_sc.nclust, "converged": bool(any(np.array_equal(e, err_sc) for e in errs_sc)),
                        "uniques_per_s_whole_loop": d.nraw / (time.perf_counter() - t_sc)}
             for g in gens:

@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORDS = ["r08e_bench_cfg3_default_line_as_the_driver_runs_it.json", "r07w_bench_cfg3_default_line.json", "r08c_bench_cfg3_default_line_final_code_slow_host_box.json", "r07n_bench_cfg2.json", "r07i_bench_cfg4_inflight2_without.json", "r07n_bench_cfg5.json"]   # [0] = the default run
+RECORDS = ["r10f_bench_cfg3_default_line.json", "r08e_bench_cfg3_default_line_as_the_driver_runs_it.json", "r07w_bench_cfg3_default_line.json", "r08c_bench_cfg3_default_line_final_code_slow_host_box.json", "r07n_bench_cfg2.json", "r07i_bench_cfg4_inflight2_without.json", "r07n_bench_cfg5.json"]   # [0] = the default run
 
 
 @pytest.mark.parametrize("name", RECORDS)
@@ -63,3 +63,10 @@ def test_default_line_names_the_dominant_kernel_class_and_carries_the_sub_record
     assert d["config5_long_reads"]["steps"] == 2 and d["config5_long_reads"]["partitions"] > 100
     assert d["config4_eight_samples_one_gpu"]["samples"] == 8
     assert d["per_rank"][0]["samples"] == 1 and d["samples_in_flight_per_gpu"] == 1
+    # round 6: the plain configs[1] sample rides in the line, the tail's roofline says that HBM is not its
+    # bound (PMC traffic / algorithmic bytes), and the aligned-in-vain share is reported (and is a share: round 0's pairs no
+    # longer count as committed by the rounds)
+    assert d["config2_plain_100k"]["steps"] == 3 and d["config2_plain_100k"]["partitions"] > 100
+    assert 0 < d["roofline"]["hbm_is_not_the_bound"]["traffic_over_algorithmic"] < 1
+    assert 0 <= d["phases_ms_last_step"]["alignments"]["aligned_in_vain_frac"] <= 0.12
+    assert 0 <= d["secondary_workload"]["aligned_in_vain_frac"] <= 0.12
