@@ -32,6 +32,10 @@ import time
 
 import numpy as np
 
+# (before anything initialises the HIP runtime - torch does, in main(): the library wants eight hardware queues for its streams,
+#  dada2_amd/csrc/knobs.h knobs_process_defaults; a caller's own setting wins)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -219,7 +223,7 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--shard", action="store_true", help="ONE sample, the per-unique work of its uniques split over the ranks "
                     "(dada2hip_sample_run_sharded, DESIGN.md 7): strong scaling of a single dada() call; resident samples")
-    ap.add_argument("--inflight", type=int, default=2, help="samples of one rank in flight on its GPU (configs with several samples per rank: "
+    ap.add_argument("--inflight", type=int, default=3, help="samples of one rank in flight on its GPU (configs with several samples per rank: "
                     "dada2hip_run_multi with the device listed that many times; their rounds take turns, everything else overlaps)")
     ap.add_argument("--deep", action="store_true", help="workload variant with >= 5 reads per unique (reads drawn at Q34-40)")
     ap.add_argument("--gen-only", action="store_true", help="draw this configuration's synthetic samples into the input cache and exit "

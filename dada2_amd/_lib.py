@@ -8,6 +8,11 @@ import os
 
 from .opts import COpts
 
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) when it initialises; a run uses three
+# streams and several samples in flight three each (csrc/knobs.h, knobs_process_defaults: the library sets the same default when
+# it is loaded - this line covers a torch that initialises the runtime between the import of this package and the first call).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdada2hip.so")
 _lib = None

@@ -198,11 +198,20 @@ int inflate_whole(const char *path, Bytes &text, std::string &why) {
   while (in_pos + 18 <= (size_t)fsz && gz[in_pos] == 0x1F && gz[in_pos + 1] == 0x8B) {
     size_t used = 0, made = 0;
     const int r = api.gunzip(dec, &gz[in_pos], (size_t)fsz - in_pos, text.data() + out_pos, text.size() - out_pos, &used, &made);
-    if (r == 3) { text.resize(text.size() * 2); continue; }   // LIBDEFLATE_INSUFFICIENT_SPACE: the member again, into more room
+    if (r == 3) {                                              // LIBDEFLATE_INSUFFICIENT_SPACE: the member again, into more room -
+      // up to a bound: a file that inflates beyond 64 x its size or 8 GiB is left to the streaming reader, which runs
+      // in constant memory (a hostile or very compressible file must not end in bad_alloc or the OOM killer here)
+      const size_t cap = std::min<size_t>((size_t)8 << 30, std::max<size_t>((size_t)fsz * 64, (size_t)1 << 26));
+      if (text.size() >= cap) { text.clear(); text.shrink_to_fit(); return 0; }
+      text.resize(std::min(cap, text.size() * 2));
+      continue;
+    }
     if (r != 0) { why = "damaged gzip stream (invalid or truncated deflate data, or a CRC / length mismatch)"; return -1; }
     in_pos += used; out_pos += made;
   }
   if (in_pos == 0) { why = "damaged gzip stream"; return -1; }
+  // a trailing piece that starts like a member but is too short to be one: gzread reports a truncated file, so does this
+  if (in_pos + 2 <= (size_t)fsz && gz[in_pos] == 0x1F && gz[in_pos + 1] == 0x8B) { why = "damaged gzip stream (truncated trailing member)"; return -1; }
   text.resize(out_pos);
   return 1;
 }

@@ -138,12 +138,34 @@ struct dada2hip_result {
 
 namespace {
 
-// The persistent round tail (k3_tail) needs ALL its blocks co-resident, one per CU.  Two such launches dispatched to one device
-// at the same time (two samples of dada2hip_run_multi on the same GPU) could each get part of the CUs and wait for the rest
-// forever (their barriers would time out and the runs fail), so a device has ONE persistent slot per process: the run that
-// holds it uses k3_tail, any other run on that device meanwhile takes the launch chains.
-std::mutex &persistent_slot(int device) {
-  static std::mutex slots[64];
+// (library load: the one environment default the library sets, knobs.h)
+__attribute__((constructor)) static void d2_process_defaults() { d2::knobs_process_defaults(); }
+
+// The persistent round tail (k3_tail) needs ALL its blocks co-resident, one per CU (a block takes its CU whole: 1024 threads at 128
+// registers, 156 KB of LDS).  Launches that together want more CUs than the device has would each get part of them and wait for
+// the rest until their entry barriers time out, so a device has persistent SLOTS per process: a run takes one for its rounds
+// (run_v3), waiting its turn if there is none, and several runs hold slots at the same time only while their blocks together stay
+// within three quarters of the CUs - the rest is for everybody's compare kernels.  Round 6: up to three (DADA2HIP_V3_SLOTS; until
+// then ONE, the samples' rounds taking turns): configs[3] on one GPU, 8 x 250 k uniques = 61 blocks each, 246 -> 164 ms with
+// three samples in flight (profiles/r10j_*).  Round 5 had measured side-by-side tails 2.4x SLOWER; what changed since: the tail's
+// blocks own their CUs (then: 512 threads beside the compares on every CU), one launch in flight per run instead of two, and
+// eight hardware queues (GPU_MAX_HW_QUEUES, below) instead of four for the six to nine streams of three samples.
+struct SlotSem {
+  std::mutex mu;
+  std::condition_variable cv;
+  int used = 0, blocks = 0;
+  void acquire(int cap, int my_blocks, int ncu) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&]() { return used == 0 || (used < cap && blocks + my_blocks <= ncu - ncu / 4); });
+    used++; blocks += my_blocks;
+  }
+  void release(int my_blocks) {
+    { std::lock_guard<std::mutex> lk(mu); used--; blocks -= my_blocks; }
+    cv.notify_all();
+  }
+};
+SlotSem &persistent_slot(int device) {
+  static SlotSem slots[64];
   return slots[device & 63];
 }
 // ... and across processes that share a GPU (several ranks on one device): an advisory lock on a file named after the
@@ -151,7 +173,11 @@ std::mutex &persistent_slot(int device) {
 struct PersistFile {
   int fd = -1;
   bool held = false;
+  int holders = 0;               // runs of THIS process that hold it (DADA2HIP_V3_SLOTS > 1: more than one)
+  std::mutex mu;
   bool try_acquire(int device) {
+    std::lock_guard<std::mutex> g(mu);
+    if (held) { holders++; return true; }
     if (fd < 0) {
       char bus[64] = "unknown";
       if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", device); }
@@ -166,9 +192,15 @@ struct PersistFile {
       if (fd < 0) return false;
     }
     held = flock(fd, LOCK_EX | LOCK_NB) == 0;
+    if (held) holders = 1;
     return held;
   }
-  void release() { if (held && fd >= 0) (void)flock(fd, LOCK_UN); held = false; }
+  void release() {
+    std::lock_guard<std::mutex> g(mu);
+    if (!held || --holders > 0) return;
+    if (fd >= 0) (void)flock(fd, LOCK_UN);
+    held = false;
+  }
 };
 // Boundary calls of THIS process that are running on a device right now (dada2hip_run_multi / several threads of the caller with
 // a sample each): the persistent tail plans prefetch compares only for a run that has the device to itself - with a second
@@ -1425,7 +1457,8 @@ struct Run {
   hipEvent_t v3_pf_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // end of prefetch compare k: v3_pf_ev[k & 3]
   DevBuf<unsigned long long> v3_ktime;
   PinBuf<int32_t> v3_hflags;          // [0] result blocks the host has finished with, [16] ordinal of the last launch that ended
-  std::unique_lock<std::mutex> v3_slot;   // the device's persistent slot (held for the run)
+  bool v3_slot_held = false;          // the device's persistent slot (held for the run's rounds)
+  int v3_slot_blocks = 0;
   long v2_enq = 0, v2_cons = 0;
   uint64_t v2_miss_launches = 0;
   struct EnqRec { int ev_screen, ev_nw; bool compare; };
@@ -1674,13 +1707,15 @@ struct Run {
   // rounds of one sample fill the device, the uploads, round 0 and final passes of the others overlap them; another PROCESS on
   // the same GPU that holds the slot sends this run to the launch chains.
   bool v3_acquire() {
-    if (v3_slot.owns_lock()) return true;
-    v3_slot = std::unique_lock<std::mutex>(persistent_slot(s->device));
-    if (!persistent_file(s->device).try_acquire(s->device)) { v3_slot.unlock(); return false; }
+    if (v3_slot_held) return true;
+    v3_slot_blocks = v3_grid;
+    persistent_slot(s->device).acquire(std::max(1, knobs().v3_slots), v3_slot_blocks, tail_grid(1 << 30, s->device));
+    if (!persistent_file(s->device).try_acquire(s->device)) { persistent_slot(s->device).release(v3_slot_blocks); return false; }
+    v3_slot_held = true;
     return true;
   }
   void v3_release() {
-    if (v3_slot.owns_lock()) { persistent_file(s->device).release(); v3_slot.unlock(); }
+    if (v3_slot_held) { persistent_file(s->device).release(); persistent_slot(s->device).release(v3_slot_blocks); v3_slot_held = false; }
   }
   // halt whatever this run still has queued or running on the device and wait for it (errors ignored: this runs while another
   // error unwinds).  A running k3_tail sees the halt at its next round boundary at the latest when the host stops consuming

@@ -47,6 +47,7 @@ struct Knobs {
   int v3_spec_max = -1;               // DADA2HIP_V3_SPEC_MAX=n         (tuning) ... only behind a call that moved at most n uniques
   int v3_pf_sync = 0;                 // DADA2HIP_V3_PF_SYNC=1          (measurement) every prefetch is waited for at the next serial end, the tail resident and idle
   int v3_pf_lowreg = -1;              // DADA2HIP_V3_PF_LOWREG=0|1      (tuning) prefetch screens on the 80-register build of the screen kernel (-1 = automatic: where the tail shares every CU)
+  int v3_slots = 3;                   // DADA2HIP_V3_SLOTS=n            persistent launches of this process side by side on one device (several samples in flight; 1 = their rounds take turns)
   int v3_lane = 0;                    // DADA2HIP_V3_LANE=1             the host's replay of moves and births on a second host thread (run_v3's replay lane; measured 3-4 ms SLOWER per 10^6-unique pass while the device is the bound: not the default)
   int v3_mirror = 1;                  // DADA2HIP_V3_MIRROR=0           the persistent tail reads every unique's partition / flags from global memory in each sweep (no LDS mirror)
   int v3_fail_entry = 0;              // DADA2HIP_V3_FAIL_ENTRY=n       test knob: the n-th persistent launch fails its entry barrier (-> launch chains)
@@ -101,6 +102,7 @@ struct Knobs {
     k.v3_pf_early = I("DADA2HIP_V3_PF_EARLY", -1); k.v3_pf_lowreg = T("DADA2HIP_V3_PF_LOWREG"); k.v3_pf_sync = I("DADA2HIP_V3_PF_SYNC", 0); k.v3_pf_gate_us = I("DADA2HIP_V3_PF_GATE_US", -1);
     k.v3_mirror = I("DADA2HIP_V3_MIRROR", 1);
     k.v3_lane = I("DADA2HIP_V3_LANE", 0);
+    k.v3_slots = I("DADA2HIP_V3_SLOTS", 3);
     k.v2_debug = S("DADA2HIP_V2_DEBUG") != nullptr; k.v2_summary = S("DADA2HIP_V2_SUMMARY") != nullptr;
     if (const char *e = S("DADA2HIP_V2_TRACE")) {
       k.v2_trace_on = true; k.v2_trace_seq = std::atoi(e);
@@ -136,7 +138,7 @@ inline bool same(const Knobs &a, const Knobs &b) {
          a.v2_lite == b.v2_lite && a.v2_align == b.v2_align && a.v2_filter == b.v2_filter && a.v2_grid_shuffle == b.v2_grid_shuffle &&
          a.v2_grid_pupdate == b.v2_grid_pupdate && a.v2_mov_inline == b.v2_mov_inline && a.v2_tail_chain == b.v2_tail_chain && a.v3_grid == b.v3_grid &&
          a.v3_ring == b.v3_ring && a.v3_block == b.v3_block && a.v3_overlap == b.v3_overlap && a.v3_pf_wait_us == b.v3_pf_wait_us &&
-         a.v3_fail_entry == b.v3_fail_entry && a.v3_spec == b.v3_spec && a.v3_xbar == b.v3_xbar && a.v3_spec_max == b.v3_spec_max && a.v3_pf_early == b.v3_pf_early && a.v3_pf_lowreg == b.v3_pf_lowreg && a.v3_pf_sync == b.v3_pf_sync && a.v3_pf_gate_us == b.v3_pf_gate_us && a.v3_mirror == b.v3_mirror && a.v3_lane == b.v3_lane && a.v2_debug == b.v2_debug && a.v2_summary == b.v2_summary && a.v2_trace_on == b.v2_trace_on &&
+         a.v3_fail_entry == b.v3_fail_entry && a.v3_spec == b.v3_spec && a.v3_xbar == b.v3_xbar && a.v3_spec_max == b.v3_spec_max && a.v3_pf_early == b.v3_pf_early && a.v3_pf_lowreg == b.v3_pf_lowreg && a.v3_pf_sync == b.v3_pf_sync && a.v3_pf_gate_us == b.v3_pf_gate_us && a.v3_mirror == b.v3_mirror && a.v3_lane == b.v3_lane && a.v3_slots == b.v3_slots && a.v2_debug == b.v2_debug && a.v2_summary == b.v2_summary && a.v2_trace_on == b.v2_trace_on &&
          a.v2_trace_seq == b.v2_trace_seq && a.v2_trace_file == b.v2_trace_file && a.profile == b.profile && a.node_cap == b.node_cap &&
          a.wait_block == b.wait_block && a.wait_timeout_s == b.wait_timeout_s && a.coop_max == b.coop_max && a.kord_align == b.kord_align &&
          a.screen_grid == b.screen_grid && a.ad_fcap == b.ad_fcap && a.ad_debug == b.ad_debug && a.ad_fast == b.ad_fast && a.screen_bits == b.screen_bits && a.bimera_times == b.bimera_times && a.derep_times == b.derep_times && a.derep_zlib == b.derep_zlib &&
@@ -147,6 +149,14 @@ inline bool same(const Knobs &a, const Knobs &b) {
 // Re-read the environment (every C-ABI entry point does, once, before anything else).  A snapshot that differs from the current
 // one replaces it; old snapshots are never freed (a few hundred bytes each, and only when the environment changed), so a
 // reference obtained from knobs() by another thread stays valid.
+// The ONE variable the library SETS (once, when it is loaded, and only if the caller has not): the HIP runtime maps a process's
+// streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) when it initialises.  A run uses three streams (rounds, side copies,
+// prefetch compares) and several samples in flight use three each; streams that share a queue run one behind the other - a
+// persistent launch at the head of a queue holds back whatever else was mapped onto it.  With 8: configs[3] on one GPU 200 -> 190 ms
+// at two slots, and the single-sample headline 157.3 -> 148.1 ms per call on one box (profiles/r10j_*).  No effect if the runtime
+// is already up (torch initialised first): dada2_amd/_lib.py and bench.py set it before either is.
+inline void knobs_process_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+
 inline void knobs_reload() {
   Knobs k = Knobs::from_env();
   std::lock_guard<std::mutex> g(knobs_detail::mu());

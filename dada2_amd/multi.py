@@ -56,9 +56,10 @@ def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts 
     ``dereps``       all samples (every rank sees the list; only its shard is touched)
     ``make_runner``  derep -> object with .run(err, opts, max_clust=...) -> DadaResult and .close();
                      default = GPU-resident dada2_amd.api.Sample on this rank's device
-    ``inflight``     samples of this rank running at a time (1 = the serial loop of R/dada.R:266).  Default: 2 with the library's
-                     own runners (their ``run`` is thread-safe: one resident sample each, the device's persistent slot taken in
-                     turns; each holds its own round buffers, so device memory per rank grows with it), 1 with user-supplied
+    ``inflight``     samples of this rank running at a time (1 = the serial loop of R/dada.R:266).  Default: 3 with the library's
+                     own runners (their ``run`` is thread-safe: one resident sample each; up to three hold a persistent slot of the
+                     device side by side while their blocks fit three quarters of its CUs, else they take turns - driver.cpp
+                     SlotSem; each holds its own round buffers, so device memory per rank grows with it), 1 with user-supplied
                      ``make_runner`` objects, whose ``run`` is then never called from two threads at once
     Returns (dict sample_index -> DadaResult for the local shard, err_out, list of err tried).
     Mirrors the loop of R/dada.R:256-405 (see dada2_amd.api.dada for the single-process form)."""
@@ -69,7 +70,7 @@ def dada_multi(dereps, err, *, self_consist=False, err_fun=None, opts: DadaOpts 
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     mine = shard(len(dereps), rank, world, sizes=[d.nraw for d in dereps])
     if inflight is None:
-        inflight = 2 if make_runner is None else 1
+        inflight = 3 if make_runner is None else 1
     if make_runner is None:
         from .api import Sample
         dev_index = device.index if device is not None and getattr(device, "index", None) is not None else 0

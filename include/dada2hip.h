@@ -32,6 +32,10 @@
  *   DADA2HIP_V3_OVERLAP=0|1            the next batch's compare under the persistent tail on a second stream (default: on)
  *   DADA2HIP_V3_SPEC=0|1               the evaluation of a round rides on its shuffle calls (default: on; 0 = a phase of its own)
  *   DADA2HIP_V3_MIRROR=0|1             the persistent tail keeps the per-unique facts its sweeps ask for in LDS (default: on)
+ *   DADA2HIP_V3_SLOTS=<n>              persistent launches of this process side by side on a device (default 3; 1 = the rounds of
+ *                                      several samples in flight take turns)
+ * The library SETS one variable when it is loaded, unless the caller has: GPU_MAX_HW_QUEUES=8 (the HIP runtime's hardware queues
+ * per process, 4 by default; a run uses three streams, several samples in flight three each).
  *   DADA2HIP_NW_KERNEL=lane|coop|wide  force one aligner family;  DADA2HIP_AD_HOMO=0  homopolymer gaps on the lane kernels
  *   DADA2HIP_WAIT=block, DADA2HIP_WAIT_TIMEOUT_S=<s>   sleep instead of spin while waiting; bound of every device wait
  *   DADA2HIP_HOST_THREADS=<n>, DADA2HIP_ALLOC_CACHE=0, DADA2HIP_ALLOC_CACHE_GB=<n>   marshalling pool, allocation cache
