@@ -1396,6 +1396,7 @@ struct Run {
   void check_errflag(int32_t f) {
     if (f & 1) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "Lambda out-of-range error."};
     if (f & 2) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: comparison store overflow"};
+    if (f & 32) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: a work list of a batch compare overflowed (the compare ran twice?)"};
     if (f & 16) throw RuntimeErr{DADA2HIP_ERR_RUNTIME, "dada2hip: internal error: the persistent tail's LDS mirror disagrees with the state arrays"};   // (DADA2HIP_V3_MIRROR=2 checks)
   }
 

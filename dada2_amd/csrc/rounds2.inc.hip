@@ -781,7 +781,9 @@ __global__ __launch_bounds__(256) void k2_batch_lists(Eng2 E) {
         int pos = 0;
 #pragma unroll
         for (int l = 0; l < 2 * KB_MAX; l++) if (l == list) pos = s_base[l] + mybase[l]++;
-        E.blist[(size_t)list * E.C.Npad + pos] = r0 + q;
+        // (a list holds a unique at most once per compare: pos < N <= Npad - unless the same compare ran twice, which the entry of
+        //  the persistent launch rules out since round 6; a write past the list's end would land in the next list)
+        if ((size_t)pos < E.C.Npad) E.blist[(size_t)list * E.C.Npad + pos] = r0 + q; else atomicOr(E.P.err_flag, 32);
       }
     }
   }
