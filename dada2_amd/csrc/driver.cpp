@@ -422,6 +422,12 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
     PinBuf<uint8_t> hq;
     hq.alloc((size_t)nraw * LQ);
     std::atomic<int> badq{0}, qmax{0};
+    // Several samples in flight on this device (dada2hip_run_multi's threads share it: active_runs() is raised for the call): half
+    // the pool per upload.  The uploads of the samples go through the pool one after the other and overlap the OTHER samples'
+    // rounds, so their wall time is not what counts - 64 threads read the matrix at 80 GB/s for 1.6 CPU-seconds per 2 GB, 32 at
+    // 60 GB/s for 1.1, and they leave the memory system and the container's CPU quota to the threads that feed the
+    // device: configs[3] on one GPU, three in flight, 64 / 32 / 24 / 16 threads: 187 / 174 / 183 / 193 ms (profiles/r10u_*).
+    const int marshal_threads = active_runs(device).load() > 1 ? std::max(8, HostPool::get().nthreads() / 2) : 0;
     const size_t rows_per = std::max<size_t>(1, ((size_t)16 << 20) / (size_t)LQ);
     for (size_t r0 = 0; r0 < (size_t)nraw; r0 += rows_per) {
       const size_t nr = std::min<size_t>(rows_per, nraw - r0);
@@ -454,7 +460,7 @@ void sample_create(dada2hip_sample *s, int32_t nraw, const char *const *seqs, co
         if (bad) badq.store(1, std::memory_order_relaxed);
         int cur = qmax.load();
         while (mx > cur && !qmax.compare_exchange_weak(cur, mx)) {}
-      });
+      }, marshal_threads);
       D2_HIP(hipMemcpyAsync(D.qual + r0 * LQ, hq.p + r0 * LQ, nr * (size_t)LQ, hipMemcpyHostToDevice, s->side));
     }
     D2_HIP(hipStreamSynchronize(s->side));                    // (the pinned buffer goes back to the cache)

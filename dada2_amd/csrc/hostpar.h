@@ -34,8 +34,9 @@ class HostPool {
     return *p;
   }
   int nthreads() const { return nthreads_; }
-  // f(lo, hi) over [0, n) in pieces of `grain`; the caller takes part, returns when all pieces are done
-  void run(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f) {
+  // f(lo, hi) over [0, n) in pieces of `grain`; the caller takes part, returns when all pieces are done.
+  // max_threads > 0: at most that many threads take pieces (the others wake, see that the job is not theirs and go back to sleep)
+  void run(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f, int max_threads = 0) {
     if (n == 0) return;
     if (grain == 0) grain = 1;
     if (nthreads_ <= 1 || n <= grain || in_job()) { f(0, n); return; }
@@ -44,6 +45,7 @@ class HostPool {
     {
       std::lock_guard<std::mutex> g(S->mu);
       fn_ = &f; n_ = n; grain_ = grain; next_.store(0); pending_ = (int)S->workers.size(); failed_.store(false); exc_ = nullptr;
+      cap_ = max_threads > 0 ? max_threads : nthreads_;
       gen_++;
     }
     S->cv.notify_all();
@@ -76,7 +78,7 @@ class HostPool {
     pid_ = getpid();
     stop_ = false; pending_ = 0; fn_ = nullptr;
     // workers start from the generation of their birth: a respawned pool must not replay the parent's last job
-    for (int i = 1; i < nthreads_; i++) S->workers.emplace_back([this, g0 = gen_] { loop(g0); });
+    for (int i = 1; i < nthreads_; i++) S->workers.emplace_back([this, g0 = gen_, i] { loop(g0, i); });
   }
   void respawn_after_fork() {
     static std::mutex fork_mu;
@@ -103,7 +105,7 @@ class HostPool {
     }
     in_job() = false;
   }
-  void loop(uint64_t seen) {
+  void loop(uint64_t seen, int index) {
     Sync *my = S;
     for (;;) {
       {
@@ -112,7 +114,7 @@ class HostPool {
         seen = gen_;
         if (stop_) return;
       }
-      work();
+      if (index < cap_) work();                        // (the caller is thread 0 of the job)
       {
         std::lock_guard<std::mutex> g(my->mu);
         if (--pending_ == 0) my->done_cv.notify_all();
@@ -120,6 +122,7 @@ class HostPool {
     }
   }
   int nthreads_ = 1;
+  int cap_ = 1;                  // threads that take pieces of the job in hand (run's max_threads)
   pid_t pid_ = 0;
   Sync *S = nullptr;
   const std::function<void(size_t, size_t)> *fn_ = nullptr;
@@ -132,7 +135,7 @@ class HostPool {
   bool stop_ = false;
 };
 
-inline void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f) { HostPool::get().run(n, grain, f); }
+inline void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f, int max_threads = 0) { HostPool::get().run(n, grain, f, max_threads); }
 
 // ---- allocation caches ---------------------------------------------------------------------------
 // Size classes: multiples of 1/4 of the power of two below the request (<= 25 % slack), at least 256 B; a freed block
