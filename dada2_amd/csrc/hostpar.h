@@ -6,7 +6,9 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <functional>
 #include <map>
@@ -69,6 +71,21 @@ class HostPool {
     int n = (int)std::thread::hardware_concurrency();
     if (n <= 0) n = 1;
     if (n > 64) n = 64;                                  // memory-bound copies: 16 / 32 / 64 threads = 55 / 34 / 25 ms for the 1M-unique upload (profiles/r02q_bench_cfg3_threads*.json)
+    {
+      // A container's CPU quota (cgroup v2 cpu.max: "<quota us> <period us>", "max" = none) is invisible to hardware_concurrency():
+      // the GPU boxes show 256 cores and allow sixteen CPUs' worth per 100 ms.  The marshalling is a burst (64 threads x 25 ms =
+      // one whole period's quota at 16 CPUs, measured best there: profiles/r10s_*), so the pool may be four times the quota
+      // wide and no wider - a 4-CPU container gets 16 threads instead of 64 that the kernel would park most of the time.
+      if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = "";
+        long long period = 0;
+        if (fscanf(fp, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+          const long long cpus = (atoll(q) + period - 1) / period;
+          if (cpus > 0 && 4 * cpus < n) n = (int)std::max<long long>(2, 4 * cpus);
+        }
+        fclose(fp);
+      }
+    }
     if (knobs().host_threads > 0) n = knobs().host_threads;
     nthreads_ = n;
     spawn();
