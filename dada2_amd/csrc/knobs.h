@@ -152,8 +152,8 @@ inline bool same(const Knobs &a, const Knobs &b) {
 // The ONE variable the library SETS (once, when it is loaded, and only if the caller has not): the HIP runtime maps a process's
 // streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) when it initialises.  A run uses three streams (rounds, side copies,
 // prefetch compares) and several samples in flight use three each; streams that share a queue run one behind the other - a
-// persistent launch at the head of a queue holds back whatever else was mapped onto it.  With 8: configs[3] on one GPU 200 -> 190 ms
-// at two slots, and the single-sample headline 157.3 -> 148.1 ms per call on one box (profiles/r10j_*).  No effect if the runtime
+// persistent launch at the head of a queue holds back whatever else was mapped onto it.  With 8: configs[3] on one GPU 204 -> 190 ms
+// at two slots (profiles/r10i_*, r10j_*); the single-sample call reads the same with 4, 8 or 16 (151-158 ms, profiles/r11b_*).  No effect if the runtime
 // is already up (torch initialised first): dada2_amd/_lib.py and bench.py set it before either is.
 inline void knobs_process_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
 
