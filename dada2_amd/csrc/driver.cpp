@@ -982,7 +982,7 @@ struct Run {
   // (persistent tail) the replay of a long mover list takes milliseconds in which the device can run out of queued launches:
   // it looks at the device's launch counter every few thousand moves
   bool v3_running = false;
-  std::vector<std::pair<uint64_t, int32_t>> replay_keys;
+  std::vector<std::pair<uint64_t, int32_t>> replay_keys, replay_tmp;
   std::vector<int32_t> replay_order;
   void replay_moves(const int32_t *mv, int nm) {
     const bool feed = v3_running && !lane_is_me();                  // (launches are the boundary thread's to send)
@@ -992,9 +992,35 @@ struct Run {
     // One 64-bit key per move (the keys are distinct: a slot holds one unique), sorted as integers - the comparator used to look
     // slot_of[] up twice per comparison.
     replay_keys.resize((size_t)nm);
-    for (int k = 0; k < nm; k++)
-      replay_keys[k] = {((uint64_t)(uint32_t)mv[3 * k + 1] << 32) | (uint64_t)(0x7FFFFFFFu - (uint32_t)slot_of[mv[3 * k]]), (int32_t)k};
-    std::sort(replay_keys.begin(), replay_keys.end(), [](const std::pair<uint64_t, int32_t> &x, const std::pair<uint64_t, int32_t> &y) { return x.first < y.first; });
+    uint32_t max_slot = 0, max_from = 0;
+    for (int k = 0; k < nm; k++) {
+      const uint32_t sl = (uint32_t)slot_of[mv[3 * k]], fr = (uint32_t)mv[3 * k + 1];
+      max_slot = std::max(max_slot, sl); max_from = std::max(max_from, fr);
+      replay_keys[k] = {((uint64_t)fr << 32) | (uint64_t)sl, (int32_t)k};
+    }
+    // (descending slots as ascending keys, against the largest slot of THIS list: few significant bits for the radix passes below)
+    for (int k = 0; k < nm; k++) replay_keys[k].first = (replay_keys[k].first & 0xFFFFFFFF00000000ull) | (uint64_t)(max_slot - (uint32_t)replay_keys[k].first);
+    if (nm < std::max(2, knobs().replay_radix_min))
+      std::sort(replay_keys.begin(), replay_keys.end(), [](const std::pair<uint64_t, int32_t> &x, const std::pair<uint64_t, int32_t> &y) { return x.first < y.first; });
+    else {
+      // the early rounds move 10^5 uniques per call: a comparison sort of such a list was a third of the pass's replay.  LSD radix
+      // sort, 11 bits a pass, over the bits the keys actually use (slots below the list's largest, then the source partitions)
+      auto bits_of = [](uint32_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };
+      const int bs = bits_of(max_slot), bf = bits_of(max_from);
+      replay_tmp.resize((size_t)nm);
+      std::pair<uint64_t, int32_t> *src = replay_keys.data(), *dst = replay_tmp.data();
+      auto pass = [&](int shift, int nbits) {
+        const uint32_t mask = (1u << nbits) - 1u;
+        uint32_t hist[2048 + 1] = {0};
+        for (int k = 0; k < nm; k++) hist[((src[k].first >> shift) & mask) + 1]++;
+        for (uint32_t d = 0; d < mask + 1u; d++) hist[d + 1] += hist[d];
+        for (int k = 0; k < nm; k++) dst[hist[(src[k].first >> shift) & mask]++] = src[k];
+        std::swap(src, dst);
+      };
+      for (int done = 0; done < bs; done += 11) pass(done, std::min(11, bs - done));
+      for (int done = 0; done < bf; done += 11) pass(32 + done, std::min(11, bf - done));
+      if (src != replay_keys.data()) std::copy(src, src + nm, replay_keys.data());
+    }
     std::vector<int32_t> &order = replay_order;
     order.resize((size_t)nm);
     for (int k = 0; k < nm; k++) order[k] = replay_keys[k].second;

@@ -47,6 +47,7 @@ struct Knobs {
   int v3_spec_max = -1;               // DADA2HIP_V3_SPEC_MAX=n         (tuning) ... only behind a call that moved at most n uniques
   int v3_pf_sync = 0;                 // DADA2HIP_V3_PF_SYNC=1          (measurement) every prefetch is waited for at the next serial end, the tail resident and idle
   int v3_pf_lowreg = -1;              // DADA2HIP_V3_PF_LOWREG=0|1      (tuning) prefetch screens on the 80-register build of the screen kernel (-1 = automatic: where the tail shares every CU)
+  int replay_radix_min = 4096;        // DADA2HIP_REPLAY_RADIX_MIN=n    test knob: mover lists from n entries on are ordered by the radix sort of the host's replay (1 = always)
   int v3_slots = 3;                   // DADA2HIP_V3_SLOTS=n            persistent launches of this process side by side on one device (several samples in flight; 1 = their rounds take turns)
   int v3_lane = 0;                    // DADA2HIP_V3_LANE=1             the host's replay of moves and births on a second host thread (run_v3's replay lane; measured 3-4 ms SLOWER per 10^6-unique pass while the device is the bound: not the default)
   int v3_mirror = 1;                  // DADA2HIP_V3_MIRROR=0           the persistent tail reads every unique's partition / flags from global memory in each sweep (no LDS mirror)
@@ -103,6 +104,7 @@ struct Knobs {
     k.v3_mirror = I("DADA2HIP_V3_MIRROR", 1);
     k.v3_lane = I("DADA2HIP_V3_LANE", 0);
     k.v3_slots = I("DADA2HIP_V3_SLOTS", 3);
+    k.replay_radix_min = I("DADA2HIP_REPLAY_RADIX_MIN", 4096);
     k.v2_debug = S("DADA2HIP_V2_DEBUG") != nullptr; k.v2_summary = S("DADA2HIP_V2_SUMMARY") != nullptr;
     if (const char *e = S("DADA2HIP_V2_TRACE")) {
       k.v2_trace_on = true; k.v2_trace_seq = std::atoi(e);
@@ -138,7 +140,7 @@ inline bool same(const Knobs &a, const Knobs &b) {
          a.v2_lite == b.v2_lite && a.v2_align == b.v2_align && a.v2_filter == b.v2_filter && a.v2_grid_shuffle == b.v2_grid_shuffle &&
          a.v2_grid_pupdate == b.v2_grid_pupdate && a.v2_mov_inline == b.v2_mov_inline && a.v2_tail_chain == b.v2_tail_chain && a.v3_grid == b.v3_grid &&
          a.v3_ring == b.v3_ring && a.v3_block == b.v3_block && a.v3_overlap == b.v3_overlap && a.v3_pf_wait_us == b.v3_pf_wait_us &&
-         a.v3_fail_entry == b.v3_fail_entry && a.v3_spec == b.v3_spec && a.v3_xbar == b.v3_xbar && a.v3_spec_max == b.v3_spec_max && a.v3_pf_early == b.v3_pf_early && a.v3_pf_lowreg == b.v3_pf_lowreg && a.v3_pf_sync == b.v3_pf_sync && a.v3_pf_gate_us == b.v3_pf_gate_us && a.v3_mirror == b.v3_mirror && a.v3_lane == b.v3_lane && a.v3_slots == b.v3_slots && a.v2_debug == b.v2_debug && a.v2_summary == b.v2_summary && a.v2_trace_on == b.v2_trace_on &&
+         a.v3_fail_entry == b.v3_fail_entry && a.v3_spec == b.v3_spec && a.v3_xbar == b.v3_xbar && a.v3_spec_max == b.v3_spec_max && a.v3_pf_early == b.v3_pf_early && a.v3_pf_lowreg == b.v3_pf_lowreg && a.v3_pf_sync == b.v3_pf_sync && a.v3_pf_gate_us == b.v3_pf_gate_us && a.v3_mirror == b.v3_mirror && a.v3_lane == b.v3_lane && a.v3_slots == b.v3_slots && a.replay_radix_min == b.replay_radix_min && a.v2_debug == b.v2_debug && a.v2_summary == b.v2_summary && a.v2_trace_on == b.v2_trace_on &&
          a.v2_trace_seq == b.v2_trace_seq && a.v2_trace_file == b.v2_trace_file && a.profile == b.profile && a.node_cap == b.node_cap &&
          a.wait_block == b.wait_block && a.wait_timeout_s == b.wait_timeout_s && a.coop_max == b.coop_max && a.kord_align == b.kord_align &&
          a.screen_grid == b.screen_grid && a.ad_fcap == b.ad_fcap && a.ad_debug == b.ad_debug && a.ad_fast == b.ad_fast && a.screen_bits == b.screen_bits && a.bimera_times == b.bimera_times && a.derep_times == b.derep_times && a.derep_zlib == b.derep_zlib &&

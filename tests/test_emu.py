@@ -376,9 +376,11 @@ def test_emulated_entry_barrier_failure_continues_on_the_launch_chains(emu_lib, 
                                  {"DADA2HIP_V3_GRID": "3", "DADA2HIP_V3_MIRROR": "2", "DADA2HIP_V2_MOV_INLINE": "16", "DADA2HIP_V3_SPEC_MAX": "3"},
                                  {"DADA2HIP_V3_GRID": "2", "DADA2HIP_V3_MIRROR": "0"},
                                  # the replay lane (a second host thread replays the published moves and births), with pauses
-                                 {"DADA2HIP_V3_GRID": "3", "DADA2HIP_V3_LANE": "1", "DADA2HIP_V2_MOV_INLINE": "16"}],
+                                 {"DADA2HIP_V3_GRID": "3", "DADA2HIP_V3_LANE": "1", "DADA2HIP_V2_MOV_INLINE": "16"},
+                                 # every mover list through the radix sort of the host's replay (default: lists of 4 096 movers and more)
+                                 {"DADA2HIP_V3_GRID": "2", "DADA2HIP_REPLAY_RADIX_MIN": "1"}],
                          ids=["grid4-nbuf4-ring2", "grid2-nbuf5-pauses-no-wait", "grid3-512-thread-blocks", "grid3-mirror-checked-pauses", "grid2-no-mirror",
-                              "grid3-replay-lane-pauses"])
+                              "grid3-replay-lane-pauses", "grid2-replay-radix-always"])
 def test_emulated_prefetch_compares_under_the_tail_on_a_deeper_sample(emu_lib, env):
     """The next batch's compare planned by the persistent tail and run on the second stream on the 20-partition
     golden: rounds served out of prefetched batches, with the smallest cache that allows it (the buffer whose rows the coming

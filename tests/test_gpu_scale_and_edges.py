@@ -366,6 +366,8 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
     {"DADA2HIP_V3_LANE": "1"},
     {"DADA2HIP_V3_LANE": "1", "DADA2HIP_V3_GRID": "4", "DADA2HIP_V2_MOV_INLINE": "64", "DADA2HIP_NODE_CAP": "1", "DADA2HIP_V3_RING": "2"},
     {"DADA2HIP_V2_DEPTH": "2"},
+    # the host's replay orders EVERY mover list with its radix sort (by default only lists of 4 096 movers and more)
+    {"DADA2HIP_REPLAY_RADIX_MIN": "1"},
 ], ids=["classic", "v2", "v2-nbuf1", "v2-depth1", "v2-depth3", "v2-chain1", "v2-chain2-grow", "v2-align-commit", "v2-nolite", "v2-graph",
         "tail-grid7-pauses-ring2-fcap", "chains", "chains-chain1-biglists", "chains-nolite-commit",
         "tail-serial", "overlap-host-launched", "overlap-sync-grid5", "overlap-leave-at-once-nbuf4",
@@ -373,7 +375,7 @@ _SEEDED = ((7001, 6000, 200, 48), (7002, 20000, 250, 96))
         "attempts-and-plain-calls-mixed-grid5",
         "xcd-barrier-grid9", "xcd-barrier-grid64-pauses", "flat-barrier",
         "no-mirror", "mirror-checked", "mirror-checked-grid5-mixed-calls-pauses", "mirror-checked-grid3-512-leaves-for-prefetches",
-        "replay-lane", "replay-lane-grid4-pauses-growth-ring2", "two-launches-in-flight"])
+        "replay-lane", "replay-lane-grid4-pauses-growth-ring2", "two-launches-in-flight", "replay-radix-sort-always"])
 def test_round_engines_agree_with_the_reference(env):
     """Every engine configuration must reproduce the goldens the reference produced, the oracle on two seeded samples (6 k and
     20 k uniques: dozens of rounds, multi-shuffle rounds, cache hits and misses) and the reference's own work counters."""
