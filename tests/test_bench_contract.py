@@ -6,7 +6,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORDS = ["r11d_bench_cfg3_default_line.json", "r10x_bench_cfg3_default_line.json", "r10m_bench_cfg3_default_line.json", "r10f_bench_cfg3_default_line.json", "r08e_bench_cfg3_default_line_as_the_driver_runs_it.json", "r07w_bench_cfg3_default_line.json", "r08c_bench_cfg3_default_line_final_code_slow_host_box.json", "r07n_bench_cfg2.json", "r07i_bench_cfg4_inflight2_without.json", "r07n_bench_cfg5.json"]   # [0] = the default run
+RECORDS = ["r11d_bench_cfg3_default_line.json", "r11g_bench_cfg3_default_line_second_box.json", "r10x_bench_cfg3_default_line.json", "r10m_bench_cfg3_default_line.json", "r10f_bench_cfg3_default_line.json", "r08e_bench_cfg3_default_line_as_the_driver_runs_it.json", "r07w_bench_cfg3_default_line.json", "r08c_bench_cfg3_default_line_final_code_slow_host_box.json", "r07n_bench_cfg2.json", "r07i_bench_cfg4_inflight2_without.json", "r07n_bench_cfg5.json"]   # [0] = the default run
 
 
 @pytest.mark.parametrize("name", RECORDS)
